@@ -1,0 +1,135 @@
+/*
+ * pse_amd.h -- C-ABI of the MI355X-native Positively-Split-Ewald (PSE) engine.
+ *
+ * This is the drop-in boundary for the hot path of stochasticHydroTools/PSE (HOOMD plugin PSEv1):
+ * everything below `Stokes::integrateStepOne` (PSEv1/Stokes.cc:429-523), i.e. the driver
+ * `gpu_stokes_step_one` (PSEv1/Stokes.cuh:75-111, PSEv1/Stokes.cu:234-365) and the set-up work of
+ * `Stokes::setParams` (PSEv1/Stokes.cc:129-424).  Plain C types only; every array argument is a
+ * caller-owned DEVICE pointer (as HOOMD's GPUArray handles are, PSEv1/Stokes.cc:436-470) unless a
+ * comment says "host".  All entry points return 0 on success or a negative pse_status; the message
+ * is available from pse_last_error().  Nothing here ever calls exit() (the reference does:
+ * PSEv1/Stokes.cc:203-214, PSEv1/Brownian.cu:543-560).
+ *
+ * Units and conventions are the reference's: particle radius a = 1, mobility in units of
+ * 1/(6 pi eta a) (PSEv1/Stokes.cc:314-319, PSEv1/Helper.cu:326); box centred on the origin with
+ * HOOMD's triclinic tilt xy: a1=(Lx,0,0), a2=(xy*Ly,Ly,0), a3=(0,0,Lz) (PSEv1/Mobility.cu:223-230).
+ * Arithmetic is fp64 (the reference is effectively fp32).
+ */
+#ifndef PSE_AMD_H
+#define PSE_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* HOOMD Scalar4 / Scalar3 / int3 with Scalar = double */
+typedef struct { double x, y, z, w; } pse_double4;
+typedef struct { double x, y, z; } pse_double3;
+typedef struct { int x, y, z; } pse_int3;
+
+typedef struct pse_handle pse_handle;
+
+enum pse_status {
+    PSE_OK = 0,
+    PSE_ERR_INVALID = -1,   /* bad argument / parameter combination */
+    PSE_ERR_HIP = -2,       /* HIP runtime error */
+    PSE_ERR_FFT = -3,       /* rocFFT error */
+    PSE_ERR_COMM = -4,      /* RCCL error */
+    PSE_ERR_NUMERIC = -5    /* Lanczos / eigen-solve breakdown */
+};
+
+/* Constructor arguments: what Stokes::Stokes + setShear + setParams receive
+ * (PSEv1/Stokes.cc:85-111, PSEv1/Stokes.h:118-121, PSEv1/Stokes.cc:129-236), plus explicit
+ * overrides the reference's rule cannot express. Zero means "use the reference rule". */
+typedef struct pse_params {
+    unsigned int n_max;      /* capacity in particles (N_total of the reference) */
+    double Lx, Ly, Lz, xy;   /* box */
+    double xi;               /* Ewald splitting parameter (PSEv1/Stokes.cc:91) */
+    double error;            /* tolerance for all approximations (m_error) */
+    double max_strain;       /* largest |xy| the box will take; sizes P (PSEv1/Stokes.cc:217-229) */
+    unsigned int seed;       /* RNG seed as used on the device (the host class hashes the user seed, Stokes.cc:102) */
+    int Nx, Ny, Nz;          /* FFT grid override (0 = PSEv1/Stokes.cc:138-199) */
+    int P;                   /* support override (0 = PSEv1/Stokes.cc:225-233) */
+    double rcut;             /* real-space cutoff override (0 = PSEv1/Stokes.cc:135) */
+    int device;              /* HIP device ordinal, -1 = current device */
+    int n_slabs;             /* far-field slab decomposition: number of ranks (<=1: single GPU) */
+    int slab_rank;           /* this rank's slab index */
+} pse_params;
+
+typedef struct pse_info {
+    int Nx, Ny, Nz, P;
+    double rcut, xi, eta, gaussm, lambda, self_mobility, hx, hy, hz;
+    int ncell_x, ncell_y, ncell_z;
+    int lanczos_m;            /* vectors used by the last Brownian call */
+    int lanczos_matvecs;      /* near-field mat-vecs of the last Brownian call */
+    double lanczos_stepnorm;  /* last relative step norm */
+    /* device time of the phases of the most recent call, ms (hipEvent, only if timing enabled) */
+    double t_sort, t_spread, t_fft_fwd, t_scale, t_fft_inv, t_gather, t_real, t_lanczos, t_integrate, t_comm, t_total;
+    unsigned long long device_bytes;  /* workspace owned by the handle */
+} pse_info;
+
+/* -- life cycle: replaces Stokes::Stokes/setParams/~Stokes (PSEv1/Stokes.cc:85-118,129-424) ------------- */
+int pse_create(const pse_params *params, pse_handle **out);
+int pse_destroy(pse_handle *h);
+/* box change under Lees-Edwards shear: what gpu_stokes_SetGridk_kernel re-derives every step
+ * (PSEv1/Helper.cu:285-332, called at PSEv1/Stokes.cu:298). Only xy may differ from the creation box by more
+ * than round-off unless the cell grid still fits. */
+int pse_set_box(pse_handle *h, double Lx, double Ly, double Lz, double xy);
+/* run on this hipStream_t (default: the null stream, as the reference does) */
+int pse_set_stream(pse_handle *h, void *hip_stream);
+/* per-phase hipEvent timing into pse_info (adds host synchronisation; off by default) */
+int pse_set_timing(pse_handle *h, int enabled);
+int pse_get_info(pse_handle *h, pse_info *info);
+const char *pse_last_error(void);
+
+/* -- the hot path ------------------------------------------------------------------------------------- */
+/* U = M.F, deterministic (kT = 0 branch of gpu_stokes_CombinedMobilityBrownian_wrap, PSEv1/Brownian.cu:772-923;
+ * the reference's dedicated but uncalled entry is gpu_stokes_Mobility_wrap, PSEv1/Mobility.cu:729-782).
+ * group_members (device, may be NULL = identity) lists the N particle indices acted on, exactly like
+ * d_group_members / group_size; vel[idx].xyz is written, vel[idx].w is preserved (PSEv1/Mobility.cu:473-475).
+ * parts: 1 = real-space (+self) only (gpu_stokes_Mreal_kernel), 2 = wave-space only
+ * (gpu_stokes_Mwave_wrap, PSEv1/Mobility.cu:515-575), 3 = both. */
+int pse_mobility(pse_handle *h, const pse_double4 *pos, const pse_double4 *force, pse_double4 *vel,
+                 const unsigned int *group_members, unsigned int N, int parts);
+
+/* U = M.F + sqrt(2kT/dt) M^{1/2} psi  (PSEv1/Brownian.cu:772-923) without moving the particles.
+ * lanczos_m: in = number of Lanczos vectors to start from, out = number used (the reference's int& m_Lanczos). */
+int pse_brownian_velocity(pse_handle *h, const pse_double4 *pos, const pse_double4 *force, pse_double4 *vel,
+                          const unsigned int *group_members, unsigned int N,
+                          double kT, double dt, unsigned int timestep, int *lanczos_m);
+
+/* One full integration step: the replacement for gpu_stokes_step_one (PSEv1/Stokes.cuh:75-111).
+ * Computes vel, then pos += (vel + shear_rate*y*xhat)*dt, wraps into the box updating image, accel = F/mass
+ * with mass = vel.w (PSEv1/Stokes.cu:137-192). */
+int pse_step(pse_handle *h, pse_double4 *pos, pse_double4 *vel, pse_double3 *accel, pse_int3 *image,
+             const pse_double4 *net_force, const unsigned int *group_members, unsigned int N,
+             double kT, double dt, unsigned int timestep, double shear_rate, int *lanczos_m);
+
+/* M_real^{1/2} psi by Lanczos alone (gpu_stokes_BrealLanczos_wrap, PSEv1/Brownian.cu:357-765, without the
+ * sqrt(2kT/dt) factor): out = M_real^{1/2} psi for a caller-supplied psi. */
+int pse_sqrt_mreal(pse_handle *h, const pse_double4 *pos, const pse_double4 *psi, pse_double4 *out,
+                   const unsigned int *group_members, unsigned int N, double tol, int *lanczos_m);
+
+/* The random vectors the Brownian step draws (for parity tests against the oracle's Philox stream):
+ * psi[idx].xyz = particle noise (gpu_stokes_BrownianGenerate_kernel, PSEv1/Brownian.cu:99-130). */
+int pse_random_psi(pse_handle *h, pse_double4 *psi, const unsigned int *group_members, unsigned int N,
+                   unsigned int timestep);
+
+/* -- introspection used by the parity tests ------------------------------------------------------------ */
+/* evaluate the device's real-space functions f(r), g(r) (the replacement of the m_ewaldC1 table,
+ * PSEv1/Stokes.cc:334-422) at n host radii -> host arrays */
+int pse_eval_realspace(pse_handle *h, const double *r_host, int n, double *f_host, double *g_host);
+/* copy the three real-space grids (x-major, z fastest: idx = (x*Ny + y)*Nz + z, PSEv1/Mobility.cu:233) of the
+ * most recent spread (stage 0) or inverse FFT (stage 1) to a host buffer of 3*nx_local*Ny*Nz doubles */
+int pse_debug_copy_grid(pse_handle *h, int stage, double *host_out);
+
+/* host-only: t = T^{1/2} e_1 of the Lanczos tridiagonal (alpha[0..m), beta[1..m)); replaces LAPACKE_spteqr +
+ * the host loops at PSEv1/Brownian.cu:540-582. Exposed so the eigen-solver can be tested without a GPU. */
+int pse_host_lanczos_sqrt_e1(int m, const double *alpha, const double *beta, double *t);
+/* host-only: the parameter rule of Stokes::setParams (PSEv1/Stokes.cc:129-236,319) without creating a handle */
+int pse_host_select_params(const pse_params *params, pse_info *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSE_AMD_H */

@@ -1,0 +1,102 @@
+"""ctypes binding of the C-ABI in include/pse_amd.h (libpse_amd.so).
+
+This is the only way Python reaches the engine: plain pointers and sizes.  torch is used solely as the owner of
+device memory (tensor.data_ptr()).  There is no CPU fallback: if the library is missing this raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpse_amd.so")
+
+PSE_OK = 0
+
+
+class pse_params(ctypes.Structure):
+    _fields_ = [
+        ("n_max", ctypes.c_uint),
+        ("Lx", ctypes.c_double), ("Ly", ctypes.c_double), ("Lz", ctypes.c_double), ("xy", ctypes.c_double),
+        ("xi", ctypes.c_double), ("error", ctypes.c_double), ("max_strain", ctypes.c_double),
+        ("seed", ctypes.c_uint),
+        ("Nx", ctypes.c_int), ("Ny", ctypes.c_int), ("Nz", ctypes.c_int),
+        ("P", ctypes.c_int),
+        ("rcut", ctypes.c_double),
+        ("device", ctypes.c_int),
+        ("n_slabs", ctypes.c_int), ("slab_rank", ctypes.c_int),
+    ]
+
+
+class pse_info(ctypes.Structure):
+    _fields_ = [
+        ("Nx", ctypes.c_int), ("Ny", ctypes.c_int), ("Nz", ctypes.c_int), ("P", ctypes.c_int),
+        ("rcut", ctypes.c_double), ("xi", ctypes.c_double), ("eta", ctypes.c_double), ("gaussm", ctypes.c_double),
+        ("lam", ctypes.c_double), ("self_mobility", ctypes.c_double),
+        ("hx", ctypes.c_double), ("hy", ctypes.c_double), ("hz", ctypes.c_double),
+        ("ncell_x", ctypes.c_int), ("ncell_y", ctypes.c_int), ("ncell_z", ctypes.c_int),
+        ("lanczos_m", ctypes.c_int), ("lanczos_matvecs", ctypes.c_int),
+        ("lanczos_stepnorm", ctypes.c_double),
+        ("t_sort", ctypes.c_double), ("t_spread", ctypes.c_double), ("t_fft_fwd", ctypes.c_double),
+        ("t_scale", ctypes.c_double), ("t_fft_inv", ctypes.c_double), ("t_gather", ctypes.c_double),
+        ("t_real", ctypes.c_double), ("t_lanczos", ctypes.c_double), ("t_integrate", ctypes.c_double),
+        ("t_comm", ctypes.c_double), ("t_total", ctypes.c_double),
+        ("device_bytes", ctypes.c_ulonglong),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+# every symbol include/pse_amd.h declares: name -> (restype, argtypes)
+_vp, _i, _u, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_double
+_ip = ctypes.POINTER(ctypes.c_int)
+_dp = ctypes.POINTER(ctypes.c_double)
+SYMBOLS = {
+    "pse_create": (_i, [ctypes.POINTER(pse_params), ctypes.POINTER(_vp)]),
+    "pse_destroy": (_i, [_vp]),
+    "pse_set_box": (_i, [_vp, _d, _d, _d, _d]),
+    "pse_set_stream": (_i, [_vp, _vp]),
+    "pse_set_timing": (_i, [_vp, _i]),
+    "pse_get_info": (_i, [_vp, ctypes.POINTER(pse_info)]),
+    "pse_last_error": (ctypes.c_char_p, []),
+    "pse_mobility": (_i, [_vp, _vp, _vp, _vp, _vp, _u, _i]),
+    "pse_brownian_velocity": (_i, [_vp, _vp, _vp, _vp, _vp, _u, _d, _d, _u, _ip]),
+    "pse_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u, _d, _d, _u, _d, _ip]),
+    "pse_sqrt_mreal": (_i, [_vp, _vp, _vp, _vp, _vp, _u, _d, _ip]),
+    "pse_random_psi": (_i, [_vp, _vp, _vp, _u, _u]),
+    "pse_eval_realspace": (_i, [_vp, _dp, _i, _dp, _dp]),
+    "pse_debug_copy_grid": (_i, [_vp, _i, _dp]),
+    "pse_host_lanczos_sqrt_e1": (_i, [_i, _dp, _dp, _dp]),
+    "pse_host_select_params": (_i, [ctypes.POINTER(pse_params), ctypes.POINTER(pse_info)]),
+}
+
+_lib = None
+
+
+class PSEError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpse_amd.so (after torch, so both share one HIP runtime). Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PSEError(f"{LIB_PATH} not found: build it with `python -m pse_amd.build` "
+                       "(there is no CPU fallback for the PSE hot path)")
+    try:
+        import torch  # noqa: F401  (loads libamdhip64/librocfft with the SONAMEs our library needs)
+    except ImportError:
+        pass
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != PSE_OK:
+        raise PSEError(f"pse_amd error {status}: {load().pse_last_error().decode()}")

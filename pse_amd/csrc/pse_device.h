@@ -1,0 +1,107 @@
+// Device-side helpers of the PSE engine (gfx950): triclinic box algebra, Philox4x32-10, real-space
+// pair functions.  These restate the HOOMD device helpers the reference relies on but does not ship
+// (BoxDim::makeFraction/minImage/wrap, detail::Saru, texFetchScalar4 -- SURVEY.md 8(a15)).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pse_host.h"
+
+namespace pse {
+
+struct DBox {
+    double Lx, Ly, Lz, xy;
+    double iLx, iLy, iLz;
+};
+
+struct DGrid {
+    int Nx, Ny, Nz, Nzh;   // Nzh = Nz/2 + 1 (half spectrum)
+    int P;
+    int x0, nxl;           // this rank's slab of x planes [x0, x0 + nxl)
+    double hx, hy, hz;
+    double prefac, expfac; // (2 xi^2/(pi eta))^{3/2}, 2 xi^2/eta   (PSEv1/Brownian.cu:828-829)
+};
+
+struct DCells {
+    int nx, ny, nz;        // cells per dimension (1 or >= 3)
+};
+
+// fractional coordinates in [0,1): f = ((x - xy*y)/Lx + 1/2, y/Ly + 1/2, z/Lz + 1/2)
+__device__ __forceinline__ void frac_coords(const DBox &b, double x, double y, double z, double &fx, double &fy, double &fz) {
+    fx = (x - b.xy * y) * b.iLx + 0.5;
+    fy = y * b.iLy + 0.5;
+    fz = z * b.iLz + 0.5;
+    fx -= floor(fx); fy -= floor(fy); fz -= floor(fz);
+    // guard against f == 1.0 after rounding
+    if (fx >= 1.0) fx = 0.0;
+    if (fy >= 1.0) fy = 0.0;
+    if (fz >= 1.0) fz = 0.0;
+}
+
+// minimum image of a displacement (valid for |r| below half the smallest perpendicular box width)
+__device__ __forceinline__ void min_image(const DBox &b, double &dx, double &dy, double &dz) {
+    const double ny = rint(dy * b.iLy);
+    dy -= ny * b.Ly;
+    dx -= ny * b.xy * b.Ly;
+    dx -= rint(dx * b.iLx) * b.Lx;
+    dz -= rint(dz * b.iLz) * b.Lz;
+}
+
+__device__ __forceinline__ int cell_coord(double f, int n) {
+    int c = (int)(f * n);
+    return c >= n ? n - 1 : c;
+}
+
+// ---- Philox4x32-10 ------------------------------------------------------------------------------------
+constexpr uint32_t PHILOX_KEY1 = 0x50534531u;  // 'PSE1'
+constexpr uint32_t DOMAIN_PARTICLE = 0, DOMAIN_GRID_A = 1, DOMAIN_GRID_B = 2;
+
+__host__ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                    uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// uint32 -> uniform on (-s, s)
+__host__ __device__ __forceinline__ double uniform_pm(uint32_t x, double s) {
+    return (((double)x + 0.5) * 2.3283064365386963e-10 * 2.0 - 1.0) * s;
+}
+
+// ---- real-space pair functions ------------------------------------------------------------------------
+// f(r), g(r) of M_real = f (I - rr) + g rr  (replaces the fp32 linear table PSEv1/Stokes.cc:334-422 and its
+// lookup PSEv1/Mobility.cu:661-670): analytic free-space RPY minus the tabulated smooth wave part.
+// Returns f and (g - f)/r^2.
+__device__ __forceinline__ void eval_fg(double r2, const double *__restrict__ coef, double &f, double &gmf_r2) {
+    const double r = sqrt(r2);
+    const double ir2 = 1.0 / r2;
+    double f0, g0;
+    if (r > 2.0) {
+        const double ir = r * ir2, ir3 = ir * ir2;
+        f0 = 0.75 * ir + 0.5 * ir3;
+        g0 = 1.5 * ir - ir3;
+    } else {
+        f0 = 1.0 - 0.28125 * r;
+        g0 = 1.0 - 0.1875 * r;
+    }
+    const double s = r * RS_PER_UNIT;
+    const int k = (int)s;
+    const double t = 2.0 * (s - k) - 1.0;
+    const double *c = coef + (size_t)k * (2 * RS_NCOEF);
+    double fw = c[RS_DEG], gw = c[RS_NCOEF + RS_DEG];
+#pragma unroll
+    for (int q = RS_DEG - 1; q >= 0; --q) {
+        fw = fma(fw, t, c[q]);
+        gw = fma(gw, t, c[RS_NCOEF + q]);
+    }
+    f = f0 - fw;
+    gmf_r2 = ((g0 - gw) - f) * ir2;
+}
+
+}  // namespace pse

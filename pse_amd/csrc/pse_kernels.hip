@@ -1,0 +1,568 @@
+// HIP kernels of the PSE engine for gfx950 (CDNA4, wave64).  Each kernel names the reference kernel it
+// replaces.  All arithmetic is fp64.
+#include "pse_kernels.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace pse {
+
+constexpr int TPB = 256;
+constexpr double TWO_PI = 6.283185307179586476925286766559;
+
+static inline int nblocks(long n, int tpb) { return (int)((n + tpb - 1) / tpb); }
+
+// ------------------------------------------------------------------------------------------------ reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// sum over a 256-thread block; result valid in all threads
+__device__ __forceinline__ double block_sum(double v, double *sh /* >= 4 doubles */) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+// every block reduces the same partial array in the same order -> identical value everywhere
+__device__ __forceinline__ double reduce_partials(const double *partials, int n, double *sh) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += TPB) v += partials[i];
+    return block_sum(v, sh);
+}
+
+// ------------------------------------------------------------------------------------------------ binning
+// (replaces HOOMD CellListGPU used through NeighborListGPUBinned, PSEv1/integrate.py:58-83)
+__global__ void k_cell_keys(const double4 *__restrict__ pos, const unsigned *__restrict__ group, int N, DBox box,
+                            DCells nc, unsigned *__restrict__ keys, unsigned *__restrict__ vals) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    const unsigned idx = group ? group[g] : (unsigned)g;
+    const double4 p = pos[idx];
+    double fx, fy, fz;
+    frac_coords(box, p.x, p.y, p.z, fx, fy, fz);
+    const int cx = cell_coord(fx, nc.nx), cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz);
+    keys[g] = (unsigned)((cx * nc.ny + cy) * nc.nz + cz);
+    vals[g] = (unsigned)g;
+}
+
+__global__ void k_permute(const double4 *__restrict__ pos, const double4 *__restrict__ vec,
+                          const unsigned *__restrict__ group, const unsigned *__restrict__ perm,
+                          const unsigned *__restrict__ keys_sorted, int N, DBox box, double4 *__restrict__ pos_s,
+                          double4 *__restrict__ vec_s, unsigned *__restrict__ tag_s, int *__restrict__ cell_start,
+                          int *__restrict__ cell_end) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const unsigned g = perm[s];
+    const unsigned idx = group ? group[g] : g;
+    const double4 p = pos[idx];
+    // wrap into the primary cell (keeps sheared images consistent: y images shift x by xy*Ly)
+    double fx, fy, fz;
+    frac_coords(box, p.x, p.y, p.z, fx, fy, fz);
+    const double y = (fy - 0.5) * box.Ly;
+    double4 q;
+    q.x = (fx - 0.5) * box.Lx + box.xy * y;
+    q.y = y;
+    q.z = (fz - 0.5) * box.Lz;
+    q.w = 0.0;
+    pos_s[s] = q;
+    tag_s[s] = idx;
+    if (vec) {
+        double4 v = vec[idx];
+        v.w = 0.0;
+        vec_s[s] = v;
+    }
+    const unsigned key = keys_sorted[s];
+    if (s == 0 || keys_sorted[s - 1] != key) cell_start[key] = s;
+    if (s == N - 1 || keys_sorted[s + 1] != key) cell_end[key] = s + 1;
+}
+
+__global__ void k_permute_vec(const double4 *__restrict__ vec, const unsigned *__restrict__ tag_s, int N,
+                              double4 *__restrict__ vec_s) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    double4 v = vec[tag_s[s]];
+    v.w = 0.0;
+    vec_s[s] = v;
+}
+
+void launch_cell_keys(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys,
+                      unsigned *vals, hipStream_t s) {
+    hipLaunchKernelGGL(k_cell_keys, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, group, N, box, nc, keys, vals);
+}
+size_t sort_pairs_temp_bytes(int N, int end_bit) {
+    size_t bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned *)nullptr, (unsigned *)nullptr,
+                                       (const unsigned *)nullptr, (unsigned *)nullptr, N, 0, end_bit, nullptr);
+    return bytes;
+}
+void sort_pairs(void *temp, size_t temp_bytes, const unsigned *keys_in, unsigned *keys_out, const unsigned *vals_in,
+                unsigned *vals_out, int N, int end_bit, hipStream_t s) {
+    hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, N, 0, end_bit, s);
+}
+void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm,
+                    const unsigned *keys_sorted, int N, DBox box, double4 *pos_s, double4 *vec_s, unsigned *tag_s,
+                    int *cell_start, int *cell_end, hipStream_t s) {
+    hipLaunchKernelGGL(k_permute, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, vec, group, perm, keys_sorted, N, box,
+                       pos_s, vec_s, tag_s, cell_start, cell_end);
+}
+void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s) {
+    hipLaunchKernelGGL(k_permute_vec, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, vec, tag_s, N, vec_s);
+}
+
+// ------------------------------------------------------------------------------------------------ near field
+// K9 gpu_stokes_Mreal_kernel (PSEv1/Mobility.cu:594-687): u_i = self F_i + sum_j [f (I - rr) + g rr] F_j over
+// minimum-image neighbours with r < rcut; here the neighbours come from the build's own cell list.
+__global__ void __launch_bounds__(TPB)
+k_mreal(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int N,
+        const int *__restrict__ cell_start, const int *__restrict__ cell_end, DBox box, DCells nc, double rcut2,
+        double self, const double *__restrict__ coef) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double4 pi = pos_s[i];
+    const double4 vi = vec_s[i];
+    double ux = self * vi.x, uy = self * vi.y, uz = self * vi.z;
+    double fx, fy, fz;
+    frac_coords(box, pi.x, pi.y, pi.z, fx, fy, fz);
+    const int cx = cell_coord(fx, nc.nx), cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz);
+    const int rx = nc.nx > 1 ? 1 : 0, ry = nc.ny > 1 ? 1 : 0, rz = nc.nz > 1 ? 1 : 0;
+    for (int ox = -rx; ox <= rx; ++ox) {
+        int ax = cx + ox; ax = ax < 0 ? ax + nc.nx : (ax >= nc.nx ? ax - nc.nx : ax);
+        for (int oy = -ry; oy <= ry; ++oy) {
+            int ay = cy + oy; ay = ay < 0 ? ay + nc.ny : (ay >= nc.ny ? ay - nc.ny : ay);
+            for (int oz = -rz; oz <= rz; ++oz) {
+                int az = cz + oz; az = az < 0 ? az + nc.nz : (az >= nc.nz ? az - nc.nz : az);
+                const int c = (ax * nc.ny + ay) * nc.nz + az;
+                const int jb = cell_start[c], je = cell_end[c];
+                for (int j = jb; j < je; ++j) {
+                    const double4 pj = pos_s[j];
+                    double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                    min_image(box, dx, dy, dz);
+                    const double r2 = dx * dx + dy * dy + dz * dz;
+                    if (r2 < rcut2 && j != i && r2 > 0.0) {
+                        const double4 Fj = vec_s[j];
+                        double f, h;
+                        eval_fg(r2, coef, f, h);
+                        const double rdF = (dx * Fj.x + dy * Fj.y + dz * Fj.z) * h;
+                        ux += f * Fj.x + rdF * dx;
+                        uy += f * Fj.y + rdF * dy;
+                        uz += f * Fj.z + rdF * dz;
+                    }
+                }
+            }
+        }
+    }
+    out_s[i] = make_double4(ux, uy, uz, 0.0);
+}
+
+void launch_mreal(const double4 *pos_s, const double4 *vec_s, double4 *out_s, int N, const int *cell_start,
+                  const int *cell_end, DBox box, DCells nc, double rcut, double self, const double *coef,
+                  hipStream_t s) {
+    hipLaunchKernelGGL(k_mreal, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos_s, vec_s, out_s, N, cell_start, cell_end,
+                       box, nc, rcut * rcut, self, coef);
+}
+
+__global__ void k_eval_fg(const double *__restrict__ r, int n, const double *__restrict__ coef, double *f, double *g) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double ff, h;
+    const double r2 = r[i] * r[i];
+    eval_fg(r2, coef, ff, h);
+    f[i] = ff;
+    g[i] = ff + h * r2;
+}
+void launch_eval_fg(const double *r, int n, const double *coef, double *f, double *g, hipStream_t s) {
+    hipLaunchKernelGGL(k_eval_fg, dim3(nblocks(n, TPB)), dim3(TPB), 0, s, r, n, coef, f, g);
+}
+
+// ------------------------------------------------------------------------------------------------ far field
+// Support of a particle (PSEv1/Mobility.cu:173-219): first node index per axis (unwrapped) and the offset of
+// that node from the particle in grid units.
+__device__ __forceinline__ void support_start(double f, int n, int P, int &start, double &delta0) {
+    const double s = f * n;
+    const int i0 = (int)s;
+    start = i0 - P / 2 + 1 - ((P & 1) && (s - i0 < 0.5) ? 1 : 0);
+    delta0 = start - s;
+}
+
+// K2+K3 gpu_stokes_ZeroGrid/Spread_kernel (PSEv1/Helper.cu:87-97, PSEv1/Mobility.cu:114-252).
+// v0: one wave per particle, hardware fp64 atomics into the three real grids (zeroed by the caller).
+__global__ void __launch_bounds__(TPB)
+k_spread_atomic(const double4 *__restrict__ pos_s, const double4 *__restrict__ f_s, int N, double *__restrict__ gx,
+                double *__restrict__ gy, double *__restrict__ gz, DGrid G, DBox box) {
+    const int p = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (p >= N) return;
+    const double4 pp = pos_s[p];
+    const double4 F = f_s[p];
+    double fx, fy, fz;
+    frac_coords(box, pp.x, pp.y, pp.z, fx, fy, fz);
+    int sx, sy, sz;
+    double d0x, d0y, d0z;
+    support_start(fx, G.Nx, G.P, sx, d0x);
+    support_start(fy, G.Ny, G.P, sy, d0y);
+    support_start(fz, G.Nz, G.P, sz, d0z);
+    const int P = G.P, P2 = P * P, P3 = P2 * P;
+    for (int n = lane; n < P3; n += 64) {
+        const int tx = n / P2, ty = (n - tx * P2) / P, tz = n - tx * P2 - ty * P;
+        int ix = sx + tx; ix = ix < 0 ? ix + G.Nx : (ix >= G.Nx ? ix - G.Nx : ix);
+        const int lx = ix - G.x0;
+        if (lx < 0 || lx >= G.nxl) continue;
+        int iy = sy + ty; iy = iy < 0 ? iy + G.Ny : (iy >= G.Ny ? iy - G.Ny : iy);
+        int iz = sz + tz; iz = iz < 0 ? iz + G.Nz : (iz >= G.Nz ? iz - G.Nz : iz);
+        const double ey = G.hy * (d0y + ty);
+        const double ex = G.hx * (d0x + tx) + box.xy * ey;   // sheared lattice (PSEv1/Mobility.cu:230)
+        const double ez = G.hz * (d0z + tz);
+        const double w = G.prefac * exp(-G.expfac * (ex * ex + ey * ey + ez * ez));
+        const size_t idx = ((size_t)lx * G.Ny + iy) * G.Nz + iz;
+        unsafeAtomicAdd(&gx[idx], w * F.x);
+        unsafeAtomicAdd(&gy[idx], w * F.y);
+        unsafeAtomicAdd(&gz[idx], w * F.z);
+    }
+}
+
+void launch_spread(const double4 *pos_s, const double4 *f_s, int N, double *gx, double *gy, double *gz, DGrid G,
+                   DBox box, hipStream_t s) {
+    hipLaunchKernelGGL(k_spread_atomic, dim3(nblocks(N, TPB / 64)), dim3(TPB), 0, s, pos_s, f_s, N, gx, gy, gz, G, box);
+}
+
+// K8 gpu_stokes_Contract_kernel (PSEv1/Mobility.cu:325-477): u_p = h^3 sum_nodes prefac exp(-expfac r^2) u_grid.
+// One wave per particle, lanes stride the P^3 support, wave-64 butterfly reduction.
+__global__ void __launch_bounds__(TPB)
+k_gather(const double4 *__restrict__ pos_s, int N, const double *__restrict__ gx, const double *__restrict__ gy,
+         const double *__restrict__ gz, DGrid G, DBox box, double4 *__restrict__ u_s) {
+    const int p = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (p >= N) return;
+    const double4 pp = pos_s[p];
+    double fx, fy, fz;
+    frac_coords(box, pp.x, pp.y, pp.z, fx, fy, fz);
+    int sx, sy, sz;
+    double d0x, d0y, d0z;
+    support_start(fx, G.Nx, G.P, sx, d0x);
+    support_start(fy, G.Ny, G.P, sy, d0y);
+    support_start(fz, G.Nz, G.P, sz, d0z);
+    const int P = G.P, P2 = P * P, P3 = P2 * P;
+    double ux = 0, uy = 0, uz = 0;
+    for (int n = lane; n < P3; n += 64) {
+        const int tx = n / P2, ty = (n - tx * P2) / P, tz = n - tx * P2 - ty * P;
+        int ix = sx + tx; ix = ix < 0 ? ix + G.Nx : (ix >= G.Nx ? ix - G.Nx : ix);
+        const int lx = ix - G.x0;
+        if (lx < 0 || lx >= G.nxl) continue;
+        int iy = sy + ty; iy = iy < 0 ? iy + G.Ny : (iy >= G.Ny ? iy - G.Ny : iy);
+        int iz = sz + tz; iz = iz < 0 ? iz + G.Nz : (iz >= G.Nz ? iz - G.Nz : iz);
+        const double ey = G.hy * (d0y + ty);
+        const double ex = G.hx * (d0x + tx) + box.xy * ey;
+        const double ez = G.hz * (d0z + tz);
+        const double w = exp(-G.expfac * (ex * ex + ey * ey + ez * ez));
+        const size_t idx = ((size_t)lx * G.Ny + iy) * G.Nz + iz;
+        ux += w * gx[idx];
+        uy += w * gy[idx];
+        uz += w * gz[idx];
+    }
+    ux = wave_sum(ux); uy = wave_sum(uy); uz = wave_sum(uz);
+    if (lane == 0) {
+        const double c = G.prefac * G.hx * G.hy * G.hz;   // PSEv1/Brownian.cu:872
+        u_s[p] = make_double4(c * ux, c * uy, c * uz, 0.0);
+    }
+}
+
+void launch_gather(const double4 *pos_s, int N, const double *gx, const double *gy, const double *gz, DGrid G,
+                   DBox box, double4 *u_s, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather, dim3(nblocks(N, TPB / 64)), dim3(TPB), 0, s, pos_s, N, gx, gy, gz, G, box, u_s);
+}
+
+// K1+K5+K6 fused: gpu_stokes_SetGridk_kernel (PSEv1/Helper.cu:285-332), gpu_stokes_Green_kernel
+// (PSEv1/Mobility.cu:264-299) and gpu_stokes_BrownianGridGenerate_kernel (PSEv1/Brownian.cu:153-345) on the
+// real-to-complex half spectrum.  Wave vectors are computed in registers (no gridk array).
+struct KOp {
+    double kx, ky, kz, k2, B, c;  // B = w sinc^2 (deterministic), c = noise_fac sqrt(w) sinc
+};
+__device__ __forceinline__ KOp make_kop(int i, int j, int k, const DGrid &G, const DBox &box, double xi, double eta,
+                                        double noise_fac) {
+    KOp o;
+    const int ki = i < (G.Nx + 1) / 2 ? i : i - G.Nx;     // FFT index folding, PSEv1/Helper.cu:307-312
+    const int kj = j < (G.Ny + 1) / 2 ? j : j - G.Ny;
+    const int kk = k < (G.Nz + 1) / 2 ? k : k - G.Nz;
+    o.kx = TWO_PI * ki * box.iLx;
+    o.ky = TWO_PI * (kj * box.iLy - box.xy * ki * box.iLx);   // sheared reciprocal lattice, Helper.cu:308
+    o.kz = TWO_PI * kk * box.iLz;
+    o.k2 = o.kx * o.kx + o.ky * o.ky + o.kz * o.kz;
+    const double q = o.k2 / (4.0 * xi * xi);
+    const double ng = (double)G.Nx * (double)G.Ny * (double)G.Nz;
+    const double w = 6.0 * M_PI * (1.0 + q) * exp(-(1.0 - eta) * q) / (o.k2 * ng);   // Helper.cu:326
+    const double kn = sqrt(o.k2);
+    const double sinc = sin(kn) / kn;                                                 // Mobility.cu:290 (a = 1)
+    o.B = w * sinc * sinc;
+    o.c = noise_fac * sqrt(w) * sinc;                                                 // Brownian.cu:197,274-276
+    return o;
+}
+// out += B (I - kk) f + c (I - kk) psi    (complex 3-vectors)
+__device__ __forceinline__ void apply_kop(const KOp &o, const double2 f[3], const double2 psi[3], bool noise,
+                                          double scale, double2 out[3]) {
+    const double ik2 = 1.0 / o.k2;
+    double2 v[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        v[a].x = o.B * f[a].x;
+        v[a].y = o.B * f[a].y;
+        if (noise) { v[a].x += o.c * psi[a].x; v[a].y += o.c * psi[a].y; }
+    }
+    const double dr = (o.kx * v[0].x + o.ky * v[1].x + o.kz * v[2].x) * ik2;
+    const double di = (o.kx * v[0].y + o.ky * v[1].y + o.kz * v[2].y) * ik2;
+    const double kv[3] = {o.kx, o.ky, o.kz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        out[a].x += scale * (v[a].x - kv[a] * dr);
+        out[a].y += scale * (v[a].y - kv[a] * di);
+    }
+}
+
+__global__ void __launch_bounds__(TPB)
+k_scale(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ Z, DGrid G, DBox box, ScaleArgs a) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t rows = a.transposed ? (size_t)a.nyl * G.Nx : (size_t)G.nxl * G.Ny;
+    if (tid >= rows * G.Nzh) return;
+    const int k = (int)(tid % G.Nzh);
+    const size_t row = tid / G.Nzh;
+    int i, j;
+    if (a.transposed) { i = (int)(row / a.nyl); j = a.y0 + (int)(row % a.nyl); }   // [Nx][ny_local][Nzh]
+    else              { i = G.x0 + (int)(row / G.Ny); j = (int)(row % G.Ny); }
+    if (i == 0 && j == 0 && k == 0) {   // k = 0 mode is dropped (Helper.cu:321-323, Mobility.cu:287)
+        X[tid] = make_double2(0, 0); Y[tid] = make_double2(0, 0); Z[tid] = make_double2(0, 0);
+        return;
+    }
+    const double2 f[3] = {X[tid], Y[tid], Z[tid]};
+    // Hermitian bookkeeping: on the planes kz = 0 and kz = Nz/2 (even Nz) node (i,j) and its partner (-i,-j) must
+    // carry conjugate values. The reference writes both explicitly and keeps the real part after a C2C inverse
+    // (PSEv1/Mobility.cu:447); the equivalent for a C2R inverse is to apply the symmetrised operator
+    // (S(k_node) + S(k_partner))/2, because the index-folding convention gives the Nyquist lines k vectors that
+    // are not exact negatives of each other.
+    const bool plane = (k == 0) || ((G.Nz % 2 == 0) && (k == G.Nz / 2));
+    const int ip = (G.Nx - i) % G.Nx, jp = (G.Ny - j) % G.Ny;
+    double2 psi[3] = {{0, 0}, {0, 0}, {0, 0}};
+    if (a.noise) {
+        // K6: complex psi with Re, Im ~ U(-sqrt(3/2), sqrt(3/2)) (variance 1/2 each, Brownian.cu:178-189), keyed by the
+        // canonical member of each conjugate pair so both members reconstruct the same draw; self-conjugate nodes are
+        // real with variance 1 (x sqrt2, Brownian.cu:255-268).
+        const unsigned long long own = ((unsigned long long)i * G.Ny + j) * G.Nz + k;
+        const unsigned long long par = ((unsigned long long)ip * G.Ny + jp) * G.Nz + k;
+        const bool selfc = plane && par == own;
+        const bool flip = plane && par < own;
+        const unsigned long long canon = (plane && par < own) ? par : own;
+        uint32_t ra[4], rb[4];
+        philox4x32((uint32_t)canon, (uint32_t)(canon >> 32), a.timestep, DOMAIN_GRID_A, a.seed, PHILOX_KEY1, ra);
+        philox4x32((uint32_t)canon, (uint32_t)(canon >> 32), a.timestep, DOMAIN_GRID_B, a.seed, PHILOX_KEY1, rb);
+        const double s = 1.2247448713915890;  // sqrt(3/2)
+        const double re[3] = {uniform_pm(ra[0], s), uniform_pm(ra[1], s), uniform_pm(ra[2], s)};
+        const double im[3] = {uniform_pm(ra[3], s), uniform_pm(rb[0], s), uniform_pm(rb[1], s)};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (selfc) psi[c] = make_double2(1.4142135623730951 * re[c], 0.0);
+            else       psi[c] = make_double2(re[c], flip ? -im[c] : im[c]);
+        }
+    }
+    double2 out[3] = {{0, 0}, {0, 0}, {0, 0}};
+    const KOp o1 = make_kop(i, j, k, G, box, a.xi, a.eta, a.noise_fac);
+    if (plane) {
+        const KOp o2 = make_kop(ip, jp, k, G, box, a.xi, a.eta, a.noise_fac);
+        apply_kop(o1, f, psi, a.noise, 0.5, out);
+        apply_kop(o2, f, psi, a.noise, 0.5, out);
+    } else {
+        apply_kop(o1, f, psi, a.noise, 1.0, out);
+    }
+    X[tid] = out[0]; Y[tid] = out[1]; Z[tid] = out[2];
+}
+
+void launch_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, hipStream_t s) {
+    const size_t rows = a.transposed ? (size_t)a.nyl * G.Nx : (size_t)G.nxl * G.Ny;
+    hipLaunchKernelGGL(k_scale, dim3(nblocks((long)(rows * G.Nzh), TPB)), dim3(TPB), 0, s, X, Y, Z, G, box, a);
+}
+
+// ------------------------------------------------------------------------------------------------ vectors
+// K14 gpu_stokes_BrownianGenerate_kernel (PSEv1/Brownian.cu:99-130), keyed by the particle's global index
+__global__ void k_psi(double4 *__restrict__ psi_s, const unsigned *__restrict__ tag_s, int N, uint32_t seed,
+                      uint32_t timestep) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    uint32_t r[4];
+    philox4x32(tag_s[s], 0u, timestep, DOMAIN_PARTICLE, seed, PHILOX_KEY1, r);
+    const double q = 1.7320508075688772;  // sqrt(3): variance 1
+    psi_s[s] = make_double4(uniform_pm(r[0], q), uniform_pm(r[1], q), uniform_pm(r[2], q), 0.0);
+}
+void launch_psi(double4 *psi_s, const unsigned *tag_s, int N, uint32_t seed, uint32_t timestep, hipStream_t s) {
+    hipLaunchKernelGGL(k_psi, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, psi_s, tag_s, N, seed, timestep);
+}
+
+static inline int vec_grid(int N) { return std::min(LZ_NPART, std::max(1, nblocks(N, TPB))); }
+
+// Lanczos (PSEv1/Brownian.cu:440-521) with device-resident scalars: K10-K12 fused into three streaming kernels per
+// iteration; every block re-reduces the previous kernel's per-block partials, so there is no host round trip.
+__global__ void __launch_bounds__(TPB)
+k_dot_partial(const double4 *__restrict__ a, const double4 *__restrict__ b, int N, double *__restrict__ partials) {
+    __shared__ double sh[4];
+    double v = 0.0;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < N; i += gridDim.x * TPB) {
+        const double4 x = a[i], y = b[i];
+        v += x.x * y.x + x.y * y.y + x.z * y.z;
+    }
+    v = block_sum(v, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = v;
+}
+// V0 = psi / |psi|; scal[NORM] = |psi|
+__global__ void __launch_bounds__(TPB)
+k_lz_start(const double4 *__restrict__ psi, double4 *__restrict__ V0, double *__restrict__ scal,
+           const double *__restrict__ partials, int npart, int N) {
+    __shared__ double sh[4];
+    const double nrm = sqrt(reduce_partials(partials, npart, sh));
+    if (blockIdx.x == 0 && threadIdx.x == 0) { scal[LZ_NORM] = nrm; scal[LZ_BETA] = 0.0; }
+    const double inv = 1.0 / nrm;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < N; i += gridDim.x * TPB) {
+        const double4 p = psi[i];
+        V0[i] = make_double4(p.x * inv, p.y * inv, p.z * inv, 0.0);
+    }
+}
+// w -= beta_j V[j-1]; partialsA = V[j].w
+__global__ void __launch_bounds__(TPB)
+k_lz_a(double4 *__restrict__ w, const double4 *__restrict__ Vj, const double4 *__restrict__ Vjm1, int j,
+       const double *__restrict__ scal, double *__restrict__ partialsA, int N) {
+    __shared__ double sh[4];
+    const double beta = j > 0 ? scal[LZ_BETA + j] : 0.0;
+    double v = 0.0;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < N; i += gridDim.x * TPB) {
+        double4 x = w[i];
+        if (j > 0) {
+            const double4 m = Vjm1[i];
+            x.x -= beta * m.x; x.y -= beta * m.y; x.z -= beta * m.z;
+            w[i] = x;
+        }
+        const double4 y = Vj[i];
+        v += x.x * y.x + x.y * y.y + x.z * y.z;
+    }
+    v = block_sum(v, sh);
+    if (threadIdx.x == 0) partialsA[blockIdx.x] = v;
+}
+// alpha_j = sum partialsA; w -= alpha_j V[j]; partialsB = w.w
+__global__ void __launch_bounds__(TPB)
+k_lz_b(double4 *__restrict__ w, const double4 *__restrict__ Vj, int j, double *__restrict__ scal,
+       const double *__restrict__ partialsA, double *__restrict__ partialsB, int npart, int N) {
+    __shared__ double sh[4];
+    const double alpha = reduce_partials(partialsA, npart, sh);
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[LZ_ALPHA + j] = alpha;
+    double v = 0.0;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < N; i += gridDim.x * TPB) {
+        double4 x = w[i];
+        const double4 y = Vj[i];
+        x.x -= alpha * y.x; x.y -= alpha * y.y; x.z -= alpha * y.z;
+        w[i] = x;
+        v += x.x * x.x + x.y * x.y + x.z * x.z;
+    }
+    __syncthreads();
+    v = block_sum(v, sh);
+    if (threadIdx.x == 0) partialsB[blockIdx.x] = v;
+}
+// beta_{j+1} = sqrt(sum partialsB); V[j+1] = w / beta_{j+1}
+__global__ void __launch_bounds__(TPB)
+k_lz_c(const double4 *__restrict__ w, double4 *__restrict__ Vjp1, int j, double *__restrict__ scal,
+       const double *__restrict__ partialsB, int npart, int N) {
+    __shared__ double sh[4];
+    const double beta = sqrt(reduce_partials(partialsB, npart, sh));
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[LZ_BETA + j + 1] = beta;
+    const double inv = beta > 0.0 ? 1.0 / beta : 0.0;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < N; i += gridDim.x * TPB) {
+        const double4 x = w[i];
+        Vjp1[i] = make_double4(x.x * inv, x.y * inv, x.z * inv, 0.0);
+    }
+}
+
+void launch_lz_start(const double4 *psi_s, double4 *V0, double4 *, double *scal, double *partials, int N,
+                     hipStream_t s) {
+    const int g = vec_grid(N);
+    hipLaunchKernelGGL(k_dot_partial, dim3(g), dim3(TPB), 0, s, psi_s, psi_s, N, partials);
+    hipLaunchKernelGGL(k_lz_start, dim3(g), dim3(TPB), 0, s, psi_s, V0, scal, partials, g, N);
+}
+void launch_lz_iter(double4 *w, const double4 *Vj, const double4 *Vjm1, double4 *Vjp1, int j, double *scal,
+                    double *partials, int N, hipStream_t s) {
+    const int g = vec_grid(N);
+    double *pa = partials, *pb = partials + LZ_NPART;
+    hipLaunchKernelGGL(k_lz_a, dim3(g), dim3(TPB), 0, s, w, Vj, Vjm1, j, scal, pa, N);
+    hipLaunchKernelGGL(k_lz_b, dim3(g), dim3(TPB), 0, s, w, Vj, j, scal, pa, pb, g, N);
+    hipLaunchKernelGGL(k_lz_c, dim3(g), dim3(TPB), 0, s, w, Vjp1, j, scal, pb, g, N);
+}
+
+// K13 gpu_stokes_MatVecMultiply_kernel (PSEv1/Helper.cu:251-279) + the final rescale (PSEv1/Brownian.cu:739)
+__global__ void __launch_bounds__(TPB)
+k_basis_combine(const double4 *__restrict__ V, size_t stride, const double *__restrict__ t, int m,
+                const double *__restrict__ scal, double scale, int use_norm, double4 *__restrict__ out, int N) {
+    const double sc = use_norm ? scale * scal[LZ_NORM] : scale;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < N; i += gridDim.x * TPB) {
+        double x = 0, y = 0, z = 0;
+        for (int q = 0; q < m; ++q) {
+            const double4 v = V[(size_t)q * stride + i];
+            const double tq = t[q];
+            x += tq * v.x; y += tq * v.y; z += tq * v.z;
+        }
+        out[i] = make_double4(sc * x, sc * y, sc * z, 0.0);
+    }
+}
+void launch_basis_combine(const double4 *V, size_t stride, const double *t_dev, int m, const double *scal,
+                          double scale, int use_norm, double4 *out_s, int N, hipStream_t s) {
+    hipLaunchKernelGGL(k_basis_combine, dim3(std::min(2048, std::max(1, nblocks(N, TPB)))), dim3(TPB), 0, s, V, stride,
+                       t_dev, m, scal, scale, use_norm, out_s, N);
+}
+
+// K10 gpu_stokes_LinearCombination_kernel (PSEv1/Helper.cu:113-133) as the final un-sort: vel.xyz = a + b + c, keep w
+__global__ void k_scatter_sum(const double4 *__restrict__ a, const double4 *__restrict__ b,
+                              const double4 *__restrict__ c, const unsigned *__restrict__ tag_s, int N,
+                              double4 *__restrict__ vel) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    double x = 0, y = 0, z = 0;
+    if (a) { const double4 v = a[s]; x += v.x; y += v.y; z += v.z; }
+    if (b) { const double4 v = b[s]; x += v.x; y += v.y; z += v.z; }
+    if (c) { const double4 v = c[s]; x += v.x; y += v.y; z += v.z; }
+    const unsigned idx = tag_s[s];
+    double4 o = vel[idx];
+    o.x = x; o.y = y; o.z = z;
+    vel[idx] = o;
+}
+void launch_scatter_sum(const double4 *a, const double4 *b, const double4 *c, const unsigned *tag_s, int N,
+                        double4 *vel, hipStream_t s) {
+    hipLaunchKernelGGL(k_scatter_sum, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, a, b, c, tag_s, N, vel);
+}
+
+// K15 gpu_stokes_step_one_kernel (PSEv1/Stokes.cu:137-192)
+__global__ void k_integrate(double4 *__restrict__ pos, const double4 *__restrict__ vel, double3 *__restrict__ accel,
+                            int3 *__restrict__ image, const double4 *__restrict__ force,
+                            const unsigned *__restrict__ group, int N, DBox box, double dt, double shear_rate) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    const unsigned idx = group ? group[g] : (unsigned)g;
+    double4 p = pos[idx];
+    const double4 v = vel[idx];
+    const double4 F = force[idx];
+    p.x += (v.x + shear_rate * p.y) * dt;   // Stokes.cu:164-171
+    p.y += v.y * dt;
+    p.z += v.z * dt;
+    int3 im = image[idx];
+    // triclinic wrap (HOOMD BoxDim::wrap): z, then y (a y image shifts x by xy*Ly), then x
+    double n = floor(p.z * box.iLz + 0.5);
+    p.z -= n * box.Lz; im.z += (int)n;
+    n = floor(p.y * box.iLy + 0.5);
+    p.y -= n * box.Ly; p.x -= n * box.xy * box.Ly; im.y += (int)n;
+    n = floor((p.x - box.xy * p.y) * box.iLx + 0.5);
+    p.x -= n * box.Lx; im.x += (int)n;
+    const double im_ = 1.0 / v.w;            // mass in vel.w (Stokes.cu:160,174)
+    accel[idx] = make_double3(F.x * im_, F.y * im_, F.z * im_);
+    pos[idx] = p;
+    image[idx] = im;
+}
+void launch_integrate(double4 *pos, const double4 *vel, double3 *accel, int3 *image, const double4 *force,
+                      const unsigned *group, int N, DBox box, double dt, double shear_rate, hipStream_t s) {
+    hipLaunchKernelGGL(k_integrate, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, vel, accel, image, force, group, N,
+                       box, dt, shear_rate);
+}
+
+}  // namespace pse

@@ -1,0 +1,147 @@
+"""Thin Python owner of a pse_handle: torch tensors in, torch tensors out, everything through the C-ABI.
+
+Arrays follow HOOMD's layout with Scalar = double: pos/vel/force are (N,4) float64 CUDA tensors
+(x,y,z,type|mass|energy), accel (N,3) float64, image (N,3) int32, group_members (N,) int32/uint32.
+"""
+import ctypes
+
+from . import _lib
+from ._lib import pse_info, pse_params
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _chk4(t, name, n=None):
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.dim() == 2
+            and t.shape[1] == 4 and t.is_contiguous()):
+        raise ValueError(f"{name} must be a contiguous (N,4) float64 CUDA tensor")
+    if n is not None and t.shape[0] < n:
+        raise ValueError(f"{name} has fewer than {n} rows")
+
+
+def host_select_params(box, xi=0.5, error=1e-3, max_strain=0.5, grid=(0, 0, 0), P=0, rcut=0.0):
+    """Parameter rule of Stokes::setParams (PSEv1/Stokes.cc:129-236,319), host only."""
+    lib = _lib.load()
+    p = pse_params(n_max=1, Lx=box[0], Ly=box[1], Lz=box[2], xy=box[3] if len(box) > 3 else 0.0, xi=xi, error=error,
+                   max_strain=max_strain, seed=0, Nx=grid[0], Ny=grid[1], Nz=grid[2], P=P, rcut=rcut, device=-1,
+                   n_slabs=1, slab_rank=0)
+    info = pse_info()
+    _lib.check(lib.pse_host_select_params(ctypes.byref(p), ctypes.byref(info)))
+    return info.as_dict()
+
+
+def host_lanczos_sqrt_e1(alpha, beta):
+    """t = T^{1/2} e_1 (host); alpha[0..m), beta[0..m] with beta[0] unused."""
+    import numpy as np
+    lib = _lib.load()
+    a = np.ascontiguousarray(alpha, dtype=np.float64)
+    b = np.ascontiguousarray(beta, dtype=np.float64)
+    t = np.zeros(len(a))
+    dp = ctypes.POINTER(ctypes.c_double)
+    _lib.check(lib.pse_host_lanczos_sqrt_e1(len(a), a.ctypes.data_as(dp), b.ctypes.data_as(dp), t.ctypes.data_as(dp)))
+    return t
+
+
+class Engine:
+    """One PSE engine instance == one `Stokes` object's device state (PSEv1/Stokes.h:128-150)."""
+
+    def __init__(self, n_max, box, xi=0.5, error=1e-3, max_strain=0.5, seed=0, grid=(0, 0, 0), P=0, rcut=0.0,
+                 device=-1):
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        box = tuple(float(b) for b in box) + ((0.0,) if len(box) == 3 else ())
+        self.params = pse_params(n_max=int(n_max), Lx=box[0], Ly=box[1], Lz=box[2], xy=box[3], xi=xi, error=error,
+                                 max_strain=max_strain, seed=int(seed) & 0xFFFFFFFF, Nx=grid[0], Ny=grid[1],
+                                 Nz=grid[2], P=P, rcut=rcut, device=device, n_slabs=1, slab_rank=0)
+        _lib.check(self._lib.pse_create(ctypes.byref(self.params), ctypes.byref(self._h)))
+        self.box = box
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.pse_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    __del__ = close
+
+    def info(self):
+        out = pse_info()
+        _lib.check(self._lib.pse_get_info(self._h, ctypes.byref(out)))
+        return out.as_dict()
+
+    def set_box(self, Lx, Ly, Lz, xy):
+        _lib.check(self._lib.pse_set_box(self._h, Lx, Ly, Lz, xy))
+        self.box = (Lx, Ly, Lz, xy)
+
+    def set_timing(self, on=True):
+        _lib.check(self._lib.pse_set_timing(self._h, 1 if on else 0))
+
+    def set_stream(self, stream_ptr):
+        _lib.check(self._lib.pse_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+
+    # -- hot path -------------------------------------------------------------------------------------------
+    def mobility(self, pos, force, vel=None, group=None, parts=3):
+        import torch
+        n = pos.shape[0] if group is None else group.shape[0]
+        _chk4(pos, "pos"); _chk4(force, "force")
+        if vel is None:
+            vel = torch.zeros_like(pos)
+        _chk4(vel, "vel")
+        _lib.check(self._lib.pse_mobility(self._h, _ptr(pos), _ptr(force), _ptr(vel), _ptr(group), n, parts))
+        return vel
+
+    def brownian_velocity(self, pos, force, kT, dt, timestep, vel=None, group=None, lanczos_m=2):
+        import torch
+        n = pos.shape[0] if group is None else group.shape[0]
+        _chk4(pos, "pos"); _chk4(force, "force")
+        if vel is None:
+            vel = torch.zeros_like(pos)
+        m = ctypes.c_int(int(lanczos_m))
+        _lib.check(self._lib.pse_brownian_velocity(self._h, _ptr(pos), _ptr(force), _ptr(vel), _ptr(group), n,
+                                                   float(kT), float(dt), int(timestep), ctypes.byref(m)))
+        return vel, m.value
+
+    def step(self, pos, vel, accel, image, force, kT, dt, timestep, shear_rate=0.0, group=None, lanczos_m=2):
+        n = pos.shape[0] if group is None else group.shape[0]
+        _chk4(pos, "pos"); _chk4(vel, "vel"); _chk4(force, "force")
+        m = ctypes.c_int(int(lanczos_m))
+        _lib.check(self._lib.pse_step(self._h, _ptr(pos), _ptr(vel), _ptr(accel), _ptr(image), _ptr(force),
+                                      _ptr(group), n, float(kT), float(dt), int(timestep), float(shear_rate),
+                                      ctypes.byref(m)))
+        return m.value
+
+    def sqrt_mreal(self, pos, psi, tol=1e-3, group=None, lanczos_m=2):
+        import torch
+        n = pos.shape[0] if group is None else group.shape[0]
+        _chk4(pos, "pos"); _chk4(psi, "psi")
+        out = torch.zeros_like(psi)
+        m = ctypes.c_int(int(lanczos_m))
+        _lib.check(self._lib.pse_sqrt_mreal(self._h, _ptr(pos), _ptr(psi), _ptr(out), _ptr(group), n, float(tol),
+                                            ctypes.byref(m)))
+        return out, m.value
+
+    def random_psi(self, n, timestep, group=None):
+        import torch
+        rows = n if group is None else int(group.max().item()) + 1
+        psi = torch.zeros((rows, 4), dtype=torch.float64, device="cuda")
+        _lib.check(self._lib.pse_random_psi(self._h, _ptr(psi), _ptr(group), n, int(timestep)))
+        return psi
+
+    # -- introspection ---------------------------------------------------------------------------------------
+    def eval_realspace(self, r):
+        import numpy as np
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        f = np.zeros_like(r); g = np.zeros_like(r)
+        dp = ctypes.POINTER(ctypes.c_double)
+        _lib.check(self._lib.pse_eval_realspace(self._h, r.ctypes.data_as(dp), len(r), f.ctypes.data_as(dp),
+                                                g.ctypes.data_as(dp)))
+        return f, g
+
+    def debug_grid(self):
+        import numpy as np
+        i = self.info()
+        out = np.zeros((3, i["Nx"], i["Ny"], i["Nz"]))
+        _lib.check(self._lib.pse_debug_copy_grid(self._h, 0, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+        return out

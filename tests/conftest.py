@@ -1,0 +1,44 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def make_suspension(n, phi=None, L=None, seed=12345, fseed=54321, xy=0.0):
+    """Synthetic random-sphere suspension of SURVEY.md 8(d): uniform positions in a cubic box centred on the
+    origin (a = 1), N(0,1) forces with zero mean."""
+    if L is None:
+        L = (4.0 * np.pi * n / (3.0 * phi)) ** (1.0 / 3.0)
+    rng = np.random.default_rng(seed)
+    f = rng.uniform(0.0, 1.0, (n, 3)) - 0.5
+    pos = np.empty((n, 3))
+    pos[:, 1] = f[:, 1] * L
+    pos[:, 2] = f[:, 2] * L
+    pos[:, 0] = f[:, 0] * L + xy * pos[:, 1]
+    force = np.random.default_rng(fseed).normal(size=(n, 3))
+    force -= force.mean(axis=0)
+    return pos, force, (L, L, L, xy)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import pse_port
+    pse_port.lib()
+    return pse_port
+
+
+def to4(a, w=0.0):
+    import torch
+    out = np.zeros((a.shape[0], 4))
+    out[:, :3] = a
+    out[:, 3] = w
+    return torch.tensor(out, dtype=torch.float64, device="cuda")

@@ -1,0 +1,179 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+Tolerances: real-space <= 1e-12 relative; wave-space against the NumPy restatement of the same
+algorithm <= 1e-10; total M.F against the direct Ewald sum <= 5 x error."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import make_suspension, to4
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def test_realspace_functions_match_closed_form(torch_cuda, oracle):
+    import pse_amd
+    for xi in (0.5, 0.273, 0.8):
+        rcut = math.sqrt(-math.log(1e-3)) / xi
+        eng = pse_amd.Engine(8, (4 * rcut, 4 * rcut, 4 * rcut, 0.0), xi=xi, error=1e-3, grid=(32, 32, 32), P=4)
+        r = np.concatenate([np.random.default_rng(1).uniform(1e-3, rcut, 2000), [2.0, 1.999999, 2.000001, 0.125, 1e-4]])
+        f, g = eng.eval_realspace(r)
+        fo, go = oracle.fg_real(r, xi)
+        assert np.abs(f - fo).max() < 2e-13, (xi, np.abs(f - fo).max())
+        assert np.abs(g - go).max() < 2e-13, (xi, np.abs(g - go).max())
+        eng.close()
+
+
+@pytest.mark.parametrize("xy", [0.0, 0.35])
+def test_mreal_matches_oracle(torch_cuda, oracle, xy):
+    import pse_amd
+    n = 2000
+    pos, force, box = make_suspension(n, phi=0.1, xy=xy)
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3)
+    info = eng.info()
+    u = eng.mobility(to4(pos), to4(force), parts=1).cpu().numpy()[:, :3]
+    ref = oracle.mobility_real(pos, force, box, 0.5, info["rcut"])
+    assert rel(u, ref) < 1e-12, rel(u, ref)
+
+
+@pytest.mark.parametrize("xy,err", [(0.0, 1e-3), (0.2, 1e-3), (0.0, 1e-6), (-0.45, 1e-4)])
+def test_wave_matches_port(torch_cuda, oracle, xy, err):
+    import pse_amd
+    n = 1500
+    pos, force, box = make_suspension(n, phi=0.1, xy=xy)
+    eng = pse_amd.Engine(n, box, xi=0.5, error=err)
+    info = eng.info()
+    p = oracle.select_params(box, 0.5, err, 0.5)
+    assert (info["Nx"], info["Ny"], info["Nz"]) == p["grid"] and info["P"] == p["P"]
+    assert abs(info["eta"] - p["eta"]) < 1e-14
+    u = eng.mobility(to4(pos), to4(force), parts=2).cpu().numpy()[:, :3]
+    g = eng.debug_grid()
+    ref = oracle.mobility_wave(pos, force, box, p)
+    assert rel(u, ref) < 1e-10, rel(u, ref)
+
+
+@pytest.mark.parametrize("err", [1e-3, 1e-6, 1e-9])
+def test_total_mobility_against_direct_ewald(torch_cuda, oracle, err):
+    import pse_amd
+    n = 1000
+    pos, force, box = make_suspension(n, phi=0.05)          # BASELINE config 1
+    eng = pse_amd.Engine(n, box, xi=0.5, error=err, max_strain=0.5)
+    u = eng.mobility(to4(pos), to4(force)).cpu().numpy()[:, :3]
+    ref = oracle.mobility_direct(pos, force, box, 0.5)
+    e = rel(u, ref)
+    # the NumPy restatement of the reference algorithm (same rcut/grid/P/eta) bounds what the method itself can reach:
+    # at error = 1e-9 the reference's parameter rule delivers ~1.5e-8, not 1e-9
+    p = oracle.select_params(box, 0.5, err, 0.5)
+    e_port = rel(oracle.mobility(pos, force, box, p), ref)
+    assert rel(u, oracle.mobility(pos, force, box, p)) < 1e-10
+    assert e < max(5 * err, 1.05 * e_port), (err, e, e_port)
+    assert e < 3e-8 or err > 1e-9
+
+
+def test_xi_independence(torch_cuda, oracle):
+    import pse_amd
+    n = 800
+    pos, force, box = make_suspension(n, phi=0.1)
+    us = []
+    for xi in (0.5, 0.75):
+        eng = pse_amd.Engine(n, box, xi=xi, error=1e-7)
+        us.append(eng.mobility(to4(pos), to4(force)).cpu().numpy()[:, :3])
+        eng.close()
+    assert rel(us[0], us[1]) < 5e-7
+
+
+def test_group_members_and_w_preserved(torch_cuda, oracle):
+    import torch
+    import pse_amd
+    n_total, n = 1200, 700
+    pos, force, box = make_suspension(n_total, phi=0.1)
+    members = np.sort(np.random.default_rng(3).choice(n_total, n, replace=False)).astype(np.int32)
+    eng = pse_amd.Engine(n_total, box, xi=0.5, error=1e-3)
+    vel = to4(np.zeros((n_total, 3)), w=7.5)
+    vel[:, :3] = -1.0
+    g = torch.tensor(members, dtype=torch.int32, device="cuda")
+    eng.mobility(to4(pos), to4(force), vel=vel, group=g)
+    v = vel.cpu().numpy()
+    sub = eng.mobility(to4(pos[members]), to4(force[members])).cpu().numpy()
+    assert np.all(v[:, 3] == 7.5)
+    others = np.setdiff1d(np.arange(n_total), members)
+    assert np.all(v[others, :3] == -1.0)
+    assert rel(v[members, :3], sub[:, :3]) < 1e-12
+
+
+def test_random_psi_matches_oracle_stream(torch_cuda, oracle):
+    import pse_amd
+    n = 5000
+    eng = pse_amd.Engine(n, (50, 50, 50, 0), xi=0.5, error=1e-3, seed=987654321)
+    for ts in (0, 17, 2 ** 31 + 5):
+        psi = eng.random_psi(n, ts).cpu().numpy()[:, :3]
+        ref = oracle.psi_particles(n, 987654321, ts)
+        assert np.abs(psi - ref).max() < 1e-15
+    assert abs(psi.var() - 1.0) < 0.05
+
+
+def test_lanczos_sqrt_matches_dense(torch_cuda, oracle):
+    import scipy.linalg as sl
+    import pse_amd
+    n = 60
+    pos, _, box = make_suspension(n, L=16.0)
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3)
+    rcut = eng.info()["rcut"]
+    eye = np.eye(3 * n)
+    M = np.stack([oracle.mobility_real(pos, eye[c].reshape(n, 3), box, 0.5, rcut).ravel() for c in range(3 * n)], 1)
+    psi = np.random.default_rng(5).normal(size=(n, 3))
+    ref = (sl.sqrtm(M).real @ psi.ravel()).reshape(n, 3)
+    for tol, bound in ((1e-3, 5e-3), (1e-8, 1e-7)):
+        out, m = eng.sqrt_mreal(to4(pos), to4(psi), tol=tol)
+        e = rel(out.cpu().numpy()[:, :3], ref)
+        assert e < bound, (tol, m, e)
+        up, mp = oracle.lanczos_sqrt(lambda v: oracle.mobility_real(pos, np.ascontiguousarray(v), box, 0.5, rcut), psi, 2, tol)
+        assert m == mp, (m, mp)
+        assert rel(out.cpu().numpy()[:, :3], up) < 1e-9
+
+
+@pytest.mark.parametrize("xy", [0.0, 0.3])
+def test_brownian_velocity_matches_port(torch_cuda, oracle, xy):
+    import pse_amd
+    n = 1000
+    pos, force, box = make_suspension(n, phi=0.1, xy=xy)
+    seed, ts, kT, dt = 424242, 11, 1.0, 1e-3
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3, seed=seed)
+    p = oracle.select_params(box, 0.5, 1e-3, 0.5)
+    vel, m = eng.brownian_velocity(to4(pos), to4(force), kT, dt, ts)
+    ref, mref = oracle.brownian_velocity(pos, force, box, p, kT, dt, seed, ts)
+    assert m == mref, (m, mref)
+    assert rel(vel.cpu().numpy()[:, :3], ref) < 1e-9, rel(vel.cpu().numpy()[:, :3], ref)
+
+
+def test_step_integrates_and_wraps(torch_cuda, oracle):
+    import torch
+    import pse_amd
+    n = 1000
+    pos, force, box = make_suspension(n, phi=0.1, xy=0.25)
+    seed, ts, kT, dt, rate = 99, 3, 1.0, 2e-2, 0.7
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3, seed=seed)
+    p = oracle.select_params(box, 0.5, 1e-3, 0.5)
+    dpos = to4(pos, w=1.0); dvel = to4(np.zeros((n, 3)), w=2.0); dF = to4(force, w=0.5)
+    accel = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+    image = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+    eng.step(dpos, dvel, accel, image, dF, kT, dt, ts, shear_rate=rate)
+    u, _ = oracle.brownian_velocity(pos, force, box, p, kT, dt, seed, ts)
+    newpos, newimg = oracle.integrate(pos, np.zeros((n, 3), dtype=np.int64), u, box, dt, rate)
+    got = dpos.cpu().numpy()
+    assert np.abs(got[:, :3] - newpos).max() < 1e-9
+    assert np.array_equal(image.cpu().numpy(), newimg)
+    assert np.all(got[:, 3] == 1.0)
+    assert np.abs(accel.cpu().numpy() - force / 2.0).max() < 1e-15
+    assert newimg.any(), "test should exercise the wrap"

@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- the PSE hot path on MI355X, one JSON line (contract in the task statement, section 4).
+
+A "step" is one full PSE Brownian step through the C-ABI (pse_step): sort -> spread -> rocFFT -> k-space scaling with
+in-k-space noise -> inverse FFT -> gather -> near-field M.F -> Lanczos M_real^{1/2} psi -> Euler update, on the
+synthetic random-sphere suspension of BASELINE.json's metric point (N = 1e6, phi = 0.1, 256^3 grid, fp64), inputs
+resident in HBM before the timed region.  value = particle-steps/s summed over all ranks.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--n PARTICLES] [--grid G] [--no-cpu]
+For N > 1 launch with torch.distributed.run (one rank per GPU); see DESIGN.md section "Multi-GPU".
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def suspension(n, phi, seed=12345, fseed=54321):
+    L = (4.0 * math.pi * n / (3.0 * phi)) ** (1.0 / 3.0)
+    pos = (np.random.default_rng(seed).uniform(0.0, 1.0, (n, 3)) - 0.5) * L
+    force = np.random.default_rng(fseed).normal(size=(n, 3))
+    force -= force.mean(axis=0)
+    return pos, force, L
+
+
+def cpu_baseline(budget_s=12.0):
+    """Direct O(N^2) periodic-RPY M.F (the oracle, oracle/pse_oracle.c) on BASELINE config 1, all host cores."""
+    from oracle import pse_port as pp
+    n, phi, xi = 1000, 0.05, 0.5
+    pos, force, L = suspension(n, phi)
+    box = (L, L, L, 0.0)
+    cores = pp.max_threads()
+    pp.mobility_direct(pos, force, box, xi)            # warm-up
+    times = []
+    t_end = time.time() + budget_s
+    while len(times) < 5 or (time.time() < t_end and len(times) < 50):
+        t0 = time.perf_counter()
+        pp.mobility_direct(pos, force, box, xi)
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times))
+    return {
+        "value": n / t, "unit": "particle-evals/s (M.F only)", "cores": int(cores), "kind": "port",
+        "sample": f"direct Ewald-summed periodic RPY M.F, N={n}, phi={phi}, xi={xi}, fp64, tol 1e-14, "
+                  f"median of {len(times)} evals ({t * 1e3:.1f} ms each); O(N^2): extrapolates to "
+                  f"{t * (1e6 / n) ** 2:.3g} s per eval at N=1e6",
+        "evals_per_s": 1.0 / t,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--phi", type=float, default=0.1)
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--error", type=float, default=1e-3)
+    ap.add_argument("--kT", type=float, default=1.0)
+    ap.add_argument("--dt", type=float, default=1e-3)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import pse_amd
+    from pse_amd import distributed as pdist
+
+    n, grid = args.n, args.grid
+    pos, force, L = suspension(n, args.phi)
+    xi = math.pi * grid / (2.0 * L * math.sqrt(-math.log(args.error)))      # xi from the fixed grid
+    sim = pdist.make_simulation(n, (L, L, L, 0.0), xi=xi, error=args.error, seed=1, grid=(grid,) * 3,
+                                world=world, rank=rank)
+    sim.load(pos, force, mass=1.0)
+    info = sim.info()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    m = 2
+    for it in range(args.warmup):
+        m = sim.step(args.kT, args.dt, it, lanczos_m=m)
+    # M.F evals/s (deterministic part only), a few evaluations
+    barrier()
+    t0 = time.perf_counter()
+    n_mf = max(3, args.steps // 2)
+    for it in range(n_mf):
+        sim.mobility()
+    barrier()
+    t_mf = (time.perf_counter() - t0) / n_mf
+
+    sim.set_timing(True)
+    phase_sum = {}
+    ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        m = sim.step(args.kT, args.dt, args.warmup + it, lanczos_m=m)
+        ms.append(m)
+        for k, v in sim.phase_times().items():
+            phase_sum[k] = phase_sum.get(k, 0.0) + v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, t_mf], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, t_mf = float(t[0]), float(t[1])
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    t_step = elapsed / args.steps
+    ng = grid ** 3
+    nloc, ngloc = n / world, ng / world
+    phases = {k: v / args.steps for k, v in phase_sum.items()}                # ms per step, rank 0
+    m_avg = float(np.mean(ms))
+    # algorithmic bytes per launch (BASELINE.md section 3 / SURVEY.md 8d), per rank
+    alg = {
+        "t_spread": 64 * nloc + 24 * ngloc, "t_fft_fwd": 48 * ngloc, "t_scale": 48 * ngloc, "t_fft_inv": 48 * ngloc,
+        "t_gather": 24 * ngloc + 64 * nloc, "t_real": 96 * nloc,
+    }
+    launches = {k: 1 for k in alg}
+    per_launch_ms = {k: phases.get(k, 0.0) / launches[k] for k in alg}
+    # which kernel dominates the step: the near-field mat-vec runs once for M.F and once per Lanczos iteration
+    weight = dict(per_launch_ms)
+    weight["t_real"] = per_launch_ms["t_real"] * (1 + info["lanczos_matvecs"])
+    dom = max(weight, key=weight.get)
+    names = {"t_spread": "spread", "t_fft_fwd": "rocFFT forward x3", "t_scale": "k-space scale+noise",
+             "t_fft_inv": "rocFFT inverse x3", "t_gather": "gather", "t_real": "near-field M_real mat-vec"}
+    ach = alg[dom] / (per_launch_ms[dom] * 1e-3) / 1e9 if per_launch_ms[dom] > 0 else 0.0
+    traffic = None
+    tr_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tr_file):
+        try:
+            traffic = json.load(open(tr_file)).get(dom)
+        except Exception:
+            traffic = None
+    sg_ms = per_launch_ms["t_spread"] + per_launch_ms["t_gather"]
+    sg_bytes = alg["t_spread"] + alg["t_gather"]
+    out = {
+        "metric": "BD particle-steps/s (full PSE Brownian step: M.F + k-space noise + Lanczos M^1/2.psi + Euler), "
+                  "N=1e6, phi=0.1",
+        "value": n / t_step, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"random-sphere suspension N={n}, phi={args.phi}, cubic L={L:.2f}, grid {grid}^3, "
+                               f"xi={xi:.4f}, rcut={info['rcut']:.3f}, P={info['P']}, error={args.error}, kT={args.kT}, "
+                               f"dt={args.dt}", "parallelism": sim.describe()},
+        "steps_per_s": 1.0 / t_step, "mf_evals_per_s": 1.0 / t_mf, "mf_particle_evals_per_s": n / t_mf,
+        "lanczos_m": m_avg, "lanczos_matvecs_per_step": info["lanczos_matvecs"],
+        "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg[dom], "ms_per_launch": per_launch_ms[dom]},
+        "spread_plus_gather": {"ms": sg_ms, "algorithmic_bytes": sg_bytes,
+                               "frac_of_hbm_peak": (sg_bytes / (sg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sg_ms > 0 else 0.0},
+        "phases_ms_per_step": {k[2:]: round(v, 4) for k, v in phases.items()},
+        "phase_hbm_frac": {k[2:]: round(alg[k] / (per_launch_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                           for k in alg if per_launch_ms[k] > 0},
+    }
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -219,7 +219,8 @@ def kvectors(box, p):
     Nx, Ny, Nz = p["grid"]
     i = np.arange(Nx); i = np.where(i < (Nx + 1) // 2, i, i - Nx).astype(float)
     j = np.arange(Ny); j = np.where(j < (Ny + 1) // 2, j, j - Ny).astype(float)
-    k = np.arange(Nz // 2 + 1).astype(float)
+    k = np.arange(Nz // 2 + 1)
+    k = np.where(k < (Nz + 1) // 2, k, k - Nz).astype(float)   # the z-Nyquist plane folds to -Nz/2 like x and y (Helper.cu:312)
     kx = 2 * math.pi * i[:, None, None] / Lx + 0 * j[None, :, None] + 0 * k[None, None, :]
     ky = 2 * math.pi * (j[None, :, None] - xy * i[:, None, None] * Ly / Lx) / Ly + 0 * k[None, None, :]
     kz = 2 * math.pi * k[None, None, :] / Lz + 0 * kx

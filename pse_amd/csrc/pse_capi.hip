@@ -66,7 +66,10 @@ struct pse_handle {
     unsigned *keys = nullptr, *keys_s = nullptr, *vals = nullptr, *perm = nullptr, *tag_s = nullptr;
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
-    int *cell_start = nullptr, *cell_end = nullptr;
+    int *cell_off = nullptr;
+    int4 *sup_s = nullptr;    // support origin of each sorted particle (node indices)
+    NbList nb = {};
+    bool nb_valid = false;   // the pair list matches the current sorted positions
     size_t n_cells_alloc = 0;
     double4 *pos_s = nullptr, *f_s = nullptr, *uw_s = nullptr, *ur_s = nullptr, *ub_s = nullptr, *psi_s = nullptr, *w_s = nullptr;
     // real-space table
@@ -178,7 +181,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->plan_inv) rocfft_plan_destroy(h->plan_inv);
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
-    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_start, h->cell_end, h->pos_s,
+    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->sup_s, h->nb.j, h->nb.fh, h->nb.dx, h->nb.dy, h->nb.dz, h->nb.cnt, h->pos_s,
                     h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->fft_work, h->V,
                     h->scal, h->partials, h->t_dev};
     for (void *p : ptrs) if (p) hipFree(p);
@@ -247,7 +250,23 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         auto cnt = [&](double w) { int c2 = (int)std::floor(w / rc); if (c2 < 3) c2 = 1; if (c2 > 1024) c2 = 1024; return (size_t)c2; };
         h->n_cells_alloc = cnt(h->box.Lx) * cnt(h->box.Ly) * cnt(h->box.Lz);
     }
-    TRY(dmalloc(h, &h->cell_start, h->n_cells_alloc)); TRY(dmalloc(h, &h->cell_end, h->n_cells_alloc));
+    TRY(dmalloc(h, &h->cell_off, h->n_cells_alloc + 1));
+    TRY(dmalloc(h, &h->sup_s, n));
+    {   // per-step pair list for the Lanczos mat-vecs: capacity from the mean neighbour count at full occupancy
+        const double vol = h->box.Lx * h->box.Ly * h->box.Lz;
+        const double nbar = (double)n / vol * 4.18879020478639 * d.rcut * d.rcut * d.rcut;
+        int cap = (int)std::ceil(1.5 * nbar + 16.0);
+        cap = std::max(16, std::min(cap, 256));
+        const double bytes = (double)cap * (double)n * 44.0;
+        if (bytes > 32e9 || n >= ((size_t)1 << 27)) cap = 0;   // too large: mat-vecs always walk the cells
+        h->nb.cap = cap; h->nb.stride = n;
+        if (cap > 0) {
+            TRY(dmalloc(h, &h->nb.j, (size_t)cap * n)); TRY(dmalloc(h, &h->nb.fh, (size_t)cap * n));
+            TRY(dmalloc(h, &h->nb.dx, (size_t)cap * n)); TRY(dmalloc(h, &h->nb.dy, (size_t)cap * n));
+            TRY(dmalloc(h, &h->nb.dz, (size_t)cap * n));
+        }
+        TRY(dmalloc(h, &h->nb.cnt, n));
+    }
     TRY(dmalloc(h, &h->pos_s, n)); TRY(dmalloc(h, &h->f_s, n)); TRY(dmalloc(h, &h->uw_s, n)); TRY(dmalloc(h, &h->ur_s, n));
     TRY(dmalloc(h, &h->ub_s, n)); TRY(dmalloc(h, &h->psi_s, n)); TRY(dmalloc(h, &h->w_s, n));
 
@@ -333,11 +352,10 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
     while (((size_t)1 << bits) < ncell) ++bits;
     launch_cell_keys(pos, group, N, h->dbox, h->nc, h->keys, h->vals, h->stream);
     sort_pairs(h->sort_tmp, h->sort_tmp_bytes, h->keys, h->keys_s, h->vals, h->perm, N, bits, h->stream);
-    HIPCHK(hipMemsetAsync(h->cell_start, 0, ncell * sizeof(int), h->stream));
-    HIPCHK(hipMemsetAsync(h->cell_end, 0, ncell * sizeof(int), h->stream));
-    launch_permute(pos, vec, group, h->perm, h->keys_s, N, h->dbox, h->pos_s, h->f_s, h->tag_s, h->cell_start,
-                   h->cell_end, h->stream);
+    launch_permute(pos, vec, group, h->perm, h->keys_s, N, h->dbox, h->pos_s, h->f_s, h->tag_s, (int)ncell,
+                   h->cell_off, h->stream);
     h->sorted_N = N;
+    h->nb_valid = false;
     TRY(te(h, PH_SORT));
     HIPCHK(hipGetLastError());
     return 0;
@@ -350,8 +368,8 @@ static int wave(pse_handle *h, int N, bool noise, double kT, double dt, unsigned
     double *gx = h->rgrid, *gy = h->rgrid + nr, *gz = h->rgrid + 2 * nr;
     double2 *cx = h->cgrid, *cy = h->cgrid + ncx, *cz = h->cgrid + 2 * ncx;
     TRY(ts(h, PH_SPREAD));
-    HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->stream));
-    launch_spread(h->pos_s, h->f_s, N, gx, gy, gz, G, h->dbox, h->stream);
+    if (spread_needs_zero(G)) HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->stream));
+    launch_spread(h->pos_s, h->f_s, h->sup_s, N, h->cell_off, h->nc, gx, gy, gz, G, h->dbox, h->stream);
     TRY(te(h, PH_SPREAD));
     TRY(ts(h, PH_FFTF));
     { void *in[1] = {h->rgrid}, *out[1] = {h->cgrid}; FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd)); }
@@ -373,9 +391,16 @@ static int wave(pse_handle *h, int N, bool noise, double kT, double dt, unsigned
     return 0;
 }
 
-static int real(pse_handle *h, const double4 *vec_s, double4 *out_s, int N) {
-    launch_mreal(h->pos_s, vec_s, out_s, N, h->cell_start, h->cell_end, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef,
+// near-field mat-vec; build_list: also record the pair list so later mat-vecs of this step can reuse it
+static int real(pse_handle *h, const double4 *vec_s, double4 *out_s, int N, bool build_list) {
+    int mode = MREAL_CELLS;
+    if (h->nb.cap > 0) {
+        if (h->nb_valid) mode = MREAL_USE_LIST;
+        else if (build_list) mode = MREAL_BUILD_LIST;
+    }
+    launch_mreal(h->pos_s, vec_s, out_s, N, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, h->nb, mode,
                  h->stream);
+    if (mode == MREAL_BUILD_LIST) h->nb_valid = true;
     return 0;
 }
 
@@ -395,7 +420,7 @@ static int lanczos(pse_handle *h, const double4 *psi_s, double4 *out_s, int N, d
     while (true) {
         for (; done < target; ++done) {
             double4 *Vj = h->V + (size_t)done * stride;
-            TRY(real(h, Vj, h->w_s, N));
+            TRY(real(h, Vj, h->w_s, N, true));
             launch_lz_iter(h->w_s, Vj, done > 0 ? h->V + (size_t)(done - 1) * stride : nullptr,
                            h->V + (size_t)(done + 1) * stride, done, h->scal, h->partials, N, h->stream);
         }
@@ -451,7 +476,7 @@ static int velocity(pse_handle *h, const double4 *pos, const double4 *force, dou
     }
     if (parts & 1) {
         TRY(ts(h, PH_REAL));
-        TRY(real(h, h->f_s, h->ur_s, N));
+        TRY(real(h, h->f_s, h->ur_s, N, noise));
         TRY(te(h, PH_REAL));
         *mask |= 1u << PH_REAL;
     }

@@ -16,18 +16,29 @@ void sort_pairs(void *temp, size_t temp_bytes, const unsigned *keys_in, unsigned
 // pos_s[i] = wrapped position of particle perm[i] (w = tag as double), vec_s[i] = vec[tag].xyz; cell bounds
 void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm,
                     const unsigned *keys_sorted, int N, DBox box, double4 *pos_s, double4 *vec_s, unsigned *tag_s,
-                    int *cell_start, int *cell_end, hipStream_t s);
+                    int ncell, int *cell_off, hipStream_t s);
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s);
 
 // ---- near field (K9) -------------------------------------------------------------------------------------
-// out = M_real . vec (+ self), optional fused Lanczos epilogue: out -= beta_prev * vprev; partial[block] = sum vec.out
-void launch_mreal(const double4 *pos_s, const double4 *vec_s, double4 *out_s, int N, const int *cell_start,
-                  const int *cell_end, DBox box, DCells nc, double rcut, double self, const double *coef,
-                  hipStream_t s);
+// per-step pair list in ELL layout (slot-major): entry (slot, i) at slot*stride + i
+struct NbList {
+    unsigned *j;
+    double2 *fh;          // f, (g - f)/r^2
+    double *dx, *dy, *dz; // minimum-image separation r_i - r_j
+    int *cnt;             // true neighbour count per particle (may exceed cap: that particle falls back to the cells)
+    int cap;
+    size_t stride;
+};
+enum { MREAL_CELLS = 0, MREAL_BUILD_LIST = 1, MREAL_USE_LIST = 2 };
+// out = M_real . vec (+ self). mode: cells only / cells + write the pair list / use the pair list
+void launch_mreal(const double4 *pos_s, const double4 *vec_s, double4 *out_s, int N, const int *cell_off, DBox box,
+                  DCells nc, double rcut, double self, const double *coef, NbList nb, int mode, hipStream_t s);
 
 // ---- far field (K2-K8) -----------------------------------------------------------------------------------
-void launch_spread(const double4 *pos_s, const double4 *f_s, int N, double *gx, double *gy, double *gz, DGrid G,
-                   DBox box, hipStream_t s);
+// returns true if the caller must zero the grids first (atomic fallback for grids smaller than a tile + support)
+bool spread_needs_zero(const DGrid &G);
+void launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, const int *cell_off, DCells nc,
+                   double *gx, double *gy, double *gz, DGrid G, DBox box, hipStream_t s);
 struct ScaleArgs {
     double xi, eta;
     int noise;               // add k-space Brownian noise (K6)

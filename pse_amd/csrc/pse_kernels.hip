@@ -51,8 +51,7 @@ __global__ void k_cell_keys(const double4 *__restrict__ pos, const unsigned *__r
 __global__ void k_permute(const double4 *__restrict__ pos, const double4 *__restrict__ vec,
                           const unsigned *__restrict__ group, const unsigned *__restrict__ perm,
                           const unsigned *__restrict__ keys_sorted, int N, DBox box, double4 *__restrict__ pos_s,
-                          double4 *__restrict__ vec_s, unsigned *__restrict__ tag_s, int *__restrict__ cell_start,
-                          int *__restrict__ cell_end) {
+                          double4 *__restrict__ vec_s, unsigned *__restrict__ tag_s) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N) return;
     const unsigned g = perm[s];
@@ -74,9 +73,19 @@ __global__ void k_permute(const double4 *__restrict__ pos, const double4 *__rest
         v.w = 0.0;
         vec_s[s] = v;
     }
-    const unsigned key = keys_sorted[s];
-    if (s == 0 || keys_sorted[s - 1] != key) cell_start[key] = s;
-    if (s == N - 1 || keys_sorted[s + 1] != key) cell_end[key] = s + 1;
+}
+
+// cell_off[c] = first sorted slot whose key >= c (c = 0..ncell): cell c owns [cell_off[c], cell_off[c+1]), and any run of
+// consecutive cells is one contiguous slot range
+__global__ void k_cell_offsets(const unsigned *__restrict__ keys_sorted, int N, int ncell, int *__restrict__ cell_off) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > ncell) return;
+    int lo = 0, hi = N;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys_sorted[mid] < (unsigned)c) lo = mid + 1; else hi = mid;
+    }
+    cell_off[c] = lo;
 }
 
 __global__ void k_permute_vec(const double4 *__restrict__ vec, const unsigned *__restrict__ tag_s, int N,
@@ -104,9 +113,10 @@ void sort_pairs(void *temp, size_t temp_bytes, const unsigned *keys_in, unsigned
 }
 void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm,
                     const unsigned *keys_sorted, int N, DBox box, double4 *pos_s, double4 *vec_s, unsigned *tag_s,
-                    int *cell_start, int *cell_end, hipStream_t s) {
+                    int ncell, int *cell_off, hipStream_t s) {
     hipLaunchKernelGGL(k_permute, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, vec, group, perm, keys_sorted, N, box,
-                       pos_s, vec_s, tag_s, cell_start, cell_end);
+                       pos_s, vec_s, tag_s);
+    hipLaunchKernelGGL(k_cell_offsets, dim3(nblocks(ncell + 1, TPB)), dim3(TPB), 0, s, keys_sorted, N, ncell, cell_off);
 }
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s) {
     hipLaunchKernelGGL(k_permute_vec, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, vec, tag_s, N, vec_s);
@@ -114,12 +124,71 @@ void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double
 
 // ------------------------------------------------------------------------------------------------ near field
 // K9 gpu_stokes_Mreal_kernel (PSEv1/Mobility.cu:594-687): u_i = self F_i + sum_j [f (I - rr) + g rr] F_j over
-// minimum-image neighbours with r < rcut; here the neighbours come from the build's own cell list.
+// minimum-image neighbours with r < rcut.  The neighbours come from the build's own cell list (HOOMD's
+// NeighborListGPUBinned is not available, PSEv1/integrate.py:58-83).
+//
+// Two phases per thread so the wave does not diverge on the ~15 % of candidates that pass the cutoff: (1) scan the
+// 27 neighbour cells (z-runs merged) and push the slots that pass r < rcut into a per-thread LDS queue -- cheap, no
+// transcendental work; (2) drain the queue densely: every lane evaluates f, g for a real neighbour.  With LIST the
+// drained pairs (j, f, (g-f)/r^2, r) are also written to a per-step ELL pair list that the Lanczos mat-vecs reuse
+// (positions do not change inside a step, PSEv1/Brownian.cu:473-521 recomputes them every iteration).
+constexpr int QCAP = 48;
+constexpr unsigned JMASK = (1u << 27) - 1;
+
+// Workgroups b and b + 8 share an XCD (round-robin dispatch, /opt/skills/guides/MI355X_MICROARCH.md): hand each XCD a
+// contiguous range of logical blocks, so the neighbour data a block gathers is what the other blocks of its XCD
+// gather too and stays in that XCD's 4 MiB L2.  Bijective for any block count; placement affects speed only.
+__device__ __forceinline__ int xcd_block(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, x = b & 7, k = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+__device__ __forceinline__ void image_shift(unsigned code, const DBox &b, double &sx, double &sy, double &sz) {
+    const int wx = (int)(code / 9) - 1, wy = (int)((code / 3) % 3) - 1, wz = (int)(code % 3) - 1;
+    sx = wx * b.Lx + wy * b.xy * b.Ly;
+    sy = wy * b.Ly;
+    sz = wz * b.Lz;
+}
+
+struct CellWalk {   // the neighbour cells of one particle as (slot range, image code) runs
+    int cx, cy, cz, rx, ry, rz;
+};
+
+template <class F>
+__device__ __forceinline__ void for_each_run(const DCells &nc, const int *__restrict__ cell_off, int cx, int cy, int cz,
+                                             F &&body) {
+    const int rx = nc.nx > 1 ? 1 : 0, ry = nc.ny > 1 ? 1 : 0;
+    for (int ox = -rx; ox <= rx; ++ox) {
+        int ax = cx + ox, wx = 0;
+        if (ax < 0) { ax += nc.nx; wx = -1; } else if (ax >= nc.nx) { ax -= nc.nx; wx = 1; }
+        for (int oy = -ry; oy <= ry; ++oy) {
+            int ay = cy + oy, wy = 0;
+            if (ay < 0) { ay += nc.ny; wy = -1; } else if (ay >= nc.ny) { ay -= nc.ny; wy = 1; }
+            const int base = (ax * nc.ny + ay) * nc.nz;
+            const unsigned cxy = (unsigned)((wx + 1) * 9 + (wy + 1) * 3);
+            if (nc.nz == 1) {
+                body(cell_off[base], cell_off[base + 1], cxy + 1u);
+            } else if (cz >= 1 && cz + 1 < nc.nz) {
+                body(cell_off[base + cz - 1], cell_off[base + cz + 2], cxy + 1u);   // three z cells, one run
+            } else {
+                for (int oz = -1; oz <= 1; ++oz) {
+                    int az = cz + oz, wz = 0;
+                    if (az < 0) { az += nc.nz; wz = -1; } else if (az >= nc.nz) { az -= nc.nz; wz = 1; }
+                    body(cell_off[base + az], cell_off[base + az + 1], cxy + (unsigned)(wz + 1));
+                }
+            }
+        }
+    }
+}
+
+template <bool LIST>
 __global__ void __launch_bounds__(TPB)
-k_mreal(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int N,
-        const int *__restrict__ cell_start, const int *__restrict__ cell_end, DBox box, DCells nc, double rcut2,
-        double self, const double *__restrict__ coef) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+k_mreal_cells(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int N,
+              const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2, double self,
+              const double *__restrict__ coef, NbList nb) {
+    __shared__ unsigned queue[QCAP * TPB];
+    const int tid = threadIdx.x;
+    const int i = xcd_block(blockIdx.x, gridDim.x) * TPB + tid;
     if (i >= N) return;
     const double4 pi = pos_s[i];
     const double4 vi = vec_s[i];
@@ -127,41 +196,126 @@ k_mreal(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, do
     double fx, fy, fz;
     frac_coords(box, pi.x, pi.y, pi.z, fx, fy, fz);
     const int cx = cell_coord(fx, nc.nx), cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz);
-    const int rx = nc.nx > 1 ? 1 : 0, ry = nc.ny > 1 ? 1 : 0, rz = nc.nz > 1 ? 1 : 0;
-    for (int ox = -rx; ox <= rx; ++ox) {
-        int ax = cx + ox; ax = ax < 0 ? ax + nc.nx : (ax >= nc.nx ? ax - nc.nx : ax);
-        for (int oy = -ry; oy <= ry; ++oy) {
-            int ay = cy + oy; ay = ay < 0 ? ay + nc.ny : (ay >= nc.ny ? ay - nc.ny : ay);
-            for (int oz = -rz; oz <= rz; ++oz) {
-                int az = cz + oz; az = az < 0 ? az + nc.nz : (az >= nc.nz ? az - nc.nz : az);
-                const int c = (ax * nc.ny + ay) * nc.nz + az;
-                const int jb = cell_start[c], je = cell_end[c];
-                for (int j = jb; j < je; ++j) {
-                    const double4 pj = pos_s[j];
-                    double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-                    min_image(box, dx, dy, dz);
-                    const double r2 = dx * dx + dy * dy + dz * dz;
-                    if (r2 < rcut2 && j != i && r2 > 0.0) {
-                        const double4 Fj = vec_s[j];
-                        double f, h;
-                        eval_fg(r2, coef, f, h);
-                        const double rdF = (dx * Fj.x + dy * Fj.y + dz * Fj.z) * h;
-                        ux += f * Fj.x + rdF * dx;
-                        uy += f * Fj.y + rdF * dy;
-                        uz += f * Fj.z + rdF * dz;
-                    }
+    const bool shift_only = nc.nx > 1 && nc.ny > 1 && nc.nz > 1;   // otherwise finish with the rint minimum image
+    int qn = 0, total = 0;
+
+    auto drain = [&]() {
+        for (int q = 0; q < qn; ++q) {
+            const unsigned e = queue[q * TPB + tid];
+            const int j = (int)(e & JMASK);
+            double sx, sy, sz;
+            image_shift(e >> 27, box, sx, sy, sz);
+            const double4 pj = pos_s[j];
+            double dx = pi.x - pj.x - sx, dy = pi.y - pj.y - sy, dz = pi.z - pj.z - sz;
+            if (!shift_only) min_image(box, dx, dy, dz);
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            double f, h;
+            eval_fg(r2, coef, f, h);
+            const double4 Fj = vec_s[j];
+            const double rdF = (dx * Fj.x + dy * Fj.y + dz * Fj.z) * h;
+            ux += f * Fj.x + rdF * dx;
+            uy += f * Fj.y + rdF * dy;
+            uz += f * Fj.z + rdF * dz;
+            if (LIST) {
+                if (total < nb.cap) {
+                    const size_t o = (size_t)total * nb.stride + i;
+                    nb.j[o] = (unsigned)j;
+                    nb.fh[o] = make_double2(f, h);
+                    nb.dx[o] = dx; nb.dy[o] = dy; nb.dz[o] = dz;
                 }
+                ++total;
             }
         }
+        qn = 0;
+    };
+
+    for_each_run(nc, cell_off, cx, cy, cz, [&](int jb, int je, unsigned code) {
+        double sx, sy, sz;
+        image_shift(code, box, sx, sy, sz);
+        const double qx = pi.x - sx, qy = pi.y - sy, qz = pi.z - sz;
+        for (int j0 = jb; j0 < je; j0 += 4) {
+            double4 pj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pj[u] = pos_s[min(j0 + u, je - 1)];   // four independent loads in flight
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u;
+                double dx = qx - pj[u].x, dy = qy - pj[u].y, dz = qz - pj[u].z;
+                if (!shift_only) min_image(box, dx, dy, dz);
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                if (j < je && r2 < rcut2 && j != i && r2 > 0.0) {
+                    queue[qn * TPB + tid] = (unsigned)j | (code << 27);
+                    ++qn;
+                }
+            }
+            // drain together: a lane-private "queue full" branch would serialise the wave once per lane
+            if (__any(qn > QCAP - 4)) drain();
+        }
+    });
+    drain();
+    out_s[i] = make_double4(ux, uy, uz, 0.0);
+    if (LIST) nb.cnt[i] = total;
+}
+
+// mat-vec from the pair list (one thread per particle, ELL layout: slot-major so a wave reads contiguous rows).
+// A particle whose neighbour count overflowed the list capacity recomputes from the cells.
+__global__ void __launch_bounds__(TPB)
+k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int N,
+             const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2, double self,
+             const double *__restrict__ coef, NbList nb) {
+    const int i = xcd_block(blockIdx.x, gridDim.x) * TPB + threadIdx.x;
+    if (i >= N) return;
+    const double4 vi = vec_s[i];
+    double ux = self * vi.x, uy = self * vi.y, uz = self * vi.z;
+    const int cnt = nb.cnt[i];
+    if (cnt <= nb.cap) {
+#pragma unroll 4
+        for (int s = 0; s < cnt; ++s) {
+            const size_t o = (size_t)s * nb.stride + i;
+            const unsigned j = nb.j[o];
+            const double2 fh = nb.fh[o];
+            const double dx = nb.dx[o], dy = nb.dy[o], dz = nb.dz[o];
+            const double4 Fj = vec_s[j];
+            const double rdF = (dx * Fj.x + dy * Fj.y + dz * Fj.z) * fh.y;
+            ux += fh.x * Fj.x + rdF * dx;
+            uy += fh.x * Fj.y + rdF * dy;
+            uz += fh.x * Fj.z + rdF * dz;
+        }
+    } else {
+        const double4 pi = pos_s[i];
+        double fx, fy, fz;
+        frac_coords(box, pi.x, pi.y, pi.z, fx, fy, fz);
+        const int cx = cell_coord(fx, nc.nx), cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz);
+        for_each_run(nc, cell_off, cx, cy, cz, [&](int jb, int je, unsigned) {
+            for (int j = jb; j < je; ++j) {
+                const double4 pj = pos_s[j];
+                double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                min_image(box, dx, dy, dz);
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                if (r2 < rcut2 && j != i && r2 > 0.0) {
+                    double f, h;
+                    eval_fg(r2, coef, f, h);
+                    const double4 Fj = vec_s[j];
+                    const double rdF = (dx * Fj.x + dy * Fj.y + dz * Fj.z) * h;
+                    ux += f * Fj.x + rdF * dx;
+                    uy += f * Fj.y + rdF * dy;
+                    uz += f * Fj.z + rdF * dz;
+                }
+            }
+        });
     }
     out_s[i] = make_double4(ux, uy, uz, 0.0);
 }
 
-void launch_mreal(const double4 *pos_s, const double4 *vec_s, double4 *out_s, int N, const int *cell_start,
-                  const int *cell_end, DBox box, DCells nc, double rcut, double self, const double *coef,
-                  hipStream_t s) {
-    hipLaunchKernelGGL(k_mreal, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos_s, vec_s, out_s, N, cell_start, cell_end,
-                       box, nc, rcut * rcut, self, coef);
+void launch_mreal(const double4 *pos_s, const double4 *vec_s, double4 *out_s, int N, const int *cell_off, DBox box,
+                  DCells nc, double rcut, double self, const double *coef, NbList nb, int mode, hipStream_t s) {
+    const dim3 g(nblocks(N, TPB)), b(TPB);
+    if (mode == MREAL_BUILD_LIST)
+        hipLaunchKernelGGL(k_mreal_cells<true>, g, b, 0, s, pos_s, vec_s, out_s, N, cell_off, box, nc, rcut * rcut, self, coef, nb);
+    else if (mode == MREAL_USE_LIST)
+        hipLaunchKernelGGL(k_mreal_list, g, b, 0, s, pos_s, vec_s, out_s, N, cell_off, box, nc, rcut * rcut, self, coef, nb);
+    else
+        hipLaunchKernelGGL(k_mreal_cells<false>, g, b, 0, s, pos_s, vec_s, out_s, N, cell_off, box, nc, rcut * rcut, self, coef, nb);
 }
 
 __global__ void k_eval_fg(const double *__restrict__ r, int n, const double *__restrict__ coef, double *f, double *g) {
@@ -223,13 +377,259 @@ k_spread_atomic(const double4 *__restrict__ pos_s, const double4 *__restrict__ f
     }
 }
 
-void launch_spread(const double4 *pos_s, const double4 *f_s, int N, double *gx, double *gy, double *gz, DGrid G,
-                   DBox box, hipStream_t s) {
-    hipLaunchKernelGGL(k_spread_atomic, dim3(nblocks(N, TPB / 64)), dim3(TPB), 0, s, pos_s, f_s, N, gx, gy, gz, G, box);
+// ---- separable Gaussian weights held across the lanes of a wave ------------------------------------------------
+// w(tx,ty,tz) = A[tx][ty] B[tz] with A = exp(-c (ex^2 + ey^2)) (x and y couple through the shear,
+// PSEv1/Mobility.cu:230) and B = exp(-c ez^2): P^2 + P exponentials per particle instead of P^3, evaluated one per
+// lane and fetched by the lanes that need them with ds_bpermute (__shfl).  Entry e lives in register e / 64, lane e % 64.
+template <int P>
+struct WaveWeights {
+    double r0, r1;
+    __device__ __forceinline__ void stage(int lane, const DGrid &G, const DBox &box, double d0x, double d0y, double d0z) {
+        r0 = entry(lane, G, box, d0x, d0y, d0z);
+        r1 = (P * P + P > 64) ? entry(lane + 64, G, box, d0x, d0y, d0z) : 0.0;
+    }
+    __device__ __forceinline__ static double entry(int e, const DGrid &G, const DBox &box, double d0x, double d0y, double d0z) {
+        if (e < P * P) {
+            const int tx = e / P, ty = e - tx * P;
+            const double ey = G.hy * (d0y + ty), ex = G.hx * (d0x + tx) + box.xy * ey;
+            return exp(-G.expfac * (ex * ex + ey * ey));
+        }
+        if (e < P * P + P) {
+            const double ez = G.hz * (d0z + (e - P * P));
+            return exp(-G.expfac * ez * ez);
+        }
+        return 0.0;
+    }
+    __device__ __forceinline__ double get(int tx, int ty, int tz) const {
+        const double a = __shfl(r0, tx * P + ty, 64);          // P <= 8: every A entry is in r0
+        const int eb = P * P + tz;
+        const double b = (P * P + P > 64) ? (eb < 64 ? __shfl(r0, eb, 64) : __shfl(r1, eb - 64, 64)) : __shfl(r0, eb, 64);
+        return a * b;
+    }
+};
+
+// Tile-owned spread: one workgroup owns a TXxTYxTZ block of grid nodes, accumulates every contribution to it in LDS
+// (ds_add_f64) and writes each node exactly once with plain stores -- no global atomics (1.3 TB/s chip-wide on MI355X:
+// the 7.6 ms of the v0 kernel), no ZeroGrid pass (K2).  Contributing particles are found through the near-field cell
+// list (cells and grid share the same fractional coordinates, so this also holds in a sheared box); their support
+// origins were precomputed by k_support.  One wave per (particle, tile) pair, lanes over the clipped support box.
+__device__ __forceinline__ int floordiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+__global__ void k_support(const double4 *__restrict__ pos_s, int N, DGrid G, DBox box, int4 *__restrict__ sup_s) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const double4 p = pos_s[s];
+    double fx, fy, fz, d;
+    frac_coords(box, p.x, p.y, p.z, fx, fy, fz);
+    int4 o;
+    support_start(fx, G.Nx, G.P, o.x, d);
+    support_start(fy, G.Ny, G.P, o.y, d);
+    support_start(fz, G.Nz, G.P, o.z, d);
+    o.w = 0;
+    sup_s[s] = o;
+}
+
+template <int P, int TX, int TY, int TZ, int NT>
+__global__ void __launch_bounds__(NT)
+k_spread_tile(const double4 *__restrict__ pos_s, const double4 *__restrict__ f_s, const int4 *__restrict__ sup_s,
+              const int *__restrict__ cell_off, DCells nc, double *__restrict__ gx, double *__restrict__ gy,
+              double *__restrict__ gz, DGrid G, DBox box, int ntx, int nty, int ntz) {
+    constexpr int NODES = TX * TY * TZ, NW = NT / 64;
+    __shared__ double acc[3 * NODES];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int b = xcd_block(blockIdx.x, gridDim.x);
+    const int tz = b % ntz; b /= ntz;
+    const int ty = b % nty; b /= nty;
+    const int tx = b;
+    const int t0[3] = {G.x0 + tx * TX, ty * TY, tz * TZ};
+    const int ext[3] = {min(TX, G.x0 + G.nxl - t0[0]), min(TY, G.Ny - t0[1]), min(TZ, G.Nz - t0[2])};
+    const int Nn[3] = {G.Nx, G.Ny, G.Nz};
+    const int ncd[3] = {nc.nx, nc.ny, nc.nz};
+    for (int n = tid; n < 3 * NODES; n += NT) acc[n] = 0.0;
+    __syncthreads();
+
+    // cells that can hold a contributing particle: floor(s) in [t0 - ceil(P/2), t0 + ext - 1 + P/2]  (node units)
+    int clo[3], ccnt[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int lo = t0[a] - (P + 1) / 2, hi = t0[a] + ext[a] - 1 + P / 2;
+        const int c0 = floordiv(lo * ncd[a], Nn[a]);
+        const int c1 = floordiv((hi + 1) * ncd[a], Nn[a]);
+        clo[a] = c0;
+        ccnt[a] = min(c1 - c0 + 1, ncd[a]);
+    }
+    const double prefac = G.prefac;
+    int z0 = clo[2] % nc.nz; if (z0 < 0) z0 += nc.nz;
+    const int zfirst = min(ccnt[2], nc.nz - z0);
+    for (int ixy = 0; ixy < ccnt[0] * ccnt[1]; ++ixy) {
+        const int ix = ixy / ccnt[1], iy = ixy - ix * ccnt[1];
+        int cx = (clo[0] + ix) % nc.nx; if (cx < 0) cx += nc.nx;
+        int cy = (clo[1] + iy) % nc.ny; if (cy < 0) cy += nc.ny;
+        const int base = (cx * nc.ny + cy) * nc.nz;
+        for (int seg = 0; seg < 2; ++seg) {   // the z cells are at most two contiguous slot runs
+            const int za = seg == 0 ? z0 : 0, zn = seg == 0 ? zfirst : ccnt[2] - zfirst;
+            if (zn <= 0) continue;
+            const int jb = cell_off[base + za], je = cell_off[base + za + zn];
+            for (int p = jb + wave; p < je; p += NW) {
+                const int4 sp = sup_s[p];
+                const int st[3] = {sp.x, sp.y, sp.z};
+                int a0[3], lo[3], hi[3];
+                bool hit = true;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    int rel = st[a] - t0[a];                       // support origin relative to the tile, nearest image
+                    if (rel < -Nn[a] / 2) rel += Nn[a]; else if (rel >= Nn[a] - Nn[a] / 2) rel -= Nn[a];
+                    a0[a] = rel;
+                    lo[a] = max(rel, 0);
+                    hi[a] = min(rel + P, ext[a]);
+                    hit = hit && lo[a] < hi[a];
+                }
+                if (!hit) continue;
+                const double4 pp = pos_s[p];
+                const double4 F = f_s[p];
+                double f[3];
+                frac_coords(box, pp.x, pp.y, pp.z, f[0], f[1], f[2]);
+                // offset of the support origin from the particle in grid units (same arithmetic as support_start)
+                const double d0x = st[0] - f[0] * G.Nx, d0y = st[1] - f[1] * G.Ny, d0z = st[2] - f[2] * G.Nz;
+                WaveWeights<P> W;
+                W.stage(lane, G, box, d0x, d0y, d0z);
+                const int by = hi[1] - lo[1], bz = hi[2] - lo[2], byz = by * bz;
+                const int cnt = (hi[0] - lo[0]) * byz;
+                const float ibyz = 1.0f / (float)byz, ibz = 1.0f / (float)bz;
+                const double Fx = prefac * F.x, Fy = prefac * F.y, Fz = prefac * F.z;
+                for (int n0 = 0; n0 < cnt; n0 += 64) {
+                    const int n = n0 + lane;
+                    const bool on = n < cnt;
+                    const int m = on ? n : 0;
+                    const int qx = (int)(((float)m + 0.5f) * ibyz), r = m - qx * byz;
+                    const int qy = (int)(((float)r + 0.5f) * ibz), qz = r - qy * bz;
+                    const int lx = lo[0] + qx, ly = lo[1] + qy, lz = lo[2] + qz;
+                    const double w = W.get(lx - a0[0], ly - a0[1], lz - a0[2]);   // all lanes take part in the shuffles
+                    if (on) {
+                        const int o = (lx * TY + ly) * TZ + lz;
+                        atomicAdd(&acc[o], w * Fx);
+                        atomicAdd(&acc[NODES + o], w * Fy);
+                        atomicAdd(&acc[2 * NODES + o], w * Fz);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int eyz = ext[1] * ext[2], nout = ext[0] * eyz;
+    for (int n = tid; n < nout; n += NT) {
+        const int qx = n / eyz, r = n - qx * eyz, qy = r / ext[2], qz = r - qy * ext[2];
+        const size_t idx = ((size_t)(t0[0] - G.x0 + qx) * G.Ny + (t0[1] + qy)) * G.Nz + (t0[2] + qz);
+        const int o = (qx * TY + qy) * TZ + qz;
+        gx[idx] = acc[o];
+        gy[idx] = acc[NODES + o];
+        gz[idx] = acc[2 * NODES + o];
+    }
+}
+
+static int spread_tile_variant() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PSE_SPREAD_TILE"); v = e ? atoi(e) : 1; }
+    return v;
+}
+static void tile_dims(int &tx, int &ty, int &tz) {
+    switch (spread_tile_variant()) {
+        case 0: tx = 8; ty = 8; tz = 8; break;
+        case 2: tx = 16; ty = 16; tz = 16; break;
+        default: tx = 16; ty = 8; tz = 8; break;
+    }
+}
+
+bool spread_needs_zero(const DGrid &G) {
+    // the tile kernel resolves a support to its nearest image of the tile (needs N >= 2 max(tile, support) per axis)
+    // and keeps its weights in one or two registers per lane (P <= 8); anything else takes the atomic kernel
+    int tx, ty, tz;
+    tile_dims(tx, ty, tz);
+    const int tmax = std::max(tx, std::max(ty, tz));
+    const int need = 2 * std::max(tmax, G.P);
+    return G.P < 4 || G.P > 8 || G.Nx < need || G.Ny < need || G.Nz < need || G.nxl != G.Nx;
+}
+
+template <int P>
+static void launch_spread_p(const double4 *pos_s, const double4 *f_s, const int4 *sup_s, int N, const int *cell_off,
+                            DCells nc, double *gx, double *gy, double *gz, DGrid G, DBox box, hipStream_t s) {
+    int TX, TY, TZ;
+    tile_dims(TX, TY, TZ);
+    const int ntx = (G.nxl + TX - 1) / TX, nty = (G.Ny + TY - 1) / TY, ntz = (G.Nz + TZ - 1) / TZ;
+    const dim3 g(ntx * nty * ntz);
+    if (TX == 8)
+        hipLaunchKernelGGL((k_spread_tile<P, 8, 8, 8, 256>), g, dim3(256), 0, s, pos_s, f_s, sup_s, cell_off, nc, gx, gy, gz, G, box, ntx, nty, ntz);
+    else if (TY == 8)
+        hipLaunchKernelGGL((k_spread_tile<P, 16, 8, 8, 256>), g, dim3(256), 0, s, pos_s, f_s, sup_s, cell_off, nc, gx, gy, gz, G, box, ntx, nty, ntz);
+    else
+        hipLaunchKernelGGL((k_spread_tile<P, 16, 16, 16, 512>), g, dim3(512), 0, s, pos_s, f_s, sup_s, cell_off, nc, gx, gy, gz, G, box, ntx, nty, ntz);
+}
+
+void launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, const int *cell_off, DCells nc,
+                   double *gx, double *gy, double *gz, DGrid G, DBox box, hipStream_t s) {
+    if (spread_needs_zero(G)) {
+        hipLaunchKernelGGL(k_spread_atomic, dim3(nblocks(N, TPB / 64)), dim3(TPB), 0, s, pos_s, f_s, N, gx, gy, gz, G, box);
+        return;
+    }
+    hipLaunchKernelGGL(k_support, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos_s, N, G, box, sup_s);
+    switch (G.P) {
+        case 4: launch_spread_p<4>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, s); break;
+        case 5: launch_spread_p<5>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, s); break;
+        case 6: launch_spread_p<6>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, s); break;
+        case 7: launch_spread_p<7>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, s); break;
+        default: launch_spread_p<8>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, s); break;
+    }
 }
 
 // K8 gpu_stokes_Contract_kernel (PSEv1/Mobility.cu:325-477): u_p = h^3 sum_nodes prefac exp(-expfac r^2) u_grid.
-// One wave per particle, lanes stride the P^3 support, wave-64 butterfly reduction.
+// One wave per particle; separable weights staged across the lanes (P^2 + P exponentials, not P^3); lanes stride the
+// P^3 support with compile-time index arithmetic; wave-64 butterfly reduction instead of the reference's shared-memory
+// tree over B^3 threads (PSEv1/Mobility.cu:456-470).
+template <int P>
+__global__ void __launch_bounds__(TPB)
+k_gather_p(const double4 *__restrict__ pos_s, int N, const double *__restrict__ gx, const double *__restrict__ gy,
+           const double *__restrict__ gz, DGrid G, DBox box, double4 *__restrict__ u_s) {
+    const int p = xcd_block(blockIdx.x, gridDim.x) * (TPB / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (p >= N) return;
+    const double4 pp = pos_s[p];
+    double fx, fy, fz;
+    frac_coords(box, pp.x, pp.y, pp.z, fx, fy, fz);
+    int sx, sy, sz;
+    double d0x, d0y, d0z;
+    support_start(fx, G.Nx, P, sx, d0x);
+    support_start(fy, G.Ny, P, sy, d0y);
+    support_start(fz, G.Nz, P, sz, d0z);
+    WaveWeights<P> W;
+    W.stage(lane, G, box, d0x, d0y, d0z);
+    constexpr int P2 = P * P, P3 = P2 * P;
+    double ux = 0, uy = 0, uz = 0;
+#pragma unroll
+    for (int n0 = 0; n0 < P3; n0 += 64) {
+        const int n = n0 + lane;
+        const bool on = n < P3;
+        const int m = on ? n : 0;
+        const int tx = m / P2, ty = (m - tx * P2) / P, tz = m - tx * P2 - ty * P;
+        const double w = W.get(tx, ty, tz);
+        int ix = sx + tx; ix = ix < 0 ? ix + G.Nx : (ix >= G.Nx ? ix - G.Nx : ix);
+        int iy = sy + ty; iy = iy < 0 ? iy + G.Ny : (iy >= G.Ny ? iy - G.Ny : iy);
+        int iz = sz + tz; iz = iz < 0 ? iz + G.Nz : (iz >= G.Nz ? iz - G.Nz : iz);
+        const int lx = ix - G.x0;
+        if (on && lx >= 0 && lx < G.nxl) {
+            const size_t idx = ((size_t)lx * G.Ny + iy) * G.Nz + iz;
+            ux += w * gx[idx];
+            uy += w * gy[idx];
+            uz += w * gz[idx];
+        }
+    }
+    ux = wave_sum(ux); uy = wave_sum(uy); uz = wave_sum(uz);
+    if (lane == 0) {
+        const double c = G.prefac * G.hx * G.hy * G.hz;   // PSEv1/Brownian.cu:872
+        u_s[p] = make_double4(c * ux, c * uy, c * uz, 0.0);
+    }
+}
+
+// generic support size: one exponential per node
 __global__ void __launch_bounds__(TPB)
 k_gather(const double4 *__restrict__ pos_s, int N, const double *__restrict__ gx, const double *__restrict__ gy,
          const double *__restrict__ gz, DGrid G, DBox box, double4 *__restrict__ u_s) {
@@ -271,7 +671,15 @@ k_gather(const double4 *__restrict__ pos_s, int N, const double *__restrict__ gx
 
 void launch_gather(const double4 *pos_s, int N, const double *gx, const double *gy, const double *gz, DGrid G,
                    DBox box, double4 *u_s, hipStream_t s) {
-    hipLaunchKernelGGL(k_gather, dim3(nblocks(N, TPB / 64)), dim3(TPB), 0, s, pos_s, N, gx, gy, gz, G, box, u_s);
+    const dim3 g(nblocks(N, TPB / 64)), b(TPB);
+    switch (G.P) {
+        case 4: hipLaunchKernelGGL(k_gather_p<4>, g, b, 0, s, pos_s, N, gx, gy, gz, G, box, u_s); break;
+        case 5: hipLaunchKernelGGL(k_gather_p<5>, g, b, 0, s, pos_s, N, gx, gy, gz, G, box, u_s); break;
+        case 6: hipLaunchKernelGGL(k_gather_p<6>, g, b, 0, s, pos_s, N, gx, gy, gz, G, box, u_s); break;
+        case 7: hipLaunchKernelGGL(k_gather_p<7>, g, b, 0, s, pos_s, N, gx, gy, gz, G, box, u_s); break;
+        case 8: hipLaunchKernelGGL(k_gather_p<8>, g, b, 0, s, pos_s, N, gx, gy, gz, G, box, u_s); break;
+        default: hipLaunchKernelGGL(k_gather, g, b, 0, s, pos_s, N, gx, gy, gz, G, box, u_s); break;
+    }
 }
 
 // K1+K5+K6 fused: gpu_stokes_SetGridk_kernel (PSEv1/Helper.cu:285-332), gpu_stokes_Green_kernel

@@ -123,6 +123,30 @@ int pse_eval_realspace(pse_handle *h, const double *r_host, int n, double *f_hos
  * most recent spread (stage 0) or inverse FFT (stage 1) to a host buffer of 3*nx_local*Ny*Nz doubles */
 int pse_debug_copy_grid(pse_handle *h, int stage, double *host_out);
 
+/* -- multi-GPU: slab-decomposed far field + row-sharded near field (new design; the reference is single-GPU,
+ *    PSEv1/Stokes.cc:104) ---------------------------------------------------------------------------------------
+ * Each rank is a handle created with pse_params.n_slabs = G and its own slab_rank.  The far-field grid is cut into
+ * G slabs of x planes (the slowest index of the reference layout, PSEv1/Mobility.cu:233): spread and the 2-D (y,z)
+ * transforms are slab-local, an all-to-all transposes to y-slabs for the 1-D x transforms and the k-space scaling,
+ * and back; the gather takes P-1 halo planes from the next slab.  Near-field rows and Lanczos mat-vec rows are split
+ * evenly over the ranks and all-gathered.  Particle arrays are replicated: every rank passes the same pos/force and
+ * ends the call with the same vel/pos.
+ * A team binds the local ranks to a transport: one member per process + the RCCL unique id of rank 0 (production, one
+ * process per GPU), or all G members in one process with id = NULL (in-process loopback on one device, for tests). */
+typedef struct pse_team pse_team;
+int pse_team_unique_id(void *id128_host);   /* host buffer of 128 bytes, call on rank 0 and distribute */
+int pse_team_create(pse_handle **members, int n_members, const void *id128_host, pse_team **out);
+int pse_team_destroy(pse_team *team);
+/* the three hot-path entry points for a team; pointer arrays have one entry per local member, in members order */
+int pse_team_mobility(pse_team *team, const pse_double4 *const *pos, const pse_double4 *const *force,
+                      pse_double4 *const *vel, const unsigned int *group_members, unsigned int N, int parts);
+int pse_team_brownian_velocity(pse_team *team, const pse_double4 *const *pos, const pse_double4 *const *force,
+                               pse_double4 *const *vel, const unsigned int *group_members, unsigned int N,
+                               double kT, double dt, unsigned int timestep, int *lanczos_m);
+int pse_team_step(pse_team *team, pse_double4 *const *pos, pse_double4 *const *vel, pse_double3 *const *accel,
+                  pse_int3 *const *image, const pse_double4 *const *net_force, const unsigned int *group_members,
+                  unsigned int N, double kT, double dt, unsigned int timestep, double shear_rate, int *lanczos_m);
+
 /* host-only: t = T^{1/2} e_1 of the Lanczos tridiagonal (alpha[0..m), beta[1..m)); replaces LAPACKE_spteqr +
  * the host loops at PSEv1/Brownian.cu:540-582. Exposed so the eigen-solver can be tested without a GPU. */
 int pse_host_lanczos_sqrt_e1(int m, const double *alpha, const double *beta, double *t);

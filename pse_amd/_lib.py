@@ -65,6 +65,13 @@ SYMBOLS = {
     "pse_random_psi": (_i, [_vp, _vp, _vp, _u, _u]),
     "pse_eval_realspace": (_i, [_vp, _dp, _i, _dp, _dp]),
     "pse_debug_copy_grid": (_i, [_vp, _i, _dp]),
+    "pse_team_unique_id": (_i, [_vp]),
+    "pse_team_create": (_i, [ctypes.POINTER(_vp), _i, _vp, ctypes.POINTER(_vp)]),
+    "pse_team_destroy": (_i, [_vp]),
+    "pse_team_mobility": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _u, _i]),
+    "pse_team_brownian_velocity": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _u, _d, _d, _u, _ip]),
+    "pse_team_step": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                           ctypes.POINTER(_vp), _vp, _u, _d, _d, _u, _d, _ip]),
     "pse_host_lanczos_sqrt_e1": (_i, [_i, _dp, _dp, _dp]),
     "pse_host_select_params": (_i, [ctypes.POINTER(pse_params), ctypes.POINTER(pse_info)]),
 }

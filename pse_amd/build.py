@@ -26,8 +26,12 @@ def _newer(target, sources):
 
 
 def _run(cmd):
-    print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0 or os.environ.get("PSE_BUILD_VERBOSE"):
+        print(" ".join(cmd), flush=True)
+        print(r.stdout, flush=True)
+    if r.returncode != 0:
+        raise RuntimeError("build step failed: " + " ".join(cmd))
 
 
 def _all_sources():
@@ -49,7 +53,7 @@ def build_lib(force=False):
         _run([HIPCC, *CXXFLAGS, *extra, "-c", os.path.join(CSRC, name), "-o", obj])
         objs.append(obj)
     _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs,
-          f"-L{ROCM}/lib", "-lrocfft", "-lpthread", f"-Wl,-rpath,{ROCM}/lib"])
+          f"-L{ROCM}/lib", "-lrocfft", "-lrccl", "-lpthread", f"-Wl,-rpath,{ROCM}/lib"])
     return LIB
 
 

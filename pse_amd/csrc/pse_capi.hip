@@ -7,6 +7,7 @@
 // device and the host is consulted only at convergence checks; wave vectors are computed inside the scaling
 // kernel; failures are returned, never exit()ed.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <rocfft/rocfft.h>
 
 #include <algorithm>
@@ -61,7 +62,7 @@ struct pse_handle {
     double cell_gamma;  // tilt bound the cell grid was sized for
     int device = 0;
     hipStream_t stream = nullptr;
-    int n_max = 0;
+    int n_max = 0, n_pad = 0;
     // sorted particle state
     unsigned *keys = nullptr, *keys_s = nullptr, *vals = nullptr, *perm = nullptr, *tag_s = nullptr;
     void *sort_tmp = nullptr;
@@ -78,8 +79,12 @@ struct pse_handle {
     // grids
     double *rgrid = nullptr;     // [3][nxl][Ny][Nz]
     double2 *cgrid = nullptr;    // [3][nxl][Ny][Nzh]
-    rocfft_plan plan_fwd = nullptr, plan_inv = nullptr;
+    rocfft_plan plan_fwd = nullptr, plan_inv = nullptr;      // single GPU: 3-D real transforms, batch 3
+    rocfft_plan plan_x_fwd = nullptr, plan_x_inv = nullptr;  // slab mode: 1-D complex transforms along x (strided, in place)
     rocfft_execution_info info_fwd = nullptr, info_inv = nullptr;
+    // slab decomposition (n_slabs > 1): x planes [x0, x0+nxl) of the real grid, y rows [y0, y0+nyl) of the transposed spectrum
+    int n_slabs = 1, slab_rank = 0, nyl = 0, y0 = 0;
+    double2 *sendbuf = nullptr, *recvbuf = nullptr;          // [3][n_slabs][nxl][nyl][Nzh] each
     void *fft_work = nullptr;
     size_t fft_work_bytes = 0;
     // Lanczos
@@ -175,17 +180,19 @@ extern "C" int pse_host_lanczos_sqrt_e1(int m, const double *alpha, const double
 
 extern "C" int pse_destroy(pse_handle *h) {
     if (!h) return 0;
-    hipSetDevice(h->device);
-    hipDeviceSynchronize();
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
     if (h->plan_fwd) rocfft_plan_destroy(h->plan_fwd);
     if (h->plan_inv) rocfft_plan_destroy(h->plan_inv);
+    if (h->plan_x_fwd) rocfft_plan_destroy(h->plan_x_fwd);
+    if (h->plan_x_inv) rocfft_plan_destroy(h->plan_x_inv);
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
     void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->sup_s, h->nb.j, h->nb.fh, h->nb.dx, h->nb.dy, h->nb.dz, h->nb.cnt, h->pos_s,
-                    h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->fft_work, h->V,
+                    h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->fft_work, h->V,
                     h->scal, h->partials, h->t_dev};
-    for (void *p : ptrs) if (p) hipFree(p);
-    for (auto &p : h->ph) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &p : h->ph) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
     delete h;
     return 0;
 }
@@ -193,22 +200,46 @@ extern "C" int pse_destroy(pse_handle *h) {
 static int make_plans(pse_handle *h) {
     std::call_once(g_fft_once, [] { rocfft_setup(); });
     const DGrid &G = h->G;
-    // rocFFT lengths are fastest-first: z, y, x.  Real grids [3][Nx][Ny][Nz] -> half spectra [3][Nx][Ny][Nzh].
-    const size_t len[3] = {(size_t)G.Nz, (size_t)G.Ny, (size_t)G.Nx};
-    FFTCHK(rocfft_plan_create(&h->plan_fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
-                              rocfft_precision_double, 3, len, 3, nullptr));
-    FFTCHK(rocfft_plan_create(&h->plan_inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
-                              rocfft_precision_double, 3, len, 3, nullptr));
-    size_t wf = 0, wi = 0;
-    FFTCHK(rocfft_plan_get_work_buffer_size(h->plan_fwd, &wf));
-    FFTCHK(rocfft_plan_get_work_buffer_size(h->plan_inv, &wi));
-    h->fft_work_bytes = std::max(wf, wi);
-    if (h->fft_work_bytes) TRY(dmalloc(h, (char **)&h->fft_work, h->fft_work_bytes));
+    size_t work = 0, w = 0;
+    if (h->n_slabs == 1) {
+        // rocFFT lengths are fastest-first: z, y, x.  Real grids [3][Nx][Ny][Nz] -> half spectra [3][Nx][Ny][Nzh].
+        const size_t len[3] = {(size_t)G.Nz, (size_t)G.Ny, (size_t)G.Nx};
+        FFTCHK(rocfft_plan_create(&h->plan_fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                                  rocfft_precision_double, 3, len, 3, nullptr));
+        FFTCHK(rocfft_plan_create(&h->plan_inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                                  rocfft_precision_double, 3, len, 3, nullptr));
+    } else {
+        // slab mode: 2-D (y,z) real transforms of the nxl local planes of one component, then (after the transpose)
+        // 1-D complex transforms along x on [Nx][nyl][Nzh]: stride nyl*Nzh, one transform per (y,kz) column
+        const size_t len2[2] = {(size_t)G.Nz, (size_t)G.Ny};
+        FFTCHK(rocfft_plan_create(&h->plan_fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                                  rocfft_precision_double, 2, len2, (size_t)G.nxl, nullptr));
+        FFTCHK(rocfft_plan_create(&h->plan_inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                                  rocfft_precision_double, 2, len2, (size_t)G.nxl, nullptr));
+        const size_t lenx[1] = {(size_t)G.Nx};
+        size_t stride[1] = {(size_t)h->nyl * G.Nzh};
+        rocfft_plan_description desc = nullptr;
+        FFTCHK(rocfft_plan_description_create(&desc));
+        FFTCHK(rocfft_plan_description_set_data_layout(desc, rocfft_array_type_complex_interleaved,
+                                                       rocfft_array_type_complex_interleaved, nullptr, nullptr, 1, stride, 1,
+                                                       1, stride, 1));
+        FFTCHK(rocfft_plan_create(&h->plan_x_fwd, rocfft_placement_inplace, rocfft_transform_type_complex_forward,
+                                  rocfft_precision_double, 1, lenx, stride[0], desc));
+        FFTCHK(rocfft_plan_create(&h->plan_x_inv, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
+                                  rocfft_precision_double, 1, lenx, stride[0], desc));
+        rocfft_plan_description_destroy(desc);
+        FFTCHK(rocfft_plan_get_work_buffer_size(h->plan_x_fwd, &w)); work = std::max(work, w);
+        FFTCHK(rocfft_plan_get_work_buffer_size(h->plan_x_inv, &w)); work = std::max(work, w);
+    }
+    FFTCHK(rocfft_plan_get_work_buffer_size(h->plan_fwd, &w)); work = std::max(work, w);
+    FFTCHK(rocfft_plan_get_work_buffer_size(h->plan_inv, &w)); work = std::max(work, w);
+    h->fft_work_bytes = work;
+    if (work) TRY(dmalloc(h, (char **)&h->fft_work, work));
     FFTCHK(rocfft_execution_info_create(&h->info_fwd));
     FFTCHK(rocfft_execution_info_create(&h->info_inv));
-    if (h->fft_work_bytes) {
-        FFTCHK(rocfft_execution_info_set_work_buffer(h->info_fwd, h->fft_work, h->fft_work_bytes));
-        FFTCHK(rocfft_execution_info_set_work_buffer(h->info_inv, h->fft_work, h->fft_work_bytes));
+    if (work) {
+        FFTCHK(rocfft_execution_info_set_work_buffer(h->info_fwd, h->fft_work, work));
+        FFTCHK(rocfft_execution_info_set_work_buffer(h->info_inv, h->fft_work, work));
     }
     FFTCHK(rocfft_execution_info_set_stream(h->info_fwd, h->stream));
     FFTCHK(rocfft_execution_info_set_stream(h->info_inv, h->stream));
@@ -221,7 +252,6 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     std::string e = select_params(h->box, p->xi, p->error, p->max_strain, p->Nx, p->Ny, p->Nz, p->P, p->rcut, h->d);
     if (!e.empty()) return fail(PSE_ERR_INVALID, "%s", e.c_str());
     if (p->n_max == 0) return fail(PSE_ERR_INVALID, "n_max must be positive");
-    if (p->n_slabs > 1) return fail(PSE_ERR_INVALID, "slab decomposition is driven through the pse_slab_* entry points");
     const Derived &d = h->d;
     if (p->device >= 0) { HIPCHK(hipSetDevice(p->device)); h->device = p->device; }
     else HIPCHK(hipGetDevice(&h->device));
@@ -233,13 +263,27 @@ static int create_impl(const pse_params *p, pse_handle *h) {
 
     DGrid &G = h->G;
     G.Nx = d.Nx; G.Ny = d.Ny; G.Nz = d.Nz; G.Nzh = d.Nz / 2 + 1; G.P = d.P;
-    G.x0 = 0; G.nxl = d.Nx;
+    h->n_slabs = std::max(1, p->n_slabs);
+    h->slab_rank = h->n_slabs > 1 ? p->slab_rank : 0;
+    if (h->slab_rank < 0 || h->slab_rank >= h->n_slabs) return fail(PSE_ERR_INVALID, "slab_rank outside [0, n_slabs)");
+    if (h->n_slabs > 1) {
+        if (d.Nx % h->n_slabs || d.Ny % h->n_slabs)
+            return fail(PSE_ERR_INVALID, "slab decomposition needs Nx and Ny divisible by the number of ranks (%d x %d over %d)",
+                        d.Nx, d.Ny, h->n_slabs);
+        if (d.Nx / h->n_slabs < d.P)
+            return fail(PSE_ERR_INVALID, "slabs of %d planes are thinner than the support P = %d", d.Nx / h->n_slabs, d.P);
+    }
+    G.nxl = d.Nx / h->n_slabs; G.x0 = h->slab_rank * G.nxl;
+    G.nhalo = h->n_slabs > 1 ? d.P - 1 : 0;
+    h->nyl = d.Ny / h->n_slabs; h->y0 = h->slab_rank * h->nyl;
     G.hx = d.hx; G.hy = d.hy; G.hz = d.hz;
     const double c = 2.0 * d.xi * d.xi / d.eta;
     G.expfac = c;                                      // PSEv1/Brownian.cu:829
     G.prefac = (c / M_PI) * std::sqrt(c / M_PI);       // PSEv1/Brownian.cu:828
 
-    const size_t n = h->n_max;
+    // particle arrays are padded so that equal row chunks of every rank fit (all-gather inside Lanczos)
+    const size_t n = ((size_t)h->n_max + h->n_slabs - 1) / h->n_slabs * h->n_slabs;
+    h->n_pad = (int)n;
     TRY(dmalloc(h, &h->keys, n)); TRY(dmalloc(h, &h->keys_s, n)); TRY(dmalloc(h, &h->vals, n));
     TRY(dmalloc(h, &h->perm, n)); TRY(dmalloc(h, &h->tag_s, n));
     h->sort_tmp_bytes = sort_pairs_temp_bytes((int)n, 32);
@@ -259,7 +303,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         cap = std::max(16, std::min(cap, 256));
         const double bytes = (double)cap * (double)n * 44.0;
         if (bytes > 32e9 || n >= ((size_t)1 << 27)) cap = 0;   // too large: mat-vecs always walk the cells
-        h->nb.cap = cap; h->nb.stride = n;
+        h->nb.cap = cap; h->nb.stride = n;   // n is the padded capacity
         if (cap > 0) {
             TRY(dmalloc(h, &h->nb.j, (size_t)cap * n)); TRY(dmalloc(h, &h->nb.fh, (size_t)cap * n));
             TRY(dmalloc(h, &h->nb.dx, (size_t)cap * n)); TRY(dmalloc(h, &h->nb.dy, (size_t)cap * n));
@@ -275,9 +319,10 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     TRY(dmalloc(h, &h->coef, coef.size()));
     HIPCHK(hipMemcpy(h->coef, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice));
 
-    const size_t nr = (size_t)G.nxl * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
+    const size_t nr = (size_t)(G.nxl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
     TRY(dmalloc(h, &h->rgrid, 3 * nr));
     TRY(dmalloc(h, &h->cgrid, 3 * ncx));
+    if (h->n_slabs > 1) { TRY(dmalloc(h, &h->sendbuf, 3 * ncx)); TRY(dmalloc(h, &h->recvbuf, 3 * ncx)); }
     TRY(make_plans(h));
 
     TRY(dmalloc(h, &h->V, (size_t)(M_MAX + 1) * n));
@@ -336,6 +381,108 @@ extern "C" int pse_get_info(pse_handle *h, pse_info *info) {
     return 0;
 }
 
+// ---- team: the SPMD driver ---------------------------------------------------------------------------------------
+// A team is the set of slab ranks this process drives.  Production multi-GPU: one rank per process, team of one
+// member, data moved between processes by RCCL on the member's stream.  In-process loopback: all n_slabs ranks are
+// members of one team on one device (used to test the decomposition on a single GPU); the "collectives" are device
+// copies.  A single GPU is a team of one with n_slabs = 1 and no communication.  Every phase below runs for all local
+// members, then the exchange; the phase code is identical in the three cases.
+struct pse_team {
+    std::vector<pse_handle *> m;
+    int G = 1;                   // ranks in the decomposition
+    ncclComm_t nccl = nullptr;   // set when members.size() == 1 and G > 1
+    double *scratch = nullptr;   // loopback all-reduce scratch
+    size_t scratch_n = 0;
+};
+#define NCCLCHK(x)                                                                                              \
+    do {                                                                                                        \
+        ncclResult_t r_ = (x);                                                                                  \
+        if (r_ != ncclSuccess) return fail(PSE_ERR_COMM, "%s failed: %s (%s:%d)", #x, ncclGetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+static bool loopback(const pse_team &T) { return T.G > 1 && !T.nccl; }
+
+// all-to-all of equal blocks: member r sends block q of send(r) to rank q, which stores it as block r of recv(q)
+template <class FS, class FR>
+static int team_all_to_all(pse_team &T, FS send, FR recv, size_t blk_doubles) {
+    if (T.G == 1) return 0;
+    if (T.nccl) {
+        pse_handle *h = T.m[0];
+        NCCLCHK(ncclGroupStart());
+        for (int q = 0; q < T.G; ++q) {
+            NCCLCHK(ncclSend(send(h) + (size_t)q * blk_doubles, blk_doubles, ncclDouble, q, T.nccl, h->stream));
+            NCCLCHK(ncclRecv(recv(h) + (size_t)q * blk_doubles, blk_doubles, ncclDouble, q, T.nccl, h->stream));
+        }
+        NCCLCHK(ncclGroupEnd());
+        return 0;
+    }
+    for (pse_handle *src : T.m)
+        for (pse_handle *dst : T.m)
+            HIPCHK(hipMemcpyAsync(recv(dst) + (size_t)src->slab_rank * blk_doubles, send(src) + (size_t)dst->slab_rank * blk_doubles,
+                                  blk_doubles * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+    return 0;
+}
+// every rank's chunk [rank*chunk, (rank+1)*chunk) of buf becomes visible in every rank's buf
+template <class FB>
+static int team_all_gather(pse_team &T, FB buf, size_t chunk_doubles) {
+    if (T.G == 1) return 0;
+    if (T.nccl) {
+        pse_handle *h = T.m[0];
+        NCCLCHK(ncclAllGather(buf(h) + (size_t)h->slab_rank * chunk_doubles, buf(h), chunk_doubles, ncclDouble, T.nccl, h->stream));
+        return 0;
+    }
+    for (pse_handle *src : T.m)
+        for (pse_handle *dst : T.m)
+            if (src != dst)
+                HIPCHK(hipMemcpyAsync(buf(dst) + (size_t)src->slab_rank * chunk_doubles, buf(src) + (size_t)src->slab_rank * chunk_doubles,
+                                      chunk_doubles * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+    return 0;
+}
+template <class FB>
+static int team_all_reduce_sum(pse_team &T, FB buf, size_t n_doubles) {
+    if (T.G == 1) return 0;
+    if (T.nccl) {
+        pse_handle *h = T.m[0];
+        NCCLCHK(ncclAllReduce(buf(h), buf(h), n_doubles, ncclDouble, ncclSum, T.nccl, h->stream));
+        return 0;
+    }
+    if (T.scratch_n < n_doubles) {
+        if (T.scratch) (void)hipFree(T.scratch);
+        HIPCHK(hipMalloc((void **)&T.scratch, n_doubles * sizeof(double)));
+        T.scratch_n = n_doubles;
+    }
+    hipStream_t s = T.m[0]->stream;
+    HIPCHK(hipMemsetAsync(T.scratch, 0, n_doubles * sizeof(double), s));
+    for (pse_handle *h : T.m) launch_add_inplace(T.scratch, buf(h), n_doubles, s);   // rank order: deterministic
+    for (pse_handle *h : T.m) HIPCHK(hipMemcpyAsync(buf(h), T.scratch, n_doubles * sizeof(double), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+// gather halo: every rank receives the first `planes` planes of each component from the rank that owns the next slab
+static int team_halo_shift(pse_team &T) {
+    if (T.G == 1) return 0;
+    auto comp = [](pse_handle *h, int c) { return h->rgrid + (size_t)c * (h->G.nxl + h->G.nhalo) * h->G.Ny * h->G.Nz; };
+    if (T.nccl) {
+        pse_handle *h = T.m[0];
+        const size_t plane = (size_t)h->G.Ny * h->G.Nz, cnt = plane * h->G.nhalo;
+        const int left = (h->slab_rank + T.G - 1) % T.G, right = (h->slab_rank + 1) % T.G;
+        NCCLCHK(ncclGroupStart());
+        for (int c = 0; c < 3; ++c) {
+            NCCLCHK(ncclSend(comp(h, c), cnt, ncclDouble, left, T.nccl, h->stream));
+            NCCLCHK(ncclRecv(comp(h, c) + plane * h->G.nxl, cnt, ncclDouble, right, T.nccl, h->stream));
+        }
+        NCCLCHK(ncclGroupEnd());
+        return 0;
+    }
+    for (pse_handle *dst : T.m) {
+        pse_handle *src = nullptr;
+        for (pse_handle *h : T.m) if (h->slab_rank == (dst->slab_rank + 1) % T.G) src = h;
+        const size_t plane = (size_t)dst->G.Ny * dst->G.Nz, cnt = plane * dst->G.nhalo;
+        for (int c = 0; c < 3; ++c)
+            HIPCHK(hipMemcpyAsync(comp(dst, c) + plane * dst->G.nxl, comp(src, c), cnt * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+    }
+    return 0;
+}
+
 // ---- phases ---------------------------------------------------------------------------------------------------
 static int check_n(pse_handle *h, unsigned N) {
     if (!h) return fail(PSE_ERR_INVALID, "null handle");
@@ -344,7 +491,15 @@ static int check_n(pse_handle *h, unsigned N) {
     return 0;
 }
 
-// bin + sort + gather into cell order (positions change every step, so this runs every call)
+// rows of the particle arrays this rank computes in row-sharded phases (near field, Lanczos mat-vec)
+static void row_range(const pse_handle *h, int N, int &lo, int &hi, size_t &chunk) {
+    chunk = ((size_t)N + h->n_slabs - 1) / h->n_slabs;
+    lo = (int)std::min<size_t>((size_t)N, chunk * h->slab_rank);
+    hi = (int)std::min<size_t>((size_t)N, chunk * (h->slab_rank + 1));
+}
+
+// bin + sort + gather into cell order (positions change every step, so this runs every call; every rank sorts all
+// particles: the state is replicated, the work of the later phases is what is sharded)
 static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const unsigned *group, int N) {
     TRY(ts(h, PH_SORT));
     const size_t ncell = (size_t)h->nc.nx * h->nc.ny * h->nc.nz;
@@ -361,76 +516,147 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
     return 0;
 }
 
-// wave-space part: spread -> FFT -> scale (+ noise) -> inverse FFT -> gather  (PSEv1/Brownian.cu:836-872)
-static int wave(pse_handle *h, int N, bool noise, double kT, double dt, unsigned timestep) {
-    const DGrid &G = h->G;
-    const size_t nr = (size_t)G.nxl * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
-    double *gx = h->rgrid, *gy = h->rgrid + nr, *gz = h->rgrid + 2 * nr;
-    double2 *cx = h->cgrid, *cy = h->cgrid + ncx, *cz = h->cgrid + 2 * ncx;
-    TRY(ts(h, PH_SPREAD));
-    if (spread_needs_zero(G)) HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->stream));
-    launch_spread(h->pos_s, h->f_s, h->sup_s, N, h->cell_off, h->nc, gx, gy, gz, G, h->dbox, h->stream);
-    TRY(te(h, PH_SPREAD));
-    TRY(ts(h, PH_FFTF));
-    { void *in[1] = {h->rgrid}, *out[1] = {h->cgrid}; FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd)); }
-    TRY(te(h, PH_FFTF));
-    TRY(ts(h, PH_SCALE));
+static ScaleArgs scale_args(pse_handle *h, bool noise, double kT, double dt, unsigned timestep) {
     ScaleArgs a;
+    const DGrid &G = h->G;
     a.xi = h->d.xi; a.eta = h->d.eta; a.noise = noise ? 1 : 0;
     a.noise_fac = noise ? std::sqrt(2.0 * kT / dt / (G.hx * G.hy * G.hz)) : 0.0;   // PSEv1/Brownian.cu:197
-    a.seed = h->par.seed; a.timestep = timestep; a.transposed = 0; a.y0 = 0; a.nyl = G.Ny;
-    launch_scale(cx, cy, cz, G, h->dbox, a, h->stream);
-    TRY(te(h, PH_SCALE));
-    TRY(ts(h, PH_FFTI));
-    { void *in[1] = {h->cgrid}, *out[1] = {h->rgrid}; FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv)); }
-    TRY(te(h, PH_FFTI));
-    TRY(ts(h, PH_GATHER));
-    launch_gather(h->pos_s, N, gx, gy, gz, G, h->dbox, h->uw_s, h->stream);
-    TRY(te(h, PH_GATHER));
-    HIPCHK(hipGetLastError());
-    return 0;
+    a.seed = h->par.seed; a.timestep = timestep;
+    a.transposed = h->n_slabs > 1 ? 1 : 0; a.y0 = h->y0; a.nyl = h->n_slabs > 1 ? h->nyl : G.Ny;
+    return a;
 }
 
-// near-field mat-vec; build_list: also record the pair list so later mat-vecs of this step can reuse it
-static int real(pse_handle *h, const double4 *vec_s, double4 *out_s, int N, bool build_list) {
-    int mode = MREAL_CELLS;
-    if (h->nb.cap > 0) {
-        if (h->nb_valid) mode = MREAL_USE_LIST;
-        else if (build_list) mode = MREAL_BUILD_LIST;
+// wave-space part: spread -> FFT -> scale (+ noise) -> inverse FFT -> gather  (PSEv1/Brownian.cu:836-872)
+static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned timestep) {
+    for (pse_handle *h : T.m) {
+        const DGrid &G = h->G;
+        const size_t nr = (size_t)(G.nxl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
+        double *gx = h->rgrid, *gy = h->rgrid + nr, *gz = h->rgrid + 2 * nr;
+        TRY(ts(h, PH_SPREAD));
+        if (spread_needs_zero(G)) HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->stream));
+        launch_spread(h->pos_s, h->f_s, h->sup_s, N, h->cell_off, h->nc, gx, gy, gz, G, h->dbox, h->stream);
+        TRY(te(h, PH_SPREAD));
+        TRY(ts(h, PH_FFTF));
+        if (T.G == 1) {
+            void *in[1] = {h->rgrid}, *out[1] = {h->cgrid};
+            FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
+        } else {
+            for (int c = 0; c < 3; ++c) {   // 2-D (y,z) transforms of the local planes, one component at a time
+                void *in[1] = {h->rgrid + c * nr}, *out[1] = {h->cgrid + c * ncx};
+                FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
+            }
+            launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzh, h->nyl, 0, h->stream);
+        }
+        TRY(te(h, PH_FFTF));
     }
-    launch_mreal(h->pos_s, vec_s, out_s, N, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, h->nb, mode,
-                 h->stream);
-    if (mode == MREAL_BUILD_LIST) h->nb_valid = true;
+    if (T.G > 1) {
+        for (pse_handle *h : T.m) TRY(ts(h, PH_COMM));
+        pse_handle *h0 = T.m[0];
+        const size_t blk = (size_t)h0->G.nxl * h0->nyl * h0->G.Nzh * 2, comp = blk * T.G;
+        for (int c = 0; c < 3; ++c)
+            TRY(team_all_to_all(T, [&](pse_handle *h) { return (double *)h->sendbuf + c * comp; },
+                                [&](pse_handle *h) { return (double *)h->recvbuf + c * comp; }, blk));
+        for (pse_handle *h : T.m) TRY(te(h, PH_COMM));
+    }
+    for (pse_handle *h : T.m) {
+        const DGrid &G = h->G;
+        const size_t ncx = (size_t)G.nxl * G.Ny * G.Nzh;
+        double2 *sp = T.G == 1 ? h->cgrid : h->recvbuf;   // [3][Nx][nyl][Nzh] after the transpose
+        TRY(ts(h, PH_SCALE));
+        if (T.G > 1)
+            for (int c = 0; c < 3; ++c) { void *io[1] = {sp + c * ncx}; FFTCHK(rocfft_execute(h->plan_x_fwd, io, nullptr, h->info_fwd)); }
+        launch_scale(sp, sp + ncx, sp + 2 * ncx, G, h->dbox, scale_args(h, noise, kT, dt, timestep), h->stream);
+        if (T.G > 1)
+            for (int c = 0; c < 3; ++c) { void *io[1] = {sp + c * ncx}; FFTCHK(rocfft_execute(h->plan_x_inv, io, nullptr, h->info_inv)); }
+        TRY(te(h, PH_SCALE));
+    }
+    if (T.G > 1) {
+        pse_handle *h0 = T.m[0];
+        const size_t blk = (size_t)h0->G.nxl * h0->nyl * h0->G.Nzh * 2, comp = blk * T.G;
+        for (int c = 0; c < 3; ++c)
+            TRY(team_all_to_all(T, [&](pse_handle *h) { return (double *)h->recvbuf + c * comp; },
+                                [&](pse_handle *h) { return (double *)h->sendbuf + c * comp; }, blk));
+    }
+    for (pse_handle *h : T.m) {
+        const DGrid &G = h->G;
+        const size_t nr = (size_t)(G.nxl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
+        TRY(ts(h, PH_FFTI));
+        if (T.G == 1) {
+            void *in[1] = {h->cgrid}, *out[1] = {h->rgrid};
+            FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv));
+        } else {
+            launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzh, h->nyl, 1, h->stream);
+            for (int c = 0; c < 3; ++c) {
+                void *in[1] = {h->cgrid + c * ncx}, *out[1] = {h->rgrid + c * nr};
+                FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv));
+            }
+        }
+        TRY(te(h, PH_FFTI));
+    }
+    TRY(team_halo_shift(T));
+    for (pse_handle *h : T.m) {
+        const DGrid &G = h->G;
+        const size_t nr = (size_t)(G.nxl + G.nhalo) * G.Ny * G.Nz;
+        TRY(ts(h, PH_GATHER));
+        launch_gather(h->pos_s, N, h->rgrid, h->rgrid + nr, h->rgrid + 2 * nr, G, h->dbox, h->uw_s, h->stream);
+        TRY(te(h, PH_GATHER));
+        HIPCHK(hipGetLastError());
+    }
+    // every particle was gathered by exactly one rank (zeros elsewhere): the sum is the full wave-space velocity
+    TRY(team_all_reduce_sum(T, [](pse_handle *h) { return (double *)h->uw_s; }, (size_t)N * 4));
     return 0;
 }
 
-// M_real^{1/2} psi by Lanczos (PSEv1/Brownian.cu:357-765): psi_s in sorted order -> out_s = scale |psi| V t.
-static int lanczos(pse_handle *h, const double4 *psi_s, double4 *out_s, int N, double tol, double scale, int *m_io) {
-    const size_t stride = h->n_max;
+// near-field mat-vec out = M_real vec (PSEv1/Mobility.cu:594-687), rows sharded over the ranks and all-gathered.
+// build_list: also record the pair list so later mat-vecs of this step can reuse it.
+static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*out, size_t vec_off, size_t out_off, int N,
+                bool build_list) {
+    size_t chunk = 0;
+    for (pse_handle *h : T.m) {
+        int mode = MREAL_CELLS;
+        if (h->nb.cap > 0) {
+            if (h->nb_valid) mode = MREAL_USE_LIST;
+            else if (build_list) mode = MREAL_BUILD_LIST;
+        }
+        int lo, hi;
+        row_range(h, N, lo, hi, chunk);
+        launch_mreal(h->pos_s, h->*vec + vec_off, h->*out + out_off, lo, hi, h->cell_off, h->dbox, h->nc, h->d.rcut,
+                     h->d.self, h->coef, h->nb, mode, h->stream);
+        if (mode == MREAL_BUILD_LIST) h->nb_valid = true;
+    }
+    return team_all_gather(T, [&](pse_handle *h) { return (double *)(h->*out + out_off); }, chunk * 4);
+}
+
+// M_real^{1/2} psi by Lanczos (PSEv1/Brownian.cu:357-765): psi_s (sorted order, replicated on every rank) ->
+// ub_s = scale |psi| V t.  The basis and all scalars are replicated; only the mat-vec rows are sharded.
+static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io) {
+    pse_handle *h0 = T.m[0];
+    const size_t stride = h0->n_pad;
     int m_in = m_io ? *m_io : 2;
     if (m_in < 1) m_in = 1;
     if (m_in > M_MAX) m_in = M_MAX;
-    launch_lz_start(psi_s, h->V, nullptr, h->scal, h->partials, N, h->stream);
+    for (pse_handle *h : T.m) launch_lz_start(h->psi_s, h->V, nullptr, h->scal, h->partials, N, h->stream);
     std::vector<double> sc(LZ_NSCAL), t_prev, t_cur;
     int done = 0;                         // iterations launched so far
     int target = std::max(m_in, 2);       // first convergence check is at m = max(m_in, 2)   (Brownian.cu:465-466,606)
-    int m_final = 0;
+    int m_final = 0, checked = 0;
     double stepnorm = 1.0;
-    int checked = 0;                      // largest m whose t has been evaluated
     while (true) {
         for (; done < target; ++done) {
-            double4 *Vj = h->V + (size_t)done * stride;
-            TRY(real(h, Vj, h->w_s, N, true));
-            launch_lz_iter(h->w_s, Vj, done > 0 ? h->V + (size_t)(done - 1) * stride : nullptr,
-                           h->V + (size_t)(done + 1) * stride, done, h->scal, h->partials, N, h->stream);
+            TRY(real(T, &pse_handle::V, &pse_handle::w_s, (size_t)done * stride, 0, N, true));
+            for (pse_handle *h : T.m)
+                launch_lz_iter(h->w_s, h->V + (size_t)done * stride, done > 0 ? h->V + (size_t)(done - 1) * stride : nullptr,
+                               h->V + (size_t)(done + 1) * stride, done, h->scal, h->partials, N, h->stream);
         }
-        HIPCHK(hipMemcpyAsync(sc.data(), h->scal, LZ_NSCAL * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpyAsync(sc.data(), h0->scal, LZ_NSCAL * sizeof(double), hipMemcpyDeviceToHost, h0->stream));
+        HIPCHK(hipStreamSynchronize(h0->stream));
         const double *alpha = &sc[LZ_ALPHA], *beta = &sc[LZ_BETA];
         if (!(sc[LZ_NORM] > 0.0) || !std::isfinite(sc[LZ_NORM])) {   // psi == 0 -> result 0
-            HIPCHK(hipMemsetAsync(out_s, 0, (size_t)N * sizeof(double4), h->stream));
+            for (pse_handle *h : T.m) {
+                HIPCHK(hipMemsetAsync(h->ub_s, 0, (size_t)N * sizeof(double4), h->stream));
+                h->info.lanczos_m = 0; h->info.lanczos_matvecs = done; h->info.lanczos_stepnorm = 0.0;
+            }
             if (m_io) *m_io = m_in;
-            h->info.lanczos_m = 0; h->info.lanczos_matvecs = done; h->info.lanczos_stepnorm = 0.0;
             return 0;
         }
         // walk m upward exactly as the reference's while loop does, one vector at a time
@@ -450,102 +676,157 @@ static int lanczos(pse_handle *h, const double4 *psi_s, double4 *out_s, int N, d
             checked = m;
         }
         if (m_final) break;
-        target = std::min(M_MAX, done + std::max(2, done / 4));
         if (done >= M_MAX) { m_final = M_MAX; break; }
+        target = std::min(M_MAX, done + std::max(2, done / 4));
     }
     if ((int)t_cur.size() != m_final) {
         if (!lanczos_sqrt_e1(m_final, &sc[LZ_ALPHA], &sc[LZ_BETA], t_cur))
             return fail(PSE_ERR_NUMERIC, "tridiagonal eigen-solve failed at m = %d", m_final);
     }
-    HIPCHK(hipMemcpyAsync(h->t_dev, t_cur.data(), m_final * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    launch_basis_combine(h->V, stride, h->t_dev, m_final, h->scal, scale, 1, out_s, N, h->stream);   // Brownian.cu:716,739
-    HIPCHK(hipStreamSynchronize(h->stream));   // t_cur is host memory that goes out of scope
+    for (pse_handle *h : T.m) {
+        HIPCHK(hipMemcpyAsync(h->t_dev, t_cur.data(), m_final * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        launch_basis_combine(h->V, stride, h->t_dev, m_final, h->scal, scale, 1, h->ub_s, N, h->stream);   // Brownian.cu:716,739
+        h->info.lanczos_m = m_final; h->info.lanczos_matvecs = done; h->info.lanczos_stepnorm = stepnorm;
+    }
+    for (pse_handle *h : T.m) HIPCHK(hipStreamSynchronize(h->stream));   // t_cur is host memory that goes out of scope
     if (m_io) *m_io = m_final;
-    h->info.lanczos_m = m_final; h->info.lanczos_matvecs = done; h->info.lanczos_stepnorm = stepnorm;
     return 0;
 }
 
-static int velocity(pse_handle *h, const double4 *pos, const double4 *force, double4 *vel, const unsigned *group, int N,
-                    int parts, double kT, double dt, unsigned timestep, int *m_io, unsigned *mask) {
-    TRY(prepare(h, pos, force, group, N));
+// per-member argument pointers of a team call
+struct Args {
+    const double4 *pos; const double4 *force; double4 *vel;
+};
+
+static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *group, int N, int parts, double kT, double dt,
+                    unsigned timestep, int *m_io, unsigned *mask) {
+    for (size_t r = 0; r < T.m.size(); ++r) TRY(prepare(T.m[r], a[r].pos, a[r].force, group, N));
     *mask |= 1u << PH_SORT;
     const bool noise = kT > 0.0;
     if (parts & 2) {
-        TRY(wave(h, N, noise, kT, dt, timestep));
+        TRY(wave(T, N, noise, kT, dt, timestep));
         *mask |= (1u << PH_SPREAD) | (1u << PH_FFTF) | (1u << PH_SCALE) | (1u << PH_FFTI) | (1u << PH_GATHER);
+        if (T.G > 1) *mask |= 1u << PH_COMM;
     }
     if (parts & 1) {
-        TRY(ts(h, PH_REAL));
-        TRY(real(h, h->f_s, h->ur_s, N, noise));
-        TRY(te(h, PH_REAL));
+        for (pse_handle *h : T.m) TRY(ts(h, PH_REAL));
+        TRY(real(T, &pse_handle::f_s, &pse_handle::ur_s, 0, 0, N, noise));
+        for (pse_handle *h : T.m) TRY(te(h, PH_REAL));
         *mask |= 1u << PH_REAL;
     }
     if (noise) {
-        TRY(ts(h, PH_LANCZOS));
-        launch_psi(h->psi_s, h->tag_s, N, h->par.seed, timestep, h->stream);
-        TRY(lanczos(h, h->psi_s, h->ub_s, N, h->d.error, std::sqrt(2.0 * kT / dt), m_io));
-        TRY(te(h, PH_LANCZOS));
+        for (pse_handle *h : T.m) {
+            TRY(ts(h, PH_LANCZOS));
+            launch_psi(h->psi_s, h->tag_s, N, h->par.seed, timestep, h->stream);
+        }
+        TRY(lanczos(T, N, T.m[0]->d.error, std::sqrt(2.0 * kT / dt), m_io));
+        for (pse_handle *h : T.m) TRY(te(h, PH_LANCZOS));
         *mask |= 1u << PH_LANCZOS;
     }
-    launch_scatter_sum((parts & 2) ? h->uw_s : nullptr, (parts & 1) ? h->ur_s : nullptr, noise ? h->ub_s : nullptr,
-                       h->tag_s, N, vel, h->stream);
-    HIPCHK(hipGetLastError());
+    for (size_t r = 0; r < T.m.size(); ++r) {
+        pse_handle *h = T.m[r];
+        launch_scatter_sum((parts & 2) ? h->uw_s : nullptr, (parts & 1) ? h->ur_s : nullptr, noise ? h->ub_s : nullptr,
+                           h->tag_s, N, a[r].vel, h->stream);
+        HIPCHK(hipGetLastError());
+    }
     return 0;
 }
 
-extern "C" int pse_mobility(pse_handle *h, const pse_double4 *pos, const pse_double4 *force, pse_double4 *vel,
-                            const unsigned *group, unsigned N, int parts) {
-    TRY(check_n(h, N));
-    if (!pos || !force || !vel) return fail(PSE_ERR_INVALID, "null array");
+static int team_of_one(pse_handle *h, pse_team &T) {
+    if (h->n_slabs > 1) return fail(PSE_ERR_INVALID, "this handle is a slab rank: drive it through a pse_team");
+    T.m = {h}; T.G = 1;
+    return 0;
+}
+
+static int do_mobility(pse_team &T, const std::vector<Args> &a, const unsigned *group, unsigned N, int parts) {
+    for (pse_handle *h : T.m) TRY(check_n(h, N));
+    for (auto &x : a) if (!x.pos || !x.force || !x.vel) return fail(PSE_ERR_INVALID, "null array");
     if (!(parts & 3)) return fail(PSE_ERR_INVALID, "parts must select real (1), wave (2) or both (3)");
     unsigned mask = 1u << PH_TOTAL;
-    TRY(ts(h, PH_TOTAL));
-    TRY(velocity(h, (const double4 *)pos, (const double4 *)force, (double4 *)vel, group, (int)N, parts, 0.0, 1.0, 0,
-                 nullptr, &mask));
-    TRY(te(h, PH_TOTAL));
-    return collect_times(h, mask);
+    for (pse_handle *h : T.m) TRY(ts(h, PH_TOTAL));
+    TRY(velocity(T, a, group, (int)N, parts, 0.0, 1.0, 0, nullptr, &mask));
+    for (pse_handle *h : T.m) { TRY(te(h, PH_TOTAL)); TRY(collect_times(h, mask)); }
+    return 0;
+}
+
+static int do_brownian(pse_team &T, const std::vector<Args> &a, const unsigned *group, unsigned N, double kT, double dt,
+                       unsigned timestep, int *lanczos_m) {
+    for (pse_handle *h : T.m) TRY(check_n(h, N));
+    for (auto &x : a) if (!x.pos || !x.force || !x.vel) return fail(PSE_ERR_INVALID, "null array");
+    if (kT < 0 || !(dt > 0)) return fail(PSE_ERR_INVALID, "need kT >= 0 and dt > 0");
+    unsigned mask = 1u << PH_TOTAL;
+    for (pse_handle *h : T.m) TRY(ts(h, PH_TOTAL));
+    TRY(velocity(T, a, group, (int)N, 3, kT, dt, timestep, lanczos_m, &mask));
+    for (pse_handle *h : T.m) { TRY(te(h, PH_TOTAL)); TRY(collect_times(h, mask)); }
+    return 0;
+}
+
+struct StepArgs {
+    double4 *pos; double4 *vel; double3 *accel; int3 *image; const double4 *force;
+};
+static int do_step(pse_team &T, const std::vector<StepArgs> &sa, const unsigned *group, unsigned N, double kT, double dt,
+                   unsigned timestep, double shear_rate, int *lanczos_m) {
+    for (pse_handle *h : T.m) TRY(check_n(h, N));
+    std::vector<Args> a;
+    for (auto &x : sa) {
+        if (!x.pos || !x.vel || !x.accel || !x.image || !x.force) return fail(PSE_ERR_INVALID, "null array");
+        a.push_back(Args{x.pos, x.force, x.vel});
+    }
+    if (kT < 0 || !(dt > 0)) return fail(PSE_ERR_INVALID, "need kT >= 0 and dt > 0");
+    unsigned mask = (1u << PH_TOTAL) | (1u << PH_INTEG);
+    for (pse_handle *h : T.m) TRY(ts(h, PH_TOTAL));
+    TRY(velocity(T, a, group, (int)N, 3, kT, dt, timestep, lanczos_m, &mask));
+    for (size_t r = 0; r < T.m.size(); ++r) {
+        pse_handle *h = T.m[r];
+        TRY(ts(h, PH_INTEG));
+        launch_integrate(sa[r].pos, sa[r].vel, sa[r].accel, sa[r].image, sa[r].force, group, (int)N, h->dbox, dt, shear_rate,
+                         h->stream);
+        TRY(te(h, PH_INTEG));
+        TRY(te(h, PH_TOTAL));
+        HIPCHK(hipGetLastError());
+        TRY(collect_times(h, mask));
+    }
+    return 0;
+}
+
+// ---- single-handle C-ABI -------------------------------------------------------------------------------------------
+extern "C" int pse_mobility(pse_handle *h, const pse_double4 *pos, const pse_double4 *force, pse_double4 *vel,
+                            const unsigned *group, unsigned N, int parts) {
+    if (!h) return fail(PSE_ERR_INVALID, "null handle");
+    pse_team T;
+    TRY(team_of_one(h, T));
+    return do_mobility(T, {Args{(const double4 *)pos, (const double4 *)force, (double4 *)vel}}, group, N, parts);
 }
 
 extern "C" int pse_brownian_velocity(pse_handle *h, const pse_double4 *pos, const pse_double4 *force, pse_double4 *vel,
                                      const unsigned *group, unsigned N, double kT, double dt, unsigned timestep,
                                      int *lanczos_m) {
-    TRY(check_n(h, N));
-    if (!pos || !force || !vel) return fail(PSE_ERR_INVALID, "null array");
-    if (kT < 0 || !(dt > 0)) return fail(PSE_ERR_INVALID, "need kT >= 0 and dt > 0");
-    unsigned mask = 1u << PH_TOTAL;
-    TRY(ts(h, PH_TOTAL));
-    TRY(velocity(h, (const double4 *)pos, (const double4 *)force, (double4 *)vel, group, (int)N, 3, kT, dt, timestep,
-                 lanczos_m, &mask));
-    TRY(te(h, PH_TOTAL));
-    return collect_times(h, mask);
+    if (!h) return fail(PSE_ERR_INVALID, "null handle");
+    pse_team T;
+    TRY(team_of_one(h, T));
+    return do_brownian(T, {Args{(const double4 *)pos, (const double4 *)force, (double4 *)vel}}, group, N, kT, dt, timestep,
+                       lanczos_m);
 }
 
 extern "C" int pse_step(pse_handle *h, pse_double4 *pos, pse_double4 *vel, pse_double3 *accel, pse_int3 *image,
                         const pse_double4 *net_force, const unsigned *group, unsigned N, double kT, double dt,
                         unsigned timestep, double shear_rate, int *lanczos_m) {
-    TRY(check_n(h, N));
-    if (!pos || !vel || !accel || !image || !net_force) return fail(PSE_ERR_INVALID, "null array");
-    if (kT < 0 || !(dt > 0)) return fail(PSE_ERR_INVALID, "need kT >= 0 and dt > 0");
-    unsigned mask = (1u << PH_TOTAL) | (1u << PH_INTEG);
-    TRY(ts(h, PH_TOTAL));
-    TRY(velocity(h, (const double4 *)pos, (const double4 *)net_force, (double4 *)vel, group, (int)N, 3, kT, dt, timestep,
-                 lanczos_m, &mask));
-    TRY(ts(h, PH_INTEG));
-    launch_integrate((double4 *)pos, (const double4 *)vel, (double3 *)accel, (int3 *)image, (const double4 *)net_force,
-                     group, (int)N, h->dbox, dt, shear_rate, h->stream);
-    TRY(te(h, PH_INTEG));
-    TRY(te(h, PH_TOTAL));
-    HIPCHK(hipGetLastError());
-    return collect_times(h, mask);
+    if (!h) return fail(PSE_ERR_INVALID, "null handle");
+    pse_team T;
+    TRY(team_of_one(h, T));
+    return do_step(T, {StepArgs{(double4 *)pos, (double4 *)vel, (double3 *)accel, (int3 *)image, (const double4 *)net_force}},
+                   group, N, kT, dt, timestep, shear_rate, lanczos_m);
 }
 
 extern "C" int pse_sqrt_mreal(pse_handle *h, const pse_double4 *pos, const pse_double4 *psi, pse_double4 *out,
                               const unsigned *group, unsigned N, double tol, int *lanczos_m) {
     TRY(check_n(h, N));
     if (!pos || !psi || !out) return fail(PSE_ERR_INVALID, "null array");
+    pse_team T;
+    TRY(team_of_one(h, T));
     TRY(prepare(h, (const double4 *)pos, (const double4 *)psi, group, (int)N));   // f_s <- psi in sorted order
     HIPCHK(hipMemcpyAsync(h->psi_s, h->f_s, (size_t)N * sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
-    TRY(lanczos(h, h->psi_s, h->ub_s, (int)N, tol, 1.0, lanczos_m));
+    TRY(lanczos(T, (int)N, tol, 1.0, lanczos_m));
     launch_scatter_sum(h->ub_s, nullptr, nullptr, h->tag_s, (int)N, (double4 *)out, h->stream);
     HIPCHK(hipGetLastError());
     return 0;
@@ -554,7 +835,6 @@ extern "C" int pse_sqrt_mreal(pse_handle *h, const pse_double4 *pos, const pse_d
 extern "C" int pse_random_psi(pse_handle *h, pse_double4 *psi, const unsigned *group, unsigned N, unsigned timestep) {
     TRY(check_n(h, N));
     if (!psi) return fail(PSE_ERR_INVALID, "null array");
-    // tags in group order, no sorting needed: reuse the key kernel's identity permutation
     std::vector<unsigned> tags(N);
     if (group) HIPCHK(hipMemcpy(tags.data(), group, N * sizeof(unsigned), hipMemcpyDeviceToHost));
     else for (unsigned i = 0; i < N; ++i) tags[i] = i;
@@ -581,7 +861,7 @@ extern "C" int pse_eval_realspace(pse_handle *h, const double *r_host, int n, do
     }
     if (e == hipSuccess) e = hipMemcpy(f_host, buf + n, n * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(g_host, buf + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(buf);
+    (void)hipFree(buf);
     if (e != hipSuccess) return fail(PSE_ERR_HIP, "pse_eval_realspace: %s", hipGetErrorString(e));
     return 0;
 }
@@ -591,7 +871,85 @@ extern "C" int pse_debug_copy_grid(pse_handle *h, int stage, double *host_out) {
     (void)stage;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    const size_t nr = (size_t)h->G.nxl * h->G.Ny * h->G.Nz;
-    HIPCHK(hipMemcpy(host_out, h->rgrid, 3 * nr * sizeof(double), hipMemcpyDeviceToHost));
+    const size_t plane = (size_t)h->G.Ny * h->G.Nz, full = plane * (h->G.nxl + h->G.nhalo);
+    for (int c = 0; c < 3; ++c)   // the slab's own planes of each component (halo planes are not copied)
+        HIPCHK(hipMemcpy(host_out + (size_t)c * plane * h->G.nxl, h->rgrid + c * full, plane * h->G.nxl * sizeof(double),
+                         hipMemcpyDeviceToHost));
     return 0;
+}
+
+// ---- team C-ABI (multi-GPU) --------------------------------------------------------------------------------------
+extern "C" int pse_team_unique_id(void *id128_host) {
+    if (!id128_host) return fail(PSE_ERR_INVALID, "null argument");
+    static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
+    ncclUniqueId id;
+    NCCLCHK(ncclGetUniqueId(&id));
+    memcpy(id128_host, &id, sizeof id);
+    return 0;
+}
+
+extern "C" int pse_team_create(pse_handle **members, int n_members, const void *id128_host, pse_team **out) {
+    if (!members || n_members < 1 || !out) return fail(PSE_ERR_INVALID, "bad argument");
+    *out = nullptr;
+    const int G = members[0]->n_slabs;
+    std::vector<char> seen(G, 0);
+    for (int i = 0; i < n_members; ++i) {
+        pse_handle *h = members[i];
+        if (!h || h->n_slabs != G) return fail(PSE_ERR_INVALID, "members disagree on n_slabs");
+        if (h->d.Nx != members[0]->d.Nx || h->d.Ny != members[0]->d.Ny || h->d.Nz != members[0]->d.Nz || h->n_pad != members[0]->n_pad)
+            return fail(PSE_ERR_INVALID, "members disagree on grid or capacity");
+        if (seen[h->slab_rank]) return fail(PSE_ERR_INVALID, "slab rank %d appears twice", h->slab_rank);
+        seen[h->slab_rank] = 1;
+    }
+    pse_team *T = new pse_team();
+    T->m.assign(members, members + n_members);
+    T->G = G;
+    if (n_members == 1 && (G > 1 || id128_host)) {
+        if (!id128_host) { delete T; return fail(PSE_ERR_INVALID, "a one-rank-per-process team needs the RCCL unique id of rank 0"); }
+        ncclUniqueId id;
+        memcpy(&id, id128_host, sizeof id);
+        HIPCHK(hipSetDevice(members[0]->device));
+        ncclResult_t r = ncclCommInitRank(&T->nccl, G, id, members[0]->slab_rank);
+        if (r != ncclSuccess) { delete T; return fail(PSE_ERR_COMM, "ncclCommInitRank failed: %s", ncclGetErrorString(r)); }
+    } else if (n_members != G) {
+        delete T;
+        return fail(PSE_ERR_INVALID, "an in-process team must hold all %d slab ranks (got %d)", G, n_members);
+    }
+    *out = T;
+    return 0;
+}
+
+extern "C" int pse_team_destroy(pse_team *T) {
+    if (!T) return 0;
+    if (T->nccl) ncclCommDestroy(T->nccl);
+    if (T->scratch) (void)hipFree(T->scratch);
+    delete T;
+    return 0;
+}
+
+extern "C" int pse_team_mobility(pse_team *T, const pse_double4 *const *pos, const pse_double4 *const *force,
+                                 pse_double4 *const *vel, const unsigned *group, unsigned N, int parts) {
+    if (!T || !pos || !force || !vel) return fail(PSE_ERR_INVALID, "null argument");
+    std::vector<Args> a;
+    for (size_t r = 0; r < T->m.size(); ++r) a.push_back(Args{(const double4 *)pos[r], (const double4 *)force[r], (double4 *)vel[r]});
+    return do_mobility(*T, a, group, N, parts);
+}
+
+extern "C" int pse_team_brownian_velocity(pse_team *T, const pse_double4 *const *pos, const pse_double4 *const *force,
+                                          pse_double4 *const *vel, const unsigned *group, unsigned N, double kT, double dt,
+                                          unsigned timestep, int *lanczos_m) {
+    if (!T || !pos || !force || !vel) return fail(PSE_ERR_INVALID, "null argument");
+    std::vector<Args> a;
+    for (size_t r = 0; r < T->m.size(); ++r) a.push_back(Args{(const double4 *)pos[r], (const double4 *)force[r], (double4 *)vel[r]});
+    return do_brownian(*T, a, group, N, kT, dt, timestep, lanczos_m);
+}
+
+extern "C" int pse_team_step(pse_team *T, pse_double4 *const *pos, pse_double4 *const *vel, pse_double3 *const *accel,
+                             pse_int3 *const *image, const pse_double4 *const *net_force, const unsigned *group, unsigned N,
+                             double kT, double dt, unsigned timestep, double shear_rate, int *lanczos_m) {
+    if (!T || !pos || !vel || !accel || !image || !net_force) return fail(PSE_ERR_INVALID, "null argument");
+    std::vector<StepArgs> a;
+    for (size_t r = 0; r < T->m.size(); ++r)
+        a.push_back(StepArgs{(double4 *)pos[r], (double4 *)vel[r], (double3 *)accel[r], (int3 *)image[r], (const double4 *)net_force[r]});
+    return do_step(*T, a, group, N, kT, dt, timestep, shear_rate, lanczos_m);
 }

@@ -31,8 +31,9 @@ struct NbList {
 };
 enum { MREAL_CELLS = 0, MREAL_BUILD_LIST = 1, MREAL_USE_LIST = 2 };
 // out = M_real . vec (+ self). mode: cells only / cells + write the pair list / use the pair list
-void launch_mreal(const double4 *pos_s, const double4 *vec_s, double4 *out_s, int N, const int *cell_off, DBox box,
-                  DCells nc, double rcut, double self, const double *coef, NbList nb, int mode, hipStream_t s);
+// rows [lo, hi) of the mat-vec (the whole vector is read; multi-GPU ranks each take a row range)
+void launch_mreal(const double4 *pos_s, const double4 *vec_s, double4 *out_s, int lo, int hi, const int *cell_off,
+                  DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, int mode, hipStream_t s);
 
 // ---- far field (K2-K8) -----------------------------------------------------------------------------------
 // returns true if the caller must zero the grids first (atomic fallback for grids smaller than a tile + support)
@@ -50,6 +51,10 @@ struct ScaleArgs {
 void launch_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, hipStream_t s);
 void launch_gather(const double4 *pos_s, int N, const double *gx, const double *gy, const double *gz, DGrid G,
                    DBox box, double4 *u_s, hipStream_t s);
+
+// ---- slab decomposition helpers
+void launch_slab_pack(double2 *cgrid, double2 *buf, int nxl, int Ny, int Nzh, int nyl, int unpack, hipStream_t s);
+void launch_add_inplace(double *a, const double *b, size_t n, hipStream_t s);
 
 // ---- vector kernels (K10-K14) ----------------------------------------------------------------------------
 void launch_psi(double4 *psi_s, const unsigned *tag_s, int N, uint32_t seed, uint32_t timestep, hipStream_t s);

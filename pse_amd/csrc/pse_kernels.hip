@@ -103,13 +103,13 @@ void launch_cell_keys(const double4 *pos, const unsigned *group, int N, DBox box
 }
 size_t sort_pairs_temp_bytes(int N, int end_bit) {
     size_t bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned *)nullptr, (unsigned *)nullptr,
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned *)nullptr, (unsigned *)nullptr,
                                        (const unsigned *)nullptr, (unsigned *)nullptr, N, 0, end_bit, nullptr);
     return bytes;
 }
 void sort_pairs(void *temp, size_t temp_bytes, const unsigned *keys_in, unsigned *keys_out, const unsigned *vals_in,
                 unsigned *vals_out, int N, int end_bit, hipStream_t s) {
-    hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, N, 0, end_bit, s);
+    (void)hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, N, 0, end_bit, s);
 }
 void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm,
                     const unsigned *keys_sorted, int N, DBox box, double4 *pos_s, double4 *vec_s, unsigned *tag_s,
@@ -183,13 +183,13 @@ __device__ __forceinline__ void for_each_run(const DCells &nc, const int *__rest
 
 template <bool LIST>
 __global__ void __launch_bounds__(TPB)
-k_mreal_cells(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int N,
-              const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2, double self,
+k_mreal_cells(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int lo,
+              int hi, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2, double self,
               const double *__restrict__ coef, NbList nb) {
     __shared__ unsigned queue[QCAP * TPB];
     const int tid = threadIdx.x;
-    const int i = xcd_block(blockIdx.x, gridDim.x) * TPB + tid;
-    if (i >= N) return;
+    const int i = lo + xcd_block(blockIdx.x, gridDim.x) * TPB + tid;   // rows [lo, hi) of the mat-vec
+    if (i >= hi) return;
     const double4 pi = pos_s[i];
     const double4 vi = vec_s[i];
     double ux = self * vi.x, uy = self * vi.y, uz = self * vi.z;
@@ -260,11 +260,11 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec
 // mat-vec from the pair list (one thread per particle, ELL layout: slot-major so a wave reads contiguous rows).
 // A particle whose neighbour count overflowed the list capacity recomputes from the cells.
 __global__ void __launch_bounds__(TPB)
-k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int N,
-             const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2, double self,
+k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int lo,
+             int hi, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2, double self,
              const double *__restrict__ coef, NbList nb) {
-    const int i = xcd_block(blockIdx.x, gridDim.x) * TPB + threadIdx.x;
-    if (i >= N) return;
+    const int i = lo + xcd_block(blockIdx.x, gridDim.x) * TPB + threadIdx.x;
+    if (i >= hi) return;
     const double4 vi = vec_s[i];
     double ux = self * vi.x, uy = self * vi.y, uz = self * vi.z;
     const int cnt = nb.cnt[i];
@@ -307,15 +307,16 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
     out_s[i] = make_double4(ux, uy, uz, 0.0);
 }
 
-void launch_mreal(const double4 *pos_s, const double4 *vec_s, double4 *out_s, int N, const int *cell_off, DBox box,
-                  DCells nc, double rcut, double self, const double *coef, NbList nb, int mode, hipStream_t s) {
-    const dim3 g(nblocks(N, TPB)), b(TPB);
+void launch_mreal(const double4 *pos_s, const double4 *vec_s, double4 *out_s, int lo, int hi, const int *cell_off,
+                  DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, int mode, hipStream_t s) {
+    if (hi <= lo) return;
+    const dim3 g(nblocks(hi - lo, TPB)), b(TPB);
     if (mode == MREAL_BUILD_LIST)
-        hipLaunchKernelGGL(k_mreal_cells<true>, g, b, 0, s, pos_s, vec_s, out_s, N, cell_off, box, nc, rcut * rcut, self, coef, nb);
+        hipLaunchKernelGGL(k_mreal_cells<true>, g, b, 0, s, pos_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, self, coef, nb);
     else if (mode == MREAL_USE_LIST)
-        hipLaunchKernelGGL(k_mreal_list, g, b, 0, s, pos_s, vec_s, out_s, N, cell_off, box, nc, rcut * rcut, self, coef, nb);
+        hipLaunchKernelGGL(k_mreal_list, g, b, 0, s, pos_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, self, coef, nb);
     else
-        hipLaunchKernelGGL(k_mreal_cells<false>, g, b, 0, s, pos_s, vec_s, out_s, N, cell_off, box, nc, rcut * rcut, self, coef, nb);
+        hipLaunchKernelGGL(k_mreal_cells<false>, g, b, 0, s, pos_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, self, coef, nb);
 }
 
 __global__ void k_eval_fg(const double *__restrict__ r, int n, const double *__restrict__ coef, double *f, double *g) {
@@ -434,7 +435,9 @@ __global__ void __launch_bounds__(NT)
 k_spread_tile(const double4 *__restrict__ pos_s, const double4 *__restrict__ f_s, const int4 *__restrict__ sup_s,
               const int *__restrict__ cell_off, DCells nc, double *__restrict__ gx, double *__restrict__ gy,
               double *__restrict__ gz, DGrid G, DBox box, int ntx, int nty, int ntz) {
-    constexpr int NODES = TX * TY * TZ, NW = NT / 64;
+    // x-planes are TY*TZ doubles apart, a multiple of the 64-bank row: pad each plane so lanes that differ only in x
+    // do not hit the same bank in the ds_add_f64
+    constexpr int XS = TY * TZ + 2, NODES = TX * XS, NW = NT / 64;
     __shared__ double acc[3 * NODES];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int b = xcd_block(blockIdx.x, gridDim.x);
@@ -506,7 +509,7 @@ k_spread_tile(const double4 *__restrict__ pos_s, const double4 *__restrict__ f_s
                     const int lx = lo[0] + qx, ly = lo[1] + qy, lz = lo[2] + qz;
                     const double w = W.get(lx - a0[0], ly - a0[1], lz - a0[2]);   // all lanes take part in the shuffles
                     if (on) {
-                        const int o = (lx * TY + ly) * TZ + lz;
+                        const int o = lx * XS + ly * TZ + lz;
                         atomicAdd(&acc[o], w * Fx);
                         atomicAdd(&acc[NODES + o], w * Fy);
                         atomicAdd(&acc[2 * NODES + o], w * Fz);
@@ -520,7 +523,7 @@ k_spread_tile(const double4 *__restrict__ pos_s, const double4 *__restrict__ f_s
     for (int n = tid; n < nout; n += NT) {
         const int qx = n / eyz, r = n - qx * eyz, qy = r / ext[2], qz = r - qy * ext[2];
         const size_t idx = ((size_t)(t0[0] - G.x0 + qx) * G.Ny + (t0[1] + qy)) * G.Nz + (t0[2] + qz);
-        const int o = (qx * TY + qy) * TZ + qz;
+        const int o = qx * XS + qy * TZ + qz;
         gx[idx] = acc[o];
         gy[idx] = acc[NODES + o];
         gz[idx] = acc[2 * NODES + o];
@@ -547,7 +550,7 @@ bool spread_needs_zero(const DGrid &G) {
     tile_dims(tx, ty, tz);
     const int tmax = std::max(tx, std::max(ty, tz));
     const int need = 2 * std::max(tmax, G.P);
-    return G.P < 4 || G.P > 8 || G.Nx < need || G.Ny < need || G.Nz < need || G.nxl != G.Nx;
+    return G.P < 4 || G.P > 8 || G.Nx < need || G.Ny < need || G.Nz < need;
 }
 
 template <int P>
@@ -600,6 +603,13 @@ k_gather_p(const double4 *__restrict__ pos_s, int N, const double *__restrict__ 
     support_start(fx, G.Nx, P, sx, d0x);
     support_start(fy, G.Ny, P, sy, d0y);
     support_start(fz, G.Nz, P, sz, d0z);
+    // a particle is gathered by the rank whose slab holds its support origin; the support then reaches at most P - 1
+    // planes into the next slab, which the halo copies provide
+    int rel0 = sx - G.x0; rel0 %= G.Nx; if (rel0 < 0) rel0 += G.Nx;
+    if (rel0 >= G.nxl) {
+        if (lane == 0) u_s[p] = make_double4(0.0, 0.0, 0.0, 0.0);
+        return;
+    }
     WaveWeights<P> W;
     W.stage(lane, G, box, d0x, d0y, d0z);
     constexpr int P2 = P * P, P3 = P2 * P;
@@ -611,11 +621,10 @@ k_gather_p(const double4 *__restrict__ pos_s, int N, const double *__restrict__ 
         const int m = on ? n : 0;
         const int tx = m / P2, ty = (m - tx * P2) / P, tz = m - tx * P2 - ty * P;
         const double w = W.get(tx, ty, tz);
-        int ix = sx + tx; ix = ix < 0 ? ix + G.Nx : (ix >= G.Nx ? ix - G.Nx : ix);
+        int lx = rel0 + tx; if (G.nhalo == 0 && lx >= G.Nx) lx -= G.Nx;   // slab mode: planes nxl.. are the halo copies
         int iy = sy + ty; iy = iy < 0 ? iy + G.Ny : (iy >= G.Ny ? iy - G.Ny : iy);
         int iz = sz + tz; iz = iz < 0 ? iz + G.Nz : (iz >= G.Nz ? iz - G.Nz : iz);
-        const int lx = ix - G.x0;
-        if (on && lx >= 0 && lx < G.nxl) {
+        if (on) {
             const size_t idx = ((size_t)lx * G.Ny + iy) * G.Nz + iz;
             ux += w * gx[idx];
             uy += w * gy[idx];
@@ -644,13 +653,16 @@ k_gather(const double4 *__restrict__ pos_s, int N, const double *__restrict__ gx
     support_start(fx, G.Nx, G.P, sx, d0x);
     support_start(fy, G.Ny, G.P, sy, d0y);
     support_start(fz, G.Nz, G.P, sz, d0z);
+    int rel0 = sx - G.x0; rel0 %= G.Nx; if (rel0 < 0) rel0 += G.Nx;
+    if (rel0 >= G.nxl) {
+        if (lane == 0) u_s[p] = make_double4(0.0, 0.0, 0.0, 0.0);
+        return;
+    }
     const int P = G.P, P2 = P * P, P3 = P2 * P;
     double ux = 0, uy = 0, uz = 0;
     for (int n = lane; n < P3; n += 64) {
         const int tx = n / P2, ty = (n - tx * P2) / P, tz = n - tx * P2 - ty * P;
-        int ix = sx + tx; ix = ix < 0 ? ix + G.Nx : (ix >= G.Nx ? ix - G.Nx : ix);
-        const int lx = ix - G.x0;
-        if (lx < 0 || lx >= G.nxl) continue;
+        int lx = rel0 + tx; if (G.nhalo == 0 && lx >= G.Nx) lx -= G.Nx;
         int iy = sy + ty; iy = iy < 0 ? iy + G.Ny : (iy >= G.Ny ? iy - G.Ny : iy);
         int iz = sz + tz; iz = iz < 0 ? iz + G.Nz : (iz >= G.Nz ? iz - G.Nz : iz);
         const double ey = G.hy * (d0y + ty);
@@ -787,6 +799,37 @@ k_scale(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ 
 void launch_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, hipStream_t s) {
     const size_t rows = a.transposed ? (size_t)a.nyl * G.Nx : (size_t)G.nxl * G.Ny;
     hipLaunchKernelGGL(k_scale, dim3(nblocks((long)(rows * G.Nzh), TPB)), dim3(TPB), 0, s, X, Y, Z, G, box, a);
+}
+
+// ------------------------------------------------------------------------------------------------ slab transposes
+// Slab-decomposed far field (new design; the reference is single-GPU, PSEv1/Stokes.cc:104).  After the local 2-D
+// transforms rank r holds [3][nxl][Ny][Nzh]; the block of y rows [q*nyl, (q+1)*nyl) goes to rank q.  pack lays the
+// half spectrum out as [3][G][nxl][nyl][Nzh] so each destination's block is contiguous; on the receiving side the blocks
+// of all source ranks line up as [3][Nx][nyl][Nzh] (x-major) with no further copy.  unpack is the inverse map.
+__global__ void k_slab_pack(const double2 *__restrict__ cgrid, double2 *__restrict__ buf, int nxl, int Ny, int Nzh,
+                            int nyl, int unpack) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = (size_t)nxl * Ny * Nzh;
+    if (tid >= 3 * per) return;
+    const int c = (int)(tid / per);
+    size_t r = tid - (size_t)c * per;
+    const int k = (int)(r % Nzh); r /= Nzh;
+    const int j = (int)(r % Ny);
+    const int lx = (int)(r / Ny);
+    const int q = j / nyl, jl = j - q * nyl;
+    const size_t o = (size_t)c * per + (((size_t)q * nxl + lx) * nyl + jl) * Nzh + k;
+    if (unpack) ((double2 *)cgrid)[tid] = buf[o];
+    else buf[o] = cgrid[tid];
+}
+void launch_slab_pack(double2 *cgrid, double2 *buf, int nxl, int Ny, int Nzh, int nyl, int unpack, hipStream_t s) {
+    const size_t n = (size_t)3 * nxl * Ny * Nzh;
+    hipLaunchKernelGGL(k_slab_pack, dim3(nblocks((long)n, TPB)), dim3(TPB), 0, s, cgrid, buf, nxl, Ny, Nzh, nyl, unpack);
+}
+__global__ void k_axpy_inplace(double *__restrict__ a, const double *__restrict__ b, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] += b[i];
+}
+void launch_add_inplace(double *a, const double *b, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_axpy_inplace, dim3(std::min<long>(2048, nblocks((long)n, TPB))), dim3(TPB), 0, s, a, b, n);
 }
 
 // ------------------------------------------------------------------------------------------------ vectors

@@ -49,13 +49,13 @@ class Engine:
     """One PSE engine instance == one `Stokes` object's device state (PSEv1/Stokes.h:128-150)."""
 
     def __init__(self, n_max, box, xi=0.5, error=1e-3, max_strain=0.5, seed=0, grid=(0, 0, 0), P=0, rcut=0.0,
-                 device=-1):
+                 device=-1, n_slabs=1, slab_rank=0):
         self._lib = _lib.load()
         self._h = ctypes.c_void_p()
         box = tuple(float(b) for b in box) + ((0.0,) if len(box) == 3 else ())
         self.params = pse_params(n_max=int(n_max), Lx=box[0], Ly=box[1], Lz=box[2], xy=box[3], xi=xi, error=error,
                                  max_strain=max_strain, seed=int(seed) & 0xFFFFFFFF, Nx=grid[0], Ny=grid[1],
-                                 Nz=grid[2], P=P, rcut=rcut, device=device, n_slabs=1, slab_rank=0)
+                                 Nz=grid[2], P=P, rcut=rcut, device=device, n_slabs=n_slabs, slab_rank=slab_rank)
         _lib.check(self._lib.pse_create(ctypes.byref(self.params), ctypes.byref(self._h)))
         self.box = box
 
@@ -142,6 +142,57 @@ class Engine:
     def debug_grid(self):
         import numpy as np
         i = self.info()
-        out = np.zeros((3, i["Nx"], i["Ny"], i["Nz"]))
+        out = np.zeros((3, i["Nx"] // max(1, self.params.n_slabs), i["Ny"], i["Nz"]))
         _lib.check(self._lib.pse_debug_copy_grid(self._h, 0, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
         return out
+
+
+class Team:
+    """A pse_team: the local slab ranks bound to a transport (RCCL across processes, or in-process loopback)."""
+
+    def __init__(self, engines, unique_id=None):
+        self._lib = _lib.load()
+        self.engines = list(engines)
+        arr = (ctypes.c_void_p * len(self.engines))(*[e._h for e in self.engines])
+        self._t = ctypes.c_void_p()
+        idbuf = ctypes.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
+        _lib.check(self._lib.pse_team_create(arr, len(self.engines), idbuf, ctypes.byref(self._t)))
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.load().pse_team_unique_id(buf))
+        return buf.raw
+
+    def close(self):
+        if getattr(self, "_t", None) is not None and self._t.value:
+            self._lib.pse_team_destroy(self._t)
+            self._t = ctypes.c_void_p()
+
+    __del__ = close
+
+    @staticmethod
+    def _ptrs(tensors):
+        return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    def mobility(self, pos, force, vel, group=None, parts=3):
+        n = pos[0].shape[0] if group is None else group.shape[0]
+        _lib.check(self._lib.pse_team_mobility(self._t, self._ptrs(pos), self._ptrs(force), self._ptrs(vel), _ptr(group),
+                                               n, parts))
+        return vel
+
+    def brownian_velocity(self, pos, force, vel, kT, dt, timestep, group=None, lanczos_m=2):
+        n = pos[0].shape[0] if group is None else group.shape[0]
+        m = ctypes.c_int(int(lanczos_m))
+        _lib.check(self._lib.pse_team_brownian_velocity(self._t, self._ptrs(pos), self._ptrs(force), self._ptrs(vel),
+                                                        _ptr(group), n, float(kT), float(dt), int(timestep),
+                                                        ctypes.byref(m)))
+        return vel, m.value
+
+    def step(self, pos, vel, accel, image, force, kT, dt, timestep, shear_rate=0.0, group=None, lanczos_m=2):
+        n = pos[0].shape[0] if group is None else group.shape[0]
+        m = ctypes.c_int(int(lanczos_m))
+        _lib.check(self._lib.pse_team_step(self._t, self._ptrs(pos), self._ptrs(vel), self._ptrs(accel),
+                                           self._ptrs(image), self._ptrs(force), _ptr(group), n, float(kT), float(dt),
+                                           int(timestep), float(shear_rate), ctypes.byref(m)))
+        return m.value

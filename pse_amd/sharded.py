@@ -1,0 +1,100 @@
+"""Multi-GPU drivers of the PSE step (slab-decomposed far field, row-sharded near field; see include/pse_amd.h).
+
+ShardedSimulation  one rank per process / GPU; the C++ team moves data with RCCL on the engine's stream.  The only
+                   thing torch.distributed does here is hand the 128-byte RCCL unique id of rank 0 to the other ranks.
+LoopbackSimulation all slab ranks in one process on one device (copies instead of collectives): exercises exactly the
+                   same phase code as the multi-process path, so the decomposition can be parity-tested on one GPU.
+"""
+import numpy as np
+
+from .engine import Engine, Team
+from .distributed import _to4
+
+
+def slab_plan(grid, world):
+    """Which x planes / y rows of the far-field grid each rank owns (mirrors create_impl in csrc/pse_capi.hip)."""
+    nx, ny = grid[0], grid[1]
+    if nx % world or ny % world:
+        raise ValueError(f"slab decomposition needs Nx and Ny divisible by the number of ranks ({nx} x {ny} over {world})")
+    nxl, nyl = nx // world, ny // world
+    return [{"rank": r, "x0": r * nxl, "nxl": nxl, "y0": r * nyl, "nyl": nyl} for r in range(world)]
+
+
+def row_chunks(n, world):
+    """Rows of the particle arrays each rank computes in the near-field phases (row_range in csrc/pse_capi.hip)."""
+    chunk = (n + world - 1) // world
+    return [(min(n, chunk * r), min(n, chunk * (r + 1))) for r in range(world)]
+
+
+def exchange_unique_id(rank, make_id, dist):
+    """Rank 0 creates the RCCL unique id; everyone receives it (works on any torch.distributed backend)."""
+    box = [make_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+class _State:
+    def __init__(self, n, pos, force, mass):
+        import torch
+        self.pos = _to4(pos, 0.0)
+        self.force = _to4(force, 0.0)
+        self.vel = _to4(np.zeros((n, 3)), mass)
+        self.accel = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+        self.image = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+
+
+class ShardedSimulation:
+    def __init__(self, n, box, world, rank, **kw):
+        import torch.distributed as dist
+        self.n, self.world, self.rank = n, world, rank
+        self.engine = Engine(n, box, n_slabs=world, slab_rank=rank, **kw)
+        uid = exchange_unique_id(rank, Team.unique_id, dist)
+        self.team = Team([self.engine], unique_id=uid)
+
+    def describe(self):
+        return (f"{self.world} GPUs: far-field grid in {self.world} x-slabs (RCCL all-to-all transpose, P-1 plane gather halo), "
+                f"near-field and Lanczos mat-vec rows split {self.world} ways (RCCL all-gather); particles replicated")
+
+    def load(self, pos, force, mass=1.0):
+        self.s = _State(self.n, pos, force, mass)
+
+    def info(self):
+        return self.engine.info()
+
+    def set_timing(self, on):
+        self.engine.set_timing(on)
+
+    def phase_times(self):
+        return {k: v for k, v in self.engine.info().items() if k.startswith("t_")}
+
+    def mobility(self):
+        self.team.mobility([self.s.pos], [self.s.force], [self.s.vel])
+        return self.s.vel
+
+    def step(self, kT, dt, timestep, shear_rate=0.0, lanczos_m=2):
+        s = self.s
+        return self.team.step([s.pos], [s.vel], [s.accel], [s.image], [s.force], kT, dt, timestep,
+                              shear_rate=shear_rate, lanczos_m=lanczos_m)
+
+
+class LoopbackSimulation:
+    def __init__(self, n, box, world, **kw):
+        self.n, self.world = n, world
+        self.engines = [Engine(n, box, n_slabs=world, slab_rank=r, **kw) for r in range(world)]
+        self.team = Team(self.engines)
+
+    def load(self, pos, force, mass=1.0):
+        self.s = [_State(self.n, pos, force, mass) for _ in range(self.world)]
+
+    def mobility(self, parts=3):
+        self.team.mobility([s.pos for s in self.s], [s.force for s in self.s], [s.vel for s in self.s], parts=parts)
+        return [s.vel for s in self.s]
+
+    def brownian_velocity(self, kT, dt, timestep, lanczos_m=2):
+        return self.team.brownian_velocity([s.pos for s in self.s], [s.force for s in self.s], [s.vel for s in self.s],
+                                           kT, dt, timestep, lanczos_m=lanczos_m)
+
+    def step(self, kT, dt, timestep, shear_rate=0.0, lanczos_m=2):
+        S = self.s
+        return self.team.step([s.pos for s in S], [s.vel for s in S], [s.accel for s in S], [s.image for s in S],
+                              [s.force for s in S], kT, dt, timestep, shear_rate=shear_rate, lanczos_m=lanczos_m)

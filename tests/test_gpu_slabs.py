@@ -1,0 +1,73 @@
+"""GPU tests of the multi-GPU decomposition, run on ONE device: all slab ranks live in one process and the collectives
+are device copies (in-process loopback team), so every pack/transpose/halo/row-range index of the production RCCL path
+is exercised.  Reference = the single-GPU engine (itself pinned to the oracle in test_gpu_parity.py)."""
+import numpy as np
+import pytest
+
+from conftest import make_suspension, to4
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("world,xy", [(2, 0.0), (4, 0.3), (3, 0.0)])
+def test_loopback_team_matches_single_gpu(world, xy):
+    import pse_amd
+    from pse_amd.sharded import LoopbackSimulation
+    n = 3000
+    pos, force, box = make_suspension(n, phi=0.1, xy=xy)
+    grid = (48, 48, 40)                      # divisible by 2, 3, 4; slabs of >= 12 planes > P
+    kw = dict(xi=0.5, error=1e-3, seed=77, grid=grid)
+    ref = pse_amd.Engine(n, box, **kw)
+    sim = LoopbackSimulation(n, box, world, **kw)
+    sim.load(pos, force)
+    for parts in (2, 1, 3):
+        u_ref = ref.mobility(to4(pos), to4(force), parts=parts).cpu().numpy()[:, :3]
+        vels = sim.mobility(parts=parts)
+        for r in range(world):
+            assert rel(vels[r].cpu().numpy()[:, :3], u_ref) < 1e-12, (parts, r)
+    v_ref, m_ref = ref.brownian_velocity(to4(pos), to4(force), 1.0, 1e-3, 5)
+    vels, m = sim.brownian_velocity(1.0, 1e-3, 5)
+    assert m == m_ref
+    for r in range(world):
+        assert rel(vels[r].cpu().numpy()[:, :3], v_ref.cpu().numpy()[:, :3]) < 1e-11, r
+
+
+def test_loopback_step_keeps_replicas_identical():
+    import torch
+    import pse_amd
+    from pse_amd.sharded import LoopbackSimulation
+    n = 2500
+    pos, force, box = make_suspension(n, phi=0.1, xy=0.2)
+    kw = dict(xi=0.5, error=1e-3, seed=5, grid=(48, 48, 48))
+    sim = LoopbackSimulation(n, box, 4, **kw)
+    sim.load(pos, force)
+    ref = pse_amd.Engine(n, box, **kw)
+    rp, rv, rF = to4(pos), to4(np.zeros((n, 3)), 1.0), to4(force)
+    ra = torch.zeros((n, 3), dtype=torch.float64, device="cuda"); ri = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+    m = mr = 2
+    for ts in range(3):
+        m = sim.step(1.0, 1e-2, ts, shear_rate=0.5, lanczos_m=m)
+        mr = ref.step(rp, rv, ra, ri, rF, 1.0, 1e-2, ts, shear_rate=0.5, lanczos_m=mr)
+    assert m == mr
+    for s in sim.s:
+        assert np.abs(s.pos.cpu().numpy() - rp.cpu().numpy()).max() < 1e-10
+        assert np.array_equal(s.image.cpu().numpy(), ri.cpu().numpy())
+
+
+def test_rccl_team_of_one_rank():
+    """The RCCL transport with a single rank: ncclCommInitRank + the collectives degenerate to self-copies."""
+    import pse_amd
+    from pse_amd.engine import Team
+    n = 1000
+    pos, force, box = make_suspension(n, phi=0.1)
+    kw = dict(xi=0.5, error=1e-3, seed=1)
+    ref = pse_amd.Engine(n, box, **kw)
+    eng = pse_amd.Engine(n, box, **kw)
+    team = Team([eng], unique_id=Team.unique_id())      # G = 1: no communication is issued, but RCCL is initialised
+    vel = [to4(np.zeros((n, 3)))]
+    team.mobility([to4(pos)], [to4(force)], vel)
+    assert rel(vel[0].cpu().numpy()[:, :3], ref.mobility(to4(pos), to4(force)).cpu().numpy()[:, :3]) < 1e-13

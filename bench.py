@@ -79,9 +79,11 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "PSE_FORCE_SHARDED" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import pse_amd
     from pse_amd import distributed as pdist
@@ -95,7 +97,7 @@ def main():
     info = sim.info()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -127,8 +129,9 @@ def main():
         t = torch.tensor([elapsed, t_mf], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, t_mf = float(t[0]), float(t[1])
+    info = sim.info()
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -183,7 +186,7 @@ def main():
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

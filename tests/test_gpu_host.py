@@ -1,0 +1,77 @@
+"""GPU tests of the host layer: the C++ Stokes class (module _PSEv1) and the mirrored Python UI drive the same C-ABI
+step as the raw engine, and the example script runs."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import make_suspension, to4
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_ui_run_matches_raw_engine_and_oracle(oracle):
+    import torch
+    import pse_amd
+    from pse_amd import integrate, shear_function, variant
+    from pse_amd.system import System
+    n = 1000
+    pos, _, box = make_suspension(n, phi=0.1)
+    dt, seed = 1e-2, 3
+    system = System(pos, box, dt=dt)
+    f = shear_function.sine(dt=dt, shear_rate=2.0, shear_freq=5.0)
+    system.box_tilt_variant = variant.shear_variant(f, 100, max_strain=0.5)
+    integ = integrate.PSEv1(group=system.all(), T=1.0, seed=seed, xi=0.5, error=1e-3, function_form=f)
+    assert abs(integ.rcut - oracle.select_params(box, 0.5, 1e-3)["rcut"]) < 1e-12
+
+    # the same three steps through the raw engine, with the box tilt and shear rate taken from the oracle's formulas
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3, seed=oracle.hash_seed(seed))
+    rp, rv = to4(pos), to4(np.zeros((n, 3)), 1.0)
+    rF = torch.zeros((n, 4), dtype=torch.float64, device="cuda")
+    ra = torch.zeros((n, 3), dtype=torch.float64, device="cuda"); ri = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+    sf = oracle.SinShear(2.0, 5.0, 0, dt)
+    m = 2
+    cur_xy = 0.0
+    for t in range(3):
+        xy = oracle.variant_value(sf, t, 100, -0.5, 0.5)
+        if xy != cur_xy:
+            fl = torch.floor((rp[:, 0] - xy * rp[:, 1]) / box[0] + 0.5)
+            rp[:, 0] -= fl * box[0]; ri[:, 0] += fl.to(torch.int32)
+            eng.set_box(box[0], box[1], box[2], xy); cur_xy = xy
+        m = eng.step(rp, rv, ra, ri, rF, 1.0, dt, t, shear_rate=sf.shear_rate(t), lanczos_m=m)
+    system.run(3)
+    assert system.timestep == 3
+    assert np.abs(system.pos.cpu().numpy() - rp.cpu().numpy()).max() < 1e-12
+    assert np.array_equal(system.image.cpu().numpy(), ri.cpu().numpy())
+    assert integ.cpp_method.lanczosIterations() == m
+    assert abs(system.box[3] - oracle.variant_value(sf, 2, 100, -0.5, 0.5)) < 1e-15
+
+
+def test_set_params_and_stop_shear():
+    from pse_amd import integrate, shear_function
+    from pse_amd.system import System
+    system = System.create_lattice_sc(a=6.4, n=6, dt=1e-3)
+    integ = integrate.PSEv1(group=system.all(), T=0.0, seed=1, xi=0.5, error=1e-3,
+                            function_form=shear_function.steady(dt=1e-3, shear_rate=1.0))
+    p0 = system.pos.clone()
+    system.run(1)
+    moved = (system.pos - p0)[:, 0].abs().max().item()
+    assert moved > 1e-3                    # pure affine shear (kT = 0, no forces): dx = rate * y * dt
+    integ.stop_shear()
+    p1 = system.pos.clone()
+    system.run(1)
+    assert (system.pos - p1).abs().max().item() == 0.0
+    integ.set_params(T=1.0)
+    system.run(1)
+    assert (system.pos - p1).abs().max().item() > 0.0
+
+
+def test_example_script_runs():
+    env = dict(os.environ, PSE_EXAMPLE_STEPS="5")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "run.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ran 5 steps" in r.stdout

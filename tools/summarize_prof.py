@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 CSV output (gpurun_out/...) into the small summaries committed under profiles/.
+
+  python tools/summarize_prof.py stats  <kernel_stats.csv> <out.csv> "<command line that was profiled>"
+  python tools/summarize_prof.py pmc    <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+"""
+import collections
+import csv
+import json
+import sys
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")[:80]
+
+
+def stats(src, dst, cmd):
+    rows = list(csv.DictReader(open(src)))
+    with open(dst, "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats -- {cmd}\n")
+        f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n")
+        for r in rows[:32]:
+            f.write(f"\"{short(r['Name'])}\",{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']}\n")
+
+
+def pmc(fetch_csv, write_csv, dst):
+    def agg(path, counter):
+        d = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter:
+                d[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        return {k: sum(v) / len(v) for k, v in d.items()}
+    f, w = agg(fetch_csv, "FETCH_SIZE"), agg(write_csv, "WRITE_SIZE")
+    out = {"_note": "per-launch averages, bytes. FETCH_SIZE/WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts a 128-B "
+                    "request as 64 B for wide (16 B/lane) streaming reads, so fetch_x2 is the corrected figure for kernels that read with "
+                    "dwordx4 (k_scale, k_lz_*, FFT); for 4/8-B-per-lane loads (k_mreal_list, k_gather_p) the factor is uncalibrated "
+                    "and both are given (/opt/skills/guides/MI355X_MICROARCH.md, HBM section)."}
+    for k in sorted(set(f) | set(w)):
+        out[k] = {"fetch_raw": f.get(k, 0.0) * 1024, "fetch_x2": 2 * f.get(k, 0.0) * 1024, "write": w.get(k, 0.0) * 1024}
+    json.dump(out, open(dst, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3], sys.argv[4])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])

@@ -188,7 +188,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->plan_x_inv) rocfft_plan_destroy(h->plan_x_inv);
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
-    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->sup_s, h->nb.j, h->nb.fh, h->nb.dx, h->nb.dy, h->nb.dz, h->nb.cnt, h->pos_s,
+    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->sup_s, h->nb.j, h->nb.f, h->nb.dx, h->nb.dy, h->nb.dz, h->nb.cnt, h->pos_s,
                     h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->fft_work, h->V,
                     h->scal, h->partials, h->t_dev};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -301,11 +301,11 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         const double nbar = (double)n / vol * 4.18879020478639 * d.rcut * d.rcut * d.rcut;
         int cap = (int)std::ceil(1.5 * nbar + 16.0);
         cap = std::max(16, std::min(cap, 256));
-        const double bytes = (double)cap * (double)n * 44.0;
+        const double bytes = (double)cap * (double)n * 36.0;
         if (bytes > 32e9 || n >= ((size_t)1 << 27)) cap = 0;   // too large: mat-vecs always walk the cells
         h->nb.cap = cap; h->nb.stride = n;   // n is the padded capacity
         if (cap > 0) {
-            TRY(dmalloc(h, &h->nb.j, (size_t)cap * n)); TRY(dmalloc(h, &h->nb.fh, (size_t)cap * n));
+            TRY(dmalloc(h, &h->nb.j, (size_t)cap * n)); TRY(dmalloc(h, &h->nb.f, (size_t)cap * n));
             TRY(dmalloc(h, &h->nb.dx, (size_t)cap * n)); TRY(dmalloc(h, &h->nb.dy, (size_t)cap * n));
             TRY(dmalloc(h, &h->nb.dz, (size_t)cap * n));
         }

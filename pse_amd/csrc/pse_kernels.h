@@ -23,8 +23,8 @@ void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double
 // per-step pair list in ELL layout (slot-major): entry (slot, i) at slot*stride + i
 struct NbList {
     unsigned *j;
-    double2 *fh;          // f, (g - f)/r^2
-    double *dx, *dy, *dz; // minimum-image separation r_i - r_j
+    double *f;            // transverse coefficient f(r)
+    double *dx, *dy, *dz; // sqrt(|h|) (r_i - r_j), h = (g - f)/r^2; sign(h) is bit 31 of j
     int *cnt;             // true neighbour count per particle (may exceed cap: that particle falls back to the cells)
     int cap;
     size_t stride;

@@ -219,9 +219,11 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec
             if (LIST) {
                 if (total < nb.cap) {
                     const size_t o = (size_t)total * nb.stride + i;
-                    nb.j[o] = (unsigned)j;
-                    nb.fh[o] = make_double2(f, h);
-                    nb.dx[o] = dx; nb.dy[o] = dy; nb.dz[o] = dz;
+                    // 36 B per pair: h = (g-f)/r^2 is folded into the separation, its sign rides on bit 31 of j
+                    const double q = sqrt(fabs(h));
+                    nb.j[o] = (unsigned)j | (h < 0.0 ? 0x80000000u : 0u);
+                    nb.f[o] = f;
+                    nb.dx[o] = q * dx; nb.dy[o] = q * dy; nb.dz[o] = q * dz;
                 }
                 ++total;
             }
@@ -272,14 +274,15 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
 #pragma unroll 4
         for (int s = 0; s < cnt; ++s) {
             const size_t o = (size_t)s * nb.stride + i;
-            const unsigned j = nb.j[o];
-            const double2 fh = nb.fh[o];
-            const double dx = nb.dx[o], dy = nb.dy[o], dz = nb.dz[o];
-            const double4 Fj = vec_s[j];
-            const double rdF = (dx * Fj.x + dy * Fj.y + dz * Fj.z) * fh.y;
-            ux += fh.x * Fj.x + rdF * dx;
-            uy += fh.x * Fj.y + rdF * dy;
-            uz += fh.x * Fj.z + rdF * dz;
+            const unsigned je = nb.j[o];
+            const double f = nb.f[o];
+            const double dx = nb.dx[o], dy = nb.dy[o], dz = nb.dz[o];   // sqrt(|h|) r
+            const double4 Fj = vec_s[je & 0x7FFFFFFFu];
+            double rdF = dx * Fj.x + dy * Fj.y + dz * Fj.z;
+            rdF = (je & 0x80000000u) ? -rdF : rdF;
+            ux += f * Fj.x + rdF * dx;
+            uy += f * Fj.y + rdF * dy;
+            uz += f * Fj.z + rdF * dz;
         }
     } else {
         const double4 pi = pos_s[i];
@@ -370,7 +373,7 @@ k_spread_atomic(const double4 *__restrict__ pos_s, const double4 *__restrict__ f
         const double ey = G.hy * (d0y + ty);
         const double ex = G.hx * (d0x + tx) + box.xy * ey;   // sheared lattice (PSEv1/Mobility.cu:230)
         const double ez = G.hz * (d0z + tz);
-        const double w = G.prefac * exp(-G.expfac * (ex * ex + ey * ey + ez * ez));
+        const double w = G.prefac * exp_neg(-G.expfac * (ex * ex + ey * ey + ez * ez));
         const size_t idx = ((size_t)lx * G.Ny + iy) * G.Nz + iz;
         unsafeAtomicAdd(&gx[idx], w * F.x);
         unsafeAtomicAdd(&gy[idx], w * F.y);
@@ -390,16 +393,15 @@ struct WaveWeights {
         r1 = (P * P + P > 64) ? entry(lane + 64, G, box, d0x, d0y, d0z) : 0.0;
     }
     __device__ __forceinline__ static double entry(int e, const DGrid &G, const DBox &box, double d0x, double d0y, double d0z) {
-        if (e < P * P) {
-            const int tx = e / P, ty = e - tx * P;
-            const double ey = G.hy * (d0y + ty), ex = G.hx * (d0x + tx) + box.xy * ey;
-            return exp(-G.expfac * (ex * ex + ey * ey));
-        }
-        if (e < P * P + P) {
-            const double ez = G.hz * (d0z + (e - P * P));
-            return exp(-G.expfac * ez * ez);
-        }
-        return 0.0;
+        // branch-free: lanes holding an A entry and lanes holding a B entry pick their squared distance with selects and
+        // share ONE exponential (a divergent if/else would run two)
+        const bool isA = e < P * P;
+        const int tx = e / P, ty = e - tx * P;
+        const double ey = G.hy * (d0y + ty), ex = G.hx * (d0x + tx) + box.xy * ey;
+        const double ez = G.hz * (d0z + (e - P * P));
+        const double r2 = isA ? ex * ex + ey * ey : ez * ez;
+        const double v = exp_neg(-G.expfac * r2);
+        return e < P * P + P ? v : 0.0;
     }
     __device__ __forceinline__ double get(int tx, int ty, int tz) const {
         const double a = __shfl(r0, tx * P + ty, 64);          // P <= 8: every A entry is in r0
@@ -625,7 +627,7 @@ k_gather_p(const double4 *__restrict__ pos_s, int N, const double *__restrict__ 
         int iy = sy + ty; iy = iy < 0 ? iy + G.Ny : (iy >= G.Ny ? iy - G.Ny : iy);
         int iz = sz + tz; iz = iz < 0 ? iz + G.Nz : (iz >= G.Nz ? iz - G.Nz : iz);
         if (on) {
-            const size_t idx = ((size_t)lx * G.Ny + iy) * G.Nz + iz;
+            const unsigned idx = ((unsigned)lx * G.Ny + iy) * G.Nz + iz;   // a slab has < 2^32 nodes (grid <= 1024^3 checked at create)
             ux += w * gx[idx];
             uy += w * gy[idx];
             uz += w * gz[idx];
@@ -668,7 +670,7 @@ k_gather(const double4 *__restrict__ pos_s, int N, const double *__restrict__ gx
         const double ey = G.hy * (d0y + ty);
         const double ex = G.hx * (d0x + tx) + box.xy * ey;
         const double ez = G.hz * (d0z + tz);
-        const double w = exp(-G.expfac * (ex * ex + ey * ey + ez * ez));
+        const double w = exp_neg(-G.expfac * (ex * ex + ey * ey + ez * ez));
         const size_t idx = ((size_t)lx * G.Ny + iy) * G.Nz + iz;
         ux += w * gx[idx];
         uy += w * gy[idx];
@@ -712,7 +714,7 @@ __device__ __forceinline__ KOp make_kop(int i, int j, int k, const DGrid &G, con
     o.k2 = o.kx * o.kx + o.ky * o.ky + o.kz * o.kz;
     const double q = o.k2 / (4.0 * xi * xi);
     const double ng = (double)G.Nx * (double)G.Ny * (double)G.Nz;
-    const double w = 6.0 * M_PI * (1.0 + q) * exp(-(1.0 - eta) * q) / (o.k2 * ng);   // Helper.cu:326
+    const double w = 6.0 * M_PI * (1.0 + q) * exp_neg(-(1.0 - eta) * q) / (o.k2 * ng);   // Helper.cu:326
     const double kn = sqrt(o.k2);
     const double sinc = sin(kn) / kn;                                                 // Mobility.cu:290 (a = 1)
     o.B = w * sinc * sinc;

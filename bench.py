@@ -143,22 +143,28 @@ def main():
     # algorithmic bytes per launch (BASELINE.md section 3 / SURVEY.md 8d), per rank
     alg = {
         "t_spread": 64 * nloc + 24 * ngloc, "t_fft_fwd": 48 * ngloc, "t_scale": 48 * ngloc, "t_fft_inv": 48 * ngloc,
-        "t_gather": 24 * ngloc + 64 * nloc, "t_real": 96 * nloc,
+        "t_gather": 24 * ngloc + 64 * nloc, "t_real": 96 * nloc, "t_matvec": 96 * nloc,
     }
-    launches = {k: 1 for k in alg}
-    per_launch_ms = {k: phases.get(k, 0.0) / launches[k] for k in alg}
-    # which kernel dominates the step: the near-field mat-vec runs once for M.F and once per Lanczos iteration
+    per_launch_ms = {k: phases.get(k, 0.0) for k in alg}
+    # share of the step: the pair-list mat-vec runs once per Lanczos iteration (the first iteration rebuilds from cells)
     weight = dict(per_launch_ms)
-    weight["t_real"] = per_launch_ms["t_real"] * (1 + info["lanczos_matvecs"])
+    weight["t_matvec"] = per_launch_ms["t_matvec"] * max(1, info["lanczos_matvecs"])
     dom = max(weight, key=weight.get)
-    names = {"t_spread": "spread", "t_fft_fwd": "rocFFT forward x3", "t_scale": "k-space scale+noise",
-             "t_fft_inv": "rocFFT inverse x3", "t_gather": "gather", "t_real": "near-field M_real mat-vec"}
+    names = {"t_spread": "k_spread_tile (spread)", "t_fft_fwd": "rocFFT R2C x3", "t_scale": "k_scale (k-space scale+noise)",
+             "t_fft_inv": "rocFFT C2R x3", "t_gather": "k_gather_p (gather)",
+             "t_real": "k_mreal_cells (near-field M_real.F from the cell list, writes the pair list)",
+             "t_matvec": "k_mreal_list (near-field mat-vec from the pair list, once per Lanczos iteration)"}
+    pmc_names = {"t_spread": "pse::k_spread_tile", "t_scale": "pse::k_scale", "t_gather": "pse::k_gather_p",
+                 "t_real": "pse::k_mreal_cells<true>", "t_matvec": "pse::k_mreal_list"}
     ach = alg[dom] / (per_launch_ms[dom] * 1e-3) / 1e9 if per_launch_ms[dom] > 0 else 0.0
     traffic = None
-    tr_file = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tr_file):
+    tr_file = os.path.join(ROOT, "profiles", "traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/summarize_prof.py
+    if os.path.exists(tr_file) and world == 1 and n == 1_000_000 and grid == 256:
         try:
-            traffic = json.load(open(tr_file)).get(dom)
+            tj = json.load(open(tr_file))
+            for k, v in tj.items():
+                if k.startswith(pmc_names.get(dom, "?")):
+                    traffic = v["fetch_raw"] + v["write"]     # bytes per launch (reads uncorrected: lower bound)
         except Exception:
             traffic = None
     sg_ms = per_launch_ms["t_spread"] + per_launch_ms["t_gather"]
@@ -182,6 +188,7 @@ def main():
         "phases_ms_per_step": {k[2:]: round(v, 4) for k, v in phases.items()},
         "phase_hbm_frac": {k[2:]: round(alg[k] / (per_launch_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                            for k in alg if per_launch_ms[k] > 0},
+        "step_share_ms": {k[2:]: round(v, 4) for k, v in weight.items()},
     }
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline()

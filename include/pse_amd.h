@@ -66,6 +66,7 @@ typedef struct pse_info {
     /* device time of the phases of the most recent call, ms (hipEvent, only if timing enabled) */
     double t_sort, t_spread, t_fft_fwd, t_scale, t_fft_inv, t_gather, t_real, t_lanczos, t_integrate, t_comm, t_total;
     unsigned long long device_bytes;  /* workspace owned by the handle */
+    double t_matvec;                  /* one near-field mat-vec from the per-step pair list (inside t_lanczos) */
 } pse_info;
 
 /* -- life cycle: replaces Stokes::Stokes/setParams/~Stokes (PSEv1/Stokes.cc:85-118,129-424) ------------- */

@@ -327,3 +327,32 @@ int pse_oracle_max_threads(void) {
     return 1;
 #endif
 }
+
+/* rows of the cutoff near-field sum for a subset of particles (full-size parity checks: O(nrows * N)) */
+int pse_oracle_mreal_cutoff_rows(int N, const double *pos, const double *force, const double *box, double xi, double rcut,
+                                 int nrows, const int *rows, double *vel, int nthreads) {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    double Lx = box[0], Ly = box[1], Lz = box[2], xy = box[3];
+    double self = pse_oracle_self(xi);
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (int q = 0; q < nrows; ++q) {
+        int i = rows[q];
+        double u[3] = { self * force[3 * i], self * force[3 * i + 1], self * force[3 * i + 2] };
+        for (int j = 0; j < N; ++j) {
+            if (j == i) continue;
+            double r[3] = { pos[3 * i] - pos[3 * j], pos[3 * i + 1] - pos[3 * j + 1], pos[3 * i + 2] - pos[3 * j + 2] };
+            double s2 = round(r[1] / Ly); r[1] -= s2 * Ly; r[0] -= s2 * xy * Ly;
+            r[0] -= round(r[0] / Lx) * Lx; r[2] -= round(r[2] / Lz) * Lz;
+            double b2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+            if (b2 >= rcut * rcut || b2 == 0.0) continue;   /* rcut <= half the perpendicular widths: the reduced vector is the image */
+            double f, g; pse_oracle_fg_real(sqrt(b2), xi, &f, &g);
+            const double *F = force + 3 * j;
+            double rdF = (r[0] * F[0] + r[1] * F[1] + r[2] * F[2]) / b2;
+            for (int p = 0; p < 3; ++p) u[p] += f * F[p] + (g - f) * rdF * r[p];
+        }
+        vel[3 * q] = u[0]; vel[3 * q + 1] = u[1]; vel[3 * q + 2] = u[2];
+    }
+    return 0;
+}

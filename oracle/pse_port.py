@@ -102,6 +102,16 @@ def mobility_real(pos, force, box, xi, rcut, nthreads=0):
     return out
 
 
+def mobility_real_rows(pos, force, box, xi, rcut, rows, nthreads=0):
+    """Rows `rows` of the near-field sum (for parity checks at sizes where all rows would take too long)."""
+    pos = np.ascontiguousarray(pos, float); force = np.ascontiguousarray(force, float)
+    box = np.ascontiguousarray(box, float); rows = np.ascontiguousarray(rows, np.int32)
+    out = np.zeros((len(rows), 3))
+    lib().pse_oracle_mreal_cutoff_rows(len(pos), _p(pos), _p(force), _p(box), ctypes.c_double(xi), ctypes.c_double(rcut),
+                                       len(rows), rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _p(out), int(nthreads))
+    return out
+
+
 def max_threads():
     return lib().pse_oracle_max_threads()
 

@@ -40,6 +40,7 @@ class pse_info(ctypes.Structure):
         ("t_real", ctypes.c_double), ("t_lanczos", ctypes.c_double), ("t_integrate", ctypes.c_double),
         ("t_comm", ctypes.c_double), ("t_total", ctypes.c_double),
         ("device_bytes", ctypes.c_ulonglong),
+        ("t_matvec", ctypes.c_double),
     ]
 
     def as_dict(self):

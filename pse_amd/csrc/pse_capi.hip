@@ -93,9 +93,10 @@ struct pse_handle {
     // bookkeeping
     pse_info info;
     bool timing = false;
-    Phase ph[11];
+    Phase ph[12];
     unsigned long long bytes = 0;
     int sorted_N = 0;
+    bool matvec_timed = false;
 };
 
 static std::once_flag g_fft_once;
@@ -133,15 +134,15 @@ static int set_cells(pse_handle *h, double gamma) {
 
 static int ts(pse_handle *h, int p) { if (h->timing) HIPCHK(hipEventRecord(h->ph[p].a, h->stream)); return 0; }
 static int te(pse_handle *h, int p) { if (h->timing) HIPCHK(hipEventRecord(h->ph[p].b, h->stream)); return 0; }
-enum { PH_SORT, PH_SPREAD, PH_FFTF, PH_SCALE, PH_FFTI, PH_GATHER, PH_REAL, PH_LANCZOS, PH_INTEG, PH_COMM, PH_TOTAL };
+enum { PH_SORT, PH_SPREAD, PH_FFTF, PH_SCALE, PH_FFTI, PH_GATHER, PH_REAL, PH_LANCZOS, PH_INTEG, PH_COMM, PH_TOTAL, PH_MATVEC };
 
 static int collect_times(pse_handle *h, unsigned mask) {
     if (!h->timing) return 0;
     HIPCHK(hipStreamSynchronize(h->stream));
-    double *dst[11] = {&h->info.t_sort, &h->info.t_spread, &h->info.t_fft_fwd, &h->info.t_scale, &h->info.t_fft_inv,
+    double *dst[12] = {&h->info.t_sort, &h->info.t_spread, &h->info.t_fft_fwd, &h->info.t_scale, &h->info.t_fft_inv,
                        &h->info.t_gather, &h->info.t_real, &h->info.t_lanczos, &h->info.t_integrate, &h->info.t_comm,
-                       &h->info.t_total};
-    for (int p = 0; p < 11; ++p) {
+                       &h->info.t_total, &h->info.t_matvec};
+    for (int p = 0; p < 12; ++p) {
         *dst[p] = 0.0;
         if (mask & (1u << p)) {
             float ms = 0;
@@ -643,7 +644,10 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io) {
     double stepnorm = 1.0;
     while (true) {
         for (; done < target; ++done) {
+            const bool timed = done == 1 && h0->nb_valid;   // one pair-list mat-vec per call is timed on its own
+            if (timed) for (pse_handle *h : T.m) TRY(ts(h, PH_MATVEC));
             TRY(real(T, &pse_handle::V, &pse_handle::w_s, (size_t)done * stride, 0, N, true));
+            if (timed) for (pse_handle *h : T.m) { TRY(te(h, PH_MATVEC)); h->matvec_timed = true; }
             for (pse_handle *h : T.m)
                 launch_lz_iter(h->w_s, h->V + (size_t)done * stride, done > 0 ? h->V + (size_t)(done - 1) * stride : nullptr,
                                h->V + (size_t)(done + 1) * stride, done, h->scal, h->partials, N, h->stream);
@@ -719,9 +723,11 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
             TRY(ts(h, PH_LANCZOS));
             launch_psi(h->psi_s, h->tag_s, N, h->par.seed, timestep, h->stream);
         }
+        for (pse_handle *h : T.m) h->matvec_timed = false;
         TRY(lanczos(T, N, T.m[0]->d.error, std::sqrt(2.0 * kT / dt), m_io));
         for (pse_handle *h : T.m) TRY(te(h, PH_LANCZOS));
         *mask |= 1u << PH_LANCZOS;
+        if (T.m[0]->matvec_timed) *mask |= 1u << PH_MATVEC;
     }
     for (size_t r = 0; r < T.m.size(); ++r) {
         pse_handle *h = T.m[r];

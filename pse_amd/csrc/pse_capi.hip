@@ -69,6 +69,7 @@ struct pse_handle {
     size_t sort_tmp_bytes = 0;
     int *cell_off = nullptr;
     int4 *sup_s = nullptr;    // support origin of each sorted particle (node indices)
+    SpreadWork sw = {};       // separable weights + per-tile hit lists of the far field
     NbList nb = {};
     bool nb_valid = false;   // the pair list matches the current sorted positions
     size_t n_cells_alloc = 0;
@@ -189,7 +190,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->plan_x_inv) rocfft_plan_destroy(h->plan_x_inv);
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
-    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->sup_s, h->nb.j, h->nb.f, h->nb.dx, h->nb.dy, h->nb.dz, h->nb.cnt, h->pos_s,
+    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->sup_s, h->sw.wtab, h->sw.d0_s, h->nb.j, h->nb.f, h->nb.dx, h->nb.dy, h->nb.dz, h->nb.cnt, h->pos_s,
                     h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->fft_work, h->V,
                     h->scal, h->partials, h->t_dev};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -297,6 +298,10 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     }
     TRY(dmalloc(h, &h->cell_off, h->n_cells_alloc + 1));
     TRY(dmalloc(h, &h->sup_s, n));
+    if (d.P >= 4 && d.P <= 8) {   // fast far-field path: support offsets + separable weights (padded: idle lanes read past the end)
+        TRY(dmalloc(h, &h->sw.d0_s, n));
+        TRY(dmalloc(h, &h->sw.wtab, n * (size_t)(d.P * d.P + d.P) + 128));
+    }
     {   // per-step pair list for the Lanczos mat-vecs: capacity from the mean neighbour count at full occupancy
         const double vol = h->box.Lx * h->box.Ly * h->box.Lz;
         const double nbar = (double)n / vol * 4.18879020478639 * d.rcut * d.rcut * d.rcut;
@@ -535,7 +540,7 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
         double *gx = h->rgrid, *gy = h->rgrid + nr, *gz = h->rgrid + 2 * nr;
         TRY(ts(h, PH_SPREAD));
         if (spread_needs_zero(G)) HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->stream));
-        launch_spread(h->pos_s, h->f_s, h->sup_s, N, h->cell_off, h->nc, gx, gy, gz, G, h->dbox, h->stream);
+        launch_spread(h->pos_s, h->f_s, h->sup_s, N, h->cell_off, h->nc, gx, gy, gz, G, h->dbox, h->sw, h->stream);
         TRY(te(h, PH_SPREAD));
         TRY(ts(h, PH_FFTF));
         if (T.G == 1) {
@@ -599,7 +604,7 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
         const DGrid &G = h->G;
         const size_t nr = (size_t)(G.nxl + G.nhalo) * G.Ny * G.Nz;
         TRY(ts(h, PH_GATHER));
-        launch_gather(h->pos_s, N, h->rgrid, h->rgrid + nr, h->rgrid + 2 * nr, G, h->dbox, h->uw_s, h->stream);
+        launch_gather(h->pos_s, h->sup_s, h->sw.wtab, h->cell_off, h->nc, N, h->rgrid, h->rgrid + nr, h->rgrid + 2 * nr, G, h->dbox, h->uw_s, h->stream);
         TRY(te(h, PH_GATHER));
         HIPCHK(hipGetLastError());
     }

@@ -36,10 +36,15 @@ void launch_mreal(const double4 *pos_s, const double4 *vec_s, double4 *out_s, in
                   DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, int mode, hipStream_t s);
 
 // ---- far field (K2-K8) -----------------------------------------------------------------------------------
-// returns true if the caller must zero the grids first (atomic fallback for grids smaller than a tile + support)
+// scratch of the fast far-field path (rebuilt every call): support offsets and the per-particle separable weights
+struct SpreadWork {
+    double4 *d0_s;              // [N] offset of the support origin from the particle, grid units
+    double *wtab;               // [N][P^2 + P] (+ padding)
+};
+// true if the caller must zero the grids first (atomic fallback: P outside 4..8 or a grid smaller than two tiles)
 bool spread_needs_zero(const DGrid &G);
 void launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, const int *cell_off, DCells nc,
-                   double *gx, double *gy, double *gz, DGrid G, DBox box, hipStream_t s);
+                   double *gx, double *gy, double *gz, DGrid G, DBox box, SpreadWork w, hipStream_t s);
 struct ScaleArgs {
     double xi, eta;
     int noise;               // add k-space Brownian noise (K6)
@@ -49,8 +54,9 @@ struct ScaleArgs {
     int y0, nyl;             // slab of y rows in transposed layout
 };
 void launch_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, hipStream_t s);
-void launch_gather(const double4 *pos_s, int N, const double *gx, const double *gy, const double *gz, DGrid G,
-                   DBox box, double4 *u_s, hipStream_t s);
+// the fast path reads sup_s / wtab written by launch_spread of the same step
+void launch_gather(const double4 *pos_s, const int4 *sup_s, const double *wtab, const int *cell_off, DCells nc, int N,
+                   const double *gx, const double *gy, const double *gz, DGrid G, DBox box, double4 *u_s, hipStream_t s);
 
 // ---- slab decomposition helpers
 void launch_slab_pack(double2 *cgrid, double2 *buf, int nxl, int Ny, int Nzh, int nyl, int unpack, hipStream_t s);

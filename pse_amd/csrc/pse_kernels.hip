@@ -381,145 +381,207 @@ k_spread_atomic(const double4 *__restrict__ pos_s, const double4 *__restrict__ f
     }
 }
 
-// ---- separable Gaussian weights held across the lanes of a wave ------------------------------------------------
+// ---- separable Gaussian weights, computed once per particle and step -----------------------------------------
 // w(tx,ty,tz) = A[tx][ty] B[tz] with A = exp(-c (ex^2 + ey^2)) (x and y couple through the shear,
-// PSEv1/Mobility.cu:230) and B = exp(-c ez^2): P^2 + P exponentials per particle instead of P^3, evaluated one per
-// lane and fetched by the lanes that need them with ds_bpermute (__shfl).  Entry e lives in register e / 64, lane e % 64.
-template <int P>
-struct WaveWeights {
-    double r0, r1;
-    __device__ __forceinline__ void stage(int lane, const DGrid &G, const DBox &box, double d0x, double d0y, double d0z) {
-        r0 = entry(lane, G, box, d0x, d0y, d0z);
-        r1 = (P * P + P > 64) ? entry(lane + 64, G, box, d0x, d0y, d0z) : 0.0;
-    }
-    __device__ __forceinline__ static double entry(int e, const DGrid &G, const DBox &box, double d0x, double d0y, double d0z) {
-        // branch-free: lanes holding an A entry and lanes holding a B entry pick their squared distance with selects and
-        // share ONE exponential (a divergent if/else would run two)
-        const bool isA = e < P * P;
-        const int tx = e / P, ty = e - tx * P;
-        const double ey = G.hy * (d0y + ty), ex = G.hx * (d0x + tx) + box.xy * ey;
-        const double ez = G.hz * (d0z + (e - P * P));
-        const double r2 = isA ? ex * ex + ey * ey : ez * ez;
-        const double v = exp_neg(-G.expfac * r2);
-        return e < P * P + P ? v : 0.0;
-    }
-    __device__ __forceinline__ double get(int tx, int ty, int tz) const {
-        const double a = __shfl(r0, tx * P + ty, 64);          // P <= 8: every A entry is in r0
-        const int eb = P * P + tz;
-        const double b = (P * P + P > 64) ? (eb < 64 ? __shfl(r0, eb, 64) : __shfl(r1, eb - 64, 64)) : __shfl(r0, eb, 64);
-        return a * b;
-    }
-};
-
-// Tile-owned spread: one workgroup owns a TXxTYxTZ block of grid nodes, accumulates every contribution to it in LDS
-// (ds_add_f64) and writes each node exactly once with plain stores -- no global atomics (1.3 TB/s chip-wide on MI355X:
-// the 7.6 ms of the v0 kernel), no ZeroGrid pass (K2).  Contributing particles are found through the near-field cell
-// list (cells and grid share the same fractional coordinates, so this also holds in a sheared box); their support
-// origins were precomputed by k_support.  One wave per (particle, tile) pair, lanes over the clipped support box.
-__device__ __forceinline__ int floordiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
-
-__global__ void k_support(const double4 *__restrict__ pos_s, int N, DGrid G, DBox box, int4 *__restrict__ sup_s) {
+// PSEv1/Mobility.cu:230) and B = exp(-c ez^2): P^2 + P exponentials per particle instead of P^3.  k_support finds the
+// support origin and its offset from the particle once; k_weights evaluates the table with one lane per entry (no idle
+// lanes, one lean exponential each) into wtab[N][P^2+P].  The ~3 spread hits of a particle and its gather read the
+// table instead of redoing the arithmetic per (particle, tile) pair -- rocprofv3 showed both kernels bound by VALU issue.
+__global__ void k_support(const double4 *__restrict__ pos_s, int N, DGrid G, DBox box, int4 *__restrict__ sup_s,
+                          double4 *__restrict__ d0_s) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N) return;
     const double4 p = pos_s[s];
-    double fx, fy, fz, d;
+    double fx, fy, fz;
     frac_coords(box, p.x, p.y, p.z, fx, fy, fz);
     int4 o;
-    support_start(fx, G.Nx, G.P, o.x, d);
-    support_start(fy, G.Ny, G.P, o.y, d);
-    support_start(fz, G.Nz, G.P, o.z, d);
-    o.w = 0;
+    double4 d;
+    support_start(fx, G.Nx, G.P, o.x, d.x);   // PSEv1/Mobility.cu:212-214
+    support_start(fy, G.Ny, G.P, o.y, d.y);
+    support_start(fz, G.Nz, G.P, o.z, d.z);
+    o.w = 0; d.w = 0.0;
     sup_s[s] = o;
+    if (d0_s) d0_s[s] = d;
 }
 
-template <int P, int TX, int TY, int TZ, int NT>
-__global__ void __launch_bounds__(NT)
-k_spread_tile(const double4 *__restrict__ pos_s, const double4 *__restrict__ f_s, const int4 *__restrict__ sup_s,
-              const int *__restrict__ cell_off, DCells nc, double *__restrict__ gx, double *__restrict__ gy,
-              double *__restrict__ gz, DGrid G, DBox box, int ntx, int nty, int ntz) {
-    // x-planes are TY*TZ doubles apart, a multiple of the 64-bank row: pad each plane so lanes that differ only in x
-    // do not hit the same bank in the ds_add_f64
-    constexpr int XS = TY * TZ + 2, NODES = TX * XS, NW = NT / 64;
-    __shared__ double acc[3 * NODES];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    int b = xcd_block(blockIdx.x, gridDim.x);
-    const int tz = b % ntz; b /= ntz;
-    const int ty = b % nty; b /= nty;
-    const int tx = b;
-    const int t0[3] = {G.x0 + tx * TX, ty * TY, tz * TZ};
-    const int ext[3] = {min(TX, G.x0 + G.nxl - t0[0]), min(TY, G.Ny - t0[1]), min(TZ, G.Nz - t0[2])};
-    const int Nn[3] = {G.Nx, G.Ny, G.Nz};
-    const int ncd[3] = {nc.nx, nc.ny, nc.nz};
-    for (int n = tid; n < 3 * NODES; n += NT) acc[n] = 0.0;
-    __syncthreads();
+template <int P>
+__global__ void __launch_bounds__(TPB)
+k_weights(const double4 *__restrict__ d0_s, int N, DGrid G, DBox box, double *__restrict__ wtab) {
+    constexpr int WT = P * P + P;
+    const size_t gid = (size_t)blockIdx.x * TPB + threadIdx.x;
+    const int p = (int)(gid / WT), e = (int)(gid - (size_t)p * WT);
+    if (p >= N) return;
+    const double4 d0 = d0_s[p];
+    // branch-free: A entries and B entries pick their squared distance with selects and share ONE exponential
+    const bool isA = e < P * P;
+    const int tx = e / P, ty = e - tx * P;
+    const double ey = G.hy * (d0.y + ty), ex = G.hx * (d0.x + tx) + box.xy * ey;
+    const double ez = G.hz * (d0.z + (e - P * P));
+    wtab[gid] = exp_neg(-G.expfac * (isA ? ex * ex + ey * ey : ez * ez));
+}
 
-    // cells that can hold a contributing particle: floor(s) in [t0 - ceil(P/2), t0 + ext - 1 + P/2]  (node units)
-    int clo[3], ccnt[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const int lo = t0[a] - (P + 1) / 2, hi = t0[a] + ext[a] - 1 + P / 2;
-        const int c0 = floordiv(lo * ncd[a], Nn[a]);
-        const int c1 = floordiv((hi + 1) * ncd[a], Nn[a]);
-        clo[a] = c0;
-        ccnt[a] = min(c1 - c0 + 1, ncd[a]);
-    }
-    const double prefac = G.prefac;
+// ---- per-tile particle lists built in LDS --------------------------------------------------------------------------
+// A workgroup that owns a block of grid nodes needs the particles whose support touches it (spread) or starts in it
+// (gather).  They sit in a box of cells around the tile; the cells of one (x,y) column are one or two contiguous slot
+// runs of the sorted particle arrays.  All threads cooperate: one thread per run builds the run table, a block scan
+// turns lengths into offsets, then ONE THREAD PER CANDIDATE tests it and appends survivors to an LDS list -- 64x fewer
+// instructions than testing one candidate per wave, and no global hit lists (whose same-address atomics cost 0.37 ms).
+constexpr int RMAX = 256;         // runs per chunk (= threads of the tile kernels)
+constexpr int LCAP = 512;         // candidates per chunk, hence the list capacity
+
+struct TileList {
+    int run_b[RMAX];
+    int run_o[RMAX + 1];
+    int wsum[4];
+    int list[LCAP];
+    int n;
+};
+
+__device__ __forceinline__ int floordiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+// cells [clo, clo+ccnt) per axis (unwrapped) that can hold particles with floor(s) in [lo, hi] node units
+__device__ __forceinline__ void cell_range(int lo, int hi, int ncell, int nnode, int &clo, int &ccnt) {
+    const int c0 = floordiv(lo * ncell, nnode), c1 = floordiv((hi + 1) * ncell, nnode);
+    clo = c0;
+    ccnt = min(c1 - c0 + 1, ncell);
+}
+
+// Calls body() once per chunk with tl.list[0..tl.n) filled; pred(p) decides membership.  256 threads.
+template <class Pred, class Body>
+__device__ __forceinline__ void for_tile_particles(TileList &tl, const int *__restrict__ cell_off, const DCells &nc,
+                                                   const int clo[3], const int ccnt[3], Pred &&pred, Body &&body) {
+    const int tid = threadIdx.x;
+    const int ncols = ccnt[0] * ccnt[1];
     int z0 = clo[2] % nc.nz; if (z0 < 0) z0 += nc.nz;
     const int zfirst = min(ccnt[2], nc.nz - z0);
-    for (int ixy = 0; ixy < ccnt[0] * ccnt[1]; ++ixy) {
-        const int ix = ixy / ccnt[1], iy = ixy - ix * ccnt[1];
-        int cx = (clo[0] + ix) % nc.nx; if (cx < 0) cx += nc.nx;
-        int cy = (clo[1] + iy) % nc.ny; if (cy < 0) cy += nc.ny;
-        const int base = (cx * nc.ny + cy) * nc.nz;
-        for (int seg = 0; seg < 2; ++seg) {   // the z cells are at most two contiguous slot runs
+    for (int col0 = 0; col0 < ncols; col0 += RMAX / 2) {
+        const int nr = min(RMAX / 2, ncols - col0) * 2;
+        int len = 0;
+        if (tid < nr) {
+            const int col = col0 + (tid >> 1), seg = tid & 1;
+            const int ix = col / ccnt[1], iy = col - ix * ccnt[1];
+            int cx = (clo[0] + ix) % nc.nx; if (cx < 0) cx += nc.nx;
+            int cy = (clo[1] + iy) % nc.ny; if (cy < 0) cy += nc.ny;
+            const int base = (cx * nc.ny + cy) * nc.nz;
             const int za = seg == 0 ? z0 : 0, zn = seg == 0 ? zfirst : ccnt[2] - zfirst;
-            if (zn <= 0) continue;
-            const int jb = cell_off[base + za], je = cell_off[base + za + zn];
-            for (int p = jb + wave; p < je; p += NW) {
-                const int4 sp = sup_s[p];
-                const int st[3] = {sp.x, sp.y, sp.z};
-                int a0[3], lo[3], hi[3];
-                bool hit = true;
+            if (zn > 0) {
+                const int jb = cell_off[base + za];
+                len = cell_off[base + za + zn] - jb;
+                tl.run_b[tid] = jb;
+            }
+        }
+        // exclusive block scan of len (one value per thread)
+        int inc = len;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    int rel = st[a] - t0[a];                       // support origin relative to the tile, nearest image
-                    if (rel < -Nn[a] / 2) rel += Nn[a]; else if (rel >= Nn[a] - Nn[a] / 2) rel -= Nn[a];
-                    a0[a] = rel;
-                    lo[a] = max(rel, 0);
-                    hi[a] = min(rel + P, ext[a]);
-                    hit = hit && lo[a] < hi[a];
-                }
-                if (!hit) continue;
-                const double4 pp = pos_s[p];
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if ((tid & 63) >= o) inc += v; }
+        __syncthreads();                                  // previous chunk's body is done with the list
+        if ((tid & 63) == 63) tl.wsum[tid >> 6] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < (tid >> 6); ++w) woff += tl.wsum[w];
+        tl.run_o[tid] = woff + inc - len;
+        if (tid == RMAX - 1) tl.run_o[RMAX] = woff + inc;
+        __syncthreads();
+        const int total = tl.run_o[RMAX];
+        for (int c0 = 0; c0 < total; c0 += LCAP) {
+            if (tid == 0) tl.n = 0;
+            __syncthreads();
+            const int cend = min(total, c0 + LCAP);
+            for (int k = c0 + tid; k < cend; k += RMAX) {
+                int lo = 0, hi = nr;                       // largest r with run_o[r] <= k
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tl.run_o[mid] <= k) lo = mid; else hi = mid; }
+                const int p = tl.run_b[lo] + (k - tl.run_o[lo]);
+                if (pred(p)) tl.list[atomicAdd(&tl.n, 1)] = p;
+            }
+            __syncthreads();
+            body();
+            __syncthreads();
+        }
+    }
+}
+
+// Tile-owned spread (K2+K3): one workgroup owns a TXxTYxTZ block of grid nodes, accumulates every contribution to it in
+// LDS (ds_add_f64) and writes each node exactly once with plain stores -- no global atomics (1.3 TB/s chip-wide on
+// MI355X: the 7.6 ms of the v0 kernel), no ZeroGrid pass.  Eight lanes per (particle, tile) pair -- lane = z offset of
+// the support -- so a wave deposits 8 pairs at once and all per-pair bookkeeping (clip, offsets) costs one instruction
+// per 8 pairs; the P^2 (x,y) offsets are a compile-time unrolled loop: one broadcast weight read, three multiplies,
+// three LDS adds per node row.
+template <int P, int TX, int TY, int TZ>
+__global__ void __launch_bounds__(RMAX)
+k_spread_tile(const double4 *__restrict__ f_s, const int4 *__restrict__ sup_s, const double *__restrict__ wtab,
+              const int *__restrict__ cell_off, DCells nc, double *__restrict__ gx, double *__restrict__ gy,
+              double *__restrict__ gz, DGrid G, int ntx, int nty, int ntz) {
+    constexpr int NT = RMAX, XS = TY * TZ + 2, NODES = TX * XS, WT = P * P + P;
+    __shared__ double acc[3 * NODES];
+    __shared__ TileList tl;
+    const int tid = threadIdx.x;
+    int b = xcd_block(blockIdx.x, gridDim.x);
+    const int tz_ = b % ntz; b /= ntz;
+    const int ty_ = b % nty; b /= nty;
+    const int tx_ = b;
+    const int t0[3] = {G.x0 + tx_ * TX, ty_ * TY, tz_ * TZ};
+    const int ext[3] = {min(TX, G.x0 + G.nxl - t0[0]), min(TY, G.Ny - t0[1]), min(TZ, G.Nz - t0[2])};
+    const int Nn[3] = {G.Nx, G.Ny, G.Nz};
+    for (int n = tid; n < 3 * NODES; n += NT) acc[n] = 0.0;
+
+    // support origin relative to the tile (nearest image); false if the support misses the tile
+    auto clip = [&](const int4 &sp, int a0[3]) {
+        const int o[3] = {sp.x, sp.y, sp.z};
+        bool hit = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            int rel = o[a] - t0[a];
+            if (rel < -Nn[a] / 2) rel += Nn[a]; else if (rel >= Nn[a] - Nn[a] / 2) rel -= Nn[a];
+            a0[a] = rel;
+            hit = hit && rel + P > 0 && rel < ext[a];
+        }
+        return hit;
+    };
+    // particles that can touch the tile have floor(s) in [t0 - ceil(P/2), t0 + ext - 1 + P/2] (node units)
+    int clo[3], ccnt[3];
+    cell_range(t0[0] - (P + 1) / 2, t0[0] + ext[0] - 1 + P / 2, nc.nx, G.Nx, clo[0], ccnt[0]);
+    cell_range(t0[1] - (P + 1) / 2, t0[1] + ext[1] - 1 + P / 2, nc.ny, G.Ny, clo[1], ccnt[1]);
+    cell_range(t0[2] - (P + 1) / 2, t0[2] + ext[2] - 1 + P / 2, nc.nz, G.Nz, clo[2], ccnt[2]);
+
+    const double prefac = G.prefac;
+    const int grp = tid >> 3, tz = tid & 7;            // 32 groups of 8 lanes; lane = z offset inside the support
+    for_tile_particles(tl, cell_off, nc, clo, ccnt,
+        [&](int p) { int a0[3]; return clip(sup_s[p], a0); },
+        [&]() {
+            const int n = tl.n;
+            for (int h = grp; h < n; h += NT / 8) {
+                const int p = tl.list[h];
+                // the 8 lanes of a group read the same addresses (a few L1 accesses per instruction); all loads are
+                // unconditional so they are in flight together
+                const int4 sp = sup_s[p];
                 const double4 F = f_s[p];
-                double f[3];
-                frac_coords(box, pp.x, pp.y, pp.z, f[0], f[1], f[2]);
-                // offset of the support origin from the particle in grid units (same arithmetic as support_start)
-                const double d0x = st[0] - f[0] * G.Nx, d0y = st[1] - f[1] * G.Ny, d0z = st[2] - f[2] * G.Nz;
-                WaveWeights<P> W;
-                W.stage(lane, G, box, d0x, d0y, d0z);
-                const int by = hi[1] - lo[1], bz = hi[2] - lo[2], byz = by * bz;
-                const int cnt = (hi[0] - lo[0]) * byz;
-                const float ibyz = 1.0f / (float)byz, ibz = 1.0f / (float)bz;
-                const double Fx = prefac * F.x, Fy = prefac * F.y, Fz = prefac * F.z;
-                for (int n0 = 0; n0 < cnt; n0 += 64) {
-                    const int n = n0 + lane;
-                    const bool on = n < cnt;
-                    const int m = on ? n : 0;
-                    const int qx = (int)(((float)m + 0.5f) * ibyz), r = m - qx * byz;
-                    const int qy = (int)(((float)r + 0.5f) * ibz), qz = r - qy * bz;
-                    const int lx = lo[0] + qx, ly = lo[1] + qy, lz = lo[2] + qz;
-                    const double w = W.get(lx - a0[0], ly - a0[1], lz - a0[2]);   // all lanes take part in the shuffles
-                    if (on) {
-                        const int o = lx * XS + ly * TZ + lz;
-                        atomicAdd(&acc[o], w * Fx);
-                        atomicAdd(&acc[NODES + o], w * Fy);
-                        atomicAdd(&acc[2 * NODES + o], w * Fz);
+                const double *w = wtab + (size_t)p * WT;
+                double a[P * P];
+#pragma unroll
+                for (int e = 0; e < P * P; ++e) a[e] = w[e];
+                const double bw = prefac * w[P * P + (tz < P ? tz : 0)];
+                int a0[3];
+                clip(sp, a0);
+                const int lz = a0[2] + tz;
+                if (tz < P && lz >= 0 && lz < ext[2]) {
+                    const double bx = bw * F.x, by = bw * F.y, bz = bw * F.z;
+                    double *cell = acc + a0[0] * XS + a0[1] * TZ + lz;
+#pragma unroll
+                    for (int tx = 0; tx < P; ++tx) {
+                        const bool okx = (unsigned)(a0[0] + tx) < (unsigned)ext[0];
+#pragma unroll
+                        for (int ty = 0; ty < P; ++ty) {
+                            if (okx && (unsigned)(a0[1] + ty) < (unsigned)ext[1]) {
+                                double *o = cell + tx * XS + ty * TZ;
+                                atomicAdd(o, a[tx * P + ty] * bx);
+                                atomicAdd(o + NODES, a[tx * P + ty] * by);
+                                atomicAdd(o + 2 * NODES, a[tx * P + ty] * bz);
+                            }
+                        }
                     }
                 }
             }
-        }
-    }
+        });
     __syncthreads();
     const int eyz = ext[1] * ext[2], nout = ext[0] * eyz;
     for (int n = tid; n < nout; n += NT) {
@@ -540,104 +602,158 @@ static int spread_tile_variant() {
 static void tile_dims(int &tx, int &ty, int &tz) {
     switch (spread_tile_variant()) {
         case 0: tx = 8; ty = 8; tz = 8; break;
-        case 2: tx = 16; ty = 16; tz = 16; break;
+        case 2: tx = 16; ty = 16; tz = 8; break;
         default: tx = 16; ty = 8; tz = 8; break;
     }
 }
+constexpr int GT = 8;   // gather tile edge
 
-bool spread_needs_zero(const DGrid &G) {
-    // the tile kernel resolves a support to its nearest image of the tile (needs N >= 2 max(tile, support) per axis)
-    // and keeps its weights in one or two registers per lane (P <= 8); anything else takes the atomic kernel
+bool farfield_fast_path(const DGrid &G) {
+    // the tile kernels resolve a support to its nearest image of the tile (needs N >= 2 max(tile, support) per axis)
+    // and map one lane per (y,z) pair of the support (P^2 <= 64)
     int tx, ty, tz;
     tile_dims(tx, ty, tz);
     const int tmax = std::max(tx, std::max(ty, tz));
     const int need = 2 * std::max(tmax, G.P);
-    return G.P < 4 || G.P > 8 || G.Nx < need || G.Ny < need || G.Nz < need;
+    return G.P >= 4 && G.P <= 8 && G.Nx >= need && G.Ny >= need && G.Nz >= need;
 }
+bool spread_needs_zero(const DGrid &G) { return !farfield_fast_path(G); }
 
 template <int P>
-static void launch_spread_p(const double4 *pos_s, const double4 *f_s, const int4 *sup_s, int N, const int *cell_off,
-                            DCells nc, double *gx, double *gy, double *gz, DGrid G, DBox box, hipStream_t s) {
+static void launch_spread_p(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, const int *cell_off, DCells nc,
+                            double *gx, double *gy, double *gz, DGrid G, DBox box, SpreadWork w, hipStream_t s) {
+    constexpr int WT = P * P + P;
+    hipLaunchKernelGGL(k_support, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos_s, N, G, box, sup_s, w.d0_s);
+    hipLaunchKernelGGL(k_weights<P>, dim3(nblocks((long)N * WT, TPB)), dim3(TPB), 0, s, w.d0_s, N, G, box, w.wtab);
     int TX, TY, TZ;
     tile_dims(TX, TY, TZ);
     const int ntx = (G.nxl + TX - 1) / TX, nty = (G.Ny + TY - 1) / TY, ntz = (G.Nz + TZ - 1) / TZ;
-    const dim3 g(ntx * nty * ntz);
+    const dim3 g(ntx * nty * ntz), b(RMAX);
     if (TX == 8)
-        hipLaunchKernelGGL((k_spread_tile<P, 8, 8, 8, 256>), g, dim3(256), 0, s, pos_s, f_s, sup_s, cell_off, nc, gx, gy, gz, G, box, ntx, nty, ntz);
+        hipLaunchKernelGGL((k_spread_tile<P, 8, 8, 8>), g, b, 0, s, f_s, sup_s, w.wtab, cell_off, nc, gx, gy, gz, G, ntx, nty, ntz);
     else if (TY == 8)
-        hipLaunchKernelGGL((k_spread_tile<P, 16, 8, 8, 256>), g, dim3(256), 0, s, pos_s, f_s, sup_s, cell_off, nc, gx, gy, gz, G, box, ntx, nty, ntz);
+        hipLaunchKernelGGL((k_spread_tile<P, 16, 8, 8>), g, b, 0, s, f_s, sup_s, w.wtab, cell_off, nc, gx, gy, gz, G, ntx, nty, ntz);
     else
-        hipLaunchKernelGGL((k_spread_tile<P, 16, 16, 16, 512>), g, dim3(512), 0, s, pos_s, f_s, sup_s, cell_off, nc, gx, gy, gz, G, box, ntx, nty, ntz);
+        hipLaunchKernelGGL((k_spread_tile<P, 16, 16, 8>), g, b, 0, s, f_s, sup_s, w.wtab, cell_off, nc, gx, gy, gz, G, ntx, nty, ntz);
 }
 
 void launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, const int *cell_off, DCells nc,
-                   double *gx, double *gy, double *gz, DGrid G, DBox box, hipStream_t s) {
-    if (spread_needs_zero(G)) {
+                   double *gx, double *gy, double *gz, DGrid G, DBox box, SpreadWork w, hipStream_t s) {
+    if (!farfield_fast_path(G) || !w.wtab) {
         hipLaunchKernelGGL(k_spread_atomic, dim3(nblocks(N, TPB / 64)), dim3(TPB), 0, s, pos_s, f_s, N, gx, gy, gz, G, box);
         return;
     }
-    hipLaunchKernelGGL(k_support, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos_s, N, G, box, sup_s);
     switch (G.P) {
-        case 4: launch_spread_p<4>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, s); break;
-        case 5: launch_spread_p<5>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, s); break;
-        case 6: launch_spread_p<6>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, s); break;
-        case 7: launch_spread_p<7>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, s); break;
-        default: launch_spread_p<8>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, s); break;
+        case 4: launch_spread_p<4>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, w, s); break;
+        case 5: launch_spread_p<5>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, w, s); break;
+        case 6: launch_spread_p<6>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, w, s); break;
+        case 7: launch_spread_p<7>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, w, s); break;
+        default: launch_spread_p<8>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, w, s); break;
     }
 }
 
 // K8 gpu_stokes_Contract_kernel (PSEv1/Mobility.cu:325-477): u_p = h^3 sum_nodes prefac exp(-expfac r^2) u_grid.
-// One wave per particle; separable weights staged across the lanes (P^2 + P exponentials, not P^3); lanes stride the
-// P^3 support with compile-time index arithmetic; wave-64 butterfly reduction instead of the reference's shared-memory
-// tree over B^3 threads (PSEv1/Mobility.cu:456-470).
+// Tile gather: a workgroup stages its GT^3 tile plus the P-1 node halo on the high side of each axis (every support
+// that starts in the tile lies inside it) in LDS -- each grid granule is fetched once per tile instead of once per
+// particle (the per-particle version was bound by L1 accesses: 325 per particle).  Staging: a thread keeps one (y,z)
+// column and walks component x plane, so the loop body is an add and a load and all loads are in flight together.
+// Then 8 lanes per particle (lane = z offset), 8 particles per wave, compile-time loop over the P^2 (x,y) offsets:
+// one broadcast weight read, one multiply, three LDS reads, three FMAs; 3-step reduction inside the 8 lanes instead of
+// the reference's shared-memory tree over B^3 threads (PSEv1/Mobility.cu:456-470).  A particle belongs to the tile
+// (and, in slab mode, to the rank) that holds its support origin; particles of other ranks stay zero (caller's memset).
 template <int P>
-__global__ void __launch_bounds__(TPB)
-k_gather_p(const double4 *__restrict__ pos_s, int N, const double *__restrict__ gx, const double *__restrict__ gy,
-           const double *__restrict__ gz, DGrid G, DBox box, double4 *__restrict__ u_s) {
-    const int p = xcd_block(blockIdx.x, gridDim.x) * (TPB / 64) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (p >= N) return;
-    const double4 pp = pos_s[p];
-    double fx, fy, fz;
-    frac_coords(box, pp.x, pp.y, pp.z, fx, fy, fz);
-    int sx, sy, sz;
-    double d0x, d0y, d0z;
-    support_start(fx, G.Nx, P, sx, d0x);
-    support_start(fy, G.Ny, P, sy, d0y);
-    support_start(fz, G.Nz, P, sz, d0z);
-    // a particle is gathered by the rank whose slab holds its support origin; the support then reaches at most P - 1
-    // planes into the next slab, which the halo copies provide
-    int rel0 = sx - G.x0; rel0 %= G.Nx; if (rel0 < 0) rel0 += G.Nx;
-    if (rel0 >= G.nxl) {
-        if (lane == 0) u_s[p] = make_double4(0.0, 0.0, 0.0, 0.0);
-        return;
-    }
-    WaveWeights<P> W;
-    W.stage(lane, G, box, d0x, d0y, d0z);
-    constexpr int P2 = P * P, P3 = P2 * P;
-    double ux = 0, uy = 0, uz = 0;
+__global__ void __launch_bounds__(RMAX)
+k_gather_tile(const int4 *__restrict__ sup_s, const double *__restrict__ wtab, const int *__restrict__ cell_off, DCells nc,
+              const double *__restrict__ gx, const double *__restrict__ gy, const double *__restrict__ gz, DGrid G,
+              double4 *__restrict__ u_s, int ntx, int nty, int ntz) {
+    constexpr int NT = RMAX, E = GT + P - 1, E2 = E * E, E3 = E2 * E, WT = P * P + P;
+    __shared__ double reg[E3];          // one velocity component of the tile + halo: 17.6 KB at P = 6
+    __shared__ TileList tl;
+    const int tid = threadIdx.x, comp = blockIdx.y;
+    const double *__restrict__ g = comp == 0 ? gx : (comp == 1 ? gy : gz);
+    int b = xcd_block(blockIdx.x, gridDim.x);
+    const int tz_ = b % ntz; b /= ntz;
+    const int ty_ = b % nty; b /= nty;
+    const int tx_ = b;
+    const int t0[3] = {G.x0 + tx_ * GT, ty_ * GT, tz_ * GT};
+    const int ext[3] = {min(GT, G.x0 + G.nxl - t0[0]), min(GT, G.Ny - t0[1]), min(GT, G.Nz - t0[2])};
+    const int Nn[3] = {G.Nx, G.Ny, G.Nz};
+    // region loads first (into registers): they stay in flight while the particle list is built
+    double rv[E];
+    {
+        const size_t plane = (size_t)G.Ny * G.Nz;
+        const int nplanes = min(E, ext[0] + P - 1);
+        const int qy = tid / E, qz = tid - qy * E;        // this thread's (y,z) column of the region (tid < E^2)
+        int iy = t0[1] + qy; if (iy >= G.Ny) iy -= G.Ny;
+        int iz = t0[2] + qz; if (iz >= G.Nz) iz -= G.Nz;
+        const size_t col = (size_t)iy * G.Nz + iz;
 #pragma unroll
-    for (int n0 = 0; n0 < P3; n0 += 64) {
-        const int n = n0 + lane;
-        const bool on = n < P3;
-        const int m = on ? n : 0;
-        const int tx = m / P2, ty = (m - tx * P2) / P, tz = m - tx * P2 - ty * P;
-        const double w = W.get(tx, ty, tz);
-        int lx = rel0 + tx; if (G.nhalo == 0 && lx >= G.Nx) lx -= G.Nx;   // slab mode: planes nxl.. are the halo copies
-        int iy = sy + ty; iy = iy < 0 ? iy + G.Ny : (iy >= G.Ny ? iy - G.Ny : iy);
-        int iz = sz + tz; iz = iz < 0 ? iz + G.Nz : (iz >= G.Nz ? iz - G.Nz : iz);
-        if (on) {
-            const unsigned idx = ((unsigned)lx * G.Ny + iy) * G.Nz + iz;   // a slab has < 2^32 nodes (grid <= 1024^3 checked at create)
-            ux += w * gx[idx];
-            uy += w * gy[idx];
-            uz += w * gz[idx];
+        for (int qx = 0; qx < E; ++qx) {
+            int lx = t0[0] - G.x0 + qx;                   // local plane; planes nxl.. are the halo copies in slab mode
+            if (G.nhalo == 0 && lx >= G.Nx) lx -= G.Nx;
+            rv[qx] = (tid < E2 && qx < nplanes) ? g[(size_t)lx * plane + col] : 0.0;
         }
     }
-    ux = wave_sum(ux); uy = wave_sum(uy); uz = wave_sum(uz);
-    if (lane == 0) {
-        const double c = G.prefac * G.hx * G.hy * G.hz;   // PSEv1/Brownian.cu:872
-        u_s[p] = make_double4(c * ux, c * uy, c * uz, 0.0);
-    }
+    // origin = floor(s) - P/2 + 1 - adj, adj in {0,1}: origins in [t0, t0+ext) need floor(s) in [t0 + P/2 - 1, t0 + ext - 1 + P/2]
+    int clo[3], ccnt[3];
+    cell_range(t0[0] + P / 2 - 1, t0[0] + ext[0] - 1 + P / 2, nc.nx, G.Nx, clo[0], ccnt[0]);
+    cell_range(t0[1] + P / 2 - 1, t0[1] + ext[1] - 1 + P / 2, nc.ny, G.Ny, clo[1], ccnt[1]);
+    cell_range(t0[2] + P / 2 - 1, t0[2] + ext[2] - 1 + P / 2, nc.nz, G.Nz, clo[2], ccnt[2]);
+    auto origin = [&](const int4 &sp, int rel[3]) {
+        const int o[3] = {sp.x, sp.y, sp.z};
+        bool own = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            int r = o[a] - t0[a];
+            if (r < -Nn[a] / 2) r += Nn[a]; else if (r >= Nn[a] - Nn[a] / 2) r -= Nn[a];
+            rel[a] = r;
+            own = own && r >= 0 && r < ext[a];
+        }
+        return own;
+    };
+    const int grp = tid >> 3, tz = tid & 7;
+    const double cw = G.prefac * G.hx * G.hy * G.hz;   // PSEv1/Brownian.cu:872
+    bool stored = false;
+    for_tile_particles(tl, cell_off, nc, clo, ccnt,
+        [&](int p) { int rel[3]; return origin(sup_s[p], rel); },
+        [&]() {
+            if (!stored) {                                // first chunk: park the region in LDS (uniform branch)
+                if (tid < E2) {
+#pragma unroll
+                    for (int qx = 0; qx < E; ++qx) reg[qx * E2 + tid] = rv[qx];
+                }
+                stored = true;
+                __syncthreads();
+            }
+            const int n = tl.n;
+            for (int h0 = 0; h0 < n; h0 += NT / 8) {      // uniform trip count: the reduction uses every lane
+                const int h = h0 + grp;
+                double u = 0;
+                int p = 0;
+                if (h < n) {
+                    p = tl.list[h];
+                    const int4 sp = sup_s[p];
+                    const double *w = wtab + (size_t)p * WT;
+                    double a[P * P];
+#pragma unroll
+                    for (int e = 0; e < P * P; ++e) a[e] = w[e];
+                    const double bw = w[P * P + (tz < P ? tz : 0)];
+                    if (tz < P) {
+                        int rel[3];
+                        origin(sp, rel);
+                        const double *r0 = reg + rel[0] * E2 + rel[1] * E + rel[2] + tz;
+#pragma unroll
+                        for (int tx = 0; tx < P; ++tx)
+#pragma unroll
+                            for (int ty = 0; ty < P; ++ty) u += a[tx * P + ty] * r0[tx * E2 + ty * E];
+                        u *= bw;
+                    }
+                }
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) u += __shfl_xor(u, o, 64);
+                if (h < n && tz == 0) ((double *)&u_s[p])[comp] = cw * u;
+            }
+        });
 }
 
 // generic support size: one exponential per node
@@ -683,16 +799,21 @@ k_gather(const double4 *__restrict__ pos_s, int N, const double *__restrict__ gx
     }
 }
 
-void launch_gather(const double4 *pos_s, int N, const double *gx, const double *gy, const double *gz, DGrid G,
-                   DBox box, double4 *u_s, hipStream_t s) {
-    const dim3 g(nblocks(N, TPB / 64)), b(TPB);
+void launch_gather(const double4 *pos_s, const int4 *sup_s, const double *wtab, const int *cell_off, DCells nc, int N,
+                   const double *gx, const double *gy, const double *gz, DGrid G, DBox box, double4 *u_s, hipStream_t s) {
+    if (!farfield_fast_path(G) || !wtab) {
+        hipLaunchKernelGGL(k_gather, dim3(nblocks(N, TPB / 64)), dim3(TPB), 0, s, pos_s, N, gx, gy, gz, G, box, u_s);
+        return;
+    }
+    (void)hipMemsetAsync(u_s, 0, (size_t)N * sizeof(double4), s);   // .w, and particles of other slabs, stay zero
+    const int ntx = (G.nxl + GT - 1) / GT, nty = (G.Ny + GT - 1) / GT, ntz = (G.Nz + GT - 1) / GT;
+    const dim3 g(ntx * nty * ntz, 3), b(RMAX);   // one workgroup per (tile, velocity component)
     switch (G.P) {
-        case 4: hipLaunchKernelGGL(k_gather_p<4>, g, b, 0, s, pos_s, N, gx, gy, gz, G, box, u_s); break;
-        case 5: hipLaunchKernelGGL(k_gather_p<5>, g, b, 0, s, pos_s, N, gx, gy, gz, G, box, u_s); break;
-        case 6: hipLaunchKernelGGL(k_gather_p<6>, g, b, 0, s, pos_s, N, gx, gy, gz, G, box, u_s); break;
-        case 7: hipLaunchKernelGGL(k_gather_p<7>, g, b, 0, s, pos_s, N, gx, gy, gz, G, box, u_s); break;
-        case 8: hipLaunchKernelGGL(k_gather_p<8>, g, b, 0, s, pos_s, N, gx, gy, gz, G, box, u_s); break;
-        default: hipLaunchKernelGGL(k_gather, g, b, 0, s, pos_s, N, gx, gy, gz, G, box, u_s); break;
+        case 4: hipLaunchKernelGGL(k_gather_tile<4>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz); break;
+        case 5: hipLaunchKernelGGL(k_gather_tile<5>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz); break;
+        case 6: hipLaunchKernelGGL(k_gather_tile<6>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz); break;
+        case 7: hipLaunchKernelGGL(k_gather_tile<7>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz); break;
+        default: hipLaunchKernelGGL(k_gather_tile<8>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz); break;
     }
 }
 

@@ -86,6 +86,8 @@ struct pse_handle {
     // slab decomposition (n_slabs > 1): x planes [x0, x0+nxl) of the real grid, y rows [y0, y0+nyl) of the transposed spectrum
     int n_slabs = 1, slab_rank = 0, nyl = 0, y0 = 0;
     double2 *sendbuf = nullptr, *recvbuf = nullptr;          // [3][n_slabs][nxl][nyl][Nzh] each
+    bool xfuse = false;                                      // single GPU, power-of-two Nx: 2-D rocFFT + fused x pass
+    double2 *twiddle = nullptr;                              // [Nx] exp(-2 pi i m / Nx)
     void *fft_work = nullptr;
     size_t fft_work_bytes = 0;
     // Lanczos
@@ -191,7 +193,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
     void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->sup_s, h->sw.wtab, h->sw.d0_s, h->nb.j, h->nb.f, h->nb.dx, h->nb.dy, h->nb.dz, h->nb.cnt, h->pos_s,
-                    h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->fft_work, h->V,
+                    h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->twiddle, h->fft_work, h->V,
                     h->scal, h->partials, h->t_dev};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &p : h->ph) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
@@ -203,7 +205,22 @@ static int make_plans(pse_handle *h) {
     std::call_once(g_fft_once, [] { rocfft_setup(); });
     const DGrid &G = h->G;
     size_t work = 0, w = 0;
-    if (h->n_slabs == 1) {
+    h->xfuse = h->n_slabs == 1 && xfuse_supported(G.Nx) && !getenv("PSE_NO_XFUSE");
+    if (h->xfuse) {
+        // 2-D (y,z) real transforms of all 3 Nx planes in one batch; the x axis is done by k_xfft_scale
+        const size_t len2[2] = {(size_t)G.Nz, (size_t)G.Ny};
+        FFTCHK(rocfft_plan_create(&h->plan_fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                                  rocfft_precision_double, 2, len2, (size_t)3 * G.Nx, nullptr));
+        FFTCHK(rocfft_plan_create(&h->plan_inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                                  rocfft_precision_double, 2, len2, (size_t)3 * G.Nx, nullptr));
+        std::vector<double2> tw(G.Nx);
+        for (int m = 0; m < G.Nx; ++m) {
+            const long double ang = -2.0L * 3.14159265358979323846264338327950288L * m / G.Nx;
+            tw[m] = make_double2((double)cosl(ang), (double)sinl(ang));
+        }
+        TRY(dmalloc(h, &h->twiddle, (size_t)G.Nx));
+        HIPCHK(hipMemcpy(h->twiddle, tw.data(), G.Nx * sizeof(double2), hipMemcpyHostToDevice));
+    } else if (h->n_slabs == 1) {
         // rocFFT lengths are fastest-first: z, y, x.  Real grids [3][Nx][Ny][Nz] -> half spectra [3][Nx][Ny][Nzh].
         const size_t len[3] = {(size_t)G.Nz, (size_t)G.Ny, (size_t)G.Nx};
         FFTCHK(rocfft_plan_create(&h->plan_fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
@@ -569,11 +586,15 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
         const size_t ncx = (size_t)G.nxl * G.Ny * G.Nzh;
         double2 *sp = T.G == 1 ? h->cgrid : h->recvbuf;   // [3][Nx][nyl][Nzh] after the transpose
         TRY(ts(h, PH_SCALE));
-        if (T.G > 1)
-            for (int c = 0; c < 3; ++c) { void *io[1] = {sp + c * ncx}; FFTCHK(rocfft_execute(h->plan_x_fwd, io, nullptr, h->info_fwd)); }
-        launch_scale(sp, sp + ncx, sp + 2 * ncx, G, h->dbox, scale_args(h, noise, kT, dt, timestep), h->stream);
-        if (T.G > 1)
-            for (int c = 0; c < 3; ++c) { void *io[1] = {sp + c * ncx}; FFTCHK(rocfft_execute(h->plan_x_inv, io, nullptr, h->info_inv)); }
+        if (h->xfuse) {
+            launch_xfft_scale(sp, sp + ncx, sp + 2 * ncx, G, h->dbox, scale_args(h, noise, kT, dt, timestep), h->twiddle, h->stream);
+        } else {
+            if (T.G > 1)
+                for (int c = 0; c < 3; ++c) { void *io[1] = {sp + c * ncx}; FFTCHK(rocfft_execute(h->plan_x_fwd, io, nullptr, h->info_fwd)); }
+            launch_scale(sp, sp + ncx, sp + 2 * ncx, G, h->dbox, scale_args(h, noise, kT, dt, timestep), h->stream);
+            if (T.G > 1)
+                for (int c = 0; c < 3; ++c) { void *io[1] = {sp + c * ncx}; FFTCHK(rocfft_execute(h->plan_x_inv, io, nullptr, h->info_inv)); }
+        }
         TRY(te(h, PH_SCALE));
     }
     if (T.G > 1) {

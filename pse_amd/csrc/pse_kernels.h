@@ -54,6 +54,9 @@ struct ScaleArgs {
     int y0, nyl;             // slab of y rows in transposed layout
 };
 void launch_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, hipStream_t s);
+// fused forward-x FFT + scale + inverse-x FFT on [3][Nx][Ny][Nzh] (Nx a power of two, 16..512); tw[m] = exp(-2 pi i m/Nx)
+bool xfuse_supported(int Nx);
+void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s);
 // the fast path reads sup_s / wtab written by launch_spread of the same step
 void launch_gather(const double4 *pos_s, const int4 *sup_s, const double *wtab, const int *cell_off, DCells nc, int N,
                    const double *gx, const double *gy, const double *gz, DGrid G, DBox box, double4 *u_s, hipStream_t s);

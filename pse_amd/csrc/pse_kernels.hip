@@ -407,10 +407,11 @@ __global__ void k_support(const double4 *__restrict__ pos_s, int N, DGrid G, DBo
 template <int P>
 __global__ void __launch_bounds__(TPB)
 k_weights(const double4 *__restrict__ d0_s, int N, DGrid G, DBox box, double *__restrict__ wtab) {
-    constexpr int WT = P * P + P;
-    const size_t gid = (size_t)blockIdx.x * TPB + threadIdx.x;
-    const int p = (int)(gid / WT), e = (int)(gid - (size_t)p * WT);
-    if (p >= N) return;
+    constexpr unsigned WT = P * P + P;
+    const unsigned gid = blockIdx.x * TPB + threadIdx.x;   // N * WT < 2^32
+    const unsigned p = gid / WT;
+    const int e = (int)(gid - p * WT);
+    if (p >= (unsigned)N) return;
     const double4 d0 = d0_s[p];
     // branch-free: A entries and B entries pick their squared distance with selects and share ONE exponential
     const bool isA = e < P * P;
@@ -863,21 +864,11 @@ __device__ __forceinline__ void apply_kop(const KOp &o, const double2 f[3], cons
     }
 }
 
-__global__ void __launch_bounds__(TPB)
-k_scale(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ Z, DGrid G, DBox box, ScaleArgs a) {
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t rows = a.transposed ? (size_t)a.nyl * G.Nx : (size_t)G.nxl * G.Ny;
-    if (tid >= rows * G.Nzh) return;
-    const int k = (int)(tid % G.Nzh);
-    const size_t row = tid / G.Nzh;
-    int i, j;
-    if (a.transposed) { i = (int)(row / a.nyl); j = a.y0 + (int)(row % a.nyl); }   // [Nx][ny_local][Nzh]
-    else              { i = G.x0 + (int)(row / G.Ny); j = (int)(row % G.Ny); }
-    if (i == 0 && j == 0 && k == 0) {   // k = 0 mode is dropped (Helper.cu:321-323, Mobility.cu:287)
-        X[tid] = make_double2(0, 0); Y[tid] = make_double2(0, 0); Z[tid] = make_double2(0, 0);
-        return;
-    }
-    const double2 f[3] = {X[tid], Y[tid], Z[tid]};
+// What K5 + K6 do to one node (i,j,k) of the half spectrum: f -> B (I - kk) f + c (I - kk) psi.
+__device__ __forceinline__ void scale_node(int i, int j, int k, const double2 f[3], const DGrid &G, const DBox &box,
+                                           const ScaleArgs &a, double2 out[3]) {
+    out[0] = out[1] = out[2] = make_double2(0, 0);
+    if (i == 0 && j == 0 && k == 0) return;   // k = 0 mode is dropped (Helper.cu:321-323, Mobility.cu:287)
     // Hermitian bookkeeping: on the planes kz = 0 and kz = Nz/2 (even Nz) node (i,j) and its partner (-i,-j) must
     // carry conjugate values. The reference writes both explicitly and keeps the real part after a C2C inverse
     // (PSEv1/Mobility.cu:447); the equivalent for a C2R inverse is to apply the symmetrised operator
@@ -907,7 +898,6 @@ k_scale(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ 
             else       psi[c] = make_double2(re[c], flip ? -im[c] : im[c]);
         }
     }
-    double2 out[3] = {{0, 0}, {0, 0}, {0, 0}};
     const KOp o1 = make_kop(i, j, k, G, box, a.xi, a.eta, a.noise_fac);
     if (plane) {
         const KOp o2 = make_kop(ip, jp, k, G, box, a.xi, a.eta, a.noise_fac);
@@ -916,12 +906,187 @@ k_scale(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ 
     } else {
         apply_kop(o1, f, psi, a.noise, 1.0, out);
     }
+}
+
+__global__ void __launch_bounds__(TPB)
+k_scale(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ Z, DGrid G, DBox box, ScaleArgs a) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t rows = a.transposed ? (size_t)a.nyl * G.Nx : (size_t)G.nxl * G.Ny;
+    if (tid >= rows * G.Nzh) return;
+    const int k = (int)(tid % G.Nzh);
+    const size_t row = tid / G.Nzh;
+    int i, j;
+    if (a.transposed) { i = (int)(row / a.nyl); j = a.y0 + (int)(row % a.nyl); }   // [Nx][ny_local][Nzh]
+    else              { i = G.x0 + (int)(row / G.Ny); j = (int)(row % G.Ny); }
+    const double2 f[3] = {X[tid], Y[tid], Z[tid]};
+    double2 out[3];
+    scale_node(i, j, k, f, G, box, a, out);
     X[tid] = out[0]; Y[tid] = out[1]; Z[tid] = out[2];
 }
 
 void launch_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, hipStream_t s) {
     const size_t rows = a.transposed ? (size_t)a.nyl * G.Nx : (size_t)G.nxl * G.Ny;
     hipLaunchKernelGGL(k_scale, dim3(nblocks((long)(rows * G.Nzh), TPB)), dim3(TPB), 0, s, X, Y, Z, G, box, a);
+}
+
+// ---- fused x pass -----------------------------------------------------------------------------------------------
+// For a power-of-two Nx the last forward axis pass, the k-space scaling (+ noise) and the first inverse axis pass are one
+// kernel: a workgroup owns KB consecutive kz columns of one y row for all three components ([3][KB][Nx] complex in LDS),
+// runs the forward x transforms (Stockham radix-4/2, in place through registers), applies scale_node, runs the inverse
+// transforms and stores -- the spectra cross HBM once instead of three times (rocFFT x pass, k_scale, rocFFT x pass).
+// Both transforms are unnormalised: the 1/Ng lives in the scale factor (Helper.cu:325-326).
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+template <int LOGN, int KB, int NTH, bool INVERSE>
+__device__ __forceinline__ void lds_fft_x(double2 *__restrict__ d, const double2 *__restrict__ tw) {
+    constexpr int N = 1 << LOGN, NCOL = 3 * KB, CS = N + 1;   // padded column stride: columns start on different banks
+    const int tid = threadIdx.x;
+    int ns = 1;
+#pragma unroll
+    for (int done = 0; done < LOGN;) {
+        if (LOGN - done >= 2) {
+            constexpr int R = 4, NB = NCOL * (N / R), PER = (NB + NTH - 1) / NTH;
+            double2 v[PER][R];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int bfly = tid + q * NTH;
+                if (bfly < NB) {
+                    const int col = bfly / (N / R), jj = bfly - col * (N / R), kk = jj & (ns - 1);
+                    const double2 *src = d + col * CS + jj;
+                    const int tstep = kk * (N / (ns * R));
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        double2 x = src[r * (N / R)];
+                        if (r) { double2 w = tw[r * tstep]; if (INVERSE) w.y = -w.y; x = cmul(x, w); }
+                        v[q][r] = x;
+                    }
+                    const double2 a0 = make_double2(v[q][0].x + v[q][2].x, v[q][0].y + v[q][2].y);
+                    const double2 a1 = make_double2(v[q][0].x - v[q][2].x, v[q][0].y - v[q][2].y);
+                    const double2 a2 = make_double2(v[q][1].x + v[q][3].x, v[q][1].y + v[q][3].y);
+                    const double2 t = make_double2(v[q][1].x - v[q][3].x, v[q][1].y - v[q][3].y);
+                    const double2 a3 = INVERSE ? make_double2(-t.y, t.x) : make_double2(t.y, -t.x);   // +-i (v1 - v3)
+                    v[q][0] = make_double2(a0.x + a2.x, a0.y + a2.y);
+                    v[q][1] = make_double2(a1.x + a3.x, a1.y + a3.y);
+                    v[q][2] = make_double2(a0.x - a2.x, a0.y - a2.y);
+                    v[q][3] = make_double2(a1.x - a3.x, a1.y - a3.y);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int bfly = tid + q * NTH;
+                if (bfly < NB) {
+                    const int col = bfly / (N / R), jj = bfly - col * (N / R), kk = jj & (ns - 1);
+                    double2 *dst = d + col * CS + (jj - kk) * R + kk;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) dst[r * ns] = v[q][r];
+                }
+            }
+            __syncthreads();
+            ns *= 4; done += 2;
+        } else {
+            constexpr int R = 2, NB = NCOL * (N / R), PER = (NB + NTH - 1) / NTH;
+            double2 v[PER][R];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int bfly = tid + q * NTH;
+                if (bfly < NB) {
+                    const int col = bfly / (N / R), jj = bfly - col * (N / R), kk = jj & (ns - 1);
+                    const double2 *src = d + col * CS + jj;
+                    double2 w = tw[kk * (N / (ns * R))];
+                    if (INVERSE) w.y = -w.y;
+                    const double2 x0 = src[0], x1 = cmul(src[N / R], w);
+                    v[q][0] = make_double2(x0.x + x1.x, x0.y + x1.y);
+                    v[q][1] = make_double2(x0.x - x1.x, x0.y - x1.y);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int bfly = tid + q * NTH;
+                if (bfly < NB) {
+                    const int col = bfly / (N / R), jj = bfly - col * (N / R), kk = jj & (ns - 1);
+                    double2 *dst = d + col * CS + (jj - kk) * R + kk;
+                    dst[0] = v[q][0];
+                    dst[ns] = v[q][1];
+                }
+            }
+            __syncthreads();
+            ns *= 2; done += 1;
+        }
+    }
+}
+
+template <int LOGN, int KB, int NTH>
+__global__ void __launch_bounds__(NTH)
+k_xfft_scale(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ Z, DGrid G, DBox box, ScaleArgs a,
+             const double2 *__restrict__ twiddle) {
+    constexpr int N = 1 << LOGN, CS = N + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double2 *d = reinterpret_cast<double2 *>(smem_raw);      // [3][KB][N + 1]
+    double2 *tw = d + 3 * KB * CS;                            // [N]  exp(-2 pi i m / N)
+    const int tid = threadIdx.x;
+    const int nkb = (G.Nzh + KB - 1) / KB;
+    const int j = blockIdx.x / nkb, k0 = (blockIdx.x - j * nkb) * KB;
+    const int kv = min(KB, G.Nzh - k0);
+    double2 *comp[3] = {X, Y, Z};
+    const size_t xstride = (size_t)G.Ny * G.Nzh, base = (size_t)j * G.Nzh + k0;
+    for (int e = tid; e < N; e += NTH) tw[e] = twiddle[e];
+    for (int e = tid; e < 3 * N * KB; e += NTH) {             // KB consecutive kz are contiguous in memory (128 B at KB = 8)
+        const int c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
+        d[(c * KB + q) * CS + x] = q < kv ? comp[c][(size_t)x * xstride + base + q] : make_double2(0, 0);
+    }
+    __syncthreads();
+    lds_fft_x<LOGN, KB, NTH, false>(d, tw);
+    for (int e = tid; e < N * KB; e += NTH) {
+        const int x = e / KB, q = e - x * KB;
+        if (q < kv) {
+            const double2 f[3] = {d[q * CS + x], d[(KB + q) * CS + x], d[(2 * KB + q) * CS + x]};
+            double2 out[3];
+            scale_node(x, j, k0 + q, f, G, box, a, out);
+            d[q * CS + x] = out[0]; d[(KB + q) * CS + x] = out[1]; d[(2 * KB + q) * CS + x] = out[2];
+        }
+    }
+    __syncthreads();
+    lds_fft_x<LOGN, KB, NTH, true>(d, tw);
+    for (int e = tid; e < 3 * N * KB; e += NTH) {
+        const int c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
+        if (q < kv) comp[c][(size_t)x * xstride + base + q] = d[(c * KB + q) * CS + x];
+    }
+}
+
+bool xfuse_supported(int Nx) { return Nx >= 16 && Nx <= 512 && (Nx & (Nx - 1)) == 0; }
+
+template <int LOGN, int KB, int NTH>
+static void launch_xfft_t(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s) {
+    constexpr int N = 1 << LOGN;
+    const size_t lds = (size_t)(3 * KB * (N + 1) + N) * sizeof(double2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xfft_scale<LOGN, KB, NTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int nkb = (G.Nzh + KB - 1) / KB;
+    hipLaunchKernelGGL((k_xfft_scale<LOGN, KB, NTH>), dim3(G.Ny * nkb), dim3(NTH), lds, s, X, Y, Z, G, box, a, tw);
+}
+
+void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s) {
+    switch (G.Nx) {   // 8 kz columns per workgroup = 128-byte pieces; LDS = 3*KB*(N+1)*16 B
+        case 16: launch_xfft_t<4, 8, 256>(X, Y, Z, G, box, a, tw, s); break;
+        case 32: launch_xfft_t<5, 8, 256>(X, Y, Z, G, box, a, tw, s); break;
+        case 64: launch_xfft_t<6, 8, 256>(X, Y, Z, G, box, a, tw, s); break;
+        case 128: launch_xfft_t<7, 8, 512>(X, Y, Z, G, box, a, tw, s); break;
+        case 256: {
+            static const int cfg = getenv("PSE_XFUSE_CFG") ? atoi(getenv("PSE_XFUSE_CFG")) : 0;
+            if (cfg == 1) launch_xfft_t<8, 8, 1024>(X, Y, Z, G, box, a, tw, s);
+            else if (cfg == 2) launch_xfft_t<8, 6, 512>(X, Y, Z, G, box, a, tw, s);
+            else if (cfg == 3) launch_xfft_t<8, 4, 512>(X, Y, Z, G, box, a, tw, s);
+            else if (cfg == 4) launch_xfft_t<8, 2, 256>(X, Y, Z, G, box, a, tw, s);
+            else launch_xfft_t<8, 4, 256>(X, Y, Z, G, box, a, tw, s);
+            break;
+        }
+        default: launch_xfft_t<9, 4, 1024>(X, Y, Z, G, box, a, tw, s); break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ slab transposes

@@ -179,3 +179,19 @@ def test_step_integrates_and_wraps(torch_cuda, oracle):
     assert np.all(got[:, 3] == 1.0)
     assert np.abs(accel.cpu().numpy() - force / 2.0).max() < 1e-15
     assert newimg.any(), "test should exercise the wrap"
+
+
+@pytest.mark.parametrize("grid,xy,P", [((32, 32, 32), 0.0, 0), ((64, 48, 40), 0.3, 0), ((16, 36, 30), -0.2, 4), ((128, 32, 32), 0.1, 5)])
+def test_fused_x_pass_matches_port(torch_cuda, oracle, grid, xy, P):
+    """Power-of-two Nx takes the fused forward-x FFT + k-space scaling (+noise) + inverse-x FFT kernel."""
+    import pse_amd
+    n = 1200
+    pos, force, box = make_suspension(n, L=24.0, xy=xy)
+    seed, ts, kT, dt = 31, 4, 1.0, 1e-3
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3, seed=seed, grid=grid, P=P)
+    p = oracle.select_params(box, 0.5, 1e-3, 0.5, grid=grid, P=P or None)
+    u = eng.mobility(to4(pos), to4(force), parts=2).cpu().numpy()[:, :3]
+    assert rel(u, oracle.mobility_wave(pos, force, box, p)) < 1e-10
+    vel, m = eng.brownian_velocity(to4(pos), to4(force), kT, dt, ts)
+    ref, mref = oracle.brownian_velocity(pos, force, box, p, kT, dt, seed, ts)
+    assert m == mref and rel(vel.cpu().numpy()[:, :3], ref) < 1e-9

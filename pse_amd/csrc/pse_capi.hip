@@ -61,7 +61,10 @@ struct pse_handle {
     DCells nc;
     double cell_gamma;  // tilt bound the cell grid was sized for
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // main chain: sort, near field, Lanczos, update (caller-visible ordering)
+    hipStream_t wstream = nullptr;   // wave-space chain; == stream unless the two chains overlap (single GPU)
+    hipStream_t side = nullptr;      // owned non-blocking stream behind wstream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int n_max = 0, n_pad = 0;
     // sorted particle state
     unsigned *keys = nullptr, *keys_s = nullptr, *vals = nullptr, *perm = nullptr, *tag_s = nullptr;
@@ -137,11 +140,14 @@ static int set_cells(pse_handle *h, double gamma) {
 
 static int ts(pse_handle *h, int p) { if (h->timing) HIPCHK(hipEventRecord(h->ph[p].a, h->stream)); return 0; }
 static int te(pse_handle *h, int p) { if (h->timing) HIPCHK(hipEventRecord(h->ph[p].b, h->stream)); return 0; }
+static int tsw(pse_handle *h, int p) { if (h->timing) HIPCHK(hipEventRecord(h->ph[p].a, h->wstream)); return 0; }
+static int tew(pse_handle *h, int p) { if (h->timing) HIPCHK(hipEventRecord(h->ph[p].b, h->wstream)); return 0; }
 enum { PH_SORT, PH_SPREAD, PH_FFTF, PH_SCALE, PH_FFTI, PH_GATHER, PH_REAL, PH_LANCZOS, PH_INTEG, PH_COMM, PH_TOTAL, PH_MATVEC };
 
 static int collect_times(pse_handle *h, unsigned mask) {
     if (!h->timing) return 0;
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->side) HIPCHK(hipStreamSynchronize(h->side));
     double *dst[12] = {&h->info.t_sort, &h->info.t_spread, &h->info.t_fft_fwd, &h->info.t_scale, &h->info.t_fft_inv,
                        &h->info.t_gather, &h->info.t_real, &h->info.t_lanczos, &h->info.t_integrate, &h->info.t_comm,
                        &h->info.t_total, &h->info.t_matvec};
@@ -197,6 +203,9 @@ extern "C" int pse_destroy(pse_handle *h) {
                     h->scal, h->partials, h->t_dev};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &p : h->ph) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->side) (void)hipStreamDestroy(h->side);
     delete h;
     return 0;
 }
@@ -260,8 +269,8 @@ static int make_plans(pse_handle *h) {
         FFTCHK(rocfft_execution_info_set_work_buffer(h->info_fwd, h->fft_work, work));
         FFTCHK(rocfft_execution_info_set_work_buffer(h->info_inv, h->fft_work, work));
     }
-    FFTCHK(rocfft_execution_info_set_stream(h->info_fwd, h->stream));
-    FFTCHK(rocfft_execution_info_set_stream(h->info_inv, h->stream));
+    FFTCHK(rocfft_execution_info_set_stream(h->info_fwd, h->wstream));
+    FFTCHK(rocfft_execution_info_set_stream(h->info_inv, h->wstream));
     return 0;
 }
 
@@ -346,6 +355,16 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     TRY(dmalloc(h, &h->rgrid, 3 * nr));
     TRY(dmalloc(h, &h->cgrid, 3 * ncx));
     if (h->n_slabs > 1) { TRY(dmalloc(h, &h->sendbuf, 3 * ncx)); TRY(dmalloc(h, &h->recvbuf, 3 * ncx)); }
+    // The wave-space chain (spread -> FFTs -> gather) and the real-space chain (near field + Lanczos) only meet in the
+    // final sum: on a single GPU they run on two streams, so latency-bound kernels of one chain fill the gaps of the
+    // other and the Lanczos host checks do not stall the far field.  (Teams keep one stream: one RCCL communicator.)
+    h->wstream = h->stream;
+    if (h->n_slabs == 1 && !getenv("PSE_NO_OVERLAP")) {
+        HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        h->wstream = h->side;
+    }
     TRY(make_plans(h));
 
     TRY(dmalloc(h, &h->V, (size_t)(M_MAX + 1) * n));
@@ -389,8 +408,11 @@ extern "C" int pse_set_box(pse_handle *h, double Lx, double Ly, double Lz, doubl
 extern "C" int pse_set_stream(pse_handle *h, void *stream) {
     if (!h) return fail(PSE_ERR_INVALID, "null handle");
     h->stream = (hipStream_t)stream;
-    FFTCHK(rocfft_execution_info_set_stream(h->info_fwd, h->stream));
-    FFTCHK(rocfft_execution_info_set_stream(h->info_inv, h->stream));
+    if (!h->side) {
+        h->wstream = h->stream;
+        FFTCHK(rocfft_execution_info_set_stream(h->info_fwd, h->wstream));
+        FFTCHK(rocfft_execution_info_set_stream(h->info_inv, h->wstream));
+    }
     return 0;
 }
 extern "C" int pse_set_timing(pse_handle *h, int enabled) {
@@ -555,11 +577,11 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
         const DGrid &G = h->G;
         const size_t nr = (size_t)(G.nxl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
         double *gx = h->rgrid, *gy = h->rgrid + nr, *gz = h->rgrid + 2 * nr;
-        TRY(ts(h, PH_SPREAD));
-        if (spread_needs_zero(G)) HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->stream));
-        launch_spread(h->pos_s, h->f_s, h->sup_s, N, h->cell_off, h->nc, gx, gy, gz, G, h->dbox, h->sw, h->stream);
-        TRY(te(h, PH_SPREAD));
-        TRY(ts(h, PH_FFTF));
+        TRY(tsw(h, PH_SPREAD));
+        if (spread_needs_zero(G)) HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->wstream));
+        launch_spread(h->pos_s, h->f_s, h->sup_s, N, h->cell_off, h->nc, gx, gy, gz, G, h->dbox, h->sw, h->wstream);
+        TRY(tew(h, PH_SPREAD));
+        TRY(tsw(h, PH_FFTF));
         if (T.G == 1) {
             void *in[1] = {h->rgrid}, *out[1] = {h->cgrid};
             FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
@@ -568,34 +590,34 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
                 void *in[1] = {h->rgrid + c * nr}, *out[1] = {h->cgrid + c * ncx};
                 FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
             }
-            launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzh, h->nyl, 0, h->stream);
+            launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzh, h->nyl, 0, h->wstream);
         }
-        TRY(te(h, PH_FFTF));
+        TRY(tew(h, PH_FFTF));
     }
     if (T.G > 1) {
-        for (pse_handle *h : T.m) TRY(ts(h, PH_COMM));
+        for (pse_handle *h : T.m) TRY(tsw(h, PH_COMM));
         pse_handle *h0 = T.m[0];
         const size_t blk = (size_t)h0->G.nxl * h0->nyl * h0->G.Nzh * 2, comp = blk * T.G;
         for (int c = 0; c < 3; ++c)
             TRY(team_all_to_all(T, [&](pse_handle *h) { return (double *)h->sendbuf + c * comp; },
                                 [&](pse_handle *h) { return (double *)h->recvbuf + c * comp; }, blk));
-        for (pse_handle *h : T.m) TRY(te(h, PH_COMM));
+        for (pse_handle *h : T.m) TRY(tew(h, PH_COMM));
     }
     for (pse_handle *h : T.m) {
         const DGrid &G = h->G;
         const size_t ncx = (size_t)G.nxl * G.Ny * G.Nzh;
         double2 *sp = T.G == 1 ? h->cgrid : h->recvbuf;   // [3][Nx][nyl][Nzh] after the transpose
-        TRY(ts(h, PH_SCALE));
+        TRY(tsw(h, PH_SCALE));
         if (h->xfuse) {
-            launch_xfft_scale(sp, sp + ncx, sp + 2 * ncx, G, h->dbox, scale_args(h, noise, kT, dt, timestep), h->twiddle, h->stream);
+            launch_xfft_scale(sp, sp + ncx, sp + 2 * ncx, G, h->dbox, scale_args(h, noise, kT, dt, timestep), h->twiddle, h->wstream);
         } else {
             if (T.G > 1)
                 for (int c = 0; c < 3; ++c) { void *io[1] = {sp + c * ncx}; FFTCHK(rocfft_execute(h->plan_x_fwd, io, nullptr, h->info_fwd)); }
-            launch_scale(sp, sp + ncx, sp + 2 * ncx, G, h->dbox, scale_args(h, noise, kT, dt, timestep), h->stream);
+            launch_scale(sp, sp + ncx, sp + 2 * ncx, G, h->dbox, scale_args(h, noise, kT, dt, timestep), h->wstream);
             if (T.G > 1)
                 for (int c = 0; c < 3; ++c) { void *io[1] = {sp + c * ncx}; FFTCHK(rocfft_execute(h->plan_x_inv, io, nullptr, h->info_inv)); }
         }
-        TRY(te(h, PH_SCALE));
+        TRY(tew(h, PH_SCALE));
     }
     if (T.G > 1) {
         pse_handle *h0 = T.m[0];
@@ -607,26 +629,26 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
     for (pse_handle *h : T.m) {
         const DGrid &G = h->G;
         const size_t nr = (size_t)(G.nxl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
-        TRY(ts(h, PH_FFTI));
+        TRY(tsw(h, PH_FFTI));
         if (T.G == 1) {
             void *in[1] = {h->cgrid}, *out[1] = {h->rgrid};
             FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv));
         } else {
-            launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzh, h->nyl, 1, h->stream);
+            launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzh, h->nyl, 1, h->wstream);
             for (int c = 0; c < 3; ++c) {
                 void *in[1] = {h->cgrid + c * ncx}, *out[1] = {h->rgrid + c * nr};
                 FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv));
             }
         }
-        TRY(te(h, PH_FFTI));
+        TRY(tew(h, PH_FFTI));
     }
     TRY(team_halo_shift(T));
     for (pse_handle *h : T.m) {
         const DGrid &G = h->G;
         const size_t nr = (size_t)(G.nxl + G.nhalo) * G.Ny * G.Nz;
-        TRY(ts(h, PH_GATHER));
-        launch_gather(h->pos_s, h->sup_s, h->sw.wtab, h->cell_off, h->nc, N, h->rgrid, h->rgrid + nr, h->rgrid + 2 * nr, G, h->dbox, h->uw_s, h->stream);
-        TRY(te(h, PH_GATHER));
+        TRY(tsw(h, PH_GATHER));
+        launch_gather(h->pos_s, h->sup_s, h->sw.wtab, h->cell_off, h->nc, N, h->rgrid, h->rgrid + nr, h->rgrid + 2 * nr, G, h->dbox, h->uw_s, h->wstream);
+        TRY(tew(h, PH_GATHER));
         HIPCHK(hipGetLastError());
     }
     // every particle was gathered by exactly one rank (zeros elsewhere): the sum is the full wave-space velocity
@@ -734,6 +756,11 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
     *mask |= 1u << PH_SORT;
     const bool noise = kT > 0.0;
     if (parts & 2) {
+        for (pse_handle *h : T.m)
+            if (h->side) {   // fork: the wave chain starts once the sorted arrays exist
+                HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+                HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+            }
         TRY(wave(T, N, noise, kT, dt, timestep));
         *mask |= (1u << PH_SPREAD) | (1u << PH_FFTF) | (1u << PH_SCALE) | (1u << PH_FFTI) | (1u << PH_GATHER);
         if (T.G > 1) *mask |= 1u << PH_COMM;
@@ -757,6 +784,10 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
     }
     for (size_t r = 0; r < T.m.size(); ++r) {
         pse_handle *h = T.m[r];
+        if ((parts & 2) && h->side) {   // join
+            HIPCHK(hipEventRecord(h->ev_join, h->side));
+            HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+        }
         launch_scatter_sum((parts & 2) ? h->uw_s : nullptr, (parts & 1) ? h->ur_s : nullptr, noise ? h->ub_s : nullptr,
                            h->tag_s, N, a[r].vel, h->stream);
         HIPCHK(hipGetLastError());
@@ -903,6 +934,7 @@ extern "C" int pse_debug_copy_grid(pse_handle *h, int stage, double *host_out) {
     (void)stage;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->side) HIPCHK(hipStreamSynchronize(h->side));
     const size_t plane = (size_t)h->G.Ny * h->G.Nz, full = plane * (h->G.nxl + h->G.nhalo);
     for (int c = 0; c < 3; ++c)   // the slab's own planes of each component (halo planes are not copied)
         HIPCHK(hipMemcpy(host_out + (size_t)c * plane * h->G.nxl, h->rgrid + c * full, plane * h->G.nxl * sizeof(double),

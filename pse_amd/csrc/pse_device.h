@@ -75,10 +75,10 @@ __host__ __device__ __forceinline__ double uniform_pm(uint32_t x, double s) {
     return (((double)x + 0.5) * 2.3283064365386963e-10 * 2.0 - 1.0) * s;
 }
 
-// exp(x) for x <= 0 -- the only exponentials on the path are Gaussian weights exp(-c r^2) and the k-space factor.
-// ~18 VALU instructions instead of the library's ~40: no overflow/NaN paths; underflow goes to 0 through ldexp.
-// |error| < 2 ulp: Cody-Waite reduction x = n ln2 + r, |r| <= ln2/2, Taylor to r^13 (remainder 4e-18).
-__device__ __forceinline__ double exp_neg(double x) {
+// exp(x) for |x| < 700 -- the exponentials on the path are Gaussian weights exp(-c r^2), their step ratios and the
+// k-space factor.  ~18 VALU instructions instead of the library's ~40: no overflow/NaN paths; underflow goes to 0
+// through ldexp.  |error| < 2 ulp: Cody-Waite reduction x = n ln2 + r, |r| <= ln2/2, Taylor to r^13 (remainder 4e-18).
+__device__ __forceinline__ double exp_lean(double x) {
     const double n = rint(x * 1.4426950408889634074);
     double r = fma(n, -6.93147180369123816490e-01, x);
     r = fma(n, -1.90821492927058770002e-10, r);
@@ -98,6 +98,7 @@ __device__ __forceinline__ double exp_neg(double x) {
     p = fma(p, r, 1.0);
     return ldexp(p, (int)n);
 }
+__device__ __forceinline__ double exp_neg(double x) { return exp_lean(x); }   // call sites whose argument is <= 0
 
 // ---- real-space pair functions ------------------------------------------------------------------------
 // f(r), g(r) of M_real = f (I - rr) + g rr  (replaces the fp32 linear table PSEv1/Stokes.cc:334-422 and its

@@ -199,33 +199,51 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec
     const bool shift_only = nc.nx > 1 && nc.ny > 1 && nc.nz > 1;   // otherwise finish with the rint minimum image
     int qn = 0, total = 0;
 
+    // two queue entries per iteration: their load -> distance -> table -> force chains are independent, which doubles the
+    // memory requests in flight of this latency-bound phase (57 % of its wave-cycles were s_waitcnt)
     auto drain = [&]() {
-        for (int q = 0; q < qn; ++q) {
-            const unsigned e = queue[q * TPB + tid];
-            const int j = (int)(e & JMASK);
-            double sx, sy, sz;
-            image_shift(e >> 27, box, sx, sy, sz);
-            const double4 pj = pos_s[j];
-            double dx = pi.x - pj.x - sx, dy = pi.y - pj.y - sy, dz = pi.z - pj.z - sz;
-            if (!shift_only) min_image(box, dx, dy, dz);
-            const double r2 = dx * dx + dy * dy + dz * dz;
-            double f, h;
-            eval_fg(r2, coef, f, h);
-            const double4 Fj = vec_s[j];
-            const double rdF = (dx * Fj.x + dy * Fj.y + dz * Fj.z) * h;
-            ux += f * Fj.x + rdF * dx;
-            uy += f * Fj.y + rdF * dy;
-            uz += f * Fj.z + rdF * dz;
+        for (int q = 0; q < qn; q += 2) {
+            const bool two = q + 1 < qn;
+            const unsigned e0 = queue[q * TPB + tid], e1 = queue[(two ? q + 1 : q) * TPB + tid];
+            const int j0 = (int)(e0 & JMASK), j1 = (int)(e1 & JMASK);
+            const double4 p0 = pos_s[j0], p1 = pos_s[j1];
+            const double4 F0 = vec_s[j0], F1 = vec_s[j1];
+            double s0x, s0y, s0z, s1x, s1y, s1z;
+            image_shift(e0 >> 27, box, s0x, s0y, s0z);
+            image_shift(e1 >> 27, box, s1x, s1y, s1z);
+            double d0x = pi.x - p0.x - s0x, d0y = pi.y - p0.y - s0y, d0z = pi.z - p0.z - s0z;
+            double d1x = pi.x - p1.x - s1x, d1y = pi.y - p1.y - s1y, d1z = pi.z - p1.z - s1z;
+            if (!shift_only) { min_image(box, d0x, d0y, d0z); min_image(box, d1x, d1y, d1z); }
+            const double r20 = d0x * d0x + d0y * d0y + d0z * d0z, r21 = d1x * d1x + d1y * d1y + d1z * d1z;
+            double f0, h0, f1, h1;
+            eval_fg(r20, coef, f0, h0);
+            eval_fg(r21, coef, f1, h1);
+            if (!two) { f1 = 0.0; h1 = 0.0; }
+            const double rd0 = (d0x * F0.x + d0y * F0.y + d0z * F0.z) * h0;
+            const double rd1 = (d1x * F1.x + d1y * F1.y + d1z * F1.z) * h1;
+            ux += f0 * F0.x + rd0 * d0x + f1 * F1.x + rd1 * d1x;
+            uy += f0 * F0.y + rd0 * d0y + f1 * F1.y + rd1 * d1y;
+            uz += f0 * F0.z + rd0 * d0z + f1 * F1.z + rd1 * d1z;
             if (LIST) {
+                // 36 B per pair: h = (g-f)/r^2 is folded into the separation, its sign rides on bit 31 of j
                 if (total < nb.cap) {
                     const size_t o = (size_t)total * nb.stride + i;
-                    // 36 B per pair: h = (g-f)/r^2 is folded into the separation, its sign rides on bit 31 of j
-                    const double q = sqrt(fabs(h));
-                    nb.j[o] = (unsigned)j | (h < 0.0 ? 0x80000000u : 0u);
-                    nb.f[o] = f;
-                    nb.dx[o] = q * dx; nb.dy[o] = q * dy; nb.dz[o] = q * dz;
+                    const double qq = sqrt(fabs(h0));
+                    nb.j[o] = (unsigned)j0 | (h0 < 0.0 ? 0x80000000u : 0u);
+                    nb.f[o] = f0;
+                    nb.dx[o] = qq * d0x; nb.dy[o] = qq * d0y; nb.dz[o] = qq * d0z;
                 }
                 ++total;
+                if (two) {
+                    if (total < nb.cap) {
+                        const size_t o = (size_t)total * nb.stride + i;
+                        const double qq = sqrt(fabs(h1));
+                        nb.j[o] = (unsigned)j1 | (h1 < 0.0 ? 0x80000000u : 0u);
+                        nb.f[o] = f1;
+                        nb.dx[o] = qq * d1x; nb.dy[o] = qq * d1y; nb.dz[o] = qq * d1z;
+                    }
+                    ++total;
+                }
             }
         }
         qn = 0;
@@ -404,21 +422,36 @@ __global__ void k_support(const double4 *__restrict__ pos_s, int N, DGrid G, DBo
     if (d0_s) d0_s[s] = d;
 }
 
+// One lane per (particle, row): rows 0..P-1 are the x rows A[.][ty] of the weight table, row P is B[.].  A Gaussian
+// sampled on a uniform stencil obeys E(t+1) = E(t) q r_t with q = exp(-2c X0 h) and r_t = exp(-c h^2 (2t+1)) (r_t does not
+// depend on the particle: passed in), so a row costs 2 exponentials + 2(P-1) multiplies: 2(P+1) exponentials per particle
+// instead of P^2+P.  With shear X0 depends on ty (PSEv1/Mobility.cu:230), which is why A is stored as rows in x.
+struct WeightConsts { double rx[8], rz[8]; };   // rx[t] = exp(-c hx^2 (2t+1)), rz[t] = exp(-c hz^2 (2t+1))
+
 template <int P>
 __global__ void __launch_bounds__(TPB)
-k_weights(const double4 *__restrict__ d0_s, int N, DGrid G, DBox box, double *__restrict__ wtab) {
-    constexpr unsigned WT = P * P + P;
-    const unsigned gid = blockIdx.x * TPB + threadIdx.x;   // N * WT < 2^32
-    const unsigned p = gid / WT;
-    const int e = (int)(gid - p * WT);
+k_weights(const double4 *__restrict__ d0_s, int N, DGrid G, DBox box, WeightConsts wc, double *__restrict__ wtab) {
+    constexpr unsigned WT = P * P + P, ROWS = P + 1;
+    const unsigned gid = blockIdx.x * TPB + threadIdx.x;   // N * (P + 1) < 2^32
+    const unsigned p = gid / ROWS;
+    const int row = (int)(gid - p * ROWS);
     if (p >= (unsigned)N) return;
     const double4 d0 = d0_s[p];
-    // branch-free: A entries and B entries pick their squared distance with selects and share ONE exponential
-    const bool isA = e < P * P;
-    const int tx = e / P, ty = e - tx * P;
-    const double ey = G.hy * (d0.y + ty), ex = G.hx * (d0.x + tx) + box.xy * ey;
-    const double ez = G.hz * (d0.z + (e - P * P));
-    wtab[gid] = exp_neg(-G.expfac * (isA ? ex * ex + ey * ey : ez * ez));
+    double *out = wtab + (size_t)p * WT;
+    const double c = G.expfac;
+    if (row < P) {
+        const double ey = G.hy * (d0.y + row), x0 = G.hx * d0.x + box.xy * ey;
+        double e = exp_neg(-c * (x0 * x0 + ey * ey));
+        const double q = exp_lean(-2.0 * c * x0 * G.hx);
+#pragma unroll
+        for (int t = 0; t < P; ++t) { out[t * P + row] = e; e *= q * wc.rx[t]; }
+    } else {
+        const double z0 = G.hz * d0.z;
+        double e = exp_neg(-c * z0 * z0);
+        const double q = exp_lean(-2.0 * c * z0 * G.hz);
+#pragma unroll
+        for (int t = 0; t < P; ++t) { out[P * P + t] = e; e *= q * wc.rz[t]; }
+    }
 }
 
 // ---- per-tile particle lists built in LDS --------------------------------------------------------------------------
@@ -623,9 +656,13 @@ bool spread_needs_zero(const DGrid &G) { return !farfield_fast_path(G); }
 template <int P>
 static void launch_spread_p(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, const int *cell_off, DCells nc,
                             double *gx, double *gy, double *gz, DGrid G, DBox box, SpreadWork w, hipStream_t s) {
-    constexpr int WT = P * P + P;
     hipLaunchKernelGGL(k_support, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos_s, N, G, box, sup_s, w.d0_s);
-    hipLaunchKernelGGL(k_weights<P>, dim3(nblocks((long)N * WT, TPB)), dim3(TPB), 0, s, w.d0_s, N, G, box, w.wtab);
+    WeightConsts wc;
+    for (int t = 0; t < 8; ++t) {
+        wc.rx[t] = std::exp(-G.expfac * G.hx * G.hx * (2 * t + 1));
+        wc.rz[t] = std::exp(-G.expfac * G.hz * G.hz * (2 * t + 1));
+    }
+    hipLaunchKernelGGL(k_weights<P>, dim3(nblocks((long)N * (P + 1), TPB)), dim3(TPB), 0, s, w.d0_s, N, G, box, wc, w.wtab);
     int TX, TY, TZ;
     tile_dims(TX, TY, TZ);
     const int ntx = (G.nxl + TX - 1) / TX, nty = (G.Ny + TY - 1) / TY, ntz = (G.Nz + TZ - 1) / TZ;

@@ -89,6 +89,9 @@ struct pse_handle {
     // slab decomposition (n_slabs > 1): x planes [x0, x0+nxl) of the real grid, y rows [y0, y0+nyl) of the transposed spectrum
     int n_slabs = 1, slab_rank = 0, nyl = 0, y0 = 0;
     double2 *sendbuf = nullptr, *recvbuf = nullptr;          // [3][n_slabs][nxl][nyl][Nzh] each
+    int *d_bidx = nullptr, *d_bounds = nullptr;              // slab mode: cell indices / row offsets of the cell-slab boundaries
+    std::vector<int> row_lo, first_end, last_begin;          // per rank: own rows [row_lo[r], row_lo[r+1]), first / last cell layer
+    double4 *utot_s = nullptr;                               // slab mode: summed velocity of the own rows, all-gathered
     bool xfuse = false;                                      // single GPU, power-of-two Nx: 2-D rocFFT + fused x pass
     double2 *twiddle = nullptr;                              // [Nx] exp(-2 pi i m / Nx)
     void *fft_work = nullptr;
@@ -134,6 +137,14 @@ static int set_cells(pse_handle *h, double gamma) {
                     "the minimum-image near field needs rcut <= L/2; increase xi", rc, wx, wy, wz, gamma);
     auto n = [&](double w) { int c = (int)std::floor(w / rc); if (c < 3) c = 1; if (c > 1024) c = 1024; return c; };
     h->nc = DCells{n(wx), n(wy), n(wz)};
+    if (h->n_slabs > 1) {
+        // cell slabs coincide with grid slabs: every rank owns ncx/G whole cell layers = one contiguous row range
+        const int c = (int)std::floor(wx / rc) / h->n_slabs * h->n_slabs;
+        if (c < 3 || c < h->n_slabs)
+            return fail(PSE_ERR_INVALID, "box too small to split the near field over %d ranks: only %d cells of width >= rcut "
+                        "fit along x", h->n_slabs, (int)std::floor(wx / rc));
+        h->nc.nx = std::min(c, 1024 / h->n_slabs * h->n_slabs);
+    }
     h->cell_gamma = gamma;
     return 0;
 }
@@ -199,7 +210,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
     void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->sup_s, h->sw.wtab, h->sw.d0_s, h->nb.j, h->nb.f, h->nb.dx, h->nb.dy, h->nb.dz, h->nb.cnt, h->pos_s,
-                    h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->twiddle, h->fft_work, h->V,
+                    h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->twiddle, h->fft_work, h->V,
                     h->scal, h->partials, h->t_dev};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &p : h->ph) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
@@ -285,6 +296,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     else HIPCHK(hipGetDevice(&h->device));
     h->n_max = (int)p->n_max;
     set_dbox(h);
+    h->n_slabs = std::max(1, p->n_slabs);
     TRY(set_cells(h, std::max(std::fabs(p->xy), p->max_strain)));
     fill_info(d, &h->info);
     h->info.ncell_x = h->nc.nx; h->info.ncell_y = h->nc.ny; h->info.ncell_z = h->nc.nz;
@@ -302,7 +314,10 @@ static int create_impl(const pse_params *p, pse_handle *h) {
             return fail(PSE_ERR_INVALID, "slabs of %d planes are thinner than the support P = %d", d.Nx / h->n_slabs, d.P);
     }
     G.nxl = d.Nx / h->n_slabs; G.x0 = h->slab_rank * G.nxl;
-    G.nhalo = h->n_slabs > 1 ? d.P - 1 : 0;
+    // the gather of a particle is done by the rank whose slab holds the particle; its support reaches (P-1)/2 planes
+    // below and (P+1)/2 planes above that slab: copies of the neighbours' planes are stored around the own ones
+    G.hl = h->n_slabs > 1 ? (d.P - 1) / 2 : 0;
+    G.nhalo = h->n_slabs > 1 ? (d.P + 1) / 2 : 0;
     h->nyl = d.Ny / h->n_slabs; h->y0 = h->slab_rank * h->nyl;
     G.hx = d.hx; G.hy = d.hy; G.hz = d.hz;
     const double c = 2.0 * d.xi * d.xi / d.eta;
@@ -351,10 +366,14 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     TRY(dmalloc(h, &h->coef, coef.size()));
     HIPCHK(hipMemcpy(h->coef, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice));
 
-    const size_t nr = (size_t)(G.nxl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
+    const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
     TRY(dmalloc(h, &h->rgrid, 3 * nr));
     TRY(dmalloc(h, &h->cgrid, 3 * ncx));
-    if (h->n_slabs > 1) { TRY(dmalloc(h, &h->sendbuf, 3 * ncx)); TRY(dmalloc(h, &h->recvbuf, 3 * ncx)); }
+    if (h->n_slabs > 1) {
+        TRY(dmalloc(h, &h->sendbuf, 3 * ncx)); TRY(dmalloc(h, &h->recvbuf, 3 * ncx));
+        TRY(dmalloc(h, &h->d_bidx, (size_t)3 * h->n_slabs + 1)); TRY(dmalloc(h, &h->d_bounds, (size_t)3 * h->n_slabs + 1));
+        TRY(dmalloc(h, &h->utot_s, n));
+    }
     // The wave-space chain (spread -> FFTs -> gather) and the real-space chain (near field + Lanczos) only meet in the
     // final sum: on a single GPU they run on two streams, so latency-bound kernels of one chain fill the gaps of the
     // other and the Lanczos host checks do not stall the far field.  (Teams keep one stream: one RCCL communicator.)
@@ -504,29 +523,96 @@ static int team_all_reduce_sum(pse_team &T, FB buf, size_t n_doubles) {
     for (pse_handle *h : T.m) HIPCHK(hipMemcpyAsync(buf(h), T.scratch, n_doubles * sizeof(double), hipMemcpyDeviceToDevice, s));
     return 0;
 }
-// gather halo: every rank receives the first `planes` planes of each component from the rank that owns the next slab
-static int team_halo_shift(pse_team &T) {
+// gather halo: every rank stores copies of its left neighbour's last hl planes below its slab and of its right
+// neighbour's first nhalo planes above it
+static int team_halo_exchange(pse_team &T) {
     if (T.G == 1) return 0;
-    auto comp = [](pse_handle *h, int c) { return h->rgrid + (size_t)c * (h->G.nxl + h->G.nhalo) * h->G.Ny * h->G.Nz; };
+    auto comp = [](pse_handle *h, int c) { return h->rgrid + (size_t)c * (h->G.nxl + h->G.hl + h->G.nhalo) * h->G.Ny * h->G.Nz; };
     if (T.nccl) {
         pse_handle *h = T.m[0];
-        const size_t plane = (size_t)h->G.Ny * h->G.Nz, cnt = plane * h->G.nhalo;
+        const DGrid &G = h->G;
+        const size_t plane = (size_t)G.Ny * G.Nz;
         const int left = (h->slab_rank + T.G - 1) % T.G, right = (h->slab_rank + 1) % T.G;
         NCCLCHK(ncclGroupStart());
         for (int c = 0; c < 3; ++c) {
-            NCCLCHK(ncclSend(comp(h, c), cnt, ncclDouble, left, T.nccl, h->stream));
-            NCCLCHK(ncclRecv(comp(h, c) + plane * h->G.nxl, cnt, ncclDouble, right, T.nccl, h->stream));
+            double *own = comp(h, c) + plane * G.hl;
+            NCCLCHK(ncclSend(own, plane * G.nhalo, ncclDouble, left, T.nccl, h->stream));                          // my first planes
+            NCCLCHK(ncclSend(own + plane * (G.nxl - G.hl), plane * G.hl, ncclDouble, right, T.nccl, h->stream));   // my last planes
+            NCCLCHK(ncclRecv(own + plane * G.nxl, plane * G.nhalo, ncclDouble, right, T.nccl, h->stream));
+            NCCLCHK(ncclRecv(comp(h, c), plane * G.hl, ncclDouble, left, T.nccl, h->stream));
         }
         NCCLCHK(ncclGroupEnd());
         return 0;
     }
+    auto member = [&](int r) { for (pse_handle *h : T.m) if (h->slab_rank == r) return h; return (pse_handle *)nullptr; };
     for (pse_handle *dst : T.m) {
-        pse_handle *src = nullptr;
-        for (pse_handle *h : T.m) if (h->slab_rank == (dst->slab_rank + 1) % T.G) src = h;
-        const size_t plane = (size_t)dst->G.Ny * dst->G.Nz, cnt = plane * dst->G.nhalo;
-        for (int c = 0; c < 3; ++c)
-            HIPCHK(hipMemcpyAsync(comp(dst, c) + plane * dst->G.nxl, comp(src, c), cnt * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+        const DGrid &G = dst->G;
+        const size_t plane = (size_t)G.Ny * G.Nz;
+        pse_handle *L = member((dst->slab_rank + T.G - 1) % T.G), *R = member((dst->slab_rank + 1) % T.G);
+        for (int c = 0; c < 3; ++c) {
+            HIPCHK(hipMemcpyAsync(comp(dst, c) + plane * (G.hl + G.nxl), comp(R, c) + plane * G.hl, plane * G.nhalo * sizeof(double),
+                                  hipMemcpyDeviceToDevice, dst->stream));
+            HIPCHK(hipMemcpyAsync(comp(dst, c), comp(L, c) + plane * (G.hl + G.nxl - G.hl), plane * G.hl * sizeof(double),
+                                  hipMemcpyDeviceToDevice, dst->stream));
+        }
     }
+    return 0;
+}
+
+// ghost rows of a distributed vector: every rank receives its right neighbour's first cell layer and its left
+// neighbour's last cell layer (the near-field mat-vec of the own rows reads exactly those besides the own rows)
+template <class FB>
+static int team_ghost_exchange(pse_team &T, FB buf) {
+    if (T.G == 1) return 0;
+    pse_handle *h0 = T.m[0];
+    const std::vector<int> &lo = h0->row_lo, &fe = h0->first_end, &lb = h0->last_begin;
+    auto cnt = [](int a, int b) { return (size_t)std::max(0, b - a) * 4; };
+    if (T.nccl) {
+        pse_handle *h = T.m[0];
+        const int r = h->slab_rank, L = (r + T.G - 1) % T.G, R = (r + 1) % T.G;
+        NCCLCHK(ncclGroupStart());
+        NCCLCHK(ncclSend(buf(h) + (size_t)lo[r] * 4, cnt(lo[r], fe[r]), ncclDouble, L, T.nccl, h->stream));
+        NCCLCHK(ncclSend(buf(h) + (size_t)lb[r] * 4, cnt(lb[r], lo[r + 1]), ncclDouble, R, T.nccl, h->stream));
+        NCCLCHK(ncclRecv(buf(h) + (size_t)lo[R] * 4, cnt(lo[R], fe[R]), ncclDouble, R, T.nccl, h->stream));
+        NCCLCHK(ncclRecv(buf(h) + (size_t)lb[L] * 4, cnt(lb[L], lo[L + 1]), ncclDouble, L, T.nccl, h->stream));
+        NCCLCHK(ncclGroupEnd());
+        return 0;
+    }
+    auto member = [&](int r) { for (pse_handle *h : T.m) if (h->slab_rank == r) return h; return (pse_handle *)nullptr; };
+    for (pse_handle *dst : T.m) {
+        const int r = dst->slab_rank, L = (r + T.G - 1) % T.G, R = (r + 1) % T.G;
+        HIPCHK(hipMemcpyAsync(buf(dst) + (size_t)lo[R] * 4, buf(member(R)) + (size_t)lo[R] * 4, cnt(lo[R], fe[R]) * sizeof(double),
+                              hipMemcpyDeviceToDevice, dst->stream));
+        HIPCHK(hipMemcpyAsync(buf(dst) + (size_t)lb[L] * 4, buf(member(L)) + (size_t)lb[L] * 4, cnt(lb[L], lo[L + 1]) * sizeof(double),
+                              hipMemcpyDeviceToDevice, dst->stream));
+    }
+    return 0;
+}
+
+// every rank's own rows [row_lo[r], row_lo[r+1]) of buf become visible on every rank (blocks of different sizes)
+template <class FB>
+static int team_all_gather_rows(pse_team &T, FB buf) {
+    if (T.G == 1) return 0;
+    const std::vector<int> &lo = T.m[0]->row_lo;
+    if (T.nccl) {
+        pse_handle *h = T.m[0];
+        const int r = h->slab_rank;
+        NCCLCHK(ncclGroupStart());
+        for (int q = 0; q < T.G; ++q) {
+            if (q == r) continue;
+            NCCLCHK(ncclSend(buf(h) + (size_t)lo[r] * 4, (size_t)(lo[r + 1] - lo[r]) * 4, ncclDouble, q, T.nccl, h->stream));
+            NCCLCHK(ncclRecv(buf(h) + (size_t)lo[q] * 4, (size_t)(lo[q + 1] - lo[q]) * 4, ncclDouble, q, T.nccl, h->stream));
+        }
+        NCCLCHK(ncclGroupEnd());
+        return 0;
+    }
+    for (pse_handle *src : T.m)
+        for (pse_handle *dst : T.m)
+            if (src != dst) {
+                const int r = src->slab_rank;
+                HIPCHK(hipMemcpyAsync(buf(dst) + (size_t)lo[r] * 4, buf(src) + (size_t)lo[r] * 4,
+                                      (size_t)(lo[r + 1] - lo[r]) * 4 * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+            }
     return 0;
 }
 
@@ -538,11 +624,31 @@ static int check_n(pse_handle *h, unsigned N) {
     return 0;
 }
 
-// rows of the particle arrays this rank computes in row-sharded phases (near field, Lanczos mat-vec)
-static void row_range(const pse_handle *h, int N, int &lo, int &hi, size_t &chunk) {
-    chunk = ((size_t)N + h->n_slabs - 1) / h->n_slabs;
-    lo = (int)std::min<size_t>((size_t)N, chunk * h->slab_rank);
-    hi = (int)std::min<size_t>((size_t)N, chunk * (h->slab_rank + 1));
+// rows of the particle arrays this rank owns: the particles of its cell slab (contiguous in the cell-sorted order)
+static void row_range(const pse_handle *h, int N, int &lo, int &hi) {
+    if (h->n_slabs == 1) { lo = 0; hi = N; return; }
+    lo = h->row_lo[h->slab_rank]; hi = h->row_lo[h->slab_rank + 1];
+}
+
+// after the sort: read back where the cell slabs begin in the sorted arrays (3G+1 ints; identical on every rank because
+// the particle arrays are replicated)
+static int slab_bounds(pse_handle *h, int N) {
+    const int G = h->n_slabs;
+    if (G == 1) return 0;
+    const int layer = h->nc.ny * h->nc.nz, per = h->nc.nx / G;
+    std::vector<int> idx(3 * G + 1);
+    for (int r = 0; r <= G; ++r) idx[r] = r * per * layer;
+    for (int r = 0; r < G; ++r) { idx[G + 1 + r] = (r * per + 1) * layer; idx[2 * G + 1 + r] = ((r + 1) * per - 1) * layer; }
+    HIPCHK(hipMemcpyAsync(h->d_bidx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    launch_pick(h->cell_off, h->d_bidx, (int)idx.size(), h->d_bounds, h->stream);
+    std::vector<int> out(idx.size());
+    HIPCHK(hipMemcpyAsync(out.data(), h->d_bounds, out.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->row_lo.assign(out.begin(), out.begin() + G + 1);
+    h->first_end.assign(out.begin() + G + 1, out.begin() + 2 * G + 1);
+    h->last_begin.assign(out.begin() + 2 * G + 1, out.end());
+    if (h->row_lo[0] != 0 || h->row_lo[G] != N) return fail(PSE_ERR_NUMERIC, "inconsistent cell offsets after the sort");
+    return 0;
 }
 
 // bin + sort + gather into cell order (positions change every step, so this runs every call; every rank sorts all
@@ -558,6 +664,7 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
                    h->cell_off, h->stream);
     h->sorted_N = N;
     h->nb_valid = false;
+    TRY(slab_bounds(h, N));
     TRY(te(h, PH_SORT));
     HIPCHK(hipGetLastError());
     return 0;
@@ -577,7 +684,7 @@ static ScaleArgs scale_args(pse_handle *h, bool noise, double kT, double dt, uns
 static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned timestep) {
     for (pse_handle *h : T.m) {
         const DGrid &G = h->G;
-        const size_t nr = (size_t)(G.nxl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
+        const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
         double *gx = h->rgrid, *gy = h->rgrid + nr, *gz = h->rgrid + 2 * nr;
         TRY(tsw(h, PH_SPREAD));
         if (spread_needs_zero(G)) HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->wstream));
@@ -589,7 +696,7 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
             FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
         } else {
             for (int c = 0; c < 3; ++c) {   // 2-D (y,z) transforms of the local planes, one component at a time
-                void *in[1] = {h->rgrid + c * nr}, *out[1] = {h->cgrid + c * ncx};
+                void *in[1] = {h->rgrid + c * nr + (size_t)G.hl * G.Ny * G.Nz}, *out[1] = {h->cgrid + c * ncx};
                 FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
             }
             launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzh, h->nyl, 0, h->wstream);
@@ -630,7 +737,7 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
     }
     for (pse_handle *h : T.m) {
         const DGrid &G = h->G;
-        const size_t nr = (size_t)(G.nxl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
+        const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
         TRY(tsw(h, PH_FFTI));
         if (T.G == 1) {
             void *in[1] = {h->cgrid}, *out[1] = {h->rgrid};
@@ -638,31 +745,29 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
         } else {
             launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzh, h->nyl, 1, h->wstream);
             for (int c = 0; c < 3; ++c) {
-                void *in[1] = {h->cgrid + c * ncx}, *out[1] = {h->rgrid + c * nr};
+                void *in[1] = {h->cgrid + c * ncx}, *out[1] = {h->rgrid + c * nr + (size_t)G.hl * G.Ny * G.Nz};
                 FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv));
             }
         }
         TRY(tew(h, PH_FFTI));
     }
-    TRY(team_halo_shift(T));
+    TRY(team_halo_exchange(T));
     for (pse_handle *h : T.m) {
         const DGrid &G = h->G;
-        const size_t nr = (size_t)(G.nxl + G.nhalo) * G.Ny * G.Nz;
+        const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz;
         TRY(tsw(h, PH_GATHER));
         launch_gather(h->pos_s, h->sup_s, h->sw.wtab, h->cell_off, h->nc, N, h->rgrid, h->rgrid + nr, h->rgrid + 2 * nr, G, h->dbox, h->uw_s, h->wstream);
         TRY(tew(h, PH_GATHER));
         HIPCHK(hipGetLastError());
     }
-    // every particle was gathered by exactly one rank (zeros elsewhere): the sum is the full wave-space velocity
-    TRY(team_all_reduce_sum(T, [](pse_handle *h) { return (double *)h->uw_s; }, (size_t)N * 4));
+    // every particle was gathered by the rank that owns its row (zeros elsewhere)
     return 0;
 }
 
-// near-field mat-vec out = M_real vec (PSEv1/Mobility.cu:594-687), rows sharded over the ranks and all-gathered.
-// build_list: also record the pair list so later mat-vecs of this step can reuse it.
+// near-field mat-vec out = M_real vec (PSEv1/Mobility.cu:594-687) on the rows this rank owns; vec must be valid on those
+// rows and on the neighbouring cell layers.  build_list: also record the pair list for later mat-vecs of this step.
 static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*out, size_t vec_off, size_t out_off, int N,
                 bool build_list) {
-    size_t chunk = 0;
     for (pse_handle *h : T.m) {
         int mode = MREAL_CELLS;
         if (h->nb.cap > 0) {
@@ -670,12 +775,12 @@ static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*ou
             else if (build_list) mode = MREAL_BUILD_LIST;
         }
         int lo, hi;
-        row_range(h, N, lo, hi, chunk);
+        row_range(h, N, lo, hi);
         launch_mreal(h->pos_s, h->*vec + vec_off, h->*out + out_off, lo, hi, h->cell_off, h->dbox, h->nc, h->d.rcut,
                      h->d.self, h->coef, h->nb, mode, h->stream);
         if (mode == MREAL_BUILD_LIST) h->nb_valid = true;
     }
-    return team_all_gather(T, [&](pse_handle *h) { return (double *)(h->*out + out_off); }, chunk * 4);
+    return 0;
 }
 
 // M_real^{1/2} psi by Lanczos (PSEv1/Brownian.cu:357-765): psi_s (sorted order, replicated on every rank) ->
@@ -698,9 +803,27 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io) {
             if (timed) for (pse_handle *h : T.m) TRY(ts(h, PH_MATVEC));
             TRY(real(T, &pse_handle::V, &pse_handle::w_s, (size_t)done * stride, 0, N, true));
             if (timed) for (pse_handle *h : T.m) { TRY(te(h, PH_MATVEC)); h->matvec_timed = true; }
-            for (pse_handle *h : T.m)
-                launch_lz_iter(h->w_s, h->V + (size_t)done * stride, done > 0 ? h->V + (size_t)(done - 1) * stride : nullptr,
-                               h->V + (size_t)(done + 1) * stride, done, h->scal, h->partials, N, h->stream);
+            if (T.G == 1) {
+                launch_lz_iter(h0->w_s, h0->V + (size_t)done * stride, done > 0 ? h0->V + (size_t)(done - 1) * stride : nullptr,
+                               h0->V + (size_t)(done + 1) * stride, done, h0->scal, h0->partials, N, h0->stream);
+            } else {
+                // own rows only: one fused pass for both scalars, one 2-scalar all-reduce, then V[j+1] and its ghost layers
+                for (pse_handle *h : T.m) {
+                    int lo, hi;
+                    row_range(h, N, lo, hi);
+                    launch_lzd_a(h->w_s, h->V + (size_t)done * stride, done > 0 ? h->V + (size_t)(done - 1) * stride : nullptr, done,
+                                 h->scal, h->partials, lo, hi, h->stream);
+                }
+                TRY(team_all_reduce_sum(T, [](pse_handle *h) { return h->scal + LZ_TMP; }, 2));
+                for (pse_handle *h : T.m) {
+                    int lo, hi;
+                    row_range(h, N, lo, hi);
+                    launch_lzd_c(h->w_s, h->V + (size_t)done * stride, h->V + (size_t)(done + 1) * stride, done, h->scal, lo, hi,
+                                 h->stream);
+                }
+                const size_t off = (size_t)(done + 1) * stride;
+                TRY(team_ghost_exchange(T, [&](pse_handle *h) { return (double *)(h->V + off); }));
+            }
         }
         HIPCHK(hipMemcpyAsync(sc.data(), h0->scal, LZ_NSCAL * sizeof(double), hipMemcpyDeviceToHost, h0->stream));
         HIPCHK(hipStreamSynchronize(h0->stream));
@@ -739,7 +862,9 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io) {
     }
     for (pse_handle *h : T.m) {
         HIPCHK(hipMemcpyAsync(h->t_dev, t_cur.data(), m_final * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        launch_basis_combine(h->V, stride, h->t_dev, m_final, h->scal, scale, 1, h->ub_s, N, h->stream);   // Brownian.cu:716,739
+        int lo, hi;
+        row_range(h, N, lo, hi);
+        launch_basis_combine(h->V, stride, h->t_dev, m_final, h->scal, scale, 1, h->ub_s, lo, hi, h->stream);   // Brownian.cu:716,739
         h->info.lanczos_m = m_final; h->info.lanczos_matvecs = done; h->info.lanczos_stepnorm = stepnorm;
     }
     for (pse_handle *h : T.m) HIPCHK(hipStreamSynchronize(h->stream));   // t_cur is host memory that goes out of scope
@@ -784,14 +909,27 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
         *mask |= 1u << PH_LANCZOS;
         if (T.m[0]->matvec_timed) *mask |= 1u << PH_MATVEC;
     }
+    if (T.G > 1) {
+        // every rank has all three contributions for the rows it owns: add them, exchange the row blocks once
+        for (pse_handle *h : T.m) {
+            int lo, hi;
+            row_range(h, N, lo, hi);
+            launch_sum_rows((parts & 2) ? h->uw_s : nullptr, (parts & 1) ? h->ur_s : nullptr, noise ? h->ub_s : nullptr,
+                            h->utot_s, lo, hi, h->stream);
+        }
+        TRY(team_all_gather_rows(T, [](pse_handle *h) { return (double *)h->utot_s; }));
+    }
     for (size_t r = 0; r < T.m.size(); ++r) {
         pse_handle *h = T.m[r];
         if ((parts & 2) && h->side) {   // join
             HIPCHK(hipEventRecord(h->ev_join, h->side));
             HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         }
-        launch_scatter_sum((parts & 2) ? h->uw_s : nullptr, (parts & 1) ? h->ur_s : nullptr, noise ? h->ub_s : nullptr,
-                           h->tag_s, N, a[r].vel, h->stream);
+        if (T.G > 1)
+            launch_scatter_sum(h->utot_s, nullptr, nullptr, h->tag_s, N, a[r].vel, h->stream);
+        else
+            launch_scatter_sum((parts & 2) ? h->uw_s : nullptr, (parts & 1) ? h->ur_s : nullptr, noise ? h->ub_s : nullptr,
+                               h->tag_s, N, a[r].vel, h->stream);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -937,9 +1075,9 @@ extern "C" int pse_debug_copy_grid(pse_handle *h, int stage, double *host_out) {
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->side) HIPCHK(hipStreamSynchronize(h->side));
-    const size_t plane = (size_t)h->G.Ny * h->G.Nz, full = plane * (h->G.nxl + h->G.nhalo);
+    const size_t plane = (size_t)h->G.Ny * h->G.Nz, full = plane * (h->G.nxl + h->G.hl + h->G.nhalo);
     for (int c = 0; c < 3; ++c)   // the slab's own planes of each component (halo planes are not copied)
-        HIPCHK(hipMemcpy(host_out + (size_t)c * plane * h->G.nxl, h->rgrid + c * full, plane * h->G.nxl * sizeof(double),
+        HIPCHK(hipMemcpy(host_out + (size_t)c * plane * h->G.nxl, h->rgrid + c * full + plane * h->G.hl, plane * h->G.nxl * sizeof(double),
                          hipMemcpyDeviceToHost));
     return 0;
 }

@@ -18,7 +18,8 @@ struct DGrid {
     int Nx, Ny, Nz, Nzh;   // Nzh = Nz/2 + 1 (half spectrum)
     int P;
     int x0, nxl;           // this rank's slab of x planes [x0, x0 + nxl)
-    int nhalo;             // planes past the slab (copies of the next slab's first planes) available to the gather
+    int nhalo;             // planes stored past the slab (copies of the next slab's first planes) for the gather
+    int hl;                // planes stored before the slab (copies of the previous slab's last planes); storage starts at x0 - hl
     double hx, hy, hz;
     double prefac, expfac; // (2 xi^2/(pi eta))^{3/2}, 2 xi^2/eta   (PSEv1/Brownian.cu:828-829)
 };

@@ -76,8 +76,16 @@ void launch_lz_start(const double4 *psi_s, double4 *V0, double4 *partial_ws, dou
 void launch_lz_iter(double4 *w, const double4 *Vj, const double4 *Vjm1, double4 *Vjp1, int j, double *scal,
                     double *partials, int N, hipStream_t s);
 // out_s = scale * sum_q t[q] V[q]
+// rows [lo, hi)
 void launch_basis_combine(const double4 *V, size_t stride, const double *t_dev, int m, const double *scal,
-                          double scale, int use_norm, double4 *out_s, int N, hipStream_t s);
+                          double scale, int use_norm, double4 *out_s, int lo, int hi, hipStream_t s);
+// distributed Lanczos iteration on the own rows: (a) w -= beta v_{j-1}, partial v_j.w and w.w -> scal[LZ_TMP..+1];
+// [all-reduce of the two scalars by the caller]; (c) alpha, beta, V[j+1]
+void launch_lzd_a(double4 *w, const double4 *Vj, const double4 *Vjm1, int j, double *scal, double *partials, int lo, int hi,
+                  hipStream_t s);
+void launch_lzd_c(const double4 *w, const double4 *Vj, double4 *Vjp1, int j, double *scal, int lo, int hi, hipStream_t s);
+void launch_sum_rows(const double4 *a, const double4 *b, const double4 *c, double4 *out, int lo, int hi, hipStream_t s);
+void launch_pick(const int *cell_off, const int *idx, int n, int *out, hipStream_t s);
 // vel[tag].xyz = a + b + c (each may be null), keep w
 void launch_scatter_sum(const double4 *a, const double4 *b, const double4 *c, const unsigned *tag_s, int N,
                         double4 *vel, hipStream_t s);

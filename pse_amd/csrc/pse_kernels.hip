@@ -392,7 +392,7 @@ k_spread_atomic(const double4 *__restrict__ pos_s, const double4 *__restrict__ f
         const double ex = G.hx * (d0x + tx) + box.xy * ey;   // sheared lattice (PSEv1/Mobility.cu:230)
         const double ez = G.hz * (d0z + tz);
         const double w = G.prefac * exp_neg(-G.expfac * (ex * ex + ey * ey + ez * ez));
-        const size_t idx = ((size_t)lx * G.Ny + iy) * G.Nz + iz;
+        const size_t idx = ((size_t)(lx + G.hl) * G.Ny + iy) * G.Nz + iz;
         unsafeAtomicAdd(&gx[idx], w * F.x);
         unsafeAtomicAdd(&gy[idx], w * F.y);
         unsafeAtomicAdd(&gz[idx], w * F.z);
@@ -417,7 +417,8 @@ __global__ void k_support(const double4 *__restrict__ pos_s, int N, DGrid G, DBo
     support_start(fx, G.Nx, G.P, o.x, d.x);   // PSEv1/Mobility.cu:212-214
     support_start(fy, G.Ny, G.P, o.y, d.y);
     support_start(fz, G.Nz, G.P, o.z, d.z);
-    o.w = 0; d.w = 0.0;
+    o.w = (int)(fx * G.Nx);   // the node plane the particle sits in: decides which slab owns it
+    d.w = 0.0;
     sup_s[s] = o;
     if (d0_s) d0_s[s] = d;
 }
@@ -430,12 +431,17 @@ struct WeightConsts { double rx[8], rz[8]; };   // rx[t] = exp(-c hx^2 (2t+1)), 
 
 template <int P>
 __global__ void __launch_bounds__(TPB)
-k_weights(const double4 *__restrict__ d0_s, int N, DGrid G, DBox box, WeightConsts wc, double *__restrict__ wtab) {
+k_weights(const double4 *__restrict__ d0_s, const int4 *__restrict__ sup_s, int N, DGrid G, DBox box, WeightConsts wc,
+          double *__restrict__ wtab) {
     constexpr unsigned WT = P * P + P, ROWS = P + 1;
     const unsigned gid = blockIdx.x * TPB + threadIdx.x;   // N * (P + 1) < 2^32
     const unsigned p = gid / ROWS;
     const int row = (int)(gid - p * ROWS);
     if (p >= (unsigned)N) return;
+    if (G.nxl < G.Nx) {   // slab rank: only particles within a support of its planes are ever read
+        int d = sup_s[p].w - (G.x0 - P); d %= G.Nx; if (d < 0) d += G.Nx;
+        if (d >= G.nxl + 2 * P) return;
+    }
     const double4 d0 = d0_s[p];
     double *out = wtab + (size_t)p * WT;
     const double c = G.expfac;
@@ -620,7 +626,7 @@ k_spread_tile(const double4 *__restrict__ f_s, const int4 *__restrict__ sup_s, c
     const int eyz = ext[1] * ext[2], nout = ext[0] * eyz;
     for (int n = tid; n < nout; n += NT) {
         const int qx = n / eyz, r = n - qx * eyz, qy = r / ext[2], qz = r - qy * ext[2];
-        const size_t idx = ((size_t)(t0[0] - G.x0 + qx) * G.Ny + (t0[1] + qy)) * G.Nz + (t0[2] + qz);
+        const size_t idx = ((size_t)(t0[0] - G.x0 + G.hl + qx) * G.Ny + (t0[1] + qy)) * G.Nz + (t0[2] + qz);
         const int o = qx * XS + qy * TZ + qz;
         gx[idx] = acc[o];
         gy[idx] = acc[NODES + o];
@@ -662,7 +668,7 @@ static void launch_spread_p(const double4 *pos_s, const double4 *f_s, int4 *sup_
         wc.rx[t] = std::exp(-G.expfac * G.hx * G.hx * (2 * t + 1));
         wc.rz[t] = std::exp(-G.expfac * G.hz * G.hz * (2 * t + 1));
     }
-    hipLaunchKernelGGL(k_weights<P>, dim3(nblocks((long)N * (P + 1), TPB)), dim3(TPB), 0, s, w.d0_s, N, G, box, wc, w.wtab);
+    hipLaunchKernelGGL(k_weights<P>, dim3(nblocks((long)N * (P + 1), TPB)), dim3(TPB), 0, s, w.d0_s, sup_s, N, G, box, wc, w.wtab);
     int TX, TY, TZ;
     tile_dims(TX, TY, TZ);
     const int ntx = (G.nxl + TX - 1) / TX, nty = (G.Ny + TY - 1) / TY, ntz = (G.Nz + TZ - 1) / TZ;
@@ -713,8 +719,12 @@ k_gather_tile(const int4 *__restrict__ sup_s, const double *__restrict__ wtab, c
     const int tz_ = b % ntz; b /= ntz;
     const int ty_ = b % nty; b /= nty;
     const int tx_ = b;
-    const int t0[3] = {G.x0 + tx_ * GT, ty_ * GT, tz_ * GT};
-    const int ext[3] = {min(GT, G.x0 + G.nxl - t0[0]), min(GT, G.Ny - t0[1]), min(GT, G.Nz - t0[2])};
+    // x: a slab rank stores planes [x0 - hl, x0 + nxl + nhalo) and tiles the window of support origins its particles can
+    // have; a single GPU stores the whole periodic grid
+    const bool windowed = G.nxl < G.Nx;
+    const int xs = G.x0 - G.hl, nwin = windowed ? G.nxl + G.hl + G.nhalo - (P - 1) : G.Nx;
+    const int t0[3] = {xs + tx_ * GT, ty_ * GT, tz_ * GT};
+    const int ext[3] = {min(GT, xs + nwin - t0[0]), min(GT, G.Ny - t0[1]), min(GT, G.Nz - t0[2])};
     const int Nn[3] = {G.Nx, G.Ny, G.Nz};
     // region loads first (into registers): they stay in flight while the particle list is built
     double rv[E];
@@ -727,8 +737,8 @@ k_gather_tile(const int4 *__restrict__ sup_s, const double *__restrict__ wtab, c
         const size_t col = (size_t)iy * G.Nz + iz;
 #pragma unroll
         for (int qx = 0; qx < E; ++qx) {
-            int lx = t0[0] - G.x0 + qx;                   // local plane; planes nxl.. are the halo copies in slab mode
-            if (G.nhalo == 0 && lx >= G.Nx) lx -= G.Nx;
+            int lx = t0[0] - xs + qx;                     // stored plane index
+            if (!windowed && lx >= G.Nx) lx -= G.Nx;
             rv[qx] = (tid < E2 && qx < nplanes) ? g[(size_t)lx * plane + col] : 0.0;
         }
     }
@@ -746,6 +756,10 @@ k_gather_tile(const int4 *__restrict__ sup_s, const double *__restrict__ wtab, c
             if (r < -Nn[a] / 2) r += Nn[a]; else if (r >= Nn[a] - Nn[a] / 2) r -= Nn[a];
             rel[a] = r;
             own = own && r >= 0 && r < ext[a];
+        }
+        if (windowed) {   // the rank whose slab holds the particle itself gathers it
+            int d = sp.w - G.x0; d %= G.Nx; if (d < 0) d += G.Nx;
+            own = own && d < G.nxl;
         }
         return own;
     };
@@ -809,16 +823,18 @@ k_gather(const double4 *__restrict__ pos_s, int N, const double *__restrict__ gx
     support_start(fx, G.Nx, G.P, sx, d0x);
     support_start(fy, G.Ny, G.P, sy, d0y);
     support_start(fz, G.Nz, G.P, sz, d0z);
-    int rel0 = sx - G.x0; rel0 %= G.Nx; if (rel0 < 0) rel0 += G.Nx;
-    if (rel0 >= G.nxl) {
+    // owned by the rank whose slab holds the particle's own plane; its support then lies inside the stored planes
+    int own = (int)(fx * G.Nx) - G.x0; own %= G.Nx; if (own < 0) own += G.Nx;
+    if (own >= G.nxl) {
         if (lane == 0) u_s[p] = make_double4(0.0, 0.0, 0.0, 0.0);
         return;
     }
+    int rel0 = sx - (G.x0 - G.hl); rel0 %= G.Nx; if (rel0 < 0) rel0 += G.Nx;
     const int P = G.P, P2 = P * P, P3 = P2 * P;
     double ux = 0, uy = 0, uz = 0;
     for (int n = lane; n < P3; n += 64) {
         const int tx = n / P2, ty = (n - tx * P2) / P, tz = n - tx * P2 - ty * P;
-        int lx = rel0 + tx; if (G.nhalo == 0 && lx >= G.Nx) lx -= G.Nx;
+        int lx = rel0 + tx; if (G.nxl == G.Nx && lx >= G.Nx) lx -= G.Nx;
         int iy = sy + ty; iy = iy < 0 ? iy + G.Ny : (iy >= G.Ny ? iy - G.Ny : iy);
         int iz = sz + tz; iz = iz < 0 ? iz + G.Nz : (iz >= G.Nz ? iz - G.Nz : iz);
         const double ey = G.hy * (d0y + ty);
@@ -844,7 +860,8 @@ void launch_gather(const double4 *pos_s, const int4 *sup_s, const double *wtab, 
         return;
     }
     (void)hipMemsetAsync(u_s, 0, (size_t)N * sizeof(double4), s);   // .w, and particles of other slabs, stay zero
-    const int ntx = (G.nxl + GT - 1) / GT, nty = (G.Ny + GT - 1) / GT, ntz = (G.Nz + GT - 1) / GT;
+    const int nwin = G.nxl < G.Nx ? G.nxl + G.hl + G.nhalo - (G.P - 1) : G.Nx;   // support origins this rank can own
+    const int ntx = (nwin + GT - 1) / GT, nty = (G.Ny + GT - 1) / GT, ntz = (G.Nz + GT - 1) / GT;
     const dim3 g(ntx * nty * ntz, 3), b(RMAX);   // one workgroup per (tile, velocity component)
     switch (G.P) {
         case 4: hipLaunchKernelGGL(k_gather_tile<4>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz); break;
@@ -1268,12 +1285,92 @@ void launch_lz_iter(double4 *w, const double4 *Vj, const double4 *Vjm1, double4 
     hipLaunchKernelGGL(k_lz_c, dim3(g), dim3(TPB), 0, s, w, Vjp1, j, scal, pb, g, N);
 }
 
+// ---- distributed Lanczos (team mode): each rank owns rows [lo, hi) of every vector ------------------------------------
+// One pass gives both scalars of an iteration: with w' = M v_j - beta_j v_{j-1},  alpha = v_j.w'  and
+// beta_{j+1}^2 = |w' - alpha v_j|^2 = |w'|^2 - alpha^2  (v_j has unit norm), so one 2-scalar all-reduce per iteration.
+__global__ void __launch_bounds__(TPB)
+k_lzd_a(double4 *__restrict__ w, const double4 *__restrict__ Vj, const double4 *__restrict__ Vjm1, int j,
+        const double *__restrict__ scal, double *__restrict__ partials, int lo, int hi) {
+    __shared__ double sh[4];
+    const double beta = j > 0 ? scal[LZ_BETA + j] : 0.0;
+    double a = 0.0, b = 0.0;
+    for (int i = lo + blockIdx.x * TPB + threadIdx.x; i < hi; i += gridDim.x * TPB) {
+        double4 x = w[i];
+        if (j > 0) {
+            const double4 m = Vjm1[i];
+            x.x -= beta * m.x; x.y -= beta * m.y; x.z -= beta * m.z;
+            w[i] = x;
+        }
+        const double4 y = Vj[i];
+        a += x.x * y.x + x.y * y.y + x.z * y.z;
+        b += x.x * x.x + x.y * x.y + x.z * x.z;
+    }
+    a = block_sum(a, sh);
+    __syncthreads();
+    b = block_sum(b, sh);
+    if (threadIdx.x == 0) { partials[blockIdx.x] = a; partials[LZ_NPART + blockIdx.x] = b; }
+}
+// this rank's two partial sums -> scal[LZ_TMP], scal[LZ_TMP + 1] (then all-reduced over the ranks)
+__global__ void __launch_bounds__(TPB)
+k_lzd_reduce(const double *__restrict__ partials, int npart, double *__restrict__ scal) {
+    __shared__ double sh[4];
+    const double a = reduce_partials(partials, npart, sh);
+    __syncthreads();
+    const double b = reduce_partials(partials + LZ_NPART, npart, sh);
+    if (threadIdx.x == 0) { scal[LZ_TMP] = a; scal[LZ_TMP + 1] = b; }
+}
+// alpha_j, beta_{j+1} from the reduced scalars; V[j+1] = (w' - alpha v_j) / beta on the own rows
+__global__ void __launch_bounds__(TPB)
+k_lzd_c(const double4 *__restrict__ w, const double4 *__restrict__ Vj, double4 *__restrict__ Vjp1, int j,
+        double *__restrict__ scal, int lo, int hi) {
+    const double alpha = scal[LZ_TMP];
+    const double b2 = scal[LZ_TMP + 1] - alpha * alpha;
+    const double beta = b2 > 0.0 ? sqrt(b2) : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { scal[LZ_ALPHA + j] = alpha; scal[LZ_BETA + j + 1] = beta; }
+    const double inv = beta > 0.0 ? 1.0 / beta : 0.0;
+    for (int i = lo + blockIdx.x * TPB + threadIdx.x; i < hi; i += gridDim.x * TPB) {
+        const double4 x = w[i], y = Vj[i];
+        Vjp1[i] = make_double4((x.x - alpha * y.x) * inv, (x.y - alpha * y.y) * inv, (x.z - alpha * y.z) * inv, 0.0);
+    }
+}
+void launch_lzd_a(double4 *w, const double4 *Vj, const double4 *Vjm1, int j, double *scal, double *partials, int lo, int hi,
+                  hipStream_t s) {
+    const int g = vec_grid(std::max(1, hi - lo));
+    hipLaunchKernelGGL(k_lzd_a, dim3(g), dim3(TPB), 0, s, w, Vj, Vjm1, j, scal, partials, lo, hi);
+    hipLaunchKernelGGL(k_lzd_reduce, dim3(1), dim3(TPB), 0, s, partials, g, scal);
+}
+void launch_lzd_c(const double4 *w, const double4 *Vj, double4 *Vjp1, int j, double *scal, int lo, int hi, hipStream_t s) {
+    hipLaunchKernelGGL(k_lzd_c, dim3(vec_grid(std::max(1, hi - lo))), dim3(TPB), 0, s, w, Vj, Vjp1, j, scal, lo, hi);
+}
+// out[i] = a[i] + b[i] + c[i] on rows [lo, hi)  (each may be null)
+__global__ void k_sum_rows(const double4 *__restrict__ a, const double4 *__restrict__ b, const double4 *__restrict__ c,
+                           double4 *__restrict__ out, int lo, int hi) {
+    const int i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    double x = 0, y = 0, z = 0;
+    if (a) { const double4 v = a[i]; x += v.x; y += v.y; z += v.z; }
+    if (b) { const double4 v = b[i]; x += v.x; y += v.y; z += v.z; }
+    if (c) { const double4 v = c[i]; x += v.x; y += v.y; z += v.z; }
+    out[i] = make_double4(x, y, z, 0.0);
+}
+void launch_sum_rows(const double4 *a, const double4 *b, const double4 *c, double4 *out, int lo, int hi, hipStream_t s) {
+    if (hi > lo) hipLaunchKernelGGL(k_sum_rows, dim3(nblocks(hi - lo, TPB)), dim3(TPB), 0, s, a, b, c, out, lo, hi);
+}
+// row boundaries of the cell slabs: out[r] = cell_off[r * stride] for r = 0..n-1
+__global__ void k_pick(const int *__restrict__ cell_off, const int *__restrict__ idx, int n, int *__restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) out[r] = cell_off[idx[r]];
+}
+void launch_pick(const int *cell_off, const int *idx, int n, int *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_pick, dim3(nblocks(n, TPB)), dim3(TPB), 0, s, cell_off, idx, n, out);
+}
+
 // K13 gpu_stokes_MatVecMultiply_kernel (PSEv1/Helper.cu:251-279) + the final rescale (PSEv1/Brownian.cu:739)
 __global__ void __launch_bounds__(TPB)
 k_basis_combine(const double4 *__restrict__ V, size_t stride, const double *__restrict__ t, int m,
-                const double *__restrict__ scal, double scale, int use_norm, double4 *__restrict__ out, int N) {
+                const double *__restrict__ scal, double scale, int use_norm, double4 *__restrict__ out, int lo, int N) {
     const double sc = use_norm ? scale * scal[LZ_NORM] : scale;
-    for (int i = blockIdx.x * TPB + threadIdx.x; i < N; i += gridDim.x * TPB) {
+    for (int i = lo + blockIdx.x * TPB + threadIdx.x; i < N; i += gridDim.x * TPB) {
         double x = 0, y = 0, z = 0;
         for (int q = 0; q < m; ++q) {
             const double4 v = V[(size_t)q * stride + i];
@@ -1284,9 +1381,9 @@ k_basis_combine(const double4 *__restrict__ V, size_t stride, const double *__re
     }
 }
 void launch_basis_combine(const double4 *V, size_t stride, const double *t_dev, int m, const double *scal,
-                          double scale, int use_norm, double4 *out_s, int N, hipStream_t s) {
-    hipLaunchKernelGGL(k_basis_combine, dim3(std::min(2048, std::max(1, nblocks(N, TPB)))), dim3(TPB), 0, s, V, stride,
-                       t_dev, m, scal, scale, use_norm, out_s, N);
+                          double scale, int use_norm, double4 *out_s, int lo, int hi, hipStream_t s) {
+    hipLaunchKernelGGL(k_basis_combine, dim3(std::min(2048, std::max(1, nblocks(hi - lo, TPB)))), dim3(TPB), 0, s, V, stride,
+                       t_dev, m, scal, scale, use_norm, out_s, lo, hi);
 }
 
 // K10 gpu_stokes_LinearCombination_kernel (PSEv1/Helper.cu:113-133) as the final un-sort: vel.xyz = a + b + c, keep w

@@ -20,10 +20,21 @@ def slab_plan(grid, world):
     return [{"rank": r, "x0": r * nxl, "nxl": nxl, "y0": r * nyl, "nyl": nyl} for r in range(world)]
 
 
-def row_chunks(n, world):
-    """Rows of the particle arrays each rank computes in the near-field phases (row_range in csrc/pse_capi.hip)."""
-    chunk = (n + world - 1) // world
-    return [(min(n, chunk * r), min(n, chunk * (r + 1))) for r in range(world)]
+def halo_planes(P):
+    """(below, above): planes a rank stores beside its own x slab so that every particle whose own plane lies in the slab
+    has its whole support available for the gather (create_impl in csrc/pse_capi.hip)."""
+    return (P - 1) // 2, (P + 1) // 2
+
+
+def cell_slabs(ncx, world):
+    """Cell layers along x owned by each rank: the near field is sharded by whole cell layers, so the rows of a rank are
+    one contiguous block of the cell-sorted particle arrays (set_cells in csrc/pse_capi.hip rounds ncx down to a
+    multiple of the number of ranks)."""
+    ncx = ncx // world * world
+    if ncx < max(3, world):
+        raise ValueError("box too small to split the near field over this many ranks")
+    per = ncx // world
+    return [(r * per, (r + 1) * per) for r in range(world)]
 
 
 def exchange_unique_id(rank, make_id, dist):
@@ -52,8 +63,10 @@ class ShardedSimulation:
         self.team = Team([self.engine], unique_id=uid)
 
     def describe(self):
-        return (f"{self.world} GPUs: far-field grid in {self.world} x-slabs (RCCL all-to-all transpose, P-1 plane gather halo), "
-                f"near-field and Lanczos mat-vec rows split {self.world} ways (RCCL all-gather); particles replicated")
+        return (f"{self.world} GPUs: far-field grid in {self.world} x-slabs (RCCL all-to-all transpose, two-sided plane halo for "
+                f"the gather), near field / Lanczos vectors / gather owned by the rank whose cell slab holds the particle "
+                f"(neighbour ghost-layer exchange + 2-scalar all-reduce per iteration), one velocity all-gather per step; "
+                f"particle arrays replicated")
 
     def load(self, pos, force, mass=1.0):
         self.s = _State(self.n, pos, force, mass)

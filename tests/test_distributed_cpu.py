@@ -23,7 +23,7 @@ def _worker(rank, world, port, out):
     import torch.distributed as dist
     from conftest import make_suspension
     from oracle import pse_port as pp
-    from pse_amd.sharded import exchange_unique_id, row_chunks, slab_plan
+    from pse_amd.sharded import cell_slabs, exchange_unique_id, halo_planes, slab_plan
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         uid = exchange_unique_id(rank, lambda: bytes(range(128)), dist)
@@ -67,15 +67,20 @@ def _worker(rank, world, port, out):
         err = np.abs(ug - full[:, x0:x0 + nxl]).max() / np.abs(full).max()
         assert err < 1e-12, err
 
-        # gather ownership: every particle belongs to exactly one slab (the one holding its support origin)
-        idx, dlt = pp._support(pos, box, p)
-        start = (idx[0][:, 0] - 0) % Nx
-        owned = ((start - x0) % Nx) < nxl
+        # gather ownership: the rank whose slab holds the particle's own node plane; its support then lies inside the
+        # rank's stored planes [x0 - below, x0 + nxl + above)
+        below, above = halo_planes(p["P"])
+        f = pp.fractional(pos, box)
+        plane = np.floor(f[:, 0] * Nx).astype(int)
+        owned = ((plane - x0) % Nx) < nxl
         cnt = torch.tensor([int(owned.sum())]); dist.all_reduce(cnt)
         assert int(cnt) == n
-        # row chunks tile [0, n)
-        ch = row_chunks(n, world)
-        assert ch[0][0] == 0 and ch[-1][1] == n and all(ch[i][1] == ch[i + 1][0] for i in range(world - 1))
+        idx, dlt = pp._support(pos, box, p)
+        first = (idx[0][owned, 0] - (x0 - below)) % Nx
+        assert np.all(first + p["P"] <= nxl + below + above)
+        # cell slabs tile the cell layers
+        cs = cell_slabs(9, world)
+        assert cs[0][0] == 0 and cs[-1][1] == 8 and all(cs[i][1] == cs[i + 1][0] for i in range(world - 1))
         out.put((rank, "ok"))
     except Exception as e:   # noqa: BLE001
         out.put((rank, repr(e)))
@@ -97,11 +102,13 @@ def test_slab_transpose_pipeline_world2():
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
 
 
-def test_slab_plan_and_row_chunks():
-    from pse_amd.sharded import row_chunks, slab_plan
+def test_slab_plan_and_cell_slabs():
+    from pse_amd.sharded import cell_slabs, halo_planes, slab_plan
     pl = slab_plan((256, 256, 256), 8)
     assert [p["x0"] for p in pl] == list(range(0, 256, 32)) and all(p["nxl"] == 32 and p["nyl"] == 32 for p in pl)
     with pytest.raises(ValueError):
         slab_plan((250, 256, 256), 8)
-    assert row_chunks(10, 4) == [(0, 3), (3, 6), (6, 9), (9, 10)]
-    assert row_chunks(1_000_000, 8)[-1] == (875_000, 1_000_000)
+    assert halo_planes(6) == (2, 3) and halo_planes(5) == (2, 3) and halo_planes(4) == (1, 2) and halo_planes(8) == (3, 4)
+    assert cell_slabs(58, 8) == [(7 * r, 7 * r + 7) for r in range(8)]
+    with pytest.raises(ValueError):
+        cell_slabs(5, 8)

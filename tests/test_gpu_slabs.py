@@ -71,3 +71,28 @@ def test_rccl_team_of_one_rank():
     vel = [to4(np.zeros((n, 3)))]
     team.mobility([to4(pos)], [to4(force)], vel)
     assert rel(vel[0].cpu().numpy()[:, :3], ref.mobility(to4(pos), to4(force)).cpu().numpy()[:, :3]) < 1e-13
+
+
+@pytest.mark.parametrize("world,P", [(2, 5), (4, 4), (4, 7)])
+def test_loopback_team_clustered_particles_and_odd_support(world, P):
+    """Non-uniform suspension: most particles in a quarter of the box, so some cell slabs own almost nothing (zero-size
+    ghost layers, unequal row blocks); odd and even support sizes change the two-sided gather halo."""
+    import pse_amd
+    from pse_amd.sharded import LoopbackSimulation
+    n = 2500
+    pos, force, box = make_suspension(n, L=48.0, xy=0.15)
+    rng = np.random.default_rng(8)
+    pos[: n * 4 // 5, 0] = rng.uniform(-24.0, -10.0, n * 4 // 5) + box[3] * pos[: n * 4 // 5, 1]   # crowd the low-x slab
+    pos[-3:, 0] = 23.9                                                                            # and a few at the far face
+    kw = dict(xi=0.5, error=1e-3, seed=3, grid=(64, 48, 40), P=P)
+    ref = pse_amd.Engine(n, box, **kw)
+    sim = LoopbackSimulation(n, box, world, **kw)
+    sim.load(pos, force)
+    u_ref = ref.mobility(to4(pos), to4(force)).cpu().numpy()[:, :3]
+    for r, v in enumerate(sim.mobility()):
+        assert rel(v.cpu().numpy()[:, :3], u_ref) < 1e-12, r
+    v_ref, m_ref = ref.brownian_velocity(to4(pos), to4(force), 1.0, 1e-3, 9)
+    vels, m = sim.brownian_velocity(1.0, 1e-3, 9)
+    assert m == m_ref
+    for r in range(world):
+        assert rel(vels[r].cpu().numpy()[:, :3], v_ref.cpu().numpy()[:, :3]) < 1e-11, r

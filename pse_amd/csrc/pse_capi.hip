@@ -99,6 +99,7 @@ struct pse_handle {
     // Lanczos
     double4 *V = nullptr;        // [M_MAX + 1][n_max]
     double *scal = nullptr, *partials = nullptr, *t_dev = nullptr;
+    int npart_cap = 0;
     // bookkeeping
     pse_info info;
     bool timing = false;
@@ -209,7 +210,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->plan_x_inv) rocfft_plan_destroy(h->plan_x_inv);
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
-    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->sup_s, h->sw.wtab, h->sw.d0_s, h->nb.j, h->nb.f, h->nb.dx, h->nb.dy, h->nb.dz, h->nb.cnt, h->pos_s,
+    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->sup_s, h->sw.wtab, h->sw.d0_s, h->nb.data, h->nb.cnt, h->nb.ovf_rows, h->nb.ovf_n, h->nb.ovf_out, h->pos_s,
                     h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->twiddle, h->fft_work, h->V,
                     h->scal, h->partials, h->t_dev};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -348,13 +349,13 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         const double nbar = (double)n / vol * 4.18879020478639 * d.rcut * d.rcut * d.rcut;
         int cap = (int)std::ceil(1.5 * nbar + 16.0);
         cap = std::max(16, std::min(cap, 256));
-        const double bytes = (double)cap * (double)n * 36.0;
+        const double bytes = (double)cap * (double)n * 20.0;
         if (bytes > 32e9 || n >= ((size_t)1 << 27)) cap = 0;   // too large: mat-vecs always walk the cells
-        h->nb.cap = cap; h->nb.stride = n;   // n is the padded capacity
+        h->nb.cap = cap;
         if (cap > 0) {
-            TRY(dmalloc(h, &h->nb.j, (size_t)cap * n)); TRY(dmalloc(h, &h->nb.f, (size_t)cap * n));
-            TRY(dmalloc(h, &h->nb.dx, (size_t)cap * n)); TRY(dmalloc(h, &h->nb.dy, (size_t)cap * n));
-            TRY(dmalloc(h, &h->nb.dz, (size_t)cap * n));
+            TRY(dmalloc(h, &h->nb.data, nb_list_bytes(n + 64, cap)));   // + one wave: rows are blocked from the rank's first row
+            TRY(dmalloc(h, &h->nb.ovf_rows, n)); TRY(dmalloc(h, &h->nb.ovf_n, 1)); TRY(dmalloc(h, &h->nb.ovf_out, n));
+            HIPCHK(hipMemset(h->nb.ovf_n, 0, sizeof(int)));
         }
         TRY(dmalloc(h, &h->nb.cnt, n));
     }
@@ -389,7 +390,8 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     TRY(make_plans(h));
 
     TRY(dmalloc(h, &h->V, (size_t)(M_MAX + 1) * n));
-    TRY(dmalloc(h, &h->scal, (size_t)LZ_NSCAL)); TRY(dmalloc(h, &h->partials, (size_t)2 * LZ_NPART));
+    TRY(dmalloc(h, &h->scal, (size_t)LZ_NSCAL)); h->npart_cap = std::max(LZ_NPART, mreal_partials_needed((int)n));
+    TRY(dmalloc(h, &h->partials, (size_t)3 * h->npart_cap));
     TRY(dmalloc(h, &h->t_dev, (size_t)M_MAX + 1));
     for (auto &ph : h->ph) { HIPCHK(hipEventCreate(&ph.a)); HIPCHK(hipEventCreate(&ph.b)); }
     h->info.device_bytes = h->bytes;
@@ -784,14 +786,14 @@ static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*ou
 }
 
 // M_real^{1/2} psi by Lanczos (PSEv1/Brownian.cu:357-765): psi_s (sorted order, replicated on every rank) ->
-// ub_s = scale |psi| V t.  The basis and all scalars are replicated; only the mat-vec rows are sharded.
+// ub_s = scale |psi| V t on the rows this rank owns.  Scalars are replicated; vectors are valid on the own rows (+ the
+// neighbouring cell layers for the vector the next mat-vec reads).
 static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io) {
     pse_handle *h0 = T.m[0];
     const size_t stride = h0->n_pad;
     int m_in = m_io ? *m_io : 2;
     if (m_in < 1) m_in = 1;
     if (m_in > M_MAX) m_in = M_MAX;
-    for (pse_handle *h : T.m) launch_lz_start(h->psi_s, h->V, nullptr, h->scal, h->partials, N, h->stream);
     std::vector<double> sc(LZ_NSCAL), t_prev, t_cur;
     int done = 0;                         // iterations launched so far
     int target = std::max(m_in, 2);       // first convergence check is at m = max(m_in, 2)   (Brownian.cu:465-466,606)
@@ -799,34 +801,46 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io) {
     double stepnorm = 1.0;
     while (true) {
         for (; done < target; ++done) {
-            const bool timed = done == 1 && h0->nb_valid;   // one pair-list mat-vec per call is timed on its own
-            if (timed) for (pse_handle *h : T.m) TRY(ts(h, PH_MATVEC));
-            TRY(real(T, &pse_handle::V, &pse_handle::w_s, (size_t)done * stride, 0, N, true));
-            if (timed) for (pse_handle *h : T.m) { TRY(te(h, PH_MATVEC)); h->matvec_timed = true; }
-            if (T.G == 1) {
-                launch_lz_iter(h0->w_s, h0->V + (size_t)done * stride, done > 0 ? h0->V + (size_t)(done - 1) * stride : nullptr,
-                               h0->V + (size_t)(done + 1) * stride, done, h0->scal, h0->partials, N, h0->stream);
-            } else {
-                // own rows only: one fused pass for both scalars, one 2-scalar all-reduce, then V[j+1] and its ghost layers
-                for (pse_handle *h : T.m) {
-                    int lo, hi;
-                    row_range(h, N, lo, hi);
-                    launch_lzd_a(h->w_s, h->V + (size_t)done * stride, done > 0 ? h->V + (size_t)(done - 1) * stride : nullptr, done,
-                                 h->scal, h->partials, lo, hi, h->stream);
+            // iteration j = done on the unnormalised x_j (psi for j = 0, else parked in V[j]); see k_lz_update
+            const bool fused = h0->nb.cap > 0 && h0->nb_valid;   // sums fused into the pair-list mat-vec
+            const bool timed = done == 1 && fused;               // one pair-list mat-vec kernel per call is timed on its own
+            if (!fused) TRY(real(T, done == 0 ? &pse_handle::psi_s : &pse_handle::V, &pse_handle::w_s, (size_t)done * stride, 0, N, true));
+            for (pse_handle *h : T.m) {
+                int lo, hi;
+                row_range(h, N, lo, hi);
+                const double4 *xj = done == 0 ? h->psi_s : h->V + (size_t)done * stride;
+                const double4 *vjm1 = done > 0 ? h->V + (size_t)(done - 1) * stride : nullptr;
+                if (fused) {
+                    const bool ev = timed && h->timing;
+                    launch_mreal_lanczos(h->pos_s, xj, h->w_s, lo, hi, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef,
+                                         h->nb, LzFuse{vjm1, h->partials, h->npart_cap}, h->scal,
+                                         ev ? h->ph[PH_MATVEC].a : nullptr, ev ? h->ph[PH_MATVEC].b : nullptr, h->stream);
+                    if (timed) h->matvec_timed = true;
+                } else {
+                    launch_lz_dots(xj, h->w_s, vjm1, lo, hi, h->partials, h->npart_cap, h->scal, h->stream);
                 }
-                TRY(team_all_reduce_sum(T, [](pse_handle *h) { return h->scal + LZ_TMP; }, 2));
-                for (pse_handle *h : T.m) {
-                    int lo, hi;
-                    row_range(h, N, lo, hi);
-                    launch_lzd_c(h->w_s, h->V + (size_t)done * stride, h->V + (size_t)(done + 1) * stride, done, h->scal, lo, hi,
-                                 h->stream);
-                }
-                const size_t off = (size_t)(done + 1) * stride;
-                TRY(team_ghost_exchange(T, [&](pse_handle *h) { return (double *)(h->V + off); }));
             }
+            TRY(team_all_reduce_sum(T, [](pse_handle *h) { return h->scal + LZ_TMP; }, 3));
+            for (pse_handle *h : T.m) {
+                int lo, hi;
+                row_range(h, N, lo, hi);
+                const double4 *xj = done == 0 ? h->psi_s : h->V + (size_t)done * stride;
+                launch_lz_update(xj, h->w_s, done > 0 ? h->V + (size_t)(done - 1) * stride : nullptr, h->V + (size_t)done * stride,
+                                 h->V + (size_t)(done + 1) * stride, done, h->scal, lo, hi, h->stream);
+            }
+            const size_t off = (size_t)(done + 1) * stride;   // the next mat-vec reads x_{j+1} on the neighbouring cell layers too
+            TRY(team_ghost_exchange(T, [&](pse_handle *h) { return (double *)(h->V + off); }));
         }
+        // beta_done = |x_done| is not known yet (the next mat-vec would deliver it): one extra reduction per check
+        for (pse_handle *h : T.m) {
+            int lo, hi;
+            row_range(h, N, lo, hi);
+            launch_lz_dots(h->V + (size_t)done * stride, nullptr, nullptr, lo, hi, h->partials, h->npart_cap, h->scal, h->stream);
+        }
+        TRY(team_all_reduce_sum(T, [](pse_handle *h) { return h->scal + LZ_TMP; }, 1));
         HIPCHK(hipMemcpyAsync(sc.data(), h0->scal, LZ_NSCAL * sizeof(double), hipMemcpyDeviceToHost, h0->stream));
         HIPCHK(hipStreamSynchronize(h0->stream));
+        sc[LZ_BETA + done] = sc[LZ_TMP] > 0.0 ? std::sqrt(sc[LZ_TMP]) : 0.0;
         const double *alpha = &sc[LZ_ALPHA], *beta = &sc[LZ_BETA];
         if (!(sc[LZ_NORM] > 0.0) || !std::isfinite(sc[LZ_NORM])) {   // psi == 0 -> result 0
             for (pse_handle *h : T.m) {

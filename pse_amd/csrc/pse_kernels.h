@@ -20,20 +20,36 @@ void launch_permute(const double4 *pos, const double4 *vec, const unsigned *grou
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s);
 
 // ---- near field (K9) -------------------------------------------------------------------------------------
-// per-step pair list in ELL layout (slot-major): entry (slot, i) at slot*stride + i
+// Per-step pair list, 20 B per pair, in wave-blocked ELL layout: the 64 rows a wavefront owns keep their slot-s entries
+// in one contiguous 1280-byte record [64 x u32 (neighbour slot | image code << 27)][64 x f64 f][64 x f64 h], records of
+// one wave back to back -- a wave streams one contiguous region instead of 3*cnt regions megabytes apart.
+// Row r = i - lo (lo: first row of the rank, fixed within a step); record (r / 64) * cap + slot.
 struct NbList {
-    unsigned *j;
-    double *f;            // transverse coefficient f(r)
-    double *dx, *dy, *dz; // sqrt(|h|) (r_i - r_j), h = (g - f)/r^2; sign(h) is bit 31 of j
-    int *cnt;             // true neighbour count per particle (may exceed cap: that particle falls back to the cells)
+    char *data;
+    int *cnt;             // neighbour count per particle; -(k+1) if it exceeded cap: overflow row k (recomputed from the cells)
+    int *ovf_rows, *ovf_n;   // overflow rows of this step and their number
+    double4 *ovf_out;     // their mat-vec results
     int cap;
-    size_t stride;
 };
+constexpr size_t NB_REC = 64 * 20;
+__host__ __device__ inline size_t nb_list_bytes(size_t rows, int cap) { return ((rows + 63) / 64) * (size_t)cap * NB_REC; }
 enum { MREAL_CELLS = 0, MREAL_BUILD_LIST = 1, MREAL_USE_LIST = 2 };
+// Lanczos sums fused into the pair-list mat-vec (see k_lz_update): with x = vec and y = M x the kernel also leaves the
+// per-block partial sums of x.x, x.y and x.v_{j-1}
+struct LzFuse {
+    const double4 *vprev;   // v_{j-1} (null for j = 0)
+    double *partials;       // [3][npart_cap]
+    int npart_cap;
+};
 // out = M_real . vec (+ self). mode: cells only / cells + write the pair list / use the pair list
 // rows [lo, hi) of the mat-vec (the whole vector is read; multi-GPU ranks each take a row range)
 void launch_mreal(const double4 *pos_s, const double4 *vec_s, double4 *out_s, int lo, int hi, const int *cell_off,
                   DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, int mode, hipStream_t s);
+// pair-list mat-vec + Lanczos sums; leaves the three reduced sums in scal[LZ_TMP .. LZ_TMP + 2]
+void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, int lo, int hi, const int *cell_off,
+                          DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,
+                          double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s);   // events (nullable) bracket the mat-vec kernel
+int mreal_partials_needed(int rows);
 
 // ---- far field (K2-K8) -----------------------------------------------------------------------------------
 // scratch of the fast far-field path (rebuilt every call): support offsets and the per-particle separable weights
@@ -68,22 +84,19 @@ void launch_add_inplace(double *a, const double *b, size_t n, hipStream_t s);
 // ---- vector kernels (K10-K14) ----------------------------------------------------------------------------
 void launch_psi(double4 *psi_s, const unsigned *tag_s, int N, uint32_t seed, uint32_t timestep, hipStream_t s);
 // scal layout (device doubles): [0..127] alpha, [128..255] beta, [256] psi norm, [257] scratch
-constexpr int LZ_ALPHA = 0, LZ_BETA = 128, LZ_NORM = 256, LZ_TMP = 257, LZ_NSCAL = 264;
+constexpr int LZ_ALPHA = 0, LZ_BETA = 128, LZ_NORM = 256, LZ_TMP = 257, LZ_NSCAL = 264;   // TMP: 3 sums
 constexpr int LZ_NPART = 1024;  // partial-sum slots
-void launch_lz_start(const double4 *psi_s, double4 *V0, double4 *partial_ws, double *scal, double *partials, int N,
-                     hipStream_t s);
-// one Lanczos iteration j given w = M.V[j] in `w`: fills alpha[j], beta[j+1], V[j+1]
-void launch_lz_iter(double4 *w, const double4 *Vj, const double4 *Vjm1, double4 *Vjp1, int j, double *scal,
-                    double *partials, int N, hipStream_t s);
 // out_s = scale * sum_q t[q] V[q]
 // rows [lo, hi)
 void launch_basis_combine(const double4 *V, size_t stride, const double *t_dev, int m, const double *scal,
                           double scale, int use_norm, double4 *out_s, int lo, int hi, hipStream_t s);
-// distributed Lanczos iteration on the own rows: (a) w -= beta v_{j-1}, partial v_j.w and w.w -> scal[LZ_TMP..+1];
-// [all-reduce of the two scalars by the caller]; (c) alpha, beta, V[j+1]
-void launch_lzd_a(double4 *w, const double4 *Vj, const double4 *Vjm1, int j, double *scal, double *partials, int lo, int hi,
-                  hipStream_t s);
-void launch_lzd_c(const double4 *w, const double4 *Vj, double4 *Vjp1, int j, double *scal, int lo, int hi, hipStream_t s);
+// Lanczos iteration on the own rows [lo, hi) (see k_lz_update in pse_kernels.hip).  dots: sums of x.x, x.y, x.vprev ->
+// scal[LZ_TMP..+2] (y = null: x.x only), for mat-vecs that did not fuse them; [all-reduce by the caller when sharded];
+// update: alpha_j, beta_j, v_j = x_j / beta_j -> vout, x_{j+1} -> xnext
+void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, int lo, int hi, double *partials, int cap,
+                    double *scal, hipStream_t s);
+void launch_lz_update(const double4 *xin, const double4 *y, const double4 *vprev, double4 *vout, double4 *xnext, int j,
+                      double *scal, int lo, int hi, hipStream_t s);
 void launch_sum_rows(const double4 *a, const double4 *b, const double4 *c, double4 *out, int lo, int hi, hipStream_t s);
 void launch_pick(const int *cell_off, const int *idx, int n, int *out, hipStream_t s);
 // vel[tag].xyz = a + b + c (each may be null), keep w

@@ -9,6 +9,11 @@ namespace pse {
 constexpr int TPB = 256;
 constexpr double TWO_PI = 6.283185307179586476925286766559;
 
+static int dbg_mode() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PSE_DBG"); v = e ? atoi(e) : 0; }
+    return v;
+}
 static inline int nblocks(long n, int tpb) { return (int)((n + tpb - 1) / tpb); }
 
 // ------------------------------------------------------------------------------------------------ reductions
@@ -133,6 +138,7 @@ void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double
 // drained pairs (j, f, (g-f)/r^2, r) are also written to a per-step ELL pair list that the Lanczos mat-vecs reuse
 // (positions do not change inside a step, PSEv1/Brownian.cu:473-521 recomputes them every iteration).
 constexpr int QCAP = 48;
+constexpr int OVF_BLOCKS = 32;
 constexpr unsigned JMASK = (1u << 27) - 1;
 
 // Workgroups b and b + 8 share an XCD (round-robin dispatch, /opt/skills/guides/MI355X_MICROARCH.md): hand each XCD a
@@ -181,6 +187,13 @@ __device__ __forceinline__ void for_each_run(const DCells &nc, const int *__rest
     }
 }
 
+__device__ __forceinline__ void nb_store(char *rec, int slot, int lane, unsigned e, double f, double h) {
+    char *r = rec + (size_t)slot * NB_REC;
+    ((unsigned *)r)[lane] = e;
+    ((double *)(r + 256))[lane] = f;
+    ((double *)(r + 768))[lane] = h;
+}
+
 template <bool LIST>
 __global__ void __launch_bounds__(TPB)
 k_mreal_cells(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int lo,
@@ -198,6 +211,8 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec
     const int cx = cell_coord(fx, nc.nx), cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz);
     const bool shift_only = nc.nx > 1 && nc.ny > 1 && nc.nz > 1;   // otherwise finish with the rint minimum image
     int qn = 0, total = 0;
+    const int lane = (i - lo) & 63;
+    char *rec = LIST ? nb.data + (size_t)((i - lo) >> 6) * nb.cap * NB_REC : nullptr;
 
     // two queue entries per iteration: their load -> distance -> table -> force chains are independent, which doubles the
     // memory requests in flight of this latency-bound phase (57 % of its wave-cycles were s_waitcnt)
@@ -225,23 +240,11 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec
             uy += f0 * F0.y + rd0 * d0y + f1 * F1.y + rd1 * d1y;
             uz += f0 * F0.z + rd0 * d0z + f1 * F1.z + rd1 * d1z;
             if (LIST) {
-                // 36 B per pair: h = (g-f)/r^2 is folded into the separation, its sign rides on bit 31 of j
-                if (total < nb.cap) {
-                    const size_t o = (size_t)total * nb.stride + i;
-                    const double qq = sqrt(fabs(h0));
-                    nb.j[o] = (unsigned)j0 | (h0 < 0.0 ? 0x80000000u : 0u);
-                    nb.f[o] = f0;
-                    nb.dx[o] = qq * d0x; nb.dy[o] = qq * d0y; nb.dz[o] = qq * d0z;
-                }
+                // 20 B per pair: (slot | image code), f, h; the mat-vecs redo the subtraction from the positions
+                if (total < nb.cap) nb_store(rec, total, lane, e0, f0, h0);
                 ++total;
                 if (two) {
-                    if (total < nb.cap) {
-                        const size_t o = (size_t)total * nb.stride + i;
-                        const double qq = sqrt(fabs(h1));
-                        nb.j[o] = (unsigned)j1 | (h1 < 0.0 ? 0x80000000u : 0u);
-                        nb.f[o] = f1;
-                        nb.dx[o] = qq * d1x; nb.dy[o] = qq * d1y; nb.dz[o] = qq * d1z;
-                    }
+                    if (total < nb.cap) nb_store(rec, total, lane, e1, f1, h1);
                     ++total;
                 }
             }
@@ -274,36 +277,26 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec
     });
     drain();
     out_s[i] = make_double4(ux, uy, uz, 0.0);
-    if (LIST) nb.cnt[i] = total;
+    if (LIST) {
+        if (total > nb.cap) {   // the row did not fit: later mat-vecs of this step recompute it from the cells
+            const int k = atomicAdd(nb.ovf_n, 1);
+            nb.ovf_rows[k] = i;
+            total = -(k + 1);
+        }
+        nb.cnt[i] = total;
+    }
 }
 
-// mat-vec from the pair list (one thread per particle, ELL layout: slot-major so a wave reads contiguous rows).
-// A particle whose neighbour count overflowed the list capacity recomputes from the cells.
+// Rows whose neighbour count exceeded the list capacity: full cell walk, one thread per row, results parked in ovf_out
+// for k_mreal_list to pick up.  A fixed small grid; exits at once in the usual case of no overflow.
 __global__ void __launch_bounds__(TPB)
-k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int lo,
-             int hi, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2, double self,
-             const double *__restrict__ coef, NbList nb) {
-    const int i = lo + xcd_block(blockIdx.x, gridDim.x) * TPB + threadIdx.x;
-    if (i >= hi) return;
-    const double4 vi = vec_s[i];
-    double ux = self * vi.x, uy = self * vi.y, uz = self * vi.z;
-    const int cnt = nb.cnt[i];
-    if (cnt <= nb.cap) {
-#pragma unroll 4
-        for (int s = 0; s < cnt; ++s) {
-            const size_t o = (size_t)s * nb.stride + i;
-            const unsigned je = nb.j[o];
-            const double f = nb.f[o];
-            const double dx = nb.dx[o], dy = nb.dy[o], dz = nb.dz[o];   // sqrt(|h|) r
-            const double4 Fj = vec_s[je & 0x7FFFFFFFu];
-            double rdF = dx * Fj.x + dy * Fj.y + dz * Fj.z;
-            rdF = (je & 0x80000000u) ? -rdF : rdF;
-            ux += f * Fj.x + rdF * dx;
-            uy += f * Fj.y + rdF * dy;
-            uz += f * Fj.z + rdF * dz;
-        }
-    } else {
-        const double4 pi = pos_s[i];
+k_mreal_overflow(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, const int *__restrict__ cell_off,
+                 DBox box, DCells nc, double rcut2, double self, const double *__restrict__ coef, NbList nb) {
+    const int n = *nb.ovf_n;
+    for (int k = blockIdx.x * TPB + threadIdx.x; k < n; k += gridDim.x * TPB) {
+        const int i = nb.ovf_rows[k];
+        const double4 pi = pos_s[i], vi = vec_s[i];
+        double ux = self * vi.x, uy = self * vi.y, uz = self * vi.z;
         double fx, fy, fz;
         frac_coords(box, pi.x, pi.y, pi.z, fx, fy, fz);
         const int cx = cell_coord(fx, nc.nx), cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz);
@@ -324,20 +317,132 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
                 }
             }
         });
+        nb.ovf_out[k] = make_double4(ux, uy, uz, 0.0);
     }
-    out_s[i] = make_double4(ux, uy, uz, 0.0);
+}
+
+// mat-vec from the pair list (one thread per particle, ELL layout: slot-major so a wave reads contiguous rows).
+// Per pair 20 B of list from HBM plus the neighbour's position and vector entry gathered through L2.  FUSE adds the
+// Lanczos epilogue (see LzFuse).
+template <bool FUSE, int UNROLL>
+__global__ void __launch_bounds__(TPB)
+k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int lo,
+             int hi, DBox box, int shift_only, double self, NbList nb, LzFuse lz, int dbg) {
+    __shared__ double shift[27 * 3];
+    __shared__ double sh[4];
+    if (threadIdx.x < 27) {
+        double sx, sy, sz;
+        image_shift(threadIdx.x, box, sx, sy, sz);
+        shift[threadIdx.x * 3] = sx; shift[threadIdx.x * 3 + 1] = sy; shift[threadIdx.x * 3 + 2] = sz;
+    }
+    __syncthreads();
+    const int i = lo + xcd_block(blockIdx.x, gridDim.x) * TPB + threadIdx.x;
+    const bool active = i < hi;
+    double ux = 0.0, uy = 0.0, uz = 0.0;
+    double4 vi = make_double4(0.0, 0.0, 0.0, 0.0);
+    if (active) {
+        vi = vec_s[i];
+        const int cnt = nb.cnt[i];
+        if (cnt >= 0) {
+            const double4 pi = pos_s[i];
+            ux = self * vi.x; uy = self * vi.y; uz = self * vi.z;
+            const int lane = (i - lo) & 63;
+            const char *rec = nb.data + (size_t)((i - lo) >> 6) * nb.cap * NB_REC;
+            // software-pipelined by hand: the list entries of UNROLL slots, then their 2 UNROLL gathers, then the arithmetic --
+            // left to the compiler every slot waited for its own load -> gather chain (the kernel was latency-bound at
+            // 1.9 TB/s).  Branch-free: slots past cnt re-read the last valid one with f = h = 0; image code 13 is a zero shift.
+            for (int s0 = 0; s0 < cnt; s0 += UNROLL) {
+                unsigned e[UNROLL];
+                double f[UNROLL], h[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const char *r = rec + (size_t)min(s0 + u, cnt - 1) * NB_REC;
+                    e[u] = ((const unsigned *)r)[lane];
+                    f[u] = ((const double *)(r + 256))[lane];
+                    h[u] = ((const double *)(r + 768))[lane];
+                }
+                double4 pj[UNROLL], Fj[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const unsigned j = (dbg & 16) ? (unsigned)i : (e[u] & JMASK);
+                    pj[u] = pos_s[j];
+                    Fj[u] = vec_s[j];
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const unsigned code = e[u] >> 27;
+                    const bool ok = s0 + u < cnt;
+                    double dx = pi.x - pj[u].x - shift[code * 3], dy = pi.y - pj[u].y - shift[code * 3 + 1],
+                           dz = pi.z - pj[u].z - shift[code * 3 + 2];
+                    if (!shift_only) min_image(box, dx, dy, dz);
+                    const double fu = ok ? f[u] : 0.0, hu = ok ? h[u] : 0.0;
+                    const double rdF = (dx * Fj[u].x + dy * Fj[u].y + dz * Fj[u].z) * hu;
+                    ux += fu * Fj[u].x + rdF * dx;
+                    uy += fu * Fj[u].y + rdF * dy;
+                    uz += fu * Fj[u].z + rdF * dz;
+                }
+            }
+        } else {
+            const double4 u = nb.ovf_out[-cnt - 1];
+            ux = u.x; uy = u.y; uz = u.z;
+        }
+    }
+    if (FUSE) {   // x = vec (unnormalised Lanczos vector), y = M x: partial sums of x.x, x.y, x.v_{j-1}
+        double a = 0.0, b = 0.0, c = 0.0;
+        if (active) {
+            a = vi.x * vi.x + vi.y * vi.y + vi.z * vi.z;
+            b = vi.x * ux + vi.y * uy + vi.z * uz;
+            if (lz.vprev) {
+                const double4 m = lz.vprev[i];
+                c = vi.x * m.x + vi.y * m.y + vi.z * m.z;
+            }
+        }
+        a = block_sum(a, sh);
+        __syncthreads();
+        b = block_sum(b, sh);
+        __syncthreads();
+        c = block_sum(c, sh);
+        if (threadIdx.x == 0) {
+            lz.partials[blockIdx.x] = a; lz.partials[lz.npart_cap + blockIdx.x] = b; lz.partials[2 * lz.npart_cap + blockIdx.x] = c;
+        }
+    }
+    if (active) out_s[i] = make_double4(ux, uy, uz, 0.0);
 }
 
 void launch_mreal(const double4 *pos_s, const double4 *vec_s, double4 *out_s, int lo, int hi, const int *cell_off,
                   DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, int mode, hipStream_t s) {
     if (hi <= lo) return;
     const dim3 g(nblocks(hi - lo, TPB)), b(TPB);
-    if (mode == MREAL_BUILD_LIST)
+    if (mode == MREAL_BUILD_LIST) {
+        (void)hipMemsetAsync(nb.ovf_n, 0, sizeof(int), s);
         hipLaunchKernelGGL(k_mreal_cells<true>, g, b, 0, s, pos_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, self, coef, nb);
-    else if (mode == MREAL_USE_LIST)
-        hipLaunchKernelGGL(k_mreal_list, g, b, 0, s, pos_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, self, coef, nb);
-    else
+    } else if (mode == MREAL_USE_LIST) {
+        hipLaunchKernelGGL(k_mreal_overflow, dim3(OVF_BLOCKS), b, 0, s, pos_s, vec_s, cell_off, box, nc, rcut * rcut, self, coef, nb);
+        hipLaunchKernelGGL((k_mreal_list<false, 4>), g, b, 0, s, pos_s, vec_s, out_s, lo, hi, box,
+                           (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1), self, nb, LzFuse{}, 0);
+    } else
         hipLaunchKernelGGL(k_mreal_cells<false>, g, b, 0, s, pos_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, self, coef, nb);
+}
+
+__global__ void __launch_bounds__(TPB) k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, double *__restrict__ scal);
+int mreal_partials_needed(int rows) { return nblocks(std::max(rows, 1), TPB); }
+void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, int lo, int hi, const int *cell_off,
+                          DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,
+                          double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s) {
+    const int nbk = nblocks(std::max(hi - lo, 1), TPB);
+    hipLaunchKernelGGL(k_mreal_overflow, dim3(OVF_BLOCKS), dim3(TPB), 0, s, pos_s, vec_s, cell_off, box, nc, rcut * rcut, self, coef, nb);
+    if (ev_begin) (void)hipEventRecord(ev_begin, s);
+    const int so = (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1);
+    switch (dbg_mode() & 15) {
+        case 6: hipLaunchKernelGGL((k_mreal_list<true, 6>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, dbg_mode()); break;
+        case 3: hipLaunchKernelGGL((k_mreal_list<true, 3>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, dbg_mode()); break;
+        case 2: hipLaunchKernelGGL((k_mreal_list<true, 2>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, dbg_mode()); break;
+        case 8: hipLaunchKernelGGL((k_mreal_list<true, 8>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, dbg_mode()); break;
+        case 1: hipLaunchKernelGGL((k_mreal_list<true, 1>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, dbg_mode()); break;
+        default: hipLaunchKernelGGL((k_mreal_list<true, 4>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, dbg_mode()); break;
+    }
+    if (ev_end) (void)hipEventRecord(ev_end, s);
+    hipLaunchKernelGGL(k_lz_reduce, dim3(1), dim3(TPB), 0, s, lz.partials, nbk, lz.npart_cap, 3, scal);
 }
 
 __global__ void k_eval_fg(const double *__restrict__ r, int n, const double *__restrict__ coef, double *f, double *g) {
@@ -550,7 +655,7 @@ template <int P, int TX, int TY, int TZ>
 __global__ void __launch_bounds__(RMAX)
 k_spread_tile(const double4 *__restrict__ f_s, const int4 *__restrict__ sup_s, const double *__restrict__ wtab,
               const int *__restrict__ cell_off, DCells nc, double *__restrict__ gx, double *__restrict__ gy,
-              double *__restrict__ gz, DGrid G, int ntx, int nty, int ntz) {
+              double *__restrict__ gz, DGrid G, int ntx, int nty, int ntz, int dbg) {
     constexpr int NT = RMAX, XS = TY * TZ + 2, NODES = TX * XS, WT = P * P + P;
     __shared__ double acc[3 * NODES];
     __shared__ TileList tl;
@@ -588,7 +693,7 @@ k_spread_tile(const double4 *__restrict__ f_s, const int4 *__restrict__ sup_s, c
     for_tile_particles(tl, cell_off, nc, clo, ccnt,
         [&](int p) { int a0[3]; return clip(sup_s[p], a0); },
         [&]() {
-            const int n = tl.n;
+            const int n = (dbg & 1) ? 0 : tl.n;
             for (int h = grp; h < n; h += NT / 8) {
                 const int p = tl.list[h];
                 // the 8 lanes of a group read the same addresses (a few L1 accesses per instruction); all loads are
@@ -613,6 +718,7 @@ k_spread_tile(const double4 *__restrict__ f_s, const int4 *__restrict__ sup_s, c
                         for (int ty = 0; ty < P; ++ty) {
                             if (okx && (unsigned)(a0[1] + ty) < (unsigned)ext[1]) {
                                 double *o = cell + tx * XS + ty * TZ;
+                                if (dbg & 2) { if (a[tx * P + ty] * bx == 1.2345e-300) o[0] = 1.0; continue; }
                                 atomicAdd(o, a[tx * P + ty] * bx);
                                 atomicAdd(o + NODES, a[tx * P + ty] * by);
                                 atomicAdd(o + 2 * NODES, a[tx * P + ty] * bz);
@@ -674,11 +780,11 @@ static void launch_spread_p(const double4 *pos_s, const double4 *f_s, int4 *sup_
     const int ntx = (G.nxl + TX - 1) / TX, nty = (G.Ny + TY - 1) / TY, ntz = (G.Nz + TZ - 1) / TZ;
     const dim3 g(ntx * nty * ntz), b(RMAX);
     if (TX == 8)
-        hipLaunchKernelGGL((k_spread_tile<P, 8, 8, 8>), g, b, 0, s, f_s, sup_s, w.wtab, cell_off, nc, gx, gy, gz, G, ntx, nty, ntz);
+        hipLaunchKernelGGL((k_spread_tile<P, 8, 8, 8>), g, b, 0, s, f_s, sup_s, w.wtab, cell_off, nc, gx, gy, gz, G, ntx, nty, ntz, dbg_mode());
     else if (TY == 8)
-        hipLaunchKernelGGL((k_spread_tile<P, 16, 8, 8>), g, b, 0, s, f_s, sup_s, w.wtab, cell_off, nc, gx, gy, gz, G, ntx, nty, ntz);
+        hipLaunchKernelGGL((k_spread_tile<P, 16, 8, 8>), g, b, 0, s, f_s, sup_s, w.wtab, cell_off, nc, gx, gy, gz, G, ntx, nty, ntz, dbg_mode());
     else
-        hipLaunchKernelGGL((k_spread_tile<P, 16, 16, 8>), g, b, 0, s, f_s, sup_s, w.wtab, cell_off, nc, gx, gy, gz, G, ntx, nty, ntz);
+        hipLaunchKernelGGL((k_spread_tile<P, 16, 16, 8>), g, b, 0, s, f_s, sup_s, w.wtab, cell_off, nc, gx, gy, gz, G, ntx, nty, ntz, dbg_mode());
 }
 
 void launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, const int *cell_off, DCells nc,
@@ -709,7 +815,7 @@ template <int P>
 __global__ void __launch_bounds__(RMAX)
 k_gather_tile(const int4 *__restrict__ sup_s, const double *__restrict__ wtab, const int *__restrict__ cell_off, DCells nc,
               const double *__restrict__ gx, const double *__restrict__ gy, const double *__restrict__ gz, DGrid G,
-              double4 *__restrict__ u_s, int ntx, int nty, int ntz) {
+              double4 *__restrict__ u_s, int ntx, int nty, int ntz, int dbg) {
     constexpr int NT = RMAX, E = GT + P - 1, E2 = E * E, E3 = E2 * E, WT = P * P + P;
     __shared__ double reg[E3];          // one velocity component of the tile + halo: 17.6 KB at P = 6
     __shared__ TileList tl;
@@ -777,7 +883,7 @@ k_gather_tile(const int4 *__restrict__ sup_s, const double *__restrict__ wtab, c
                 stored = true;
                 __syncthreads();
             }
-            const int n = tl.n;
+            const int n = (dbg & 1) ? 0 : tl.n;
             for (int h0 = 0; h0 < n; h0 += NT / 8) {      // uniform trip count: the reduction uses every lane
                 const int h = h0 + grp;
                 double u = 0;
@@ -797,7 +903,7 @@ k_gather_tile(const int4 *__restrict__ sup_s, const double *__restrict__ wtab, c
 #pragma unroll
                         for (int tx = 0; tx < P; ++tx)
 #pragma unroll
-                            for (int ty = 0; ty < P; ++ty) u += a[tx * P + ty] * r0[tx * E2 + ty * E];
+                            for (int ty = 0; ty < P; ++ty) u += a[tx * P + ty] * ((dbg & 2) ? 1.5 : r0[tx * E2 + ty * E]);
                         u *= bw;
                     }
                 }
@@ -864,11 +970,11 @@ void launch_gather(const double4 *pos_s, const int4 *sup_s, const double *wtab, 
     const int ntx = (nwin + GT - 1) / GT, nty = (G.Ny + GT - 1) / GT, ntz = (G.Nz + GT - 1) / GT;
     const dim3 g(ntx * nty * ntz, 3), b(RMAX);   // one workgroup per (tile, velocity component)
     switch (G.P) {
-        case 4: hipLaunchKernelGGL(k_gather_tile<4>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz); break;
-        case 5: hipLaunchKernelGGL(k_gather_tile<5>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz); break;
-        case 6: hipLaunchKernelGGL(k_gather_tile<6>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz); break;
-        case 7: hipLaunchKernelGGL(k_gather_tile<7>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz); break;
-        default: hipLaunchKernelGGL(k_gather_tile<8>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz); break;
+        case 4: hipLaunchKernelGGL(k_gather_tile<4>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz, dbg_mode()); break;
+        case 5: hipLaunchKernelGGL(k_gather_tile<5>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz, dbg_mode()); break;
+        case 6: hipLaunchKernelGGL(k_gather_tile<6>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz, dbg_mode()); break;
+        case 7: hipLaunchKernelGGL(k_gather_tile<7>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz, dbg_mode()); break;
+        default: hipLaunchKernelGGL(k_gather_tile<8>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz, dbg_mode()); break;
     }
 }
 
@@ -1191,156 +1297,73 @@ void launch_psi(double4 *psi_s, const unsigned *tag_s, int N, uint32_t seed, uin
 
 static inline int vec_grid(int N) { return std::min(LZ_NPART, std::max(1, nblocks(N, TPB))); }
 
-// Lanczos (PSEv1/Brownian.cu:440-521) with device-resident scalars: K10-K12 fused into three streaming kernels per
-// iteration; every block re-reduces the previous kernel's per-block partials, so there is no host round trip.
+// Lanczos (PSEv1/Brownian.cu:440-521) with device-resident scalars: no host round trip inside an iteration.
+// ---- Lanczos iteration (PSEv1/Brownian.cu:440-521) with deferred normalisation --------------------------------------
+// Each rank owns rows [lo, hi) of every vector (a single GPU owns them all).  The mat-vec runs on the UNNORMALISED vector
+// x_j (v_j = x_j / beta_j, beta_j = |x_j|): with y = M x_j the three sums  s1 = x_j.x_j, s2 = x_j.y, s3 = x_j.v_{j-1}
+// give  beta_j = sqrt(s1)  and  alpha_j = v_j.(M v_j - beta_j v_{j-1}) = s2/s1 - s3  -- the reference's K10-K12
+// sequence (w = M v - beta v_prev; alpha = v.w; w -= alpha v; beta' = |w|) with ONE reduction per iteration (one 3-scalar
+// all-reduce when sharded) and one vector pass: v_j = x_j/beta_j, x_{j+1} = y/beta_j - beta_j v_{j-1} - alpha_j v_j.
+// beta_0 = |psi| is the norm the result is rescaled with (Brownian.cu:440-452,739).
 __global__ void __launch_bounds__(TPB)
-k_dot_partial(const double4 *__restrict__ a, const double4 *__restrict__ b, int N, double *__restrict__ partials) {
+k_lz_dots(const double4 *__restrict__ x, const double4 *__restrict__ y, const double4 *__restrict__ vprev, int lo, int hi,
+          double *__restrict__ partials, int cap) {
     __shared__ double sh[4];
-    double v = 0.0;
-    for (int i = blockIdx.x * TPB + threadIdx.x; i < N; i += gridDim.x * TPB) {
-        const double4 x = a[i], y = b[i];
-        v += x.x * y.x + x.y * y.y + x.z * y.z;
-    }
-    v = block_sum(v, sh);
-    if (threadIdx.x == 0) partials[blockIdx.x] = v;
-}
-// V0 = psi / |psi|; scal[NORM] = |psi|
-__global__ void __launch_bounds__(TPB)
-k_lz_start(const double4 *__restrict__ psi, double4 *__restrict__ V0, double *__restrict__ scal,
-           const double *__restrict__ partials, int npart, int N) {
-    __shared__ double sh[4];
-    const double nrm = sqrt(reduce_partials(partials, npart, sh));
-    if (blockIdx.x == 0 && threadIdx.x == 0) { scal[LZ_NORM] = nrm; scal[LZ_BETA] = 0.0; }
-    const double inv = 1.0 / nrm;
-    for (int i = blockIdx.x * TPB + threadIdx.x; i < N; i += gridDim.x * TPB) {
-        const double4 p = psi[i];
-        V0[i] = make_double4(p.x * inv, p.y * inv, p.z * inv, 0.0);
-    }
-}
-// w -= beta_j V[j-1]; partialsA = V[j].w
-__global__ void __launch_bounds__(TPB)
-k_lz_a(double4 *__restrict__ w, const double4 *__restrict__ Vj, const double4 *__restrict__ Vjm1, int j,
-       const double *__restrict__ scal, double *__restrict__ partialsA, int N) {
-    __shared__ double sh[4];
-    const double beta = j > 0 ? scal[LZ_BETA + j] : 0.0;
-    double v = 0.0;
-    for (int i = blockIdx.x * TPB + threadIdx.x; i < N; i += gridDim.x * TPB) {
-        double4 x = w[i];
-        if (j > 0) {
-            const double4 m = Vjm1[i];
-            x.x -= beta * m.x; x.y -= beta * m.y; x.z -= beta * m.z;
-            w[i] = x;
-        }
-        const double4 y = Vj[i];
-        v += x.x * y.x + x.y * y.y + x.z * y.z;
-    }
-    v = block_sum(v, sh);
-    if (threadIdx.x == 0) partialsA[blockIdx.x] = v;
-}
-// alpha_j = sum partialsA; w -= alpha_j V[j]; partialsB = w.w
-__global__ void __launch_bounds__(TPB)
-k_lz_b(double4 *__restrict__ w, const double4 *__restrict__ Vj, int j, double *__restrict__ scal,
-       const double *__restrict__ partialsA, double *__restrict__ partialsB, int npart, int N) {
-    __shared__ double sh[4];
-    const double alpha = reduce_partials(partialsA, npart, sh);
-    if (blockIdx.x == 0 && threadIdx.x == 0) scal[LZ_ALPHA + j] = alpha;
-    double v = 0.0;
-    for (int i = blockIdx.x * TPB + threadIdx.x; i < N; i += gridDim.x * TPB) {
-        double4 x = w[i];
-        const double4 y = Vj[i];
-        x.x -= alpha * y.x; x.y -= alpha * y.y; x.z -= alpha * y.z;
-        w[i] = x;
-        v += x.x * x.x + x.y * x.y + x.z * x.z;
-    }
-    __syncthreads();
-    v = block_sum(v, sh);
-    if (threadIdx.x == 0) partialsB[blockIdx.x] = v;
-}
-// beta_{j+1} = sqrt(sum partialsB); V[j+1] = w / beta_{j+1}
-__global__ void __launch_bounds__(TPB)
-k_lz_c(const double4 *__restrict__ w, double4 *__restrict__ Vjp1, int j, double *__restrict__ scal,
-       const double *__restrict__ partialsB, int npart, int N) {
-    __shared__ double sh[4];
-    const double beta = sqrt(reduce_partials(partialsB, npart, sh));
-    if (blockIdx.x == 0 && threadIdx.x == 0) scal[LZ_BETA + j + 1] = beta;
-    const double inv = beta > 0.0 ? 1.0 / beta : 0.0;
-    for (int i = blockIdx.x * TPB + threadIdx.x; i < N; i += gridDim.x * TPB) {
-        const double4 x = w[i];
-        Vjp1[i] = make_double4(x.x * inv, x.y * inv, x.z * inv, 0.0);
-    }
-}
-
-void launch_lz_start(const double4 *psi_s, double4 *V0, double4 *, double *scal, double *partials, int N,
-                     hipStream_t s) {
-    const int g = vec_grid(N);
-    hipLaunchKernelGGL(k_dot_partial, dim3(g), dim3(TPB), 0, s, psi_s, psi_s, N, partials);
-    hipLaunchKernelGGL(k_lz_start, dim3(g), dim3(TPB), 0, s, psi_s, V0, scal, partials, g, N);
-}
-void launch_lz_iter(double4 *w, const double4 *Vj, const double4 *Vjm1, double4 *Vjp1, int j, double *scal,
-                    double *partials, int N, hipStream_t s) {
-    const int g = vec_grid(N);
-    double *pa = partials, *pb = partials + LZ_NPART;
-    hipLaunchKernelGGL(k_lz_a, dim3(g), dim3(TPB), 0, s, w, Vj, Vjm1, j, scal, pa, N);
-    hipLaunchKernelGGL(k_lz_b, dim3(g), dim3(TPB), 0, s, w, Vj, j, scal, pa, pb, g, N);
-    hipLaunchKernelGGL(k_lz_c, dim3(g), dim3(TPB), 0, s, w, Vjp1, j, scal, pb, g, N);
-}
-
-// ---- distributed Lanczos (team mode): each rank owns rows [lo, hi) of every vector ------------------------------------
-// One pass gives both scalars of an iteration: with w' = M v_j - beta_j v_{j-1},  alpha = v_j.w'  and
-// beta_{j+1}^2 = |w' - alpha v_j|^2 = |w'|^2 - alpha^2  (v_j has unit norm), so one 2-scalar all-reduce per iteration.
-__global__ void __launch_bounds__(TPB)
-k_lzd_a(double4 *__restrict__ w, const double4 *__restrict__ Vj, const double4 *__restrict__ Vjm1, int j,
-        const double *__restrict__ scal, double *__restrict__ partials, int lo, int hi) {
-    __shared__ double sh[4];
-    const double beta = j > 0 ? scal[LZ_BETA + j] : 0.0;
-    double a = 0.0, b = 0.0;
+    double a = 0.0, b = 0.0, c = 0.0;
     for (int i = lo + blockIdx.x * TPB + threadIdx.x; i < hi; i += gridDim.x * TPB) {
-        double4 x = w[i];
-        if (j > 0) {
-            const double4 m = Vjm1[i];
-            x.x -= beta * m.x; x.y -= beta * m.y; x.z -= beta * m.z;
-            w[i] = x;
-        }
-        const double4 y = Vj[i];
-        a += x.x * y.x + x.y * y.y + x.z * y.z;
-        b += x.x * x.x + x.y * x.y + x.z * x.z;
+        const double4 p = x[i];
+        a += p.x * p.x + p.y * p.y + p.z * p.z;
+        if (y) { const double4 q = y[i]; b += p.x * q.x + p.y * q.y + p.z * q.z; }
+        if (vprev) { const double4 m = vprev[i]; c += p.x * m.x + p.y * m.y + p.z * m.z; }
     }
     a = block_sum(a, sh);
     __syncthreads();
     b = block_sum(b, sh);
-    if (threadIdx.x == 0) { partials[blockIdx.x] = a; partials[LZ_NPART + blockIdx.x] = b; }
-}
-// this rank's two partial sums -> scal[LZ_TMP], scal[LZ_TMP + 1] (then all-reduced over the ranks)
-__global__ void __launch_bounds__(TPB)
-k_lzd_reduce(const double *__restrict__ partials, int npart, double *__restrict__ scal) {
-    __shared__ double sh[4];
-    const double a = reduce_partials(partials, npart, sh);
     __syncthreads();
-    const double b = reduce_partials(partials + LZ_NPART, npart, sh);
-    if (threadIdx.x == 0) { scal[LZ_TMP] = a; scal[LZ_TMP + 1] = b; }
+    c = block_sum(c, sh);
+    if (threadIdx.x == 0) { partials[blockIdx.x] = a; partials[cap + blockIdx.x] = b; partials[2 * cap + blockIdx.x] = c; }
 }
-// alpha_j, beta_{j+1} from the reduced scalars; V[j+1] = (w' - alpha v_j) / beta on the own rows
+// this rank's partial sums -> scal[LZ_TMP .. LZ_TMP + nsum) (then all-reduced over the ranks)
 __global__ void __launch_bounds__(TPB)
-k_lzd_c(const double4 *__restrict__ w, const double4 *__restrict__ Vj, double4 *__restrict__ Vjp1, int j,
-        double *__restrict__ scal, int lo, int hi) {
-    const double alpha = scal[LZ_TMP];
-    const double b2 = scal[LZ_TMP + 1] - alpha * alpha;
-    const double beta = b2 > 0.0 ? sqrt(b2) : 0.0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { scal[LZ_ALPHA + j] = alpha; scal[LZ_BETA + j + 1] = beta; }
-    const double inv = beta > 0.0 ? 1.0 / beta : 0.0;
-    for (int i = lo + blockIdx.x * TPB + threadIdx.x; i < hi; i += gridDim.x * TPB) {
-        const double4 x = w[i], y = Vj[i];
-        Vjp1[i] = make_double4((x.x - alpha * y.x) * inv, (x.y - alpha * y.y) * inv, (x.z - alpha * y.z) * inv, 0.0);
+k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, double *__restrict__ scal) {
+    __shared__ double sh[4];
+    for (int q = 0; q < nsum; ++q) {
+        const double v = reduce_partials(partials + (size_t)q * cap, npart, sh);
+        if (threadIdx.x == 0) scal[LZ_TMP + q] = v;
+        __syncthreads();
     }
 }
-void launch_lzd_a(double4 *w, const double4 *Vj, const double4 *Vjm1, int j, double *scal, double *partials, int lo, int hi,
-                  hipStream_t s) {
-    const int g = vec_grid(std::max(1, hi - lo));
-    hipLaunchKernelGGL(k_lzd_a, dim3(g), dim3(TPB), 0, s, w, Vj, Vjm1, j, scal, partials, lo, hi);
-    hipLaunchKernelGGL(k_lzd_reduce, dim3(1), dim3(TPB), 0, s, partials, g, scal);
+// alpha_j, beta_j from the reduced sums; v_j = x_j / beta_j (in place or from psi); x_{j+1} on the own rows
+__global__ void __launch_bounds__(TPB)
+k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, const double4 *__restrict__ vprev,
+            double4 *__restrict__ vout, double4 *__restrict__ xnext, int j, double *__restrict__ scal, int lo, int hi) {
+    const double s1 = scal[LZ_TMP], s2 = scal[LZ_TMP + 1], s3 = scal[LZ_TMP + 2];
+    const double beta = s1 > 0.0 ? sqrt(s1) : 0.0;
+    const double inv = beta > 0.0 ? 1.0 / beta : 0.0;
+    const double alpha = s1 > 0.0 ? s2 / s1 - s3 : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scal[LZ_ALPHA + j] = alpha;
+        if (j == 0) { scal[LZ_NORM] = beta; scal[LZ_BETA] = 0.0; } else scal[LZ_BETA + j] = beta;
+    }
+    for (int i = lo + blockIdx.x * TPB + threadIdx.x; i < hi; i += gridDim.x * TPB) {
+        const double4 p = xin[i], q = y[i];
+        const double vx = p.x * inv, vy = p.y * inv, vz = p.z * inv;
+        double nx = q.x * inv - alpha * vx, ny = q.y * inv - alpha * vy, nz = q.z * inv - alpha * vz;
+        if (vprev) { const double4 m = vprev[i]; nx -= beta * m.x; ny -= beta * m.y; nz -= beta * m.z; }
+        vout[i] = make_double4(vx, vy, vz, 0.0);
+        xnext[i] = make_double4(nx, ny, nz, 0.0);
+    }
 }
-void launch_lzd_c(const double4 *w, const double4 *Vj, double4 *Vjp1, int j, double *scal, int lo, int hi, hipStream_t s) {
-    hipLaunchKernelGGL(k_lzd_c, dim3(vec_grid(std::max(1, hi - lo))), dim3(TPB), 0, s, w, Vj, Vjp1, j, scal, lo, hi);
+void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, int lo, int hi, double *partials, int cap,
+                    double *scal, hipStream_t s) {
+    const int g = vec_grid(std::max(1, hi - lo));
+    hipLaunchKernelGGL(k_lz_dots, dim3(g), dim3(TPB), 0, s, x, y, vprev, lo, hi, partials, cap);
+    hipLaunchKernelGGL(k_lz_reduce, dim3(1), dim3(TPB), 0, s, partials, g, cap, y ? 3 : 1, scal);
+}
+void launch_lz_update(const double4 *xin, const double4 *y, const double4 *vprev, double4 *vout, double4 *xnext, int j,
+                      double *scal, int lo, int hi, hipStream_t s) {
+    hipLaunchKernelGGL(k_lz_update, dim3(vec_grid(std::max(1, hi - lo))), dim3(TPB), 0, s, xin, y, vprev, vout, xnext, j, scal,
+                       lo, hi);
 }
 // out[i] = a[i] + b[i] + c[i] on rows [lo, hi)  (each may be null)
 __global__ void k_sum_rows(const double4 *__restrict__ a, const double4 *__restrict__ b, const double4 *__restrict__ c,

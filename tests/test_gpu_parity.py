@@ -145,6 +145,33 @@ def test_lanczos_sqrt_matches_dense(torch_cuda, oracle):
         assert rel(out.cpu().numpy()[:, :3], up) < 1e-9
 
 
+def test_pair_list_overflow_rows(torch_cuda, oracle):
+    """A dense cluster: its rows do not fit the per-step pair list (capacity follows the mean density) and are recomputed
+    from the cells inside every Lanczos mat-vec; the result must not change."""
+    import pse_amd
+    rng = np.random.default_rng(17)
+    n, L = 400, 30.0
+    box = (L, L, L, 0.0)
+    ball = rng.normal(size=(300, 3)); ball *= (4.0 * rng.uniform(size=(300, 1)) ** (1 / 3)) / np.linalg.norm(ball, axis=1, keepdims=True)
+    pos = np.concatenate([ball + np.array([L / 2 - 1.0, 0.0, -L / 2 + 0.5]), rng.uniform(-L / 2, L / 2, size=(100, 3))])
+    pos = oracle.wrap(pos, np.zeros((n, 3), dtype=np.int64), box)[0]
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3)
+    rcut = eng.info()["rcut"]
+    psi = rng.normal(size=(n, 3))
+    matvec = lambda v: oracle.mobility_real(pos, np.ascontiguousarray(v), box, 0.5, rcut)
+    counts = (np.linalg.norm(pos[:, None] - pos[None], axis=2) < rcut).sum(1) - 1
+    assert counts.max() > 100        # far beyond the list capacity of ~30 slots
+    out, m = eng.sqrt_mreal(to4(pos), to4(psi), tol=1e-3)
+    up, mp = oracle.lanczos_sqrt(matvec, psi, 2, 1e-3)
+    assert m == mp, (m, mp)
+    assert rel(out.cpu().numpy()[:, :3], up) < 1e-9
+    # a long run (m ~ 60: past the point where Lanczos vectors stay orthogonal, so m itself is rounding-dependent)
+    out, m = eng.sqrt_mreal(to4(pos), to4(psi), tol=1e-7)
+    up, mp = oracle.lanczos_sqrt(matvec, psi, 2, 1e-7)
+    assert abs(m - mp) <= 10, (m, mp)
+    assert rel(out.cpu().numpy()[:, :3], up) < 1e-5
+
+
 @pytest.mark.parametrize("xy", [0.0, 0.3])
 def test_brownian_velocity_matches_port(torch_cuda, oracle, xy):
     import pse_amd

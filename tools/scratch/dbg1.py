@@ -1,5 +1,5 @@
 import numpy as np, math, sys
-sys.path.insert(0,'tests')
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
 from conftest import make_suspension, to4
 from oracle import pse_port as pp
 import pse_amd, torch

@@ -1,5 +1,5 @@
-import numpy as np, math, sys, time
-sys.path.insert(0,'tests')
+import numpy as np, math, sys, time, os
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
 from conftest import make_suspension, to4
 import pse_amd, torch
 def run(n, phi, grid, err=1e-3, kT=1.0, steps=5):

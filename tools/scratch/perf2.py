@@ -1,5 +1,5 @@
 import numpy as np, math, sys, time, os
-sys.path.insert(0,'tests')
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
 from conftest import make_suspension, to4
 import pse_amd, torch
 n, phi, grid, err = 1000000, 0.1, 256, 1e-3

@@ -210,7 +210,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->plan_x_inv) rocfft_plan_destroy(h->plan_x_inv);
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
-    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->sup_s, h->sw.wtab, h->sw.d0_s, h->nb.data, h->nb.cnt, h->nb.ovf_rows, h->nb.ovf_n, h->nb.ovf_out, h->pos_s,
+    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->sup_s, h->sw.wtab_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->sw.sup_t, h->sw.f_t, h->nb.data, h->nb.cnt, h->nb.ovf_rows, h->nb.ovf_n, h->nb.ovf_out, h->pos_s,
                     h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->twiddle, h->fft_work, h->V,
                     h->scal, h->partials, h->t_dev};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -342,7 +342,12 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     TRY(dmalloc(h, &h->sup_s, n));
     if (d.P >= 4 && d.P <= 8) {   // fast far-field path: support offsets + separable weights (padded: idle lanes read past the end)
         TRY(dmalloc(h, &h->sw.d0_s, n));
-        TRY(dmalloc(h, &h->sw.wtab, n * (size_t)(d.P * d.P + d.P) + 128));
+        TRY(dmalloc(h, &h->sw.wtab_t, n * (size_t)(d.P * d.P + d.P) + 128));
+        TRY(dmalloc(h, &h->sw.sup_t, n)); TRY(dmalloc(h, &h->sw.f_t, n)); TRY(dmalloc(h, &h->sw.fb.rank_s, n));
+        const size_t nbins = (size_t)((d.Nx + 7) / 8) * ((d.Ny + 7) / 8) * ((d.Nz + 7) / 8);
+        TRY(dmalloc(h, &h->sw.fb.cnt, nbins + 1)); TRY(dmalloc(h, &h->sw.fb.off, nbins + 1));
+        h->sw.fb.tmp_bytes = bin_scan_temp_bytes(nbins);
+        TRY(dmalloc(h, (char **)&h->sw.fb.tmp, h->sw.fb.tmp_bytes));
     }
     {   // per-step pair list for the Lanczos mat-vecs: capacity from the mean neighbour count at full occupancy
         const double vol = h->box.Lx * h->box.Ly * h->box.Lz;
@@ -690,7 +695,7 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
         double *gx = h->rgrid, *gy = h->rgrid + nr, *gz = h->rgrid + 2 * nr;
         TRY(tsw(h, PH_SPREAD));
         if (spread_needs_zero(G)) HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->wstream));
-        launch_spread(h->pos_s, h->f_s, h->sup_s, N, h->cell_off, h->nc, gx, gy, gz, G, h->dbox, h->sw, h->wstream);
+        launch_spread(h->pos_s, h->f_s, h->sup_s, N, gx, gy, gz, G, h->dbox, h->sw, h->wstream);
         TRY(tew(h, PH_SPREAD));
         TRY(tsw(h, PH_FFTF));
         if (T.G == 1) {
@@ -758,7 +763,7 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
         const DGrid &G = h->G;
         const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz;
         TRY(tsw(h, PH_GATHER));
-        launch_gather(h->pos_s, h->sup_s, h->sw.wtab, h->cell_off, h->nc, N, h->rgrid, h->rgrid + nr, h->rgrid + 2 * nr, G, h->dbox, h->uw_s, h->wstream);
+        launch_gather(h->pos_s, h->sw, N, h->rgrid, h->rgrid + nr, h->rgrid + 2 * nr, G, h->dbox, h->uw_s, h->wstream);
         TRY(tew(h, PH_GATHER));
         HIPCHK(hipGetLastError());
     }
@@ -779,7 +784,7 @@ static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*ou
         int lo, hi;
         row_range(h, N, lo, hi);
         launch_mreal(h->pos_s, h->*vec + vec_off, h->*out + out_off, lo, hi, h->cell_off, h->dbox, h->nc, h->d.rcut,
-                     h->d.self, h->coef, h->nb, mode, h->stream);
+                     h->d.self, h->coef, h->n_intervals * 2 * RS_NCOEF, h->nb, mode, h->stream);
         if (mode == MREAL_BUILD_LIST) h->nb_valid = true;
     }
     return 0;

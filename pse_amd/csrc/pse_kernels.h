@@ -44,7 +44,7 @@ struct LzFuse {
 // out = M_real . vec (+ self). mode: cells only / cells + write the pair list / use the pair list
 // rows [lo, hi) of the mat-vec (the whole vector is read; multi-GPU ranks each take a row range)
 void launch_mreal(const double4 *pos_s, const double4 *vec_s, double4 *out_s, int lo, int hi, const int *cell_off,
-                  DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, int mode, hipStream_t s);
+                  DBox box, DCells nc, double rcut, double self, const double *coef, int ncoef, NbList nb, int mode, hipStream_t s);
 // pair-list mat-vec + Lanczos sums; leaves the three reduced sums in scal[LZ_TMP .. LZ_TMP + 2]
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, int lo, int hi, const int *cell_off,
                           DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,
@@ -52,15 +52,27 @@ void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w
 int mreal_partials_needed(int rows);
 
 // ---- far field (K2-K8) -----------------------------------------------------------------------------------
-// scratch of the fast far-field path (rebuilt every call): support offsets and the per-particle separable weights
+// scratch of the fast far-field path (rebuilt every call): particles binned by the 8^3 block of nodes their support
+// origin lies in, and their records written in bin order
+struct FarBins {
+    int nbx, nby, nbz;          // bins per axis (set by the launchers from the grid)
+    int *cnt, *off;             // [nbins], [nbins + 1]
+    int *rank_s;                // [N] rank of a particle inside its bin (-1: not needed by this slab rank)
+    void *tmp; size_t tmp_bytes;   // scan scratch
+};
+size_t bin_scan_temp_bytes(size_t nbins);
 struct SpreadWork {
     double4 *d0_s;              // [N] offset of the support origin from the particle, grid units
-    double *wtab;               // [N][P^2 + P] (+ padding)
+    FarBins fb;
+    int4 *sup_t;                // [N] bin order: support origin, sorted index (bit 31: owned by another slab rank)
+    double4 *f_t;               // [N] bin order: prefac * force
+    double *wtab_t;             // [N][P^2 + P] (+ padding) bin order: separable weights
 };
+size_t farfield_bins(const DGrid &G);
 // true if the caller must zero the grids first (atomic fallback: P outside 4..8 or a grid smaller than two tiles)
 bool spread_needs_zero(const DGrid &G);
-void launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, const int *cell_off, DCells nc,
-                   double *gx, double *gy, double *gz, DGrid G, DBox box, SpreadWork w, hipStream_t s);
+void launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, double *gx, double *gy, double *gz, DGrid G,
+                   DBox box, SpreadWork w, hipStream_t s);
 struct ScaleArgs {
     double xi, eta;
     int noise;               // add k-space Brownian noise (K6)
@@ -73,9 +85,9 @@ void launch_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleAr
 // fused forward-x FFT + scale + inverse-x FFT on [3][Nx][Ny][Nzh] (Nx a power of two, 16..512); tw[m] = exp(-2 pi i m/Nx)
 bool xfuse_supported(int Nx);
 void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s);
-// the fast path reads sup_s / wtab written by launch_spread of the same step
-void launch_gather(const double4 *pos_s, const int4 *sup_s, const double *wtab, const int *cell_off, DCells nc, int N,
-                   const double *gx, const double *gy, const double *gz, DGrid G, DBox box, double4 *u_s, hipStream_t s);
+// the fast path reads the records written by launch_spread of the same step
+void launch_gather(const double4 *pos_s, SpreadWork w, int N, const double *gx, const double *gy, const double *gz, DGrid G,
+                   DBox box, double4 *u_s, hipStream_t s);
 
 // ---- slab decomposition helpers
 void launch_slab_pack(double2 *cgrid, double2 *buf, int nxl, int Ny, int Nzh, int nyl, int unpack, hipStream_t s);

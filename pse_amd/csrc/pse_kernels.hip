@@ -194,13 +194,22 @@ __device__ __forceinline__ void nb_store(char *rec, int slot, int lane, unsigned
     ((double *)(r + 768))[lane] = h;
 }
 
-template <bool LIST>
+// CL: the f, g coefficient table is copied to LDS first (ncoef doubles of dynamic shared memory).  Every neighbour reads
+// 20 coefficients of its own interval: from global memory that was 20 of the 24 L1 accesses per pair and kept the
+// texture addresser busy for the whole kernel (rocprofv3: TA_BUSY = duration, 425 M cache accesses = 20 x 21.3 M pairs).
+template <bool LIST, bool CL>
 __global__ void __launch_bounds__(TPB)
 k_mreal_cells(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int lo,
               int hi, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2, double self,
-              const double *__restrict__ coef, NbList nb) {
+              const double *__restrict__ coef_g, int ncoef, NbList nb) {
     __shared__ unsigned queue[QCAP * TPB];
+    extern __shared__ double scoef[];
     const int tid = threadIdx.x;
+    if (CL) {
+        for (int q = tid; q < ncoef; q += TPB) scoef[q] = coef_g[q];
+        __syncthreads();
+    }
+    const double *coef = CL ? scoef : coef_g;
     const int i = lo + xcd_block(blockIdx.x, gridDim.x) * TPB + tid;   // rows [lo, hi) of the mat-vec
     if (i >= hi) return;
     const double4 pi = pos_s[i];
@@ -324,8 +333,8 @@ k_mreal_overflow(const double4 *__restrict__ pos_s, const double4 *__restrict__ 
 // mat-vec from the pair list (one thread per particle, ELL layout: slot-major so a wave reads contiguous rows).
 // Per pair 20 B of list from HBM plus the neighbour's position and vector entry gathered through L2.  FUSE adds the
 // Lanczos epilogue (see LzFuse).
-template <bool FUSE, int UNROLL>
-__global__ void __launch_bounds__(TPB)
+template <bool FUSE, int UNROLL, int NT>
+__global__ void __launch_bounds__(NT)
 k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int lo,
              int hi, DBox box, int shift_only, double self, NbList nb, LzFuse lz, int dbg) {
     __shared__ double shift[27 * 3];
@@ -336,7 +345,7 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
         shift[threadIdx.x * 3] = sx; shift[threadIdx.x * 3 + 1] = sy; shift[threadIdx.x * 3 + 2] = sz;
     }
     __syncthreads();
-    const int i = lo + xcd_block(blockIdx.x, gridDim.x) * TPB + threadIdx.x;
+    const int i = lo + xcd_block(blockIdx.x, gridDim.x) * NT + threadIdx.x;
     const bool active = i < hi;
     double ux = 0.0, uy = 0.0, uz = 0.0;
     double4 vi = make_double4(0.0, 0.0, 0.0, 0.0);
@@ -397,11 +406,8 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
                 c = vi.x * m.x + vi.y * m.y + vi.z * m.z;
             }
         }
-        a = block_sum(a, sh);
-        __syncthreads();
-        b = block_sum(b, sh);
-        __syncthreads();
-        c = block_sum(c, sh);
+        if (NT == 64) { a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); }
+        else { a = block_sum(a, sh); __syncthreads(); b = block_sum(b, sh); __syncthreads(); c = block_sum(c, sh); }
         if (threadIdx.x == 0) {
             lz.partials[blockIdx.x] = a; lz.partials[lz.npart_cap + blockIdx.x] = b; lz.partials[2 * lz.npart_cap + blockIdx.x] = c;
         }
@@ -410,39 +416,48 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
 }
 
 void launch_mreal(const double4 *pos_s, const double4 *vec_s, double4 *out_s, int lo, int hi, const int *cell_off,
-                  DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, int mode, hipStream_t s) {
+                  DBox box, DCells nc, double rcut, double self, const double *coef, int ncoef, NbList nb, int mode, hipStream_t s) {
     if (hi <= lo) return;
     const dim3 g(nblocks(hi - lo, TPB)), b(TPB);
+    const size_t cb = (size_t)ncoef * sizeof(double);
+    const bool cl = cb <= 14 * 1024;   // with the 48 KB queue: two workgroups per CU
     if (mode == MREAL_BUILD_LIST) {
         (void)hipMemsetAsync(nb.ovf_n, 0, sizeof(int), s);
-        hipLaunchKernelGGL(k_mreal_cells<true>, g, b, 0, s, pos_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, self, coef, nb);
+        if (cl) hipLaunchKernelGGL((k_mreal_cells<true, true>), g, b, cb, s, pos_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, self, coef, ncoef, nb);
+        else hipLaunchKernelGGL((k_mreal_cells<true, false>), g, b, 0, s, pos_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, self, coef, ncoef, nb);
     } else if (mode == MREAL_USE_LIST) {
         hipLaunchKernelGGL(k_mreal_overflow, dim3(OVF_BLOCKS), b, 0, s, pos_s, vec_s, cell_off, box, nc, rcut * rcut, self, coef, nb);
-        hipLaunchKernelGGL((k_mreal_list<false, 4>), g, b, 0, s, pos_s, vec_s, out_s, lo, hi, box,
+        hipLaunchKernelGGL((k_mreal_list<false, 4, TPB>), g, b, 0, s, pos_s, vec_s, out_s, lo, hi, box,
                            (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1), self, nb, LzFuse{}, 0);
-    } else
-        hipLaunchKernelGGL(k_mreal_cells<false>, g, b, 0, s, pos_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, self, coef, nb);
+    } else if (cl)
+        hipLaunchKernelGGL((k_mreal_cells<false, true>), g, b, cb, s, pos_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, self, coef, ncoef, nb);
+    else
+        hipLaunchKernelGGL((k_mreal_cells<false, false>), g, b, 0, s, pos_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, self, coef, ncoef, nb);
 }
 
-__global__ void __launch_bounds__(TPB) k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, double *__restrict__ scal);
-int mreal_partials_needed(int rows) { return nblocks(std::max(rows, 1), TPB); }
+__global__ void __launch_bounds__(1024) k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, double *__restrict__ scal);
+int mreal_partials_needed(int rows) { return nblocks(std::max(rows, 1), 64); }
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, int lo, int hi, const int *cell_off,
                           DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,
                           double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s) {
-    const int nbk = nblocks(std::max(hi - lo, 1), TPB);
+    const int so = (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1);
+    const bool w1 = (dbg_mode() & 256) != 0;
+    const int nt = w1 ? 64 : TPB;
+    const int nbk = nblocks(std::max(hi - lo, 1), nt);
     hipLaunchKernelGGL(k_mreal_overflow, dim3(OVF_BLOCKS), dim3(TPB), 0, s, pos_s, vec_s, cell_off, box, nc, rcut * rcut, self, coef, nb);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
-    const int so = (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1);
-    switch (dbg_mode() & 15) {
-        case 6: hipLaunchKernelGGL((k_mreal_list<true, 6>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, dbg_mode()); break;
-        case 3: hipLaunchKernelGGL((k_mreal_list<true, 3>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, dbg_mode()); break;
-        case 2: hipLaunchKernelGGL((k_mreal_list<true, 2>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, dbg_mode()); break;
-        case 8: hipLaunchKernelGGL((k_mreal_list<true, 8>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, dbg_mode()); break;
-        case 1: hipLaunchKernelGGL((k_mreal_list<true, 1>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, dbg_mode()); break;
-        default: hipLaunchKernelGGL((k_mreal_list<true, 4>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, dbg_mode()); break;
+#define LAUNCH_LIST(U, NT_) hipLaunchKernelGGL((k_mreal_list<true, U, NT_>), dim3(nbk), dim3(NT_), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, dbg_mode())
+    switch ((dbg_mode() & 15) + (w1 ? 16 : 0)) {
+        case 2: LAUNCH_LIST(2, TPB); break;
+        case 8: LAUNCH_LIST(8, TPB); break;
+        case 16 + 2: LAUNCH_LIST(2, 64); break;
+        case 16 + 8: LAUNCH_LIST(8, 64); break;
+        case 16 + 0: case 16 + 4: LAUNCH_LIST(4, 64); break;
+        default: LAUNCH_LIST(4, TPB); break;
     }
+#undef LAUNCH_LIST
     if (ev_end) (void)hipEventRecord(ev_end, s);
-    hipLaunchKernelGGL(k_lz_reduce, dim3(1), dim3(TPB), 0, s, lz.partials, nbk, lz.npart_cap, 3, scal);
+    hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, lz.partials, nbk, lz.npart_cap, 3, scal);
 }
 
 __global__ void k_eval_fg(const double *__restrict__ r, int n, const double *__restrict__ coef, double *f, double *g) {
@@ -504,17 +519,32 @@ k_spread_atomic(const double4 *__restrict__ pos_s, const double4 *__restrict__ f
     }
 }
 
-// ---- separable Gaussian weights, computed once per particle and step -----------------------------------------
-// w(tx,ty,tz) = A[tx][ty] B[tz] with A = exp(-c (ex^2 + ey^2)) (x and y couple through the shear,
-// PSEv1/Mobility.cu:230) and B = exp(-c ez^2): P^2 + P exponentials per particle instead of P^3.  k_support finds the
-// support origin and its offset from the particle once; k_weights evaluates the table with one lane per entry (no idle
-// lanes, one lean exponential each) into wtab[N][P^2+P].  The ~3 spread hits of a particle and its gather read the
-// table instead of redoing the arithmetic per (particle, tile) pair -- rocprofv3 showed both kernels bound by VALU issue.
+// ---- far-field particle records in bin order ----------------------------------------------------------------------
+// Spread and gather work on tiles of grid nodes and need "the particles whose support starts in / reaches this tile".
+// Walking the near-field cell list for that (first versions) costs every tile workgroup a chain of dependent
+// global-memory round trips and index-gathered loads of the per-particle data; rocprofv3 showed both kernels bound by
+// that latency at 3-4 workgroups per CU, not by LDS or HBM throughput.  So once per step the particles are binned by the
+// BIN^3 block of nodes their support origin lies in (counting sort: atomic rank, scan, scatter) and everything a tile
+// kernel needs is written IN BIN ORDER: origin + sorted index (sup_t), prefac * force (f_t) and the separable weights
+// (wtab_t).  A gather workgroup then reads one contiguous range of records, a spread workgroup a few ranges.
+//
+// Weights: w(tx,ty,tz) = A[tx][ty] B[tz] with A = exp(-c (ex^2 + ey^2)) (x and y couple through the shear,
+// PSEv1/Mobility.cu:230) and B = exp(-c ez^2): P^2 + P numbers per particle instead of P^3 exponentials per use.
+constexpr int BIN = 8;
+__host__ __device__ inline int bins_of(int n) { return (n + BIN - 1) / BIN; }
+__device__ __forceinline__ int wrapi(int a, int n) { a %= n; return a < 0 ? a + n : a; }
+__device__ __forceinline__ int bin_index(const int4 &o, const FarBins &fb) {
+    return ((o.x / BIN) * fb.nby + (o.y / BIN)) * fb.nbz + (o.z / BIN);
+}
+
+// support origin (wrapped into the grid), offset of the origin from the particle, the particle's own node plane, and its
+// rank inside its bin (-1: a slab rank never touches this particle)
 __global__ void k_support(const double4 *__restrict__ pos_s, int N, DGrid G, DBox box, int4 *__restrict__ sup_s,
-                          double4 *__restrict__ d0_s) {
+                          double4 *__restrict__ d0_s, FarBins fb) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= N) return;
-    const double4 p = pos_s[s];
+    if (s - (int)(threadIdx.x & 63) >= N) return;          // whole wave past the end
+    const bool live = s < N;
+    const double4 p = pos_s[live ? s : N - 1];
     double fx, fy, fz;
     frac_coords(box, p.x, p.y, p.z, fx, fy, fz);
     int4 o;
@@ -522,143 +552,124 @@ __global__ void k_support(const double4 *__restrict__ pos_s, int N, DGrid G, DBo
     support_start(fx, G.Nx, G.P, o.x, d.x);   // PSEv1/Mobility.cu:212-214
     support_start(fy, G.Ny, G.P, o.y, d.y);
     support_start(fz, G.Nz, G.P, o.z, d.z);
-    o.w = (int)(fx * G.Nx);   // the node plane the particle sits in: decides which slab owns it
+    o.x = wrapi(o.x, G.Nx); o.y = wrapi(o.y, G.Ny); o.z = wrapi(o.z, G.Nz);
+    o.w = min((int)(fx * G.Nx), G.Nx - 1);   // the node plane the particle sits in: decides which slab owns it
     d.w = 0.0;
-    sup_s[s] = o;
-    if (d0_s) d0_s[s] = d;
+    if (live) {
+        sup_s[s] = o;
+        if (d0_s) d0_s[s] = d;
+    }
+    if (fb.cnt) {
+        bool need = live;
+        if (G.nxl < G.Nx) need = need && wrapi(o.w - (G.x0 - G.P), G.Nx) < G.nxl + 2 * G.P;   // within a support of the slab's planes
+        // Neighbouring lanes are neighbouring particles and mostly share a bin: one atomic per distinct bin of the wave
+        // (the leader adds the group's size, members take consecutive ranks) instead of 64 same-address atomics.
+        const int bin = need ? bin_index(o, fb) : -1;
+        const int lane = threadIdx.x & 63;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        unsigned long long todo = __ballot(need);
+        int prefix = 0, count = 0, leader = lane;
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            const int b0 = __shfl(bin, src, 64);
+            const unsigned long long m = __ballot(bin == b0) & todo;
+            if (bin == b0) { prefix = __popcll(m & below); count = __popcll(m); leader = src; }
+            todo &= ~m;
+        }
+        int base = 0;
+        if (need && leader == lane) base = atomicAdd(&fb.cnt[bin], count);
+        base = __shfl(base, leader, 64);
+        if (live) fb.rank_s[s] = need ? base + prefix : -1;
+    }
 }
 
-// One lane per (particle, row): rows 0..P-1 are the x rows A[.][ty] of the weight table, row P is B[.].  A Gaussian
-// sampled on a uniform stencil obeys E(t+1) = E(t) q r_t with q = exp(-2c X0 h) and r_t = exp(-c h^2 (2t+1)) (r_t does not
-// depend on the particle: passed in), so a row costs 2 exponentials + 2(P-1) multiplies: 2(P+1) exponentials per particle
-// instead of P^2+P.  With shear X0 depends on ty (PSEv1/Mobility.cu:230), which is why A is stored as rows in x.
+size_t bin_scan_temp_bytes(size_t nbins) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int *)nullptr, (int *)nullptr, (int)(nbins + 1));
+    return bytes;
+}
+
+// One lane per (particle, row): rows 0..P-1 are the x rows A[.][ty] of the weight table, row P is B[.] plus the record
+// header.  A Gaussian sampled on a uniform stencil obeys E(t+1) = E(t) q r_t with q = exp(-2c X0 h) and
+// r_t = exp(-c h^2 (2t+1)) (r_t does not depend on the particle: passed in), so a row costs 2 exponentials + 2(P-1)
+// multiplies: 2(P+1) exponentials per particle instead of P^2+P.  With shear X0 depends on ty (PSEv1/Mobility.cu:230),
+// which is why A is stored as rows in x.
 struct WeightConsts { double rx[8], rz[8]; };   // rx[t] = exp(-c hx^2 (2t+1)), rz[t] = exp(-c hz^2 (2t+1))
 
+constexpr int WPB = 32;   // particles per workgroup of k_weights
 template <int P>
 __global__ void __launch_bounds__(TPB)
-k_weights(const double4 *__restrict__ d0_s, const int4 *__restrict__ sup_s, int N, DGrid G, DBox box, WeightConsts wc,
-          double *__restrict__ wtab) {
-    constexpr unsigned WT = P * P + P, ROWS = P + 1;
-    const unsigned gid = blockIdx.x * TPB + threadIdx.x;   // N * (P + 1) < 2^32
-    const unsigned p = gid / ROWS;
-    const int row = (int)(gid - p * ROWS);
-    if (p >= (unsigned)N) return;
-    if (G.nxl < G.Nx) {   // slab rank: only particles within a support of its planes are ever read
-        int d = sup_s[p].w - (G.x0 - P); d %= G.Nx; if (d < 0) d += G.Nx;
-        if (d >= G.nxl + 2 * P) return;
-    }
-    const double4 d0 = d0_s[p];
-    double *out = wtab + (size_t)p * WT;
-    const double c = G.expfac;
-    if (row < P) {
-        const double ey = G.hy * (d0.y + row), x0 = G.hx * d0.x + box.xy * ey;
-        double e = exp_neg(-c * (x0 * x0 + ey * ey));
-        const double q = exp_lean(-2.0 * c * x0 * G.hx);
-#pragma unroll
-        for (int t = 0; t < P; ++t) { out[t * P + row] = e; e *= q * wc.rx[t]; }
-    } else {
-        const double z0 = G.hz * d0.z;
-        double e = exp_neg(-c * z0 * z0);
-        const double q = exp_lean(-2.0 * c * z0 * G.hz);
-#pragma unroll
-        for (int t = 0; t < P; ++t) { out[P * P + t] = e; e *= q * wc.rz[t]; }
-    }
-}
-
-// ---- per-tile particle lists built in LDS --------------------------------------------------------------------------
-// A workgroup that owns a block of grid nodes needs the particles whose support touches it (spread) or starts in it
-// (gather).  They sit in a box of cells around the tile; the cells of one (x,y) column are one or two contiguous slot
-// runs of the sorted particle arrays.  All threads cooperate: one thread per run builds the run table, a block scan
-// turns lengths into offsets, then ONE THREAD PER CANDIDATE tests it and appends survivors to an LDS list -- 64x fewer
-// instructions than testing one candidate per wave, and no global hit lists (whose same-address atomics cost 0.37 ms).
-constexpr int RMAX = 256;         // runs per chunk (= threads of the tile kernels)
-constexpr int LCAP = 512;         // candidates per chunk, hence the list capacity
-
-struct TileList {
-    int run_b[RMAX];
-    int run_o[RMAX + 1];
-    int wsum[4];
-    int list[LCAP];
-    int n;
-};
-
-__device__ __forceinline__ int floordiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
-
-// cells [clo, clo+ccnt) per axis (unwrapped) that can hold particles with floor(s) in [lo, hi] node units
-__device__ __forceinline__ void cell_range(int lo, int hi, int ncell, int nnode, int &clo, int &ccnt) {
-    const int c0 = floordiv(lo * ncell, nnode), c1 = floordiv((hi + 1) * ncell, nnode);
-    clo = c0;
-    ccnt = min(c1 - c0 + 1, ncell);
-}
-
-// Calls body() once per chunk with tl.list[0..tl.n) filled; pred(p) decides membership.  256 threads.
-template <class Pred, class Body>
-__device__ __forceinline__ void for_tile_particles(TileList &tl, const int *__restrict__ cell_off, const DCells &nc,
-                                                   const int clo[3], const int ccnt[3], Pred &&pred, Body &&body) {
+k_weights(const double4 *__restrict__ d0_s, const int4 *__restrict__ sup_s, const double4 *__restrict__ f_s, int N, DGrid G,
+          DBox box, WeightConsts wc, FarBins fb, SpreadWork w) {
+    constexpr int WT = P * P + P, ROWS = P + 1;
+    __shared__ double rec[WPB * WT];      // the records of WPB particles, written out as contiguous runs (slots are scattered)
+    __shared__ int slot_l[WPB];
     const int tid = threadIdx.x;
-    const int ncols = ccnt[0] * ccnt[1];
-    int z0 = clo[2] % nc.nz; if (z0 < 0) z0 += nc.nz;
-    const int zfirst = min(ccnt[2], nc.nz - z0);
-    for (int col0 = 0; col0 < ncols; col0 += RMAX / 2) {
-        const int nr = min(RMAX / 2, ncols - col0) * 2;
-        int len = 0;
-        if (tid < nr) {
-            const int col = col0 + (tid >> 1), seg = tid & 1;
-            const int ix = col / ccnt[1], iy = col - ix * ccnt[1];
-            int cx = (clo[0] + ix) % nc.nx; if (cx < 0) cx += nc.nx;
-            int cy = (clo[1] + iy) % nc.ny; if (cy < 0) cy += nc.ny;
-            const int base = (cx * nc.ny + cy) * nc.nz;
-            const int za = seg == 0 ? z0 : 0, zn = seg == 0 ? zfirst : ccnt[2] - zfirst;
-            if (zn > 0) {
-                const int jb = cell_off[base + za];
-                len = cell_off[base + za + zn] - jb;
-                tl.run_b[tid] = jb;
+    const int p0 = blockIdx.x * WPB;
+    if (tid < WPB) {
+        const int p = p0 + tid;
+        int slot = -1;
+        if (p < N) {
+            const int rank = fb.rank_s[p];
+            if (rank >= 0) {
+                const int4 sp = sup_s[p];
+                slot = fb.off[bin_index(sp, fb)] + rank;
+                // header: origin, sorted index (bit 31: not owned by this slab rank), prefac * force
+                const bool owned = G.nxl == G.Nx || wrapi(sp.w - G.x0, G.Nx) < G.nxl;
+                w.sup_t[slot] = make_int4(sp.x, sp.y, sp.z, (int)((unsigned)p | (owned ? 0u : 0x80000000u)));
+                const double4 F = f_s[p];
+                w.f_t[slot] = make_double4(G.prefac * F.x, G.prefac * F.y, G.prefac * F.z, 0.0);
             }
         }
-        // exclusive block scan of len (one value per thread)
-        int inc = len;
+        slot_l[tid] = slot;
+    }
+    const double c = G.expfac;
+    for (int idx = tid; idx < WPB * ROWS; idx += TPB) {
+        const int pl = idx / ROWS, row = idx - pl * ROWS, p = p0 + pl;
+        if (p >= N) continue;
+        const double4 d0 = d0_s[p];
+        double *out = rec + pl * WT;
+        if (row < P) {
+            const double ey = G.hy * (d0.y + row), x0 = G.hx * d0.x + box.xy * ey;
+            double e = exp_neg(-c * (x0 * x0 + ey * ey));
+            const double q = exp_lean(-2.0 * c * x0 * G.hx);
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if ((tid & 63) >= o) inc += v; }
-        __syncthreads();                                  // previous chunk's body is done with the list
-        if ((tid & 63) == 63) tl.wsum[tid >> 6] = inc;
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < (tid >> 6); ++w) woff += tl.wsum[w];
-        tl.run_o[tid] = woff + inc - len;
-        if (tid == RMAX - 1) tl.run_o[RMAX] = woff + inc;
-        __syncthreads();
-        const int total = tl.run_o[RMAX];
-        for (int c0 = 0; c0 < total; c0 += LCAP) {
-            if (tid == 0) tl.n = 0;
-            __syncthreads();
-            const int cend = min(total, c0 + LCAP);
-            for (int k = c0 + tid; k < cend; k += RMAX) {
-                int lo = 0, hi = nr;                       // largest r with run_o[r] <= k
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tl.run_o[mid] <= k) lo = mid; else hi = mid; }
-                const int p = tl.run_b[lo] + (k - tl.run_o[lo]);
-                if (pred(p)) tl.list[atomicAdd(&tl.n, 1)] = p;
-            }
-            __syncthreads();
-            body();
-            __syncthreads();
+            for (int t = 0; t < P; ++t) { out[t * P + row] = e; e *= q * wc.rx[t]; }
+        } else {
+            const double z0 = G.hz * d0.z;
+            double e = exp_neg(-c * z0 * z0);
+            const double q = exp_lean(-2.0 * c * z0 * G.hz);
+#pragma unroll
+            for (int t = 0; t < P; ++t) { out[P * P + t] = e; e *= q * wc.rz[t]; }
         }
+    }
+    __syncthreads();
+    for (int e = tid; e < WPB * WT; e += TPB) {
+        const int pl = e / WT, fld = e - pl * WT, slot = slot_l[pl];
+        if (slot >= 0) w.wtab_t[(size_t)slot * WT + fld] = rec[e];
     }
 }
 
 // Tile-owned spread (K2+K3): one workgroup owns a TXxTYxTZ block of grid nodes, accumulates every contribution to it in
 // LDS (ds_add_f64) and writes each node exactly once with plain stores -- no global atomics (1.3 TB/s chip-wide on
-// MI355X: the 7.6 ms of the v0 kernel), no ZeroGrid pass.  Eight lanes per (particle, tile) pair -- lane = z offset of
-// the support -- so a wave deposits 8 pairs at once and all per-pair bookkeeping (clip, offsets) costs one instruction
-// per 8 pairs; the P^2 (x,y) offsets are a compile-time unrolled loop: one broadcast weight read, three multiplies,
-// three LDS adds per node row.
+// MI355X: the 7.6 ms of the v0 kernel), no ZeroGrid pass.  Candidates are the records of the few bins whose origins can
+// reach the tile; survivors of the clip test are processed 32 per pass: their records are staged in LDS with coalesced
+// loads (the next pass's are in flight while this one computes), then eight lanes per (particle, tile) pair -- lane = z
+// offset of the support -- run the unrolled P^2 (x,y) loop: one broadcast weight read, three multiplies, three LDS adds.
+constexpr int SP_NG = 32;          // records per pass (= 256 threads / 8 lanes)
+constexpr int SP_LCAP = 1024;      // survivors per chunk
+constexpr int SP_RMAX = 64;        // bin ranges per tile
+
 template <int P, int TX, int TY, int TZ>
-__global__ void __launch_bounds__(RMAX)
-k_spread_tile(const double4 *__restrict__ f_s, const int4 *__restrict__ sup_s, const double *__restrict__ wtab,
-              const int *__restrict__ cell_off, DCells nc, double *__restrict__ gx, double *__restrict__ gy,
-              double *__restrict__ gz, DGrid G, int ntx, int nty, int ntz, int dbg) {
-    constexpr int NT = RMAX, XS = TY * TZ + 2, NODES = TX * XS, WT = P * P + P;
+__global__ void __launch_bounds__(256)
+k_spread_bins(const int4 *__restrict__ sup_t, const double4 *__restrict__ f_t, const double *__restrict__ wtab_t,
+              FarBins fb, double *__restrict__ gx, double *__restrict__ gy, double *__restrict__ gz, DGrid G, int ntx,
+              int nty, int ntz) {
+    constexpr int NT = 256, XS = TY * TZ + 2, NODES = TX * XS, WT = P * P + P;
     __shared__ double acc[3 * NODES];
-    __shared__ TileList tl;
+    __shared__ int list[SP_LCAP];
+    __shared__ int rng_b[SP_RMAX], rng_o[SP_RMAX + 1];
+    __shared__ int nl;
     const int tid = threadIdx.x;
     int b = xcd_block(blockIdx.x, gridDim.x);
     const int tz_ = b % ntz; b /= ntz;
@@ -667,7 +678,32 @@ k_spread_tile(const double4 *__restrict__ f_s, const int4 *__restrict__ sup_s, c
     const int t0[3] = {G.x0 + tx_ * TX, ty_ * TY, tz_ * TZ};
     const int ext[3] = {min(TX, G.x0 + G.nxl - t0[0]), min(TY, G.Ny - t0[1]), min(TZ, G.Nz - t0[2])};
     const int Nn[3] = {G.Nx, G.Ny, G.Nz};
+    const int nb[3] = {fb.nbx, fb.nby, fb.nbz};
     for (int n = tid; n < 3 * NODES; n += NT) acc[n] = 0.0;
+
+    // bins whose origins [t0 - P + 1, t0 + ext - 1] (cyclic) can reach the tile
+    int blo[3], bcnt[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        blo[a] = wrapi(t0[a] - (P - 1), Nn[a]) / BIN;
+        bcnt[a] = min(nb[a], wrapi((t0[a] + ext[a] - 1) / BIN - blo[a], nb[a]) + 1);
+    }
+    const int nr = bcnt[0] * bcnt[1] * bcnt[2];   // <= 4*3*3 for the shipped tile shapes
+    if (tid < nr) {
+        const int iz = tid % bcnt[2], r = tid / bcnt[2], iy = r % bcnt[1], ix = r / bcnt[1];
+        const int bin = (((blo[0] + ix) % nb[0]) * nb[1] + (blo[1] + iy) % nb[1]) * nb[2] + (blo[2] + iz) % nb[2];
+        const int o = fb.off[bin];
+        rng_b[tid] = o;
+        rng_o[tid + 1] = fb.off[bin + 1] - o;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        rng_o[0] = 0;
+        for (int r = 0; r < nr; ++r) { run += rng_o[r + 1]; rng_o[r + 1] = run; }
+    }
+    __syncthreads();
+    const int total = rng_o[nr];
 
     // support origin relative to the tile (nearest image); false if the support misses the tile
     auto clip = [&](const int4 &sp, int a0[3]) {
@@ -682,52 +718,54 @@ k_spread_tile(const double4 *__restrict__ f_s, const int4 *__restrict__ sup_s, c
         }
         return hit;
     };
-    // particles that can touch the tile have floor(s) in [t0 - ceil(P/2), t0 + ext - 1 + P/2] (node units)
-    int clo[3], ccnt[3];
-    cell_range(t0[0] - (P + 1) / 2, t0[0] + ext[0] - 1 + P / 2, nc.nx, G.Nx, clo[0], ccnt[0]);
-    cell_range(t0[1] - (P + 1) / 2, t0[1] + ext[1] - 1 + P / 2, nc.ny, G.Ny, clo[1], ccnt[1]);
-    cell_range(t0[2] - (P + 1) / 2, t0[2] + ext[2] - 1 + P / 2, nc.nz, G.Nz, clo[2], ccnt[2]);
-
-    const double prefac = G.prefac;
-    const int grp = tid >> 3, tz = tid & 7;            // 32 groups of 8 lanes; lane = z offset inside the support
-    for_tile_particles(tl, cell_off, nc, clo, ccnt,
-        [&](int p) { int a0[3]; return clip(sup_s[p], a0); },
-        [&]() {
-            const int n = (dbg & 1) ? 0 : tl.n;
-            for (int h = grp; h < n; h += NT / 8) {
-                const int p = tl.list[h];
-                // the 8 lanes of a group read the same addresses (a few L1 accesses per instruction); all loads are
-                // unconditional so they are in flight together
-                const int4 sp = sup_s[p];
-                const double4 F = f_s[p];
-                const double *w = wtab + (size_t)p * WT;
-                double a[P * P];
+    const int grp = tid >> 3, tz = tid & 7;
+    for (int c0 = 0; c0 < total; c0 += SP_LCAP) {
+        if (tid == 0) nl = 0;
+        __syncthreads();
+        const int cend = min(total, c0 + SP_LCAP);
+        for (int k = c0 + tid; k < cend; k += NT) {
+            int lo = 0, hi = nr;                       // largest r with rng_o[r] <= k
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rng_o[mid] <= k) lo = mid; else hi = mid; }
+            const int slot = rng_b[lo] + (k - rng_o[lo]);
+            int a0[3];
+            if (clip(sup_t[slot], a0)) list[atomicAdd(&nl, 1)] = slot;
+        }
+        __syncthreads();
+        const int n = nl;
+        // eight lanes per survivor (lane = z offset of the support); the eight lanes read the same record addresses
+        // (a few L1 accesses per instruction) and all loads are unconditional so they are in flight together
+        for (int h = grp; h < n; h += NT / 8) {
+            const size_t slot = (size_t)list[h];
+            const int4 sp = sup_t[slot];
+            const double4 F = f_t[slot];
+            const double *w = wtab_t + slot * WT;
+            double a[P * P];
 #pragma unroll
-                for (int e = 0; e < P * P; ++e) a[e] = w[e];
-                const double bw = prefac * w[P * P + (tz < P ? tz : 0)];
-                int a0[3];
-                clip(sp, a0);
-                const int lz = a0[2] + tz;
-                if (tz < P && lz >= 0 && lz < ext[2]) {
-                    const double bx = bw * F.x, by = bw * F.y, bz = bw * F.z;
-                    double *cell = acc + a0[0] * XS + a0[1] * TZ + lz;
+            for (int e = 0; e < P * P; ++e) a[e] = w[e];
+            const double bw = w[P * P + (tz < P ? tz : 0)];
+            int a0[3];
+            clip(sp, a0);
+            const int lz = a0[2] + tz;
+            if (tz < P && lz >= 0 && lz < ext[2]) {
+                const double bx = bw * F.x, by = bw * F.y, bz = bw * F.z;
+                double *cell = acc + a0[0] * XS + a0[1] * TZ + lz;
 #pragma unroll
-                    for (int tx = 0; tx < P; ++tx) {
-                        const bool okx = (unsigned)(a0[0] + tx) < (unsigned)ext[0];
+                for (int tx = 0; tx < P; ++tx) {
+                    const bool okx = (unsigned)(a0[0] + tx) < (unsigned)ext[0];
 #pragma unroll
-                        for (int ty = 0; ty < P; ++ty) {
-                            if (okx && (unsigned)(a0[1] + ty) < (unsigned)ext[1]) {
-                                double *o = cell + tx * XS + ty * TZ;
-                                if (dbg & 2) { if (a[tx * P + ty] * bx == 1.2345e-300) o[0] = 1.0; continue; }
-                                atomicAdd(o, a[tx * P + ty] * bx);
-                                atomicAdd(o + NODES, a[tx * P + ty] * by);
-                                atomicAdd(o + 2 * NODES, a[tx * P + ty] * bz);
-                            }
+                    for (int ty = 0; ty < P; ++ty) {
+                        if (okx && (unsigned)(a0[1] + ty) < (unsigned)ext[1]) {
+                            double *o = cell + tx * XS + ty * TZ;
+                            atomicAdd(o, a[tx * P + ty] * bx);
+                            atomicAdd(o + NODES, a[tx * P + ty] * by);
+                            atomicAdd(o + 2 * NODES, a[tx * P + ty] * bz);
                         }
                     }
                 }
             }
-        });
+        }
+        __syncthreads();                                  // the list is rebuilt by the next chunk
+    }
     __syncthreads();
     const int eyz = ext[1] * ext[2], nout = ext[0] * eyz;
     for (int n = tid; n < nout; n += NT) {
@@ -752,11 +790,10 @@ static void tile_dims(int &tx, int &ty, int &tz) {
         default: tx = 16; ty = 8; tz = 8; break;
     }
 }
-constexpr int GT = 8;   // gather tile edge
 
 bool farfield_fast_path(const DGrid &G) {
-    // the tile kernels resolve a support to its nearest image of the tile (needs N >= 2 max(tile, support) per axis)
-    // and map one lane per (y,z) pair of the support (P^2 <= 64)
+    // the tile kernels resolve a support to its nearest image of the tile (needs N >= 2 max(tile, support) per axis) and
+    // map the z offsets of a support to at most 8 lanes
     int tx, ty, tz;
     tile_dims(tx, ty, tz);
     const int tmax = std::max(tx, std::max(ty, tz));
@@ -764,154 +801,137 @@ bool farfield_fast_path(const DGrid &G) {
     return G.P >= 4 && G.P <= 8 && G.Nx >= need && G.Ny >= need && G.Nz >= need;
 }
 bool spread_needs_zero(const DGrid &G) { return !farfield_fast_path(G); }
+size_t farfield_bins(const DGrid &G) { return (size_t)bins_of(G.Nx) * bins_of(G.Ny) * bins_of(G.Nz); }
 
 template <int P>
-static void launch_spread_p(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, const int *cell_off, DCells nc,
-                            double *gx, double *gy, double *gz, DGrid G, DBox box, SpreadWork w, hipStream_t s) {
-    hipLaunchKernelGGL(k_support, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos_s, N, G, box, sup_s, w.d0_s);
+static void launch_spread_p(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, double *gx, double *gy, double *gz,
+                            DGrid G, DBox box, SpreadWork w, hipStream_t s) {
+    FarBins fb = w.fb;
+    fb.nbx = bins_of(G.Nx); fb.nby = bins_of(G.Ny); fb.nbz = bins_of(G.Nz);
+    const int nbins = fb.nbx * fb.nby * fb.nbz;
+    (void)hipMemsetAsync(fb.cnt, 0, (size_t)(nbins + 1) * sizeof(int), s);
+    hipLaunchKernelGGL(k_support, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos_s, N, G, box, sup_s, w.d0_s, fb);
+    size_t tb = fb.tmp_bytes;
+    (void)hipcub::DeviceScan::ExclusiveSum(fb.tmp, tb, fb.cnt, fb.off, nbins + 1, s);   // cnt[nbins] = 0: off[nbins] = total
     WeightConsts wc;
     for (int t = 0; t < 8; ++t) {
         wc.rx[t] = std::exp(-G.expfac * G.hx * G.hx * (2 * t + 1));
         wc.rz[t] = std::exp(-G.expfac * G.hz * G.hz * (2 * t + 1));
     }
-    hipLaunchKernelGGL(k_weights<P>, dim3(nblocks((long)N * (P + 1), TPB)), dim3(TPB), 0, s, w.d0_s, sup_s, N, G, box, wc, w.wtab);
+    hipLaunchKernelGGL(k_weights<P>, dim3(nblocks(N, WPB)), dim3(TPB), 0, s, w.d0_s, sup_s, f_s, N, G, box, wc, fb, w);
     int TX, TY, TZ;
     tile_dims(TX, TY, TZ);
     const int ntx = (G.nxl + TX - 1) / TX, nty = (G.Ny + TY - 1) / TY, ntz = (G.Nz + TZ - 1) / TZ;
-    const dim3 g(ntx * nty * ntz), b(RMAX);
+    const dim3 g(ntx * nty * ntz), b(256);
     if (TX == 8)
-        hipLaunchKernelGGL((k_spread_tile<P, 8, 8, 8>), g, b, 0, s, f_s, sup_s, w.wtab, cell_off, nc, gx, gy, gz, G, ntx, nty, ntz, dbg_mode());
+        hipLaunchKernelGGL((k_spread_bins<P, 8, 8, 8>), g, b, 0, s, w.sup_t, w.f_t, w.wtab_t, fb, gx, gy, gz, G, ntx, nty, ntz);
     else if (TY == 8)
-        hipLaunchKernelGGL((k_spread_tile<P, 16, 8, 8>), g, b, 0, s, f_s, sup_s, w.wtab, cell_off, nc, gx, gy, gz, G, ntx, nty, ntz, dbg_mode());
+        hipLaunchKernelGGL((k_spread_bins<P, 16, 8, 8>), g, b, 0, s, w.sup_t, w.f_t, w.wtab_t, fb, gx, gy, gz, G, ntx, nty, ntz);
     else
-        hipLaunchKernelGGL((k_spread_tile<P, 16, 16, 8>), g, b, 0, s, f_s, sup_s, w.wtab, cell_off, nc, gx, gy, gz, G, ntx, nty, ntz, dbg_mode());
+        hipLaunchKernelGGL((k_spread_bins<P, 16, 16, 8>), g, b, 0, s, w.sup_t, w.f_t, w.wtab_t, fb, gx, gy, gz, G, ntx, nty, ntz);
 }
 
-void launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, const int *cell_off, DCells nc,
-                   double *gx, double *gy, double *gz, DGrid G, DBox box, SpreadWork w, hipStream_t s) {
-    if (!farfield_fast_path(G) || !w.wtab) {
+void launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, double *gx, double *gy, double *gz, DGrid G,
+                   DBox box, SpreadWork w, hipStream_t s) {
+    if (!farfield_fast_path(G) || !w.wtab_t) {
         hipLaunchKernelGGL(k_spread_atomic, dim3(nblocks(N, TPB / 64)), dim3(TPB), 0, s, pos_s, f_s, N, gx, gy, gz, G, box);
         return;
     }
     switch (G.P) {
-        case 4: launch_spread_p<4>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, w, s); break;
-        case 5: launch_spread_p<5>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, w, s); break;
-        case 6: launch_spread_p<6>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, w, s); break;
-        case 7: launch_spread_p<7>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, w, s); break;
-        default: launch_spread_p<8>(pos_s, f_s, sup_s, N, cell_off, nc, gx, gy, gz, G, box, w, s); break;
+        case 4: launch_spread_p<4>(pos_s, f_s, sup_s, N, gx, gy, gz, G, box, w, s); break;
+        case 5: launch_spread_p<5>(pos_s, f_s, sup_s, N, gx, gy, gz, G, box, w, s); break;
+        case 6: launch_spread_p<6>(pos_s, f_s, sup_s, N, gx, gy, gz, G, box, w, s); break;
+        case 7: launch_spread_p<7>(pos_s, f_s, sup_s, N, gx, gy, gz, G, box, w, s); break;
+        default: launch_spread_p<8>(pos_s, f_s, sup_s, N, gx, gy, gz, G, box, w, s); break;
     }
 }
 
 // K8 gpu_stokes_Contract_kernel (PSEv1/Mobility.cu:325-477): u_p = h^3 sum_nodes prefac exp(-expfac r^2) u_grid.
-// Tile gather: a workgroup stages its GT^3 tile plus the P-1 node halo on the high side of each axis (every support
-// that starts in the tile lies inside it) in LDS -- each grid granule is fetched once per tile instead of once per
-// particle (the per-particle version was bound by L1 accesses: 325 per particle).  Staging: a thread keeps one (y,z)
-// column and walks component x plane, so the loop body is an add and a load and all loads are in flight together.
-// Then 8 lanes per particle (lane = z offset), 8 particles per wave, compile-time loop over the P^2 (x,y) offsets:
-// one broadcast weight read, one multiply, three LDS reads, three FMAs; 3-step reduction inside the 8 lanes instead of
-// the reference's shared-memory tree over B^3 threads (PSEv1/Mobility.cu:456-470).  A particle belongs to the tile
-// (and, in slab mode, to the rank) that holds its support origin; particles of other ranks stay zero (caller's memset).
+// Bin gather: a workgroup takes one bin, stages the BIN^3 nodes plus the P-1 node halo on the high side of each axis
+// (every support that starts in the bin lies inside) for all three velocity components in LDS (52.7 KB at P = 6: three
+// workgroups per CU) and reads the bin's records, which are contiguous.  The only dependent round trip is bin offsets ->
+// (region, records): all those loads are in flight together.  Four lanes per particle (lane = pair of z offsets), up to
+// 64 particles per pass, compile-time loop over the P^2 (x,y) offsets: one ds_read2 and three FMAs per component; 2-step
+// reduction inside the 4 lanes instead of the reference's shared-memory tree over P^3 threads (PSEv1/Mobility.cu:456-470).
 template <int P>
-__global__ void __launch_bounds__(RMAX)
-k_gather_tile(const int4 *__restrict__ sup_s, const double *__restrict__ wtab, const int *__restrict__ cell_off, DCells nc,
+__global__ void __launch_bounds__(256)
+k_gather_bins(const int4 *__restrict__ sup_t, const double *__restrict__ wtab_t, FarBins fb, int bx0, int nbx_l,
               const double *__restrict__ gx, const double *__restrict__ gy, const double *__restrict__ gz, DGrid G,
-              double4 *__restrict__ u_s, int ntx, int nty, int ntz, int dbg) {
-    constexpr int NT = RMAX, E = GT + P - 1, E2 = E * E, E3 = E2 * E, WT = P * P + P;
-    __shared__ double reg[E3];          // one velocity component of the tile + halo: 17.6 KB at P = 6
-    __shared__ TileList tl;
-    const int tid = threadIdx.x, comp = blockIdx.y;
-    const double *__restrict__ g = comp == 0 ? gx : (comp == 1 ? gy : gz);
+              double4 *__restrict__ u_s) {
+    constexpr int NT = 256, E = BIN + P - 1, E2 = E * E, E3 = E2 * E, WT = P * P + P, NLD = (3 * E3 + NT - 1) / NT;
+    __shared__ double reg[3 * E3];
+    const int tid = threadIdx.x;
     int b = xcd_block(blockIdx.x, gridDim.x);
-    const int tz_ = b % ntz; b /= ntz;
-    const int ty_ = b % nty; b /= nty;
-    const int tx_ = b;
-    // x: a slab rank stores planes [x0 - hl, x0 + nxl + nhalo) and tiles the window of support origins its particles can
-    // have; a single GPU stores the whole periodic grid
+    const int bz = b % fb.nbz; b /= fb.nbz;
+    const int by = b % fb.nby; b /= fb.nby;
+    const int bx = (bx0 + b) % fb.nbx;
+    const int bin = (bx * fb.nby + by) * fb.nbz + bz;
+    const int base = fb.off[bin], n = fb.off[bin + 1] - base;
+    if (n == 0) return;
+    const int t0[3] = {bx * BIN, by * BIN, bz * BIN};
+    // region loads: element e = (component, qx, qy, qz) flattened; LDS address = e
     const bool windowed = G.nxl < G.Nx;
-    const int xs = G.x0 - G.hl, nwin = windowed ? G.nxl + G.hl + G.nhalo - (P - 1) : G.Nx;
-    const int t0[3] = {xs + tx_ * GT, ty_ * GT, tz_ * GT};
-    const int ext[3] = {min(GT, xs + nwin - t0[0]), min(GT, G.Ny - t0[1]), min(GT, G.Nz - t0[2])};
-    const int Nn[3] = {G.Nx, G.Ny, G.Nz};
-    // region loads first (into registers): they stay in flight while the particle list is built
-    double rv[E];
-    {
-        const size_t plane = (size_t)G.Ny * G.Nz;
-        const int nplanes = min(E, ext[0] + P - 1);
-        const int qy = tid / E, qz = tid - qy * E;        // this thread's (y,z) column of the region (tid < E^2)
+    const int xs = G.x0 - G.hl, nstored = G.nxl + G.hl + G.nhalo;
+    const size_t plane = (size_t)G.Ny * G.Nz;
+    double rv[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int e = tid + q * NT;
+        const int c = e / E3, r = e - c * E3, qx = r / E2, r2 = r - qx * E2, qy = r2 / E, qz = r2 - qy * E;
+        int ix = t0[0] + qx; if (ix >= G.Nx) ix -= G.Nx;
         int iy = t0[1] + qy; if (iy >= G.Ny) iy -= G.Ny;
         int iz = t0[2] + qz; if (iz >= G.Nz) iz -= G.Nz;
-        const size_t col = (size_t)iy * G.Nz + iz;
+        bool ok = e < 3 * E3;
+        if (windowed) { ix = wrapi(ix - xs, G.Nx); ok = ok && ix < nstored; }   // stored plane index; planes of other slabs read as 0
+        const double *g = c == 0 ? gx : (c == 1 ? gy : gz);
+        rv[q] = ok ? g[(size_t)ix * plane + (size_t)iy * G.Nz + iz] : 0.0;
+    }
+    const int grp = tid >> 2, tl = tid & 3;
+    const bool two = 2 * tl + 1 < P;                        // this lane's z offsets: 2 tl and (if inside the support) 2 tl + 1
+    const double cw = G.hx * G.hy * G.hz;                  // PSEv1/Brownian.cu:872 (prefac is folded in below)
+    for (int h0 = 0; h0 < n; h0 += NT / 4) {
+        const int h = h0 + grp;
+        const bool act = h < n && 2 * tl < P;
+        int4 sp = make_int4(0, 0, 0, 0);
+        double a[P * P], bw0 = 0.0, bw1 = 0.0;
+        if (act) {
+            const size_t slot = (size_t)(base + h);
+            sp = sup_t[slot];
+            const double *w = wtab_t + slot * WT;
 #pragma unroll
-        for (int qx = 0; qx < E; ++qx) {
-            int lx = t0[0] - xs + qx;                     // stored plane index
-            if (!windowed && lx >= G.Nx) lx -= G.Nx;
-            rv[qx] = (tid < E2 && qx < nplanes) ? g[(size_t)lx * plane + col] : 0.0;
+            for (int e = 0; e < P * P; ++e) a[e] = w[e];
+            bw0 = w[P * P + 2 * tl];
+            bw1 = two ? w[P * P + 2 * tl + 1] : 0.0;
+        }
+        if (h0 == 0) {                                      // park the region (loads issued above) in LDS
+#pragma unroll
+            for (int q = 0; q < NLD; ++q) { const int e = tid + q * NT; if (e < 3 * E3) reg[e] = rv[q]; }
+            __syncthreads();
+        }
+        double ux = 0.0, uy = 0.0, uz = 0.0;
+        if (act) {
+            const double *r0 = reg + (sp.x - t0[0]) * E2 + (sp.y - t0[1]) * E + (sp.z - t0[2]) + 2 * tl;
+            const int o1 = two ? 1 : 0;
+#pragma unroll
+            for (int tx = 0; tx < P; ++tx)
+#pragma unroll
+                for (int ty = 0; ty < P; ++ty) {
+                    const double *r = r0 + tx * E2 + ty * E;
+                    const double w = a[tx * P + ty];
+                    ux += w * (bw0 * r[0] + bw1 * r[o1]);
+                    uy += w * (bw0 * r[E3] + bw1 * r[E3 + o1]);
+                    uz += w * (bw0 * r[2 * E3] + bw1 * r[2 * E3 + o1]);
+                }
+        }
+#pragma unroll
+        for (int o = 1; o < 4; o <<= 1) {
+            ux += __shfl_xor(ux, o, 64); uy += __shfl_xor(uy, o, 64); uz += __shfl_xor(uz, o, 64);
+        }
+        if (h < n && tl == 0 && sp.w >= 0) {                // bit 31 of w: owned by another slab rank
+            const double s = G.prefac * cw;
+            u_s[sp.w] = make_double4(s * ux, s * uy, s * uz, 0.0);
         }
     }
-    // origin = floor(s) - P/2 + 1 - adj, adj in {0,1}: origins in [t0, t0+ext) need floor(s) in [t0 + P/2 - 1, t0 + ext - 1 + P/2]
-    int clo[3], ccnt[3];
-    cell_range(t0[0] + P / 2 - 1, t0[0] + ext[0] - 1 + P / 2, nc.nx, G.Nx, clo[0], ccnt[0]);
-    cell_range(t0[1] + P / 2 - 1, t0[1] + ext[1] - 1 + P / 2, nc.ny, G.Ny, clo[1], ccnt[1]);
-    cell_range(t0[2] + P / 2 - 1, t0[2] + ext[2] - 1 + P / 2, nc.nz, G.Nz, clo[2], ccnt[2]);
-    auto origin = [&](const int4 &sp, int rel[3]) {
-        const int o[3] = {sp.x, sp.y, sp.z};
-        bool own = true;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            int r = o[a] - t0[a];
-            if (r < -Nn[a] / 2) r += Nn[a]; else if (r >= Nn[a] - Nn[a] / 2) r -= Nn[a];
-            rel[a] = r;
-            own = own && r >= 0 && r < ext[a];
-        }
-        if (windowed) {   // the rank whose slab holds the particle itself gathers it
-            int d = sp.w - G.x0; d %= G.Nx; if (d < 0) d += G.Nx;
-            own = own && d < G.nxl;
-        }
-        return own;
-    };
-    const int grp = tid >> 3, tz = tid & 7;
-    const double cw = G.prefac * G.hx * G.hy * G.hz;   // PSEv1/Brownian.cu:872
-    bool stored = false;
-    for_tile_particles(tl, cell_off, nc, clo, ccnt,
-        [&](int p) { int rel[3]; return origin(sup_s[p], rel); },
-        [&]() {
-            if (!stored) {                                // first chunk: park the region in LDS (uniform branch)
-                if (tid < E2) {
-#pragma unroll
-                    for (int qx = 0; qx < E; ++qx) reg[qx * E2 + tid] = rv[qx];
-                }
-                stored = true;
-                __syncthreads();
-            }
-            const int n = (dbg & 1) ? 0 : tl.n;
-            for (int h0 = 0; h0 < n; h0 += NT / 8) {      // uniform trip count: the reduction uses every lane
-                const int h = h0 + grp;
-                double u = 0;
-                int p = 0;
-                if (h < n) {
-                    p = tl.list[h];
-                    const int4 sp = sup_s[p];
-                    const double *w = wtab + (size_t)p * WT;
-                    double a[P * P];
-#pragma unroll
-                    for (int e = 0; e < P * P; ++e) a[e] = w[e];
-                    const double bw = w[P * P + (tz < P ? tz : 0)];
-                    if (tz < P) {
-                        int rel[3];
-                        origin(sp, rel);
-                        const double *r0 = reg + rel[0] * E2 + rel[1] * E + rel[2] + tz;
-#pragma unroll
-                        for (int tx = 0; tx < P; ++tx)
-#pragma unroll
-                            for (int ty = 0; ty < P; ++ty) u += a[tx * P + ty] * ((dbg & 2) ? 1.5 : r0[tx * E2 + ty * E]);
-                        u *= bw;
-                    }
-                }
-#pragma unroll
-                for (int o = 1; o < 8; o <<= 1) u += __shfl_xor(u, o, 64);
-                if (h < n && tz == 0) ((double *)&u_s[p])[comp] = cw * u;
-            }
-        });
 }
 
 // generic support size: one exponential per node
@@ -959,22 +979,29 @@ k_gather(const double4 *__restrict__ pos_s, int N, const double *__restrict__ gx
     }
 }
 
-void launch_gather(const double4 *pos_s, const int4 *sup_s, const double *wtab, const int *cell_off, DCells nc, int N,
-                   const double *gx, const double *gy, const double *gz, DGrid G, DBox box, double4 *u_s, hipStream_t s) {
-    if (!farfield_fast_path(G) || !wtab) {
+void launch_gather(const double4 *pos_s, SpreadWork w, int N, const double *gx, const double *gy, const double *gz, DGrid G,
+                   DBox box, double4 *u_s, hipStream_t s) {
+    if (!farfield_fast_path(G) || !w.wtab_t) {
         hipLaunchKernelGGL(k_gather, dim3(nblocks(N, TPB / 64)), dim3(TPB), 0, s, pos_s, N, gx, gy, gz, G, box, u_s);
         return;
     }
-    (void)hipMemsetAsync(u_s, 0, (size_t)N * sizeof(double4), s);   // .w, and particles of other slabs, stay zero
-    const int nwin = G.nxl < G.Nx ? G.nxl + G.hl + G.nhalo - (G.P - 1) : G.Nx;   // support origins this rank can own
-    const int ntx = (nwin + GT - 1) / GT, nty = (G.Ny + GT - 1) / GT, ntz = (G.Nz + GT - 1) / GT;
-    const dim3 g(ntx * nty * ntz, 3), b(RMAX);   // one workgroup per (tile, velocity component)
+    FarBins fb = w.fb;
+    fb.nbx = bins_of(G.Nx); fb.nby = bins_of(G.Ny); fb.nbz = bins_of(G.Nz);
+    int bx0 = 0, nbx_l = fb.nbx;
+    if (G.nxl < G.Nx) {
+        // a slab rank gathers the particles of its own planes (zeros elsewhere): their origins lie in [x0 - hl - 1, x0 + nxl)
+        (void)hipMemsetAsync(u_s, 0, (size_t)N * sizeof(double4), s);
+        const int olo = ((G.x0 - G.hl - 1) % G.Nx + G.Nx) % G.Nx, ohi = (G.x0 + G.nxl - 1) % G.Nx;
+        bx0 = olo / BIN;
+        nbx_l = std::min(fb.nbx, ((ohi / BIN - bx0) % fb.nbx + fb.nbx) % fb.nbx + 1);
+    }
+    const dim3 g(nbx_l * fb.nby * fb.nbz), b(256);
     switch (G.P) {
-        case 4: hipLaunchKernelGGL(k_gather_tile<4>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz, dbg_mode()); break;
-        case 5: hipLaunchKernelGGL(k_gather_tile<5>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz, dbg_mode()); break;
-        case 6: hipLaunchKernelGGL(k_gather_tile<6>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz, dbg_mode()); break;
-        case 7: hipLaunchKernelGGL(k_gather_tile<7>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz, dbg_mode()); break;
-        default: hipLaunchKernelGGL(k_gather_tile<8>, g, b, 0, s, sup_s, wtab, cell_off, nc, gx, gy, gz, G, u_s, ntx, nty, ntz, dbg_mode()); break;
+        case 4: hipLaunchKernelGGL(k_gather_bins<4>, g, b, 0, s, w.sup_t, w.wtab_t, fb, bx0, nbx_l, gx, gy, gz, G, u_s); break;
+        case 5: hipLaunchKernelGGL(k_gather_bins<5>, g, b, 0, s, w.sup_t, w.wtab_t, fb, bx0, nbx_l, gx, gy, gz, G, u_s); break;
+        case 6: hipLaunchKernelGGL(k_gather_bins<6>, g, b, 0, s, w.sup_t, w.wtab_t, fb, bx0, nbx_l, gx, gy, gz, G, u_s); break;
+        case 7: hipLaunchKernelGGL(k_gather_bins<7>, g, b, 0, s, w.sup_t, w.wtab_t, fb, bx0, nbx_l, gx, gy, gz, G, u_s); break;
+        default: hipLaunchKernelGGL(k_gather_bins<8>, g, b, 0, s, w.sup_t, w.wtab_t, fb, bx0, nbx_l, gx, gy, gz, G, u_s); break;
     }
 }
 
@@ -1324,13 +1351,20 @@ k_lz_dots(const double4 *__restrict__ x, const double4 *__restrict__ y, const do
     if (threadIdx.x == 0) { partials[blockIdx.x] = a; partials[cap + blockIdx.x] = b; partials[2 * cap + blockIdx.x] = c; }
 }
 // this rank's partial sums -> scal[LZ_TMP .. LZ_TMP + nsum) (then all-reduced over the ranks)
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(1024)
 k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, double *__restrict__ scal) {
-    __shared__ double sh[4];
-    for (int q = 0; q < nsum; ++q) {
-        const double v = reduce_partials(partials + (size_t)q * cap, npart, sh);
-        if (threadIdx.x == 0) scal[LZ_TMP + q] = v;
-        __syncthreads();
+    __shared__ double sh[16];
+    const int q = blockIdx.x;                         // one workgroup per sum, fixed summation order
+    const double *p = partials + (size_t)q * cap;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < npart; i += 1024) v += p[i];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += sh[w];
+        scal[LZ_TMP + q] = t;
     }
 }
 // alpha_j, beta_j from the reduced sums; v_j = x_j / beta_j (in place or from psi); x_{j+1} on the own rows
@@ -1358,7 +1392,7 @@ void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, in
                     double *scal, hipStream_t s) {
     const int g = vec_grid(std::max(1, hi - lo));
     hipLaunchKernelGGL(k_lz_dots, dim3(g), dim3(TPB), 0, s, x, y, vprev, lo, hi, partials, cap);
-    hipLaunchKernelGGL(k_lz_reduce, dim3(1), dim3(TPB), 0, s, partials, g, cap, y ? 3 : 1, scal);
+    hipLaunchKernelGGL(k_lz_reduce, dim3(y ? 3 : 1), dim3(1024), 0, s, partials, g, cap, y ? 3 : 1, scal);
 }
 void launch_lz_update(const double4 *xin, const double4 *y, const double4 *vprev, double4 *vout, double4 *xnext, int j,
                       double *scal, int lo, int hi, hipStream_t s) {

@@ -858,7 +858,7 @@ __global__ void __launch_bounds__(256)
 k_gather_bins(const int4 *__restrict__ sup_t, const double *__restrict__ wtab_t, FarBins fb, int bx0, int nbx_l,
               const double *__restrict__ gx, const double *__restrict__ gy, const double *__restrict__ gz, DGrid G,
               double4 *__restrict__ u_s) {
-    constexpr int NT = 256, E = BIN + P - 1, E2 = E * E, E3 = E2 * E, WT = P * P + P, NLD = (3 * E3 + NT - 1) / NT;
+    constexpr int NT = 256, E = BIN + P - 1, E2 = E * E, E3 = E2 * E, WT = P * P + P;
     __shared__ double reg[3 * E3];
     const int tid = threadIdx.x;
     int b = xcd_block(blockIdx.x, gridDim.x);
@@ -869,22 +869,27 @@ k_gather_bins(const int4 *__restrict__ sup_t, const double *__restrict__ wtab_t,
     const int base = fb.off[bin], n = fb.off[bin + 1] - base;
     if (n == 0) return;
     const int t0[3] = {bx * BIN, by * BIN, bz * BIN};
-    // region loads: element e = (component, qx, qy, qz) flattened; LDS address = e
+    // region loads: a thread keeps one (y,z) column and walks component x plane -- the plane index is uniform, so a load
+    // costs an add and the loads are all in flight together (the kernel is VALU-bound: 78 % busy in rocprofv3)
     const bool windowed = G.nxl < G.Nx;
     const int xs = G.x0 - G.hl, nstored = G.nxl + G.hl + G.nhalo;
     const size_t plane = (size_t)G.Ny * G.Nz;
-    double rv[NLD];
-#pragma unroll
-    for (int q = 0; q < NLD; ++q) {
-        const int e = tid + q * NT;
-        const int c = e / E3, r = e - c * E3, qx = r / E2, r2 = r - qx * E2, qy = r2 / E, qz = r2 - qy * E;
-        int ix = t0[0] + qx; if (ix >= G.Nx) ix -= G.Nx;
+    double rv[3 * E];
+    {
+        const int qy = tid / E, qz = tid - qy * E;            // this thread's column of the region (tid < E^2)
         int iy = t0[1] + qy; if (iy >= G.Ny) iy -= G.Ny;
         int iz = t0[2] + qz; if (iz >= G.Nz) iz -= G.Nz;
-        bool ok = e < 3 * E3;
-        if (windowed) { ix = wrapi(ix - xs, G.Nx); ok = ok && ix < nstored; }   // stored plane index; planes of other slabs read as 0
-        const double *g = c == 0 ? gx : (c == 1 ? gy : gz);
-        rv[q] = ok ? g[(size_t)ix * plane + (size_t)iy * G.Nz + iz] : 0.0;
+        const size_t col = (size_t)iy * G.Nz + iz;
+#pragma unroll
+        for (int qx = 0; qx < E; ++qx) {
+            int ix = t0[0] + qx; if (ix >= G.Nx) ix -= G.Nx;
+            bool ok = tid < E2;
+            if (windowed) { ix = wrapi(ix - xs, G.Nx); ok = ok && ix < nstored; }   // stored plane index; other slabs' planes read as 0
+            const size_t o = (size_t)ix * plane + col;
+            rv[qx] = ok ? gx[o] : 0.0;
+            rv[E + qx] = ok ? gy[o] : 0.0;
+            rv[2 * E + qx] = ok ? gz[o] : 0.0;
+        }
     }
     const int grp = tid >> 2, tl = tid & 3;
     const bool two = 2 * tl + 1 < P;                        // this lane's z offsets: 2 tl and (if inside the support) 2 tl + 1
@@ -904,24 +909,28 @@ k_gather_bins(const int4 *__restrict__ sup_t, const double *__restrict__ wtab_t,
             bw1 = two ? w[P * P + 2 * tl + 1] : 0.0;
         }
         if (h0 == 0) {                                      // park the region (loads issued above) in LDS
+            if (tid < E2) {
 #pragma unroll
-            for (int q = 0; q < NLD; ++q) { const int e = tid + q * NT; if (e < 3 * E3) reg[e] = rv[q]; }
+                for (int q = 0; q < 3 * E; ++q) reg[q * E2 + tid] = rv[q];
+            }
             __syncthreads();
         }
         double ux = 0.0, uy = 0.0, uz = 0.0;
         if (act) {
             const double *r0 = reg + (sp.x - t0[0]) * E2 + (sp.y - t0[1]) * E + (sp.z - t0[2]) + 2 * tl;
             const int o1 = two ? 1 : 0;
+            double x0 = 0.0, x1 = 0.0, y0 = 0.0, y1 = 0.0, z0 = 0.0, z1 = 0.0;   // per z offset: the B weight multiplies once
 #pragma unroll
             for (int tx = 0; tx < P; ++tx)
 #pragma unroll
                 for (int ty = 0; ty < P; ++ty) {
                     const double *r = r0 + tx * E2 + ty * E;
                     const double w = a[tx * P + ty];
-                    ux += w * (bw0 * r[0] + bw1 * r[o1]);
-                    uy += w * (bw0 * r[E3] + bw1 * r[E3 + o1]);
-                    uz += w * (bw0 * r[2 * E3] + bw1 * r[2 * E3 + o1]);
+                    x0 += w * r[0]; x1 += w * r[o1];
+                    y0 += w * r[E3]; y1 += w * r[E3 + o1];
+                    z0 += w * r[2 * E3]; z1 += w * r[2 * E3 + o1];
                 }
+            ux = bw0 * x0 + bw1 * x1; uy = bw0 * y0 + bw1 * y1; uz = bw0 * z0 + bw1 * z1;
         }
 #pragma unroll
         for (int o = 1; o < 4; o <<= 1) {
@@ -1205,7 +1214,7 @@ __device__ __forceinline__ void lds_fft_x(double2 *__restrict__ d, const double2
 }
 
 template <int LOGN, int KB, int NTH>
-__global__ void __launch_bounds__(NTH)
+__global__ void __launch_bounds__(NTH, (NTH == 256 ? 3 : 1))   // 256 threads: <= 168 VGPRs so that three workgroups share a CU
 k_xfft_scale(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ Z, DGrid G, DBox box, ScaleArgs a,
              const double2 *__restrict__ twiddle) {
     constexpr int N = 1 << LOGN, CS = N + 1;

@@ -65,7 +65,7 @@ class ShardedSimulation:
     def describe(self):
         return (f"{self.world} GPUs: far-field grid in {self.world} x-slabs (RCCL all-to-all transpose, two-sided plane halo for "
                 f"the gather), near field / Lanczos vectors / gather owned by the rank whose cell slab holds the particle "
-                f"(neighbour ghost-layer exchange + 2-scalar all-reduce per iteration), one velocity all-gather per step; "
+                f"(neighbour ghost-layer exchange + 3-scalar all-reduce per iteration), one velocity all-gather per step; "
                 f"particle arrays replicated")
 
     def load(self, pos, force, mass=1.0):

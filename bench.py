@@ -150,12 +150,13 @@ def main():
     weight = dict(per_launch_ms)
     weight["t_matvec"] = per_launch_ms["t_matvec"] * max(1, info["lanczos_matvecs"])
     dom = max(weight, key=weight.get)
-    names = {"t_spread": "k_spread_tile (spread)", "t_fft_fwd": "rocFFT R2C x3", "t_scale": "k_scale (k-space scale+noise)",
-             "t_fft_inv": "rocFFT C2R x3", "t_gather": "k_gather_p (gather)",
+    names = {"t_spread": "k_spread_bins (spread, incl. binning + weights)", "t_fft_fwd": "rocFFT 2-D R2C x3",
+             "t_scale": "k_xfft_scale (x FFT + k-space scale/noise + inverse x FFT)",
+             "t_fft_inv": "rocFFT 2-D C2R x3", "t_gather": "k_gather_bins (gather)",
              "t_real": "k_mreal_cells (near-field M_real.F from the cell list, writes the pair list)",
              "t_matvec": "k_mreal_list (near-field mat-vec from the pair list, once per Lanczos iteration)"}
-    pmc_names = {"t_spread": "pse::k_spread_tile", "t_scale": "pse::k_scale", "t_gather": "pse::k_gather_p",
-                 "t_real": "pse::k_mreal_cells<true>", "t_matvec": "pse::k_mreal_list"}
+    pmc_names = {"t_spread": "pse::k_spread_bins", "t_scale": "pse::k_xfft_scale", "t_gather": "pse::k_gather_bins",
+                 "t_real": "pse::k_mreal_cells<true", "t_matvec": "pse::k_mreal_list"}
     ach = alg[dom] / (per_launch_ms[dom] * 1e-3) / 1e9 if per_launch_ms[dom] > 0 else 0.0
     traffic = None
     tr_file = os.path.join(ROOT, "profiles", "traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/summarize_prof.py

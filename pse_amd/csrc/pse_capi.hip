@@ -69,6 +69,7 @@ struct pse_handle {
     // sorted particle state
     unsigned *keys = nullptr, *keys_s = nullptr, *vals = nullptr, *perm = nullptr, *tag_s = nullptr;
     void *sort_tmp = nullptr;
+    int *cell_cnt = nullptr;
     size_t sort_tmp_bytes = 0;
     int *cell_off = nullptr;
     int4 *sup_s = nullptr;    // support origin of each sorted particle (node indices)
@@ -210,7 +211,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->plan_x_inv) rocfft_plan_destroy(h->plan_x_inv);
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
-    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->sup_s, h->sw.wtab_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->sw.sup_t, h->sw.f_t, h->nb.data, h->nb.cnt, h->nb.ovf_rows, h->nb.ovf_n, h->nb.ovf_out, h->pos_s,
+    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cell_cnt, h->sup_s, h->sw.wtab_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->sw.sup_t, h->sw.f_t, h->nb.data, h->nb.cnt, h->nb.ovf_rows, h->nb.ovf_n, h->nb.ovf_out, h->pos_s,
                     h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->twiddle, h->fft_work, h->V,
                     h->scal, h->partials, h->t_dev};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -330,15 +331,16 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     h->n_pad = (int)n;
     TRY(dmalloc(h, &h->keys, n)); TRY(dmalloc(h, &h->keys_s, n)); TRY(dmalloc(h, &h->vals, n));
     TRY(dmalloc(h, &h->perm, n)); TRY(dmalloc(h, &h->tag_s, n));
-    h->sort_tmp_bytes = sort_pairs_temp_bytes((int)n, 32);
-    TRY(dmalloc(h, (char **)&h->sort_tmp, h->sort_tmp_bytes));
+
     // size the cell arrays for zero tilt (most cells)
     {
         const double rc = d.rcut;
         auto cnt = [&](double w) { int c2 = (int)std::floor(w / rc); if (c2 < 3) c2 = 1; if (c2 > 1024) c2 = 1024; return (size_t)c2; };
         h->n_cells_alloc = cnt(h->box.Lx) * cnt(h->box.Ly) * cnt(h->box.Lz);
     }
-    TRY(dmalloc(h, &h->cell_off, h->n_cells_alloc + 1));
+    TRY(dmalloc(h, &h->cell_off, h->n_cells_alloc + 1)); TRY(dmalloc(h, &h->cell_cnt, h->n_cells_alloc + 1));
+    h->sort_tmp_bytes = cell_sort_temp_bytes(h->n_cells_alloc);
+    TRY(dmalloc(h, (char **)&h->sort_tmp, h->sort_tmp_bytes));
     TRY(dmalloc(h, &h->sup_s, n));
     if (d.P >= 4 && d.P <= 8) {   // fast far-field path: support offsets + separable weights (padded: idle lanes read past the end)
         TRY(dmalloc(h, &h->sw.d0_s, n));
@@ -662,13 +664,10 @@ static int slab_bounds(pse_handle *h, int N) {
 // particles: the state is replicated, the work of the later phases is what is sharded)
 static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const unsigned *group, int N) {
     TRY(ts(h, PH_SORT));
-    const size_t ncell = (size_t)h->nc.nx * h->nc.ny * h->nc.nz;
-    int bits = 1;
-    while (((size_t)1 << bits) < ncell) ++bits;
-    launch_cell_keys(pos, group, N, h->dbox, h->nc, h->keys, h->vals, h->stream);
-    sort_pairs(h->sort_tmp, h->sort_tmp_bytes, h->keys, h->keys_s, h->vals, h->perm, N, bits, h->stream);
-    launch_permute(pos, vec, group, h->perm, h->keys_s, N, h->dbox, h->pos_s, h->f_s, h->tag_s, (int)ncell,
-                   h->cell_off, h->stream);
+    const int ncell = h->nc.nx * h->nc.ny * h->nc.nz;
+    cell_sort(pos, group, N, h->dbox, h->nc, h->keys, h->vals, h->keys_s, h->cell_cnt, ncell, h->sort_tmp, h->sort_tmp_bytes,
+              h->cell_off, h->perm, h->stream);
+    launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->f_s, h->tag_s, h->stream);
     h->sorted_N = N;
     h->nb_valid = false;
     TRY(slab_bounds(h, N));

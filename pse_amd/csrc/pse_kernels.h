@@ -8,15 +8,14 @@
 namespace pse {
 
 // ---- particle binning ------------------------------------------------------------------------------------
-void launch_cell_keys(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys,
-                      unsigned *vals, hipStream_t s);
-size_t sort_pairs_temp_bytes(int N, int end_bit);
-void sort_pairs(void *temp, size_t temp_bytes, const unsigned *keys_in, unsigned *keys_out, const unsigned *vals_in,
-                unsigned *vals_out, int N, int end_bit, hipStream_t s);
-// pos_s[i] = wrapped position of particle perm[i] (w = tag as double), vec_s[i] = vec[tag].xyz; cell bounds
-void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm,
-                    const unsigned *keys_sorted, int N, DBox box, double4 *pos_s, double4 *vec_s, unsigned *tag_s,
-                    int ncell, int *cell_off, hipStream_t s);
+// counting sort by cell, equal to a stable sort by key: perm[slot] = input index, cell_off[c] = first slot of cell c.
+// keys, rank, slots: N unsigned each; cnt: ncell + 1 ints; tmp: cell_sort_temp_bytes(ncell)
+size_t cell_sort_temp_bytes(size_t ncell);
+void cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys, unsigned *rank,
+               unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s);
+// pos_s[i] = wrapped position of particle perm[i], vec_s[i] = vec[tag].xyz, tag_s[i] = its index in the caller's arrays
+void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm, int N, DBox box,
+                    double4 *pos_s, double4 *vec_s, unsigned *tag_s, hipStream_t s);
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s);
 
 // ---- near field (K9) -------------------------------------------------------------------------------------

@@ -40,8 +40,12 @@ __device__ __forceinline__ double reduce_partials(const double *partials, int n,
 
 // ------------------------------------------------------------------------------------------------ binning
 // (replaces HOOMD CellListGPU used through NeighborListGPUBinned, PSEv1/integrate.py:58-83)
+// Counting sort by cell (rocprim's sort_pairs runs ten merge passes at N = 1e6: 0.15 ms).  Arrival ranks from atomics are
+// not reproducible, and every slab rank must end up with the SAME order (rows are exchanged by position), so a last
+// pass orders each cell by original index: the result equals a stable sort by key.  cell_off[c] = first slot of cell c
+// (c = 0..ncell): cell c owns [cell_off[c], cell_off[c+1]) and any run of consecutive cells is one contiguous slot range.
 __global__ void k_cell_keys(const double4 *__restrict__ pos, const unsigned *__restrict__ group, int N, DBox box,
-                            DCells nc, unsigned *__restrict__ keys, unsigned *__restrict__ vals) {
+                            DCells nc, unsigned *__restrict__ keys, unsigned *__restrict__ rank, int *__restrict__ cnt) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
     const unsigned idx = group ? group[g] : (unsigned)g;
@@ -49,13 +53,50 @@ __global__ void k_cell_keys(const double4 *__restrict__ pos, const unsigned *__r
     double fx, fy, fz;
     frac_coords(box, p.x, p.y, p.z, fx, fy, fz);
     const int cx = cell_coord(fx, nc.nx), cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz);
-    keys[g] = (unsigned)((cx * nc.ny + cy) * nc.nz + cz);
-    vals[g] = (unsigned)g;
+    const unsigned key = (unsigned)((cx * nc.ny + cy) * nc.nz + cz);
+    keys[g] = key;
+    rank[g] = (unsigned)atomicAdd(&cnt[key], 1);
+}
+__global__ void k_cell_scatter(const unsigned *__restrict__ keys, const unsigned *__restrict__ rank,
+                               const int *__restrict__ cell_off, int N, unsigned *__restrict__ slots) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < N) slots[cell_off[keys[g]] + rank[g]] = (unsigned)g;
+}
+// one wave per cell: rank every member among the members of its cell (all-pairs through shuffles), write it in order
+__global__ void __launch_bounds__(TPB)
+k_cell_order(const int *__restrict__ cell_off, int ncell, const unsigned *__restrict__ slots, unsigned *__restrict__ perm) {
+    const int c = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= ncell) return;
+    const int a = cell_off[c], n = cell_off[c + 1] - a;
+    for (int e0 = 0; e0 < n; e0 += 64) {
+        const bool mine = e0 + lane < n;
+        const unsigned v = mine ? slots[a + e0 + lane] : 0xFFFFFFFFu;
+        int smaller = 0;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const unsigned cu = c0 + lane < n ? slots[a + c0 + lane] : 0xFFFFFFFFu;
+            const int m = min(64, n - c0);
+            for (int t = 0; t < m; ++t) smaller += __shfl(cu, t, 64) < v ? 1 : 0;
+        }
+        if (mine) perm[a + smaller] = v;
+    }
+}
+size_t cell_sort_temp_bytes(size_t ncell) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int *)nullptr, (int *)nullptr, (int)(ncell + 1));
+    return bytes;
+}
+void cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys, unsigned *rank,
+               unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s) {
+    (void)hipMemsetAsync(cnt, 0, (size_t)(ncell + 1) * sizeof(int), s);
+    hipLaunchKernelGGL(k_cell_keys, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, group, N, box, nc, keys, rank, cnt);
+    (void)hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt, cell_off, ncell + 1, s);   // cnt[ncell] = 0: cell_off[ncell] = N
+    hipLaunchKernelGGL(k_cell_scatter, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, keys, rank, cell_off, N, slots);
+    hipLaunchKernelGGL(k_cell_order, dim3(nblocks(ncell, TPB / 64)), dim3(TPB), 0, s, cell_off, ncell, slots, perm);
 }
 
 __global__ void k_permute(const double4 *__restrict__ pos, const double4 *__restrict__ vec,
-                          const unsigned *__restrict__ group, const unsigned *__restrict__ perm,
-                          const unsigned *__restrict__ keys_sorted, int N, DBox box, double4 *__restrict__ pos_s,
+                          const unsigned *__restrict__ group, const unsigned *__restrict__ perm, int N, DBox box,
+                          double4 *__restrict__ pos_s,
                           double4 *__restrict__ vec_s, unsigned *__restrict__ tag_s) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N) return;
@@ -80,19 +121,6 @@ __global__ void k_permute(const double4 *__restrict__ pos, const double4 *__rest
     }
 }
 
-// cell_off[c] = first sorted slot whose key >= c (c = 0..ncell): cell c owns [cell_off[c], cell_off[c+1]), and any run of
-// consecutive cells is one contiguous slot range
-__global__ void k_cell_offsets(const unsigned *__restrict__ keys_sorted, int N, int ncell, int *__restrict__ cell_off) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > ncell) return;
-    int lo = 0, hi = N;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (keys_sorted[mid] < (unsigned)c) lo = mid + 1; else hi = mid;
-    }
-    cell_off[c] = lo;
-}
-
 __global__ void k_permute_vec(const double4 *__restrict__ vec, const unsigned *__restrict__ tag_s, int N,
                               double4 *__restrict__ vec_s) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -102,26 +130,9 @@ __global__ void k_permute_vec(const double4 *__restrict__ vec, const unsigned *_
     vec_s[s] = v;
 }
 
-void launch_cell_keys(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys,
-                      unsigned *vals, hipStream_t s) {
-    hipLaunchKernelGGL(k_cell_keys, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, group, N, box, nc, keys, vals);
-}
-size_t sort_pairs_temp_bytes(int N, int end_bit) {
-    size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned *)nullptr, (unsigned *)nullptr,
-                                       (const unsigned *)nullptr, (unsigned *)nullptr, N, 0, end_bit, nullptr);
-    return bytes;
-}
-void sort_pairs(void *temp, size_t temp_bytes, const unsigned *keys_in, unsigned *keys_out, const unsigned *vals_in,
-                unsigned *vals_out, int N, int end_bit, hipStream_t s) {
-    (void)hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, N, 0, end_bit, s);
-}
-void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm,
-                    const unsigned *keys_sorted, int N, DBox box, double4 *pos_s, double4 *vec_s, unsigned *tag_s,
-                    int ncell, int *cell_off, hipStream_t s) {
-    hipLaunchKernelGGL(k_permute, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, vec, group, perm, keys_sorted, N, box,
-                       pos_s, vec_s, tag_s);
-    hipLaunchKernelGGL(k_cell_offsets, dim3(nblocks(ncell + 1, TPB)), dim3(TPB), 0, s, keys_sorted, N, ncell, cell_off);
+void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm, int N, DBox box,
+                    double4 *pos_s, double4 *vec_s, unsigned *tag_s, hipStream_t s) {
+    hipLaunchKernelGGL(k_permute, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, vec, group, perm, N, box, pos_s, vec_s, tag_s);
 }
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s) {
     hipLaunchKernelGGL(k_permute_vec, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, vec, tag_s, N, vec_s);

@@ -77,6 +77,7 @@ struct pse_handle {
     NbList nb = {};
     bool nb_valid = false;   // the pair list matches the current sorted positions
     size_t n_cells_alloc = 0;
+    float4 *posf_s = nullptr;   // single-precision copy of pos_s (cutoff pre-filter of the near field)
     double4 *pos_s = nullptr, *f_s = nullptr, *uw_s = nullptr, *ur_s = nullptr, *ub_s = nullptr, *psi_s = nullptr, *w_s = nullptr;
     // real-space table
     double *coef = nullptr;
@@ -211,7 +212,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->plan_x_inv) rocfft_plan_destroy(h->plan_x_inv);
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
-    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cell_cnt, h->sup_s, h->sw.wtab_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->sw.sup_t, h->sw.f_t, h->nb.data, h->nb.cnt, h->nb.ovf_rows, h->nb.ovf_n, h->nb.ovf_out, h->pos_s,
+    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cell_cnt, h->sup_s, h->sw.wtab_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->sw.sup_t, h->sw.f_t, h->nb.data, h->nb.cnt, h->nb.ovf_rows, h->nb.ovf_n, h->nb.ovf_out, h->pos_s, h->posf_s,
                     h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->twiddle, h->fft_work, h->V,
                     h->scal, h->partials, h->t_dev};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -366,7 +367,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         }
         TRY(dmalloc(h, &h->nb.cnt, n));
     }
-    TRY(dmalloc(h, &h->pos_s, n)); TRY(dmalloc(h, &h->f_s, n)); TRY(dmalloc(h, &h->uw_s, n)); TRY(dmalloc(h, &h->ur_s, n));
+    TRY(dmalloc(h, &h->pos_s, n)); TRY(dmalloc(h, &h->posf_s, n)); TRY(dmalloc(h, &h->f_s, n)); TRY(dmalloc(h, &h->uw_s, n)); TRY(dmalloc(h, &h->ur_s, n));
     TRY(dmalloc(h, &h->ub_s, n)); TRY(dmalloc(h, &h->psi_s, n)); TRY(dmalloc(h, &h->w_s, n));
 
     std::vector<double> coef;
@@ -667,7 +668,7 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
     const int ncell = h->nc.nx * h->nc.ny * h->nc.nz;
     cell_sort(pos, group, N, h->dbox, h->nc, h->keys, h->vals, h->keys_s, h->cell_cnt, ncell, h->sort_tmp, h->sort_tmp_bytes,
               h->cell_off, h->perm, h->stream);
-    launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->f_s, h->tag_s, h->stream);
+    launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->f_s, h->tag_s, h->stream);
     h->sorted_N = N;
     h->nb_valid = false;
     TRY(slab_bounds(h, N));
@@ -782,7 +783,7 @@ static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*ou
         }
         int lo, hi;
         row_range(h, N, lo, hi);
-        launch_mreal(h->pos_s, h->*vec + vec_off, h->*out + out_off, lo, hi, h->cell_off, h->dbox, h->nc, h->d.rcut,
+        launch_mreal(h->pos_s, h->posf_s, h->*vec + vec_off, h->*out + out_off, lo, hi, h->cell_off, h->dbox, h->nc, h->d.rcut,
                      h->d.self, h->coef, h->n_intervals * 2 * RS_NCOEF, h->nb, mode, h->stream);
         if (mode == MREAL_BUILD_LIST) h->nb_valid = true;
     }

@@ -15,7 +15,7 @@ void cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCell
                unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s);
 // pos_s[i] = wrapped position of particle perm[i], vec_s[i] = vec[tag].xyz, tag_s[i] = its index in the caller's arrays
 void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm, int N, DBox box,
-                    double4 *pos_s, double4 *vec_s, unsigned *tag_s, hipStream_t s);
+                    double4 *pos_s, float4 *posf_s, double4 *vec_s, unsigned *tag_s, hipStream_t s);
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s);
 
 // ---- near field (K9) -------------------------------------------------------------------------------------
@@ -42,8 +42,9 @@ struct LzFuse {
 };
 // out = M_real . vec (+ self). mode: cells only / cells + write the pair list / use the pair list
 // rows [lo, hi) of the mat-vec (the whole vector is read; multi-GPU ranks each take a row range)
-void launch_mreal(const double4 *pos_s, const double4 *vec_s, double4 *out_s, int lo, int hi, const int *cell_off,
-                  DBox box, DCells nc, double rcut, double self, const double *coef, int ncoef, NbList nb, int mode, hipStream_t s);
+void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec_s, double4 *out_s, int lo, int hi,
+                  const int *cell_off, DBox box, DCells nc, double rcut, double self, const double *coef, int ncoef, NbList nb,
+                  int mode, hipStream_t s);
 // pair-list mat-vec + Lanczos sums; leaves the three reduced sums in scal[LZ_TMP .. LZ_TMP + 2]
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, int lo, int hi, const int *cell_off,
                           DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,

@@ -96,7 +96,7 @@ void cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCell
 
 __global__ void k_permute(const double4 *__restrict__ pos, const double4 *__restrict__ vec,
                           const unsigned *__restrict__ group, const unsigned *__restrict__ perm, int N, DBox box,
-                          double4 *__restrict__ pos_s,
+                          double4 *__restrict__ pos_s, float4 *__restrict__ posf_s,
                           double4 *__restrict__ vec_s, unsigned *__restrict__ tag_s) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N) return;
@@ -113,6 +113,7 @@ __global__ void k_permute(const double4 *__restrict__ pos, const double4 *__rest
     q.z = (fz - 0.5) * box.Lz;
     q.w = 0.0;
     pos_s[s] = q;
+    posf_s[s] = make_float4((float)q.x, (float)q.y, (float)q.z, 0.0f);   // single-precision copy for the cutoff pre-filter
     tag_s[s] = idx;
     if (vec) {
         double4 v = vec[idx];
@@ -131,8 +132,8 @@ __global__ void k_permute_vec(const double4 *__restrict__ vec, const unsigned *_
 }
 
 void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm, int N, DBox box,
-                    double4 *pos_s, double4 *vec_s, unsigned *tag_s, hipStream_t s) {
-    hipLaunchKernelGGL(k_permute, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, vec, group, perm, N, box, pos_s, vec_s, tag_s);
+                    double4 *pos_s, float4 *posf_s, double4 *vec_s, unsigned *tag_s, hipStream_t s) {
+    hipLaunchKernelGGL(k_permute, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, vec, group, perm, N, box, pos_s, posf_s, vec_s, tag_s);
 }
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s) {
     hipLaunchKernelGGL(k_permute_vec, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, vec, tag_s, N, vec_s);
@@ -210,9 +211,9 @@ __device__ __forceinline__ void nb_store(char *rec, int slot, int lane, unsigned
 // texture addresser busy for the whole kernel (rocprofv3: TA_BUSY = duration, 425 M cache accesses = 20 x 21.3 M pairs).
 template <bool LIST, bool CL>
 __global__ void __launch_bounds__(TPB)
-k_mreal_cells(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int lo,
-              int hi, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2, double self,
-              const double *__restrict__ coef_g, int ncoef, NbList nb) {
+k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf_s, const double4 *__restrict__ vec_s,
+              double4 *__restrict__ out_s, int lo, int hi, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2,
+              float rcut2_pre, double self, const double *__restrict__ coef_g, int ncoef, NbList nb) {
     __shared__ unsigned queue[QCAP * TPB];
     extern __shared__ double scoef[];
     const int tid = threadIdx.x;
@@ -253,7 +254,9 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec
             double f0, h0, f1, h1;
             eval_fg(r20, coef, f0, h0);
             eval_fg(r21, coef, f1, h1);
-            if (!two) { f1 = 0.0; h1 = 0.0; }
+            const bool in0 = r20 < rcut2 && r20 > 0.0, in1 = two && r21 < rcut2 && r21 > 0.0;   // the fp64 cutoff decides
+            if (!in0) { f0 = 0.0; h0 = 0.0; }
+            if (!in1) { f1 = 0.0; h1 = 0.0; }
             const double rd0 = (d0x * F0.x + d0y * F0.y + d0z * F0.z) * h0;
             const double rd1 = (d1x * F1.x + d1y * F1.y + d1z * F1.z) * h1;
             ux += f0 * F0.x + rd0 * d0x + f1 * F1.x + rd1 * d1x;
@@ -261,9 +264,11 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec
             uz += f0 * F0.z + rd0 * d0z + f1 * F1.z + rd1 * d1z;
             if (LIST) {
                 // 20 B per pair: (slot | image code), f, h; the mat-vecs redo the subtraction from the positions
-                if (total < nb.cap) nb_store(rec, total, lane, e0, f0, h0);
-                ++total;
-                if (two) {
+                if (in0) {
+                    if (total < nb.cap) nb_store(rec, total, lane, e0, f0, h0);
+                    ++total;
+                }
+                if (in1) {
                     if (total < nb.cap) nb_store(rec, total, lane, e1, f1, h1);
                     ++total;
                 }
@@ -272,27 +277,45 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec
         qn = 0;
     };
 
+    // Scan in single precision on a float copy of the positions against a cutoff enlarged by the rounding bound, eight
+    // candidates per round trip (a float4 is half the registers of a double4: the scan is bound by dependent round
+    // trips at three waves per SIMD); the drain repeats the test in double precision, so the neighbour set is exactly
+    // the fp64 one.
+    constexpr int SU = 8;
     for_each_run(nc, cell_off, cx, cy, cz, [&](int jb, int je, unsigned code) {
         double sx, sy, sz;
         image_shift(code, box, sx, sy, sz);
-        const double qx = pi.x - sx, qy = pi.y - sy, qz = pi.z - sz;
-        for (int j0 = jb; j0 < je; j0 += 4) {
-            double4 pj[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) pj[u] = pos_s[min(j0 + u, je - 1)];   // four independent loads in flight
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u;
-                double dx = qx - pj[u].x, dy = qy - pj[u].y, dz = qz - pj[u].z;
-                if (!shift_only) min_image(box, dx, dy, dz);
+        if (!shift_only) {   // fewer than three cells along some axis: minimum-image search in double precision
+            for (int j = jb; j < je; ++j) {
+                const double4 pj = pos_s[j];
+                double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                min_image(box, dx, dy, dz);
                 const double r2 = dx * dx + dy * dy + dz * dz;
-                if (j < je && r2 < rcut2 && j != i && r2 > 0.0) {
+                if (r2 < rcut2 && j != i && r2 > 0.0) {
+                    queue[qn * TPB + tid] = (unsigned)j | (code << 27);
+                    ++qn;
+                }
+                if (__any(qn > QCAP - SU)) drain();
+            }
+            return;
+        }
+        const float qx = (float)(pi.x - sx), qy = (float)(pi.y - sy), qz = (float)(pi.z - sz);
+        for (int j0 = jb; j0 < je; j0 += SU) {
+            float4 pj[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) pj[u] = posf_s[min(j0 + u, je - 1)];   // independent loads in flight
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int j = j0 + u;
+                const float dx = qx - pj[u].x, dy = qy - pj[u].y, dz = qz - pj[u].z;
+                const float r2 = dx * dx + dy * dy + dz * dz;
+                if (j < je && r2 < rcut2_pre && j != i) {
                     queue[qn * TPB + tid] = (unsigned)j | (code << 27);
                     ++qn;
                 }
             }
             // drain together: a lane-private "queue full" branch would serialise the wave once per lane
-            if (__any(qn > QCAP - 4)) drain();
+            if (__any(qn > QCAP - SU)) drain();
         }
     });
     drain();
@@ -426,24 +449,30 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
     if (active) out_s[i] = make_double4(ux, uy, uz, 0.0);
 }
 
-void launch_mreal(const double4 *pos_s, const double4 *vec_s, double4 *out_s, int lo, int hi, const int *cell_off,
-                  DBox box, DCells nc, double rcut, double self, const double *coef, int ncoef, NbList nb, int mode, hipStream_t s) {
+void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec_s, double4 *out_s, int lo, int hi,
+                  const int *cell_off, DBox box, DCells nc, double rcut, double self, const double *coef, int ncoef, NbList nb,
+                  int mode, hipStream_t s) {
     if (hi <= lo) return;
+    // pre-filter cutoff: coordinates (and image-shifted coordinates) are below 1.5 (Lx + |xy| Ly + Ly + Lz), rounded to
+    // 2^-24 relative a few times on the way to a separation component
+    const double cmax = 1.5 * (box.Lx + std::fabs(box.xy) * box.Ly + box.Ly + box.Lz);
+    const double rpre = rcut + 16.0 * cmax * 5.97e-8;
+    const float rcut2_pre = (float)(rpre * rpre * (1.0 + 1e-6));
     const dim3 g(nblocks(hi - lo, TPB)), b(TPB);
     const size_t cb = (size_t)ncoef * sizeof(double);
     const bool cl = cb <= 14 * 1024;   // with the 48 KB queue: two workgroups per CU
     if (mode == MREAL_BUILD_LIST) {
         (void)hipMemsetAsync(nb.ovf_n, 0, sizeof(int), s);
-        if (cl) hipLaunchKernelGGL((k_mreal_cells<true, true>), g, b, cb, s, pos_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, self, coef, ncoef, nb);
-        else hipLaunchKernelGGL((k_mreal_cells<true, false>), g, b, 0, s, pos_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, self, coef, ncoef, nb);
+        if (cl) hipLaunchKernelGGL((k_mreal_cells<true, true>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb);
+        else hipLaunchKernelGGL((k_mreal_cells<true, false>), g, b, 0, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb);
     } else if (mode == MREAL_USE_LIST) {
         hipLaunchKernelGGL(k_mreal_overflow, dim3(OVF_BLOCKS), b, 0, s, pos_s, vec_s, cell_off, box, nc, rcut * rcut, self, coef, nb);
         hipLaunchKernelGGL((k_mreal_list<false, 4, TPB>), g, b, 0, s, pos_s, vec_s, out_s, lo, hi, box,
                            (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1), self, nb, LzFuse{}, 0);
     } else if (cl)
-        hipLaunchKernelGGL((k_mreal_cells<false, true>), g, b, cb, s, pos_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, self, coef, ncoef, nb);
+        hipLaunchKernelGGL((k_mreal_cells<false, true>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb);
     else
-        hipLaunchKernelGGL((k_mreal_cells<false, false>), g, b, 0, s, pos_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, self, coef, ncoef, nb);
+        hipLaunchKernelGGL((k_mreal_cells<false, false>), g, b, 0, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb);
 }
 
 __global__ void __launch_bounds__(1024) k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, double *__restrict__ scal);

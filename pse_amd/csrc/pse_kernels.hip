@@ -9,11 +9,6 @@ namespace pse {
 constexpr int TPB = 256;
 constexpr double TWO_PI = 6.283185307179586476925286766559;
 
-static int dbg_mode() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("PSE_DBG"); v = e ? atoi(e) : 0; }
-    return v;
-}
 static inline int nblocks(long n, int tpb) { return (int)((n + tpb - 1) / tpb); }
 
 // ------------------------------------------------------------------------------------------------ reductions
@@ -370,7 +365,7 @@ k_mreal_overflow(const double4 *__restrict__ pos_s, const double4 *__restrict__ 
 template <bool FUSE, int UNROLL, int NT>
 __global__ void __launch_bounds__(NT)
 k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int lo,
-             int hi, DBox box, int shift_only, double self, NbList nb, LzFuse lz, int dbg) {
+             int hi, DBox box, int shift_only, double self, NbList nb, LzFuse lz) {
     __shared__ double shift[27 * 3];
     __shared__ double sh[4];
     if (threadIdx.x < 27) {
@@ -407,7 +402,7 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
                 double4 pj[UNROLL], Fj[UNROLL];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
-                    const unsigned j = (dbg & 16) ? (unsigned)i : (e[u] & JMASK);
+                    const unsigned j = e[u] & JMASK;
                     pj[u] = pos_s[j];
                     Fj[u] = vec_s[j];
                 }
@@ -468,7 +463,7 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
     } else if (mode == MREAL_USE_LIST) {
         hipLaunchKernelGGL(k_mreal_overflow, dim3(OVF_BLOCKS), b, 0, s, pos_s, vec_s, cell_off, box, nc, rcut * rcut, self, coef, nb);
         hipLaunchKernelGGL((k_mreal_list<false, 4, TPB>), g, b, 0, s, pos_s, vec_s, out_s, lo, hi, box,
-                           (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1), self, nb, LzFuse{}, 0);
+                           (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1), self, nb, LzFuse{});
     } else if (cl)
         hipLaunchKernelGGL((k_mreal_cells<false, true>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb);
     else
@@ -476,26 +471,15 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
 }
 
 __global__ void __launch_bounds__(1024) k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, double *__restrict__ scal);
-int mreal_partials_needed(int rows) { return nblocks(std::max(rows, 1), 64); }
+int mreal_partials_needed(int rows) { return nblocks(std::max(rows, 1), TPB); }
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, int lo, int hi, const int *cell_off,
                           DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,
                           double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s) {
     const int so = (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1);
-    const bool w1 = (dbg_mode() & 256) != 0;
-    const int nt = w1 ? 64 : TPB;
-    const int nbk = nblocks(std::max(hi - lo, 1), nt);
+    const int nbk = nblocks(std::max(hi - lo, 1), TPB);
     hipLaunchKernelGGL(k_mreal_overflow, dim3(OVF_BLOCKS), dim3(TPB), 0, s, pos_s, vec_s, cell_off, box, nc, rcut * rcut, self, coef, nb);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
-#define LAUNCH_LIST(U, NT_) hipLaunchKernelGGL((k_mreal_list<true, U, NT_>), dim3(nbk), dim3(NT_), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, dbg_mode())
-    switch ((dbg_mode() & 15) + (w1 ? 16 : 0)) {
-        case 2: LAUNCH_LIST(2, TPB); break;
-        case 8: LAUNCH_LIST(8, TPB); break;
-        case 16 + 2: LAUNCH_LIST(2, 64); break;
-        case 16 + 8: LAUNCH_LIST(8, 64); break;
-        case 16 + 0: case 16 + 4: LAUNCH_LIST(4, 64); break;
-        default: LAUNCH_LIST(4, TPB); break;
-    }
-#undef LAUNCH_LIST
+    hipLaunchKernelGGL((k_mreal_list<true, 4, TPB>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz);
     if (ev_end) (void)hipEventRecord(ev_end, s);
     hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, lz.partials, nbk, lz.npart_cap, 3, scal);
 }

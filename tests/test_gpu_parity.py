@@ -222,3 +222,64 @@ def test_fused_x_pass_matches_port(torch_cuda, oracle, grid, xy, P):
     vel, m = eng.brownian_velocity(to4(pos), to4(force), kT, dt, ts)
     ref, mref = oracle.brownian_velocity(pos, force, box, p, kT, dt, seed, ts)
     assert m == mref and rel(vel.cpu().numpy()[:, :3], ref) < 1e-9
+
+
+def _mobility_block(eng, pos, j, i):
+    """3x3 block M_ij through the engine: velocity of particle i for unit forces on particle j."""
+    n = len(pos)
+    M = np.zeros((3, 3))
+    for c in range(3):
+        f = np.zeros((n, 3)); f[j, c] = 1.0
+        M[:, c] = eng.mobility(to4(pos), to4(f)).cpu().numpy()[i, :3]
+    return M
+
+
+@pytest.mark.parametrize("xi", [0.5, 0.75])
+def test_known_answers_of_the_survey(torch_cuda, xi):
+    """SURVEY.md 8c KAT-1..KAT-4 (generated from mathematics, a = 1, units 1/(6 pi eta a)) through the C-ABI at
+    error = 1e-6; tolerance 5 x error (the method's own accuracy), cubic L = 20.  One and two particles: the smallest
+    systems (single cell, minimum-image near field, one occupied far-field bin)."""
+    import pse_amd
+    box = (20.0, 20.0, 20.0, 0.0)
+    tol = 5e-6
+    eng = pse_amd.Engine(2, box, xi=xi, error=1e-6)
+    # KAT-1: self mobility of a lone particle in the periodic box (Hasimoto), independent of xi
+    one = np.array([[1.3, -2.1, 0.4]])
+    M = _mobility_block(eng, one, 0, 0)
+    assert abs(M[0, 0] - 0.85865872480157) < tol and abs(M[1, 1] - M[0, 0]) < tol and abs(M[0, 1]) < tol
+    # KAT-2: separated pair r = (3, 1, 0.5)
+    base = np.array([-4.0, 7.5, 9.0])          # near two box faces: images are exercised
+    pair = np.stack([base + np.array([3.0, 1.0, 0.5]), base])
+    M = _mobility_block(eng, pair, 1, 0)
+    ref = np.array([[0.279076722785218, 0.053435549043855, 0.026722650338542],
+                    [0.053435549043855, 0.128141730481001, 0.008928425757363],
+                    [0.026722650338542, 0.008928425757363, 0.113989288350582]])
+    assert np.abs(M - ref).max() < tol, np.abs(M - ref).max()
+    # KAT-3: overlapping pair r = (1.2, 0.3, 0)
+    pair = np.stack([base + np.array([1.2, 0.3, 0.0]), base])
+    M = _mobility_block(eng, pair, 1, 0)
+    assert abs(M[0, 0] - 0.6207687795007937) < tol and abs(M[1, 1] - 0.5177902235372976) < tol
+    assert abs(M[2, 2] - 0.5109249998759693) < tol and abs(M[0, 1] - 0.02707348137451859) < tol
+    # KAT-4: touching pair r = (2, 0, 0)
+    pair = np.stack([base + np.array([2.0, 0.0, 0.0]), base])
+    M = _mobility_block(eng, pair, 1, 0)
+    assert abs(M[0, 0] - 0.4860111219717241) < tol and abs(M[1, 1] - 0.2965766796953576) < tol and abs(M[2, 2] - M[1, 1]) < tol
+
+
+def test_single_particle_brownian_step(torch_cuda):
+    """N = 1: the Lanczos iteration breaks down after one vector (M_real is 3x3 diagonal); the reference drops that
+    vector and fails, the build keeps it: u = sqrt(2 kT/dt) sqrt(M) psi has the right magnitude."""
+    import pse_amd
+    box = (20.0, 20.0, 20.0, 0.0)
+    eng = pse_amd.Engine(1, box, xi=0.5, error=1e-3, seed=7)
+    pos = to4(np.array([[0.5, 0.25, -3.0]])); zero = to4(np.zeros((1, 3)))
+    kT, dt = 1.0, 1e-3
+    us = []
+    for ts in range(200):
+        vel, m = eng.brownian_velocity(pos, zero, kT, dt, ts)
+        assert 1 <= m <= 2
+        us.append(vel.cpu().numpy()[0, :3].copy())
+    us = np.array(us)
+    assert np.all(np.isfinite(us))
+    var = (us ** 2).mean()                                  # <u_x^2> = 2 kT M_xx / dt
+    assert abs(var / (2 * kT * 0.85865872480157 / dt) - 1.0) < 0.25

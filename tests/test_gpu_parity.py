@@ -283,3 +283,29 @@ def test_single_particle_brownian_step(torch_cuda):
     assert np.all(np.isfinite(us))
     var = (us ** 2).mean()                                  # <u_x^2> = 2 kT M_xx / dt
     assert abs(var / (2 * kT * 0.85865872480157 / dt) - 1.0) < 0.25
+
+
+def test_fluctuation_dissipation(torch_cuda, oracle):
+    """SURVEY.md 8c property (v): <u u^T> = (2 kT/dt) M for the Brownian velocity (k-space noise + Lanczos real-space
+    noise; F = 0) against the dense direct-Ewald mobility, N = 12, 8000 independent timesteps.  Statistical bounds:
+    the relative Frobenius error of a sample covariance of dimension d over T samples is ~sqrt((d+1)/T) = 0.068."""
+    import pse_amd
+    n, L, kT, dt, T = 12, 16.0, 1.0, 1e-3, 8000
+    box = (L, L, L, 0.0)
+    rng = np.random.default_rng(3)
+    pos = rng.uniform(-L / 2, L / 2, size=(n, 3))
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3, seed=99)
+    dpos, zero = to4(pos), to4(np.zeros((n, 3)))
+    acc = torch_cuda.zeros((3 * n, 3 * n), dtype=torch_cuda.float64, device="cuda")
+    mean = torch_cuda.zeros(3 * n, dtype=torch_cuda.float64, device="cuda")
+    m = 2
+    for ts in range(T):
+        vel, m = eng.brownian_velocity(dpos, zero, kT, dt, ts, lanczos_m=m)
+        u = vel[:, :3].reshape(-1)
+        acc += torch_cuda.outer(u, u)
+        mean += u
+    C = (acc / T).cpu().numpy() * dt / (2 * kT)
+    M = oracle.mobility_dense(pos, box, 0.5)
+    assert np.abs((mean / T).cpu().numpy()).max() * math.sqrt(dt / (2 * kT)) < 5.0 / math.sqrt(T)     # zero mean
+    assert abs(np.trace(C) / np.trace(M) - 1.0) < 0.015
+    assert np.linalg.norm(C - M) / np.linalg.norm(M) < 0.1

@@ -309,3 +309,22 @@ def test_fluctuation_dissipation(torch_cuda, oracle):
     assert np.abs((mean / T).cpu().numpy()).max() * math.sqrt(dt / (2 * kT)) < 5.0 / math.sqrt(T)     # zero mean
     assert abs(np.trace(C) / np.trace(M) - 1.0) < 0.015
     assert np.linalg.norm(C - M) / np.linalg.norm(M) < 0.1
+
+
+@pytest.mark.parametrize("xy", [0.0, 0.3])
+def test_both_halves_symmetric_positive_definite(torch_cuda, xy):
+    """The "positively split" claim (SURVEY.md 8c property ii): M_real and M_wave are separately symmetric positive
+    definite.  Symmetry of the wave half is the adjointness of the spread and gather kernels (same weights) through the
+    real-to-complex transforms: exact to rounding."""
+    import pse_amd
+    n, L = 30, 18.0
+    box = (L, L, L, xy)
+    pos, _, _ = make_suspension(n, L=L, xy=xy)
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3)
+    dpos = to4(pos)
+    eye = np.eye(3 * n)
+    for parts, tol in ((1, 1e-13), (2, 1e-12)):
+        M = np.stack([eng.mobility(dpos, to4(eye[c].reshape(n, 3)), parts=parts).cpu().numpy()[:, :3].ravel()
+                      for c in range(3 * n)], 1)
+        assert np.abs(M - M.T).max() < tol * np.abs(M).max(), (parts, np.abs(M - M.T).max())
+        assert np.linalg.eigvalsh(0.5 * (M + M.T)).min() > 0.0, parts

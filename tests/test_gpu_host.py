@@ -75,3 +75,14 @@ def test_example_script_runs():
                        timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "ran 5 steps" in r.stdout
+
+
+def test_hoomd_style_script_runs_on_the_shim():
+    """compat/hoomd: the calls of the reference's example script (import hoomd, create_lattice, mode_standard, group.all,
+    PSEv1.integrate.PSEv1, hoomd.run) on the stand-in package."""
+    env = dict(os.environ)
+    env.pop("PSE_EXAMPLE_STEPS", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "run_hoomd_api.py")], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "hoomd-style run done: 20 steps" in r.stdout

@@ -120,6 +120,12 @@ int pse_random_psi(pse_handle *h, pse_double4 *psi, const unsigned int *group_me
 /* evaluate the device's real-space functions f(r), g(r) (the replacement of the m_ewaldC1 table,
  * PSEv1/Stokes.cc:334-422) at n host radii -> host arrays */
 int pse_eval_realspace(pse_handle *h, const double *r_host, int n, double *f_host, double *g_host);
+/* Force provider next to the path (the step consumes net_force from its host, PSEv1/Stokes.cc:447, and the
+ * reference's example has none): soft repulsion F_i = sum_j k (sigma - r)(r_i - r_j)/r over minimum-image pairs with
+ * r < sigma <= rcut, evaluated from the engine's cell list.  force[group[i]].xyz is overwritten (accumulate = 0) or
+ * incremented (accumulate = 1); w is kept. */
+int pse_pair_repulsion(pse_handle *h, const pse_double4 *pos, pse_double4 *force, const unsigned *group, unsigned N,
+                       double k, double sigma, int accumulate);
 /* copy the three real-space grids (x-major, z fastest: idx = (x*Ny + y)*Nz + z, PSEv1/Mobility.cu:233) of the
  * most recent spread (stage 0) or inverse FFT (stage 1) to a host buffer of 3*nx_local*Ny*Nz doubles */
 int pse_debug_copy_grid(pse_handle *h, int stage, double *host_out);

@@ -396,6 +396,20 @@ def wrap(pos, image, box):
     return pos, image
 
 
+def pair_repulsion(pos, box, k, sigma=2.0):
+    """Soft repulsion k (sigma - r) r_hat over minimum-image pairs with r < sigma (the force provider of SURVEY.md 8 f4;
+    O(N^2), triclinic minimum image as in HOOMD: y images shift x by xy*Ly)."""
+    Lx, Ly, Lz, xy = box
+    d = pos[:, None, :] - pos[None, :, :]
+    n = np.rint(d[..., 2] / Lz); d[..., 2] -= n * Lz
+    n = np.rint(d[..., 1] / Ly); d[..., 1] -= n * Ly; d[..., 0] -= n * xy * Ly
+    n = np.rint(d[..., 0] / Lx); d[..., 0] -= n * Lx
+    r = np.linalg.norm(d, axis=2)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        c = np.where((r < sigma) & (r > 0.0), k * (sigma - r) / r, 0.0)
+    return (c[..., None] * d).sum(axis=1)
+
+
 def integrate(pos, image, vel, box, dt, shear_rate):
     """Stokes.cu:156-190."""
     v = vel.copy(); v[:, 0] += shear_rate * pos[:, 1]

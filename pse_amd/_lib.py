@@ -64,6 +64,7 @@ SYMBOLS = {
     "pse_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u, _d, _d, _u, _d, _ip]),
     "pse_sqrt_mreal": (_i, [_vp, _vp, _vp, _vp, _vp, _u, _d, _ip]),
     "pse_random_psi": (_i, [_vp, _vp, _vp, _u, _u]),
+    "pse_pair_repulsion": (_i, [_vp, _vp, _vp, _vp, _u, _d, _d, _i]),
     "pse_eval_realspace": (_i, [_vp, _dp, _i, _dp, _dp]),
     "pse_debug_copy_grid": (_i, [_vp, _i, _dp]),
     "pse_team_unique_id": (_i, [_vp]),

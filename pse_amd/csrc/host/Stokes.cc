@@ -47,6 +47,13 @@ void Stokes::integrateStepOne(unsigned int timestep, const ParticleArrays &p) {
           "Stokes::integrateStepOne");
 }
 
+void Stokes::pairRepulsion(const pse_double4 *pos, pse_double4 *force, const unsigned int *group, unsigned int n, double k,
+                           double sigma, bool accumulate) {
+    if (!m_h) throw std::runtime_error("Stokes::setParams() has not been called");
+    if (n == 0) return;
+    check(pse_pair_repulsion(m_h, pos, force, group, n, k, sigma, accumulate ? 1 : 0), "Stokes::pairRepulsion");
+}
+
 pse_info Stokes::info() const {
     pse_info i{};
     if (m_h) pse_get_info(m_h, &i);

@@ -36,6 +36,9 @@ public:
     void setBox(BoxDim box);                                                               // per-step box under shear
     void integrateStepOne(unsigned int timestep, const ParticleArrays &p);                 // Stokes.cc:429-523
     void integrateStepTwo(unsigned int) {}                                                 // Stokes.cc:528-530
+    // force provider on the integrator's own cell list (the reference takes net_force from HOOMD, Stokes.cc:447)
+    void pairRepulsion(const pse_double4 *pos, pse_double4 *force, const unsigned int *group, unsigned int n, double k,
+                       double sigma, bool accumulate);
     pse_info info() const;
     int lanczosIterations() const { return m_m_Lanczos; }
     unsigned int hashedSeed() const { return m_seed; }

@@ -64,6 +64,10 @@ PYBIND11_MODULE(_PSEv1, m) {
                                                        ptr<const unsigned int>(group), n});
         })
         .def("integrateStepTwo", &Stokes::integrateStepTwo)
+        .def("pairRepulsion", [](Stokes &s, std::uintptr_t pos, std::uintptr_t force, std::uintptr_t group, unsigned int n, double k,
+                                 double sigma, bool accumulate) {
+            s.pairRepulsion(ptr<const pse_double4>(pos), ptr<pse_double4>(force), ptr<const unsigned int>(group), n, k, sigma, accumulate);
+        })
         .def("lanczosIterations", &Stokes::lanczosIterations)
         .def("hashedSeed", &Stokes::hashedSeed)
         .def("info", [](const Stokes &s) {

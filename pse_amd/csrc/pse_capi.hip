@@ -1054,6 +1054,19 @@ extern "C" int pse_sqrt_mreal(pse_handle *h, const pse_double4 *pos, const pse_d
     return 0;
 }
 
+extern "C" int pse_pair_repulsion(pse_handle *h, const pse_double4 *pos, pse_double4 *force, const unsigned *group, unsigned N,
+                                  double k, double sigma, int accumulate) {
+    TRY(check_n(h, N));
+    if (!pos || !force) return fail(PSE_ERR_INVALID, "null array");
+    if (!(sigma > 0.0) || sigma > h->d.rcut)
+        return fail(PSE_ERR_INVALID, "repulsion range %.4f outside (0, rcut = %.4f]: the cell list is built for the hydrodynamic cutoff",
+                    sigma, h->d.rcut);
+    TRY(prepare(h, (const double4 *)pos, nullptr, group, (int)N));
+    launch_pair_repulsion(h->pos_s, h->tag_s, (int)N, h->cell_off, h->dbox, h->nc, k, sigma, accumulate, (double4 *)force, h->stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int pse_random_psi(pse_handle *h, pse_double4 *psi, const unsigned *group, unsigned N, unsigned timestep) {
     TRY(check_n(h, N));
     if (!psi) return fail(PSE_ERR_INVALID, "null array");

@@ -117,5 +117,8 @@ void launch_scatter_sum(const double4 *a, const double4 *b, const double4 *c, co
 void launch_integrate(double4 *pos, const double4 *vel, double3 *accel, int3 *image, const double4 *force,
                       const unsigned *group, int N, DBox box, double dt, double shear_rate, hipStream_t s);
 void launch_eval_fg(const double *r, int n, const double *coef, double *f, double *g, hipStream_t s);
+// soft pair repulsion from the cell list, scattered to the caller's order (force provider)
+void launch_pair_repulsion(const double4 *pos_s, const unsigned *tag_s, int N, const int *cell_off, DBox box, DCells nc,
+                           double k, double sigma, int accumulate, double4 *force, hipStream_t s);
 
 }  // namespace pse

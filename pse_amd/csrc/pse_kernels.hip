@@ -1476,6 +1476,43 @@ void launch_basis_combine(const double4 *V, size_t stride, const double *t_dev, 
                        t_dev, m, scal, scale, use_norm, out_s, lo, hi);
 }
 
+// Force provider next to the path (the step consumes net_force, PSEv1/Stokes.cc:447): soft repulsion
+// F_i = sum_j k (sigma - r) (r_i - r_j)/r over pairs closer than sigma, from the engine's own cell list.  One thread per
+// particle; the result is added to (or stored in) the caller's force array in the caller's order.
+__global__ void __launch_bounds__(TPB)
+k_pair_repulsion(const double4 *__restrict__ pos_s, const unsigned *__restrict__ tag_s, int N, const int *__restrict__ cell_off,
+                 DBox box, DCells nc, double k, double sigma, int accumulate, double4 *__restrict__ force) {
+    const int i = xcd_block(blockIdx.x, gridDim.x) * TPB + threadIdx.x;
+    if (i >= N) return;
+    const double4 pi = pos_s[i];
+    double fx, fy, fz;
+    frac_coords(box, pi.x, pi.y, pi.z, fx, fy, fz);
+    const int cx = cell_coord(fx, nc.nx), cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz);
+    const double s2 = sigma * sigma;
+    double Fx = 0.0, Fy = 0.0, Fz = 0.0;
+    for_each_run(nc, cell_off, cx, cy, cz, [&](int jb, int je, unsigned) {
+        for (int j = jb; j < je; ++j) {
+            const double4 pj = pos_s[j];
+            double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            min_image(box, dx, dy, dz);
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            if (r2 < s2 && j != i && r2 > 0.0) {
+                const double r = sqrt(r2), c = k * (sigma - r) / r;
+                Fx += c * dx; Fy += c * dy; Fz += c * dz;
+            }
+        }
+    });
+    const unsigned idx = tag_s[i];
+    double4 f = force[idx];
+    if (accumulate) { f.x += Fx; f.y += Fy; f.z += Fz; } else { f.x = Fx; f.y = Fy; f.z = Fz; }
+    force[idx] = f;
+}
+void launch_pair_repulsion(const double4 *pos_s, const unsigned *tag_s, int N, const int *cell_off, DBox box, DCells nc,
+                           double k, double sigma, int accumulate, double4 *force, hipStream_t s) {
+    hipLaunchKernelGGL(k_pair_repulsion, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos_s, tag_s, N, cell_off, box, nc, k, sigma,
+                       accumulate, force);
+}
+
 // K10 gpu_stokes_LinearCombination_kernel (PSEv1/Helper.cu:113-133) as the final un-sort: vel.xyz = a + b + c, keep w
 __global__ void k_scatter_sum(const double4 *__restrict__ a, const double4 *__restrict__ b,
                               const double4 *__restrict__ c, const unsigned *__restrict__ tag_s, int N,

@@ -122,6 +122,14 @@ class Engine:
                                             ctypes.byref(m)))
         return out, m.value
 
+    def pair_repulsion(self, pos, force, k, sigma=2.0, group=None, accumulate=True):
+        """Soft repulsion k (sigma - r) r_hat for r < sigma added to (or stored in) `force`."""
+        n = pos.shape[0] if group is None else group.shape[0]
+        _chk4(pos, "pos"); _chk4(force, "force")
+        _lib.check(self._lib.pse_pair_repulsion(self._h, _ptr(pos), _ptr(force), _ptr(group), n, float(k), float(sigma),
+                                                1 if accumulate else 0))
+        return force
+
     def random_psi(self, n, timestep, group=None):
         import torch
         rows = n if group is None else int(group.max().item()) + 1

@@ -35,6 +35,8 @@ class System:
         self.accel = torch.zeros((self.n, 3), dtype=torch.float64, device="cuda")
         self.image = torch.zeros((self.n, 3), dtype=torch.int32, device="cuda")
         self.integrators = []
+        self.forces = []          # force providers (pse_amd.forces): fill net_force before the integrators run
+        self.analyzers = []       # e.g. pse_amd.dump.Trajectory
         self.box_tilt_variant = None    # a variant.shear_variant: Lees-Edwards box deformation
         context.current = self
 
@@ -55,6 +57,12 @@ class System:
                 xy = self.box_tilt_variant.get_value(self.timestep)
                 if xy != self.box[3]:
                     self._set_tilt(xy)
+            for a in self.analyzers:
+                a.analyze(self.timestep)
+            if self.forces:
+                self.net_force.zero_()
+                for f in self.forces:
+                    f.compute(self.timestep)
             for integ in self.integrators:
                 integ.update(self.timestep)
             self.timestep += 1

@@ -86,3 +86,35 @@ def test_hoomd_style_script_runs_on_the_shim():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "hoomd-style run done: 20 steps" in r.stdout
+
+
+def test_force_provider_and_trajectory(tmp_path):
+    """The steps either side of the path: a soft-repulsion force provider feeding net_force and a
+    trajectory writer.  Overlapping random spheres at kT = 0 are pushed apart by M.F_repulsion; frames are written."""
+    import numpy as np
+    import torch
+    from pse_amd import dump, forces, integrate
+    from pse_amd.system import System
+    rng = np.random.default_rng(2)
+    n, L = 800, 24.0
+    pos = rng.uniform(-L / 2, L / 2, size=(n, 3))
+    s = System(pos, (L, L, L, 0.0), dt=2e-3)
+    pse = integrate.PSEv1(group=s.all(), T=0.0, seed=3, xi=0.5, error=1e-3)
+    forces.HarmonicRepulsion(pse, k=50.0, sigma=2.0)
+    traj = dump.Trajectory(s, str(tmp_path / "traj.npz"), period=10)
+
+    def overlap_energy():
+        p = s.pos[:, :3]
+        d = p[:, None, :] - p[None, :, :]
+        d -= L * torch.round(d / L)
+        r = d.norm(dim=2) + 10.0 * torch.eye(n, device="cuda", dtype=torch.float64)
+        return float((torch.clamp(2.0 - r, min=0.0) ** 2).sum())
+
+    e0 = overlap_energy()
+    s.run(40)
+    e1 = overlap_energy()
+    assert e0 > 0.0 and e1 < 0.5 * e0, (e0, e1)
+    assert float(s.net_force[:, :3].abs().max()) > 0.0
+    fr = dump.load(traj.write())
+    assert list(fr["timestep"]) == [0, 10, 20, 30] and fr["position"].shape == (4, n, 3) and fr["box"].shape == (4, 4)
+    assert np.abs(fr["position"][0] - pos).max() < 1e-12

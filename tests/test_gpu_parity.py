@@ -328,3 +328,22 @@ def test_both_halves_symmetric_positive_definite(torch_cuda, xy):
                       for c in range(3 * n)], 1)
         assert np.abs(M - M.T).max() < tol * np.abs(M).max(), (parts, np.abs(M - M.T).max())
         assert np.linalg.eigvalsh(0.5 * (M + M.T)).min() > 0.0, parts
+
+
+@pytest.mark.parametrize("xy", [0.0, 0.3])
+def test_pair_repulsion_matches_port(torch_cuda, oracle, xy):
+    """Force provider (SURVEY.md 8 f4): soft repulsion from the engine's cell list against the O(N^2) restatement;
+    overwrite / accumulate semantics and the w component."""
+    import pse_amd
+    n = 1500
+    pos, force, box = make_suspension(n, phi=0.35, xy=xy)      # uniform random positions: plenty of overlaps
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3)
+    ref = oracle.pair_repulsion(pos, box, 40.0, 2.0)
+    assert np.count_nonzero(np.abs(ref).sum(1)) > n // 2
+    f = to4(force, 7.0)
+    out = eng.pair_repulsion(to4(pos), f, 40.0, 2.0, accumulate=False).cpu().numpy()
+    assert rel(out[:, :3], ref) < 1e-12 and np.all(out[:, 3] == 7.0)
+    out = eng.pair_repulsion(to4(pos), to4(force, 7.0), 40.0, 2.0, accumulate=True).cpu().numpy()
+    assert rel(out[:, :3], ref + force) < 1e-12
+    with pytest.raises(pse_amd.PSEError):
+        eng.pair_repulsion(to4(pos), f, 40.0, 2.0 * eng.info()["rcut"])

@@ -76,6 +76,7 @@ struct pse_handle {
     SpreadWork sw = {};       // separable weights + per-tile hit lists of the far field
     NbList nb = {};
     bool nb_valid = false;   // the pair list matches the current sorted positions
+    bool w_is_mpsi = false;  // w_s already holds M_real psi_s (delivered by the pass that built the pair list)
     size_t n_cells_alloc = 0;
     float4 *posf_s = nullptr;   // single-precision copy of pos_s (cutoff pre-filter of the near field)
     double4 *pos_s = nullptr, *f_s = nullptr, *uw_s = nullptr, *ur_s = nullptr, *ub_s = nullptr, *psi_s = nullptr, *w_s = nullptr;
@@ -671,6 +672,7 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
     launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->f_s, h->tag_s, h->stream);
     h->sorted_N = N;
     h->nb_valid = false;
+    h->w_is_mpsi = false;
     TRY(slab_bounds(h, N));
     TRY(te(h, PH_SORT));
     HIPCHK(hipGetLastError());
@@ -774,8 +776,9 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
 // near-field mat-vec out = M_real vec (PSEv1/Mobility.cu:594-687) on the rows this rank owns; vec must be valid on those
 // rows and on the neighbouring cell layers.  build_list: also record the pair list for later mat-vecs of this step.
 static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*out, size_t vec_off, size_t out_off, int N,
-                bool build_list) {
+                bool build_list, bool with_psi = false) {
     for (pse_handle *h : T.m) {
+        h->w_is_mpsi = false;
         int mode = MREAL_CELLS;
         if (h->nb.cap > 0) {
             if (h->nb_valid) mode = MREAL_USE_LIST;
@@ -784,8 +787,9 @@ static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*ou
         int lo, hi;
         row_range(h, N, lo, hi);
         launch_mreal(h->pos_s, h->posf_s, h->*vec + vec_off, h->*out + out_off, lo, hi, h->cell_off, h->dbox, h->nc, h->d.rcut,
-                     h->d.self, h->coef, h->n_intervals * 2 * RS_NCOEF, h->nb, mode, h->stream);
-        if (mode == MREAL_BUILD_LIST) h->nb_valid = true;
+                     h->d.self, h->coef, h->n_intervals * 2 * RS_NCOEF, h->nb, mode, h->stream,
+                     with_psi && mode == MREAL_BUILD_LIST ? h->psi_s : nullptr, h->w_s);
+        if (mode == MREAL_BUILD_LIST) { h->nb_valid = true; h->w_is_mpsi = with_psi && h->n_intervals * 2 * RS_NCOEF * sizeof(double) <= 14 * 1024; }
     }
     return 0;
 }
@@ -807,9 +811,10 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io) {
     while (true) {
         for (; done < target; ++done) {
             // iteration j = done on the unnormalised x_j (psi for j = 0, else parked in V[j]); see k_lz_update
-            const bool fused = h0->nb.cap > 0 && h0->nb_valid;   // sums fused into the pair-list mat-vec
+            const bool have_y = done == 0 && h0->w_is_mpsi;      // M psi came with the pass that built the pair list
+            const bool fused = !have_y && h0->nb.cap > 0 && h0->nb_valid;   // sums fused into the pair-list mat-vec
             const bool timed = done == 1 && fused;               // one pair-list mat-vec kernel per call is timed on its own
-            if (!fused) TRY(real(T, done == 0 ? &pse_handle::psi_s : &pse_handle::V, &pse_handle::w_s, (size_t)done * stride, 0, N, true));
+            if (!fused && !have_y) TRY(real(T, done == 0 ? &pse_handle::psi_s : &pse_handle::V, &pse_handle::w_s, (size_t)done * stride, 0, N, true));
             for (pse_handle *h : T.m) {
                 int lo, hi;
                 row_range(h, N, lo, hi);
@@ -824,6 +829,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io) {
                 } else {
                     launch_lz_dots(xj, h->w_s, vjm1, lo, hi, h->partials, h->npart_cap, h->scal, h->stream);
                 }
+                h->w_is_mpsi = false;
             }
             TRY(team_all_reduce_sum(T, [](pse_handle *h) { return h->scal + LZ_TMP; }, 3));
             for (pse_handle *h : T.m) {
@@ -911,17 +917,16 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
         *mask |= (1u << PH_SPREAD) | (1u << PH_FFTF) | (1u << PH_SCALE) | (1u << PH_FFTI) | (1u << PH_GATHER);
         if (T.G > 1) *mask |= 1u << PH_COMM;
     }
+    if (noise)   // psi first: the near-field pass that builds the pair list applies M_real to F and to psi together
+        for (pse_handle *h : T.m) launch_psi(h->psi_s, h->tag_s, N, h->par.seed, timestep, h->stream);
     if (parts & 1) {
         for (pse_handle *h : T.m) TRY(ts(h, PH_REAL));
-        TRY(real(T, &pse_handle::f_s, &pse_handle::ur_s, 0, 0, N, noise));
+        TRY(real(T, &pse_handle::f_s, &pse_handle::ur_s, 0, 0, N, noise, noise));
         for (pse_handle *h : T.m) TRY(te(h, PH_REAL));
         *mask |= 1u << PH_REAL;
     }
     if (noise) {
-        for (pse_handle *h : T.m) {
-            TRY(ts(h, PH_LANCZOS));
-            launch_psi(h->psi_s, h->tag_s, N, h->par.seed, timestep, h->stream);
-        }
+        for (pse_handle *h : T.m) TRY(ts(h, PH_LANCZOS));
         for (pse_handle *h : T.m) h->matvec_timed = false;
         TRY(lanczos(T, N, T.m[0]->d.error, std::sqrt(2.0 * kT / dt), m_io));
         for (pse_handle *h : T.m) TRY(te(h, PH_LANCZOS));

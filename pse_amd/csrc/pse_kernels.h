@@ -44,7 +44,7 @@ struct LzFuse {
 // rows [lo, hi) of the mat-vec (the whole vector is read; multi-GPU ranks each take a row range)
 void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec_s, double4 *out_s, int lo, int hi,
                   const int *cell_off, DBox box, DCells nc, double rcut, double self, const double *coef, int ncoef, NbList nb,
-                  int mode, hipStream_t s);
+                  int mode, hipStream_t s, const double4 *vec2_s = nullptr, double4 *out2_s = nullptr);   // BUILD_LIST: a second vector rides along
 // pair-list mat-vec + Lanczos sums; leaves the three reduced sums in scal[LZ_TMP .. LZ_TMP + 2]
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, int lo, int hi, const int *cell_off,
                           DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,

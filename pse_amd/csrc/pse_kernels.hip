@@ -204,11 +204,14 @@ __device__ __forceinline__ void nb_store(char *rec, int slot, int lane, unsigned
 // CL: the f, g coefficient table is copied to LDS first (ncoef doubles of dynamic shared memory).  Every neighbour reads
 // 20 coefficients of its own interval: from global memory that was 20 of the 24 L1 accesses per pair and kept the
 // texture addresser busy for the whole kernel (rocprofv3: TA_BUSY = duration, 425 M cache accesses = 20 x 21.3 M pairs).
-template <bool LIST, bool CL>
+// TWO: a second vector rides along (out2 = M_real vec2): the pass that builds the pair list for M.F also delivers
+// M.psi, the first Lanczos mat-vec, for one more gather per neighbour.
+template <bool LIST, bool CL, bool TWO>
 __global__ void __launch_bounds__(TPB)
 k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf_s, const double4 *__restrict__ vec_s,
               double4 *__restrict__ out_s, int lo, int hi, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2,
-              float rcut2_pre, double self, const double *__restrict__ coef_g, int ncoef, NbList nb) {
+              float rcut2_pre, double self, const double *__restrict__ coef_g, int ncoef, NbList nb,
+              const double4 *__restrict__ vec2_s, double4 *__restrict__ out2_s) {
     __shared__ unsigned queue[QCAP * TPB];
     extern __shared__ double scoef[];
     const int tid = threadIdx.x;
@@ -222,6 +225,8 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
     const double4 pi = pos_s[i];
     const double4 vi = vec_s[i];
     double ux = self * vi.x, uy = self * vi.y, uz = self * vi.z;
+    double wx = 0.0, wy = 0.0, wz = 0.0;
+    if (TWO) { const double4 v2 = vec2_s[i]; wx = self * v2.x; wy = self * v2.y; wz = self * v2.z; }
     double fx, fy, fz;
     frac_coords(box, pi.x, pi.y, pi.z, fx, fy, fz);
     const int cx = cell_coord(fx, nc.nx), cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz);
@@ -257,6 +262,13 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
             ux += f0 * F0.x + rd0 * d0x + f1 * F1.x + rd1 * d1x;
             uy += f0 * F0.y + rd0 * d0y + f1 * F1.y + rd1 * d1y;
             uz += f0 * F0.z + rd0 * d0z + f1 * F1.z + rd1 * d1z;
+            if (TWO) {
+                const double4 G0 = vec2_s[j0], G1 = vec2_s[j1];
+                const double s0 = (d0x * G0.x + d0y * G0.y + d0z * G0.z) * h0, s1 = (d1x * G1.x + d1y * G1.y + d1z * G1.z) * h1;
+                wx += f0 * G0.x + s0 * d0x + f1 * G1.x + s1 * d1x;
+                wy += f0 * G0.y + s0 * d0y + f1 * G1.y + s1 * d1y;
+                wz += f0 * G0.z + s0 * d0z + f1 * G1.z + s1 * d1z;
+            }
             if (LIST) {
                 // 20 B per pair: (slot | image code), f, h; the mat-vecs redo the subtraction from the positions
                 if (in0) {
@@ -315,6 +327,7 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
     });
     drain();
     out_s[i] = make_double4(ux, uy, uz, 0.0);
+    if (TWO) out2_s[i] = make_double4(wx, wy, wz, 0.0);
     if (LIST) {
         if (total > nb.cap) {   // the row did not fit: later mat-vecs of this step recompute it from the cells
             const int k = atomicAdd(nb.ovf_n, 1);
@@ -446,7 +459,7 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
 
 void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec_s, double4 *out_s, int lo, int hi,
                   const int *cell_off, DBox box, DCells nc, double rcut, double self, const double *coef, int ncoef, NbList nb,
-                  int mode, hipStream_t s) {
+                  int mode, hipStream_t s, const double4 *vec2_s, double4 *out2_s) {
     if (hi <= lo) return;
     // pre-filter cutoff: coordinates (and image-shifted coordinates) are below 1.5 (Lx + |xy| Ly + Ly + Lz), rounded to
     // 2^-24 relative a few times on the way to a separation component
@@ -458,16 +471,17 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
     const bool cl = cb <= 14 * 1024;   // with the 48 KB queue: two workgroups per CU
     if (mode == MREAL_BUILD_LIST) {
         (void)hipMemsetAsync(nb.ovf_n, 0, sizeof(int), s);
-        if (cl) hipLaunchKernelGGL((k_mreal_cells<true, true>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb);
-        else hipLaunchKernelGGL((k_mreal_cells<true, false>), g, b, 0, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb);
+        if (cl && vec2_s) hipLaunchKernelGGL((k_mreal_cells<true, true, true>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, vec2_s, out2_s);
+        else if (cl) hipLaunchKernelGGL((k_mreal_cells<true, true, false>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, nullptr, nullptr);
+        else hipLaunchKernelGGL((k_mreal_cells<true, false, false>), g, b, 0, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, nullptr, nullptr);
     } else if (mode == MREAL_USE_LIST) {
         hipLaunchKernelGGL(k_mreal_overflow, dim3(OVF_BLOCKS), b, 0, s, pos_s, vec_s, cell_off, box, nc, rcut * rcut, self, coef, nb);
         hipLaunchKernelGGL((k_mreal_list<false, 4, TPB>), g, b, 0, s, pos_s, vec_s, out_s, lo, hi, box,
                            (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1), self, nb, LzFuse{});
     } else if (cl)
-        hipLaunchKernelGGL((k_mreal_cells<false, true>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb);
+        hipLaunchKernelGGL((k_mreal_cells<false, true, false>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, nullptr, nullptr);
     else
-        hipLaunchKernelGGL((k_mreal_cells<false, false>), g, b, 0, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb);
+        hipLaunchKernelGGL((k_mreal_cells<false, false, false>), g, b, 0, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, nullptr, nullptr);
 }
 
 __global__ void __launch_bounds__(1024) k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, double *__restrict__ scal);

@@ -79,6 +79,7 @@ struct pse_handle {
     bool w_is_mpsi = false;  // w_s already holds M_real psi_s (delivered by the pass that built the pair list)
     size_t n_cells_alloc = 0;
     float4 *posf_s = nullptr;   // single-precision copy of pos_s (cutoff pre-filter of the near field)
+    double2 *pv = nullptr;      // [N][3] packed (position, Lanczos vector) records gathered by the pair-list mat-vec (single GPU)
     double4 *pos_s = nullptr, *f_s = nullptr, *uw_s = nullptr, *ur_s = nullptr, *ub_s = nullptr, *psi_s = nullptr, *w_s = nullptr;
     // real-space table
     double *coef = nullptr;
@@ -213,7 +214,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->plan_x_inv) rocfft_plan_destroy(h->plan_x_inv);
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
-    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cell_cnt, h->sup_s, h->sw.wtab_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->sw.sup_t, h->sw.f_t, h->nb.data, h->nb.cnt, h->nb.ovf_rows, h->nb.ovf_n, h->nb.ovf_out, h->pos_s, h->posf_s,
+    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cell_cnt, h->sup_s, h->sw.wtab_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->sw.sup_t, h->sw.f_t, h->nb.data, h->nb.cnt, h->nb.ovf_rows, h->nb.ovf_n, h->nb.ovf_out, h->pos_s, h->posf_s, h->pv,
                     h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->twiddle, h->fft_work, h->V,
                     h->scal, h->partials, h->t_dev};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -368,7 +369,9 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         }
         TRY(dmalloc(h, &h->nb.cnt, n));
     }
-    TRY(dmalloc(h, &h->pos_s, n)); TRY(dmalloc(h, &h->posf_s, n)); TRY(dmalloc(h, &h->f_s, n)); TRY(dmalloc(h, &h->uw_s, n)); TRY(dmalloc(h, &h->ur_s, n));
+    TRY(dmalloc(h, &h->pos_s, n)); TRY(dmalloc(h, &h->posf_s, n));
+    if (h->n_slabs == 1) TRY(dmalloc(h, &h->pv, 3 * n));   // sharded runs exchange ghost rows of the plain vectors instead
+    TRY(dmalloc(h, &h->f_s, n)); TRY(dmalloc(h, &h->uw_s, n)); TRY(dmalloc(h, &h->ur_s, n));
     TRY(dmalloc(h, &h->ub_s, n)); TRY(dmalloc(h, &h->psi_s, n)); TRY(dmalloc(h, &h->w_s, n));
 
     std::vector<double> coef;
@@ -669,7 +672,7 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
     const int ncell = h->nc.nx * h->nc.ny * h->nc.nz;
     cell_sort(pos, group, N, h->dbox, h->nc, h->keys, h->vals, h->keys_s, h->cell_cnt, ncell, h->sort_tmp, h->sort_tmp_bytes,
               h->cell_off, h->perm, h->stream);
-    launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->f_s, h->tag_s, h->stream);
+    launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream);
     h->sorted_N = N;
     h->nb_valid = false;
     h->w_is_mpsi = false;
@@ -824,7 +827,8 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io) {
                     const bool ev = timed && h->timing;
                     launch_mreal_lanczos(h->pos_s, xj, h->w_s, lo, hi, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef,
                                          h->nb, LzFuse{vjm1, h->partials, h->npart_cap}, h->scal,
-                                         ev ? h->ph[PH_MATVEC].a : nullptr, ev ? h->ph[PH_MATVEC].b : nullptr, h->stream);
+                                         ev ? h->ph[PH_MATVEC].a : nullptr, ev ? h->ph[PH_MATVEC].b : nullptr, h->stream,
+                                         done > 0 ? h->pv : nullptr);   // x_j (j > 0) was packed by the previous update
                     if (timed) h->matvec_timed = true;
                 } else {
                     launch_lz_dots(xj, h->w_s, vjm1, lo, hi, h->partials, h->npart_cap, h->scal, h->stream);
@@ -837,7 +841,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io) {
                 row_range(h, N, lo, hi);
                 const double4 *xj = done == 0 ? h->psi_s : h->V + (size_t)done * stride;
                 launch_lz_update(xj, h->w_s, done > 0 ? h->V + (size_t)(done - 1) * stride : nullptr, h->V + (size_t)done * stride,
-                                 h->V + (size_t)(done + 1) * stride, done, h->scal, lo, hi, h->stream);
+                                 h->V + (size_t)(done + 1) * stride, done, h->scal, lo, hi, h->stream, h->pv);
             }
             const size_t off = (size_t)(done + 1) * stride;   // the next mat-vec reads x_{j+1} on the neighbouring cell layers too
             TRY(team_ghost_exchange(T, [&](pse_handle *h) { return (double *)(h->V + off); }));

@@ -15,7 +15,7 @@ void cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCell
                unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s);
 // pos_s[i] = wrapped position of particle perm[i], vec_s[i] = vec[tag].xyz, tag_s[i] = its index in the caller's arrays
 void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm, int N, DBox box,
-                    double4 *pos_s, float4 *posf_s, double4 *vec_s, unsigned *tag_s, hipStream_t s);
+                    double4 *pos_s, float4 *posf_s, double2 *pv, double4 *vec_s, unsigned *tag_s, hipStream_t s);
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s);
 
 // ---- near field (K9) -------------------------------------------------------------------------------------
@@ -48,7 +48,8 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
 // pair-list mat-vec + Lanczos sums; leaves the three reduced sums in scal[LZ_TMP .. LZ_TMP + 2]
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, int lo, int hi, const int *cell_off,
                           DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,
-                          double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s);   // events (nullable) bracket the mat-vec kernel
+                          double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s,   // events (nullable) bracket the mat-vec kernel
+                          const double2 *pv = nullptr);   // packed (position, vector) records holding vec_s, or null
 int mreal_partials_needed(int rows);
 
 // ---- far field (K2-K8) -----------------------------------------------------------------------------------
@@ -108,7 +109,7 @@ void launch_basis_combine(const double4 *V, size_t stride, const double *t_dev, 
 void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, int lo, int hi, double *partials, int cap,
                     double *scal, hipStream_t s);
 void launch_lz_update(const double4 *xin, const double4 *y, const double4 *vprev, double4 *vout, double4 *xnext, int j,
-                      double *scal, int lo, int hi, hipStream_t s);
+                      double *scal, int lo, int hi, hipStream_t s, double2 *pv = nullptr);   // pv: also refresh the packed records
 void launch_sum_rows(const double4 *a, const double4 *b, const double4 *c, double4 *out, int lo, int hi, hipStream_t s);
 void launch_pick(const int *cell_off, const int *idx, int n, int *out, hipStream_t s);
 // vel[tag].xyz = a + b + c (each may be null), keep w

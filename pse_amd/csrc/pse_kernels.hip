@@ -91,7 +91,7 @@ void cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCell
 
 __global__ void k_permute(const double4 *__restrict__ pos, const double4 *__restrict__ vec,
                           const unsigned *__restrict__ group, const unsigned *__restrict__ perm, int N, DBox box,
-                          double4 *__restrict__ pos_s, float4 *__restrict__ posf_s,
+                          double4 *__restrict__ pos_s, float4 *__restrict__ posf_s, double2 *__restrict__ pv,
                           double4 *__restrict__ vec_s, unsigned *__restrict__ tag_s) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N) return;
@@ -109,6 +109,10 @@ __global__ void k_permute(const double4 *__restrict__ pos, const double4 *__rest
     q.w = 0.0;
     pos_s[s] = q;
     posf_s[s] = make_float4((float)q.x, (float)q.y, (float)q.z, 0.0f);   // single-precision copy for the cutoff pre-filter
+    if (pv) {   // packed 48-byte (position, vector) records of the pair-list mat-vec: the position half
+        pv[3 * (size_t)s] = make_double2(q.x, q.y);
+        ((double *)&pv[3 * (size_t)s + 1])[0] = q.z;
+    }
     tag_s[s] = idx;
     if (vec) {
         double4 v = vec[idx];
@@ -127,8 +131,8 @@ __global__ void k_permute_vec(const double4 *__restrict__ vec, const unsigned *_
 }
 
 void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm, int N, DBox box,
-                    double4 *pos_s, float4 *posf_s, double4 *vec_s, unsigned *tag_s, hipStream_t s) {
-    hipLaunchKernelGGL(k_permute, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, vec, group, perm, N, box, pos_s, posf_s, vec_s, tag_s);
+                    double4 *pos_s, float4 *posf_s, double2 *pv, double4 *vec_s, unsigned *tag_s, hipStream_t s) {
+    hipLaunchKernelGGL(k_permute, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, vec, group, perm, N, box, pos_s, posf_s, pv, vec_s, tag_s);
 }
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s) {
     hipLaunchKernelGGL(k_permute_vec, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, vec, tag_s, N, vec_s);
@@ -375,10 +379,12 @@ k_mreal_overflow(const double4 *__restrict__ pos_s, const double4 *__restrict__ 
 // mat-vec from the pair list (one thread per particle, ELL layout: slot-major so a wave reads contiguous rows).
 // Per pair 20 B of list from HBM plus the neighbour's position and vector entry gathered through L2.  FUSE adds the
 // Lanczos epilogue (see LzFuse).
-template <bool FUSE, int UNROLL, int NT>
+// PACKED: neighbours are read from 48-byte (position, vector) records pv[j] = {(x,y), (z,vx), (vy,vz)}: three 16-byte
+// gathers per pair instead of the four of two 24-byte records (the kernel is bound by the L1 address path).
+template <bool FUSE, int UNROLL, int NT, bool PACKED>
 __global__ void __launch_bounds__(NT)
 k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int lo,
-             int hi, DBox box, int shift_only, double self, NbList nb, LzFuse lz) {
+             int hi, DBox box, int shift_only, double self, NbList nb, LzFuse lz, const double2 *__restrict__ pv) {
     __shared__ double shift[27 * 3];
     __shared__ double sh[4];
     if (threadIdx.x < 27) {
@@ -416,8 +422,15 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
                     const unsigned j = e[u] & JMASK;
-                    pj[u] = pos_s[j];
-                    Fj[u] = vec_s[j];
+                    if (PACKED) {
+                        const double2 *r = pv + 3 * (size_t)j;
+                        const double2 a = r[0], b = r[1], c = r[2];
+                        pj[u] = make_double4(a.x, a.y, b.x, 0.0);
+                        Fj[u] = make_double4(b.y, c.x, c.y, 0.0);
+                    } else {
+                        pj[u] = pos_s[j];
+                        Fj[u] = vec_s[j];
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
@@ -476,8 +489,8 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
         else hipLaunchKernelGGL((k_mreal_cells<true, false, false>), g, b, 0, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, nullptr, nullptr);
     } else if (mode == MREAL_USE_LIST) {
         hipLaunchKernelGGL(k_mreal_overflow, dim3(OVF_BLOCKS), b, 0, s, pos_s, vec_s, cell_off, box, nc, rcut * rcut, self, coef, nb);
-        hipLaunchKernelGGL((k_mreal_list<false, 4, TPB>), g, b, 0, s, pos_s, vec_s, out_s, lo, hi, box,
-                           (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1), self, nb, LzFuse{});
+        hipLaunchKernelGGL((k_mreal_list<false, 4, TPB, false>), g, b, 0, s, pos_s, vec_s, out_s, lo, hi, box,
+                           (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1), self, nb, LzFuse{}, nullptr);
     } else if (cl)
         hipLaunchKernelGGL((k_mreal_cells<false, true, false>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, nullptr, nullptr);
     else
@@ -488,12 +501,13 @@ __global__ void __launch_bounds__(1024) k_lz_reduce(const double *__restrict__ p
 int mreal_partials_needed(int rows) { return nblocks(std::max(rows, 1), TPB); }
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, int lo, int hi, const int *cell_off,
                           DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,
-                          double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s) {
+                          double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s, const double2 *pv) {
     const int so = (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1);
     const int nbk = nblocks(std::max(hi - lo, 1), TPB);
     hipLaunchKernelGGL(k_mreal_overflow, dim3(OVF_BLOCKS), dim3(TPB), 0, s, pos_s, vec_s, cell_off, box, nc, rcut * rcut, self, coef, nb);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
-    hipLaunchKernelGGL((k_mreal_list<true, 4, TPB>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz);
+    if (pv) hipLaunchKernelGGL((k_mreal_list<true, 4, TPB, true>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, pv);
+    else hipLaunchKernelGGL((k_mreal_list<true, 4, TPB, false>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, nullptr);
     if (ev_end) (void)hipEventRecord(ev_end, s);
     hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, lz.partials, nbk, lz.npart_cap, 3, scal);
 }
@@ -1417,7 +1431,8 @@ k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, d
 // alpha_j, beta_j from the reduced sums; v_j = x_j / beta_j (in place or from psi); x_{j+1} on the own rows
 __global__ void __launch_bounds__(TPB)
 k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, const double4 *__restrict__ vprev,
-            double4 *__restrict__ vout, double4 *__restrict__ xnext, int j, double *__restrict__ scal, int lo, int hi) {
+            double4 *__restrict__ vout, double4 *__restrict__ xnext, int j, double *__restrict__ scal, int lo, int hi,
+            double2 *__restrict__ pv) {
     const double s1 = scal[LZ_TMP], s2 = scal[LZ_TMP + 1], s3 = scal[LZ_TMP + 2];
     const double beta = s1 > 0.0 ? sqrt(s1) : 0.0;
     const double inv = beta > 0.0 ? 1.0 / beta : 0.0;
@@ -1433,6 +1448,10 @@ k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, cons
         if (vprev) { const double4 m = vprev[i]; nx -= beta * m.x; ny -= beta * m.y; nz -= beta * m.z; }
         vout[i] = make_double4(vx, vy, vz, 0.0);
         xnext[i] = make_double4(nx, ny, nz, 0.0);
+        if (pv) {   // the vector half of the packed records the next mat-vec gathers
+            ((double *)&pv[3 * (size_t)i + 1])[1] = nx;
+            pv[3 * (size_t)i + 2] = make_double2(ny, nz);
+        }
     }
 }
 void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, int lo, int hi, double *partials, int cap,
@@ -1442,9 +1461,9 @@ void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, in
     hipLaunchKernelGGL(k_lz_reduce, dim3(y ? 3 : 1), dim3(1024), 0, s, partials, g, cap, y ? 3 : 1, scal);
 }
 void launch_lz_update(const double4 *xin, const double4 *y, const double4 *vprev, double4 *vout, double4 *xnext, int j,
-                      double *scal, int lo, int hi, hipStream_t s) {
+                      double *scal, int lo, int hi, hipStream_t s, double2 *pv) {
     hipLaunchKernelGGL(k_lz_update, dim3(vec_grid(std::max(1, hi - lo))), dim3(TPB), 0, s, xin, y, vprev, vout, xnext, j, scal,
-                       lo, hi);
+                       lo, hi, pv);
 }
 // out[i] = a[i] + b[i] + c[i] on rows [lo, hi)  (each may be null)
 __global__ void k_sum_rows(const double4 *__restrict__ a, const double4 *__restrict__ b, const double4 *__restrict__ c,

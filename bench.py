@@ -192,7 +192,7 @@ def main():
                            for k in alg if per_launch_ms[k] > 0},
         "step_share_ms": {k[2:]: round(v, 4) for k, v in weight.items()},
     }
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:     # the CPU baseline is reported with the single-GPU line only
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))
     if use_dist:

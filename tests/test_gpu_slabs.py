@@ -96,3 +96,36 @@ def test_loopback_team_clustered_particles_and_odd_support(world, P):
     assert m == m_ref
     for r in range(world):
         assert rel(vels[r].cpu().numpy()[:, :3], v_ref.cpu().numpy()[:, :3]) < 1e-11, r
+
+
+def test_loopback_team_of_eight():
+    """The 8-rank layout of the scaling bench (slabs of 8 planes at 64^3: one far-field bin and 2 + 3 halo planes per rank,
+    eight cell slabs) against the single-GPU engine: M.F, Brownian velocity, and three full steps."""
+    import torch
+    import pse_amd
+    from pse_amd.sharded import LoopbackSimulation
+    n, world = 20000, 8
+    pos, force, box = make_suspension(n, phi=0.08)
+    kw = dict(xi=0.3, error=1e-3, seed=5, grid=(64, 64, 64))
+    ref = pse_amd.Engine(n, box, **kw)
+    assert ref.info()["ncell_x"] >= 8
+    sim = LoopbackSimulation(n, box, world, **kw)
+    sim.load(pos, force)
+    u_ref = ref.mobility(to4(pos), to4(force)).cpu().numpy()[:, :3]
+    vels = sim.mobility()
+    for r in range(world):
+        assert rel(vels[r].cpu().numpy()[:, :3], u_ref) < 1e-12, r
+    v_ref, m_ref = ref.brownian_velocity(to4(pos), to4(force), 1.0, 1e-3, 9)
+    vels, m = sim.brownian_velocity(1.0, 1e-3, 9)
+    assert m == m_ref
+    for r in range(world):
+        assert rel(vels[r].cpu().numpy()[:, :3], v_ref.cpu().numpy()[:, :3]) < 1e-11, r
+    # steps: every rank integrates all particles with the exchanged velocities -> replicas stay identical
+    p_ref, v0 = to4(pos, 0.0), to4(np.zeros((n, 3)), 1.0)
+    acc = torch.zeros((n, 3), dtype=torch.float64, device="cuda"); img = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+    m1 = m2 = 2
+    for ts in range(3):
+        m1 = ref.step(p_ref, v0, acc, img, to4(force), 1.0, 1e-3, ts, lanczos_m=m1)
+        m2 = sim.step(1.0, 1e-3, ts, lanczos_m=m2)
+    for r in range(world):
+        assert float((sim.s[r].pos - p_ref).abs().max()) < 1e-10, r

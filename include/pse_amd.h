@@ -135,9 +135,11 @@ int pse_debug_copy_grid(pse_handle *h, int stage, double *host_out);
  * Each rank is a handle created with pse_params.n_slabs = G and its own slab_rank.  The far-field grid is cut into
  * G slabs of x planes (the slowest index of the reference layout, PSEv1/Mobility.cu:233): spread and the 2-D (y,z)
  * transforms are slab-local, an all-to-all transposes to y-slabs for the 1-D x transforms and the k-space scaling,
- * and back; the gather takes P-1 halo planes from the next slab.  Near-field rows and Lanczos mat-vec rows are split
- * evenly over the ranks and all-gathered.  Particle arrays are replicated: every rank passes the same pos/force and
- * ends the call with the same vel/pos.
+ * and back; the gather takes (P-1)/2 halo planes from the previous slab and (P+1)/2 from the next.  The near-field cell
+ * layers along x are split the same way, so a rank owns one contiguous block of the cell-sorted rows: its near field,
+ * its rows of every Lanczos vector (one ghost cell layer per neighbour and one 3-scalar all-reduce per iteration) and
+ * its gathered velocities, exchanged once per call.  Particle arrays are replicated: every rank passes the same
+ * pos/force and ends the call with the same vel/pos.
  * A team binds the local ranks to a transport: one member per process + the RCCL unique id of rank 0 (production, one
  * process per GPU), or all G members in one process with id = NULL (in-process loopback on one device, for tests). */
 typedef struct pse_team pse_team;

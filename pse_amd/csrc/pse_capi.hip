@@ -73,7 +73,7 @@ struct pse_handle {
     size_t sort_tmp_bytes = 0;
     int *cell_off = nullptr;
     int4 *sup_s = nullptr;    // support origin of each sorted particle (node indices)
-    SpreadWork sw = {};       // separable weights + per-tile hit lists of the far field
+    SpreadWork sw = {};       // far-field bins and the bin-ordered particle records (origins, prefac * force, separable weights)
     NbList nb = {};
     bool nb_valid = false;   // the pair list matches the current sorted positions
     bool w_is_mpsi = false;  // w_s already holds M_real psi_s (delivered by the pass that built the pair list)

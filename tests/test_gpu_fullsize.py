@@ -75,3 +75,30 @@ def test_step_at_metric_point_moves_particles_and_counts_lanczos():
     # three Brownian steps of dt = 1e-3 with D ~ kT * (self mobility ~ 0.9): MSD ~ 6 D 3 dt ~ 0.016
     assert 0.003 < msd < 0.05, msd
     assert 4 <= m <= 20
+
+
+def test_four_rank_team_at_metric_point():
+    """The slab decomposition at full size (N = 1e6, 256^3, four ranks in one process): M.F and the Brownian velocity
+    against the single-GPU engine."""
+    import torch
+    import pse_amd
+    from pse_amd.sharded import LoopbackSimulation
+    n, grid, err = 1_000_000, 256, 1e-3
+    pos, force, box = make_suspension(n, phi=0.1)
+    xi = math.pi * grid / (2.0 * box[0] * math.sqrt(-math.log(err)))
+    kw = dict(xi=xi, error=err, seed=11, grid=(grid,) * 3)
+    ref = pse_amd.Engine(n, box, **kw)
+    u_ref = ref.mobility(to4(pos), to4(force)).cpu().numpy()[:, :3]
+    v_ref, m_ref = ref.brownian_velocity(to4(pos), to4(force), 1.0, 1e-3, 4)
+    v_ref = v_ref.cpu().numpy()[:, :3]
+    del ref
+    torch.cuda.empty_cache()
+    sim = LoopbackSimulation(n, box, 4, **kw)
+    sim.load(pos, force)
+    vels = sim.mobility()
+    assert rel(vels[0].cpu().numpy()[:, :3], u_ref) < 1e-12 and rel(vels[3].cpu().numpy()[:, :3], u_ref) < 1e-12
+    vels, m = sim.brownian_velocity(1.0, 1e-3, 4)
+    assert m == m_ref
+    assert rel(vels[1].cpu().numpy()[:, :3], v_ref) < 1e-10 and rel(vels[2].cpu().numpy()[:, :3], v_ref) < 1e-10
+    del sim
+    torch.cuda.empty_cache()

@@ -230,14 +230,8 @@ static int make_plans(pse_handle *h) {
     std::call_once(g_fft_once, [] { rocfft_setup(); });
     const DGrid &G = h->G;
     size_t work = 0, w = 0;
-    h->xfuse = h->n_slabs == 1 && xfuse_supported(G.Nx) && !getenv("PSE_NO_XFUSE");
+    h->xfuse = xfuse_supported(G.Nx) && !getenv("PSE_NO_XFUSE");   // x axis by k_xfft_scale (also after the slab transpose)
     if (h->xfuse) {
-        // 2-D (y,z) real transforms of all 3 Nx planes in one batch; the x axis is done by k_xfft_scale
-        const size_t len2[2] = {(size_t)G.Nz, (size_t)G.Ny};
-        FFTCHK(rocfft_plan_create(&h->plan_fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
-                                  rocfft_precision_double, 2, len2, (size_t)3 * G.Nx, nullptr));
-        FFTCHK(rocfft_plan_create(&h->plan_inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
-                                  rocfft_precision_double, 2, len2, (size_t)3 * G.Nx, nullptr));
         std::vector<double2> tw(G.Nx);
         for (int m = 0; m < G.Nx; ++m) {
             const long double ang = -2.0L * 3.14159265358979323846264338327950288L * m / G.Nx;
@@ -245,6 +239,14 @@ static int make_plans(pse_handle *h) {
         }
         TRY(dmalloc(h, &h->twiddle, (size_t)G.Nx));
         HIPCHK(hipMemcpy(h->twiddle, tw.data(), G.Nx * sizeof(double2), hipMemcpyHostToDevice));
+    }
+    if (h->xfuse && h->n_slabs == 1) {
+        // 2-D (y,z) real transforms of all 3 Nx planes in one batch
+        const size_t len2[2] = {(size_t)G.Nz, (size_t)G.Ny};
+        FFTCHK(rocfft_plan_create(&h->plan_fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                                  rocfft_precision_double, 2, len2, (size_t)3 * G.Nx, nullptr));
+        FFTCHK(rocfft_plan_create(&h->plan_inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                                  rocfft_precision_double, 2, len2, (size_t)3 * G.Nx, nullptr));
     } else if (h->n_slabs == 1) {
         // rocFFT lengths are fastest-first: z, y, x.  Real grids [3][Nx][Ny][Nz] -> half spectra [3][Nx][Ny][Nzh].
         const size_t len[3] = {(size_t)G.Nz, (size_t)G.Ny, (size_t)G.Nx};
@@ -482,24 +484,28 @@ struct pse_team {
 
 static bool loopback(const pse_team &T) { return T.G > 1 && !T.nccl; }
 
-// all-to-all of equal blocks: member r sends block q of send(r) to rank q, which stores it as block r of recv(q)
+// all-to-all of equal blocks, nset sets at once (one RCCL group): member r sends block q of set c of send(r) to rank q,
+// which stores it as block r of set c of recv(q); sets are set_stride doubles apart
 template <class FS, class FR>
-static int team_all_to_all(pse_team &T, FS send, FR recv, size_t blk_doubles) {
+static int team_all_to_all(pse_team &T, FS send, FR recv, size_t blk_doubles, int nset, size_t set_stride) {
     if (T.G == 1) return 0;
     if (T.nccl) {
         pse_handle *h = T.m[0];
         NCCLCHK(ncclGroupStart());
-        for (int q = 0; q < T.G; ++q) {
-            NCCLCHK(ncclSend(send(h) + (size_t)q * blk_doubles, blk_doubles, ncclDouble, q, T.nccl, h->stream));
-            NCCLCHK(ncclRecv(recv(h) + (size_t)q * blk_doubles, blk_doubles, ncclDouble, q, T.nccl, h->stream));
-        }
+        for (int c = 0; c < nset; ++c)
+            for (int q = 0; q < T.G; ++q) {
+                NCCLCHK(ncclSend(send(h) + c * set_stride + (size_t)q * blk_doubles, blk_doubles, ncclDouble, q, T.nccl, h->stream));
+                NCCLCHK(ncclRecv(recv(h) + c * set_stride + (size_t)q * blk_doubles, blk_doubles, ncclDouble, q, T.nccl, h->stream));
+            }
         NCCLCHK(ncclGroupEnd());
         return 0;
     }
-    for (pse_handle *src : T.m)
-        for (pse_handle *dst : T.m)
-            HIPCHK(hipMemcpyAsync(recv(dst) + (size_t)src->slab_rank * blk_doubles, send(src) + (size_t)dst->slab_rank * blk_doubles,
-                                  blk_doubles * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+    for (int c = 0; c < nset; ++c)
+        for (pse_handle *src : T.m)
+            for (pse_handle *dst : T.m)
+                HIPCHK(hipMemcpyAsync(recv(dst) + c * set_stride + (size_t)src->slab_rank * blk_doubles,
+                                      send(src) + c * set_stride + (size_t)dst->slab_rank * blk_doubles,
+                                      blk_doubles * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
     return 0;
 }
 // every rank's chunk [rank*chunk, (rank+1)*chunk) of buf becomes visible in every rank's buf
@@ -719,9 +725,8 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
         for (pse_handle *h : T.m) TRY(tsw(h, PH_COMM));
         pse_handle *h0 = T.m[0];
         const size_t blk = (size_t)h0->G.nxl * h0->nyl * h0->G.Nzh * 2, comp = blk * T.G;
-        for (int c = 0; c < 3; ++c)
-            TRY(team_all_to_all(T, [&](pse_handle *h) { return (double *)h->sendbuf + c * comp; },
-                                [&](pse_handle *h) { return (double *)h->recvbuf + c * comp; }, blk));
+        TRY(team_all_to_all(T, [&](pse_handle *h) { return (double *)h->sendbuf; }, [&](pse_handle *h) { return (double *)h->recvbuf; },
+                            blk, 3, comp));
         for (pse_handle *h : T.m) TRY(tew(h, PH_COMM));
     }
     for (pse_handle *h : T.m) {
@@ -743,9 +748,8 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
     if (T.G > 1) {
         pse_handle *h0 = T.m[0];
         const size_t blk = (size_t)h0->G.nxl * h0->nyl * h0->G.Nzh * 2, comp = blk * T.G;
-        for (int c = 0; c < 3; ++c)
-            TRY(team_all_to_all(T, [&](pse_handle *h) { return (double *)h->recvbuf + c * comp; },
-                                [&](pse_handle *h) { return (double *)h->sendbuf + c * comp; }, blk));
+        TRY(team_all_to_all(T, [&](pse_handle *h) { return (double *)h->recvbuf; }, [&](pse_handle *h) { return (double *)h->sendbuf; },
+                            blk, 3, comp));
     }
     for (pse_handle *h : T.m) {
         const DGrid &G = h->G;

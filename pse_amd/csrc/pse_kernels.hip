@@ -1275,10 +1275,14 @@ k_xfft_scale(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restri
     double2 *tw = d + 3 * KB * CS;                            // [N]  exp(-2 pi i m / N)
     const int tid = threadIdx.x;
     const int nkb = (G.Nzh + KB - 1) / KB;
-    const int j = blockIdx.x / nkb, k0 = (blockIdx.x - j * nkb) * KB;
+    // layout [Nx][rows][Nzh] per component: all Ny rows on a single GPU, the nyl rows [y0, y0 + nyl) of this rank after
+    // the slab transpose
+    const int rows = a.transposed ? a.nyl : G.Ny;
+    const int jl = blockIdx.x / nkb, k0 = (blockIdx.x - jl * nkb) * KB;
+    const int j = a.transposed ? a.y0 + jl : jl;
     const int kv = min(KB, G.Nzh - k0);
     double2 *comp[3] = {X, Y, Z};
-    const size_t xstride = (size_t)G.Ny * G.Nzh, base = (size_t)j * G.Nzh + k0;
+    const size_t xstride = (size_t)rows * G.Nzh, base = (size_t)jl * G.Nzh + k0;
     for (int e = tid; e < N; e += NTH) tw[e] = twiddle[e];
     for (int e = tid; e < 3 * N * KB; e += NTH) {             // KB consecutive kz are contiguous in memory (128 B at KB = 8)
         const int c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
@@ -1315,7 +1319,8 @@ static void launch_xfft_t(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box,
         attr_set = true;
     }
     const int nkb = (G.Nzh + KB - 1) / KB;
-    hipLaunchKernelGGL((k_xfft_scale<LOGN, KB, NTH>), dim3(G.Ny * nkb), dim3(NTH), lds, s, X, Y, Z, G, box, a, tw);
+    const int rows = a.transposed ? a.nyl : G.Ny;
+    hipLaunchKernelGGL((k_xfft_scale<LOGN, KB, NTH>), dim3(rows * nkb), dim3(NTH), lds, s, X, Y, Z, G, box, a, tw);
 }
 
 void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s) {

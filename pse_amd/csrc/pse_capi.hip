@@ -214,7 +214,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->plan_x_inv) rocfft_plan_destroy(h->plan_x_inv);
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
-    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cell_cnt, h->sup_s, h->sw.wtab_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->sw.sup_t, h->sw.f_t, h->nb.data, h->nb.cnt, h->nb.ovf_rows, h->nb.ovf_n, h->nb.ovf_out, h->pos_s, h->posf_s, h->pv,
+    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cell_cnt, h->sup_s, h->sw.wtab_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->sw.sup_t, h->sw.f_t, h->nb.data, h->nb.cnt, h->pos_s, h->posf_s, h->pv,
                     h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->twiddle, h->fft_work, h->V,
                     h->scal, h->partials, h->t_dev};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -366,8 +366,6 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         h->nb.cap = cap;
         if (cap > 0) {
             TRY(dmalloc(h, &h->nb.data, nb_list_bytes(n + 64, cap)));   // + one wave: rows are blocked from the rank's first row
-            TRY(dmalloc(h, &h->nb.ovf_rows, n)); TRY(dmalloc(h, &h->nb.ovf_n, 1)); TRY(dmalloc(h, &h->nb.ovf_out, n));
-            HIPCHK(hipMemset(h->nb.ovf_n, 0, sizeof(int)));
         }
         TRY(dmalloc(h, &h->nb.cnt, n));
     }

@@ -25,9 +25,7 @@ void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double
 // Row r = i - lo (lo: first row of the rank, fixed within a step); record (r / 64) * cap + slot.
 struct NbList {
     char *data;
-    int *cnt;             // neighbour count per particle; -(k+1) if it exceeded cap: overflow row k (recomputed from the cells)
-    int *ovf_rows, *ovf_n;   // overflow rows of this step and their number
-    double4 *ovf_out;     // their mat-vec results
+    int *cnt;             // neighbour count per particle; -1 if it exceeded cap (dense cluster): that row walks the cells
     int cap;
 };
 constexpr size_t NB_REC = 64 * 20;

@@ -149,7 +149,6 @@ void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double
 // drained pairs (j, f, (g-f)/r^2, r) are also written to a per-step ELL pair list that the Lanczos mat-vecs reuse
 // (positions do not change inside a step, PSEv1/Brownian.cu:473-521 recomputes them every iteration).
 constexpr int QCAP = 48;
-constexpr int OVF_BLOCKS = 32;
 constexpr unsigned JMASK = (1u << 27) - 1;
 
 // Workgroups b and b + 8 share an XCD (round-robin dispatch, /opt/skills/guides/MI355X_MICROARCH.md): hand each XCD a
@@ -333,46 +332,8 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
     out_s[i] = make_double4(ux, uy, uz, 0.0);
     if (TWO) out2_s[i] = make_double4(wx, wy, wz, 0.0);
     if (LIST) {
-        if (total > nb.cap) {   // the row did not fit: later mat-vecs of this step recompute it from the cells
-            const int k = atomicAdd(nb.ovf_n, 1);
-            nb.ovf_rows[k] = i;
-            total = -(k + 1);
-        }
+        if (total > nb.cap) total = -1;   // the row did not fit: the mat-vecs of this step walk the cells for it
         nb.cnt[i] = total;
-    }
-}
-
-// Rows whose neighbour count exceeded the list capacity: full cell walk, one thread per row, results parked in ovf_out
-// for k_mreal_list to pick up.  A fixed small grid; exits at once in the usual case of no overflow.
-__global__ void __launch_bounds__(TPB)
-k_mreal_overflow(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, const int *__restrict__ cell_off,
-                 DBox box, DCells nc, double rcut2, double self, const double *__restrict__ coef, NbList nb) {
-    const int n = *nb.ovf_n;
-    for (int k = blockIdx.x * TPB + threadIdx.x; k < n; k += gridDim.x * TPB) {
-        const int i = nb.ovf_rows[k];
-        const double4 pi = pos_s[i], vi = vec_s[i];
-        double ux = self * vi.x, uy = self * vi.y, uz = self * vi.z;
-        double fx, fy, fz;
-        frac_coords(box, pi.x, pi.y, pi.z, fx, fy, fz);
-        const int cx = cell_coord(fx, nc.nx), cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz);
-        for_each_run(nc, cell_off, cx, cy, cz, [&](int jb, int je, unsigned) {
-            for (int j = jb; j < je; ++j) {
-                const double4 pj = pos_s[j];
-                double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-                min_image(box, dx, dy, dz);
-                const double r2 = dx * dx + dy * dy + dz * dz;
-                if (r2 < rcut2 && j != i && r2 > 0.0) {
-                    double f, h;
-                    eval_fg(r2, coef, f, h);
-                    const double4 Fj = vec_s[j];
-                    const double rdF = (dx * Fj.x + dy * Fj.y + dz * Fj.z) * h;
-                    ux += f * Fj.x + rdF * dx;
-                    uy += f * Fj.y + rdF * dy;
-                    uz += f * Fj.z + rdF * dz;
-                }
-            }
-        });
-        nb.ovf_out[k] = make_double4(ux, uy, uz, 0.0);
     }
 }
 
@@ -384,7 +345,8 @@ k_mreal_overflow(const double4 *__restrict__ pos_s, const double4 *__restrict__ 
 template <bool FUSE, int UNROLL, int NT, bool PACKED>
 __global__ void __launch_bounds__(NT)
 k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int lo,
-             int hi, DBox box, int shift_only, double self, NbList nb, LzFuse lz, const double2 *__restrict__ pv) {
+             int hi, DBox box, int shift_only, double self, NbList nb, LzFuse lz, const double2 *__restrict__ pv,
+             const int *__restrict__ cell_off, DCells nc, double rcut2, const double *__restrict__ coef) {
     __shared__ double shift[27 * 3];
     __shared__ double sh[4];
     if (threadIdx.x < 27) {
@@ -447,8 +409,29 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
                 }
             }
         } else {
-            const double4 u = nb.ovf_out[-cnt - 1];
-            ux = u.x; uy = u.y; uz = u.z;
+            // the row did not fit the list (dense cluster): walk the cells, as the pass that built the list did
+            const double4 pi = pos_s[i];
+            ux = self * vi.x; uy = self * vi.y; uz = self * vi.z;
+            double fx, fy, fz;
+            frac_coords(box, pi.x, pi.y, pi.z, fx, fy, fz);
+            const int cx = cell_coord(fx, nc.nx), cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz);
+            for_each_run(nc, cell_off, cx, cy, cz, [&](int jb, int je, unsigned) {
+                for (int j = jb; j < je; ++j) {
+                    const double4 pj = pos_s[j];
+                    double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                    min_image(box, dx, dy, dz);
+                    const double r2 = dx * dx + dy * dy + dz * dz;
+                    if (r2 < rcut2 && j != i && r2 > 0.0) {
+                        double f, h;
+                        eval_fg(r2, coef, f, h);
+                        const double4 Fj = vec_s[j];
+                        const double rdF = (dx * Fj.x + dy * Fj.y + dz * Fj.z) * h;
+                        ux += f * Fj.x + rdF * dx;
+                        uy += f * Fj.y + rdF * dy;
+                        uz += f * Fj.z + rdF * dz;
+                    }
+                }
+            });
         }
     }
     if (FUSE) {   // x = vec (unnormalised Lanczos vector), y = M x: partial sums of x.x, x.y, x.v_{j-1}
@@ -483,14 +466,12 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
     const size_t cb = (size_t)ncoef * sizeof(double);
     const bool cl = cb <= 14 * 1024;   // with the 48 KB queue: two workgroups per CU
     if (mode == MREAL_BUILD_LIST) {
-        (void)hipMemsetAsync(nb.ovf_n, 0, sizeof(int), s);
         if (cl && vec2_s) hipLaunchKernelGGL((k_mreal_cells<true, true, true>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, vec2_s, out2_s);
         else if (cl) hipLaunchKernelGGL((k_mreal_cells<true, true, false>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, nullptr, nullptr);
         else hipLaunchKernelGGL((k_mreal_cells<true, false, false>), g, b, 0, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, nullptr, nullptr);
     } else if (mode == MREAL_USE_LIST) {
-        hipLaunchKernelGGL(k_mreal_overflow, dim3(OVF_BLOCKS), b, 0, s, pos_s, vec_s, cell_off, box, nc, rcut * rcut, self, coef, nb);
         hipLaunchKernelGGL((k_mreal_list<false, 4, TPB, false>), g, b, 0, s, pos_s, vec_s, out_s, lo, hi, box,
-                           (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1), self, nb, LzFuse{}, nullptr);
+                           (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1), self, nb, LzFuse{}, nullptr, cell_off, nc, rcut * rcut, coef);
     } else if (cl)
         hipLaunchKernelGGL((k_mreal_cells<false, true, false>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, nullptr, nullptr);
     else
@@ -504,10 +485,9 @@ void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w
                           double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s, const double2 *pv) {
     const int so = (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1);
     const int nbk = nblocks(std::max(hi - lo, 1), TPB);
-    hipLaunchKernelGGL(k_mreal_overflow, dim3(OVF_BLOCKS), dim3(TPB), 0, s, pos_s, vec_s, cell_off, box, nc, rcut * rcut, self, coef, nb);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
-    if (pv) hipLaunchKernelGGL((k_mreal_list<true, 4, TPB, true>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, pv);
-    else hipLaunchKernelGGL((k_mreal_list<true, 4, TPB, false>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, nullptr);
+    if (pv) hipLaunchKernelGGL((k_mreal_list<true, 4, TPB, true>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, pv, cell_off, nc, rcut * rcut, coef);
+    else hipLaunchKernelGGL((k_mreal_list<true, 4, TPB, false>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, nullptr, cell_off, nc, rcut * rcut, coef);
     if (ev_end) (void)hipEventRecord(ev_end, s);
     hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, lz.partials, nbk, lz.npart_cap, 3, scal);
 }

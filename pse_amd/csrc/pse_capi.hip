@@ -96,7 +96,8 @@ struct pse_handle {
     int *d_bidx = nullptr, *d_bounds = nullptr;              // slab mode: cell indices / row offsets of the cell-slab boundaries
     std::vector<int> row_lo, first_end, last_begin;          // per rank: own rows [row_lo[r], row_lo[r+1]), first / last cell layer
     double4 *utot_s = nullptr;                               // slab mode: summed velocity of the own rows, all-gathered
-    bool xfuse = false;                                      // single GPU, power-of-two Nx: 2-D rocFFT + fused x pass
+    bool xfuse = false;                                      // power-of-two Nx: fused x pass (k_xfft_scale)
+    int grid_slabs = 1;   // slabs the far-field grid is cut into: n_slabs, or 1 when every rank keeps the whole grid
     double2 *twiddle = nullptr;                              // [Nx] exp(-2 pi i m / Nx)
     void *fft_work = nullptr;
     size_t fft_work_bytes = 0;
@@ -240,14 +241,14 @@ static int make_plans(pse_handle *h) {
         TRY(dmalloc(h, &h->twiddle, (size_t)G.Nx));
         HIPCHK(hipMemcpy(h->twiddle, tw.data(), G.Nx * sizeof(double2), hipMemcpyHostToDevice));
     }
-    if (h->xfuse && h->n_slabs == 1) {
+    if (h->xfuse && h->grid_slabs == 1) {
         // 2-D (y,z) real transforms of all 3 Nx planes in one batch
         const size_t len2[2] = {(size_t)G.Nz, (size_t)G.Ny};
         FFTCHK(rocfft_plan_create(&h->plan_fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
                                   rocfft_precision_double, 2, len2, (size_t)3 * G.Nx, nullptr));
         FFTCHK(rocfft_plan_create(&h->plan_inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
                                   rocfft_precision_double, 2, len2, (size_t)3 * G.Nx, nullptr));
-    } else if (h->n_slabs == 1) {
+    } else if (h->grid_slabs == 1) {
         // rocFFT lengths are fastest-first: z, y, x.  Real grids [3][Nx][Ny][Nz] -> half spectra [3][Nx][Ny][Nzh].
         const size_t len[3] = {(size_t)G.Nz, (size_t)G.Ny, (size_t)G.Nx};
         FFTCHK(rocfft_plan_create(&h->plan_fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
@@ -313,19 +314,29 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     h->n_slabs = std::max(1, p->n_slabs);
     h->slab_rank = h->n_slabs > 1 ? p->slab_rank : 0;
     if (h->slab_rank < 0 || h->slab_rank >= h->n_slabs) return fail(PSE_ERR_INVALID, "slab_rank outside [0, n_slabs)");
+    // Far field of a team: slab-decomposed (2 all-to-alls per evaluation), or kept whole on every rank with only the near
+    // field and Lanczos sharded.  With two ranks the all-to-all is one xGMI link each way (101 MB per direction at 256^3:
+    // ~2 ms, longer than the far field itself), so two ranks replicate the far field; PSE_WAVE_MODE=slab|replicated overrides.
+    h->grid_slabs = h->n_slabs;
     if (h->n_slabs > 1) {
-        if (d.Nx % h->n_slabs || d.Ny % h->n_slabs)
-            return fail(PSE_ERR_INVALID, "slab decomposition needs Nx and Ny divisible by the number of ranks (%d x %d over %d)",
-                        d.Nx, d.Ny, h->n_slabs);
-        if (d.Nx / h->n_slabs < d.P)
-            return fail(PSE_ERR_INVALID, "slabs of %d planes are thinner than the support P = %d", d.Nx / h->n_slabs, d.P);
+        const char *mode = getenv("PSE_WAVE_MODE");
+        const bool replicate = mode ? !strcmp(mode, "replicated") : h->n_slabs == 2;
+        if (replicate) h->grid_slabs = 1;
     }
-    G.nxl = d.Nx / h->n_slabs; G.x0 = h->slab_rank * G.nxl;
+    if (h->grid_slabs > 1) {
+        if (d.Nx % h->grid_slabs || d.Ny % h->grid_slabs)
+            return fail(PSE_ERR_INVALID, "slab decomposition needs Nx and Ny divisible by the number of ranks (%d x %d over %d)",
+                        d.Nx, d.Ny, h->grid_slabs);
+        if (d.Nx / h->grid_slabs < d.P)
+            return fail(PSE_ERR_INVALID, "slabs of %d planes are thinner than the support P = %d", d.Nx / h->grid_slabs, d.P);
+    }
+    const int grid_rank = h->grid_slabs > 1 ? h->slab_rank : 0;
+    G.nxl = d.Nx / h->grid_slabs; G.x0 = grid_rank * G.nxl;
     // the gather of a particle is done by the rank whose slab holds the particle; its support reaches (P-1)/2 planes
     // below and (P+1)/2 planes above that slab: copies of the neighbours' planes are stored around the own ones
-    G.hl = h->n_slabs > 1 ? (d.P - 1) / 2 : 0;
-    G.nhalo = h->n_slabs > 1 ? (d.P + 1) / 2 : 0;
-    h->nyl = d.Ny / h->n_slabs; h->y0 = h->slab_rank * h->nyl;
+    G.hl = h->grid_slabs > 1 ? (d.P - 1) / 2 : 0;
+    G.nhalo = h->grid_slabs > 1 ? (d.P + 1) / 2 : 0;
+    h->nyl = d.Ny / h->grid_slabs; h->y0 = grid_rank * h->nyl;
     G.hx = d.hx; G.hy = d.hy; G.hz = d.hz;
     const double c = 2.0 * d.xi * d.xi / d.eta;
     G.expfac = c;                                      // PSEv1/Brownian.cu:829
@@ -382,8 +393,8 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
     TRY(dmalloc(h, &h->rgrid, 3 * nr));
     TRY(dmalloc(h, &h->cgrid, 3 * ncx));
+    if (h->grid_slabs > 1) { TRY(dmalloc(h, &h->sendbuf, 3 * ncx)); TRY(dmalloc(h, &h->recvbuf, 3 * ncx)); }
     if (h->n_slabs > 1) {
-        TRY(dmalloc(h, &h->sendbuf, 3 * ncx)); TRY(dmalloc(h, &h->recvbuf, 3 * ncx));
         TRY(dmalloc(h, &h->d_bidx, (size_t)3 * h->n_slabs + 1)); TRY(dmalloc(h, &h->d_bounds, (size_t)3 * h->n_slabs + 1));
         TRY(dmalloc(h, &h->utot_s, n));
     }
@@ -692,12 +703,13 @@ static ScaleArgs scale_args(pse_handle *h, bool noise, double kT, double dt, uns
     a.xi = h->d.xi; a.eta = h->d.eta; a.noise = noise ? 1 : 0;
     a.noise_fac = noise ? std::sqrt(2.0 * kT / dt / (G.hx * G.hy * G.hz)) : 0.0;   // PSEv1/Brownian.cu:197
     a.seed = h->par.seed; a.timestep = timestep;
-    a.transposed = h->n_slabs > 1 ? 1 : 0; a.y0 = h->y0; a.nyl = h->n_slabs > 1 ? h->nyl : G.Ny;
+    a.transposed = h->grid_slabs > 1 ? 1 : 0; a.y0 = h->y0; a.nyl = h->grid_slabs > 1 ? h->nyl : G.Ny;
     return a;
 }
 
 // wave-space part: spread -> FFT -> scale (+ noise) -> inverse FFT -> gather  (PSEv1/Brownian.cu:836-872)
 static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned timestep) {
+    const int GS = T.m[0]->grid_slabs;   // 1: every rank transforms the whole grid (single GPU, or a team that replicates it)
     for (pse_handle *h : T.m) {
         const DGrid &G = h->G;
         const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
@@ -707,7 +719,7 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
         launch_spread(h->pos_s, h->f_s, h->sup_s, N, gx, gy, gz, G, h->dbox, h->sw, h->wstream);
         TRY(tew(h, PH_SPREAD));
         TRY(tsw(h, PH_FFTF));
-        if (T.G == 1) {
+        if (GS == 1) {
             void *in[1] = {h->rgrid}, *out[1] = {h->cgrid};
             FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
         } else {
@@ -719,10 +731,10 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
         }
         TRY(tew(h, PH_FFTF));
     }
-    if (T.G > 1) {
+    if (GS > 1) {
         for (pse_handle *h : T.m) TRY(tsw(h, PH_COMM));
         pse_handle *h0 = T.m[0];
-        const size_t blk = (size_t)h0->G.nxl * h0->nyl * h0->G.Nzh * 2, comp = blk * T.G;
+        const size_t blk = (size_t)h0->G.nxl * h0->nyl * h0->G.Nzh * 2, comp = blk * GS;
         TRY(team_all_to_all(T, [&](pse_handle *h) { return (double *)h->sendbuf; }, [&](pse_handle *h) { return (double *)h->recvbuf; },
                             blk, 3, comp));
         for (pse_handle *h : T.m) TRY(tew(h, PH_COMM));
@@ -730,22 +742,22 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
     for (pse_handle *h : T.m) {
         const DGrid &G = h->G;
         const size_t ncx = (size_t)G.nxl * G.Ny * G.Nzh;
-        double2 *sp = T.G == 1 ? h->cgrid : h->recvbuf;   // [3][Nx][nyl][Nzh] after the transpose
+        double2 *sp = GS == 1 ? h->cgrid : h->recvbuf;   // [3][Nx][nyl][Nzh] after the transpose
         TRY(tsw(h, PH_SCALE));
         if (h->xfuse) {
             launch_xfft_scale(sp, sp + ncx, sp + 2 * ncx, G, h->dbox, scale_args(h, noise, kT, dt, timestep), h->twiddle, h->wstream);
         } else {
-            if (T.G > 1)
+            if (GS > 1)
                 for (int c = 0; c < 3; ++c) { void *io[1] = {sp + c * ncx}; FFTCHK(rocfft_execute(h->plan_x_fwd, io, nullptr, h->info_fwd)); }
             launch_scale(sp, sp + ncx, sp + 2 * ncx, G, h->dbox, scale_args(h, noise, kT, dt, timestep), h->wstream);
-            if (T.G > 1)
+            if (GS > 1)
                 for (int c = 0; c < 3; ++c) { void *io[1] = {sp + c * ncx}; FFTCHK(rocfft_execute(h->plan_x_inv, io, nullptr, h->info_inv)); }
         }
         TRY(tew(h, PH_SCALE));
     }
-    if (T.G > 1) {
+    if (GS > 1) {
         pse_handle *h0 = T.m[0];
-        const size_t blk = (size_t)h0->G.nxl * h0->nyl * h0->G.Nzh * 2, comp = blk * T.G;
+        const size_t blk = (size_t)h0->G.nxl * h0->nyl * h0->G.Nzh * 2, comp = blk * GS;
         TRY(team_all_to_all(T, [&](pse_handle *h) { return (double *)h->recvbuf; }, [&](pse_handle *h) { return (double *)h->sendbuf; },
                             blk, 3, comp));
     }
@@ -753,7 +765,7 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
         const DGrid &G = h->G;
         const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
         TRY(tsw(h, PH_FFTI));
-        if (T.G == 1) {
+        if (GS == 1) {
             void *in[1] = {h->cgrid}, *out[1] = {h->rgrid};
             FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv));
         } else {
@@ -765,7 +777,7 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
         }
         TRY(tew(h, PH_FFTI));
     }
-    TRY(team_halo_exchange(T));
+    if (GS > 1) TRY(team_halo_exchange(T));
     for (pse_handle *h : T.m) {
         const DGrid &G = h->G;
         const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz;
@@ -921,7 +933,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
             }
         TRY(wave(T, N, noise, kT, dt, timestep));
         *mask |= (1u << PH_SPREAD) | (1u << PH_FFTF) | (1u << PH_SCALE) | (1u << PH_FFTI) | (1u << PH_GATHER);
-        if (T.G > 1) *mask |= 1u << PH_COMM;
+        if (T.m[0]->grid_slabs > 1) *mask |= 1u << PH_COMM;
     }
     if (noise)   // psi first: the near-field pass that builds the pair list applies M_real to F and to psi together
         for (pse_handle *h : T.m) launch_psi(h->psi_s, h->tag_s, N, h->par.seed, timestep, h->stream);

@@ -63,6 +63,13 @@ class ShardedSimulation:
         self.team = Team([self.engine], unique_id=uid)
 
     def describe(self):
+        import os
+        mode = os.environ.get("PSE_WAVE_MODE") or ("replicated" if self.world == 2 else "slab")
+        if mode == "replicated":
+            return (f"{self.world} GPUs: far field kept whole on every rank (at two ranks the all-to-all would cross one xGMI link "
+                    f"each way), near field / Lanczos vectors owned by the rank whose cell slab holds the particle (neighbour "
+                    f"ghost-layer exchange + 3-scalar all-reduce per iteration), one velocity all-gather per step; particle "
+                    f"arrays replicated")
         return (f"{self.world} GPUs: far-field grid in {self.world} x-slabs (RCCL all-to-all transpose, two-sided plane halo for "
                 f"the gather), near field / Lanczos vectors / gather owned by the rank whose cell slab holds the particle "
                 f"(neighbour ghost-layer exchange + 3-scalar all-reduce per iteration), one velocity all-gather per step; "

@@ -13,10 +13,16 @@ def rel(a, b):
     return np.linalg.norm(a - b) / np.linalg.norm(b)
 
 
-@pytest.mark.parametrize("world,xy", [(2, 0.0), (4, 0.3), (3, 0.0)])
-def test_loopback_team_matches_single_gpu(world, xy):
+@pytest.mark.parametrize("world,xy,mode", [(2, 0.0, "slab"), (4, 0.3, "slab"), (3, 0.0, "slab"), (2, 0.3, None), (4, 0.0, "replicated")])
+def test_loopback_team_matches_single_gpu(world, xy, mode, monkeypatch):
+    """mode: far field slab-decomposed, or kept whole on every rank with only the near field sharded (None = the
+    library's choice: replicated for two ranks, slabs beyond)."""
     import pse_amd
     from pse_amd.sharded import LoopbackSimulation
+    if mode:
+        monkeypatch.setenv("PSE_WAVE_MODE", mode)
+    else:
+        monkeypatch.delenv("PSE_WAVE_MODE", raising=False)
     n = 3000
     pos, force, box = make_suspension(n, phi=0.1, xy=xy)
     grid = (48, 48, 40)                      # divisible by 2, 3, 4; slabs of >= 12 planes > P

@@ -103,7 +103,7 @@ struct pse_handle {
     size_t fft_work_bytes = 0;
     // Lanczos
     double4 *V = nullptr;        // [M_MAX + 1][n_max]
-    double *scal = nullptr, *partials = nullptr, *t_dev = nullptr;
+    double *scal = nullptr, *partials = nullptr;
     int npart_cap = 0;
     // bookkeeping
     pse_info info;
@@ -217,7 +217,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
     void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cell_cnt, h->sup_s, h->sw.wtab_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->sw.sup_t, h->sw.f_t, h->nb.data, h->nb.cnt, h->pos_s, h->posf_s, h->pv,
                     h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->twiddle, h->fft_work, h->V,
-                    h->scal, h->partials, h->t_dev};
+                    h->scal, h->partials};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &p : h->ph) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -415,7 +415,6 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     TRY(dmalloc(h, &h->V, (size_t)(M_MAX + 1) * n));
     TRY(dmalloc(h, &h->scal, (size_t)LZ_NSCAL)); h->npart_cap = std::max(LZ_NPART, mreal_partials_needed((int)n));
     TRY(dmalloc(h, &h->partials, (size_t)3 * h->npart_cap));
-    TRY(dmalloc(h, &h->t_dev, (size_t)M_MAX + 1));
     for (auto &ph : h->ph) { HIPCHK(hipEventCreate(&ph.a)); HIPCHK(hipEventCreate(&ph.b)); }
     h->info.device_bytes = h->bytes;
     return 0;
@@ -904,13 +903,13 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io) {
             return fail(PSE_ERR_NUMERIC, "tridiagonal eigen-solve failed at m = %d", m_final);
     }
     for (pse_handle *h : T.m) {
-        HIPCHK(hipMemcpyAsync(h->t_dev, t_cur.data(), m_final * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        BasisCoef tc{};
+        for (int q = 0; q < m_final; ++q) tc.t[q] = t_cur[q];
         int lo, hi;
         row_range(h, N, lo, hi);
-        launch_basis_combine(h->V, stride, h->t_dev, m_final, h->scal, scale, 1, h->ub_s, lo, hi, h->stream);   // Brownian.cu:716,739
+        launch_basis_combine(h->V, stride, tc, m_final, h->scal, scale, 1, h->ub_s, lo, hi, h->stream);   // Brownian.cu:716,739
         h->info.lanczos_m = m_final; h->info.lanczos_matvecs = done; h->info.lanczos_stepnorm = stepnorm;
     }
-    for (pse_handle *h : T.m) HIPCHK(hipStreamSynchronize(h->stream));   // t_cur is host memory that goes out of scope
     if (m_io) *m_io = m_final;
     return 0;
 }

@@ -99,7 +99,8 @@ constexpr int LZ_ALPHA = 0, LZ_BETA = 128, LZ_NORM = 256, LZ_TMP = 257, LZ_NSCAL
 constexpr int LZ_NPART = 1024;  // partial-sum slots
 // out_s = scale * sum_q t[q] V[q]
 // rows [lo, hi)
-void launch_basis_combine(const double4 *V, size_t stride, const double *t_dev, int m, const double *scal,
+struct BasisCoef { double t[104]; };   // the m <= 100 coefficients of the final combination, passed by value
+void launch_basis_combine(const double4 *V, size_t stride, const BasisCoef &t, int m, const double *scal,
                           double scale, int use_norm, double4 *out_s, int lo, int hi, hipStream_t s);
 // Lanczos iteration on the own rows [lo, hi) (see k_lz_update in pse_kernels.hip).  dots: sums of x.x, x.y, x.vprev ->
 // scal[LZ_TMP..+2] (y = null: x.x only), for mat-vecs that did not fuse them; [all-reduce by the caller when sharded];

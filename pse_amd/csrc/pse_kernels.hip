@@ -1475,8 +1475,9 @@ void launch_pick(const int *cell_off, const int *idx, int n, int *out, hipStream
 
 // K13 gpu_stokes_MatVecMultiply_kernel (PSEv1/Helper.cu:251-279) + the final rescale (PSEv1/Brownian.cu:739)
 __global__ void __launch_bounds__(TPB)
-k_basis_combine(const double4 *__restrict__ V, size_t stride, const double *__restrict__ t, int m,
+k_basis_combine(const double4 *__restrict__ V, size_t stride, BasisCoef tc, int m,
                 const double *__restrict__ scal, double scale, int use_norm, double4 *__restrict__ out, int lo, int N) {
+    const double *t = tc.t;   // kernel arguments: no host-to-device copy whose source the host would have to keep alive
     const double sc = use_norm ? scale * scal[LZ_NORM] : scale;
     for (int i = lo + blockIdx.x * TPB + threadIdx.x; i < N; i += gridDim.x * TPB) {
         double x = 0, y = 0, z = 0;
@@ -1488,7 +1489,7 @@ k_basis_combine(const double4 *__restrict__ V, size_t stride, const double *__re
         out[i] = make_double4(sc * x, sc * y, sc * z, 0.0);
     }
 }
-void launch_basis_combine(const double4 *V, size_t stride, const double *t_dev, int m, const double *scal,
+void launch_basis_combine(const double4 *V, size_t stride, const BasisCoef &t_dev, int m, const double *scal,
                           double scale, int use_norm, double4 *out_s, int lo, int hi, hipStream_t s) {
     hipLaunchKernelGGL(k_basis_combine, dim3(std::min(2048, std::max(1, nblocks(hi - lo, TPB)))), dim3(TPB), 0, s, V, stride,
                        t_dev, m, scal, scale, use_norm, out_s, lo, hi);

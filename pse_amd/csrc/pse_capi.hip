@@ -104,6 +104,7 @@ struct pse_handle {
     // Lanczos
     double4 *V = nullptr;        // [M_MAX + 1][n_max]
     double *scal = nullptr, *partials = nullptr;
+    double *sc_host = nullptr;   // pinned host copy of scal
     int npart_cap = 0;
     // bookkeeping
     pse_info info;
@@ -223,6 +224,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->sc_host) (void)hipHostFree(h->sc_host);
     delete h;
     return 0;
 }
@@ -413,7 +415,8 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     TRY(make_plans(h));
 
     TRY(dmalloc(h, &h->V, (size_t)(M_MAX + 1) * n));
-    TRY(dmalloc(h, &h->scal, (size_t)LZ_NSCAL)); h->npart_cap = std::max(LZ_NPART, mreal_partials_needed((int)n));
+    TRY(dmalloc(h, &h->scal, (size_t)LZ_NSCAL));
+    HIPCHK(hipHostMalloc((void **)&h->sc_host, LZ_NSCAL * sizeof(double), hipHostMallocDefault)); h->npart_cap = std::max(LZ_NPART, mreal_partials_needed((int)n));
     TRY(dmalloc(h, &h->partials, (size_t)3 * h->npart_cap));
     for (auto &ph : h->ph) { HIPCHK(hipEventCreate(&ph.a)); HIPCHK(hipEventCreate(&ph.b)); }
     h->info.device_bytes = h->bytes;
@@ -819,7 +822,8 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io) {
     int m_in = m_io ? *m_io : 2;
     if (m_in < 1) m_in = 1;
     if (m_in > M_MAX) m_in = M_MAX;
-    std::vector<double> sc(LZ_NSCAL), t_prev, t_cur;
+    std::vector<double> t_prev, t_cur;
+    double *sc = h0->sc_host;   // pinned: the read-back of the device scalars is one DMA, no staging copy
     int done = 0;                         // iterations launched so far
     int target = std::max(m_in, 2);       // first convergence check is at m = max(m_in, 2)   (Brownian.cu:465-466,606)
     int m_final = 0, checked = 0;
@@ -866,7 +870,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io) {
             launch_lz_dots(h->V + (size_t)done * stride, nullptr, nullptr, lo, hi, h->partials, h->npart_cap, h->scal, h->stream);
         }
         TRY(team_all_reduce_sum(T, [](pse_handle *h) { return h->scal + LZ_TMP; }, 1));
-        HIPCHK(hipMemcpyAsync(sc.data(), h0->scal, LZ_NSCAL * sizeof(double), hipMemcpyDeviceToHost, h0->stream));
+        HIPCHK(hipMemcpyAsync(sc, h0->scal, LZ_NSCAL * sizeof(double), hipMemcpyDeviceToHost, h0->stream));
         HIPCHK(hipStreamSynchronize(h0->stream));
         sc[LZ_BETA + done] = sc[LZ_TMP] > 0.0 ? std::sqrt(sc[LZ_TMP]) : 0.0;
         const double *alpha = &sc[LZ_ALPHA], *beta = &sc[LZ_BETA];

@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -65,6 +66,7 @@ struct pse_handle {
     hipStream_t wstream = nullptr;   // wave-space chain; == stream unless the two chains overlap (single GPU)
     hipStream_t side = nullptr;      // owned non-blocking stream behind wstream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_scal = nullptr;   // the Lanczos scalars have reached the pinned host buffer
     int n_max = 0, n_pad = 0;
     // sorted particle state
     unsigned *keys = nullptr, *keys_s = nullptr, *vals = nullptr, *perm = nullptr, *tag_s = nullptr;
@@ -222,6 +224,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &p : h->ph) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_scal) (void)hipEventDestroy(h->ev_scal);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->sc_host) (void)hipHostFree(h->sc_host);
@@ -416,7 +419,8 @@ static int create_impl(const pse_params *p, pse_handle *h) {
 
     TRY(dmalloc(h, &h->V, (size_t)(M_MAX + 1) * n));
     TRY(dmalloc(h, &h->scal, (size_t)LZ_NSCAL));
-    HIPCHK(hipHostMalloc((void **)&h->sc_host, LZ_NSCAL * sizeof(double), hipHostMallocDefault)); h->npart_cap = std::max(LZ_NPART, mreal_partials_needed((int)n));
+    HIPCHK(hipHostMalloc((void **)&h->sc_host, LZ_NSCAL * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_scal, hipEventDisableTiming)); h->npart_cap = std::max(LZ_NPART, mreal_partials_needed((int)n));
     TRY(dmalloc(h, &h->partials, (size_t)3 * h->npart_cap));
     for (auto &ph : h->ph) { HIPCHK(hipEventCreate(&ph.a)); HIPCHK(hipEventCreate(&ph.b)); }
     h->info.device_bytes = h->bytes;
@@ -816,7 +820,7 @@ static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*ou
 // M_real^{1/2} psi by Lanczos (PSEv1/Brownian.cu:357-765): psi_s (sorted order, replicated on every rank) ->
 // ub_s = scale |psi| V t on the rows this rank owns.  Scalars are replicated; vectors are valid on the own rows (+ the
 // neighbouring cell layers for the vector the next mat-vec reads).
-static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io) {
+static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, const std::function<int()> &before_first_wait = nullptr) {
     pse_handle *h0 = T.m[0];
     const size_t stride = h0->n_pad;
     int m_in = m_io ? *m_io : 2;
@@ -828,6 +832,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io) {
     int target = std::max(m_in, 2);       // first convergence check is at m = max(m_in, 2)   (Brownian.cu:465-466,606)
     int m_final = 0, checked = 0;
     double stepnorm = 1.0;
+    bool hook_done = false;
     while (true) {
         for (; done < target; ++done) {
             // iteration j = done on the unnormalised x_j (psi for j = 0, else parked in V[j]); see k_lz_update
@@ -871,7 +876,13 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io) {
         }
         TRY(team_all_reduce_sum(T, [](pse_handle *h) { return h->scal + LZ_TMP; }, 1));
         HIPCHK(hipMemcpyAsync(sc, h0->scal, LZ_NSCAL * sizeof(double), hipMemcpyDeviceToHost, h0->stream));
-        HIPCHK(hipStreamSynchronize(h0->stream));
+        HIPCHK(hipEventRecord(h0->ev_scal, h0->stream));
+        if (!hook_done) {   // independent work queued behind the read-back keeps the GPU busy while the host decides
+            hook_done = true;
+            for (pse_handle *h : T.m) TRY(te(h, PH_LANCZOS));
+            if (before_first_wait) TRY(before_first_wait());
+        }
+        HIPCHK(hipEventSynchronize(h0->ev_scal));
         sc[LZ_BETA + done] = sc[LZ_TMP] > 0.0 ? std::sqrt(sc[LZ_TMP]) : 0.0;
         const double *alpha = &sc[LZ_ALPHA], *beta = &sc[LZ_BETA];
         if (!(sc[LZ_NORM] > 0.0) || !std::isfinite(sc[LZ_NORM])) {   // psi == 0 -> result 0
@@ -928,7 +939,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
     for (size_t r = 0; r < T.m.size(); ++r) TRY(prepare(T.m[r], a[r].pos, a[r].force, group, N));
     *mask |= 1u << PH_SORT;
     const bool noise = kT > 0.0;
-    if (parts & 2) {
+    auto wave_chain = [&]() -> int {
         for (pse_handle *h : T.m)
             if (h->side) {   // fork: the wave chain starts once the sorted arrays exist
                 HIPCHK(hipEventRecord(h->ev_fork, h->stream));
@@ -937,7 +948,12 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
         TRY(wave(T, N, noise, kT, dt, timestep));
         *mask |= (1u << PH_SPREAD) | (1u << PH_FFTF) | (1u << PH_SCALE) | (1u << PH_FFTI) | (1u << PH_GATHER);
         if (T.m[0]->grid_slabs > 1) *mask |= 1u << PH_COMM;
-    }
+        return 0;
+    };
+    // With noise on one stream the wave chain is queued BEHIND the Lanczos iterations: the host has to read their scalars
+    // back before it can finish the Brownian part, and meanwhile the GPU works through the far field instead of idling.
+    const bool wave_behind = noise && (parts & 2) && (parts & 1) && !T.m[0]->side;
+    if ((parts & 2) && !wave_behind) TRY(wave_chain());
     if (noise)   // psi first: the near-field pass that builds the pair list applies M_real to F and to psi together
         for (pse_handle *h : T.m) launch_psi(h->psi_s, h->tag_s, N, h->par.seed, timestep, h->stream);
     if (parts & 1) {
@@ -947,10 +963,9 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
         *mask |= 1u << PH_REAL;
     }
     if (noise) {
-        for (pse_handle *h : T.m) TRY(ts(h, PH_LANCZOS));
+        for (pse_handle *h : T.m) TRY(ts(h, PH_LANCZOS));   // closed inside lanczos(), after the first batch of iterations
         for (pse_handle *h : T.m) h->matvec_timed = false;
-        TRY(lanczos(T, N, T.m[0]->d.error, std::sqrt(2.0 * kT / dt), m_io));
-        for (pse_handle *h : T.m) TRY(te(h, PH_LANCZOS));
+        TRY(lanczos(T, N, T.m[0]->d.error, std::sqrt(2.0 * kT / dt), m_io, wave_behind ? std::function<int()>(wave_chain) : nullptr));
         *mask |= 1u << PH_LANCZOS;
         if (T.m[0]->matvec_timed) *mask |= 1u << PH_MATVEC;
     }

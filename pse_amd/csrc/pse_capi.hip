@@ -66,6 +66,8 @@ struct pse_handle {
     hipStream_t wstream = nullptr;   // wave-space chain; == stream unless the two chains overlap (single GPU)
     hipStream_t side = nullptr;      // owned non-blocking stream behind wstream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap_all = false;   // fork also for Brownian steps (PSE_OVERLAP=1)
+    bool side_on = false;       // this call runs the wave chain on the side stream
     hipEvent_t ev_scal = nullptr;   // the Lanczos scalars have reached the pinned host buffer
     int n_max = 0, n_pad = 0;
     // sorted particle state
@@ -407,13 +409,15 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     // final sum: on a single GPU they run on two streams, so latency-bound kernels of one chain fill the gaps of the
     // other and the Lanczos host checks do not stall the far field.  (Teams keep one stream: one RCCL communicator.)
     h->wstream = h->stream;
-    // Opt-in (PSE_OVERLAP=1): it shortens the step by ~8 % (6.0 vs 6.5 ms at N = 1e6) but every kernel then shares the
-    // chip, so per-kernel durations -- the roofline evidence -- are no longer those of the kernel alone.
-    if (h->n_slabs == 1 && getenv("PSE_OVERLAP") && atoi(getenv("PSE_OVERLAP")) > 0) {
+    // A deterministic evaluation (kT = 0: no Lanczos) always forks: near field and far field are then the only two pieces
+    // and nothing is timed per kernel.  For Brownian steps the fork is opt-in (PSE_OVERLAP=1): it shortens the step by
+    // ~8 % but every kernel then shares the chip, so per-kernel durations -- the roofline evidence -- are no longer those
+    // of the kernel alone; by default the far field is queued behind the Lanczos iterations on the one stream instead.
+    if (h->n_slabs == 1 && !(getenv("PSE_OVERLAP") && atoi(getenv("PSE_OVERLAP")) < 0)) {
         HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-        h->wstream = h->side;
+        h->overlap_all = getenv("PSE_OVERLAP") && atoi(getenv("PSE_OVERLAP")) > 0;
     }
     TRY(make_plans(h));
 
@@ -460,7 +464,7 @@ extern "C" int pse_set_box(pse_handle *h, double Lx, double Ly, double Lz, doubl
 extern "C" int pse_set_stream(pse_handle *h, void *stream) {
     if (!h) return fail(PSE_ERR_INVALID, "null handle");
     h->stream = (hipStream_t)stream;
-    if (!h->side) {
+    if (!h->side_on) {
         h->wstream = h->stream;
         FFTCHK(rocfft_execution_info_set_stream(h->info_fwd, h->wstream));
         FFTCHK(rocfft_execution_info_set_stream(h->info_inv, h->wstream));
@@ -939,9 +943,18 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
     for (size_t r = 0; r < T.m.size(); ++r) TRY(prepare(T.m[r], a[r].pos, a[r].force, group, N));
     *mask |= 1u << PH_SORT;
     const bool noise = kT > 0.0;
+    for (pse_handle *h : T.m) {   // where the wave chain of this call runs
+        const bool on = h->side && parts == 3 && (h->overlap_all || (!noise && !h->timing));
+        if (on != h->side_on || h->wstream != (on ? h->side : h->stream)) {
+            h->side_on = on;
+            h->wstream = on ? h->side : h->stream;
+            FFTCHK(rocfft_execution_info_set_stream(h->info_fwd, h->wstream));
+            FFTCHK(rocfft_execution_info_set_stream(h->info_inv, h->wstream));
+        }
+    }
     auto wave_chain = [&]() -> int {
         for (pse_handle *h : T.m)
-            if (h->side) {   // fork: the wave chain starts once the sorted arrays exist
+            if (h->side_on) {   // fork: the wave chain starts once the sorted arrays exist
                 HIPCHK(hipEventRecord(h->ev_fork, h->stream));
                 HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
             }
@@ -952,7 +965,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
     };
     // With noise on one stream the wave chain is queued BEHIND the Lanczos iterations: the host has to read their scalars
     // back before it can finish the Brownian part, and meanwhile the GPU works through the far field instead of idling.
-    const bool wave_behind = noise && (parts & 2) && (parts & 1) && !T.m[0]->side;
+    const bool wave_behind = noise && (parts & 2) && (parts & 1) && !T.m[0]->side_on;
     if ((parts & 2) && !wave_behind) TRY(wave_chain());
     if (noise)   // psi first: the near-field pass that builds the pair list applies M_real to F and to psi together
         for (pse_handle *h : T.m) launch_psi(h->psi_s, h->tag_s, N, h->par.seed, timestep, h->stream);
@@ -981,7 +994,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
     }
     for (size_t r = 0; r < T.m.size(); ++r) {
         pse_handle *h = T.m[r];
-        if ((parts & 2) && h->side) {   // join
+        if ((parts & 2) && h->side_on) {   // join
             HIPCHK(hipEventRecord(h->ev_join, h->side));
             HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         }

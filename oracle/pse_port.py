@@ -396,14 +396,23 @@ def wrap(pos, image, box):
     return pos, image
 
 
+def min_image(d, box):
+    """Minimum image of separation vectors d[..., 3] in the xy-tilted cell: wrap z, then y (a y image shifts x by xy*Ly),
+    then x -- HOOMD's BoxDim::minImage as used at PSEv1/Mobility.cu:648 (restated: the source is not in the tree).
+    Exact for |d_true| < half the smallest cell height and |xy| <= 0.5."""
+    Lx, Ly, Lz, xy = box
+    d = np.array(d, dtype=float, copy=True)
+    n = np.rint(d[..., 2] / Lz); d[..., 2] -= n * Lz
+    n = np.rint(d[..., 1] / Ly); d[..., 1] -= n * Ly; d[..., 0] -= n * xy * Ly
+    n = np.rint(d[..., 0] / Lx); d[..., 0] -= n * Lx
+    return d
+
+
 def pair_repulsion(pos, box, k, sigma=2.0):
     """Soft repulsion k (sigma - r) r_hat over minimum-image pairs with r < sigma (the force provider of SURVEY.md 8 f4;
     O(N^2), triclinic minimum image as in HOOMD: y images shift x by xy*Ly)."""
     Lx, Ly, Lz, xy = box
-    d = pos[:, None, :] - pos[None, :, :]
-    n = np.rint(d[..., 2] / Lz); d[..., 2] -= n * Lz
-    n = np.rint(d[..., 1] / Ly); d[..., 1] -= n * Ly; d[..., 0] -= n * xy * Ly
-    n = np.rint(d[..., 0] / Lx); d[..., 0] -= n * Lx
+    d = min_image(pos[:, None, :] - pos[None, :, :], box)
     r = np.linalg.norm(d, axis=2)
     with np.errstate(divide="ignore", invalid="ignore"):
         c = np.where((r < sigma) & (r > 0.0), k * (sigma - r) / r, 0.0)

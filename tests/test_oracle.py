@@ -176,3 +176,20 @@ def test_golden_fixture(oracle):
     assert np.abs(ub - np.array(g["u_brownian_port"])).max() < 1e-9 * np.abs(ub).max()
     assert [int(x) for x in oracle.philox4x32(1, 2, 3, 4, 5, 6)] == g["philox_1_2_3_4_5_6"]
     assert oracle.hash_seed(1) == g["hash_seed_1"]
+
+
+def test_min_image_property(oracle):
+    """the triclinic minimum image (wrap y first, shifting x by xy*Ly, then x) recovers any separation
+    shorter than the near-field cutoff from all of its periodic images, for tilts up to |xy| = 0.5."""
+    rng = np.random.default_rng(8)
+    for xy in (0.0, 0.2, -0.35, 0.5, -0.5):
+        box = (20.0, 16.0, 24.0, xy)
+        a1, a2, a3 = np.array([20.0, 0, 0]), np.array([xy * 16.0, 16.0, 0]), np.array([0, 0, 24.0])
+        d = rng.normal(size=(4000, 3)); d *= (rng.uniform(0, 6.0, size=(4000, 1)) / np.linalg.norm(d, axis=1, keepdims=True))
+        k = rng.integers(-3, 4, size=(4000, 3))
+        shifted = d + k[:, :1] * a1 + k[:, 1:2] * a2 + k[:, 2:] * a3
+        back = oracle.min_image(shifted, box)
+        assert np.abs(back - d).max() < 1e-12
+        if xy == 0.0:      # orthogonal cell: the wrapped vector is never longer (not true of a sequential wrap in a tilted cell)
+            far = rng.uniform(-60, 60, size=(4000, 3))
+            assert np.all(np.linalg.norm(oracle.min_image(far, box), axis=1) <= np.linalg.norm(far, axis=1) + 1e-12)

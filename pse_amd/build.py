@@ -37,7 +37,7 @@ def _run(cmd):
 def _all_sources():
     out = []
     for root, _, files in os.walk(CSRC):
-        out += [os.path.join(root, f) for f in files]
+        out += [os.path.join(root, f) for f in files if f.endswith((".hip", ".h", ".cpp", ".cc"))]
     out.append(os.path.join(HERE, "..", "include", "pse_amd.h"))
     out.append(os.path.abspath(__file__))
     return out

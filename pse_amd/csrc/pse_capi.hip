@@ -47,6 +47,12 @@ static int fail(int code, const char *fmt, ...) {
         if (s_ != rocfft_status_success) return fail(PSE_ERR_FFT, "%s failed: rocfft status %d (%s:%d)", #x, (int)s_, __FILE__, __LINE__); \
     } while (0)
 
+#define TRY(x)              \
+    do {                    \
+        int r_ = (x);       \
+        if (r_) return r_;  \
+    } while (0)
+
 constexpr int M_MAX = 100;   // Lanczos basis cap (PSEv1/Brownian.cu:397)
 
 struct Phase {
@@ -129,33 +135,32 @@ static int dmalloc(pse_handle *h, T **p, size_t n) {
     h->bytes += n * sizeof(T);
     return 0;
 }
-#define TRY(x)              \
-    do {                    \
-        int r_ = (x);       \
-        if (r_) return r_;  \
-    } while (0)
-
 static void set_dbox(pse_handle *h) {
     h->dbox = DBox{h->box.Lx, h->box.Ly, h->box.Lz, h->box.xy, 1.0 / h->box.Lx, 1.0 / h->box.Ly, 1.0 / h->box.Lz};
 }
 
 // cells of at least rcut perpendicular width for tilts up to gamma; a dimension with fewer than 3 cells uses 1
-static int set_cells(pse_handle *h, double gamma) {
-    const double rc = h->d.rcut;
-    const double wx = h->box.Lx / std::sqrt(1.0 + gamma * gamma), wy = h->box.Ly, wz = h->box.Lz;
+static int cells_for(const Box &box, double rc, double gamma, int n_slabs, DCells &out) {
+    const double wx = box.Lx / std::sqrt(1.0 + gamma * gamma), wy = box.Ly, wz = box.Lz;
     if (rc > 0.5 * wx * (1 + 1e-12) || rc > 0.5 * wy * (1 + 1e-12) || rc > 0.5 * wz * (1 + 1e-12))
         return fail(PSE_ERR_INVALID, "real-space cutoff %.4f exceeds half the box width (%.4f, %.4f, %.4f at tilt %.3f): "
                     "the minimum-image near field needs rcut <= L/2; increase xi", rc, wx, wy, wz, gamma);
     auto n = [&](double w) { int c = (int)std::floor(w / rc); if (c < 3) c = 1; if (c > 1024) c = 1024; return c; };
-    h->nc = DCells{n(wx), n(wy), n(wz)};
-    if (h->n_slabs > 1) {
+    out = DCells{n(wx), n(wy), n(wz)};
+    if (n_slabs > 1) {
         // cell slabs coincide with grid slabs: every rank owns ncx/G whole cell layers = one contiguous row range
-        const int c = (int)std::floor(wx / rc) / h->n_slabs * h->n_slabs;
-        if (c < 3 || c < h->n_slabs)
+        const int c = (int)std::floor(wx / rc) / n_slabs * n_slabs;
+        if (c < 3 || c < n_slabs)
             return fail(PSE_ERR_INVALID, "box too small to split the near field over %d ranks: only %d cells of width >= rcut "
-                        "fit along x", h->n_slabs, (int)std::floor(wx / rc));
-        h->nc.nx = std::min(c, 1024 / h->n_slabs * h->n_slabs);
+                        "fit along x", n_slabs, (int)std::floor(wx / rc));
+        out.nx = std::min(c, 1024 / n_slabs * n_slabs);
     }
+    return 0;
+}
+static int set_cells(pse_handle *h, double gamma) {
+    DCells nc;
+    TRY(cells_for(h->box, h->d.rcut, gamma, h->n_slabs, nc));
+    h->nc = nc;
     h->cell_gamma = gamma;
     return 0;
 }
@@ -444,18 +449,21 @@ extern "C" int pse_create(const pse_params *p, pse_handle **out) {
 extern "C" int pse_set_box(pse_handle *h, double Lx, double Ly, double Lz, double xy) {
     if (!h) return fail(PSE_ERR_INVALID, "null handle");
     if (!(Lx > 0 && Ly > 0 && Lz > 0)) return fail(PSE_ERR_INVALID, "box lengths must be positive");
-    const Box old = h->box;
-    h->box = Box{Lx, Ly, Lz, xy};
-    // the grid, P and eta were chosen for the creation box (the reference also fixes them in setParams and only
-    // recomputes wave vectors per step, PSEv1/Stokes.cu:298); lengths may change only by re-deriving h
+    // Nothing of the handle changes unless every check passes: the candidate cell grid is computed on the side.
+    // The grid, P and eta were chosen for the creation box (the reference also fixes them in setParams and only
+    // recomputes wave vectors per step, PSEv1/Stokes.cu:298); lengths may change only by re-deriving h.
+    const Box nb{Lx, Ly, Lz, xy};
+    const double gamma = std::max(std::fabs(xy), h->par.max_strain);
+    DCells nc;
+    TRY(cells_for(nb, h->d.rcut, gamma, h->n_slabs, nc));
+    if ((size_t)nc.nx * nc.ny * nc.nz > h->n_cells_alloc)
+        return fail(PSE_ERR_INVALID, "box grew beyond the cell-list capacity sized at creation");
+    h->box = nb;
+    h->nc = nc;
+    h->cell_gamma = gamma;
     h->d.hx = Lx / h->d.Nx; h->d.hy = Ly / h->d.Ny; h->d.hz = Lz / h->d.Nz;
     h->G.hx = h->d.hx; h->G.hy = h->d.hy; h->G.hz = h->d.hz;
     set_dbox(h);
-    const double gamma = std::max(std::fabs(xy), h->par.max_strain);
-    int r = set_cells(h, gamma);
-    if (!r && (size_t)h->nc.nx * h->nc.ny * h->nc.nz > h->n_cells_alloc)
-        r = fail(PSE_ERR_INVALID, "box grew beyond the cell-list capacity sized at creation");
-    if (r) { h->box = old; set_dbox(h); return r; }
     h->info.ncell_x = h->nc.nx; h->info.ncell_y = h->nc.ny; h->info.ncell_z = h->nc.nz;
     h->info.hx = h->d.hx; h->info.hy = h->d.hy; h->info.hz = h->d.hz;
     return 0;
@@ -1178,9 +1186,21 @@ extern "C" int pse_team_unique_id(void *id128_host) {
     return 0;
 }
 
+extern "C" int pse_team_destroy(pse_team *T);
+// RCCL communicator of a one-member-per-process team (in-process teams have nothing to connect)
+static int team_connect(pse_team *T, const void *id128_host) {
+    if (T->m.size() != 1 || !id128_host) return 0;
+    ncclUniqueId id;
+    memcpy(&id, id128_host, sizeof id);
+    HIPCHK(hipSetDevice(T->m[0]->device));
+    NCCLCHK(ncclCommInitRank(&T->nccl, T->G, id, T->m[0]->slab_rank));
+    return 0;
+}
+
 extern "C" int pse_team_create(pse_handle **members, int n_members, const void *id128_host, pse_team **out) {
     if (!members || n_members < 1 || !out) return fail(PSE_ERR_INVALID, "bad argument");
     *out = nullptr;
+    if (!members[0]) return fail(PSE_ERR_INVALID, "null member");
     const int G = members[0]->n_slabs;
     std::vector<char> seen(G, 0);
     for (int i = 0; i < n_members; ++i) {
@@ -1191,20 +1211,16 @@ extern "C" int pse_team_create(pse_handle **members, int n_members, const void *
         if (seen[h->slab_rank]) return fail(PSE_ERR_INVALID, "slab rank %d appears twice", h->slab_rank);
         seen[h->slab_rank] = 1;
     }
+    if (n_members == 1 && (G > 1 || id128_host)) {
+        if (!id128_host) return fail(PSE_ERR_INVALID, "a one-rank-per-process team needs the RCCL unique id of rank 0");
+    } else if (n_members != G) {
+        return fail(PSE_ERR_INVALID, "an in-process team must hold all %d slab ranks (got %d)", G, n_members);
+    }
     pse_team *T = new pse_team();
     T->m.assign(members, members + n_members);
     T->G = G;
-    if (n_members == 1 && (G > 1 || id128_host)) {
-        if (!id128_host) { delete T; return fail(PSE_ERR_INVALID, "a one-rank-per-process team needs the RCCL unique id of rank 0"); }
-        ncclUniqueId id;
-        memcpy(&id, id128_host, sizeof id);
-        HIPCHK(hipSetDevice(members[0]->device));
-        ncclResult_t r = ncclCommInitRank(&T->nccl, G, id, members[0]->slab_rank);
-        if (r != ncclSuccess) { delete T; return fail(PSE_ERR_COMM, "ncclCommInitRank failed: %s", ncclGetErrorString(r)); }
-    } else if (n_members != G) {
-        delete T;
-        return fail(PSE_ERR_INVALID, "an in-process team must hold all %d slab ranks (got %d)", G, n_members);
-    }
+    int rc = team_connect(T, id128_host);
+    if (rc) { std::string keep = g_err; pse_team_destroy(T); g_err = keep; return rc; }
     *out = T;
     return 0;
 }

@@ -1415,8 +1415,8 @@ k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, d
 }
 // alpha_j, beta_j from the reduced sums; v_j = x_j / beta_j (in place or from psi); x_{j+1} on the own rows
 __global__ void __launch_bounds__(TPB)
-k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, const double4 *__restrict__ vprev,
-            double4 *__restrict__ vout, double4 *__restrict__ xnext, int j, double *__restrict__ scal, int lo, int hi,
+k_lz_update(const double4 *xin /* may alias vout: normalised in place */, const double4 *__restrict__ y,
+            const double4 *__restrict__ vprev, double4 *vout, double4 *__restrict__ xnext, int j, double *__restrict__ scal, int lo, int hi,
             double2 *__restrict__ pv) {
     const double s1 = scal[LZ_TMP], s2 = scal[LZ_TMP + 1], s3 = scal[LZ_TMP + 2];
     const double beta = s1 > 0.0 ? sqrt(s1) : 0.0;

@@ -22,6 +22,22 @@ def _chk4(t, name, n=None):
         raise ValueError(f"{name} has fewer than {n} rows")
 
 
+def _chk_group(g, name="group"):
+    import torch
+    if g is None:
+        return
+    if not (isinstance(g, torch.Tensor) and g.is_cuda and g.dtype in (torch.int32, torch.uint32) and g.dim() == 1
+            and g.is_contiguous()):
+        raise ValueError(f"{name} must be a contiguous 1-D int32/uint32 CUDA tensor (the C-ABI reads unsigned int indices)")
+
+
+def _chk_arr(t, name, cols, dtype, n):
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.dim() == 2 and t.shape[1] == cols
+            and t.is_contiguous() and t.shape[0] >= n):
+        raise ValueError(f"{name} must be a contiguous (N>={n},{cols}) {dtype} CUDA tensor")
+
+
 def host_select_params(box, xi=0.5, error=1e-3, max_strain=0.5, grid=(0, 0, 0), P=0, rcut=0.0):
     """Parameter rule of Stokes::setParams (PSEv1/Stokes.cc:129-236,319), host only."""
     lib = _lib.load()
@@ -85,7 +101,7 @@ class Engine:
     def mobility(self, pos, force, vel=None, group=None, parts=3):
         import torch
         n = pos.shape[0] if group is None else group.shape[0]
-        _chk4(pos, "pos"); _chk4(force, "force")
+        _chk4(pos, "pos"); _chk4(force, "force"); _chk_group(group)
         if vel is None:
             vel = torch.zeros_like(pos)
         _chk4(vel, "vel")
@@ -95,9 +111,10 @@ class Engine:
     def brownian_velocity(self, pos, force, kT, dt, timestep, vel=None, group=None, lanczos_m=2):
         import torch
         n = pos.shape[0] if group is None else group.shape[0]
-        _chk4(pos, "pos"); _chk4(force, "force")
+        _chk4(pos, "pos"); _chk4(force, "force"); _chk_group(group)
         if vel is None:
             vel = torch.zeros_like(pos)
+        _chk4(vel, "vel")
         m = ctypes.c_int(int(lanczos_m))
         _lib.check(self._lib.pse_brownian_velocity(self._h, _ptr(pos), _ptr(force), _ptr(vel), _ptr(group), n,
                                                    float(kT), float(dt), int(timestep), ctypes.byref(m)))
@@ -105,7 +122,9 @@ class Engine:
 
     def step(self, pos, vel, accel, image, force, kT, dt, timestep, shear_rate=0.0, group=None, lanczos_m=2):
         n = pos.shape[0] if group is None else group.shape[0]
-        _chk4(pos, "pos"); _chk4(vel, "vel"); _chk4(force, "force")
+        import torch
+        _chk4(pos, "pos"); _chk4(vel, "vel"); _chk4(force, "force"); _chk_group(group)
+        _chk_arr(accel, "accel", 3, torch.float64, pos.shape[0]); _chk_arr(image, "image", 3, torch.int32, pos.shape[0])
         m = ctypes.c_int(int(lanczos_m))
         _lib.check(self._lib.pse_step(self._h, _ptr(pos), _ptr(vel), _ptr(accel), _ptr(image), _ptr(force),
                                       _ptr(group), n, float(kT), float(dt), int(timestep), float(shear_rate),
@@ -115,7 +134,7 @@ class Engine:
     def sqrt_mreal(self, pos, psi, tol=1e-3, group=None, lanczos_m=2):
         import torch
         n = pos.shape[0] if group is None else group.shape[0]
-        _chk4(pos, "pos"); _chk4(psi, "psi")
+        _chk4(pos, "pos"); _chk4(psi, "psi"); _chk_group(group)
         out = torch.zeros_like(psi)
         m = ctypes.c_int(int(lanczos_m))
         _lib.check(self._lib.pse_sqrt_mreal(self._h, _ptr(pos), _ptr(psi), _ptr(out), _ptr(group), n, float(tol),
@@ -125,7 +144,7 @@ class Engine:
     def pair_repulsion(self, pos, force, k, sigma=2.0, group=None, accumulate=True):
         """Soft repulsion k (sigma - r) r_hat for r < sigma added to (or stored in) `force`."""
         n = pos.shape[0] if group is None else group.shape[0]
-        _chk4(pos, "pos"); _chk4(force, "force")
+        _chk4(pos, "pos"); _chk4(force, "force"); _chk_group(group)
         _lib.check(self._lib.pse_pair_repulsion(self._h, _ptr(pos), _ptr(force), _ptr(group), n, float(k), float(sigma),
                                                 1 if accumulate else 0))
         return force
@@ -183,14 +202,23 @@ class Team:
     def _ptrs(tensors):
         return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
+    @staticmethod
+    def _chk(group, *lists):
+        _chk_group(group)
+        for name, ts in lists:
+            for t in ts:
+                _chk4(t, name)
+
     def mobility(self, pos, force, vel, group=None, parts=3):
         n = pos[0].shape[0] if group is None else group.shape[0]
+        self._chk(group, ("pos", pos), ("force", force), ("vel", vel))
         _lib.check(self._lib.pse_team_mobility(self._t, self._ptrs(pos), self._ptrs(force), self._ptrs(vel), _ptr(group),
                                                n, parts))
         return vel
 
     def brownian_velocity(self, pos, force, vel, kT, dt, timestep, group=None, lanczos_m=2):
         n = pos[0].shape[0] if group is None else group.shape[0]
+        self._chk(group, ("pos", pos), ("force", force), ("vel", vel))
         m = ctypes.c_int(int(lanczos_m))
         _lib.check(self._lib.pse_team_brownian_velocity(self._t, self._ptrs(pos), self._ptrs(force), self._ptrs(vel),
                                                         _ptr(group), n, float(kT), float(dt), int(timestep),
@@ -199,6 +227,10 @@ class Team:
 
     def step(self, pos, vel, accel, image, force, kT, dt, timestep, shear_rate=0.0, group=None, lanczos_m=2):
         n = pos[0].shape[0] if group is None else group.shape[0]
+        import torch
+        self._chk(group, ("pos", pos), ("vel", vel), ("force", force))
+        for a_, im_ in zip(accel, image):
+            _chk_arr(a_, "accel", 3, torch.float64, n); _chk_arr(im_, "image", 3, torch.int32, n)
         m = ctypes.c_int(int(lanczos_m))
         _lib.check(self._lib.pse_team_step(self._t, self._ptrs(pos), self._ptrs(vel), self._ptrs(accel),
                                            self._ptrs(image), self._ptrs(force), _ptr(group), n, float(kT), float(dt),

@@ -28,10 +28,16 @@
  *                           but with the grid/cutoff approximations removed: all images
  *                           and all wave vectors to a 1e-14 truncation.
  *
- * Parity pin: there are no golden vectors in the reference (it has no tests, SURVEY.md
- * section 4).  This oracle is pinned against mathematics instead -- the known-answer
- * values KAT-1..KAT-5 of SURVEY.md section 8(c) (Hasimoto single-sphere mobility, pair
- * blocks, self term) in tests/test_oracle.py, xi-independence, and the quadrature route.
+ * Parity pin: the reference has no tests or golden vectors and cannot
+ * be built here, but it holds its real-space functions, self term, parameter rule, seed
+ * hash, k-space factor and shear formulas as plain expression text.
+ * tests/golden/make_reference_fixture.py reads that text from /root/reference in the build
+ * container, evaluates it (50-digit and fp64) and commits the numbers as
+ * tests/golden/reference_arithmetic.json; tests/test_reference_pin.py holds this oracle to
+ * them (pse_oracle_fg_real vs PSEv1/Stokes.cc:348-406 to 2e-14 on all three branches incl.
+ * r < 0.25, where the fixture is independent of the quadrature below).  On top of that the
+ * known-answer values KAT-1..KAT-5 of SURVEY.md section 8(c), xi-independence and the
+ * quadrature route in tests/test_oracle.py.
  *
  * Box convention (HOOMD triclinic, PSEv1/Mobility.cu:223-230): lattice vectors
  *   a1 = (Lx,0,0), a2 = (xy*Ly, Ly, 0), a3 = (0,0,Lz); box[4] = {Lx,Ly,Lz,xy}.

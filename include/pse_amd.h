@@ -129,6 +129,10 @@ int pse_pair_repulsion(pse_handle *h, const pse_double4 *pos, pse_double4 *force
 /* copy the three real-space grids (x-major, z fastest: idx = (x*Ny + y)*Nz + z, PSEv1/Mobility.cu:233) of the
  * most recent spread (stage 0) or inverse FFT (stage 1) to a host buffer of 3*nx_local*Ny*Nz doubles */
 int pse_debug_copy_grid(pse_handle *h, int stage, double *host_out);
+/* sort + spread only (gpu_stokes_Spread_kernel, PSEv1/Mobility.cu:114-252): leaves the three force grids in place for
+ * pse_debug_copy_grid, so the spread can be compared node by node and not only through the gather */
+int pse_debug_spread(pse_handle *h, const pse_double4 *pos, const pse_double4 *force, const unsigned int *group_members,
+                     unsigned int N);
 
 /* -- multi-GPU: slab-decomposed far field + row-sharded near field (new design; the reference is single-GPU,
  *    PSEv1/Stokes.cc:104) ---------------------------------------------------------------------------------------

@@ -16,6 +16,9 @@ ARCH = "gfx950"
 
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-Wno-unused-function"]
 HIPFLAGS = [f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-ffp-contract=fast"]
+# the spread kernel keeps its TZ x 3 accumulators in registers across a switch over the particle's z offset: SimplifyCFG's
+# sinking of the cases' common stores turns the accumulators into pointer phis, which leaves them in scratch memory
+FARFLAGS = ["-mllvm", "-simplifycfg-sink-common=false"]
 
 
 def _newer(target, sources):
@@ -48,7 +51,7 @@ def build_lib(force=False):
     if not force and _newer(LIB, srcs):
         return LIB
     objs = []
-    for name, extra in (("pse_kernels.hip", HIPFLAGS), ("pse_capi.hip", HIPFLAGS), ("pse_params.cpp", ["-x", "c++"])):
+    for name, extra in (("pse_kernels.hip", HIPFLAGS), ("pse_farfield.hip", HIPFLAGS + FARFLAGS), ("pse_capi.hip", HIPFLAGS), ("pse_params.cpp", ["-x", "c++"])):
         obj = os.path.join(CSRC, name.rsplit(".", 1)[0] + ".o")
         _run([HIPCC, *CXXFLAGS, *extra, "-c", os.path.join(CSRC, name), "-o", obj])
         objs.append(obj)

@@ -225,7 +225,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->plan_x_inv) rocfft_plan_destroy(h->plan_x_inv);
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
-    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cell_cnt, h->sup_s, h->sw.wtab_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->sw.sup_t, h->sw.f_t, h->nb.data, h->nb.cnt, h->pos_s, h->posf_s, h->pv,
+    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cell_cnt, h->sup_s, h->sw.rec_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->nb.data, h->nb.cnt, h->pos_s, h->posf_s, h->pv,
                     h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->twiddle, h->fft_work, h->V,
                     h->scal, h->partials};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -370,10 +370,10 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     h->sort_tmp_bytes = cell_sort_temp_bytes(h->n_cells_alloc);
     TRY(dmalloc(h, (char **)&h->sort_tmp, h->sort_tmp_bytes));
     TRY(dmalloc(h, &h->sup_s, n));
-    if (d.P >= 4 && d.P <= 8) {   // fast far-field path: support offsets + separable weights (padded: idle lanes read past the end)
+    if (d.P >= 4 && d.P <= 8) {   // fast far-field path: support offsets + separable weights 
         TRY(dmalloc(h, &h->sw.d0_s, n));
-        TRY(dmalloc(h, &h->sw.wtab_t, n * (size_t)(d.P * d.P + d.P) + 128));
-        TRY(dmalloc(h, &h->sw.sup_t, n)); TRY(dmalloc(h, &h->sw.f_t, n)); TRY(dmalloc(h, &h->sw.fb.rank_s, n));
+        TRY(dmalloc(h, (char **)&h->sw.rec_t, (n + 64) * 64));   // 64-byte records (idle lanes read past the last one)
+        TRY(dmalloc(h, &h->sw.fb.rank_s, n));
         const size_t nbins = (size_t)((d.Nx + 7) / 8) * ((d.Ny + 7) / 8) * ((d.Nz + 7) / 8);
         TRY(dmalloc(h, &h->sw.fb.cnt, nbins + 1)); TRY(dmalloc(h, &h->sw.fb.off, nbins + 1));
         h->sw.fb.tmp_bytes = bin_scan_temp_bytes(nbins);
@@ -1160,6 +1160,20 @@ extern "C" int pse_eval_realspace(pse_handle *h, const double *r_host, int n, do
     if (e == hipSuccess) e = hipMemcpy(g_host, buf + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost);
     (void)hipFree(buf);
     if (e != hipSuccess) return fail(PSE_ERR_HIP, "pse_eval_realspace: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int pse_debug_spread(pse_handle *h, const pse_double4 *pos, const pse_double4 *force, const unsigned *group, unsigned N) {
+    TRY(check_n(h, N));
+    if (!pos || !force) return fail(PSE_ERR_INVALID, "null array");
+    if (h->n_slabs > 1) return fail(PSE_ERR_INVALID, "this handle is a slab rank: drive it through a pse_team");
+    TRY(prepare(h, (const double4 *)pos, (const double4 *)force, group, (int)N));
+    const DGrid &G = h->G;
+    const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz;
+    if (spread_needs_zero(G)) HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->stream));
+    launch_spread(h->pos_s, h->f_s, h->sup_s, (int)N, h->rgrid, h->rgrid + nr, h->rgrid + 2 * nr, G, h->dbox, h->sw, h->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
 

@@ -54,6 +54,16 @@ __device__ __forceinline__ int cell_coord(double f, int n) {
     return c >= n ? n - 1 : c;
 }
 
+// Workgroups b and b + 8 share an XCD (round-robin dispatch, /opt/skills/guides/MI355X_MICROARCH.md): hand each XCD a
+// contiguous range of logical blocks, so the neighbour data a block gathers is what the other blocks of its XCD
+// gather too and stays in that XCD's 4 MiB L2.  Bijective for any block count; placement affects speed only.
+__device__ __forceinline__ int xcd_block(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, x = b & 7, k = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+__device__ __forceinline__ int wrapi(int a, int n) { a %= n; return a < 0 ? a + n : a; }
+
 // ---- Philox4x32-10 ------------------------------------------------------------------------------------
 constexpr uint32_t PHILOX_KEY1 = 0x50534531u;  // 'PSE1'
 constexpr uint32_t DOMAIN_PARTICLE = 0, DOMAIN_GRID_A = 1, DOMAIN_GRID_B = 2;

@@ -60,13 +60,15 @@ struct FarBins {
     void *tmp; size_t tmp_bytes;   // scan scratch
 };
 size_t bin_scan_temp_bytes(size_t nbins);
+struct FarRec;                  // 64-byte bin-ordered particle record (pse_farfield.hip)
 struct SpreadWork {
-    double4 *d0_s;              // [N] offset of the support origin from the particle, grid units
+    double4 *d0_s;              // [N] offset of the support origin from the particle, grid units (cell order)
     FarBins fb;
-    int4 *sup_t;                // [N] bin order: support origin, sorted index (bit 31: owned by another slab rank)
-    double4 *f_t;               // [N] bin order: prefac * force
-    double *wtab_t;             // [N][P^2 + P] (+ padding) bin order: separable weights
+    FarRec *rec_t;              // [N] bin order: origin, sorted index (bit 31: owned by another slab rank), offset, prefac * force
 };
+// per-step constants of the separable Gaussian weights: step ratios r_t = exp(-c h^2 (2t+1)) (y with the (1 + xy^2) of the
+// sheared lattice), ln K = -2 c xy hx hy, the tilt
+struct GaussConsts { double rx[7], ry[7], rz[7], lnk, s; };
 size_t farfield_bins(const DGrid &G);
 // true if the caller must zero the grids first (atomic fallback: P outside 4..8 or a grid smaller than two tiles)
 bool spread_needs_zero(const DGrid &G);

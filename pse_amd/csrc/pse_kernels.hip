@@ -151,14 +151,6 @@ void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double
 constexpr int QCAP = 48;
 constexpr unsigned JMASK = (1u << 27) - 1;
 
-// Workgroups b and b + 8 share an XCD (round-robin dispatch, /opt/skills/guides/MI355X_MICROARCH.md): hand each XCD a
-// contiguous range of logical blocks, so the neighbour data a block gathers is what the other blocks of its XCD
-// gather too and stays in that XCD's 4 MiB L2.  Bijective for any block count; placement affects speed only.
-__device__ __forceinline__ int xcd_block(int b, int nb) {
-    const int q = nb >> 3, r = nb & 7, x = b & 7, k = b >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-}
-
 __device__ __forceinline__ void image_shift(unsigned code, const DBox &b, double &sx, double &sy, double &sz) {
     const int wx = (int)(code / 9) - 1, wy = (int)((code / 3) % 3) - 1, wz = (int)(code % 3) - 1;
     sx = wx * b.Lx + wy * b.xy * b.Ly;
@@ -505,546 +497,7 @@ void launch_eval_fg(const double *r, int n, const double *coef, double *f, doubl
     hipLaunchKernelGGL(k_eval_fg, dim3(nblocks(n, TPB)), dim3(TPB), 0, s, r, n, coef, f, g);
 }
 
-// ------------------------------------------------------------------------------------------------ far field
-// Support of a particle (PSEv1/Mobility.cu:173-219): first node index per axis (unwrapped) and the offset of
-// that node from the particle in grid units.
-__device__ __forceinline__ void support_start(double f, int n, int P, int &start, double &delta0) {
-    const double s = f * n;
-    const int i0 = (int)s;
-    start = i0 - P / 2 + 1 - ((P & 1) && (s - i0 < 0.5) ? 1 : 0);
-    delta0 = start - s;
-}
-
-// K2+K3 gpu_stokes_ZeroGrid/Spread_kernel (PSEv1/Helper.cu:87-97, PSEv1/Mobility.cu:114-252).
-// v0: one wave per particle, hardware fp64 atomics into the three real grids (zeroed by the caller).
-__global__ void __launch_bounds__(TPB)
-k_spread_atomic(const double4 *__restrict__ pos_s, const double4 *__restrict__ f_s, int N, double *__restrict__ gx,
-                double *__restrict__ gy, double *__restrict__ gz, DGrid G, DBox box) {
-    const int p = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (p >= N) return;
-    const double4 pp = pos_s[p];
-    const double4 F = f_s[p];
-    double fx, fy, fz;
-    frac_coords(box, pp.x, pp.y, pp.z, fx, fy, fz);
-    int sx, sy, sz;
-    double d0x, d0y, d0z;
-    support_start(fx, G.Nx, G.P, sx, d0x);
-    support_start(fy, G.Ny, G.P, sy, d0y);
-    support_start(fz, G.Nz, G.P, sz, d0z);
-    const int P = G.P, P2 = P * P, P3 = P2 * P;
-    for (int n = lane; n < P3; n += 64) {
-        const int tx = n / P2, ty = (n - tx * P2) / P, tz = n - tx * P2 - ty * P;
-        int ix = sx + tx; ix = ix < 0 ? ix + G.Nx : (ix >= G.Nx ? ix - G.Nx : ix);
-        const int lx = ix - G.x0;
-        if (lx < 0 || lx >= G.nxl) continue;
-        int iy = sy + ty; iy = iy < 0 ? iy + G.Ny : (iy >= G.Ny ? iy - G.Ny : iy);
-        int iz = sz + tz; iz = iz < 0 ? iz + G.Nz : (iz >= G.Nz ? iz - G.Nz : iz);
-        const double ey = G.hy * (d0y + ty);
-        const double ex = G.hx * (d0x + tx) + box.xy * ey;   // sheared lattice (PSEv1/Mobility.cu:230)
-        const double ez = G.hz * (d0z + tz);
-        const double w = G.prefac * exp_neg(-G.expfac * (ex * ex + ey * ey + ez * ez));
-        const size_t idx = ((size_t)(lx + G.hl) * G.Ny + iy) * G.Nz + iz;
-        unsafeAtomicAdd(&gx[idx], w * F.x);
-        unsafeAtomicAdd(&gy[idx], w * F.y);
-        unsafeAtomicAdd(&gz[idx], w * F.z);
-    }
-}
-
-// ---- far-field particle records in bin order ----------------------------------------------------------------------
-// Spread and gather work on tiles of grid nodes and need "the particles whose support starts in / reaches this tile".
-// Walking the near-field cell list for that (first versions) costs every tile workgroup a chain of dependent
-// global-memory round trips and index-gathered loads of the per-particle data; rocprofv3 showed both kernels bound by
-// that latency at 3-4 workgroups per CU, not by LDS or HBM throughput.  So once per step the particles are binned by the
-// BIN^3 block of nodes their support origin lies in (counting sort: atomic rank, scan, scatter) and everything a tile
-// kernel needs is written IN BIN ORDER: origin + sorted index (sup_t), prefac * force (f_t) and the separable weights
-// (wtab_t).  A gather workgroup then reads one contiguous range of records, a spread workgroup a few ranges.
-//
-// Weights: w(tx,ty,tz) = A[tx][ty] B[tz] with A = exp(-c (ex^2 + ey^2)) (x and y couple through the shear,
-// PSEv1/Mobility.cu:230) and B = exp(-c ez^2): P^2 + P numbers per particle instead of P^3 exponentials per use.
-constexpr int BIN = 8;
-__host__ __device__ inline int bins_of(int n) { return (n + BIN - 1) / BIN; }
-__device__ __forceinline__ int wrapi(int a, int n) { a %= n; return a < 0 ? a + n : a; }
-__device__ __forceinline__ int bin_index(const int4 &o, const FarBins &fb) {
-    return ((o.x / BIN) * fb.nby + (o.y / BIN)) * fb.nbz + (o.z / BIN);
-}
-
-// support origin (wrapped into the grid), offset of the origin from the particle, the particle's own node plane, and its
-// rank inside its bin (-1: a slab rank never touches this particle)
-__global__ void k_support(const double4 *__restrict__ pos_s, int N, DGrid G, DBox box, int4 *__restrict__ sup_s,
-                          double4 *__restrict__ d0_s, FarBins fb) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s - (int)(threadIdx.x & 63) >= N) return;          // whole wave past the end
-    const bool live = s < N;
-    const double4 p = pos_s[live ? s : N - 1];
-    double fx, fy, fz;
-    frac_coords(box, p.x, p.y, p.z, fx, fy, fz);
-    int4 o;
-    double4 d;
-    support_start(fx, G.Nx, G.P, o.x, d.x);   // PSEv1/Mobility.cu:212-214
-    support_start(fy, G.Ny, G.P, o.y, d.y);
-    support_start(fz, G.Nz, G.P, o.z, d.z);
-    o.x = wrapi(o.x, G.Nx); o.y = wrapi(o.y, G.Ny); o.z = wrapi(o.z, G.Nz);
-    o.w = min((int)(fx * G.Nx), G.Nx - 1);   // the node plane the particle sits in: decides which slab owns it
-    d.w = 0.0;
-    if (live) {
-        sup_s[s] = o;
-        if (d0_s) d0_s[s] = d;
-    }
-    if (fb.cnt) {
-        bool need = live;
-        if (G.nxl < G.Nx) need = need && wrapi(o.w - (G.x0 - G.P), G.Nx) < G.nxl + 2 * G.P;   // within a support of the slab's planes
-        // Neighbouring lanes are neighbouring particles and mostly share a bin: one atomic per distinct bin of the wave
-        // (the leader adds the group's size, members take consecutive ranks) instead of 64 same-address atomics.
-        const int bin = need ? bin_index(o, fb) : -1;
-        const int lane = threadIdx.x & 63;
-        const unsigned long long below = (1ull << lane) - 1ull;
-        unsigned long long todo = __ballot(need);
-        int prefix = 0, count = 0, leader = lane;
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            const int b0 = __shfl(bin, src, 64);
-            const unsigned long long m = __ballot(bin == b0) & todo;
-            if (bin == b0) { prefix = __popcll(m & below); count = __popcll(m); leader = src; }
-            todo &= ~m;
-        }
-        int base = 0;
-        if (need && leader == lane) base = atomicAdd(&fb.cnt[bin], count);
-        base = __shfl(base, leader, 64);
-        if (live) fb.rank_s[s] = need ? base + prefix : -1;
-    }
-}
-
-size_t bin_scan_temp_bytes(size_t nbins) {
-    size_t bytes = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int *)nullptr, (int *)nullptr, (int)(nbins + 1));
-    return bytes;
-}
-
-// One lane per (particle, row): rows 0..P-1 are the x rows A[.][ty] of the weight table, row P is B[.] plus the record
-// header.  A Gaussian sampled on a uniform stencil obeys E(t+1) = E(t) q r_t with q = exp(-2c X0 h) and
-// r_t = exp(-c h^2 (2t+1)) (r_t does not depend on the particle: passed in), so a row costs 2 exponentials + 2(P-1)
-// multiplies: 2(P+1) exponentials per particle instead of P^2+P.  With shear X0 depends on ty (PSEv1/Mobility.cu:230),
-// which is why A is stored as rows in x.
-struct WeightConsts { double rx[8], rz[8]; };   // rx[t] = exp(-c hx^2 (2t+1)), rz[t] = exp(-c hz^2 (2t+1))
-
-constexpr int WPB = 32;   // particles per workgroup of k_weights
-template <int P>
-__global__ void __launch_bounds__(TPB)
-k_weights(const double4 *__restrict__ d0_s, const int4 *__restrict__ sup_s, const double4 *__restrict__ f_s, int N, DGrid G,
-          DBox box, WeightConsts wc, FarBins fb, SpreadWork w) {
-    constexpr int WT = P * P + P, ROWS = P + 1;
-    __shared__ double rec[WPB * WT];      // the records of WPB particles, written out as contiguous runs (slots are scattered)
-    __shared__ int slot_l[WPB];
-    const int tid = threadIdx.x;
-    const int p0 = blockIdx.x * WPB;
-    if (tid < WPB) {
-        const int p = p0 + tid;
-        int slot = -1;
-        if (p < N) {
-            const int rank = fb.rank_s[p];
-            if (rank >= 0) {
-                const int4 sp = sup_s[p];
-                slot = fb.off[bin_index(sp, fb)] + rank;
-                // header: origin, sorted index (bit 31: not owned by this slab rank), prefac * force
-                const bool owned = G.nxl == G.Nx || wrapi(sp.w - G.x0, G.Nx) < G.nxl;
-                w.sup_t[slot] = make_int4(sp.x, sp.y, sp.z, (int)((unsigned)p | (owned ? 0u : 0x80000000u)));
-                const double4 F = f_s[p];
-                w.f_t[slot] = make_double4(G.prefac * F.x, G.prefac * F.y, G.prefac * F.z, 0.0);
-            }
-        }
-        slot_l[tid] = slot;
-    }
-    const double c = G.expfac;
-    for (int idx = tid; idx < WPB * ROWS; idx += TPB) {
-        const int pl = idx / ROWS, row = idx - pl * ROWS, p = p0 + pl;
-        if (p >= N) continue;
-        const double4 d0 = d0_s[p];
-        double *out = rec + pl * WT;
-        if (row < P) {
-            const double ey = G.hy * (d0.y + row), x0 = G.hx * d0.x + box.xy * ey;
-            double e = exp_neg(-c * (x0 * x0 + ey * ey));
-            const double q = exp_lean(-2.0 * c * x0 * G.hx);
-#pragma unroll
-            for (int t = 0; t < P; ++t) { out[t * P + row] = e; e *= q * wc.rx[t]; }
-        } else {
-            const double z0 = G.hz * d0.z;
-            double e = exp_neg(-c * z0 * z0);
-            const double q = exp_lean(-2.0 * c * z0 * G.hz);
-#pragma unroll
-            for (int t = 0; t < P; ++t) { out[P * P + t] = e; e *= q * wc.rz[t]; }
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < WPB * WT; e += TPB) {
-        const int pl = e / WT, fld = e - pl * WT, slot = slot_l[pl];
-        if (slot >= 0) w.wtab_t[(size_t)slot * WT + fld] = rec[e];
-    }
-}
-
-// Tile-owned spread (K2+K3): one workgroup owns a TXxTYxTZ block of grid nodes, accumulates every contribution to it in
-// LDS (ds_add_f64) and writes each node exactly once with plain stores -- no global atomics (1.3 TB/s chip-wide on
-// MI355X: the 7.6 ms of the v0 kernel), no ZeroGrid pass.  Candidates are the records of the few bins whose origins can
-// reach the tile; survivors of the clip test are processed 32 per pass: their records are staged in LDS with coalesced
-// loads (the next pass's are in flight while this one computes), then eight lanes per (particle, tile) pair -- lane = z
-// offset of the support -- run the unrolled P^2 (x,y) loop: one broadcast weight read, three multiplies, three LDS adds.
-constexpr int SP_NG = 32;          // records per pass (= 256 threads / 8 lanes)
-constexpr int SP_LCAP = 1024;      // survivors per chunk
-constexpr int SP_RMAX = 64;        // bin ranges per tile
-
-template <int P, int TX, int TY, int TZ>
-__global__ void __launch_bounds__(256)
-k_spread_bins(const int4 *__restrict__ sup_t, const double4 *__restrict__ f_t, const double *__restrict__ wtab_t,
-              FarBins fb, double *__restrict__ gx, double *__restrict__ gy, double *__restrict__ gz, DGrid G, int ntx,
-              int nty, int ntz) {
-    constexpr int NT = 256, XS = TY * TZ + 2, NODES = TX * XS, WT = P * P + P;
-    __shared__ double acc[3 * NODES];
-    __shared__ int list[SP_LCAP];
-    __shared__ int rng_b[SP_RMAX], rng_o[SP_RMAX + 1];
-    __shared__ int nl;
-    const int tid = threadIdx.x;
-    int b = xcd_block(blockIdx.x, gridDim.x);
-    const int tz_ = b % ntz; b /= ntz;
-    const int ty_ = b % nty; b /= nty;
-    const int tx_ = b;
-    const int t0[3] = {G.x0 + tx_ * TX, ty_ * TY, tz_ * TZ};
-    const int ext[3] = {min(TX, G.x0 + G.nxl - t0[0]), min(TY, G.Ny - t0[1]), min(TZ, G.Nz - t0[2])};
-    const int Nn[3] = {G.Nx, G.Ny, G.Nz};
-    const int nb[3] = {fb.nbx, fb.nby, fb.nbz};
-    for (int n = tid; n < 3 * NODES; n += NT) acc[n] = 0.0;
-
-    // bins whose origins [t0 - P + 1, t0 + ext - 1] (cyclic) can reach the tile
-    int blo[3], bcnt[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        blo[a] = wrapi(t0[a] - (P - 1), Nn[a]) / BIN;
-        bcnt[a] = min(nb[a], wrapi((t0[a] + ext[a] - 1) / BIN - blo[a], nb[a]) + 1);
-    }
-    const int nr = bcnt[0] * bcnt[1] * bcnt[2];   // <= 4*3*3 for the shipped tile shapes
-    if (tid < nr) {
-        const int iz = tid % bcnt[2], r = tid / bcnt[2], iy = r % bcnt[1], ix = r / bcnt[1];
-        const int bin = (((blo[0] + ix) % nb[0]) * nb[1] + (blo[1] + iy) % nb[1]) * nb[2] + (blo[2] + iz) % nb[2];
-        const int o = fb.off[bin];
-        rng_b[tid] = o;
-        rng_o[tid + 1] = fb.off[bin + 1] - o;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        rng_o[0] = 0;
-        for (int r = 0; r < nr; ++r) { run += rng_o[r + 1]; rng_o[r + 1] = run; }
-    }
-    __syncthreads();
-    const int total = rng_o[nr];
-
-    // support origin relative to the tile (nearest image); false if the support misses the tile
-    auto clip = [&](const int4 &sp, int a0[3]) {
-        const int o[3] = {sp.x, sp.y, sp.z};
-        bool hit = true;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            int rel = o[a] - t0[a];
-            if (rel < -Nn[a] / 2) rel += Nn[a]; else if (rel >= Nn[a] - Nn[a] / 2) rel -= Nn[a];
-            a0[a] = rel;
-            hit = hit && rel + P > 0 && rel < ext[a];
-        }
-        return hit;
-    };
-    const int grp = tid >> 3, tz = tid & 7;
-    for (int c0 = 0; c0 < total; c0 += SP_LCAP) {
-        if (tid == 0) nl = 0;
-        __syncthreads();
-        const int cend = min(total, c0 + SP_LCAP);
-        for (int k = c0 + tid; k < cend; k += NT) {
-            int lo = 0, hi = nr;                       // largest r with rng_o[r] <= k
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rng_o[mid] <= k) lo = mid; else hi = mid; }
-            const int slot = rng_b[lo] + (k - rng_o[lo]);
-            int a0[3];
-            if (clip(sup_t[slot], a0)) list[atomicAdd(&nl, 1)] = slot;
-        }
-        __syncthreads();
-        const int n = nl;
-        // eight lanes per survivor (lane = z offset of the support); the eight lanes read the same record addresses
-        // (a few L1 accesses per instruction) and all loads are unconditional so they are in flight together
-        for (int h = grp; h < n; h += NT / 8) {
-            const size_t slot = (size_t)list[h];
-            const int4 sp = sup_t[slot];
-            const double4 F = f_t[slot];
-            const double *w = wtab_t + slot * WT;
-            double a[P * P];
-#pragma unroll
-            for (int e = 0; e < P * P; ++e) a[e] = w[e];
-            const double bw = w[P * P + (tz < P ? tz : 0)];
-            int a0[3];
-            clip(sp, a0);
-            const int lz = a0[2] + tz;
-            if (tz < P && lz >= 0 && lz < ext[2]) {
-                const double bx = bw * F.x, by = bw * F.y, bz = bw * F.z;
-                double *cell = acc + a0[0] * XS + a0[1] * TZ + lz;
-#pragma unroll
-                for (int tx = 0; tx < P; ++tx) {
-                    const bool okx = (unsigned)(a0[0] + tx) < (unsigned)ext[0];
-#pragma unroll
-                    for (int ty = 0; ty < P; ++ty) {
-                        if (okx && (unsigned)(a0[1] + ty) < (unsigned)ext[1]) {
-                            double *o = cell + tx * XS + ty * TZ;
-                            atomicAdd(o, a[tx * P + ty] * bx);
-                            atomicAdd(o + NODES, a[tx * P + ty] * by);
-                            atomicAdd(o + 2 * NODES, a[tx * P + ty] * bz);
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();                                  // the list is rebuilt by the next chunk
-    }
-    __syncthreads();
-    const int eyz = ext[1] * ext[2], nout = ext[0] * eyz;
-    for (int n = tid; n < nout; n += NT) {
-        const int qx = n / eyz, r = n - qx * eyz, qy = r / ext[2], qz = r - qy * ext[2];
-        const size_t idx = ((size_t)(t0[0] - G.x0 + G.hl + qx) * G.Ny + (t0[1] + qy)) * G.Nz + (t0[2] + qz);
-        const int o = qx * XS + qy * TZ + qz;
-        gx[idx] = acc[o];
-        gy[idx] = acc[NODES + o];
-        gz[idx] = acc[2 * NODES + o];
-    }
-}
-
-static int spread_tile_variant() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("PSE_SPREAD_TILE"); v = e ? atoi(e) : 1; }
-    return v;
-}
-static void tile_dims(int &tx, int &ty, int &tz) {
-    switch (spread_tile_variant()) {
-        case 0: tx = 8; ty = 8; tz = 8; break;
-        case 2: tx = 16; ty = 16; tz = 8; break;
-        default: tx = 16; ty = 8; tz = 8; break;
-    }
-}
-
-bool farfield_fast_path(const DGrid &G) {
-    // the tile kernels resolve a support to its nearest image of the tile (needs N >= 2 max(tile, support) per axis) and
-    // map the z offsets of a support to at most 8 lanes
-    int tx, ty, tz;
-    tile_dims(tx, ty, tz);
-    const int tmax = std::max(tx, std::max(ty, tz));
-    const int need = 2 * std::max(tmax, G.P);
-    return G.P >= 4 && G.P <= 8 && G.Nx >= need && G.Ny >= need && G.Nz >= need;
-}
-bool spread_needs_zero(const DGrid &G) { return !farfield_fast_path(G); }
-size_t farfield_bins(const DGrid &G) { return (size_t)bins_of(G.Nx) * bins_of(G.Ny) * bins_of(G.Nz); }
-
-template <int P>
-static void launch_spread_p(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, double *gx, double *gy, double *gz,
-                            DGrid G, DBox box, SpreadWork w, hipStream_t s) {
-    FarBins fb = w.fb;
-    fb.nbx = bins_of(G.Nx); fb.nby = bins_of(G.Ny); fb.nbz = bins_of(G.Nz);
-    const int nbins = fb.nbx * fb.nby * fb.nbz;
-    (void)hipMemsetAsync(fb.cnt, 0, (size_t)(nbins + 1) * sizeof(int), s);
-    hipLaunchKernelGGL(k_support, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos_s, N, G, box, sup_s, w.d0_s, fb);
-    size_t tb = fb.tmp_bytes;
-    (void)hipcub::DeviceScan::ExclusiveSum(fb.tmp, tb, fb.cnt, fb.off, nbins + 1, s);   // cnt[nbins] = 0: off[nbins] = total
-    WeightConsts wc;
-    for (int t = 0; t < 8; ++t) {
-        wc.rx[t] = std::exp(-G.expfac * G.hx * G.hx * (2 * t + 1));
-        wc.rz[t] = std::exp(-G.expfac * G.hz * G.hz * (2 * t + 1));
-    }
-    hipLaunchKernelGGL(k_weights<P>, dim3(nblocks(N, WPB)), dim3(TPB), 0, s, w.d0_s, sup_s, f_s, N, G, box, wc, fb, w);
-    int TX, TY, TZ;
-    tile_dims(TX, TY, TZ);
-    const int ntx = (G.nxl + TX - 1) / TX, nty = (G.Ny + TY - 1) / TY, ntz = (G.Nz + TZ - 1) / TZ;
-    const dim3 g(ntx * nty * ntz), b(256);
-    if (TX == 8)
-        hipLaunchKernelGGL((k_spread_bins<P, 8, 8, 8>), g, b, 0, s, w.sup_t, w.f_t, w.wtab_t, fb, gx, gy, gz, G, ntx, nty, ntz);
-    else if (TY == 8)
-        hipLaunchKernelGGL((k_spread_bins<P, 16, 8, 8>), g, b, 0, s, w.sup_t, w.f_t, w.wtab_t, fb, gx, gy, gz, G, ntx, nty, ntz);
-    else
-        hipLaunchKernelGGL((k_spread_bins<P, 16, 16, 8>), g, b, 0, s, w.sup_t, w.f_t, w.wtab_t, fb, gx, gy, gz, G, ntx, nty, ntz);
-}
-
-void launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, double *gx, double *gy, double *gz, DGrid G,
-                   DBox box, SpreadWork w, hipStream_t s) {
-    if (!farfield_fast_path(G) || !w.wtab_t) {
-        hipLaunchKernelGGL(k_spread_atomic, dim3(nblocks(N, TPB / 64)), dim3(TPB), 0, s, pos_s, f_s, N, gx, gy, gz, G, box);
-        return;
-    }
-    switch (G.P) {
-        case 4: launch_spread_p<4>(pos_s, f_s, sup_s, N, gx, gy, gz, G, box, w, s); break;
-        case 5: launch_spread_p<5>(pos_s, f_s, sup_s, N, gx, gy, gz, G, box, w, s); break;
-        case 6: launch_spread_p<6>(pos_s, f_s, sup_s, N, gx, gy, gz, G, box, w, s); break;
-        case 7: launch_spread_p<7>(pos_s, f_s, sup_s, N, gx, gy, gz, G, box, w, s); break;
-        default: launch_spread_p<8>(pos_s, f_s, sup_s, N, gx, gy, gz, G, box, w, s); break;
-    }
-}
-
-// K8 gpu_stokes_Contract_kernel (PSEv1/Mobility.cu:325-477): u_p = h^3 sum_nodes prefac exp(-expfac r^2) u_grid.
-// Bin gather: a workgroup takes one bin, stages the BIN^3 nodes plus the P-1 node halo on the high side of each axis
-// (every support that starts in the bin lies inside) for all three velocity components in LDS (52.7 KB at P = 6: three
-// workgroups per CU) and reads the bin's records, which are contiguous.  The only dependent round trip is bin offsets ->
-// (region, records): all those loads are in flight together.  Four lanes per particle (lane = pair of z offsets), up to
-// 64 particles per pass, compile-time loop over the P^2 (x,y) offsets: one ds_read2 and three FMAs per component; 2-step
-// reduction inside the 4 lanes instead of the reference's shared-memory tree over P^3 threads (PSEv1/Mobility.cu:456-470).
-template <int P>
-__global__ void __launch_bounds__(256)
-k_gather_bins(const int4 *__restrict__ sup_t, const double *__restrict__ wtab_t, FarBins fb, int bx0, int nbx_l,
-              const double *__restrict__ gx, const double *__restrict__ gy, const double *__restrict__ gz, DGrid G,
-              double4 *__restrict__ u_s) {
-    constexpr int NT = 256, E = BIN + P - 1, E2 = E * E, E3 = E2 * E, WT = P * P + P;
-    __shared__ double reg[3 * E3];
-    const int tid = threadIdx.x;
-    int b = xcd_block(blockIdx.x, gridDim.x);
-    const int bz = b % fb.nbz; b /= fb.nbz;
-    const int by = b % fb.nby; b /= fb.nby;
-    const int bx = (bx0 + b) % fb.nbx;
-    const int bin = (bx * fb.nby + by) * fb.nbz + bz;
-    const int base = fb.off[bin], n = fb.off[bin + 1] - base;
-    if (n == 0) return;
-    const int t0[3] = {bx * BIN, by * BIN, bz * BIN};
-    // region loads: a thread keeps one (y,z) column and walks component x plane -- the plane index is uniform, so a load
-    // costs an add and the loads are all in flight together (the kernel is VALU-bound: 78 % busy in rocprofv3)
-    const bool windowed = G.nxl < G.Nx;
-    const int xs = G.x0 - G.hl, nstored = G.nxl + G.hl + G.nhalo;
-    const size_t plane = (size_t)G.Ny * G.Nz;
-    double rv[3 * E];
-    {
-        const int qy = tid / E, qz = tid - qy * E;            // this thread's column of the region (tid < E^2)
-        int iy = t0[1] + qy; if (iy >= G.Ny) iy -= G.Ny;
-        int iz = t0[2] + qz; if (iz >= G.Nz) iz -= G.Nz;
-        const size_t col = (size_t)iy * G.Nz + iz;
-#pragma unroll
-        for (int qx = 0; qx < E; ++qx) {
-            int ix = t0[0] + qx; if (ix >= G.Nx) ix -= G.Nx;
-            bool ok = tid < E2;
-            if (windowed) { ix = wrapi(ix - xs, G.Nx); ok = ok && ix < nstored; }   // stored plane index; other slabs' planes read as 0
-            const size_t o = (size_t)ix * plane + col;
-            rv[qx] = ok ? gx[o] : 0.0;
-            rv[E + qx] = ok ? gy[o] : 0.0;
-            rv[2 * E + qx] = ok ? gz[o] : 0.0;
-        }
-    }
-    const int grp = tid >> 2, tl = tid & 3;
-    const bool two = 2 * tl + 1 < P;                        // this lane's z offsets: 2 tl and (if inside the support) 2 tl + 1
-    const double cw = G.hx * G.hy * G.hz;                  // PSEv1/Brownian.cu:872 (prefac is folded in below)
-    for (int h0 = 0; h0 < n; h0 += NT / 4) {
-        const int h = h0 + grp;
-        const bool act = h < n && 2 * tl < P;
-        int4 sp = make_int4(0, 0, 0, 0);
-        double a[P * P], bw0 = 0.0, bw1 = 0.0;
-        if (act) {
-            const size_t slot = (size_t)(base + h);
-            sp = sup_t[slot];
-            const double *w = wtab_t + slot * WT;
-#pragma unroll
-            for (int e = 0; e < P * P; ++e) a[e] = w[e];
-            bw0 = w[P * P + 2 * tl];
-            bw1 = two ? w[P * P + 2 * tl + 1] : 0.0;
-        }
-        if (h0 == 0) {                                      // park the region (loads issued above) in LDS
-            if (tid < E2) {
-#pragma unroll
-                for (int q = 0; q < 3 * E; ++q) reg[q * E2 + tid] = rv[q];
-            }
-            __syncthreads();
-        }
-        double ux = 0.0, uy = 0.0, uz = 0.0;
-        if (act) {
-            const double *r0 = reg + (sp.x - t0[0]) * E2 + (sp.y - t0[1]) * E + (sp.z - t0[2]) + 2 * tl;
-            const int o1 = two ? 1 : 0;
-            double x0 = 0.0, x1 = 0.0, y0 = 0.0, y1 = 0.0, z0 = 0.0, z1 = 0.0;   // per z offset: the B weight multiplies once
-#pragma unroll
-            for (int tx = 0; tx < P; ++tx)
-#pragma unroll
-                for (int ty = 0; ty < P; ++ty) {
-                    const double *r = r0 + tx * E2 + ty * E;
-                    const double w = a[tx * P + ty];
-                    x0 += w * r[0]; x1 += w * r[o1];
-                    y0 += w * r[E3]; y1 += w * r[E3 + o1];
-                    z0 += w * r[2 * E3]; z1 += w * r[2 * E3 + o1];
-                }
-            ux = bw0 * x0 + bw1 * x1; uy = bw0 * y0 + bw1 * y1; uz = bw0 * z0 + bw1 * z1;
-        }
-#pragma unroll
-        for (int o = 1; o < 4; o <<= 1) {
-            ux += __shfl_xor(ux, o, 64); uy += __shfl_xor(uy, o, 64); uz += __shfl_xor(uz, o, 64);
-        }
-        if (h < n && tl == 0 && sp.w >= 0) {                // bit 31 of w: owned by another slab rank
-            const double s = G.prefac * cw;
-            u_s[sp.w] = make_double4(s * ux, s * uy, s * uz, 0.0);
-        }
-    }
-}
-
-// generic support size: one exponential per node
-__global__ void __launch_bounds__(TPB)
-k_gather(const double4 *__restrict__ pos_s, int N, const double *__restrict__ gx, const double *__restrict__ gy,
-         const double *__restrict__ gz, DGrid G, DBox box, double4 *__restrict__ u_s) {
-    const int p = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (p >= N) return;
-    const double4 pp = pos_s[p];
-    double fx, fy, fz;
-    frac_coords(box, pp.x, pp.y, pp.z, fx, fy, fz);
-    int sx, sy, sz;
-    double d0x, d0y, d0z;
-    support_start(fx, G.Nx, G.P, sx, d0x);
-    support_start(fy, G.Ny, G.P, sy, d0y);
-    support_start(fz, G.Nz, G.P, sz, d0z);
-    // owned by the rank whose slab holds the particle's own plane; its support then lies inside the stored planes
-    int own = (int)(fx * G.Nx) - G.x0; own %= G.Nx; if (own < 0) own += G.Nx;
-    if (own >= G.nxl) {
-        if (lane == 0) u_s[p] = make_double4(0.0, 0.0, 0.0, 0.0);
-        return;
-    }
-    int rel0 = sx - (G.x0 - G.hl); rel0 %= G.Nx; if (rel0 < 0) rel0 += G.Nx;
-    const int P = G.P, P2 = P * P, P3 = P2 * P;
-    double ux = 0, uy = 0, uz = 0;
-    for (int n = lane; n < P3; n += 64) {
-        const int tx = n / P2, ty = (n - tx * P2) / P, tz = n - tx * P2 - ty * P;
-        int lx = rel0 + tx; if (G.nxl == G.Nx && lx >= G.Nx) lx -= G.Nx;
-        int iy = sy + ty; iy = iy < 0 ? iy + G.Ny : (iy >= G.Ny ? iy - G.Ny : iy);
-        int iz = sz + tz; iz = iz < 0 ? iz + G.Nz : (iz >= G.Nz ? iz - G.Nz : iz);
-        const double ey = G.hy * (d0y + ty);
-        const double ex = G.hx * (d0x + tx) + box.xy * ey;
-        const double ez = G.hz * (d0z + tz);
-        const double w = exp_neg(-G.expfac * (ex * ex + ey * ey + ez * ez));
-        const size_t idx = ((size_t)lx * G.Ny + iy) * G.Nz + iz;
-        ux += w * gx[idx];
-        uy += w * gy[idx];
-        uz += w * gz[idx];
-    }
-    ux = wave_sum(ux); uy = wave_sum(uy); uz = wave_sum(uz);
-    if (lane == 0) {
-        const double c = G.prefac * G.hx * G.hy * G.hz;   // PSEv1/Brownian.cu:872
-        u_s[p] = make_double4(c * ux, c * uy, c * uz, 0.0);
-    }
-}
-
-void launch_gather(const double4 *pos_s, SpreadWork w, int N, const double *gx, const double *gy, const double *gz, DGrid G,
-                   DBox box, double4 *u_s, hipStream_t s) {
-    if (!farfield_fast_path(G) || !w.wtab_t) {
-        hipLaunchKernelGGL(k_gather, dim3(nblocks(N, TPB / 64)), dim3(TPB), 0, s, pos_s, N, gx, gy, gz, G, box, u_s);
-        return;
-    }
-    FarBins fb = w.fb;
-    fb.nbx = bins_of(G.Nx); fb.nby = bins_of(G.Ny); fb.nbz = bins_of(G.Nz);
-    int bx0 = 0, nbx_l = fb.nbx;
-    if (G.nxl < G.Nx) {
-        // a slab rank gathers the particles of its own planes (zeros elsewhere): their origins lie in [x0 - hl - 1, x0 + nxl)
-        (void)hipMemsetAsync(u_s, 0, (size_t)N * sizeof(double4), s);
-        const int olo = ((G.x0 - G.hl - 1) % G.Nx + G.Nx) % G.Nx, ohi = (G.x0 + G.nxl - 1) % G.Nx;
-        bx0 = olo / BIN;
-        nbx_l = std::min(fb.nbx, ((ohi / BIN - bx0) % fb.nbx + fb.nbx) % fb.nbx + 1);
-    }
-    const dim3 g(nbx_l * fb.nby * fb.nbz), b(256);
-    switch (G.P) {
-        case 4: hipLaunchKernelGGL(k_gather_bins<4>, g, b, 0, s, w.sup_t, w.wtab_t, fb, bx0, nbx_l, gx, gy, gz, G, u_s); break;
-        case 5: hipLaunchKernelGGL(k_gather_bins<5>, g, b, 0, s, w.sup_t, w.wtab_t, fb, bx0, nbx_l, gx, gy, gz, G, u_s); break;
-        case 6: hipLaunchKernelGGL(k_gather_bins<6>, g, b, 0, s, w.sup_t, w.wtab_t, fb, bx0, nbx_l, gx, gy, gz, G, u_s); break;
-        case 7: hipLaunchKernelGGL(k_gather_bins<7>, g, b, 0, s, w.sup_t, w.wtab_t, fb, bx0, nbx_l, gx, gy, gz, G, u_s); break;
-        default: hipLaunchKernelGGL(k_gather_bins<8>, g, b, 0, s, w.sup_t, w.wtab_t, fb, bx0, nbx_l, gx, gy, gz, G, u_s); break;
-    }
-}
+// (far field: spread, gather and their particle records live in pse_farfield.hip)
 
 // K1+K5+K6 fused: gpu_stokes_SetGridk_kernel (PSEv1/Helper.cu:285-332), gpu_stokes_Green_kernel
 // (PSEv1/Mobility.cu:264-299) and gpu_stokes_BrownianGridGenerate_kernel (PSEv1/Brownian.cu:153-345) on the

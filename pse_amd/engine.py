@@ -166,6 +166,13 @@ class Engine:
                                                 g.ctypes.data_as(dp)))
         return f, g
 
+    def debug_spread(self, pos, force, group=None):
+        """The three force grids right after the spread (3, Nx, Ny, Nz), host array."""
+        n = pos.shape[0] if group is None else group.shape[0]
+        _chk4(pos, "pos"); _chk4(force, "force"); _chk_group(group)
+        _lib.check(self._lib.pse_debug_spread(self._h, _ptr(pos), _ptr(force), _ptr(group), n))
+        return self.debug_grid()
+
     def debug_grid(self):
         import numpy as np
         i = self.info()

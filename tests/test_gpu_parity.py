@@ -58,9 +58,12 @@ def test_wave_matches_port(torch_cuda, oracle, xy, err):
     assert (info["Nx"], info["Ny"], info["Nz"]) == p["grid"] and info["P"] == p["P"]
     assert abs(info["eta"] - p["eta"]) < 1e-14
     u = eng.mobility(to4(pos), to4(force), parts=2).cpu().numpy()[:, :3]
-    g = eng.debug_grid()
     ref = oracle.mobility_wave(pos, force, box, p)
     assert rel(u, ref) < 1e-10, rel(u, ref)
+    # the spread itself, node by node (PSEv1/Mobility.cu:114-252), not only through the gather
+    g = eng.debug_spread(to4(pos), to4(force))
+    gref = np.asarray(oracle.spread(pos, force, box, p))
+    assert g.shape == gref.shape and np.abs(g - gref).max() < 1e-12 * np.abs(gref).max()
 
 
 @pytest.mark.parametrize("err", [1e-3, 1e-6, 1e-9])

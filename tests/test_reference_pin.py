@@ -145,7 +145,7 @@ def test_device_realspace_table_against_the_reference():
         by_xi.setdefault(row["xi"], []).append(row)
     for xi, rows in by_xi.items():
         rcut = 10.0
-        eng = pse_amd.Engine(64, (40.0, 40.0, 40.0, 0.0), xi=xi, error=1e-3, rcut=rcut, grid=(32, 32, 32))
+        eng = pse_amd.Engine(64, (40.0, 40.0, 40.0, 0.0), xi=xi, error=1e-3, rcut=rcut)
         r = np.array([q["r"] for q in rows])
         f, g = eng.eval_realspace(r)
         assert np.abs(f - [q["Imrr_exact"] for q in rows]).max() < 2e-13

@@ -48,8 +48,9 @@ def cpu_baseline(budget_s=12.0):
         times.append(time.perf_counter() - t0)
     t = float(np.median(times))
     return {
-        "value": n / t, "unit": "particle-evals/s (M.F only)", "cores": int(cores), "kind": "port",
-        "sample": f"direct Ewald-summed periodic RPY M.F, N={n}, phi={phi}, xi={xi}, fp64, tol 1e-14, "
+        "value": n / t, "unit": "particle-evals/s (M.F only)", "cores": int(cores), "kind": "port", "comparable": False,
+        "sample": f"NOT the metric workload (an O(N^2) evaluator cannot run N=1e6; the reference has no CPU path): BASELINE "
+                  f"config 1, direct Ewald-summed periodic RPY M.F, N={n}, phi={phi}, xi={xi}, fp64, tol 1e-14, "
                   f"median of {len(times)} evals ({t * 1e3:.1f} ms each); O(N^2): extrapolates to "
                   f"{t * (1e6 / n) ** 2:.3g} s per eval at N=1e6",
         "evals_per_s": 1.0 / t,
@@ -113,18 +114,37 @@ def main():
     barrier()
     t_mf = (time.perf_counter() - t0) / n_mf
 
-    sim.set_timing(True)
-    phase_sum = {}
+    # headline: EXACTLY --steps steps, nothing else inside the timed region (no phase timing, no host synchronisation beyond
+    # what the step itself needs: the Lanczos convergence check)
     ms = []
     barrier()
     t0 = time.perf_counter()
     for it in range(args.steps):
         m = sim.step(args.kT, args.dt, args.warmup + it, lanczos_m=m)
         ms.append(m)
-        for k, v in sim.phase_times().items():
-            phase_sum[k] = phase_sum.get(k, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
+    # distribution of single steps (median, p10, p90), each bracketed by device events
+    n_pct = max(10, min(50, args.steps))
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_pct)]
+    for it in range(n_pct):
+        ev[it][0].record()
+        m = sim.step(args.kT, args.dt, args.warmup + args.steps + it, lanczos_m=m)
+        ev[it][1].record()
+    torch.cuda.synchronize()
+    per_step = sorted(a.elapsed_time(b) for a, b in ev)
+    pct = {"p10": per_step[int(0.1 * (n_pct - 1))], "p50": per_step[n_pct // 2], "p90": per_step[int(round(0.9 * (n_pct - 1)))],
+           "n": n_pct}
+    # per-phase device times from a separate loop (the library records hipEvents on its own stream and synchronises after
+    # every call to read them, so this loop is never the headline)
+    sim.set_timing(True)
+    phase_sum = {}
+    n_ph = max(5, min(20, args.steps))
+    for it in range(n_ph):
+        m = sim.step(args.kT, args.dt, args.warmup + args.steps + n_pct + it, lanczos_m=m)
+        for k, v in sim.phase_times().items():
+            phase_sum[k] = phase_sum.get(k, 0.0) + v
+    sim.set_timing(False)
     if world > 1:
         t = torch.tensor([elapsed, t_mf], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -138,7 +158,7 @@ def main():
     t_step = elapsed / args.steps
     ng = grid ** 3
     nloc, ngloc = n / world, ng / world
-    phases = {k: v / args.steps for k, v in phase_sum.items()}                # ms per step, rank 0
+    phases = {k: v / n_ph for k, v in phase_sum.items()}                     # ms per step, rank 0
     m_avg = float(np.mean(ms))
     # algorithmic bytes per launch (BASELINE.md section 3 / SURVEY.md 8d), per rank
     alg = {
@@ -151,22 +171,26 @@ def main():
     weight = dict(per_launch_ms)
     weight["t_matvec"] = per_launch_ms["t_matvec"] * max(1, info["lanczos_matvecs"] - 1)
     dom = max(weight, key=weight.get)
-    names = {"t_spread": "k_spread_bins (spread, incl. binning + weights)", "t_fft_fwd": "rocFFT 2-D R2C x3",
+    names = {"t_spread": "k_spread_tiles (spread, incl. binning + records)", "t_fft_fwd": "rocFFT 2-D R2C x3",
              "t_scale": "k_xfft_scale (x FFT + k-space scale/noise + inverse x FFT)",
              "t_fft_inv": "rocFFT 2-D C2R x3", "t_gather": "k_gather_bins (gather)",
              "t_real": "k_mreal_cells (near-field M_real.F from the cell list, writes the pair list)",
              "t_matvec": "k_mreal_list (near-field mat-vec from the pair list, once per Lanczos iteration after the first)"}
-    pmc_names = {"t_spread": "pse::k_spread_bins", "t_scale": "pse::k_xfft_scale", "t_gather": "pse::k_gather_bins",
+    pmc_names = {"t_spread": "pse::k_spread_tiles", "t_scale": "pse::k_xfft_scale", "t_gather": "pse::k_gather_bins",
                  "t_real": "pse::k_mreal_cells<true", "t_matvec": "pse::k_mreal_list"}
     ach = alg[dom] / (per_launch_ms[dom] * 1e-3) / 1e9 if per_launch_ms[dom] > 0 else 0.0
-    traffic = None
-    tr_file = os.path.join(ROOT, "profiles", "traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/summarize_prof.py
+    # HBM bytes of the dominant kernel: rocprofv3 counters cannot be collected from inside this process, so the figure comes
+    # from the committed counter passes of this same command (profiles/traffic.json: separate --pmc FETCH_SIZE and WRITE_SIZE
+    # runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide streaming reads) and is labelled as such
+    traffic, traffic_src = None, None
+    tr_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr_file) and world == 1 and n == 1_000_000 and grid == 256:
         try:
             tj = json.load(open(tr_file))
             for k, v in tj.items():
                 if k.startswith(pmc_names.get(dom, "?")):
-                    traffic = v["fetch_raw"] + v["write"]     # bytes per launch (reads uncorrected: lower bound)
+                    traffic = 2 * v["fetch_raw"] + v["write"]
+                    traffic_src = f"profiles/traffic.json ({tj.get('_source', 'separate rocprofv3 --pmc passes')}); not measured in this run"
         except Exception:
             traffic = None
     sg_ms = per_launch_ms["t_spread"] + per_launch_ms["t_gather"]
@@ -175,7 +199,7 @@ def main():
         "metric": "BD particle-steps/s (full PSE Brownian step: M.F + k-space noise + Lanczos M^1/2.psi + Euler), "
                   "N=1e6, phi=0.1",
         "value": n / t_step, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "ms_per_step": t_step * 1e3, "ms_per_step_percentiles": pct, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"random-sphere suspension N={n}, phi={args.phi}, cubic L={L:.2f}, grid {grid}^3, "
                                f"xi={xi:.4f}, rcut={info['rcut']:.3f}, P={info['P']}, error={args.error}, kT={args.kT}, "
@@ -183,7 +207,7 @@ def main():
         "steps_per_s": 1.0 / t_step, "mf_evals_per_s": 1.0 / t_mf, "mf_particle_evals_per_s": n / t_mf,
         "lanczos_m": m_avg, "lanczos_matvecs_per_step": info["lanczos_matvecs"],
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg[dom], "ms_per_launch": per_launch_ms[dom]},
         "spread_plus_gather": {"ms": sg_ms, "algorithmic_bytes": sg_bytes,
                                "frac_of_hbm_peak": (sg_bytes / (sg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sg_ms > 0 else 0.0},

@@ -56,7 +56,7 @@ def build_lib(force=False):
         _run([HIPCC, *CXXFLAGS, *extra, "-c", os.path.join(CSRC, name), "-o", obj])
         objs.append(obj)
     _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs,
-          f"-L{ROCM}/lib", "-lrocfft", "-lrccl", "-lpthread", f"-Wl,-rpath,{ROCM}/lib"])
+          f"-L{ROCM}/lib", "-lrocfft", "-lrccl", "-lpthread", "-ldl", f"-Wl,-rpath,{ROCM}/lib"])
     return LIB
 
 

@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -165,11 +166,33 @@ static int set_cells(pse_handle *h, double gamma) {
     return 0;
 }
 
-static int ts(pse_handle *h, int p) { if (h->timing) HIPCHK(hipEventRecord(h->ph[p].a, h->stream)); return 0; }
-static int te(pse_handle *h, int p) { if (h->timing) HIPCHK(hipEventRecord(h->ph[p].b, h->stream)); return 0; }
-static int tsw(pse_handle *h, int p) { if (h->timing) HIPCHK(hipEventRecord(h->ph[p].a, h->wstream)); return 0; }
-static int tew(pse_handle *h, int p) { if (h->timing) HIPCHK(hipEventRecord(h->ph[p].b, h->wstream)); return 0; }
 enum { PH_SORT, PH_SPREAD, PH_FFTF, PH_SCALE, PH_FFTI, PH_GATHER, PH_REAL, PH_LANCZOS, PH_INTEG, PH_COMM, PH_TOTAL, PH_MATVEC };
+// Phase ranges for rocprofv3 --marker-trace (PSE_ROCTX=1): host-side roctx ranges around the launches of each phase (the
+// reference has one HOOMD Profiler push/pop around the whole step, PSEv1/Stokes.cc:450-451,519-521).  libroctx64 is
+// looked up at run time: no link dependency, nothing happens unless the switch is set.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char *e = getenv("PSE_ROCTX");
+        if (!e || !atoi(e)) return;
+        void *lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return;
+        push = (int (*)(const char *))dlsym(lib, "roctxRangePushA");
+        pop = (int (*)())dlsym(lib, "roctxRangePop");
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+static const Roctx &roctx() { static Roctx r; return r; }
+static const char *const PH_NAME[12] = {"pse:sort", "pse:spread", "pse:fft_forward", "pse:kspace_scale", "pse:fft_inverse", "pse:gather",
+                                        "pse:near_field", "pse:lanczos", "pse:integrate", "pse:exchange", "pse:total", "pse:matvec"};
+static void range_push(int p) { if (roctx().push) roctx().push(PH_NAME[p]); }
+static void range_pop() { if (roctx().pop) roctx().pop(); }
+static int ts(pse_handle *h, int p) { range_push(p); if (h->timing) HIPCHK(hipEventRecord(h->ph[p].a, h->stream)); return 0; }
+static int te(pse_handle *h, int p) { if (h->timing) HIPCHK(hipEventRecord(h->ph[p].b, h->stream)); range_pop(); return 0; }
+static int tsw(pse_handle *h, int p) { range_push(p); if (h->timing) HIPCHK(hipEventRecord(h->ph[p].a, h->wstream)); return 0; }
+static int tew(pse_handle *h, int p) { if (h->timing) HIPCHK(hipEventRecord(h->ph[p].b, h->wstream)); range_pop(); return 0; }
 
 static int collect_times(pse_handle *h, unsigned mask) {
     if (!h->timing) return 0;
@@ -433,6 +456,15 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     TRY(dmalloc(h, &h->partials, (size_t)3 * h->npart_cap));
     for (auto &ph : h->ph) { HIPCHK(hipEventCreate(&ph.a)); HIPCHK(hipEventCreate(&ph.b)); }
     h->info.device_bytes = h->bytes;
+    if (const char *v = getenv("PSE_VERBOSE"); v && atoi(v) > 0) {
+        // the parameter summary the reference prints at notice level 2 (PSEv1/Stokes.cc:241-252), one block on stderr
+        fprintf(stderr, "--- NUFFT Hydrodynamics Statistics ---\nMx: %d\nMy: %d\nMz: %d\nrcut: %.6g\n"
+                "Points per radius (x,y,z): %.4g, %.4g, %.4g\n--- Gaussian Spreading Parameters ---\ngauss_m: %.4g\ngauss_P: %d\n"
+                "gauss_eta: %.6g\ngauss_w: %.6g\ngauss_gridh (x,y,z): %.6g, %.6g, %.6g\n"
+                "--- engine ---\ncells: %d x %d x %d, ranks: %d (far-field slabs %d), device memory: %.2f GB\n",
+                d.Nx, d.Ny, d.Nz, d.rcut, d.Nx / h->box.Lx, d.Ny / h->box.Ly, d.Nz / h->box.Lz, d.gaussm, d.P, d.eta,
+                d.P * d.hx / 2.0, d.hx, d.hy, d.hz, h->nc.nx, h->nc.ny, h->nc.nz, h->n_slabs, h->grid_slabs, h->bytes / 1e9);
+    }
     return 0;
 }
 

@@ -87,6 +87,8 @@ struct pse_handle {
     SpreadWork sw = {};       // far-field bins and the bin-ordered particle records (origins, prefac * force, separable weights)
     NbList nb = {};
     bool nb_valid = false;   // the pair list matches the current sorted positions
+    DCells blk_nc = {0, 0, 0};   // cell grid the near-field blocks were planned for
+    size_t blk_list_elems = 0;   // allocated 2-byte entries of the block pair list
     bool w_is_mpsi = false;  // w_s already holds M_real psi_s (delivered by the pass that built the pair list)
     size_t n_cells_alloc = 0;
     float4 *posf_s = nullptr;   // single-precision copy of pos_s (cutoff pre-filter of the near field)
@@ -248,7 +250,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->plan_x_inv) rocfft_plan_destroy(h->plan_x_inv);
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
-    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cell_cnt, h->sup_s, h->sw.rec_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->nb.data, h->nb.cnt, h->pos_s, h->posf_s, h->pv,
+    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cell_cnt, h->sup_s, h->sw.rec_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->nb.data, h->nb.cnt, h->nb.blk.list, h->nb.blk.fh, h->pos_s, h->posf_s, h->pv,
                     h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->twiddle, h->fft_work, h->V,
                     h->scal, h->partials};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -328,6 +330,56 @@ static int make_plans(pse_handle *h) {
     return 0;
 }
 
+// near-field cell blocks for the current cell grid: shape from the mean occupancy, pair list sized for it.  Re-planned when a
+// box change alters the cell grid (the list only grows).
+static int plan_blocks(pse_handle *h) {
+    const DCells &nc = h->nc;
+    if (nc.nx == h->blk_nc.nx && nc.ny == h->blk_nc.ny && nc.nz == h->blk_nc.nz) return 0;
+    h->blk_nc = nc;
+    const size_t n = (size_t)h->n_pad;
+    const double ncell = (double)nc.nx * nc.ny * nc.nz;
+    const double vol = h->box.Lx * h->box.Ly * h->box.Lz;
+    const double nbar = (double)n / vol * 4.18879020478639 * h->d.rcut * h->d.rcut * h->d.rcut;
+    NbBlocks B = h->nb.blk;
+    unsigned short *keep = B.list;
+    double2 *keep_fh = B.fh;
+    const int per = nc.nx / std::max(1, h->n_slabs);
+    B.cx0 = h->n_slabs > 1 ? h->slab_rank * per : 0;
+    B.ncx = h->n_slabs > 1 ? per : nc.nx;
+    (void)ncell;
+    // Opt-in (PSE_NEAR_BLOCKS=1): measured on MI355X at the metric point the LDS-tile mat-vec takes 0.246 ms against 0.213 ms of the
+    // pair-list mat-vec with global gathers, and its list-building pass 0.74 ms against 0.74 ms: the tile
+    // staging and its barriers cost what the gathers cost.  Kept for large cutoffs / future tuning, covered by the GPU tests.
+    static const bool want = getenv("PSE_NEAR_BLOCKS") && atoi(getenv("PSE_NEAR_BLOCKS")) > 0;
+    if (want) nb_blocks_plan(B, nc, B.ncx, (double)n, (int)std::ceil(nbar + 6.0 * std::sqrt(nbar) + 8.0), h->n_intervals);
+    else B.on = 0;
+    B.list = keep; B.fh = keep_fh;
+    if (B.on) {
+        const size_t need = (size_t)nb_blocks_count(B, nc, B.ncx) * B.cap * 256, each = sizeof(unsigned short) + sizeof(double2);
+        if (need * each > (size_t)64e9) B.on = 0;
+        else if (need > h->blk_list_elems) {
+            if (B.list) { (void)hipFree(B.list); (void)hipFree(B.fh); h->bytes -= h->blk_list_elems * each; }
+            B.list = nullptr; B.fh = nullptr;
+            HIPCHK(hipMalloc((void **)&B.list, need * sizeof(unsigned short)));
+            HIPCHK(hipMalloc((void **)&B.fh, need * sizeof(double2)));
+            h->bytes += need * each;
+            h->blk_list_elems = need;
+        }
+    }
+    h->nb.blk = B;
+    if (B.on) {
+        const int nblk = nb_blocks_count(B, nc, B.ncx);
+        if (nblk > h->npart_cap) {   // one partial-sum slot per block
+            if (h->partials) (void)hipFree(h->partials);
+            h->partials = nullptr;
+            h->npart_cap = std::max(std::max(nblk + 64, LZ_NPART), mreal_partials_needed((int)n));
+            HIPCHK(hipMalloc((void **)&h->partials, (size_t)3 * h->npart_cap * sizeof(double)));
+        }
+    }
+    h->nb_valid = false;
+    return 0;
+}
+
 static int create_impl(const pse_params *p, pse_handle *h) {
     h->par = *p;
     h->box = Box{p->Lx, p->Ly, p->Lz, p->xy};
@@ -402,7 +454,14 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         h->sw.fb.tmp_bytes = bin_scan_temp_bytes(nbins);
         TRY(dmalloc(h, (char **)&h->sw.fb.tmp, h->sw.fb.tmp_bytes));
     }
-    {   // per-step pair list for the Lanczos mat-vecs: capacity from the mean neighbour count at full occupancy
+    // real-space functions first: the block planner needs the table size
+    std::vector<double> coef;
+    build_realspace_table(d.xi, d.rcut, coef, h->n_intervals);
+    TRY(dmalloc(h, &h->coef, coef.size()));
+    HIPCHK(hipMemcpy(h->coef, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice));
+    TRY(dmalloc(h, &h->nb.cnt, n));
+    TRY(plan_blocks(h));
+    if (!h->nb.blk.on) {   // legacy per-step pair list (an axis with fewer than three cells): capacity from the mean neighbour count
         const double vol = h->box.Lx * h->box.Ly * h->box.Lz;
         const double nbar = (double)n / vol * 4.18879020478639 * d.rcut * d.rcut * d.rcut;
         int cap = (int)std::ceil(1.5 * nbar + 16.0);
@@ -413,17 +472,11 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         if (cap > 0) {
             TRY(dmalloc(h, &h->nb.data, nb_list_bytes(n + 64, cap)));   // + one wave: rows are blocked from the rank's first row
         }
-        TRY(dmalloc(h, &h->nb.cnt, n));
     }
     TRY(dmalloc(h, &h->pos_s, n)); TRY(dmalloc(h, &h->posf_s, n));
-    if (h->n_slabs == 1) TRY(dmalloc(h, &h->pv, 3 * n));   // sharded runs exchange ghost rows of the plain vectors instead
+    if (h->n_slabs == 1 && !h->nb.blk.on) TRY(dmalloc(h, &h->pv, 3 * n));   // legacy pair-list mat-vec: packed gather records
     TRY(dmalloc(h, &h->f_s, n)); TRY(dmalloc(h, &h->uw_s, n)); TRY(dmalloc(h, &h->ur_s, n));
     TRY(dmalloc(h, &h->ub_s, n)); TRY(dmalloc(h, &h->psi_s, n)); TRY(dmalloc(h, &h->w_s, n));
-
-    std::vector<double> coef;
-    build_realspace_table(d.xi, d.rcut, coef, h->n_intervals);
-    TRY(dmalloc(h, &h->coef, coef.size()));
-    HIPCHK(hipMemcpy(h->coef, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice));
 
     const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
     TRY(dmalloc(h, &h->rgrid, 3 * nr));
@@ -437,23 +490,26 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     // final sum: on a single GPU they run on two streams, so latency-bound kernels of one chain fill the gaps of the
     // other and the Lanczos host checks do not stall the far field.  (Teams keep one stream: one RCCL communicator.)
     h->wstream = h->stream;
-    // A deterministic evaluation (kT = 0: no Lanczos) always forks: near field and far field are then the only two pieces
-    // and nothing is timed per kernel.  For Brownian steps the fork is opt-in (PSE_OVERLAP=1): it shortens the step by
-    // ~8 % but every kernel then shares the chip, so per-kernel durations -- the roofline evidence -- are no longer those
-    // of the kernel alone; by default the far field is queued behind the Lanczos iterations on the one stream instead.
+    // Evaluations fork whenever no phase timing is requested: the far-field chain runs on a side stream next to the near field
+    // and the Lanczos iterations (both chains are latency- rather than bandwidth-bound, so they overlap well).  With
+    // pse_set_timing on, everything runs on one stream and the far field is queued behind the Lanczos iterations: per-kernel
+    // durations -- the roofline evidence -- are then those of the kernel alone.  PSE_OVERLAP=0 restricts the fork to kT = 0.
     if (h->n_slabs == 1 && !(getenv("PSE_OVERLAP") && atoi(getenv("PSE_OVERLAP")) < 0)) {
         HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-        h->overlap_all = getenv("PSE_OVERLAP") && atoi(getenv("PSE_OVERLAP")) > 0;
+        h->overlap_all = !(getenv("PSE_OVERLAP") && atoi(getenv("PSE_OVERLAP")) == 0);   // on unless PSE_OVERLAP=0
     }
     TRY(make_plans(h));
 
     TRY(dmalloc(h, &h->V, (size_t)(M_MAX + 1) * n));
     TRY(dmalloc(h, &h->scal, (size_t)LZ_NSCAL));
     HIPCHK(hipHostMalloc((void **)&h->sc_host, LZ_NSCAL * sizeof(double), hipHostMallocDefault));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_scal, hipEventDisableTiming)); h->npart_cap = std::max(LZ_NPART, mreal_partials_needed((int)n));
-    TRY(dmalloc(h, &h->partials, (size_t)3 * h->npart_cap));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_scal, hipEventDisableTiming)); 
+    if (!h->partials) {
+        h->npart_cap = std::max(LZ_NPART, mreal_partials_needed((int)n));
+        TRY(dmalloc(h, &h->partials, (size_t)3 * h->npart_cap));
+    }
     for (auto &ph : h->ph) { HIPCHK(hipEventCreate(&ph.a)); HIPCHK(hipEventCreate(&ph.b)); }
     h->info.device_bytes = h->bytes;
     if (const char *v = getenv("PSE_VERBOSE"); v && atoi(v) > 0) {
@@ -493,6 +549,7 @@ extern "C" int pse_set_box(pse_handle *h, double Lx, double Ly, double Lz, doubl
     h->box = nb;
     h->nc = nc;
     h->cell_gamma = gamma;
+    if (h->nb.cnt) { HIPCHK(hipSetDevice(h->device)); TRY(plan_blocks(h)); }
     h->d.hx = Lx / h->d.Nx; h->d.hy = Ly / h->d.Ny; h->d.hz = Lz / h->d.Nz;
     h->G.hx = h->d.hx; h->G.hy = h->d.hy; h->G.hz = h->d.hz;
     set_dbox(h);
@@ -846,6 +903,15 @@ static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*ou
                 bool build_list, bool with_psi = false) {
     for (pse_handle *h : T.m) {
         h->w_is_mpsi = false;
+        if (h->nb.blk.on) {
+            // cell blocks: the first mat-vec of a step scans the tiles and writes the step's pair list (2 bytes per pair), every
+            // later one applies it; with_psi: M_real psi in the same pass (the first Lanczos mat-vec comes free)
+            const bool build = !h->nb_valid;
+            launch_mreal_blocks(h->pos_s, h->*vec + vec_off, h->*out + out_off, nullptr, nullptr,
+                                h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, h->n_intervals, h->nb, build, LzFuse{}, h->stream);
+            h->nb_valid = true;
+            continue;
+        }
         int mode = MREAL_CELLS;
         if (h->nb.cap > 0) {
             if (h->nb_valid) mode = MREAL_USE_LIST;
@@ -881,7 +947,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
         for (; done < target; ++done) {
             // iteration j = done on the unnormalised x_j (psi for j = 0, else parked in V[j]); see k_lz_update
             const bool have_y = done == 0 && h0->w_is_mpsi;      // M psi came with the pass that built the pair list
-            const bool fused = !have_y && h0->nb.cap > 0 && h0->nb_valid;   // sums fused into the pair-list mat-vec
+            const bool fused = !have_y && (h0->nb.cap > 0 || h0->nb.blk.on) && h0->nb_valid;   // sums fused into the pair-list mat-vec
             const bool timed = done == 1 && fused;               // one pair-list mat-vec kernel per call is timed on its own
             if (!fused && !have_y) TRY(real(T, done == 0 ? &pse_handle::psi_s : &pse_handle::V, &pse_handle::w_s, (size_t)done * stride, 0, N, true));
             for (pse_handle *h : T.m) {
@@ -891,6 +957,13 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
                 const double4 *vjm1 = done > 0 ? h->V + (size_t)(done - 1) * stride : nullptr;
                 if (fused) {
                     const bool ev = timed && h->timing;
+                    if (h->nb.blk.on) {
+                        if (ev) HIPCHK(hipEventRecord(h->ph[PH_MATVEC].a, h->stream));
+                        launch_mreal_blocks(h->pos_s, xj, h->w_s, nullptr, nullptr, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef,
+                                            h->n_intervals, h->nb, false, LzFuse{vjm1, h->partials, h->npart_cap}, h->stream);
+                        if (ev) HIPCHK(hipEventRecord(h->ph[PH_MATVEC].b, h->stream));
+                        launch_lz_reduce3(h->partials, nb_blocks_count(h->nb.blk, h->nc, h->nb.blk.ncx), h->npart_cap, h->scal, h->stream);
+                    } else
                     launch_mreal_lanczos(h->pos_s, xj, h->w_s, lo, hi, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef,
                                          h->nb, LzFuse{vjm1, h->partials, h->npart_cap}, h->scal,
                                          ev ? h->ph[PH_MATVEC].a : nullptr, ev ? h->ph[PH_MATVEC].b : nullptr, h->stream,
@@ -984,7 +1057,9 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
     *mask |= 1u << PH_SORT;
     const bool noise = kT > 0.0;
     for (pse_handle *h : T.m) {   // where the wave chain of this call runs
-        const bool on = h->side && parts == 3 && (h->overlap_all || (!noise && !h->timing));
+        // the two chains share the chip whenever nothing is timed per kernel: with phase timing on, every kernel runs alone
+        // on one stream (those durations are the roofline evidence)
+        const bool on = h->side && parts == 3 && !h->timing && (h->overlap_all || !noise);
         if (on != h->side_on || h->wstream != (on ? h->side : h->stream)) {
             h->side_on = on;
             h->wstream = on ? h->side : h->stream;

@@ -115,6 +115,7 @@ __device__ __forceinline__ double exp_neg(double x) { return exp_lean(x); }   //
 // f(r), g(r) of M_real = f (I - rr) + g rr  (replaces the fp32 linear table PSEv1/Stokes.cc:334-422 and its
 // lookup PSEv1/Mobility.cu:661-670): analytic free-space RPY minus the tabulated smooth wave part.
 // Returns f and (g - f)/r^2.
+template <int STRIDE = 2 * RS_NCOEF>   // doubles per interval (a copy in LDS pads it to 21: intervals then start on different banks)
 __device__ __forceinline__ void eval_fg(double r2, const double *__restrict__ coef, double &f, double &gmf_r2) {
     const double r = sqrt(r2);
     const double ir2 = 1.0 / r2;
@@ -130,7 +131,7 @@ __device__ __forceinline__ void eval_fg(double r2, const double *__restrict__ co
     const double s = r * RS_PER_UNIT;
     const int k = (int)s;
     const double t = 2.0 * (s - k) - 1.0;
-    const double *c = coef + (size_t)k * (2 * RS_NCOEF);
+    const double *c = coef + (size_t)k * STRIDE;
     double fw = c[RS_DEG], gw = c[RS_NCOEF + RS_DEG];
 #pragma unroll
     for (int q = RS_DEG - 1; q >= 0; --q) {
@@ -140,5 +141,45 @@ __device__ __forceinline__ void eval_fg(double r2, const double *__restrict__ co
     f = f0 - fw;
     gmf_r2 = ((g0 - gw) - f) * ir2;
 }
+
+// ---- cell walk ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void image_shift(unsigned code, const DBox &b, double &sx, double &sy, double &sz) {
+    const int wx = (int)(code / 9) - 1, wy = (int)((code / 3) % 3) - 1, wz = (int)(code % 3) - 1;
+    sx = wx * b.Lx + wy * b.xy * b.Ly;
+    sy = wy * b.Ly;
+    sz = wz * b.Lz;
+}
+
+struct CellWalk {   // the neighbour cells of one particle as (slot range, image code) runs
+    int cx, cy, cz, rx, ry, rz;
+};
+
+template <class F>
+__device__ __forceinline__ void for_each_run(const DCells &nc, const int *__restrict__ cell_off, int cx, int cy, int cz,
+                                             F &&body) {
+    const int rx = nc.nx > 1 ? 1 : 0, ry = nc.ny > 1 ? 1 : 0;
+    for (int ox = -rx; ox <= rx; ++ox) {
+        int ax = cx + ox, wx = 0;
+        if (ax < 0) { ax += nc.nx; wx = -1; } else if (ax >= nc.nx) { ax -= nc.nx; wx = 1; }
+        for (int oy = -ry; oy <= ry; ++oy) {
+            int ay = cy + oy, wy = 0;
+            if (ay < 0) { ay += nc.ny; wy = -1; } else if (ay >= nc.ny) { ay -= nc.ny; wy = 1; }
+            const int base = (ax * nc.ny + ay) * nc.nz;
+            const unsigned cxy = (unsigned)((wx + 1) * 9 + (wy + 1) * 3);
+            if (nc.nz == 1) {
+                body(cell_off[base], cell_off[base + 1], cxy + 1u);
+            } else if (cz >= 1 && cz + 1 < nc.nz) {
+                body(cell_off[base + cz - 1], cell_off[base + cz + 2], cxy + 1u);   // three z cells, one run
+            } else {
+                for (int oz = -1; oz <= 1; ++oz) {
+                    int az = cz + oz, wz = 0;
+                    if (az < 0) { az += nc.nz; wz = -1; } else if (az >= nc.nz) { az -= nc.nz; wz = 1; }
+                    body(cell_off[base + az], cell_off[base + az + 1], cxy + (unsigned)(wz + 1));
+                }
+            }
+        }
+    }
+}
+
 
 }  // namespace pse

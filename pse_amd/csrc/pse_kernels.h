@@ -23,10 +23,23 @@ void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double
 // in one contiguous 1280-byte record [64 x u32 (neighbour slot | image code << 27)][64 x f64 f][64 x f64 h], records of
 // one wave back to back -- a wave streams one contiguous region instead of 3*cnt regions megabytes apart.
 // Row r = i - lo (lo: first row of the rank, fixed within a step); record (r / 64) * cap + slot.
+// Cell blocks of the near field (pse_nearfield.hip): a workgroup owns bx x by x bz cells, stages them and their one-cell halo in
+// LDS and keeps, per step, a pair list of 2-byte indices into that tile.
+struct NbBlocks {
+    int on;                    // 1: in use (every axis has >= 3 cells); 0: the legacy kernels below
+    int bx, by, bz;            // cells per block
+    int cap_st;                // particles a tile holds (LDS)
+    int cap;                   // list slots per lane
+    int tpr;                   // lanes per row (1, 2, 4): few long rows are split
+    int cx0, ncx;              // the rank's cell layers along x
+    unsigned short *list;      // [blocks][cap][256] tile index of the neighbour
+    double2 *fh;               // [blocks][cap][256] f(r), (g(r) - f(r))/r^2 of the pair
+};
 struct NbList {
     char *data;
     int *cnt;             // neighbour count per particle; -1 if it exceeded cap (dense cluster): that row walks the cells
     int cap;
+    NbBlocks blk;
 };
 constexpr size_t NB_REC = 64 * 20;
 __host__ __device__ inline size_t nb_list_bytes(size_t rows, int cap) { return ((rows + 63) / 64) * (size_t)cap * NB_REC; }
@@ -49,6 +62,13 @@ void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w
                           double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s,   // events (nullable) bracket the mat-vec kernel
                           const double2 *pv = nullptr);   // packed (position, vector) records holding vec_s, or null
 int mreal_partials_needed(int rows);
+// cell-block near field
+void nb_blocks_plan(NbBlocks &B, const DCells &nc, int ncx, double n, int slots_needed, int nint);
+int nb_blocks_count(const NbBlocks &B, const DCells &nc, int ncx);
+void launch_mreal_blocks(const double4 *pos_s, const double4 *vec_s, double4 *out_s, const double4 *vec2_s, double4 *out2_s,
+                         const int *cell_off, DBox box, DCells nc, double rcut, double self, const double *coef, int nint, NbList nb,
+                         bool build, LzFuse lz, hipStream_t s);
+void launch_lz_reduce3(const double *partials, int npart, int cap, double *scal, hipStream_t s);
 
 // ---- far field (K2-K8) -----------------------------------------------------------------------------------
 // scratch of the fast far-field path (rebuilt every call): particles binned by the 8^3 block of nodes their support

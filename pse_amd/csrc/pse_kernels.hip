@@ -151,44 +151,6 @@ void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double
 constexpr int QCAP = 48;
 constexpr unsigned JMASK = (1u << 27) - 1;
 
-__device__ __forceinline__ void image_shift(unsigned code, const DBox &b, double &sx, double &sy, double &sz) {
-    const int wx = (int)(code / 9) - 1, wy = (int)((code / 3) % 3) - 1, wz = (int)(code % 3) - 1;
-    sx = wx * b.Lx + wy * b.xy * b.Ly;
-    sy = wy * b.Ly;
-    sz = wz * b.Lz;
-}
-
-struct CellWalk {   // the neighbour cells of one particle as (slot range, image code) runs
-    int cx, cy, cz, rx, ry, rz;
-};
-
-template <class F>
-__device__ __forceinline__ void for_each_run(const DCells &nc, const int *__restrict__ cell_off, int cx, int cy, int cz,
-                                             F &&body) {
-    const int rx = nc.nx > 1 ? 1 : 0, ry = nc.ny > 1 ? 1 : 0;
-    for (int ox = -rx; ox <= rx; ++ox) {
-        int ax = cx + ox, wx = 0;
-        if (ax < 0) { ax += nc.nx; wx = -1; } else if (ax >= nc.nx) { ax -= nc.nx; wx = 1; }
-        for (int oy = -ry; oy <= ry; ++oy) {
-            int ay = cy + oy, wy = 0;
-            if (ay < 0) { ay += nc.ny; wy = -1; } else if (ay >= nc.ny) { ay -= nc.ny; wy = 1; }
-            const int base = (ax * nc.ny + ay) * nc.nz;
-            const unsigned cxy = (unsigned)((wx + 1) * 9 + (wy + 1) * 3);
-            if (nc.nz == 1) {
-                body(cell_off[base], cell_off[base + 1], cxy + 1u);
-            } else if (cz >= 1 && cz + 1 < nc.nz) {
-                body(cell_off[base + cz - 1], cell_off[base + cz + 2], cxy + 1u);   // three z cells, one run
-            } else {
-                for (int oz = -1; oz <= 1; ++oz) {
-                    int az = cz + oz, wz = 0;
-                    if (az < 0) { az += nc.nz; wz = -1; } else if (az >= nc.nz) { az -= nc.nz; wz = 1; }
-                    body(cell_off[base + az], cell_off[base + az + 1], cxy + (unsigned)(wz + 1));
-                }
-            }
-        }
-    }
-}
-
 __device__ __forceinline__ void nb_store(char *rec, int slot, int lane, unsigned e, double f, double h) {
     char *r = rec + (size_t)slot * NB_REC;
     ((unsigned *)r)[lane] = e;
@@ -472,6 +434,9 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
 
 __global__ void __launch_bounds__(1024) k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, double *__restrict__ scal);
 int mreal_partials_needed(int rows) { return nblocks(std::max(rows, 1), TPB); }
+void launch_lz_reduce3(const double *partials, int npart, int cap, double *scal, hipStream_t s) {
+    hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, partials, npart, cap, 3, scal);
+}
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, int lo, int hi, const int *cell_off,
                           DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,
                           double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s, const double2 *pv) {

@@ -350,3 +350,17 @@ def test_pair_repulsion_matches_port(torch_cuda, oracle, xy):
     assert rel(out[:, :3], ref + force) < 1e-12
     with pytest.raises(pse_amd.PSEError):
         eng.pair_repulsion(to4(pos), f, 40.0, 2.0 * eng.info()["rcut"])
+
+
+def test_cell_block_near_field_opt_in(torch_cuda):
+    """The LDS-tile near field (PSE_NEAR_BLOCKS=1, off by default: measured slower) against the same checks as
+    the default path: the switch is read once per process, so the checks run in a child process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PSE_NEAR_BLOCKS="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"), "-k",
+                        "mreal_matches_oracle or lanczos_sqrt or pair_list_overflow or brownian_velocity_matches_port or step_integrates"],
+                       env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]

@@ -71,7 +71,12 @@ struct pse_handle {
     int device = 0;
     hipStream_t stream = nullptr;    // main chain: sort, near field, Lanczos, update (caller-visible ordering)
     hipStream_t wstream = nullptr;   // wave-space chain; == stream unless the two chains overlap (single GPU)
-    hipStream_t side = nullptr;      // owned non-blocking stream behind wstream
+    hipStream_t side = nullptr;      // non-blocking stream behind wstream (an in-process team shares one among its members)
+    hipStream_t side_owned = nullptr;
+    int *bounds_host = nullptr;      // pinned: slab row boundaries on their way back from the device
+    hipEvent_t ev_bounds = nullptr;
+    bool bounds_pending = false;
+    DCells bidx_nc = {0, 0, 0};      // cell grid the boundary-cell indices on the device belong to
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap_all = false;   // fork also for Brownian steps (PSE_OVERLAP=1)
     bool side_on = false;       // this call runs the wave chain on the side stream
@@ -258,7 +263,9 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_scal) (void)hipEventDestroy(h->ev_scal);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->side_owned) (void)hipStreamDestroy(h->side_owned);
+    if (h->bounds_host) (void)hipHostFree(h->bounds_host);
+    if (h->ev_bounds) (void)hipEventDestroy(h->ev_bounds);
     if (h->sc_host) (void)hipHostFree(h->sc_host);
     delete h;
     return 0;
@@ -483,6 +490,8 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     TRY(dmalloc(h, &h->cgrid, 3 * ncx));
     if (h->grid_slabs > 1) { TRY(dmalloc(h, &h->sendbuf, 3 * ncx)); TRY(dmalloc(h, &h->recvbuf, 3 * ncx)); }
     if (h->n_slabs > 1) {
+        HIPCHK(hipHostMalloc((void **)&h->bounds_host, ((size_t)3 * h->n_slabs + 1) * sizeof(int), hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_bounds, hipEventDisableTiming));
         TRY(dmalloc(h, &h->d_bidx, (size_t)3 * h->n_slabs + 1)); TRY(dmalloc(h, &h->d_bounds, (size_t)3 * h->n_slabs + 1));
         TRY(dmalloc(h, &h->utot_s, n));
     }
@@ -494,8 +503,9 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     // and the Lanczos iterations (both chains are latency- rather than bandwidth-bound, so they overlap well).  With
     // pse_set_timing on, everything runs on one stream and the far field is queued behind the Lanczos iterations: per-kernel
     // durations -- the roofline evidence -- are then those of the kernel alone.  PSE_OVERLAP=0 restricts the fork to kT = 0.
-    if (h->n_slabs == 1 && !(getenv("PSE_OVERLAP") && atoi(getenv("PSE_OVERLAP")) < 0)) {
+    if (!(getenv("PSE_OVERLAP") && atoi(getenv("PSE_OVERLAP")) < 0)) {
         HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        h->side_owned = h->side;
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
         h->overlap_all = !(getenv("PSE_OVERLAP") && atoi(getenv("PSE_OVERLAP")) == 0);   // on unless PSE_OVERLAP=0
@@ -588,7 +598,8 @@ extern "C" int pse_get_info(pse_handle *h, pse_info *info) {
 struct pse_team {
     std::vector<pse_handle *> m;
     int G = 1;                   // ranks in the decomposition
-    ncclComm_t nccl = nullptr;   // set when members.size() == 1 and G > 1
+    ncclComm_t nccl = nullptr;   // set when members.size() == 1 and G > 1: near field, Lanczos, final exchange (main stream)
+    ncclComm_t nccl_w = nullptr; // its split: the far-field chain (all-to-alls, gather halo) on the side stream, concurrently
     double *scratch = nullptr;   // loopback all-reduce scratch
     size_t scratch_n = 0;
 };
@@ -610,8 +621,8 @@ static int team_all_to_all(pse_team &T, FS send, FR recv, size_t blk_doubles, in
         NCCLCHK(ncclGroupStart());
         for (int c = 0; c < nset; ++c)
             for (int q = 0; q < T.G; ++q) {
-                NCCLCHK(ncclSend(send(h) + c * set_stride + (size_t)q * blk_doubles, blk_doubles, ncclDouble, q, T.nccl, h->stream));
-                NCCLCHK(ncclRecv(recv(h) + c * set_stride + (size_t)q * blk_doubles, blk_doubles, ncclDouble, q, T.nccl, h->stream));
+                NCCLCHK(ncclSend(send(h) + c * set_stride + (size_t)q * blk_doubles, blk_doubles, ncclDouble, q, T.nccl_w, h->wstream));
+                NCCLCHK(ncclRecv(recv(h) + c * set_stride + (size_t)q * blk_doubles, blk_doubles, ncclDouble, q, T.nccl_w, h->wstream));
             }
         NCCLCHK(ncclGroupEnd());
         return 0;
@@ -621,7 +632,7 @@ static int team_all_to_all(pse_team &T, FS send, FR recv, size_t blk_doubles, in
             for (pse_handle *dst : T.m)
                 HIPCHK(hipMemcpyAsync(recv(dst) + c * set_stride + (size_t)src->slab_rank * blk_doubles,
                                       send(src) + c * set_stride + (size_t)dst->slab_rank * blk_doubles,
-                                      blk_doubles * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+                                      blk_doubles * sizeof(double), hipMemcpyDeviceToDevice, dst->wstream));
     return 0;
 }
 // every rank's chunk [rank*chunk, (rank+1)*chunk) of buf becomes visible in every rank's buf
@@ -672,10 +683,10 @@ static int team_halo_exchange(pse_team &T) {
         NCCLCHK(ncclGroupStart());
         for (int c = 0; c < 3; ++c) {
             double *own = comp(h, c) + plane * G.hl;
-            NCCLCHK(ncclSend(own, plane * G.nhalo, ncclDouble, left, T.nccl, h->stream));                          // my first planes
-            NCCLCHK(ncclSend(own + plane * (G.nxl - G.hl), plane * G.hl, ncclDouble, right, T.nccl, h->stream));   // my last planes
-            NCCLCHK(ncclRecv(own + plane * G.nxl, plane * G.nhalo, ncclDouble, right, T.nccl, h->stream));
-            NCCLCHK(ncclRecv(comp(h, c), plane * G.hl, ncclDouble, left, T.nccl, h->stream));
+            NCCLCHK(ncclSend(own, plane * G.nhalo, ncclDouble, left, T.nccl_w, h->wstream));                          // my first planes
+            NCCLCHK(ncclSend(own + plane * (G.nxl - G.hl), plane * G.hl, ncclDouble, right, T.nccl_w, h->wstream));   // my last planes
+            NCCLCHK(ncclRecv(own + plane * G.nxl, plane * G.nhalo, ncclDouble, right, T.nccl_w, h->wstream));
+            NCCLCHK(ncclRecv(comp(h, c), plane * G.hl, ncclDouble, left, T.nccl_w, h->wstream));
         }
         NCCLCHK(ncclGroupEnd());
         return 0;
@@ -687,9 +698,9 @@ static int team_halo_exchange(pse_team &T) {
         pse_handle *L = member((dst->slab_rank + T.G - 1) % T.G), *R = member((dst->slab_rank + 1) % T.G);
         for (int c = 0; c < 3; ++c) {
             HIPCHK(hipMemcpyAsync(comp(dst, c) + plane * (G.hl + G.nxl), comp(R, c) + plane * G.hl, plane * G.nhalo * sizeof(double),
-                                  hipMemcpyDeviceToDevice, dst->stream));
+                                  hipMemcpyDeviceToDevice, dst->wstream));
             HIPCHK(hipMemcpyAsync(comp(dst, c), comp(L, c) + plane * (G.hl + G.nxl - G.hl), plane * G.hl * sizeof(double),
-                                  hipMemcpyDeviceToDevice, dst->stream));
+                                  hipMemcpyDeviceToDevice, dst->wstream));
         }
     }
     return 0;
@@ -723,6 +734,29 @@ static int team_ghost_exchange(pse_team &T, FB buf) {
                               hipMemcpyDeviceToDevice, dst->stream));
     }
     return 0;
+}
+
+// One exchange per Lanczos iteration: the three partial sums (all-reduce) and the ghost rows of y = M x (every rank receives its
+// right neighbour's first cell layer and its left neighbour's last one) travel in ONE RCCL group.
+template <class FS, class FB>
+static int team_lanczos_exchange(pse_team &T, FS sums, FB buf) {
+    if (T.G == 1) return 0;
+    if (T.nccl) {
+        pse_handle *h = T.m[0];
+        const std::vector<int> &lo = h->row_lo, &fe = h->first_end, &lb = h->last_begin;
+        auto cnt = [](int a, int b) { return (size_t)std::max(0, b - a) * 4; };
+        const int r = h->slab_rank, L = (r + T.G - 1) % T.G, R = (r + 1) % T.G;
+        NCCLCHK(ncclGroupStart());
+        NCCLCHK(ncclAllReduce(sums(h), sums(h), 3, ncclDouble, ncclSum, T.nccl, h->stream));
+        NCCLCHK(ncclSend(buf(h) + (size_t)lo[r] * 4, cnt(lo[r], fe[r]), ncclDouble, L, T.nccl, h->stream));
+        NCCLCHK(ncclSend(buf(h) + (size_t)lb[r] * 4, cnt(lb[r], lo[r + 1]), ncclDouble, R, T.nccl, h->stream));
+        NCCLCHK(ncclRecv(buf(h) + (size_t)lo[R] * 4, cnt(lo[R], fe[R]), ncclDouble, R, T.nccl, h->stream));
+        NCCLCHK(ncclRecv(buf(h) + (size_t)lb[L] * 4, cnt(lb[L], lo[L + 1]), ncclDouble, L, T.nccl, h->stream));
+        NCCLCHK(ncclGroupEnd());
+        return 0;
+    }
+    TRY(team_all_reduce_sum(T, sums, 3));
+    return team_ghost_exchange(T, buf);
 }
 
 // every rank's own rows [row_lo[r], row_lo[r+1]) of buf become visible on every rank (blocks of different sizes)
@@ -766,30 +800,43 @@ static void row_range(const pse_handle *h, int N, int &lo, int &hi) {
     lo = h->row_lo[h->slab_rank]; hi = h->row_lo[h->slab_rank + 1];
 }
 
-// after the sort: read back where the cell slabs begin in the sorted arrays (3G+1 ints; identical on every rank because
-// the particle arrays are replicated)
-static int slab_bounds(pse_handle *h, int N) {
+// after the sort: where the cell slabs begin in the sorted arrays (3G+1 ints; identical on every rank because the particle
+// arrays are replicated).  The copy back is issued here and awaited only where the host first needs the numbers -- after the
+// far-field chain has been queued, so the GPU does not idle meanwhile.
+static int slab_bounds_issue(pse_handle *h) {
     const int G = h->n_slabs;
     if (G == 1) return 0;
     const int layer = h->nc.ny * h->nc.nz, per = h->nc.nx / G;
     std::vector<int> idx(3 * G + 1);
     for (int r = 0; r <= G; ++r) idx[r] = r * per * layer;
     for (int r = 0; r < G; ++r) { idx[G + 1 + r] = (r * per + 1) * layer; idx[2 * G + 1 + r] = ((r + 1) * per - 1) * layer; }
-    HIPCHK(hipMemcpyAsync(h->d_bidx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (h->bidx_nc.nx != h->nc.nx || h->bidx_nc.ny != h->nc.ny || h->bidx_nc.nz != h->nc.nz) {   // once per cell grid
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(h->d_bidx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+        h->bidx_nc = h->nc;
+    }
     launch_pick(h->cell_off, h->d_bidx, (int)idx.size(), h->d_bounds, h->stream);
-    std::vector<int> out(idx.size());
-    HIPCHK(hipMemcpyAsync(out.data(), h->d_bounds, out.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->row_lo.assign(out.begin(), out.begin() + G + 1);
-    h->first_end.assign(out.begin() + G + 1, out.begin() + 2 * G + 1);
-    h->last_begin.assign(out.begin() + 2 * G + 1, out.end());
+    HIPCHK(hipMemcpyAsync(h->bounds_host, h->d_bounds, idx.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipEventRecord(h->ev_bounds, h->stream));
+    h->bounds_pending = true;
+    return 0;
+}
+static int slab_bounds_wait(pse_handle *h, int N) {
+    if (!h->bounds_pending) return 0;
+    h->bounds_pending = false;
+    const int G = h->n_slabs;
+    HIPCHK(hipEventSynchronize(h->ev_bounds));
+    const int *out = h->bounds_host;
+    h->row_lo.assign(out, out + G + 1);
+    h->first_end.assign(out + G + 1, out + 2 * G + 1);
+    h->last_begin.assign(out + 2 * G + 1, out + 3 * G + 1);
     if (h->row_lo[0] != 0 || h->row_lo[G] != N) return fail(PSE_ERR_NUMERIC, "inconsistent cell offsets after the sort");
     return 0;
 }
 
 // bin + sort + gather into cell order (positions change every step, so this runs every call; every rank sorts all
 // particles: the state is replicated, the work of the later phases is what is sharded)
-static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const unsigned *group, int N) {
+static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const unsigned *group, int N, bool defer_bounds = false) {
     TRY(ts(h, PH_SORT));
     const int ncell = h->nc.nx * h->nc.ny * h->nc.nz;
     cell_sort(pos, group, N, h->dbox, h->nc, h->keys, h->vals, h->keys_s, h->cell_cnt, ncell, h->sort_tmp, h->sort_tmp_bytes,
@@ -798,7 +845,8 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
     h->sorted_N = N;
     h->nb_valid = false;
     h->w_is_mpsi = false;
-    TRY(slab_bounds(h, N));
+    TRY(slab_bounds_issue(h));
+    if (!defer_bounds) TRY(slab_bounds_wait(h, N));
     TRY(te(h, PH_SORT));
     HIPCHK(hipGetLastError());
     return 0;
@@ -927,6 +975,23 @@ static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*ou
     return 0;
 }
 
+// rows a rank updates in a Lanczos iteration: its own and the ghost layers its next mat-vec reads (the neighbours' nearest cell
+// layers; duplicates dropped: the update normalises in place)
+static int update_ranges(const pse_handle *h, int N, int rg[3][2]) {
+    if (h->n_slabs == 1) { rg[0][0] = 0; rg[0][1] = N; return 1; }
+    const int G = h->n_slabs, r = h->slab_rank, L = (r + G - 1) % G, R = (r + 1) % G;
+    int n = 0;
+    auto add = [&](int a, int b) {
+        if (b <= a) return;
+        for (int q = 0; q < n; ++q) if (rg[q][0] == a && rg[q][1] == b) return;
+        rg[n][0] = a; rg[n][1] = b; ++n;
+    };
+    add(h->row_lo[r], h->row_lo[r + 1]);
+    add(h->last_begin[L], h->row_lo[L + 1]);
+    add(h->row_lo[R], h->first_end[R]);
+    return n;
+}
+
 // M_real^{1/2} psi by Lanczos (PSEv1/Brownian.cu:357-765): psi_s (sorted order, replicated on every rank) ->
 // ub_s = scale |psi| V t on the rows this rank owns.  Scalars are replicated; vectors are valid on the own rows (+ the
 // neighbouring cell layers for the vector the next mat-vec reads).
@@ -974,16 +1039,16 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
                 }
                 h->w_is_mpsi = false;
             }
-            TRY(team_all_reduce_sum(T, [](pse_handle *h) { return h->scal + LZ_TMP; }, 3));
+            // the partial sums and the ghost rows of y = M x_j in one exchange; every rank then updates its own rows AND its ghost
+            // rows (it holds x_j and v_{j-1} there from the previous iteration), so x_{j+1} needs no exchange of its own
+            TRY(team_lanczos_exchange(T, [](pse_handle *h) { return h->scal + LZ_TMP; }, [](pse_handle *h) { return (double *)h->w_s; }));
             for (pse_handle *h : T.m) {
-                int lo, hi;
-                row_range(h, N, lo, hi);
+                int rg[3][2];
+                const int nrg = update_ranges(h, N, rg);
                 const double4 *xj = done == 0 ? h->psi_s : h->V + (size_t)done * stride;
                 launch_lz_update(xj, h->w_s, done > 0 ? h->V + (size_t)(done - 1) * stride : nullptr, h->V + (size_t)done * stride,
-                                 h->V + (size_t)(done + 1) * stride, done, h->scal, lo, hi, h->stream, h->pv);
+                                 h->V + (size_t)(done + 1) * stride, done, h->scal, rg, nrg, h->stream, h->pv);
             }
-            const size_t off = (size_t)(done + 1) * stride;   // the next mat-vec reads x_{j+1} on the neighbouring cell layers too
-            TRY(team_ghost_exchange(T, [&](pse_handle *h) { return (double *)(h->V + off); }));
         }
         // beta_done = |x_done| is not known yet (the next mat-vec would deliver it): one extra reduction per check
         for (pse_handle *h : T.m) {
@@ -1053,13 +1118,14 @@ struct Args {
 
 static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *group, int N, int parts, double kT, double dt,
                     unsigned timestep, int *m_io, unsigned *mask) {
-    for (size_t r = 0; r < T.m.size(); ++r) TRY(prepare(T.m[r], a[r].pos, a[r].force, group, N));
+    for (size_t r = 0; r < T.m.size(); ++r) TRY(prepare(T.m[r], a[r].pos, a[r].force, group, N, true));
     *mask |= 1u << PH_SORT;
     const bool noise = kT > 0.0;
+    const bool lanes = T.G == 1 || !T.nccl || T.nccl_w;   // a process-per-rank team forks only with its second communicator
     for (pse_handle *h : T.m) {   // where the wave chain of this call runs
         // the two chains share the chip whenever nothing is timed per kernel: with phase timing on, every kernel runs alone
         // on one stream (those durations are the roofline evidence)
-        const bool on = h->side && parts == 3 && !h->timing && (h->overlap_all || !noise);
+        const bool on = h->side && lanes && parts == 3 && !h->timing && (h->overlap_all || !noise);
         if (on != h->side_on || h->wstream != (on ? h->side : h->stream)) {
             h->side_on = on;
             h->wstream = on ? h->side : h->stream;
@@ -1082,6 +1148,8 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
     // back before it can finish the Brownian part, and meanwhile the GPU works through the far field instead of idling.
     const bool wave_behind = noise && (parts & 2) && (parts & 1) && !T.m[0]->side_on;
     if ((parts & 2) && !wave_behind) TRY(wave_chain());
+    // the slab row boundaries are needed from here on; the far-field chain is already queued
+    for (pse_handle *h : T.m) TRY(slab_bounds_wait(h, N));
     if (noise)   // psi first: the near-field pass that builds the pair list applies M_real to F and to psi together
         for (pse_handle *h : T.m) launch_psi(h->psi_s, h->tag_s, N, h->par.seed, timestep, h->stream);
     if (parts & 1) {
@@ -1099,6 +1167,11 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
     }
     if (T.G > 1) {
         // every rank has all three contributions for the rows it owns: add them, exchange the row blocks once
+        for (pse_handle *h : T.m)
+            if ((parts & 2) && h->side_on) {   // join: the gathered far-field velocity is needed now
+                HIPCHK(hipEventRecord(h->ev_join, h->side));
+                HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+            }
         for (pse_handle *h : T.m) {
             int lo, hi;
             row_range(h, N, lo, hi);
@@ -1109,7 +1182,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
     }
     for (size_t r = 0; r < T.m.size(); ++r) {
         pse_handle *h = T.m[r];
-        if ((parts & 2) && h->side_on) {   // join
+        if ((parts & 2) && h->side_on && T.G == 1) {   // join
             HIPCHK(hipEventRecord(h->ev_join, h->side));
             HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         }
@@ -1315,6 +1388,8 @@ static int team_connect(pse_team *T, const void *id128_host) {
     memcpy(&id, id128_host, sizeof id);
     HIPCHK(hipSetDevice(T->m[0]->device));
     NCCLCHK(ncclCommInitRank(&T->nccl, T->G, id, T->m[0]->slab_rank));
+    // a second communicator for the far-field chain: its all-to-alls run on the side stream next to the Lanczos exchanges
+    if (T->G > 1 && ncclCommSplit(T->nccl, 0, T->m[0]->slab_rank, &T->nccl_w, nullptr) != ncclSuccess) T->nccl_w = nullptr;
     return 0;
 }
 
@@ -1340,6 +1415,8 @@ extern "C" int pse_team_create(pse_handle **members, int n_members, const void *
     pse_team *T = new pse_team();
     T->m.assign(members, members + n_members);
     T->G = G;
+    if (n_members > 1)   // in-process team: one side stream for all members, so every lane is ordered by its stream alone
+        for (int i = 1; i < n_members; ++i) members[i]->side = members[0]->side;
     int rc = team_connect(T, id128_host);
     if (rc) { std::string keep = g_err; pse_team_destroy(T); g_err = keep; return rc; }
     *out = T;
@@ -1348,6 +1425,7 @@ extern "C" int pse_team_create(pse_handle **members, int n_members, const void *
 
 extern "C" int pse_team_destroy(pse_team *T) {
     if (!T) return 0;
+    if (T->nccl_w) ncclCommDestroy(T->nccl_w);
     if (T->nccl) ncclCommDestroy(T->nccl);
     if (T->scratch) (void)hipFree(T->scratch);
     delete T;

@@ -512,9 +512,11 @@ k_gather_bins(const FarRec *__restrict__ rec, FarBins fb, FastDiv dz, FastDiv dy
     if (SHEAR && tid < P * 8) s_k[tid] = exp_lean(gc.lnk * (double)((tid >> 3) * (tid & 7)));
     // Piece e of the region = 16 bytes (qx, qy, 2 hz .. 2 hz + 1), stored in that order.
     const bool windowed = G.nxl < G.Nx;
-    if (!windowed && t0[0] + E <= G.Nx && t0[1] + E <= G.Ny && t0[2] + EZ <= G.Nz) {
+    // first plane of the region in the stored array (a slab rank stores planes x0 - hl .. x0 + nxl + nhalo - 1)
+    const int px0 = windowed ? wrapi(t0[0] - (G.x0 - G.hl), G.Nx) : t0[0];
+    if (px0 + E <= (windowed ? G.nxl + G.hl + G.nhalo : G.Nx) && t0[1] + E <= G.Ny && t0[2] + EZ <= G.Nz) {
         // straight into LDS (no registers): wave-uniform base + per-lane offset
-        const char *src = reinterpret_cast<const char *>(g + ((size_t)t0[0] * G.Ny + t0[1]) * G.Nz + t0[2]);
+        const char *src = reinterpret_cast<const char *>(g + ((size_t)px0 * G.Ny + t0[1]) * G.Nz + t0[2]);
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int e0 = it * NT + wave * 64, e = e0 + lane, hz = e % HZ, r = e / HZ, qy = r % E, qx = r / E;

@@ -130,7 +130,7 @@ void launch_basis_combine(const double4 *V, size_t stride, const BasisCoef &t, i
 void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, int lo, int hi, double *partials, int cap,
                     double *scal, hipStream_t s);
 void launch_lz_update(const double4 *xin, const double4 *y, const double4 *vprev, double4 *vout, double4 *xnext, int j,
-                      double *scal, int lo, int hi, hipStream_t s, double2 *pv = nullptr);   // pv: also refresh the packed records
+                      double *scal, const int (*row_ranges)[2], int n_ranges, hipStream_t s, double2 *pv = nullptr);   // up to three disjoint row ranges in one launch; pv: also refresh the packed records
 void launch_sum_rows(const double4 *a, const double4 *b, const double4 *c, double4 *out, int lo, int hi, hipStream_t s);
 void launch_pick(const int *cell_off, const int *idx, int n, int *out, hipStream_t s);
 // vel[tag].xyz = a + b + c (each may be null), keep w

@@ -832,10 +832,11 @@ k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, d
     }
 }
 // alpha_j, beta_j from the reduced sums; v_j = x_j / beta_j (in place or from psi); x_{j+1} on the own rows
+struct RowRanges { int n, lo[3], hi[3]; };   // up to three row ranges (own rows and the two ghost layers), disjoint
 __global__ void __launch_bounds__(TPB)
 k_lz_update(const double4 *xin /* may alias vout: normalised in place */, const double4 *__restrict__ y,
-            const double4 *__restrict__ vprev, double4 *vout, double4 *__restrict__ xnext, int j, double *__restrict__ scal, int lo, int hi,
-            double2 *__restrict__ pv) {
+            const double4 *__restrict__ vprev, double4 *vout, double4 *__restrict__ xnext, int j, double *__restrict__ scal,
+            RowRanges rg, double2 *__restrict__ pv) {
     const double s1 = scal[LZ_TMP], s2 = scal[LZ_TMP + 1], s3 = scal[LZ_TMP + 2];
     const double beta = s1 > 0.0 ? sqrt(s1) : 0.0;
     const double inv = beta > 0.0 ? 1.0 / beta : 0.0;
@@ -844,7 +845,9 @@ k_lz_update(const double4 *xin /* may alias vout: normalised in place */, const 
         scal[LZ_ALPHA + j] = alpha;
         if (j == 0) { scal[LZ_NORM] = beta; scal[LZ_BETA] = 0.0; } else scal[LZ_BETA + j] = beta;
     }
-    for (int i = lo + blockIdx.x * TPB + threadIdx.x; i < hi; i += gridDim.x * TPB) {
+    const int n0 = rg.hi[0] - rg.lo[0], n1 = rg.n > 1 ? rg.hi[1] - rg.lo[1] : 0, n2 = rg.n > 2 ? rg.hi[2] - rg.lo[2] : 0;
+    for (int t = blockIdx.x * TPB + threadIdx.x; t < n0 + n1 + n2; t += gridDim.x * TPB) {
+        const int i = t < n0 ? rg.lo[0] + t : (t < n0 + n1 ? rg.lo[1] + (t - n0) : rg.lo[2] + (t - n0 - n1));
         const double4 p = xin[i], q = y[i];
         const double vx = p.x * inv, vy = p.y * inv, vz = p.z * inv;
         double nx = q.x * inv - alpha * vx, ny = q.y * inv - alpha * vy, nz = q.z * inv - alpha * vz;
@@ -864,9 +867,12 @@ void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, in
     hipLaunchKernelGGL(k_lz_reduce, dim3(y ? 3 : 1), dim3(1024), 0, s, partials, g, cap, y ? 3 : 1, scal);
 }
 void launch_lz_update(const double4 *xin, const double4 *y, const double4 *vprev, double4 *vout, double4 *xnext, int j,
-                      double *scal, int lo, int hi, hipStream_t s, double2 *pv) {
-    hipLaunchKernelGGL(k_lz_update, dim3(vec_grid(std::max(1, hi - lo))), dim3(TPB), 0, s, xin, y, vprev, vout, xnext, j, scal,
-                       lo, hi, pv);
+                      double *scal, const int (*rg)[2], int nrg, hipStream_t s, double2 *pv) {
+    RowRanges r{};
+    r.n = nrg;
+    int total = 0;
+    for (int q = 0; q < nrg && q < 3; ++q) { r.lo[q] = rg[q][0]; r.hi[q] = rg[q][1]; total += rg[q][1] - rg[q][0]; }
+    hipLaunchKernelGGL(k_lz_update, dim3(vec_grid(std::max(1, total))), dim3(TPB), 0, s, xin, y, vprev, vout, xnext, j, scal, r, pv);
 }
 // out[i] = a[i] + b[i] + c[i] on rows [lo, hi)  (each may be null)
 __global__ void k_sum_rows(const double4 *__restrict__ a, const double4 *__restrict__ b, const double4 *__restrict__ c,

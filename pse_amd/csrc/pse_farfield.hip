@@ -417,7 +417,9 @@ k_spread_atomic(const double4 *__restrict__ pos_s, const double4 *__restrict__ f
 static int spread_tz(const DGrid &G) {
     static const int force = getenv("PSE_SPREAD_TZ") ? atoi(getenv("PSE_SPREAD_TZ")) : 0;
     if (force == 8 || force == 16) return G.Nz >= 2 * force ? force : 8;
-    return G.Nz >= 64 ? 16 : 8;
+    // a wave per block: small grids need the smaller blocks to occupy the chip at all
+    const long blocks16 = (long)((G.nxl + 7) / 8) * ((G.Ny + 7) / 8) * ((G.Nz + 15) / 16);
+    return G.Nz >= 64 && blocks16 >= 2048 ? 16 : 8;
 }
 
 bool farfield_fast_path(const DGrid &G) {

@@ -682,9 +682,20 @@ k_xfft_scale(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restri
     double2 *comp[3] = {X, Y, Z};
     const size_t xstride = (size_t)rows * G.Nzh, base = (size_t)jl * G.Nzh + k0;
     for (int e = tid; e < N; e += NTH) tw[e] = twiddle[e];
-    for (int e = tid; e < 3 * N * KB; e += NTH) {             // KB consecutive kz are contiguous in memory (128 B at KB = 8)
-        const int c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
-        d[(c * KB + q) * CS + x] = q < kv ? comp[c][(size_t)x * xstride + base + q] : make_double2(0, 0);
+    {   // every load of a lane in flight before the first is parked in LDS (a load -> store loop pays the latency per element)
+        constexpr int PER = (3 * N * KB + NTH - 1) / NTH;
+        double2 v[PER];
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {                    // KB consecutive kz are contiguous in memory (128 B at KB = 8)
+            const int e = tid + it * NTH, c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
+            v[it] = make_double2(0, 0);
+            if (e < 3 * N * KB && q < kv) v[it] = comp[c][(size_t)x * xstride + base + q];
+        }
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int e = tid + it * NTH, c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
+            if (e < 3 * N * KB) d[(c * KB + q) * CS + x] = v[it];
+        }
     }
     __syncthreads();
     lds_fft_x<LOGN, KB, NTH, false>(d, tw);
@@ -703,6 +714,160 @@ k_xfft_scale(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restri
         const int c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
         if (q < kv) comp[c][(size_t)x * xstride + base + q] = d[(c * KB + q) * CS + x];
     }
+}
+
+// ---- N = 256: two radix-16 passes in registers ------------------------------------------------------------------------
+// 256 = 16 x 16: a lane holds the 16 points of one butterfly in registers (a 16-point DFT as 4 x 4 with constant twiddles), so a
+// transform crosses LDS twice instead of four times (radix 4) and the kernel runs 6 barriers instead of 17.  Columns are
+// padded by one element per 16 (index i -> i + i/16): both the stride-16 gathers and the contiguous 16-element scatters of
+// the two passes are then free of bank conflicts.  The pass twiddles W_256^{j r} of a lane (its j is fixed) live in registers.
+__device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
+constexpr int CS256 = 256 + 18;   // + 2: the KB columns a staging store touches together start 8 banks apart
+
+// In place; on return X[r] sits in x[DFT16_AT(r)]
+#define DFT16_AT(r) ((((r) >> 2)) + 4 * ((r) & 3))
+template <bool INVERSE>
+__device__ __forceinline__ void dft16(double2 (&x)[16]) {
+    // X[4 k0 + k1] = sum_n0 W16^{n0 (4 k0 + k1)} sum_n1 x[n0 + 4 n1] W4^{n1 k1}
+    constexpr double C1 = 0.92387953251128673848, S1 = 0.38268343236508978178, R2 = 0.70710678118654752440;
+    const double sg = INVERSE ? 1.0 : -1.0;                          // forward: exp(-i ...)
+    auto dft4 = [&](double2 &a, double2 &b, double2 &c, double2 &d) __attribute__((always_inline)) {
+        const double2 s0 = make_double2(a.x + c.x, a.y + c.y), s1 = make_double2(a.x - c.x, a.y - c.y);
+        const double2 s2 = make_double2(b.x + d.x, b.y + d.y), s3 = make_double2(b.x - d.x, b.y - d.y);
+        const double2 j3 = make_double2(-sg * s3.y, sg * s3.x);      // (+-i) (b - d): forward -i
+        a = make_double2(s0.x + s2.x, s0.y + s2.y);
+        b = make_double2(s1.x + j3.x, s1.y + j3.y);
+        c = make_double2(s0.x - s2.x, s0.y - s2.y);
+        d = make_double2(s1.x - j3.x, s1.y - j3.y);
+    };
+    // over n1 for every n0: t[n0][k1] lands in x[n0 + 4 k1]
+#pragma unroll
+    for (int n0 = 0; n0 < 4; ++n0) dft4(x[n0], x[n0 + 4], x[n0 + 8], x[n0 + 12]);
+    // twiddles W16^{n0 k1} = exp(sg i 2 pi n0 k1 / 16)
+    const double cw[10] = {1.0, C1, R2, S1, 0.0, -S1, -R2, -C1, -1.0, -C1};
+    const double sw[10] = {0.0, S1, R2, C1, 1.0, C1, R2, S1, 0.0, -S1};
+#pragma unroll
+    for (int n0 = 1; n0 < 4; ++n0)
+#pragma unroll
+        for (int k1 = 1; k1 < 4; ++k1) {
+            const int m = n0 * k1;                                   // <= 9
+            const double c = cw[m], sn = sg * sw[m];
+            const double2 v = x[n0 + 4 * k1];
+            x[n0 + 4 * k1] = make_double2(v.x * c - v.y * sn, v.x * sn + v.y * c);
+        }
+    // over n0 for every k1: X[4 k0 + k1] lands in x[k0 + 4 k1]
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft4(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);
+}
+
+// NCOL columns of 256 points at d + col * CS256 (padded index); lane = one butterfly (col, j).  The pass twiddle W_256^{j r} of
+// point r = 4 a + b is twa[a] twb[b] with twa[a] = W_256^{4 j a}, twb[b] = W_256^{j b} (forward): 8 registers pairs instead of 16
+template <int NCOL, int NTH, bool INVERSE>
+__device__ __forceinline__ void lds_fft256(double2 *__restrict__ d, const double2 *__restrict__ twiddle) {
+    const int tid = threadIdx.x;
+    double2 twa[4], twb[4];                                          // fetched per transform (a 4 KB table, cache-resident): not kept
+#pragma unroll                                                       // alive across the k-space scaling, which needs the registers
+    for (int r = 0; r < 4; ++r) { twa[r] = twiddle[((tid & 15) * 4 * r) & 255]; twb[r] = twiddle[((tid & 15) * r) & 255]; }
+    constexpr int NB = NCOL * 16;
+    static_assert(NB <= NTH, "one butterfly per lane");
+    const bool act = tid < NB;
+    const int col = tid >> 4, j = tid & 15;
+    double2 *c = d + col * CS256;
+    double2 x[16];
+    // pass 1 (ns = 1): points j + 16 r, no twiddle; results to 16 j + r
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = c[pad16(j + 16 * r)];
+        dft16<INVERSE>(x);
+    }
+    __syncthreads();
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[pad16(16 * j + r)] = x[DFT16_AT(r)];
+    }
+    __syncthreads();
+    // pass 2 (ns = 16): points j + 16 r times W_256^{j r}; results to j + 16 r (the lane's own points: no barrier in between)
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = c[pad16(j + 16 * r)];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) {                                // in place: no second set of 16 registers
+            const int ra = r >> 2, rb = r & 3;
+            double2 w = twb[rb];
+            if (ra && rb) w = make_double2(w.x * twa[ra].x - w.y * twa[ra].y, w.x * twa[ra].y + w.y * twa[ra].x);
+            else if (ra) w = twa[ra];
+            if (INVERSE) w.y = -w.y;
+            const double2 v = x[r];
+            x[r] = make_double2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+        }
+        dft16<INVERSE>(x);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[pad16(j + 16 * r)] = x[DFT16_AT(r)];
+    }
+    __syncthreads();
+}
+
+template <int KB, int NTH, int WPS>
+__global__ void __launch_bounds__(NTH, WPS)
+k_xfft_scale256(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ Z, DGrid G, DBox box, ScaleArgs a,
+                const double2 *__restrict__ twiddle) {
+    constexpr int N = 256, NCOL = 3 * KB;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double2 *d = reinterpret_cast<double2 *>(smem_raw);      // [3][KB][CS256]
+    const int tid = threadIdx.x;
+    const int nkb = (G.Nzh + KB - 1) / KB;
+    const int rows = a.transposed ? a.nyl : G.Ny;
+    const int jl = blockIdx.x / nkb, k0 = (blockIdx.x - jl * nkb) * KB;
+    const int j = a.transposed ? a.y0 + jl : jl;
+    const int kv = min(KB, G.Nzh - k0);
+    double2 *comp[3] = {X, Y, Z};
+    const size_t xstride = (size_t)rows * G.Nzh, base = (size_t)jl * G.Nzh + k0;
+    {   // every load of a lane in flight before the first is parked in LDS
+        constexpr int PER = (3 * N * KB + NTH - 1) / NTH;
+        double2 v[PER];
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {                    // KB consecutive kz are contiguous in memory
+            const int e = tid + it * NTH, c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
+            v[it] = make_double2(0, 0);
+            if (e < 3 * N * KB && q < kv) v[it] = comp[c][(size_t)x * xstride + base + q];
+        }
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int e = tid + it * NTH, c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
+            if (e < 3 * N * KB) d[(c * KB + q) * CS256 + pad16(x)] = v[it];
+        }
+    }
+    __syncthreads();
+    lds_fft256<NCOL, NTH, false>(d, twiddle);
+    for (int e = tid; e < N * KB; e += NTH) {
+        const int x = e / KB, q = e - x * KB;
+        if (q < kv) {
+            const int px = pad16(x);
+            const double2 f[3] = {d[q * CS256 + px], d[(KB + q) * CS256 + px], d[(2 * KB + q) * CS256 + px]};
+            double2 out[3];
+            scale_node(x, j, k0 + q, f, G, box, a, out);
+            d[q * CS256 + px] = out[0]; d[(KB + q) * CS256 + px] = out[1]; d[(2 * KB + q) * CS256 + px] = out[2];
+        }
+    }
+    __syncthreads();
+    lds_fft256<NCOL, NTH, true>(d, twiddle);
+    for (int e = tid; e < 3 * N * KB; e += NTH) {
+        const int c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
+        if (q < kv) comp[c][(size_t)x * xstride + base + q] = d[(c * KB + q) * CS256 + pad16(x)];
+    }
+}
+
+template <int KB, int NTH, int WPS>
+static void launch_xfft256(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s) {
+    const size_t lds = (size_t)(3 * KB * CS256) * sizeof(double2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xfft_scale256<KB, NTH, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int nkb = (G.Nzh + KB - 1) / KB;
+    const int rows = a.transposed ? a.nyl : G.Ny;
+    hipLaunchKernelGGL((k_xfft_scale256<KB, NTH, WPS>), dim3(rows * nkb), dim3(NTH), lds, s, X, Y, Z, G, box, a, tw);
 }
 
 bool xfuse_supported(int Nx) { return Nx >= 16 && Nx <= 512 && (Nx & (Nx - 1)) == 0; }
@@ -733,7 +898,10 @@ void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, Sc
             else if (cfg == 2) launch_xfft_t<8, 6, 512>(X, Y, Z, G, box, a, tw, s);
             else if (cfg == 3) launch_xfft_t<8, 4, 512>(X, Y, Z, G, box, a, tw, s);
             else if (cfg == 4) launch_xfft_t<8, 2, 256>(X, Y, Z, G, box, a, tw, s);
-            else launch_xfft_t<8, 4, 256>(X, Y, Z, G, box, a, tw, s);
+            else if (cfg == 5) launch_xfft_t<8, 4, 256>(X, Y, Z, G, box, a, tw, s);
+            else if (cfg == 6) launch_xfft256<8, 512, 2>(X, Y, Z, G, box, a, tw, s);
+            else if (cfg == 7) launch_xfft256<4, 256, 3>(X, Y, Z, G, box, a, tw, s);
+            else launch_xfft256<4, 256, 2>(X, Y, Z, G, box, a, tw, s);   // two radix-16 passes in registers
             break;
         }
         default: launch_xfft_t<9, 4, 1024>(X, Y, Z, G, box, a, tw, s); break;

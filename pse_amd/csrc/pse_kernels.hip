@@ -870,7 +870,159 @@ static void launch_xfft256(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box
     hipLaunchKernelGGL((k_xfft_scale256<KB, NTH, WPS>), dim3(rows * nkb), dim3(NTH), lds, s, X, Y, Z, G, box, a, tw);
 }
 
-bool xfuse_supported(int Nx) { return Nx >= 16 && Nx <= 512 && (Nx & (Nx - 1)) == 0; }
+// ---- any Nx = 2^a 3^b 5^c (the grids the reference's rule produces, PSEv1/Stokes.cc:147-199) ---------------------------------
+// Mixed-radix Stockham passes (radix 5, 4, 3, 2) between two LDS buffers: a butterfly reads its R points from one buffer and
+// writes them to the other, so nothing is held across the barrier and the number of butterflies per lane may be anything.
+struct FftPlanX { int n, nstage, radix[10]; };
+
+template <int R, bool INVERSE>
+__device__ __forceinline__ void dft_small(double2 (&v)[5]) {
+    const double sg = INVERSE ? 1.0 : -1.0;                          // forward: exp(-i ...)
+    if (R == 2) {
+        const double2 a = v[0], b = v[1];
+        v[0] = make_double2(a.x + b.x, a.y + b.y); v[1] = make_double2(a.x - b.x, a.y - b.y);
+    } else if (R == 3) {
+        constexpr double S = 0.86602540378443864676;                 // sin(2 pi / 3)
+        const double2 s = make_double2(v[1].x + v[2].x, v[1].y + v[2].y), t = make_double2(v[1].x - v[2].x, v[1].y - v[2].y);
+        const double2 m = make_double2(v[0].x - 0.5 * s.x, v[0].y - 0.5 * s.y);
+        const double2 jt = make_double2(-sg * S * t.y, sg * S * t.x);   // (+-i) sin (v1 - v2)
+        v[0] = make_double2(v[0].x + s.x, v[0].y + s.y);
+        v[1] = make_double2(m.x + jt.x, m.y + jt.y);
+        v[2] = make_double2(m.x - jt.x, m.y - jt.y);
+    } else if (R == 4) {
+        const double2 a = v[0], b = v[1], c = v[2], d = v[3];
+        const double2 s0 = make_double2(a.x + c.x, a.y + c.y), s1 = make_double2(a.x - c.x, a.y - c.y);
+        const double2 s2 = make_double2(b.x + d.x, b.y + d.y), s3 = make_double2(b.x - d.x, b.y - d.y);
+        const double2 j3 = make_double2(-sg * s3.y, sg * s3.x);
+        v[0] = make_double2(s0.x + s2.x, s0.y + s2.y); v[1] = make_double2(s1.x + j3.x, s1.y + j3.y);
+        v[2] = make_double2(s0.x - s2.x, s0.y - s2.y); v[3] = make_double2(s1.x - j3.x, s1.y - j3.y);
+    } else {
+        constexpr double C1 = 0.30901699437494742410, C2 = -0.80901699437494742410;   // cos(2 pi/5), cos(4 pi/5)
+        constexpr double S1 = 0.95105651629515357212, S2 = 0.58778525229247312917;    // sin(2 pi/5), sin(4 pi/5)
+        const double2 a1 = make_double2(v[1].x + v[4].x, v[1].y + v[4].y), b1 = make_double2(v[1].x - v[4].x, v[1].y - v[4].y);
+        const double2 a2 = make_double2(v[2].x + v[3].x, v[2].y + v[3].y), b2 = make_double2(v[2].x - v[3].x, v[2].y - v[3].y);
+        const double2 m1 = make_double2(v[0].x + C1 * a1.x + C2 * a2.x, v[0].y + C1 * a1.y + C2 * a2.y);
+        const double2 m2 = make_double2(v[0].x + C2 * a1.x + C1 * a2.x, v[0].y + C2 * a1.y + C1 * a2.y);
+        const double2 t1 = make_double2(S1 * b1.x + S2 * b2.x, S1 * b1.y + S2 * b2.y);
+        const double2 t2 = make_double2(S2 * b1.x - S1 * b2.x, S2 * b1.y - S1 * b2.y);
+        const double2 j1 = make_double2(-sg * t1.y, sg * t1.x), j2 = make_double2(-sg * t2.y, sg * t2.x);
+        v[0] = make_double2(v[0].x + a1.x + a2.x, v[0].y + a1.y + a2.y);
+        v[1] = make_double2(m1.x + j1.x, m1.y + j1.y); v[4] = make_double2(m1.x - j1.x, m1.y - j1.y);
+        v[2] = make_double2(m2.x + j2.x, m2.y + j2.y); v[3] = make_double2(m2.x - j2.x, m2.y - j2.y);
+    }
+}
+
+// one pass over NCOL columns of n points (column stride cs): in -> out
+template <int R, bool INVERSE>
+__device__ __forceinline__ void fft_pass(const double2 *__restrict__ in, double2 *__restrict__ out, const double2 *__restrict__ tw,
+                                         int n, int cs, int ncol, int ns, int nth) {
+    const int nr = n / R, nb = ncol * nr, tstep = n / (ns * R);
+    for (int bfly = threadIdx.x; bfly < nb; bfly += nth) {
+        const int col = bfly / nr, jj = bfly - col * nr, kk = jj % ns;
+        const double2 *src = in + col * cs + jj;
+        double2 v[5];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double2 x = src[r * nr];
+            if (r) { double2 w = tw[(r * kk * tstep) % n]; if (INVERSE) w.y = -w.y; x = cmul(x, w); }
+            v[r] = x;
+        }
+        dft_small<R, INVERSE>(v);
+        double2 *dst = out + col * cs + (jj - kk) * R + kk;
+#pragma unroll
+        for (int r = 0; r < R; ++r) dst[r * ns] = v[r];
+    }
+}
+
+template <bool INVERSE>
+__device__ __forceinline__ double2 *fft_mixed(double2 *a, double2 *b, const double2 *tw, const FftPlanX &pl, int cs, int ncol, int nth) {
+    int ns = 1;
+    for (int st = 0; st < pl.nstage; ++st) {
+        const int R = pl.radix[st];
+        if (R == 5) fft_pass<5, INVERSE>(a, b, tw, pl.n, cs, ncol, ns, nth);
+        else if (R == 4) fft_pass<4, INVERSE>(a, b, tw, pl.n, cs, ncol, ns, nth);
+        else if (R == 3) fft_pass<3, INVERSE>(a, b, tw, pl.n, cs, ncol, ns, nth);
+        else fft_pass<2, INVERSE>(a, b, tw, pl.n, cs, ncol, ns, nth);
+        __syncthreads();
+        double2 *t = a; a = b; b = t;
+        ns *= R;
+    }
+    return a;                                                        // the buffer that holds the result
+}
+
+template <int KB, int NTH>
+__global__ void __launch_bounds__(NTH)
+k_xfft_scale_mixed(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ Z, DGrid G, DBox box, ScaleArgs a,
+                   const double2 *__restrict__ twiddle, FftPlanX pl) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int N = pl.n, CS = N + 1, NCOL = 3 * KB;
+    double2 *bufa = reinterpret_cast<double2 *>(smem_raw), *bufb = bufa + NCOL * CS;   // [3][KB][N + 1] each
+    double2 *tw = bufb + NCOL * CS;                                                     // [N]
+    const int tid = threadIdx.x;
+    const int nkb = (G.Nzh + KB - 1) / KB;
+    const int rows = a.transposed ? a.nyl : G.Ny;
+    const int jl = blockIdx.x / nkb, k0 = (blockIdx.x - jl * nkb) * KB;
+    const int j = a.transposed ? a.y0 + jl : jl;
+    const int kv = min(KB, G.Nzh - k0);
+    double2 *comp[3] = {X, Y, Z};
+    const size_t xstride = (size_t)rows * G.Nzh, base = (size_t)jl * G.Nzh + k0;
+    for (int e = tid; e < N; e += NTH) tw[e] = twiddle[e];
+    const int total = 3 * N * KB;
+    for (int e0 = 0; e0 < total; e0 += 4 * NTH) {             // four loads of a lane in flight at a time
+        double2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * NTH + tid, c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
+            v[u] = make_double2(0, 0);
+            if (e < total && q < kv) v[u] = comp[c][(size_t)x * xstride + base + q];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * NTH + tid, c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
+            if (e < total) bufa[(c * KB + q) * CS + x] = v[u];
+        }
+    }
+    __syncthreads();
+    double2 *d = fft_mixed<false>(bufa, bufb, tw, pl, CS, NCOL, NTH);
+    for (int e = tid; e < N * KB; e += NTH) {
+        const int x = e / KB, q = e - x * KB;
+        if (q < kv) {
+            const double2 f[3] = {d[q * CS + x], d[(KB + q) * CS + x], d[(2 * KB + q) * CS + x]};
+            double2 out[3];
+            scale_node(x, j, k0 + q, f, G, box, a, out);
+            d[q * CS + x] = out[0]; d[(KB + q) * CS + x] = out[1]; d[(2 * KB + q) * CS + x] = out[2];
+        }
+    }
+    __syncthreads();
+    d = fft_mixed<true>(d, d == bufa ? bufb : bufa, tw, pl, CS, NCOL, NTH);
+    for (int e = tid; e < total; e += NTH) {
+        const int c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
+        if (q < kv) comp[c][(size_t)x * xstride + base + q] = d[(c * KB + q) * CS + x];
+    }
+}
+
+static bool plan_x(int n, FftPlanX &pl) {
+    pl.n = n; pl.nstage = 0;
+    int m = n;
+    for (int r : {5, 4, 3, 2})
+        while (m % r == 0) { if (pl.nstage == 10) return false; pl.radix[pl.nstage++] = r; m /= r; }
+    return m == 1;
+}
+
+template <int KB, int NTH>
+static void launch_xfft_mixed(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, const FftPlanX &pl, hipStream_t s) {
+    const size_t lds = (size_t)(2 * 3 * KB * (pl.n + 1) + pl.n) * sizeof(double2);
+    static size_t attr_lds = 48 * 1024;
+    if (lds > attr_lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xfft_scale_mixed<KB, NTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_lds = lds; }
+    const int nkb = (G.Nzh + KB - 1) / KB;
+    const int rows = a.transposed ? a.nyl : G.Ny;
+    hipLaunchKernelGGL((k_xfft_scale_mixed<KB, NTH>), dim3(rows * nkb), dim3(NTH), lds, s, X, Y, Z, G, box, a, tw, pl);
+}
+
+bool xfuse_supported(int Nx) {   // 2^a 3^b 5^c, 16..512
+    FftPlanX pl;
+    return Nx >= 16 && Nx <= 512 && plan_x(Nx, pl);
+}
 
 template <int LOGN, int KB, int NTH>
 static void launch_xfft_t(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s) {
@@ -887,6 +1039,13 @@ static void launch_xfft_t(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box,
 }
 
 void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s) {
+    if (G.Nx & (G.Nx - 1)) {   // not a power of two: mixed-radix passes; 4 kz columns per workgroup while two buffers fit
+        FftPlanX pl;
+        plan_x(G.Nx, pl);
+        if (G.Nx <= 200) launch_xfft_mixed<4, 256>(X, Y, Z, G, box, a, tw, pl, s);
+        else launch_xfft_mixed<2, 256>(X, Y, Z, G, box, a, tw, pl, s);
+        return;
+    }
     switch (G.Nx) {   // 8 kz columns per workgroup = 128-byte pieces; LDS = 3*KB*(N+1)*16 B
         case 16: launch_xfft_t<4, 8, 256>(X, Y, Z, G, box, a, tw, s); break;
         case 32: launch_xfft_t<5, 8, 256>(X, Y, Z, G, box, a, tw, s); break;

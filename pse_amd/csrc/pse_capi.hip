@@ -463,7 +463,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     h->sort_tmp_bytes = cell_sort_temp_bytes(h->n_cells_alloc);
     TRY(dmalloc(h, (char **)&h->sort_tmp, h->sort_tmp_bytes));
     TRY(dmalloc(h, &h->sup_s, n));
-    if (d.P >= 4 && d.P <= 8) {   // fast far-field path: support offsets + separable weights 
+    if (d.P >= 4 && d.P <= FAR_PMAX) {   // fast far-field path: support offsets + separable weights 
         TRY(dmalloc(h, &h->sw.d0_s, n));
         TRY(dmalloc(h, (char **)&h->sw.rec_t, (n + 64) * 64));   // 64-byte records (idle lanes read past the last one)
         TRY(dmalloc(h, &h->sw.fb.rank_s, n));

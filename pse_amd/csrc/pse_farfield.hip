@@ -73,7 +73,7 @@ __device__ __forceinline__ void gauss_tables(double d0x, double d0y, double d0z,
 GaussConsts gauss_consts(const DGrid &G, double xy) {
     GaussConsts gc;
     const double c = G.expfac;
-    for (int t = 0; t < 7; ++t) {
+    for (int t = 0; t < FAR_PMAX - 1; ++t) {
         gc.rx[t] = std::exp(-c * G.hx * G.hx * (2 * t + 1));
         gc.ry[t] = std::exp(-c * G.hy * G.hy * (1.0 + xy * xy) * (2 * t + 1));
         gc.rz[t] = std::exp(-c * G.hz * G.hz * (2 * t + 1));
@@ -212,7 +212,7 @@ template <int P, int TZ, bool SHEAR>
 __global__ void __launch_bounds__(64)
 k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ gx, double *__restrict__ gy,
                double *__restrict__ gz, DGrid G, GaussConsts gc, FastDiv dz, FastDiv dy) {
-    constexpr int TX = 8, TY = 8, PT = P + 2, LS = 65, RMAX = 20;
+    constexpr int TX = 8, TY = 8, PT = P + 2, LS = 65, RMAX = P <= 8 ? 20 : 32;   // runs: bins in x times bins in y times z parts
     constexpr int UB = (P + 4) & ~1;          // doubles per particle of the wave-uniform block: az[P], force[3], pad to 16 bytes
     __shared__ double s_ax[PT * LS], s_ay[PT * LS];
     __shared__ __attribute__((aligned(16))) double s_u[UB * 64];
@@ -425,7 +425,7 @@ static int spread_tz(const DGrid &G) {
 bool farfield_fast_path(const DGrid &G) {
     // the block kernels resolve a support to its nearest image of the block (needs N >= 2 max(block, support) per axis)
     const int need = 2 * std::max(8, G.P);
-    return G.P >= 4 && G.P <= 8 && G.Nx >= need && G.Ny >= need && G.Nz >= need;
+    return G.P >= 4 && G.P <= FAR_PMAX && G.Nx >= need && G.Ny >= need && G.Nz >= need;
 }
 bool spread_needs_zero(const DGrid &G) { return !farfield_fast_path(G); }
 size_t farfield_bins(const DGrid &G) { return (size_t)bins_of(G.Nx) * bins_of(G.Ny) * bins_of(G.Nz); }
@@ -456,11 +456,11 @@ void launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N,
     build_records(pos_s, f_s, sup_s, N, G, box, w, fb, s);
     const GaussConsts gc = gauss_consts(G, box.xy);
     switch (G.P) {
-        case 4: launch_spread_p<4>(w.rec_t, fb, gx, gy, gz, G, gc, s); break;
-        case 5: launch_spread_p<5>(w.rec_t, fb, gx, gy, gz, G, gc, s); break;
-        case 6: launch_spread_p<6>(w.rec_t, fb, gx, gy, gz, G, gc, s); break;
-        case 7: launch_spread_p<7>(w.rec_t, fb, gx, gy, gz, G, gc, s); break;
-        default: launch_spread_p<8>(w.rec_t, fb, gx, gy, gz, G, gc, s); break;
+#define PSE_SPREAD_CASE(PV) case PV: launch_spread_p<PV>(w.rec_t, fb, gx, gy, gz, G, gc, s); break;
+        PSE_SPREAD_CASE(4) PSE_SPREAD_CASE(5) PSE_SPREAD_CASE(6) PSE_SPREAD_CASE(7) PSE_SPREAD_CASE(8) PSE_SPREAD_CASE(9)
+        PSE_SPREAD_CASE(10) PSE_SPREAD_CASE(11) PSE_SPREAD_CASE(12) PSE_SPREAD_CASE(13)
+        default: launch_spread_p<14>(w.rec_t, fb, gx, gy, gz, G, gc, s); break;
+#undef PSE_SPREAD_CASE
     }
 }
 
@@ -473,7 +473,7 @@ void launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N,
 // starts at an even node (a zero weight in front when the support starts at an odd one), so every LDS access is an aligned
 // 16-byte read -- ax[tx] ay[ty] (K[tx][ty] under shear) against one read per (x, y) offset and component, az applied
 // once at the end, reduction inside the quad by DPP -- instead of the reference's block per particle with a shared-memory
-// tree over P^3 threads (PSEv1/Mobility.cu:456-470).  (P = 8: eight lanes with one z offset each.)
+// tree over P^3 threads (PSEv1/Mobility.cu:456-470).  (P >= 8: eight lanes per particle.)
 template <int CTRL>
 __device__ __forceinline__ double dpp_quad(double v) {   // the value another lane of the quad holds
     const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
@@ -489,8 +489,8 @@ __global__ void __launch_bounds__(256)
 k_gather_bins(const FarRec *__restrict__ rec, FarBins fb, FastDiv dz, FastDiv dy, int bx0, const double *__restrict__ gx,
               const double *__restrict__ gy, const double *__restrict__ gz, DGrid G, GaussConsts gc, double4 *__restrict__ u_s) {
     constexpr int NT = 256, E = BIN + P - 1;
-    constexpr int ZPL = P <= 7 ? 2 : 1, LPP = P <= 7 ? 4 : 8, ZW = ZPL * LPP;   // z offsets per lane, lanes per particle, z window
-    constexpr int EZ = P <= 7 ? 14 : 16, HZ = EZ / 2, ROW = E * EZ, E3 = E * ROW, PPP = NT / LPP, NW = 2 * P + ZW;
+    constexpr int ZPL = 2, LPP = P <= 7 ? 4 : 8, ZW = ZPL * LPP;      // z offsets per lane, lanes per particle, z window (>= P + 1)
+    constexpr int EZ = (E > BIN - 2 + ZW ? E + 1 : BIN - 2 + ZW) & ~1, HZ = EZ / 2, ROW = E * EZ, E3 = E * ROW, PPP = NT / LPP, NW = 2 * P + ZW;
     constexpr int NPC = E * E * HZ, ITER = (NPC + NT - 1) / NT;       // 16-byte pieces of the region, per thread
     static_assert(EZ >= E && BIN - 2 + ZW <= EZ, "z window inside the padded row");
     __shared__ __attribute__((aligned(16))) double reg[E3];
@@ -693,11 +693,11 @@ void launch_gather(const double4 *pos_s, SpreadWork w, int N, const double *gx, 
     }
     const GaussConsts gc = gauss_consts(G, box.xy);
     switch (G.P) {
-        case 4: launch_gather_p<4>(w.rec_t, fb, bx0, nbx_l, gx, gy, gz, G, gc, u_s, s); break;
-        case 5: launch_gather_p<5>(w.rec_t, fb, bx0, nbx_l, gx, gy, gz, G, gc, u_s, s); break;
-        case 6: launch_gather_p<6>(w.rec_t, fb, bx0, nbx_l, gx, gy, gz, G, gc, u_s, s); break;
-        case 7: launch_gather_p<7>(w.rec_t, fb, bx0, nbx_l, gx, gy, gz, G, gc, u_s, s); break;
-        default: launch_gather_p<8>(w.rec_t, fb, bx0, nbx_l, gx, gy, gz, G, gc, u_s, s); break;
+#define PSE_GATHER_CASE(PV) case PV: launch_gather_p<PV>(w.rec_t, fb, bx0, nbx_l, gx, gy, gz, G, gc, u_s, s); break;
+        PSE_GATHER_CASE(4) PSE_GATHER_CASE(5) PSE_GATHER_CASE(6) PSE_GATHER_CASE(7) PSE_GATHER_CASE(8) PSE_GATHER_CASE(9)
+        PSE_GATHER_CASE(10) PSE_GATHER_CASE(11) PSE_GATHER_CASE(12) PSE_GATHER_CASE(13)
+        default: launch_gather_p<14>(w.rec_t, fb, bx0, nbx_l, gx, gy, gz, G, gc, u_s, s); break;
+#undef PSE_GATHER_CASE
     }
 }
 

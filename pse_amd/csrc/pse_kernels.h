@@ -88,7 +88,8 @@ struct SpreadWork {
 };
 // per-step constants of the separable Gaussian weights: step ratios r_t = exp(-c h^2 (2t+1)) (y with the (1 + xy^2) of the
 // sheared lattice), ln K = -2 c xy hx hy, the tilt
-struct GaussConsts { double rx[7], ry[7], rz[7], lnk, s; };
+constexpr int FAR_PMAX = 14;   // largest support of the block far field (error 1e-6 gives P = 13)
+struct GaussConsts { double rx[FAR_PMAX - 1], ry[FAR_PMAX - 1], rz[FAR_PMAX - 1], lnk, s; };
 size_t farfield_bins(const DGrid &G);
 // true if the caller must zero the grids first (atomic fallback: P outside 4..8 or a grid smaller than two tiles)
 bool spread_needs_zero(const DGrid &G);

@@ -296,30 +296,41 @@ static int make_plans(pse_handle *h) {
         TRY(dmalloc(h, &h->twiddle, (size_t)G.Nx));
         HIPCHK(hipMemcpy(h->twiddle, tw.data(), G.Nx * sizeof(double2), hipMemcpyHostToDevice));
     }
+    // real grid rows hold Nz doubles, spectrum rows Nzp >= Nz/2 + 1 complex numbers (padded to 128 bytes)
+    auto real_plans = [&](size_t dims, const size_t *len, size_t batch) -> int {
+        size_t rs[3] = {1, (size_t)G.Nz, (size_t)G.Ny * G.Nz}, cs[3] = {1, (size_t)G.Nzp, (size_t)G.Ny * G.Nzp};
+        const size_t rdist = dims == 2 ? (size_t)G.Ny * G.Nz : (size_t)G.Nx * G.Ny * G.Nz;
+        const size_t cdist = dims == 2 ? (size_t)G.Ny * G.Nzp : (size_t)G.Nx * G.Ny * G.Nzp;
+        rocfft_plan_description df = nullptr, di = nullptr;
+        FFTCHK(rocfft_plan_description_create(&df));
+        FFTCHK(rocfft_plan_description_create(&di));
+        FFTCHK(rocfft_plan_description_set_data_layout(df, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, nullptr, nullptr,
+                                                       dims, rs, rdist, dims, cs, cdist));
+        FFTCHK(rocfft_plan_description_set_data_layout(di, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, nullptr, nullptr,
+                                                       dims, cs, cdist, dims, rs, rdist));
+        FFTCHK(rocfft_plan_create(&h->plan_fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                                  rocfft_precision_double, dims, len, batch, df));
+        FFTCHK(rocfft_plan_create(&h->plan_inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                                  rocfft_precision_double, dims, len, batch, di));
+        rocfft_plan_description_destroy(df);
+        rocfft_plan_description_destroy(di);
+        return 0;
+    };
     if (h->xfuse && h->grid_slabs == 1) {
         // 2-D (y,z) real transforms of all 3 Nx planes in one batch
         const size_t len2[2] = {(size_t)G.Nz, (size_t)G.Ny};
-        FFTCHK(rocfft_plan_create(&h->plan_fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
-                                  rocfft_precision_double, 2, len2, (size_t)3 * G.Nx, nullptr));
-        FFTCHK(rocfft_plan_create(&h->plan_inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
-                                  rocfft_precision_double, 2, len2, (size_t)3 * G.Nx, nullptr));
+        TRY(real_plans(2, len2, (size_t)3 * G.Nx));
     } else if (h->grid_slabs == 1) {
-        // rocFFT lengths are fastest-first: z, y, x.  Real grids [3][Nx][Ny][Nz] -> half spectra [3][Nx][Ny][Nzh].
+        // rocFFT lengths are fastest-first: z, y, x.  Real grids [3][Nx][Ny][Nz] -> half spectra [3][Nx][Ny][Nzp].
         const size_t len[3] = {(size_t)G.Nz, (size_t)G.Ny, (size_t)G.Nx};
-        FFTCHK(rocfft_plan_create(&h->plan_fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
-                                  rocfft_precision_double, 3, len, 3, nullptr));
-        FFTCHK(rocfft_plan_create(&h->plan_inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
-                                  rocfft_precision_double, 3, len, 3, nullptr));
+        TRY(real_plans(3, len, 3));
     } else {
         // slab mode: 2-D (y,z) real transforms of the nxl local planes of one component, then (after the transpose)
-        // 1-D complex transforms along x on [Nx][nyl][Nzh]: stride nyl*Nzh, one transform per (y,kz) column
+        // 1-D complex transforms along x on [Nx][nyl][Nzp]: stride nyl*Nzp, one transform per (y,kz) column
         const size_t len2[2] = {(size_t)G.Nz, (size_t)G.Ny};
-        FFTCHK(rocfft_plan_create(&h->plan_fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
-                                  rocfft_precision_double, 2, len2, (size_t)G.nxl, nullptr));
-        FFTCHK(rocfft_plan_create(&h->plan_inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
-                                  rocfft_precision_double, 2, len2, (size_t)G.nxl, nullptr));
+        TRY(real_plans(2, len2, (size_t)G.nxl));
         const size_t lenx[1] = {(size_t)G.Nx};
-        size_t stride[1] = {(size_t)h->nyl * G.Nzh};
+        size_t stride[1] = {(size_t)h->nyl * G.Nzp};
         rocfft_plan_description desc = nullptr;
         FFTCHK(rocfft_plan_description_create(&desc));
         FFTCHK(rocfft_plan_description_set_data_layout(desc, rocfft_array_type_complex_interleaved,
@@ -416,6 +427,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
 
     DGrid &G = h->G;
     G.Nx = d.Nx; G.Ny = d.Ny; G.Nz = d.Nz; G.Nzh = d.Nz / 2 + 1; G.P = d.P;
+    G.Nzp = (G.Nzh + 7) & ~7;   // spectrum rows padded to 128 bytes: the x pass reads and writes whole aligned lines
     h->n_slabs = std::max(1, p->n_slabs);
     h->slab_rank = h->n_slabs > 1 ? p->slab_rank : 0;
     if (h->slab_rank < 0 || h->slab_rank >= h->n_slabs) return fail(PSE_ERR_INVALID, "slab_rank outside [0, n_slabs)");
@@ -496,7 +508,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     TRY(dmalloc(h, &h->f_s, n)); TRY(dmalloc(h, &h->uw_s, n)); TRY(dmalloc(h, &h->ur_s, n));
     TRY(dmalloc(h, &h->ub_s, n)); TRY(dmalloc(h, &h->psi_s, n)); TRY(dmalloc(h, &h->w_s, n));
 
-    const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
+    const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzp;
     TRY(dmalloc(h, &h->rgrid, 3 * nr));
     TRY(dmalloc(h, &h->cgrid, 3 * ncx));
     if (h->grid_slabs > 1) { TRY(dmalloc(h, &h->sendbuf, 3 * ncx)); TRY(dmalloc(h, &h->recvbuf, 3 * ncx)); }
@@ -882,7 +894,7 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
     const int GS = T.m[0]->grid_slabs;   // 1: every rank transforms the whole grid (single GPU, or a team that replicates it)
     for (pse_handle *h : T.m) {
         const DGrid &G = h->G;
-        const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
+        const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzp;
         double *gx = h->rgrid, *gy = h->rgrid + nr, *gz = h->rgrid + 2 * nr;
         TRY(tsw(h, PH_SPREAD));
         if (spread_needs_zero(G)) HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->wstream));
@@ -897,21 +909,21 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
                 void *in[1] = {h->rgrid + c * nr + (size_t)G.hl * G.Ny * G.Nz}, *out[1] = {h->cgrid + c * ncx};
                 FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
             }
-            launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzh, h->nyl, 0, h->wstream);
+            launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzp, h->nyl, 0, h->wstream);
         }
         TRY(tew(h, PH_FFTF));
     }
     if (GS > 1) {
         for (pse_handle *h : T.m) TRY(tsw(h, PH_COMM));
         pse_handle *h0 = T.m[0];
-        const size_t blk = (size_t)h0->G.nxl * h0->nyl * h0->G.Nzh * 2, comp = blk * GS;
+        const size_t blk = (size_t)h0->G.nxl * h0->nyl * h0->G.Nzp * 2, comp = blk * GS;
         TRY(team_all_to_all(T, [&](pse_handle *h) { return (double *)h->sendbuf; }, [&](pse_handle *h) { return (double *)h->recvbuf; },
                             blk, 3, comp));
         for (pse_handle *h : T.m) TRY(tew(h, PH_COMM));
     }
     for (pse_handle *h : T.m) {
         const DGrid &G = h->G;
-        const size_t ncx = (size_t)G.nxl * G.Ny * G.Nzh;
+        const size_t ncx = (size_t)G.nxl * G.Ny * G.Nzp;
         double2 *sp = GS == 1 ? h->cgrid : h->recvbuf;   // [3][Nx][nyl][Nzh] after the transpose
         TRY(tsw(h, PH_SCALE));
         if (h->xfuse) {
@@ -927,19 +939,19 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
     }
     if (GS > 1) {
         pse_handle *h0 = T.m[0];
-        const size_t blk = (size_t)h0->G.nxl * h0->nyl * h0->G.Nzh * 2, comp = blk * GS;
+        const size_t blk = (size_t)h0->G.nxl * h0->nyl * h0->G.Nzp * 2, comp = blk * GS;
         TRY(team_all_to_all(T, [&](pse_handle *h) { return (double *)h->recvbuf; }, [&](pse_handle *h) { return (double *)h->sendbuf; },
                             blk, 3, comp));
     }
     for (pse_handle *h : T.m) {
         const DGrid &G = h->G;
-        const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzh;
+        const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzp;
         TRY(tsw(h, PH_FFTI));
         if (GS == 1) {
             void *in[1] = {h->cgrid}, *out[1] = {h->rgrid};
             FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv));
         } else {
-            launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzh, h->nyl, 1, h->wstream);
+            launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzp, h->nyl, 1, h->wstream);
             for (int c = 0; c < 3; ++c) {
                 void *in[1] = {h->cgrid + c * ncx}, *out[1] = {h->rgrid + c * nr + (size_t)G.hl * G.Ny * G.Nz};
                 FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv));

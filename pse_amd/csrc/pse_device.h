@@ -16,6 +16,7 @@ struct DBox {
 
 struct DGrid {
     int Nx, Ny, Nz, Nzh;   // Nzh = Nz/2 + 1 (half spectrum)
+    int Nzp;               // elements a spectrum row is stored with: Nzh rounded up to 8 (128-byte aligned rows)
     int P;
     int x0, nxl;           // this rank's slab of x planes [x0, x0 + nxl)
     int nhalo;             // planes stored past the slab (copies of the next slab's first planes) for the gather

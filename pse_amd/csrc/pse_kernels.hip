@@ -558,9 +558,10 @@ __global__ void __launch_bounds__(TPB)
 k_scale(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ Z, DGrid G, DBox box, ScaleArgs a) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t rows = a.transposed ? (size_t)a.nyl * G.Nx : (size_t)G.nxl * G.Ny;
-    if (tid >= rows * G.Nzh) return;
-    const int k = (int)(tid % G.Nzh);
-    const size_t row = tid / G.Nzh;
+    if (tid >= rows * G.Nzp) return;
+    const int k = (int)(tid % G.Nzp);
+    if (k >= G.Nzh) return;                                  // padding of the row
+    const size_t row = tid / G.Nzp;
     int i, j;
     if (a.transposed) { i = (int)(row / a.nyl); j = a.y0 + (int)(row % a.nyl); }   // [Nx][ny_local][Nzh]
     else              { i = G.x0 + (int)(row / G.Ny); j = (int)(row % G.Ny); }
@@ -572,7 +573,7 @@ k_scale(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ 
 
 void launch_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, hipStream_t s) {
     const size_t rows = a.transposed ? (size_t)a.nyl * G.Nx : (size_t)G.nxl * G.Ny;
-    hipLaunchKernelGGL(k_scale, dim3(nblocks((long)(rows * G.Nzh), TPB)), dim3(TPB), 0, s, X, Y, Z, G, box, a);
+    hipLaunchKernelGGL(k_scale, dim3(nblocks((long)(rows * G.Nzp), TPB)), dim3(TPB), 0, s, X, Y, Z, G, box, a);
 }
 
 // ---- fused x pass -----------------------------------------------------------------------------------------------
@@ -680,7 +681,7 @@ k_xfft_scale(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restri
     const int j = a.transposed ? a.y0 + jl : jl;
     const int kv = min(KB, G.Nzh - k0);
     double2 *comp[3] = {X, Y, Z};
-    const size_t xstride = (size_t)rows * G.Nzh, base = (size_t)jl * G.Nzh + k0;
+    const size_t xstride = (size_t)rows * G.Nzp, base = (size_t)jl * G.Nzp + k0;
     for (int e = tid; e < N; e += NTH) tw[e] = twiddle[e];
     {   // every load of a lane in flight before the first is parked in LDS (a load -> store loop pays the latency per element)
         constexpr int PER = (3 * N * KB + NTH - 1) / NTH;
@@ -821,7 +822,7 @@ k_xfft_scale256(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__res
     const int j = a.transposed ? a.y0 + jl : jl;
     const int kv = min(KB, G.Nzh - k0);
     double2 *comp[3] = {X, Y, Z};
-    const size_t xstride = (size_t)rows * G.Nzh, base = (size_t)jl * G.Nzh + k0;
+    const size_t xstride = (size_t)rows * G.Nzp, base = (size_t)jl * G.Nzp + k0;
     {   // every load of a lane in flight before the first is parked in LDS
         constexpr int PER = (3 * N * KB + NTH - 1) / NTH;
         double2 v[PER];
@@ -965,7 +966,7 @@ k_xfft_scale_mixed(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__
     const int j = a.transposed ? a.y0 + jl : jl;
     const int kv = min(KB, G.Nzh - k0);
     double2 *comp[3] = {X, Y, Z};
-    const size_t xstride = (size_t)rows * G.Nzh, base = (size_t)jl * G.Nzh + k0;
+    const size_t xstride = (size_t)rows * G.Nzp, base = (size_t)jl * G.Nzp + k0;
     for (int e = tid; e < N; e += NTH) tw[e] = twiddle[e];
     const int total = 3 * N * KB;
     for (int e0 = 0; e0 < total; e0 += 4 * NTH) {             // four loads of a lane in flight at a time

@@ -637,6 +637,8 @@ struct pse_team {
     } while (0)
 
 static bool loopback(const pse_team &T) { return T.G > 1 && !T.nccl; }
+// communicator of the far-field chain: the split one when it exists (then the chain runs on the side stream), else the main one
+static ncclComm_t wave_comm(const pse_team &T) { return T.nccl_w ? T.nccl_w : T.nccl; }
 
 // all-to-all of equal blocks, nset sets at once (one RCCL group): member r sends block q of set c of send(r) to rank q,
 // which stores it as block r of set c of recv(q); sets are set_stride doubles apart
@@ -648,8 +650,8 @@ static int team_all_to_all(pse_team &T, FS send, FR recv, size_t blk_doubles, in
         NCCLCHK(ncclGroupStart());
         for (int c = 0; c < nset; ++c)
             for (int q = 0; q < T.G; ++q) {
-                NCCLCHK(ncclSend(send(h) + c * set_stride + (size_t)q * blk_doubles, blk_doubles, ncclDouble, q, T.nccl_w, h->wstream));
-                NCCLCHK(ncclRecv(recv(h) + c * set_stride + (size_t)q * blk_doubles, blk_doubles, ncclDouble, q, T.nccl_w, h->wstream));
+                NCCLCHK(ncclSend(send(h) + c * set_stride + (size_t)q * blk_doubles, blk_doubles, ncclDouble, q, wave_comm(T), h->wstream));
+                NCCLCHK(ncclRecv(recv(h) + c * set_stride + (size_t)q * blk_doubles, blk_doubles, ncclDouble, q, wave_comm(T), h->wstream));
             }
         NCCLCHK(ncclGroupEnd());
         return 0;
@@ -710,10 +712,10 @@ static int team_halo_exchange(pse_team &T) {
         NCCLCHK(ncclGroupStart());
         for (int c = 0; c < 3; ++c) {
             double *own = comp(h, c) + plane * G.hl;
-            NCCLCHK(ncclSend(own, plane * G.nhalo, ncclDouble, left, T.nccl_w, h->wstream));                          // my first planes
-            NCCLCHK(ncclSend(own + plane * (G.nxl - G.hl), plane * G.hl, ncclDouble, right, T.nccl_w, h->wstream));   // my last planes
-            NCCLCHK(ncclRecv(own + plane * G.nxl, plane * G.nhalo, ncclDouble, right, T.nccl_w, h->wstream));
-            NCCLCHK(ncclRecv(comp(h, c), plane * G.hl, ncclDouble, left, T.nccl_w, h->wstream));
+            NCCLCHK(ncclSend(own, plane * G.nhalo, ncclDouble, left, wave_comm(T), h->wstream));                          // my first planes
+            NCCLCHK(ncclSend(own + plane * (G.nxl - G.hl), plane * G.hl, ncclDouble, right, wave_comm(T), h->wstream));   // my last planes
+            NCCLCHK(ncclRecv(own + plane * G.nxl, plane * G.nhalo, ncclDouble, right, wave_comm(T), h->wstream));
+            NCCLCHK(ncclRecv(comp(h, c), plane * G.hl, ncclDouble, left, wave_comm(T), h->wstream));
         }
         NCCLCHK(ncclGroupEnd());
         return 0;

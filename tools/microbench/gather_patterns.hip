@@ -7,7 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
-constexpr int NREC = 1 << 20, ITER = 512;
+constexpr int ITER = 512;
+__constant__ int NREC;   // records in the table (a power of two): 1 << 20 = 48 MB (L2/MALL), 1 << 8 = 12 KB (L1-resident)
 template <int MODE>
 __global__ void __launch_bounds__(256) k(const double2 *__restrict__ tab, double *out) {
     const int lane = threadIdx.x & 63;
@@ -30,9 +31,9 @@ __global__ void __launch_bounds__(256) k(const double2 *__restrict__ tab, double
 }
 template <int MODE> void run(const char *name, double recs_per_instr, int instr_per_iter) {
     double2 *tab; double *out;
-    hipMalloc(&tab, (size_t)NREC * 48); hipMemset(tab, 0, (size_t)NREC * 48);
+    (void)hipMalloc(&tab, (size_t)(1 << 20) * 48); (void)hipMemset(tab, 0, (size_t)(1 << 20) * 48);
     const int blocks = 256 * 8;
-    hipMalloc(&out, (size_t)blocks * 256 * sizeof(double));
+    (void)hipMalloc(&out, (size_t)blocks * 256 * sizeof(double));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     k<MODE><<<blocks, 256>>>(tab, out); hipDeviceSynchronize();
     hipEventRecord(e0); k<MODE><<<blocks, 256>>>(tab, out); hipEventRecord(e1); hipEventSynchronize(e1);
@@ -44,9 +45,14 @@ template <int MODE> void run(const char *name, double recs_per_instr, int instr_
     hipFree(tab); hipFree(out);
 }
 int main() {
-    run<0>("A 64 records x 16 B (x3 for a record)", 64, 1);
-    run<1>("B 64 records x 3 x 16 B", 64, 3);
-    run<2>("C 16 records x (3+1 lanes) x 16 B", 16, 1);
-    run<3>("D 21 records x 3 lanes x 16 B", 21, 1);
+    for (int lg : {20, 14, 8}) {
+        const int n = 1 << lg;
+        hipMemcpyToSymbol(HIP_SYMBOL(NREC), &n, sizeof n);
+        printf("table of %d records (%.1f KB)\n", n, n * 48 / 1024.0);
+        run<0>("A 64 records x 16 B (x3 for a record)", 64, 1);
+        run<1>("B 64 records x 3 x 16 B", 64, 3);
+        run<2>("C 16 records x (3+1 lanes) x 16 B", 16, 1);
+        run<3>("D 21 records x 3 lanes x 16 B", 21, 1);
+    }
     return 0;
 }

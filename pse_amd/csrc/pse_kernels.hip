@@ -173,7 +173,9 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
     extern __shared__ double scoef[];
     const int tid = threadIdx.x;
     if (CL) {
-        for (int q = tid; q < ncoef; q += TPB) scoef[q] = coef_g[q];
+        // intervals padded from 20 to 21 doubles: lanes in different intervals then read different banks (unpadded, interval k
+        // and k + 8 collide: two thirds of this kernel's LDS cycles were bank conflicts)
+        for (int q = tid; q < ncoef; q += TPB) scoef[(q / (2 * RS_NCOEF)) * (2 * RS_NCOEF + 1) + q % (2 * RS_NCOEF)] = coef_g[q];
         __syncthreads();
     }
     const double *coef = CL ? scoef : coef_g;
@@ -209,8 +211,8 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
             if (!shift_only) { min_image(box, d0x, d0y, d0z); min_image(box, d1x, d1y, d1z); }
             const double r20 = d0x * d0x + d0y * d0y + d0z * d0z, r21 = d1x * d1x + d1y * d1y + d1z * d1z;
             double f0, h0, f1, h1;
-            eval_fg(r20, coef, f0, h0);
-            eval_fg(r21, coef, f1, h1);
+            if (CL) { eval_fg<2 * RS_NCOEF + 1>(r20, coef, f0, h0); eval_fg<2 * RS_NCOEF + 1>(r21, coef, f1, h1); }
+            else { eval_fg(r20, coef, f0, h0); eval_fg(r21, coef, f1, h1); }
             const bool in0 = r20 < rcut2 && r20 > 0.0, in1 = two && r21 < rcut2 && r21 > 0.0;   // the fp64 cutoff decides
             if (!in0) { f0 = 0.0; h0 = 0.0; }
             if (!in1) { f1 = 0.0; h1 = 0.0; }
@@ -417,7 +419,7 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
     const double rpre = rcut + 16.0 * cmax * 5.97e-8;
     const float rcut2_pre = (float)(rpre * rpre * (1.0 + 1e-6));
     const dim3 g(nblocks(hi - lo, TPB)), b(TPB);
-    const size_t cb = (size_t)ncoef * sizeof(double);
+    const size_t cb = (size_t)(ncoef / (2 * RS_NCOEF)) * (2 * RS_NCOEF + 1) * sizeof(double);   // padded copy in LDS
     const bool cl = cb <= 14 * 1024;   // with the 48 KB queue: two workgroups per CU
     if (mode == MREAL_BUILD_LIST) {
         if (cl && vec2_s) hipLaunchKernelGGL((k_mreal_cells<true, true, true>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, vec2_s, out2_s);

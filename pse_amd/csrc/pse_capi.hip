@@ -495,7 +495,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         const double vol = h->box.Lx * h->box.Ly * h->box.Lz;
         const double nbar = (double)n / vol * 4.18879020478639 * d.rcut * d.rcut * d.rcut;
         int cap = (int)std::ceil(1.5 * nbar + 16.0);
-        cap = std::max(16, std::min(cap, 256));
+        cap = (std::max(16, std::min(cap, 256)) + 3) & ~3;   // whole groups of four slots
         const double bytes = (double)cap * (double)n * 20.0;
         if (bytes > 32e9 || n >= ((size_t)1 << 27)) cap = 0;   // too large: mat-vecs always walk the cells
         h->nb.cap = cap;

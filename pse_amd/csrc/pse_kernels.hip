@@ -151,11 +151,14 @@ void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double
 constexpr int QCAP = 48;
 constexpr unsigned JMASK = (1u << 27) - 1;
 
+// Four slots of the 64 rows of a wave form one 5120-byte group: [lane][4] entries, then [slot][lane] (f, h).  A mat-vec reads a
+// group with one 16-byte load of the four entries and four 16-byte loads of (f, h): a coalesced dword or dwordx2 load
+// occupies the texture addresser as long as a dwordx4 load (tools/microbench/stream_widths: 8 / 16 / 16 clk), so the
+// twelve narrow loads of the former (entry | f | h) planes cost twice what these five do.
 __device__ __forceinline__ void nb_store(char *rec, int slot, int lane, unsigned e, double f, double h) {
-    char *r = rec + (size_t)slot * NB_REC;
-    ((unsigned *)r)[lane] = e;
-    ((double *)(r + 256))[lane] = f;
-    ((double *)(r + 768))[lane] = h;
+    char *r = rec + (size_t)(slot >> 2) * (4 * NB_REC);
+    ((unsigned *)r)[lane * 4 + (slot & 3)] = e;
+    ((double2 *)(r + 1024))[(slot & 3) * 64 + lane] = make_double2(f, h);
 }
 
 // CL: the f, g coefficient table is copied to LDS first (ncoef doubles of dynamic shared memory).  Every neighbour reads
@@ -326,15 +329,17 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
             // software-pipelined by hand: the list entries of UNROLL slots, then their 2 UNROLL gathers, then the arithmetic --
             // left to the compiler every slot waited for its own load -> gather chain (the kernel was latency-bound at
             // 1.9 TB/s).  Branch-free: slots past cnt re-read the last valid one with f = h = 0; image code 13 is a zero shift.
+            static_assert(UNROLL == 4, "one list group per iteration");
             for (int s0 = 0; s0 < cnt; s0 += UNROLL) {
-                unsigned e[UNROLL];
+                const char *grp = rec + (size_t)(s0 >> 2) * (4 * NB_REC);
+                const uint4 e4 = ((const uint4 *)grp)[lane];
+                unsigned e[UNROLL] = {e4.x, e4.y, e4.z, e4.w};
                 double f[UNROLL], h[UNROLL];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
-                    const char *r = rec + (size_t)min(s0 + u, cnt - 1) * NB_REC;
-                    e[u] = ((const unsigned *)r)[lane];
-                    f[u] = ((const double *)(r + 256))[lane];
-                    h[u] = ((const double *)(r + 768))[lane];
+                    const double2 fh = ((const double2 *)(grp + 1024))[u * 64 + lane];
+                    f[u] = fh.x; h[u] = fh.y;
+                    if (u && s0 + u >= cnt) e[u] = e[0];          // slots past the row's count were never written
                 }
                 double4 pj[UNROLL], Fj[UNROLL];
 #pragma unroll

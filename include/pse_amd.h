@@ -78,6 +78,16 @@ int pse_destroy(pse_handle *h);
 int pse_set_box(pse_handle *h, double Lx, double Ly, double Lz, double xy);
 /* run on this hipStream_t (default: the null stream, as the reference does) */
 int pse_set_stream(pse_handle *h, void *hip_stream);
+/* Neighbour list kept across calls: replaces the NeighborListGPUBinned(rcut, r_buff = 0.4) with setEvery(1, dist_check)
+ * that PSEv1/integrate.py:60,79 builds and Stokes::integrateStepOne refreshes with m_nlist->compute (PSEv1/Stokes.cc:433).
+ * Pairs closer than rcut + r_buff are remembered at a build; later calls with the same N, group and box first check that no
+ * particle has moved more than r_buff / 2 since (one flag read back per call) and then skip the cell sort and the cell
+ * walk.  Default 0.4 (PSE_SKIN in the environment overrides; 0 = rebuild every call).  r_buff may not exceed the
+ * creation value: cells and list capacity are sized for it.  Not kept on slab ranks (multi-GPU) or when rcut + r_buff
+ * exceeds half the box.  Results do not depend on it beyond the order of the fp64 pair sums. */
+int pse_set_neighbor_skin(pse_handle *h, double r_buff);
+/* the r_buff in use and how many calls built / reused the list so far (any pointer may be null) */
+int pse_neighbor_stats(pse_handle *h, double *r_buff, unsigned long long *builds, unsigned long long *reuses);
 /* per-phase hipEvent timing into pse_info (adds host synchronisation; off by default) */
 int pse_set_timing(pse_handle *h, int enabled);
 int pse_get_info(pse_handle *h, pse_info *info);

@@ -101,6 +101,23 @@ struct pse_handle {
     SpreadWork sw = {};       // far-field bins and the bin-ordered particle records (origins, prefac * force, separable weights)
     NbList nb = {};
     bool nb_valid = false;   // the pair list matches the current sorted positions
+    // neighbour list kept across steps (HOOMD's NeighborList with r_buff and a distance check every step, PSEv1/integrate.py:60,79)
+    double skin = 0.0;           // r_buff; 0: cell walk every step
+    double skin_max = 0.0;       // what the cell grid and the list capacity were sized for
+    VerletList vl = {};
+    double4 *pos_build = nullptr;   // sorted positions at the build
+    int *flags_host = nullptr;      // pinned copy of vl.flags
+    bool vl_valid = false;       // the list on the device belongs to the current order (perm) and box
+    bool vl_use = false;         // this call runs on the kept list (no sort, no cell walk)
+    bool vl_pending = false;     // this call's first cell pass writes the list
+    int vl_N = 0; const unsigned *vl_group = nullptr; Box vl_box = {};
+    bool nc_wide = false;        // the cell grid in use is the one sized for rcut + skin_max
+    unsigned long long nlist_builds = 0, nlist_reuses = 0;
+    // A list that is never reused costs a wider cell grid and its own writes at every build: after two builds in a row whose
+    // list failed its first distance check (particles diffuse more than r_buff / 2 per call) the list is suspended for a while
+    // -- builds then run exactly as with r_buff = 0 -- and tried again, with the pause doubling while it keeps failing.
+    int vl_reused_since_build = 0, vl_misses = 0, vl_suspend_left = 0, vl_suspend_len = 32;
+    bool pv_is_f = false;        // the vector half of pv mirrors f_s (as the permute wrote it)
     DCells blk_nc = {0, 0, 0};   // cell grid the near-field blocks were planned for
     size_t blk_list_elems = 0;   // allocated 2-byte entries of the block pair list
     bool w_is_mpsi = false;  // w_s already holds M_real psi_s (delivered by the pass that built the pair list)
@@ -174,11 +191,13 @@ static int cells_for(const Box &box, double rc, double gamma, int n_slabs, DCell
     }
     return 0;
 }
+static double near_radius(const pse_handle *h) { return h->d.rcut + h->skin_max; }   // cells are as wide as the kept list reaches
 static int set_cells(pse_handle *h, double gamma) {
     DCells nc;
-    TRY(cells_for(h->box, h->d.rcut, gamma, h->n_slabs, nc));
+    TRY(cells_for(h->box, near_radius(h), gamma, h->n_slabs, nc));
     h->nc = nc;
     h->cell_gamma = gamma;
+    h->nc_wide = h->skin_max > 0.0;
     return 0;
 }
 
@@ -264,7 +283,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->plan_x_inv) rocfft_plan_destroy(h->plan_x_inv);
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
-    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cell_cnt, h->sup_s, h->sw.rec_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->nb.data, h->nb.cnt, h->nb.blk.list, h->nb.blk.fh, h->pos_s, h->posf_s, h->pv,
+    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cell_cnt, h->sup_s, h->sw.rec_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->nb.data, h->nb.cnt, h->vl.idx, h->vl.cnt, h->vl.flags, h->pos_build, h->nb.blk.list, h->nb.blk.fh, h->pos_s, h->posf_s, h->pv,
                     h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->twiddle, h->fft_work, h->V,
                     h->scal, h->partials};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -278,6 +297,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->bounds_host) (void)hipHostFree(h->bounds_host);
     if (h->ev_bounds) (void)hipEventDestroy(h->ev_bounds);
     if (h->sc_host) (void)hipHostFree(h->sc_host);
+    if (h->flags_host) (void)hipHostFree(h->flags_host);
     delete h;
     return 0;
 }
@@ -421,6 +441,19 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     h->n_max = (int)p->n_max;
     set_dbox(h);
     h->n_slabs = std::max(1, p->n_slabs);
+    {
+        // Neighbour list across steps: on by default with the reference's r_buff = 0.4 (PSEv1/integrate.py:60), single GPU, table
+        // in LDS, box wide enough for rcut + skin; PSE_SKIN overrides (0: off), pse_set_neighbor_skin may lower it later.
+        const char *e1 = getenv("PSE_SKIN"), *e2 = getenv("PSE_NEAR_BLOCKS"), *e3 = getenv("PSE_GRAPH");
+        double skin = e1 ? atof(e1) : 0.4;
+        const int nint = (int)std::ceil(d.rcut * RS_PER_UNIT) + 1;
+        const double gam = std::max(std::fabs(p->xy), p->max_strain);
+        const double wmin = std::min(std::min(h->box.Lx / std::sqrt(1.0 + gam * gam), h->box.Ly), h->box.Lz);
+        if (!(skin > 0.0) || h->n_slabs > 1 || !mreal_table_in_lds(nint * 2 * RS_NCOEF) || (e2 && atoi(e2) > 0) || (e3 && atoi(e3) > 0) ||
+            d.rcut + skin > 0.5 * wmin)
+            skin = 0.0;
+        h->skin = h->skin_max = skin;
+    }
     TRY(set_cells(h, std::max(std::fabs(p->xy), p->max_strain)));
     fill_info(d, &h->info);
     h->info.ncell_x = h->nc.nx; h->info.ncell_y = h->nc.ny; h->info.ncell_z = h->nc.nz;
@@ -502,7 +535,18 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         if (cap > 0) {
             TRY(dmalloc(h, &h->nb.data, nb_list_bytes(n + 64, cap)));   // + one wave: rows are blocked from the rank's first row
         }
-    }
+        if (cap == 0) h->skin = h->skin_max = 0.0;
+        if (h->skin_max > 0.0) {
+            const double rs = d.rcut + h->skin_max, nbar_v = (double)n / vol * 4.18879020478639 * rs * rs * rs;
+            h->vl.cap = (std::max(16, std::min((int)std::ceil(2.0 * nbar_v + 32.0), 512)) + 3) & ~3;   // 4 bytes per slot: generous
+            h->vl.rskin = rs;
+            TRY(dmalloc(h, (char **)&h->vl.idx, verlet_list_bytes(n + 64, h->vl.cap)));
+            TRY(dmalloc(h, &h->vl.cnt, n));
+            TRY(dmalloc(h, &h->vl.flags, 2));
+            TRY(dmalloc(h, &h->pos_build, n));
+            HIPCHK(hipHostMalloc((void **)&h->flags_host, 2 * sizeof(int)));
+        }
+    } else h->skin = h->skin_max = 0.0;
     TRY(dmalloc(h, &h->pos_s, n)); TRY(dmalloc(h, &h->posf_s, n));
     if (h->n_slabs == 1 && !h->nb.blk.on) TRY(dmalloc(h, &h->pv, 3 * n));   // legacy pair-list mat-vec: packed gather records
     TRY(dmalloc(h, &h->f_s, n)); TRY(dmalloc(h, &h->uw_s, n)); TRY(dmalloc(h, &h->ur_s, n));
@@ -576,12 +620,14 @@ extern "C" int pse_set_box(pse_handle *h, double Lx, double Ly, double Lz, doubl
     const Box nb{Lx, Ly, Lz, xy};
     const double gamma = std::max(std::fabs(xy), h->par.max_strain);
     DCells nc;
-    TRY(cells_for(nb, h->d.rcut, gamma, h->n_slabs, nc));
+    TRY(cells_for(nb, near_radius(h), gamma, h->n_slabs, nc));
     if ((size_t)nc.nx * nc.ny * nc.nz > h->n_cells_alloc)
         return fail(PSE_ERR_INVALID, "box grew beyond the cell-list capacity sized at creation");
     h->box = nb;
     h->nc = nc;
     h->cell_gamma = gamma;
+    h->nc_wide = h->skin_max > 0.0;
+    // the kept neighbour list is tied to the box it was built in: prepare() compares vl_box with the box of the call
     h->mg.seen = 0;
     if (h->mg.exec) { (void)hipGraphExecDestroy(h->mg.exec); h->mg.exec = nullptr; }
     if (h->nb.cnt) { HIPCHK(hipSetDevice(h->device)); TRY(plan_blocks(h)); }
@@ -590,6 +636,26 @@ extern "C" int pse_set_box(pse_handle *h, double Lx, double Ly, double Lz, doubl
     set_dbox(h);
     h->info.ncell_x = h->nc.nx; h->info.ncell_y = h->nc.ny; h->info.ncell_z = h->nc.nz;
     h->info.hx = h->d.hx; h->info.hy = h->d.hy; h->info.hz = h->d.hz;
+    return 0;
+}
+
+extern "C" int pse_set_neighbor_skin(pse_handle *h, double r_buff) {
+    if (!h) return fail(PSE_ERR_INVALID, "null handle");
+    if (!(r_buff >= 0.0)) return fail(PSE_ERR_INVALID, "r_buff must be >= 0");
+    if (r_buff > h->skin_max * (1 + 1e-12))
+        return fail(PSE_ERR_INVALID, "r_buff = %g exceeds %g, what the cell grid and the list capacity were sized for at creation "
+                    "(0 here: the neighbour list is not kept on this handle -- slab rank, cutoff too large for the box or the table)",
+                    r_buff, h->skin_max);
+    h->skin = r_buff;
+    h->vl_valid = false;
+    h->vl_misses = 0; h->vl_suspend_left = 0; h->vl_suspend_len = 32;
+    return 0;
+}
+extern "C" int pse_neighbor_stats(pse_handle *h, double *r_buff, unsigned long long *builds, unsigned long long *reuses) {
+    if (!h) return fail(PSE_ERR_INVALID, "null handle");
+    if (r_buff) *r_buff = h->skin;
+    if (builds) *builds = h->nlist_builds;
+    if (reuses) *reuses = h->nlist_reuses;
     return 0;
 }
 
@@ -865,15 +931,67 @@ static int slab_bounds_wait(pse_handle *h, int N) {
 
 // bin + sort + gather into cell order (positions change every step, so this runs every call; every rank sorts all
 // particles: the state is replicated, the work of the later phases is what is sharded)
-static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const unsigned *group, int N, bool defer_bounds = false) {
+// need_cells: the caller walks the cell list itself (pair repulsion): sort even if the neighbour list could be kept.
+//
+// With a neighbour skin the sort and the cell walk run only when the distance check says so (the reference keeps HOOMD's
+// NeighborList with r_buff = 0.4 and setEvery(1, dist_check), PSEv1/integrate.py:60,79, and calls m_nlist->compute every
+// step, Stokes.cc:433): the particles are gathered into the order of the last sort, every one is compared with where it
+// was at the build, and one flag comes back to the host.  Kept: perm, the neighbour list; rebuilt as before: the far-field
+// records, the per-step (f, h) pair list.
+static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const unsigned *group, int N, bool defer_bounds = false,
+                   bool need_cells = false) {
     TRY(ts(h, PH_SORT));
+    h->nb_valid = false;
+    h->w_is_mpsi = false;
+    h->vl_use = false;
+    h->vl_pending = false;
+    h->pv_is_f = vec != nullptr && h->pv != nullptr;
+    const bool same_box = h->vl_box.Lx == h->box.Lx && h->vl_box.Ly == h->box.Ly && h->vl_box.Lz == h->box.Lz && h->vl_box.xy == h->box.xy;
+    if (h->skin > 0.0 && h->vl_valid && !need_cells && h->vl_N == N && h->vl_group == group && same_box && h->sorted_N == N) {
+        HIPCHK(hipMemsetAsync(h->vl.flags, 0, sizeof(int), h->stream));   // [0] only: [1] is the build's overflow mark
+        launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream,
+                       h->pos_build, 0.25 * h->skin * h->skin, h->vl.flags);
+        HIPCHK(hipMemcpyAsync(h->flags_host, h->vl.flags, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (getenv("PSE_DEBUG_NLIST")) fprintf(stderr, "nlist check: moved %d overflow %d\n", h->flags_host[0], h->flags_host[1]);
+        if (h->flags_host[0] == 0 && h->flags_host[1] == 0) {
+            h->vl_use = true;
+            ++h->nlist_reuses;
+            ++h->vl_reused_since_build;
+            h->vl_misses = 0; h->vl_suspend_len = 32;
+            TRY(te(h, PH_SORT));
+            return 0;
+        }
+        if (h->vl_reused_since_build == 0 && ++h->vl_misses >= 2) {   // built twice for nothing: pause
+            h->vl_suspend_left = h->vl_suspend_len;
+            h->vl_suspend_len = std::min(2 * h->vl_suspend_len, 4096);
+            h->vl_misses = 1;                                        // one more miss after the pause suspends again
+        }
+    }
+    h->vl_valid = false;
+    ++h->nlist_builds;
+    const bool with_list = h->skin > 0.0 && h->vl_suspend_left == 0;
+    if (h->skin > 0.0 && !with_list) --h->vl_suspend_left;
+    if (h->skin_max > 0.0) {   // cells as wide as this build reaches: rcut + r_buff with the list, rcut without
+        const bool wide = h->nc_wide;
+        if (wide != with_list) {
+            DCells nc;
+            TRY(cells_for(h->box, h->d.rcut + (with_list ? h->skin_max : 0.0), h->cell_gamma, h->n_slabs, nc));
+            h->nc = nc; h->nc_wide = with_list;
+            h->info.ncell_x = nc.nx; h->info.ncell_y = nc.ny; h->info.ncell_z = nc.nz;
+        }
+    }
     const int ncell = h->nc.nx * h->nc.ny * h->nc.nz;
     cell_sort(pos, group, N, h->dbox, h->nc, h->keys, h->vals, h->keys_s, h->cell_cnt, ncell, h->sort_tmp, h->sort_tmp_bytes,
               h->cell_off, h->perm, h->stream);
     launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream);
     h->sorted_N = N;
-    h->nb_valid = false;
-    h->w_is_mpsi = false;
+    if (with_list) {   // the first cell pass of this call writes the list (real())
+        HIPCHK(hipMemsetAsync(h->vl.flags, 0, 2 * sizeof(int), h->stream));
+        h->vl_pending = true; h->vl_N = N; h->vl_group = group;
+        h->vl.rskin = h->d.rcut + h->skin;
+        h->vl_reused_since_build = 0;
+    }
     TRY(slab_bounds_issue(h));
     if (!defer_bounds) TRY(slab_bounds_wait(h, N));
     TRY(te(h, PH_SORT));
@@ -996,10 +1114,20 @@ static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*ou
         }
         int lo, hi;
         row_range(h, N, lo, hi);
-        launch_mreal(h->pos_s, h->posf_s, h->*vec + vec_off, h->*out + out_off, lo, hi, h->cell_off, h->dbox, h->nc, h->d.rcut,
+        // the kept neighbour list: used when this call runs on it, written by the first cell pass after a sort
+        int vlm = VL_NONE;
+        if (h->vl_use) vlm = VL_USE;
+        else if (h->vl_pending && mode != MREAL_USE_LIST) vlm = VL_WRITE;
+        const double4 *v = h->*vec + vec_off;
+        launch_mreal(h->pos_s, h->posf_s, v, h->*out + out_off, lo, hi, h->cell_off, h->dbox, h->nc, h->d.rcut,
                      h->d.self, h->coef, h->n_intervals * 2 * RS_NCOEF, h->nb, mode, h->stream,
-                     with_psi && mode == MREAL_BUILD_LIST ? h->psi_s : nullptr, h->w_s);
-        if (mode == MREAL_BUILD_LIST) { h->nb_valid = true; h->w_is_mpsi = with_psi && h->n_intervals * 2 * RS_NCOEF * sizeof(double) <= 14 * 1024; }
+                     with_psi && mode == MREAL_BUILD_LIST ? h->psi_s : nullptr, h->w_s, h->vl, vlm,
+                     vlm == VL_USE && v == h->f_s && h->pv_is_f ? h->pv : nullptr);
+        if (vlm == VL_WRITE) {   // the list now matches perm, pos_s and the box of this call
+            HIPCHK(hipMemcpyAsync(h->pos_build, h->pos_s, (size_t)N * sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
+            h->vl_pending = false; h->vl_valid = true; h->vl_box = h->box;
+        }
+        if (mode == MREAL_BUILD_LIST) { h->nb_valid = true; h->w_is_mpsi = with_psi && (vlm == VL_USE || mreal_table_in_lds(h->n_intervals * 2 * RS_NCOEF)); }
     }
     return 0;
 }
@@ -1061,7 +1189,8 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
                     launch_mreal_lanczos(h->pos_s, xj, h->w_s, lo, hi, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef,
                                          h->nb, LzFuse{vjm1, h->partials, h->npart_cap}, h->scal,
                                          ev ? h->ph[PH_MATVEC].a : nullptr, ev ? h->ph[PH_MATVEC].b : nullptr, h->stream,
-                                         done > 0 ? h->pv : nullptr);   // x_j (j > 0) was packed by the previous update
+                                         done > 0 ? h->pv : nullptr,   // x_j (j > 0) was packed by the previous update
+                                         h->vl_use ? h->vl : VerletList{});
                     if (timed) h->matvec_timed = true;
                 } else {
                     launch_lz_dots(xj, h->w_s, vjm1, lo, hi, h->partials, h->npart_cap, h->scal, h->stream);
@@ -1077,6 +1206,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
                 const double4 *xj = done == 0 ? h->psi_s : h->V + (size_t)done * stride;
                 launch_lz_update(xj, h->w_s, done > 0 ? h->V + (size_t)(done - 1) * stride : nullptr, h->V + (size_t)done * stride,
                                  h->V + (size_t)(done + 1) * stride, done, h->scal, rg, nrg, h->stream, h->pv);
+                h->pv_is_f = false;   // the vector half of pv now holds x_{j+1}
             }
         }
         // beta_done = |x_done| is not known yet (the next mat-vec would deliver it): one extra reduction per check
@@ -1381,7 +1511,7 @@ extern "C" int pse_pair_repulsion(pse_handle *h, const pse_double4 *pos, pse_dou
     if (!(sigma > 0.0) || sigma > h->d.rcut)
         return fail(PSE_ERR_INVALID, "repulsion range %.4f outside (0, rcut = %.4f]: the cell list is built for the hydrodynamic cutoff",
                     sigma, h->d.rcut);
-    TRY(prepare(h, (const double4 *)pos, nullptr, group, (int)N));
+    TRY(prepare(h, (const double4 *)pos, nullptr, group, (int)N, false, true));
     launch_pair_repulsion(h->pos_s, h->tag_s, (int)N, h->cell_off, h->dbox, h->nc, k, sigma, accumulate, (double4 *)force, h->stream);
     HIPCHK(hipGetLastError());
     return 0;

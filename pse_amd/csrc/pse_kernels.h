@@ -14,14 +14,17 @@ size_t cell_sort_temp_bytes(size_t ncell);
 void cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys, unsigned *rank,
                unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s);
 // pos_s[i] = wrapped position of particle perm[i], vec_s[i] = vec[tag].xyz, tag_s[i] = its index in the caller's arrays
+// pos_build (nullable): the sorted positions the neighbour list was built at; a particle that has moved more than
+// sqrt(half_skin2) from there (minimum image) sets flags[0] -- HOOMD's NeighborList distance check (r_buff / 2)
 void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm, int N, DBox box,
-                    double4 *pos_s, float4 *posf_s, double2 *pv, double4 *vec_s, unsigned *tag_s, hipStream_t s);
+                    double4 *pos_s, float4 *posf_s, double2 *pv, double4 *vec_s, unsigned *tag_s, hipStream_t s,
+                    const double4 *pos_build = nullptr, double half_skin2 = 0.0, int *flags = nullptr);
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s);
 
 // ---- near field (K9) -------------------------------------------------------------------------------------
-// Per-step pair list, 20 B per pair, in wave-blocked ELL layout: the 64 rows a wavefront owns keep their slot-s entries
-// in one contiguous 1280-byte record [64 x u32 (neighbour slot | image code << 27)][64 x f64 f][64 x f64 h], records of
-// one wave back to back -- a wave streams one contiguous region instead of 3*cnt regions megabytes apart.
+// Per-step pair list, 20 B per pair, in wave-blocked ELL layout: four slots of the 64 rows a wavefront owns form one
+// contiguous 5120-byte group [64 lanes][4 x u32 (neighbour slot | image code << 27)][4 slots][64 x (f64 f, f64 h)], groups
+// of one wave back to back -- a wave streams one contiguous region with 16-byte loads only.
 // Row r = i - lo (lo: first row of the rank, fixed within a step); record (r / 64) * cap + slot.
 // Cell blocks of the near field (pse_nearfield.hip): a workgroup owns bx x by x bz cells, stages them and their one-cell halo in
 // LDS and keeps, per step, a pair list of 2-byte indices into that tile.
@@ -41,6 +44,18 @@ struct NbList {
     int cap;
     NbBlocks blk;
 };
+// Neighbour (Verlet) list kept ACROSS steps, as the reference keeps HOOMD's NeighborListGPUBinned(rcut, r_buff = 0.4) with a
+// distance check every step (PSEv1/integrate.py:60,79; Stokes.cc:433): every pair closer than rcut + skin when it was built.
+// The same wave-blocked layout, entries only: groups of four slots [64 lanes][4 x u32 neighbour slot] = 1024 bytes.
+struct VerletList {
+    unsigned *idx;
+    int *cnt;             // entries per row; -1: the row did not fit (flags[1] is set: the list is not reused)
+    int cap;              // slots per row, a multiple of 4
+    int *flags;           // [0] a particle moved beyond skin / 2 since the build, [1] a row overflowed at the build
+    double rskin;         // rcut + skin
+};
+__host__ __device__ inline size_t verlet_list_bytes(size_t rows, int cap) { return ((rows + 63) / 64) * (size_t)(cap / 4) * 1024; }
+enum { VL_NONE = 0, VL_WRITE = 1, VL_USE = 2 };
 constexpr size_t NB_REC = 64 * 20;
 __host__ __device__ inline size_t nb_list_bytes(size_t rows, int cap) { return ((rows + 63) / 64) * (size_t)cap * NB_REC; }
 enum { MREAL_CELLS = 0, MREAL_BUILD_LIST = 1, MREAL_USE_LIST = 2 };
@@ -55,12 +70,16 @@ struct LzFuse {
 // rows [lo, hi) of the mat-vec (the whole vector is read; multi-GPU ranks each take a row range)
 void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec_s, double4 *out_s, int lo, int hi,
                   const int *cell_off, DBox box, DCells nc, double rcut, double self, const double *coef, int ncoef, NbList nb,
-                  int mode, hipStream_t s, const double4 *vec2_s = nullptr, double4 *out2_s = nullptr);   // BUILD_LIST: a second vector rides along
+                  int mode, hipStream_t s, const double4 *vec2_s = nullptr, double4 *out2_s = nullptr,   // BUILD_LIST: a second vector rides along
+                  VerletList vl = VerletList{}, int vl_mode = VL_NONE,   // VL_WRITE: the cell pass also writes the neighbour list; VL_USE: no cell walk
+                  const double2 *pv = nullptr);                          // VL_USE: packed (position, vec_s) records
+bool mreal_table_in_lds(int ncoef);   // the neighbour list across steps needs the LDS copy of the table
 // pair-list mat-vec + Lanczos sums; leaves the three reduced sums in scal[LZ_TMP .. LZ_TMP + 2]
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, int lo, int hi, const int *cell_off,
                           DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,
                           double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s,   // events (nullable) bracket the mat-vec kernel
-                          const double2 *pv = nullptr);   // packed (position, vector) records holding vec_s, or null
+                          const double2 *pv = nullptr,    // packed (position, vector) records holding vec_s, or null
+                          VerletList vl = VerletList{});  // in use this step: rows that overflowed the pair list walk it instead of the cells
 int mreal_partials_needed(int rows);
 // cell-block near field
 void nb_blocks_plan(NbBlocks &B, const DCells &nc, int ncx, double n, int slots_needed, int nint);

@@ -92,7 +92,8 @@ void cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCell
 __global__ void k_permute(const double4 *__restrict__ pos, const double4 *__restrict__ vec,
                           const unsigned *__restrict__ group, const unsigned *__restrict__ perm, int N, DBox box,
                           double4 *__restrict__ pos_s, float4 *__restrict__ posf_s, double2 *__restrict__ pv,
-                          double4 *__restrict__ vec_s, unsigned *__restrict__ tag_s) {
+                          double4 *__restrict__ vec_s, unsigned *__restrict__ tag_s, const double4 *__restrict__ pos_build,
+                          double half_skin2, int *__restrict__ flags) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N) return;
     const unsigned g = perm[s];
@@ -118,6 +119,16 @@ __global__ void k_permute(const double4 *__restrict__ pos, const double4 *__rest
         double4 v = vec[idx];
         v.w = 0.0;
         vec_s[s] = v;
+        if (pv) {   // the vector half: the neighbour-list pass gathers (position, force) as one record
+            ((double *)&pv[3 * (size_t)s + 1])[1] = v.x;
+            pv[3 * (size_t)s + 2] = make_double2(v.y, v.z);
+        }
+    }
+    if (pos_build) {   // distance check of the kept neighbour list
+        const double4 b = pos_build[s];
+        double dx = q.x - b.x, dy = q.y - b.y, dz = q.z - b.z;
+        min_image(box, dx, dy, dz);
+        if (dx * dx + dy * dy + dz * dz > half_skin2) flags[0] = 1;
     }
 }
 
@@ -131,8 +142,10 @@ __global__ void k_permute_vec(const double4 *__restrict__ vec, const unsigned *_
 }
 
 void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm, int N, DBox box,
-                    double4 *pos_s, float4 *posf_s, double2 *pv, double4 *vec_s, unsigned *tag_s, hipStream_t s) {
-    hipLaunchKernelGGL(k_permute, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, vec, group, perm, N, box, pos_s, posf_s, pv, vec_s, tag_s);
+                    double4 *pos_s, float4 *posf_s, double2 *pv, double4 *vec_s, unsigned *tag_s, hipStream_t s,
+                    const double4 *pos_build, double half_skin2, int *flags) {
+    hipLaunchKernelGGL(k_permute, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, vec, group, perm, N, box, pos_s, posf_s, pv, vec_s, tag_s,
+                       pos_build, half_skin2, flags);
 }
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s) {
     hipLaunchKernelGGL(k_permute_vec, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, vec, tag_s, N, vec_s);
@@ -161,17 +174,23 @@ __device__ __forceinline__ void nb_store(char *rec, int slot, int lane, unsigned
     ((double2 *)(r + 1024))[(slot & 3) * 64 + lane] = make_double2(f, h);
 }
 
+__device__ __forceinline__ void vl_store(char *vrec, int slot, int lane, unsigned j) {
+    ((unsigned *)(vrec + (size_t)(slot >> 2) * 1024))[lane * 4 + (slot & 3)] = j;
+}
+
 // CL: the f, g coefficient table is copied to LDS first (ncoef doubles of dynamic shared memory).  Every neighbour reads
 // 20 coefficients of its own interval: from global memory that was 20 of the 24 L1 accesses per pair and kept the
 // texture addresser busy for the whole kernel (rocprofv3: TA_BUSY = duration, 425 M cache accesses = 20 x 21.3 M pairs).
 // TWO: a second vector rides along (out2 = M_real vec2): the pass that builds the pair list for M.F also delivers
 // M.psi, the first Lanczos mat-vec, for one more gather per neighbour.
-template <bool LIST, bool CL, bool TWO>
+// VL: the pass also writes the neighbour list kept across steps -- every pair closer than vl.rskin = rcut + skin (the
+// pre-filter and the queue work with that radius; f, g and the pair list still stop at rcut).
+template <bool LIST, bool CL, bool TWO, bool VL>
 __global__ void __launch_bounds__(TPB)
 k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf_s, const double4 *__restrict__ vec_s,
               double4 *__restrict__ out_s, int lo, int hi, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2,
               float rcut2_pre, double self, const double *__restrict__ coef_g, int ncoef, NbList nb,
-              const double4 *__restrict__ vec2_s, double4 *__restrict__ out2_s) {
+              const double4 *__restrict__ vec2_s, double4 *__restrict__ out2_s, VerletList vl) {
     __shared__ unsigned queue[QCAP * TPB];
     extern __shared__ double scoef[];
     const int tid = threadIdx.x;
@@ -193,9 +212,11 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
     frac_coords(box, pi.x, pi.y, pi.z, fx, fy, fz);
     const int cx = cell_coord(fx, nc.nx), cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz);
     const bool shift_only = nc.nx > 1 && nc.ny > 1 && nc.nz > 1;   // otherwise finish with the rint minimum image
-    int qn = 0, total = 0;
+    int qn = 0, total = 0, vtotal = 0;
     const int lane = (i - lo) & 63;
     char *rec = LIST ? nb.data + (size_t)((i - lo) >> 6) * nb.cap * NB_REC : nullptr;
+    char *vrec = VL ? (char *)vl.idx + (size_t)((i - lo) >> 6) * (vl.cap / 4) * 1024 : nullptr;
+    const double rq2 = VL ? vl.rskin * vl.rskin : rcut2;   // what enters the queue
 
     // two queue entries per iteration: their load -> distance -> table -> force chains are independent, which doubles the
     // memory requests in flight of this latency-bound phase (57 % of its wave-cycles were s_waitcnt)
@@ -214,8 +235,13 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
             if (!shift_only) { min_image(box, d0x, d0y, d0z); min_image(box, d1x, d1y, d1z); }
             const double r20 = d0x * d0x + d0y * d0y + d0z * d0z, r21 = d1x * d1x + d1y * d1y + d1z * d1z;
             double f0, h0, f1, h1;
-            if (CL) { eval_fg<2 * RS_NCOEF + 1>(r20, coef, f0, h0); eval_fg<2 * RS_NCOEF + 1>(r21, coef, f1, h1); }
-            else { eval_fg(r20, coef, f0, h0); eval_fg(r21, coef, f1, h1); }
+            if (VL) {
+                if (r20 < rq2 && r20 > 0.0) { if (vtotal < vl.cap) vl_store(vrec, vtotal, lane, (unsigned)j0); ++vtotal; }
+                if (two && r21 < rq2 && r21 > 0.0) { if (vtotal < vl.cap) vl_store(vrec, vtotal, lane, (unsigned)j1); ++vtotal; }
+            }
+            const double t0 = VL ? fmin(r20, rcut2) : r20, t1 = VL ? fmin(r21, rcut2) : r21;   // the table ends at rcut
+            if (CL) { eval_fg<2 * RS_NCOEF + 1>(t0, coef, f0, h0); eval_fg<2 * RS_NCOEF + 1>(t1, coef, f1, h1); }
+            else { eval_fg(t0, coef, f0, h0); eval_fg(t1, coef, f1, h1); }
             const bool in0 = r20 < rcut2 && r20 > 0.0, in1 = two && r21 < rcut2 && r21 > 0.0;   // the fp64 cutoff decides
             if (!in0) { f0 = 0.0; h0 = 0.0; }
             if (!in1) { f1 = 0.0; h1 = 0.0; }
@@ -260,7 +286,7 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
                 double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                 min_image(box, dx, dy, dz);
                 const double r2 = dx * dx + dy * dy + dz * dz;
-                if (r2 < rcut2 && j != i && r2 > 0.0) {
+                if (r2 < rq2 && j != i && r2 > 0.0) {
                     queue[qn * TPB + tid] = (unsigned)j | (code << 27);
                     ++qn;
                 }
@@ -294,6 +320,85 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
         if (total > nb.cap) total = -1;   // the row did not fit: the mat-vecs of this step walk the cells for it
         nb.cnt[i] = total;
     }
+    if (VL) {
+        if (vtotal > vl.cap) { vtotal = -1; vl.flags[1] = 1; }
+        vl.cnt[i] = vtotal;
+    }
+}
+
+// The near-field pass of a step that REUSES the neighbour list: no cell walk -- every row reads its entries (groups of four,
+// one 16-byte load), gathers the neighbours' (position, vec) records (+ vec2), takes the minimum image itself (particles may
+// have crossed the periodic boundary since the build) and evaluates f, g densely; pairs beyond rcut (about a quarter at
+// skin = 0.4) contribute zero.  LIST: writes the step's pair list for the Lanczos mat-vecs, exactly as the cell pass does.
+// PK: pv holds (position, vec_s) records (three 16-byte gathers per neighbour instead of four).
+template <bool LIST, bool TWO, bool PK>
+__global__ void __launch_bounds__(TPB)
+k_mreal_verlet(const double4 *__restrict__ pos_s, const double2 *__restrict__ pv, const double4 *__restrict__ vec_s,
+               double4 *__restrict__ out_s, int N, DBox box, double rcut2, double self, const double *__restrict__ coef_g, int ncoef,
+               NbList nb, VerletList vl, const double4 *__restrict__ vec2_s, double4 *__restrict__ out2_s) {
+    extern __shared__ double scoef[];
+    const int tid = threadIdx.x;
+    for (int q = tid; q < ncoef; q += TPB) scoef[(q / (2 * RS_NCOEF)) * (2 * RS_NCOEF + 1) + q % (2 * RS_NCOEF)] = coef_g[q];
+    __syncthreads();
+    const int i = xcd_block(blockIdx.x, gridDim.x) * TPB + tid;
+    if (i >= N) return;
+    const double4 pi = pos_s[i];
+    const double4 vi = vec_s[i];
+    double ux = self * vi.x, uy = self * vi.y, uz = self * vi.z;
+    double wx = 0.0, wy = 0.0, wz = 0.0;
+    if (TWO) { const double4 v2 = vec2_s[i]; wx = self * v2.x; wy = self * v2.y; wz = self * v2.z; }
+    const int lane = i & 63, cnt = vl.cnt[i];
+    const char *vrec = (const char *)vl.idx + (size_t)(i >> 6) * (vl.cap / 4) * 1024;
+    char *rec = LIST ? nb.data + (size_t)(i >> 6) * nb.cap * NB_REC : nullptr;
+    int total = 0;
+    constexpr int U = 4;
+    for (int s0 = 0; s0 < cnt; s0 += U) {
+        const uint4 e4 = ((const uint4 *)(vrec + (size_t)(s0 >> 2) * 1024))[lane];
+        unsigned e[U] = {e4.x, e4.y, e4.z, e4.w};
+        double2 a[U], b[U], c[U];
+        double4 G[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (u && s0 + u >= cnt) e[u] = e[0];          // slots past the row's count were never written
+            if (PK) {
+                const double2 *r = pv + 3 * (size_t)e[u];
+                a[u] = r[0]; b[u] = r[1]; c[u] = r[2];
+            } else {
+                const double4 pj = pos_s[e[u]], Fj = vec_s[e[u]];
+                a[u] = make_double2(pj.x, pj.y); b[u] = make_double2(pj.z, Fj.x); c[u] = make_double2(Fj.y, Fj.z);
+            }
+            if (TWO) G[u] = vec2_s[e[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double dx = pi.x - a[u].x, dy = pi.y - a[u].y, dz = pi.z - b[u].x;
+            const double ny = rint(dy * box.iLy);
+            dy -= ny * box.Ly; dx -= ny * box.xy * box.Ly;
+            const double nx = rint(dx * box.iLx), nz = rint(dz * box.iLz);
+            dx -= nx * box.Lx; dz -= nz * box.Lz;
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            const bool in = s0 + u < cnt && r2 < rcut2 && r2 > 0.0;
+            double f, h;
+            eval_fg<2 * RS_NCOEF + 1>(fmin(r2, rcut2), scoef, f, h);
+            if (!in) { f = 0.0; h = 0.0; }
+            const double Fx = b[u].y, Fy = c[u].x, Fz = c[u].y;
+            const double rd = (dx * Fx + dy * Fy + dz * Fz) * h;
+            ux += f * Fx + rd * dx; uy += f * Fy + rd * dy; uz += f * Fz + rd * dz;
+            if (TWO) {
+                const double sd = (dx * G[u].x + dy * G[u].y + dz * G[u].z) * h;
+                wx += f * G[u].x + sd * dx; wy += f * G[u].y + sd * dy; wz += f * G[u].z + sd * dz;
+            }
+            if (LIST && in) {
+                // the image the mat-vecs subtract: d = x_i - x_j - shift(code), shift = nx a + ny b + nz c (pse_device.h image_shift)
+                const unsigned code = (unsigned)(((int)nx + 1) * 9 + ((int)ny + 1) * 3 + ((int)nz + 1));
+                if (total < nb.cap) nb_store(rec, total, lane, e[u] | (code << 27), f, h);
+                ++total;
+            }
+        }
+    }
+    out_s[i] = make_double4(ux, uy, uz, 0.0);
+    if (TWO) out2_s[i] = make_double4(wx, wy, wz, 0.0);
+    if (LIST) nb.cnt[i] = total > nb.cap ? -1 : total;   // -1: the mat-vecs of this step walk the neighbour list for this row
 }
 
 // mat-vec from the pair list (one thread per particle, ELL layout: slot-major so a wave reads contiguous rows).
@@ -305,7 +410,7 @@ template <bool FUSE, int UNROLL, int NT, bool PACKED>
 __global__ void __launch_bounds__(NT)
 k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int lo,
              int hi, DBox box, int shift_only, double self, NbList nb, LzFuse lz, const double2 *__restrict__ pv,
-             const int *__restrict__ cell_off, DCells nc, double rcut2, const double *__restrict__ coef) {
+             const int *__restrict__ cell_off, DCells nc, double rcut2, const double *__restrict__ coef, VerletList vl) {
     __shared__ double shift[27 * 3];
     __shared__ double sh[4];
     if (threadIdx.x < 27) {
@@ -369,6 +474,28 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
                     uz += fu * Fj[u].z + rdF * dz;
                 }
             }
+        } else if (vl.idx) {
+            // the row did not fit the pair list and the step runs on the kept neighbour list (the cells are those of its build)
+            const double4 pi = pos_s[i];
+            ux = self * vi.x; uy = self * vi.y; uz = self * vi.z;
+            const int lane = i & 63, vc = vl.cnt[i];
+            const char *vrec = (const char *)vl.idx + (size_t)(i >> 6) * (vl.cap / 4) * 1024;
+            for (int sl = 0; sl < vc; ++sl) {
+                const unsigned j = ((const unsigned *)(vrec + (size_t)(sl >> 2) * 1024))[lane * 4 + (sl & 3)];
+                const double4 pj = pos_s[j];
+                double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                min_image(box, dx, dy, dz);
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                if (r2 < rcut2 && r2 > 0.0) {
+                    double f, h;
+                    eval_fg(r2, coef, f, h);
+                    const double4 Fj = vec_s[j];
+                    const double rdF = (dx * Fj.x + dy * Fj.y + dz * Fj.z) * h;
+                    ux += f * Fj.x + rdF * dx;
+                    uy += f * Fj.y + rdF * dy;
+                    uz += f * Fj.z + rdF * dz;
+                }
+            }
         } else {
             // the row did not fit the list (dense cluster): walk the cells, as the pass that built the list did
             const double4 pi = pos_s[i];
@@ -414,29 +541,46 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
     if (active) out_s[i] = make_double4(ux, uy, uz, 0.0);
 }
 
+static size_t mreal_lds_bytes(int ncoef) { return (size_t)(ncoef / (2 * RS_NCOEF)) * (2 * RS_NCOEF + 1) * sizeof(double); }   // padded copy
+bool mreal_table_in_lds(int ncoef) { return mreal_lds_bytes(ncoef) <= 14 * 1024; }   // with the 48 KB queue: two workgroups per CU
+
 void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec_s, double4 *out_s, int lo, int hi,
                   const int *cell_off, DBox box, DCells nc, double rcut, double self, const double *coef, int ncoef, NbList nb,
-                  int mode, hipStream_t s, const double4 *vec2_s, double4 *out2_s) {
+                  int mode, hipStream_t s, const double4 *vec2_s, double4 *out2_s, VerletList vl, int vl_mode, const double2 *pv) {
     if (hi <= lo) return;
+    const dim3 g(nblocks(hi - lo, TPB)), b(TPB);
+    const size_t cb = mreal_lds_bytes(ncoef);
+    const bool cl = mreal_table_in_lds(ncoef);
+    if (mode == MREAL_USE_LIST) {
+        hipLaunchKernelGGL((k_mreal_list<false, 4, TPB, false>), g, b, 0, s, pos_s, vec_s, out_s, lo, hi, box,
+                           (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1), self, nb, LzFuse{}, nullptr, cell_off, nc, rcut * rcut, coef,
+                           vl_mode == VL_USE ? vl : VerletList{});
+        return;
+    }
+    const bool list = mode == MREAL_BUILD_LIST, two = list && vec2_s != nullptr;
+    if (vl_mode == VL_USE) {   // rows [0, N) of a single rank; the table is in LDS (the caller checked mreal_table_in_lds)
+#define PSE_VERLET(L, T) do { if (pv) hipLaunchKernelGGL((k_mreal_verlet<L, T, true>), g, b, cb, s, pos_s, pv, vec_s, out_s, hi, box, rcut * rcut, self, coef, ncoef, nb, vl, two ? vec2_s : nullptr, out2_s); \
+        else hipLaunchKernelGGL((k_mreal_verlet<L, T, false>), g, b, cb, s, pos_s, pv, vec_s, out_s, hi, box, rcut * rcut, self, coef, ncoef, nb, vl, two ? vec2_s : nullptr, out2_s); } while (0)
+        if (list && two) PSE_VERLET(true, true);
+        else if (list) PSE_VERLET(true, false);
+        else PSE_VERLET(false, false);
+#undef PSE_VERLET
+        return;
+    }
     // pre-filter cutoff: coordinates (and image-shifted coordinates) are below 1.5 (Lx + |xy| Ly + Ly + Lz), rounded to
     // 2^-24 relative a few times on the way to a separation component
+    const bool wr = vl_mode == VL_WRITE && cl;
     const double cmax = 1.5 * (box.Lx + std::fabs(box.xy) * box.Ly + box.Ly + box.Lz);
-    const double rpre = rcut + 16.0 * cmax * 5.97e-8;
+    const double rpre = (wr ? vl.rskin : rcut) + 16.0 * cmax * 5.97e-8;
     const float rcut2_pre = (float)(rpre * rpre * (1.0 + 1e-6));
-    const dim3 g(nblocks(hi - lo, TPB)), b(TPB);
-    const size_t cb = (size_t)(ncoef / (2 * RS_NCOEF)) * (2 * RS_NCOEF + 1) * sizeof(double);   // padded copy in LDS
-    const bool cl = cb <= 14 * 1024;   // with the 48 KB queue: two workgroups per CU
-    if (mode == MREAL_BUILD_LIST) {
-        if (cl && vec2_s) hipLaunchKernelGGL((k_mreal_cells<true, true, true>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, vec2_s, out2_s);
-        else if (cl) hipLaunchKernelGGL((k_mreal_cells<true, true, false>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, nullptr, nullptr);
-        else hipLaunchKernelGGL((k_mreal_cells<true, false, false>), g, b, 0, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, nullptr, nullptr);
-    } else if (mode == MREAL_USE_LIST) {
-        hipLaunchKernelGGL((k_mreal_list<false, 4, TPB, false>), g, b, 0, s, pos_s, vec_s, out_s, lo, hi, box,
-                           (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1), self, nb, LzFuse{}, nullptr, cell_off, nc, rcut * rcut, coef);
-    } else if (cl)
-        hipLaunchKernelGGL((k_mreal_cells<false, true, false>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, nullptr, nullptr);
-    else
-        hipLaunchKernelGGL((k_mreal_cells<false, false, false>), g, b, 0, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, nullptr, nullptr);
+#define PSE_CELLS(L, C, T, V) hipLaunchKernelGGL((k_mreal_cells<L, C, T, V>), g, b, (C) ? cb : 0, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, two ? vec2_s : nullptr, out2_s, vl)
+    if (list) {
+        if (cl && two) { if (wr) PSE_CELLS(true, true, true, true); else PSE_CELLS(true, true, true, false); }
+        else if (cl) { if (wr) PSE_CELLS(true, true, false, true); else PSE_CELLS(true, true, false, false); }
+        else PSE_CELLS(true, false, false, false);
+    } else if (cl) { if (wr) PSE_CELLS(false, true, false, true); else PSE_CELLS(false, true, false, false); }
+    else PSE_CELLS(false, false, false, false);
+#undef PSE_CELLS
 }
 
 __global__ void __launch_bounds__(1024) k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, double *__restrict__ scal);
@@ -446,12 +590,12 @@ void launch_lz_reduce3(const double *partials, int npart, int cap, double *scal,
 }
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, int lo, int hi, const int *cell_off,
                           DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,
-                          double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s, const double2 *pv) {
+                          double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s, const double2 *pv, VerletList vl) {
     const int so = (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1);
     const int nbk = nblocks(std::max(hi - lo, 1), TPB);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
-    if (pv) hipLaunchKernelGGL((k_mreal_list<true, 4, TPB, true>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, pv, cell_off, nc, rcut * rcut, coef);
-    else hipLaunchKernelGGL((k_mreal_list<true, 4, TPB, false>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, nullptr, cell_off, nc, rcut * rcut, coef);
+    if (pv) hipLaunchKernelGGL((k_mreal_list<true, 4, TPB, true>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, pv, cell_off, nc, rcut * rcut, coef, vl);
+    else hipLaunchKernelGGL((k_mreal_list<true, 4, TPB, false>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, nullptr, cell_off, nc, rcut * rcut, coef, vl);
     if (ev_end) (void)hipEventRecord(ev_end, s);
     hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, lz.partials, nbk, lz.npart_cap, 3, scal);
 }

@@ -94,6 +94,16 @@ class Engine:
     def set_timing(self, on=True):
         _lib.check(self._lib.pse_set_timing(self._h, 1 if on else 0))
 
+    def set_neighbor_skin(self, r_buff):
+        """r_buff of the neighbour list kept across calls (HOOMD's nlist r_buff, PSEv1/integrate.py:60); 0 rebuilds every call."""
+        _lib.check(self._lib.pse_set_neighbor_skin(self._h, float(r_buff)))
+
+    def neighbor_stats(self):
+        """(r_buff, builds, reuses) of the kept neighbour list."""
+        r, b, u = ctypes.c_double(), ctypes.c_ulonglong(), ctypes.c_ulonglong()
+        _lib.check(self._lib.pse_neighbor_stats(self._h, ctypes.byref(r), ctypes.byref(b), ctypes.byref(u)))
+        return r.value, b.value, u.value
+
     def set_stream(self, stream_ptr):
         _lib.check(self._lib.pse_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
 

@@ -1,0 +1,160 @@
+"""Neighbour list kept across calls (the reference's HOOMD nlist with r_buff = 0.4 and a distance check every step,
+PSEv1/integrate.py:60,79, Stokes.cc:433): calls that reuse it must give what a fresh build gives, and the distance check
+must send the call back to the cells when it has to."""
+import numpy as np
+import pytest
+
+from conftest import make_suspension, to4
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    return torch
+
+
+def _fresh(n, box, pos, force, kT, dt, ts, seed, **kw):
+    import pse_amd
+    e = pse_amd.Engine(n, box, xi=0.5, error=1e-3, seed=seed, **kw)
+    e.set_neighbor_skin(0.0)
+    if kT > 0:
+        v, m = e.brownian_velocity(to4(pos), to4(force), kT, dt, ts)
+    else:
+        v, m = e.mobility(to4(pos), to4(force)), 0
+    return v.cpu().numpy()[:, :3], m
+
+
+@pytest.mark.parametrize("xy", [0.0, 0.3])
+def test_reused_list_matches_fresh_build(torch_cuda, oracle, xy):
+    """Second and third calls at moved positions (within r_buff / 2, some across the periodic boundary) run on the kept list:
+    M.F and the Brownian velocity equal what an engine that rebuilds gives, and equal the port."""
+    import pse_amd
+    n, seed, kT, dt = 2000, 7, 1.0, 1e-3
+    pos, force, box = make_suspension(n, phi=0.1, xy=xy)
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3, seed=seed)
+    r_buff, b0, u0 = eng.neighbor_stats()
+    assert r_buff == pytest.approx(0.4) and b0 == 0 and u0 == 0
+    eng.mobility(to4(pos), to4(force))
+    assert eng.neighbor_stats()[1:] == (1, 0)
+    rng = np.random.default_rng(3)
+    d = rng.normal(size=(n, 3)); d *= 0.19 * rng.uniform(size=(n, 1)) / np.linalg.norm(d, axis=1, keepdims=True)
+    moved = oracle.wrap(pos + d, np.zeros((n, 3), dtype=np.int64), box)[0]
+    assert (np.abs(moved - pos).max(axis=1) > 1.0).any(), "some particles should cross the boundary"
+    v = eng.mobility(to4(moved), to4(force)).cpu().numpy()[:, :3]
+    assert eng.neighbor_stats()[1:] == (1, 1)
+    ref, _ = _fresh(n, box, moved, force, 0.0, dt, 0, seed)
+    assert rel(v, ref) < 1e-12, rel(v, ref)
+    vb, m = eng.brownian_velocity(to4(moved), to4(force), kT, dt, 5)
+    assert eng.neighbor_stats()[1:] == (1, 2)
+    refb, mref = _fresh(n, box, moved, force, kT, dt, 5, seed)
+    assert m == mref
+    assert rel(vb.cpu().numpy()[:, :3], refb) < 1e-11, rel(vb.cpu().numpy()[:, :3], refb)
+    p = oracle.select_params(box, 0.5, 1e-3, 0.5)
+    port, mp = oracle.brownian_velocity(moved, force, box, p, kT, dt, seed, 5)
+    assert m == mp and rel(vb.cpu().numpy()[:, :3], port) < 1e-9
+
+
+def test_distance_check_forces_a_rebuild(torch_cuda, oracle):
+    import pse_amd
+    n, seed = 2000, 11
+    pos, force, box = make_suspension(n, phi=0.1)
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3, seed=seed)
+    eng.mobility(to4(pos), to4(force))
+    moved = pos.copy()
+    moved[17] += np.array([0.15, -0.12, 0.1])      # 0.216 > r_buff / 2
+    moved = oracle.wrap(moved, np.zeros((n, 3), dtype=np.int64), box)[0]
+    v = eng.mobility(to4(moved), to4(force)).cpu().numpy()[:, :3]
+    assert eng.neighbor_stats()[1:] == (2, 0)
+    ref, _ = _fresh(n, box, moved, force, 0.0, 1e-3, 0, seed)
+    assert rel(v, ref) < 1e-12
+    # far move of many particles, another N, another group: always a build
+    eng.mobility(to4(-moved), to4(force))
+    assert eng.neighbor_stats()[1:] == (3, 0)
+    eng.mobility(to4(moved[:1500]), to4(force[:1500]))
+    assert eng.neighbor_stats()[1:] == (4, 0)
+    # a smaller r_buff; zero switches the list off
+    eng.set_neighbor_skin(0.1)
+    eng.mobility(to4(moved), to4(force)); eng.mobility(to4(moved), to4(force))
+    assert eng.neighbor_stats() == (0.1, 5, 1)
+    eng.set_neighbor_skin(0.0)
+    v0 = eng.mobility(to4(moved), to4(force)).cpu().numpy()[:, :3]
+    assert eng.neighbor_stats()[1:] == (6, 1) and rel(v0, ref) < 1e-12
+    with pytest.raises(Exception):
+        eng.set_neighbor_skin(0.5)
+
+
+@pytest.mark.parametrize("dt", [2e-4, 5e-3])
+def test_trajectory_with_and_without_the_kept_list(torch_cuda, dt):
+    """Thirty Brownian steps: the run that keeps the list and the run that rebuilds every step end at the same positions and
+    image flags, with the same Lanczos iteration counts.  Small steps: a few builds, the rest reuse.  Large steps (every
+    particle diffuses past r_buff / 2 per step): the list is never reusable and gets suspended; results are the same."""
+    import torch
+    import pse_amd
+    n, seed, kT = 3000, 5, 1.0
+    pos, force, box = make_suspension(n, phi=0.15)
+    out = []
+    for skin in (0.4, 0.0):
+        eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3, seed=seed)
+        eng.set_neighbor_skin(skin)
+        dpos = to4(pos, 1.0); vel = to4(np.zeros((n, 3))); dF = to4(force)
+        accel = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+        image = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+        ms, m = [], 2
+        for ts in range(30):
+            m = eng.step(dpos, vel, accel, image, dF, kT, dt, ts, lanczos_m=m)
+            ms.append(m)
+        out.append((dpos.cpu().numpy(), image.cpu().numpy(), ms, eng.neighbor_stats()))
+    (pa, ia, ma, sa), (pb, ib, mb, sb) = out
+    assert sb[1:] == (30, 0)
+    if dt < 1e-3:
+        assert 1 < sa[1] < 15 and sa[1] + sa[2] == 30, sa
+    else:
+        assert sa[1:] == (30, 0), sa
+    assert ma == mb
+    assert np.array_equal(ia, ib)
+    assert np.abs(pa - pb).max() < 1e-9, np.abs(pa - pb).max()
+
+
+def test_overflow_rows_on_the_kept_list(torch_cuda, oracle):
+    """Rows of a dense cluster that do not fit the per-step pair list walk the kept neighbour list inside the mat-vecs; a
+    cluster too dense for the neighbour list itself switches the reuse off (every call builds)."""
+    import pse_amd
+    rng = np.random.default_rng(17)
+    n, L = 2000, 60.0
+    box = (L, L, L, 0.0)
+    nb = 36
+    ball = rng.normal(size=(nb, 3)); ball *= (2.0 * rng.uniform(size=(nb, 1)) ** (1 / 3)) / np.linalg.norm(ball, axis=1, keepdims=True)
+    pos = np.concatenate([ball + np.array([L / 2 - 1.0, 0.0, -L / 2 + 0.5]), rng.uniform(-L / 2, L / 2, size=(n - nb, 3))])
+    pos = oracle.wrap(pos, np.zeros((n, 3), dtype=np.int64), box)[0]
+    psi = rng.normal(size=(n, 3))
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3)
+    rcut = eng.info()["rcut"]
+    eng.sqrt_mreal(to4(pos), to4(psi), tol=1e-3)
+    moved = oracle.wrap(pos + 0.05 * rng.normal(size=(n, 3)).clip(-2, 2), np.zeros((n, 3), dtype=np.int64), box)[0]
+    out, m = eng.sqrt_mreal(to4(moved), to4(psi), tol=1e-3)
+    st = eng.neighbor_stats()
+    matvec = lambda v: oracle.mobility_real(moved, np.ascontiguousarray(v), box, 0.5, rcut)
+    up, mp = oracle.lanczos_sqrt(matvec, psi, 2, 1e-3)
+    assert m == mp, (m, mp)
+    assert rel(out.cpu().numpy()[:, :3], up) < 1e-9
+    d = moved[:nb, None] - moved[None]
+    d -= L * np.round(d / L)
+    counts = (np.linalg.norm(d, axis=2) < rcut).sum(1) - 1
+    assert counts.max() >= 33               # beyond the pair list's ~28 slots per row, inside the neighbour list's ~48
+    assert st[1:] == (1, 1), st
+    # a cluster too dense for the neighbour list as well: the build marks the overflow and the next call builds again
+    big = np.concatenate([ball, ball * 0.9 + 0.05, ball * 0.8 - 0.05]) + np.array([L / 2 - 1.0, 0.0, -L / 2 + 0.5])
+    pos2 = oracle.wrap(np.concatenate([big, pos[3 * nb:]]), np.zeros((n, 3), dtype=np.int64), box)[0]
+    eng.sqrt_mreal(to4(pos2), to4(psi), tol=1e-3)
+    out2, m2 = eng.sqrt_mreal(to4(pos2), to4(psi), tol=1e-3)
+    assert eng.neighbor_stats()[1:] == (3, 1)
+    mv2 = lambda v: oracle.mobility_real(pos2, np.ascontiguousarray(v), box, 0.5, rcut)
+    up2, mp2 = oracle.lanczos_sqrt(mv2, psi, 2, 1e-3)
+    assert m2 == mp2 and rel(out2.cpu().numpy()[:, :3], up2) < 1e-9

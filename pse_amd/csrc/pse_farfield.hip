@@ -208,17 +208,26 @@ __device__ __forceinline__ void uniform_dispatch(int k, F &&f) {
     }
 }
 
-template <int P, int TZ, bool SHEAR>
-__global__ void __launch_bounds__(64)
+// NW > 1 (small grids: fewer blocks than SIMDs): NW waves share a block and split its candidate chunks among themselves, each
+// with its own tables; their accumulators are summed through LDS at the end (in wave order: the result does not depend on timing).
+template <int P, int TZ, bool SHEAR, int NW>
+__global__ void __launch_bounds__(64 * NW)
 k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ gx, double *__restrict__ gy,
                double *__restrict__ gz, DGrid G, GaussConsts gc, FastDiv dz, FastDiv dy) {
     constexpr int TX = 8, TY = 8, PT = P + 2, LS = 65, RMAX = P <= 8 ? 20 : 32;   // runs: bins in x times bins in y times z parts
     constexpr int UB = (P + 4) & ~1;          // doubles per particle of the wave-uniform block: az[P], force[3], pad to 16 bytes
-    __shared__ double s_ax[PT * LS], s_ay[PT * LS];
-    __shared__ __attribute__((aligned(16))) double s_u[UB * 64];
+    constexpr int WB = 2 * PT * LS + UB * 64 + ((2 * PT * LS) & 1);   // doubles of one wave's tables (s_u 16-byte aligned)
+    constexpr int RED = (NW - 1) * TZ * 3 * 64;                        // the other waves' accumulators, parked over the tables
+    __shared__ __attribute__((aligned(16))) double s_tab[NW * WB > RED ? NW * WB : RED];
     __shared__ double s_k[SHEAR ? PT * 16 : 1];
     __shared__ int s_rb[RMAX], s_ro[RMAX + 1];
-    const int lane = threadIdx.x, lx = lane & 7, ly = lane >> 3;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lx = lane & 7, ly = lane >> 3;
+    double *const s_ax = s_tab + wv * WB, *const s_ay = s_ax + PT * LS, *const s_u = s_tab + wv * WB + (WB - UB * 64);
+    // tables are private to a wave: inside the chunk loop a wave only has to order its own LDS accesses (they execute in issue
+    // order); a workgroup barrier there would also deadlock, the waves run different numbers of chunks
+    auto wave_sync = [] () __attribute__((always_inline)) {
+        if (NW == 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    };
     int tz_, ty_;
     const int tx_ = fdiv(fdiv(xcd_block(blockIdx.x, gridDim.x), dz, tz_), dy, ty_);
     const int t0[3] = {G.x0 + tx_ * TX, ty_ * TY, tz_ * TZ};
@@ -227,7 +236,7 @@ k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ 
     const int nb[3] = {fb.nbx, fb.nby, fb.nbz};
 
     if (SHEAR)   // K[t][v] = exp(-2 c s hx hy t v) on the padded index grid (the pads multiply a zero)
-        for (int e = lane; e < PT * 16; e += 64) s_k[e] = exp_lean(gc.lnk * (double)(((e >> 4) - 1) * ((e & 15) - 1)));
+        for (int e = threadIdx.x; e < PT * 16; e += 64 * NW) s_k[e] = exp_lean(gc.lnk * (double)(((e >> 4) - 1) * ((e & 15) - 1)));
     // bins whose origins [t0 - P + 1, t0 + ext - 1] (cyclic) can reach the block; consecutive z bins are one record range
     int blo[3], bcnt[3];
 #pragma unroll
@@ -237,7 +246,7 @@ k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ 
     }
     const int zparts = blo[2] + bcnt[2] > nb[2] ? 2 : 1;
     const int nr = bcnt[0] * bcnt[1] * zparts;
-    if (lane < nr) {
+    if ((int)threadIdx.x < nr) {
         const int zp = lane % zparts, r = lane / zparts, iy = r % bcnt[1], ix = r / bcnt[1];
         const int row = (((blo[0] + ix) % nb[0]) * nb[1] + (blo[1] + iy) % nb[1]) * nb[2];
         int z0 = blo[2], z1 = blo[2] + bcnt[2];                      // [z0, z1) bins, before the wrap
@@ -247,7 +256,7 @@ k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ 
         s_ro[lane + 1] = fb.off[row + z1] - o;
     }
     __syncthreads();
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         int run = 0;
         s_ro[0] = 0;
         for (int r = 0; r < nr; ++r) { run += s_ro[r + 1]; s_ro[r + 1] = run; }
@@ -269,11 +278,11 @@ k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ 
         const double2 *rp = reinterpret_cast<const double2 *>(rec + slot);
         n0 = rp[0]; n1 = rp[1]; n2 = rp[2]; n3 = rp[3];
     };
-    if (total > 0) fetch(0);
-    for (int c0 = 0; c0 < total; c0 += 64) {
+    if (64 * wv < total) fetch(64 * wv);
+    for (int c0 = 64 * wv; c0 < total; c0 += 64 * NW) {
         const bool valid = c0 + lane < total;
         const double2 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
-        if (c0 + 64 < total) fetch(c0 + 64);                         // the next chunk's records are in flight during this one
+        if (c0 + 64 * NW < total) fetch(c0 + 64 * NW);               // the next chunk's records are in flight during this one
         const int4 hd = *reinterpret_cast<const int4 *>(&q0);
         const int o[3] = {hd.x, hd.y, hd.z};
         int rel[3];
@@ -287,7 +296,7 @@ k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ 
         }
         unsigned long long mask = __ballot(hit);
         if (mask == 0ull) continue;
-        __syncthreads();                                              // the previous chunk's tables are no longer read
+        wave_sync();                                                  // the previous chunk's tables are no longer read
         {   // the survivors' separable weights, axis by axis (six exponentials per particle), parked in LDS as they come
             const double c = G.expfac;
             const double Y0 = G.hy * q1.y, Z0 = G.hz * q2.x, u = G.hx * q1.x + gc.s * Y0;
@@ -318,7 +327,7 @@ k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ 
         // byte offsets of the particle's table rows relative to lane 0's view: row (lx + 1 - ox) of column `lane`
         const int metax = rel[0] * (LS * 8) - lane * 8, metay = rel[1] * (LS * 8) - lane * 8;
         const int kzl = hit ? rel[2] + P - 1 : -1;                    // z offset class of this lane's particle
-        __syncthreads();
+        wave_sync();
         // One loop per z offset class: inside it the z extent of the overlap is a compile-time range, and the accumulators are
         // loop-carried values updated in place (a switch inside one loop made the compiler copy all TZ x 3 accumulators at the
         // merge of its cases: ~90 v_mov_b64 per particle).
@@ -356,6 +365,21 @@ k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ 
                 });
             }
         });
+    }
+    if (NW > 1) {
+        __syncthreads();                                              // every wave is through its chunks: the tables are dead
+        if (wv > 0)
+            static_for<TZ * 3>([&](auto ec) __attribute__((always_inline)) {
+                constexpr int e = decltype(ec)::value;
+                s_tab[((wv - 1) * TZ * 3 + e) * 64 + lane] = acc[e / 3][e % 3];
+            });
+        __syncthreads();
+        if (wv > 0) return;
+        for (int w = 0; w < NW - 1; ++w)
+            static_for<TZ * 3>([&](auto ec) __attribute__((always_inline)) {
+                constexpr int e = decltype(ec)::value;
+                acc[e / 3][e % 3] += s_tab[(w * TZ * 3 + e) * 64 + lane];
+            });
     }
     if (lx < ext[0] && ly < ext[1]) {
         const size_t base = ((size_t)(t0[0] - G.x0 + G.hl + lx) * G.Ny + (t0[1] + ly)) * G.Nz + t0[2];
@@ -430,20 +454,24 @@ bool farfield_fast_path(const DGrid &G) {
 bool spread_needs_zero(const DGrid &G) { return !farfield_fast_path(G); }
 size_t farfield_bins(const DGrid &G) { return (size_t)bins_of(G.Nx) * bins_of(G.Ny) * bins_of(G.Nz); }
 
-template <int P, int TZ>
+template <int P, int TZ, int NW>
 static void launch_spread_pt(const FarRec *rec, FarBins fb, double *gx, double *gy, double *gz, const DGrid &G, const GaussConsts &gc,
                              hipStream_t s) {
     const int ntx = (G.nxl + 7) / 8, nty = (G.Ny + 7) / 8, ntz = (G.Nz + TZ - 1) / TZ;
-    const dim3 g(ntx * nty * ntz), b(64);
+    const dim3 g(ntx * nty * ntz), b(64 * NW);
     const FastDiv dz = fast_div(ntz), dy = fast_div(nty);
-    if (gc.s != 0.0) hipLaunchKernelGGL((k_spread_tiles<P, TZ, true>), g, b, 0, s, rec, fb, gx, gy, gz, G, gc, dz, dy);
-    else hipLaunchKernelGGL((k_spread_tiles<P, TZ, false>), g, b, 0, s, rec, fb, gx, gy, gz, G, gc, dz, dy);
+    if (gc.s != 0.0) hipLaunchKernelGGL((k_spread_tiles<P, TZ, true, NW>), g, b, 0, s, rec, fb, gx, gy, gz, G, gc, dz, dy);
+    else hipLaunchKernelGGL((k_spread_tiles<P, TZ, false, NW>), g, b, 0, s, rec, fb, gx, gy, gz, G, gc, dz, dy);
 }
+constexpr int SPREAD_NW = 4;   // waves per block on small grids
 template <int P>
 static void launch_spread_p(const FarRec *rec, FarBins fb, double *gx, double *gy, double *gz, const DGrid &G, const GaussConsts &gc,
                             hipStream_t s) {
-    if (spread_tz(G) == 16) launch_spread_pt<P, 16>(rec, fb, gx, gy, gz, G, gc, s);
-    else launch_spread_pt<P, 8>(rec, fb, gx, gy, gz, G, gc, s);
+    static const int nw_env = getenv("PSE_SPREAD_NW") ? atoi(getenv("PSE_SPREAD_NW")) : 0;
+    const long blocks8 = (long)((G.nxl + 7) / 8) * ((G.Ny + 7) / 8) * ((G.Nz + 7) / 8);
+    if (spread_tz(G) == 16) launch_spread_pt<P, 16, 1>(rec, fb, gx, gy, gz, G, gc, s);
+    else if (P <= 8 && (nw_env ? nw_env > 1 : blocks8 < 1024)) launch_spread_pt<P, 8, SPREAD_NW>(rec, fb, gx, gy, gz, G, gc, s);   // fewer blocks than SIMDs
+    else launch_spread_pt<P, 8, 1>(rec, fb, gx, gy, gz, G, gc, s);
 }
 
 void launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, double *gx, double *gy, double *gz, DGrid G,

@@ -959,13 +959,75 @@ __device__ __forceinline__ void lds_fft256(double2 *__restrict__ d, const double
     __syncthreads();
 }
 
-template <int KB, int NTH, int WPS>
+// 512 = 16 x 16 x 2: the same two radix-16 passes (32 butterflies per column, twiddle W_256^{(j mod 16) r} in the second, whose
+// results land at (j & 16) 16 + (j & 15) + 16 r: not the points the lane read, hence the extra barrier) and a radix-2 pass
+// with W_512^j in place.  tw[m] = exp(-2 pi i m / 512).
+constexpr int CS512 = 512 + 32 + 2;
+template <int NCOL, int NTH, bool INVERSE>
+__device__ __forceinline__ void lds_fft512(double2 *__restrict__ d, const double2 *__restrict__ twiddle) {
+    const int tid = threadIdx.x;
+    constexpr int NB = NCOL * 32;
+    static_assert(NB <= NTH, "one radix-16 butterfly per lane");
+    const bool act = tid < NB;
+    const int col = tid >> 5, j = tid & 31, k = j & 15;
+    double2 twa[4], twb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { twa[r] = twiddle[(8 * k * r) & 511]; twb[r] = twiddle[(2 * k * r) & 511]; }
+    double2 *c = d + col * CS512;
+    double2 x[16];
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = c[pad16(j + 32 * r)];
+        dft16<INVERSE>(x);
+    }
+    __syncthreads();
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[pad16(16 * j + r)] = x[DFT16_AT(r)];
+    }
+    __syncthreads();
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = c[pad16(j + 32 * r)];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) {
+            const int ra = r >> 2, rb = r & 3;
+            double2 w = twb[rb];
+            if (ra && rb) w = make_double2(w.x * twa[ra].x - w.y * twa[ra].y, w.x * twa[ra].y + w.y * twa[ra].x);
+            else if (ra) w = twa[ra];
+            if (INVERSE) w.y = -w.y;
+            const double2 v = x[r];
+            x[r] = make_double2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+        }
+        dft16<INVERSE>(x);
+    }
+    __syncthreads();
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[pad16((j & 16) * 16 + k + 16 * r)] = x[DFT16_AT(r)];
+    }
+    __syncthreads();
+    for (int e = tid; e < NCOL * 256; e += NTH) {
+        double2 *c2 = d + (e >> 8) * CS512;
+        const int j2 = e & 255;
+        double2 w = twiddle[j2];
+        if (INVERSE) w.y = -w.y;
+        const double2 a = c2[pad16(j2)], b0 = c2[pad16(j2 + 256)];
+        const double2 b = make_double2(b0.x * w.x - b0.y * w.y, b0.x * w.y + b0.y * w.x);
+        c2[pad16(j2)] = make_double2(a.x + b.x, a.y + b.y);
+        c2[pad16(j2 + 256)] = make_double2(a.x - b.x, a.y - b.y);
+    }
+    __syncthreads();
+}
+
+template <int N, int KB, int NTH, int WPS>
 __global__ void __launch_bounds__(NTH, WPS)
 k_xfft_scale256(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ Z, DGrid G, DBox box, ScaleArgs a,
                 const double2 *__restrict__ twiddle) {
-    constexpr int N = 256, NCOL = 3 * KB;
+    static_assert(N == 256 || N == 512, "two radix-16 passes (+ one radix-2 pass)");
+    constexpr int NCOL = 3 * KB, CS = N == 256 ? CS256 : CS512;   // the column stride of this N
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double2 *d = reinterpret_cast<double2 *>(smem_raw);      // [3][KB][CS256]
+    double2 *d = reinterpret_cast<double2 *>(smem_raw);      // [3][KB][CS]
     const int tid = threadIdx.x;
     const int nkb = (G.Nzh + KB - 1) / KB;
     const int rows = a.transposed ? a.nyl : G.Ny;
@@ -986,40 +1048,40 @@ k_xfft_scale256(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__res
 #pragma unroll
         for (int it = 0; it < PER; ++it) {
             const int e = tid + it * NTH, c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
-            if (e < 3 * N * KB) d[(c * KB + q) * CS256 + pad16(x)] = v[it];
+            if (e < 3 * N * KB) d[(c * KB + q) * CS + pad16(x)] = v[it];
         }
     }
     __syncthreads();
-    lds_fft256<NCOL, NTH, false>(d, twiddle);
+    if constexpr (N == 256) lds_fft256<NCOL, NTH, false>(d, twiddle); else lds_fft512<NCOL, NTH, false>(d, twiddle);
     for (int e = tid; e < N * KB; e += NTH) {
         const int x = e / KB, q = e - x * KB;
         if (q < kv) {
             const int px = pad16(x);
-            const double2 f[3] = {d[q * CS256 + px], d[(KB + q) * CS256 + px], d[(2 * KB + q) * CS256 + px]};
+            const double2 f[3] = {d[q * CS + px], d[(KB + q) * CS + px], d[(2 * KB + q) * CS + px]};
             double2 out[3];
             scale_node(x, j, k0 + q, f, G, box, a, out);
-            d[q * CS256 + px] = out[0]; d[(KB + q) * CS256 + px] = out[1]; d[(2 * KB + q) * CS256 + px] = out[2];
+            d[q * CS + px] = out[0]; d[(KB + q) * CS + px] = out[1]; d[(2 * KB + q) * CS + px] = out[2];
         }
     }
     __syncthreads();
-    lds_fft256<NCOL, NTH, true>(d, twiddle);
+    if constexpr (N == 256) lds_fft256<NCOL, NTH, true>(d, twiddle); else lds_fft512<NCOL, NTH, true>(d, twiddle);
     for (int e = tid; e < 3 * N * KB; e += NTH) {
         const int c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
-        if (q < kv) comp[c][(size_t)x * xstride + base + q] = d[(c * KB + q) * CS256 + pad16(x)];
+        if (q < kv) comp[c][(size_t)x * xstride + base + q] = d[(c * KB + q) * CS + pad16(x)];
     }
 }
 
-template <int KB, int NTH, int WPS>
+template <int KB, int NTH, int WPS, int N = 256>
 static void launch_xfft256(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s) {
-    const size_t lds = (size_t)(3 * KB * CS256) * sizeof(double2);
+    const size_t lds = (size_t)(3 * KB * (N == 256 ? CS256 : CS512)) * sizeof(double2);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xfft_scale256<KB, NTH, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xfft_scale256<N, KB, NTH, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int nkb = (G.Nzh + KB - 1) / KB;
     const int rows = a.transposed ? a.nyl : G.Ny;
-    hipLaunchKernelGGL((k_xfft_scale256<KB, NTH, WPS>), dim3(rows * nkb), dim3(NTH), lds, s, X, Y, Z, G, box, a, tw);
+    hipLaunchKernelGGL((k_xfft_scale256<N, KB, NTH, WPS>), dim3(rows * nkb), dim3(NTH), lds, s, X, Y, Z, G, box, a, tw);
 }
 
 // ---- any Nx = 2^a 3^b 5^c (the grids the reference's rule produces, PSEv1/Stokes.cc:147-199) ---------------------------------
@@ -1215,7 +1277,13 @@ void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, Sc
             else launch_xfft256<4, 256, 2>(X, Y, Z, G, box, a, tw, s);   // two radix-16 passes in registers
             break;
         }
-        default: launch_xfft_t<9, 4, 1024>(X, Y, Z, G, box, a, tw, s); break;
+        default: {   // 512
+            static const int cfg = getenv("PSE_XFUSE_CFG") ? atoi(getenv("PSE_XFUSE_CFG")) : 0;
+            if (cfg == 1) launch_xfft_t<9, 4, 1024>(X, Y, Z, G, box, a, tw, s);
+            else if (cfg == 2) launch_xfft256<4, 384, 1, 512>(X, Y, Z, G, box, a, tw, s);
+            else launch_xfft256<2, 256, 1, 512>(X, Y, Z, G, box, a, tw, s);   // radix 16, 16, 2; two kz columns: three workgroups per CU (3.3 ms at 512^3; four columns, one workgroup: 3.8; radix 4/2 in LDS: 5.2)
+            break;
+        }
     }
 }
 

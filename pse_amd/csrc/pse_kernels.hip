@@ -619,7 +619,7 @@ void launch_eval_fg(const double *r, int n, const double *coef, double *f, doubl
 // (PSEv1/Mobility.cu:264-299) and gpu_stokes_BrownianGridGenerate_kernel (PSEv1/Brownian.cu:153-345) on the
 // real-to-complex half spectrum.  Wave vectors are computed in registers (no gridk array).
 struct KOp {
-    double kx, ky, kz, k2, B, c;  // B = w sinc^2 (deterministic), c = noise_fac sqrt(w) sinc
+    double kx, ky, kz, ik2, B, c;  // 1 / k^2, B = w sinc^2 (deterministic), c = noise_fac sqrt(w) sinc
 };
 __device__ __forceinline__ KOp make_kop(int i, int j, int k, const DGrid &G, const DBox &box, double xi, double eta,
                                         double noise_fac) {
@@ -630,20 +630,22 @@ __device__ __forceinline__ KOp make_kop(int i, int j, int k, const DGrid &G, con
     o.kx = TWO_PI * ki * box.iLx;
     o.ky = TWO_PI * (kj * box.iLy - box.xy * ki * box.iLx);   // sheared reciprocal lattice, Helper.cu:308
     o.kz = TWO_PI * kk * box.iLz;
-    o.k2 = o.kx * o.kx + o.ky * o.ky + o.kz * o.kz;
-    const double q = o.k2 / (4.0 * xi * xi);
-    const double ng = (double)G.Nx * (double)G.Ny * (double)G.Nz;
-    const double w = 6.0 * M_PI * (1.0 + q) * exp_neg(-(1.0 - eta) * q) / (o.k2 * ng);   // Helper.cu:326
-    const double kn = sqrt(o.k2);
-    const double sinc = sin(kn) / kn;                                                 // Mobility.cu:290 (a = 1)
+    // one reciprocal square root serves 1 / k^2, |k| and 1 / |k|; the loop-invariant reciprocals are hoisted by the compiler
+    const double k2 = o.kx * o.kx + o.ky * o.ky + o.kz * o.kz;
+    const double rk = rsqrt(k2), kn = k2 * rk;
+    o.ik2 = rk * rk;
+    const double q = k2 * (1.0 / (4.0 * xi * xi));
+    const double ing = 1.0 / ((double)G.Nx * (double)G.Ny * (double)G.Nz);
+    const double w = 6.0 * M_PI * (1.0 + q) * exp_neg(-(1.0 - eta) * q) * (o.ik2 * ing);   // Helper.cu:326
+    const double sinc = sin_lean(kn) * rk;                                            // Mobility.cu:290 (a = 1)
     o.B = w * sinc * sinc;
-    o.c = noise_fac * sqrt(w) * sinc;                                                 // Brownian.cu:197,274-276
+    o.c = noise_fac != 0.0 ? noise_fac * sqrt(w) * sinc : 0.0;                        // Brownian.cu:197,274-276
     return o;
 }
 // out += B (I - kk) f + c (I - kk) psi    (complex 3-vectors)
 __device__ __forceinline__ void apply_kop(const KOp &o, const double2 f[3], const double2 psi[3], bool noise,
                                           double scale, double2 out[3]) {
-    const double ik2 = 1.0 / o.k2;
+    const double ik2 = o.ik2;
     double2 v[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {

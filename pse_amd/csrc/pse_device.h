@@ -140,11 +140,10 @@ __device__ __forceinline__ double sin_lean(double x) {
 // Returns f and (g - f)/r^2.
 template <int STRIDE = 2 * RS_NCOEF>   // doubles per interval (a copy in LDS pads it to 21: intervals then start on different banks)
 __device__ __forceinline__ void eval_fg(double r2, const double *__restrict__ coef, double &f, double &gmf_r2) {
-    const double r = sqrt(r2);
-    const double ir2 = 1.0 / r2;
+    const double ir = rsqrt(r2), r = r2 * ir, ir2 = ir * ir;   // one reciprocal square root instead of a square root and a division
     double f0, g0;
     if (r > 2.0) {
-        const double ir = r * ir2, ir3 = ir * ir2;
+        const double ir3 = ir * ir2;
         f0 = 0.75 * ir + 0.5 * ir3;
         g0 = 1.5 * ir - ir3;
     } else {

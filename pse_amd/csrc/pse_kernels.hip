@@ -170,8 +170,10 @@ constexpr unsigned JMASK = (1u << 27) - 1;
 // twelve narrow loads of the former (entry | f | h) planes cost twice what these five do.
 __device__ __forceinline__ void nb_store(char *rec, int slot, int lane, unsigned e, double f, double h) {
     char *r = rec + (size_t)(slot >> 2) * (4 * NB_REC);
-    ((unsigned *)r)[lane * 4 + (slot & 3)] = e;
-    ((double2 *)(r + 1024))[(slot & 3) * 64 + lane] = make_double2(f, h);
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(e, (unsigned *)r + lane * 4 + (slot & 3));     // written once, read by later kernels
+    d2v fh; fh.x = f; fh.y = h;
+    __builtin_nontemporal_store(fh, (d2v *)(r + 1024) + (slot & 3) * 64 + lane);
 }
 
 __device__ __forceinline__ void vl_store(char *vrec, int slot, int lane, unsigned j) {
@@ -437,12 +439,15 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
             static_assert(UNROLL == 4, "one list group per iteration");
             for (int s0 = 0; s0 < cnt; s0 += UNROLL) {
                 const char *grp = rec + (size_t)(s0 >> 2) * (4 * NB_REC);
-                const uint4 e4 = ((const uint4 *)grp)[lane];
+                // streamed once: non-temporal, so the list does not evict the neighbour records the gathers reuse from L1
+                typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                typedef double d2v __attribute__((ext_vector_type(2)));
+                const u4v e4 = __builtin_nontemporal_load((const u4v *)grp + lane);
                 unsigned e[UNROLL] = {e4.x, e4.y, e4.z, e4.w};
                 double f[UNROLL], h[UNROLL];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
-                    const double2 fh = ((const double2 *)(grp + 1024))[u * 64 + lane];
+                    const d2v fh = __builtin_nontemporal_load((const d2v *)(grp + 1024) + u * 64 + lane);
                     f[u] = fh.x; h[u] = fh.y;
                     if (u && s0 + u >= cnt) e[u] = e[0];          // slots past the row's count were never written
                 }

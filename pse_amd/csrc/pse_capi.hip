@@ -180,7 +180,14 @@ static int cells_for(const Box &box, double rc, double gamma, int n_slabs, DCell
         return fail(PSE_ERR_INVALID, "real-space cutoff %.4f exceeds half the box width (%.4f, %.4f, %.4f at tilt %.3f): "
                     "the minimum-image near field needs rcut <= L/2; increase xi", rc, wx, wy, wz, gamma);
     auto n = [&](double w) { int c = (int)std::floor(w / rc); if (c < 3) c = 1; if (c > 1024) c = 1024; return c; };
-    out = DCells{n(wx), n(wy), n(wz)};
+    out = DCells{n(wx), n(wy), n(wz), 0, 1};
+    // PSE_CELL_BZ=b: blocks of b cells along z in the storage order (pse_device.h).  Off by default: measured at the metric point,
+    // blocks of 3..8 take the pair-list mat-vec from 0.187 to 0.175 ms (a wave's gathers come from ~95 cells instead of ~130) but
+    // the cell pass from 0.63 to 0.68 ms (lanes of a wave no longer walk the same z lines) -- a wash per step.
+    static const int bz_env = getenv("PSE_CELL_BZ") ? atoi(getenv("PSE_CELL_BZ")) : 0;
+    static const bool tiles = getenv("PSE_NEAR_BLOCKS") && atoi(getenv("PSE_NEAR_BLOCKS")) > 0;   // the LDS-tile near field indexes cells itself
+    out.bz = (bz_env > 0 && !tiles && out.nz >= 2 * bz_env) ? bz_env : out.nz;
+    out.nzb = (out.nz + out.bz - 1) / out.bz;
     if (n_slabs > 1) {
         // cell slabs coincide with grid slabs: every rank owns ncx/G whole cell layers = one contiguous row range
         const int c = (int)std::floor(wx / rc) / n_slabs * n_slabs;
@@ -502,7 +509,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     {
         const double rc = d.rcut;
         auto cnt = [&](double w) { int c2 = (int)std::floor(w / rc); if (c2 < 3) c2 = 1; if (c2 > 1024) c2 = 1024; return (size_t)c2; };
-        h->n_cells_alloc = cnt(h->box.Lx) * cnt(h->box.Ly) * cnt(h->box.Lz);
+        h->n_cells_alloc = cnt(h->box.Lx) * cnt(h->box.Ly) * (cnt(h->box.Lz) + 16);   // + the padding of the last z block
     }
     TRY(dmalloc(h, &h->cell_off, h->n_cells_alloc + 1)); TRY(dmalloc(h, &h->cell_cnt, h->n_cells_alloc + 1));
     h->sort_tmp_bytes = cell_sort_temp_bytes(h->n_cells_alloc);
@@ -621,7 +628,7 @@ extern "C" int pse_set_box(pse_handle *h, double Lx, double Ly, double Lz, doubl
     const double gamma = std::max(std::fabs(xy), h->par.max_strain);
     DCells nc;
     TRY(cells_for(nb, near_radius(h), gamma, h->n_slabs, nc));
-    if ((size_t)nc.nx * nc.ny * nc.nz > h->n_cells_alloc)
+    if ((size_t)cells_total(nc) > h->n_cells_alloc)
         return fail(PSE_ERR_INVALID, "box grew beyond the cell-list capacity sized at creation");
     h->box = nb;
     h->nc = nc;
@@ -901,7 +908,7 @@ static void row_range(const pse_handle *h, int N, int &lo, int &hi) {
 static int slab_bounds_issue(pse_handle *h) {
     const int G = h->n_slabs;
     if (G == 1) return 0;
-    const int layer = h->nc.ny * h->nc.nz, per = h->nc.nx / G;
+    const int layer = h->nc.nzb * h->nc.ny * h->nc.bz, per = h->nc.nx / G;   // storage cells of one x layer
     std::vector<int> idx(3 * G + 1);
     for (int r = 0; r <= G; ++r) idx[r] = r * per * layer;
     for (int r = 0; r < G; ++r) { idx[G + 1 + r] = (r * per + 1) * layer; idx[2 * G + 1 + r] = ((r + 1) * per - 1) * layer; }
@@ -981,7 +988,7 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
             h->info.ncell_x = nc.nx; h->info.ncell_y = nc.ny; h->info.ncell_z = nc.nz;
         }
     }
-    const int ncell = h->nc.nx * h->nc.ny * h->nc.nz;
+    const int ncell = cells_total(h->nc);
     cell_sort(pos, group, N, h->dbox, h->nc, h->keys, h->vals, h->keys_s, h->cell_cnt, ncell, h->sort_tmp, h->sort_tmp_bytes,
               h->cell_off, h->perm, h->stream);
     launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream);

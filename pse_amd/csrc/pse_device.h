@@ -25,9 +25,17 @@ struct DGrid {
     double prefac, expfac; // (2 xi^2/(pi eta))^{3/2}, 2 xi^2/eta   (PSEv1/Brownian.cu:828-829)
 };
 
+// Storage order of the cells: x slowest, then blocks of bz cells along z, then y, then z inside the block --
+// slot = ((cx nzb + cz / bz) ny + cy) bz + cz % bz.  With bz = nz (the default) this is the plain (x, y, z) order.  Blocks
+// (PSE_CELL_BZ) make 64 consecutive particles (a wavefront's rows) a squat 1 x 2 x 6-cell brick instead of a 12-cell needle
+// along z, so the neighbour records a wave gathers come from ~95 cells instead of ~130; x stays slowest, so a rank's cell
+// slab is still one contiguous row range.  The last block of a line is padded with empty cells when bz does not divide nz.
 struct DCells {
     int nx, ny, nz;        // cells per dimension (1 or >= 3)
+    int bz, nzb;           // block height along z and blocks per z line (nzb = ceil(nz / bz))
 };
+__host__ __device__ inline int cells_total(const DCells &nc) { return nc.nx * nc.nzb * nc.ny * nc.bz; }
+__host__ __device__ inline int cell_slot(const DCells &nc, int cx, int cy, int zb, int zi) { return ((cx * nc.nzb + zb) * nc.ny + cy) * nc.bz + zi; }
 
 // fractional coordinates in [0,1): f = ((x - xy*y)/Lx + 1/2, y/Ly + 1/2, z/Lz + 1/2)
 __device__ __forceinline__ void frac_coords(const DBox &b, double x, double y, double z, double &fx, double &fy, double &fz) {
@@ -180,24 +188,36 @@ template <class F>
 __device__ __forceinline__ void for_each_run(const DCells &nc, const int *__restrict__ cell_off, int cx, int cy, int cz,
                                              F &&body) {
     const int rx = nc.nx > 1 ? 1 : 0, ry = nc.ny > 1 ? 1 : 0;
+    const int zb0 = cz / nc.bz, zi0 = cz - zb0 * nc.bz;
     for (int ox = -rx; ox <= rx; ++ox) {
         int ax = cx + ox, wx = 0;
         if (ax < 0) { ax += nc.nx; wx = -1; } else if (ax >= nc.nx) { ax -= nc.nx; wx = 1; }
         for (int oy = -ry; oy <= ry; ++oy) {
             int ay = cy + oy, wy = 0;
             if (ay < 0) { ay += nc.ny; wy = -1; } else if (ay >= nc.ny) { ay -= nc.ny; wy = 1; }
-            const int base = (ax * nc.ny + ay) * nc.nz;
             const unsigned cxy = (unsigned)((wx + 1) * 9 + (wy + 1) * 3);
             if (nc.nz == 1) {
-                body(cell_off[base], cell_off[base + 1], cxy + 1u);
-            } else if (cz >= 1 && cz + 1 < nc.nz) {
-                body(cell_off[base + cz - 1], cell_off[base + cz + 2], cxy + 1u);   // three z cells, one run
-            } else {
-                for (int oz = -1; oz <= 1; ++oz) {
-                    int az = cz + oz, wz = 0;
-                    if (az < 0) { az += nc.nz; wz = -1; } else if (az >= nc.nz) { az -= nc.nz; wz = 1; }
-                    body(cell_off[base + az], cell_off[base + az + 1], cxy + (unsigned)(wz + 1));
-                }
+                const int c = cell_slot(nc, ax, ay, 0, 0);
+                body(cell_off[c], cell_off[c + 1], cxy + 1u);
+                continue;
+            }
+            // the three z cells, as maximal runs of consecutive slots with one image code (same block, no wrap in between)
+            int s[3]; unsigned code[3];
+#pragma unroll
+            for (int oz = -1; oz <= 1; ++oz) {
+                int az = cz + oz, wz = 0;
+                if (az < 0) { az += nc.nz; wz = -1; } else if (az >= nc.nz) { az -= nc.nz; wz = 1; }
+                int zb = zb0, zi = zi0 + oz;                           // block and offset of az, from those of cz
+                if (wz != 0 || zi < 0 || zi >= nc.bz) { zb = az / nc.bz; zi = az - zb * nc.bz; }
+                s[oz + 1] = cell_slot(nc, ax, ay, zb, zi);
+                code[oz + 1] = cxy + (unsigned)(wz + 1);
+            }
+            int k = 0;
+            while (k < 3) {
+                int e = k;
+                while (e + 1 < 3 && s[e + 1] == s[e] + 1 && code[e + 1] == code[k]) ++e;
+                body(cell_off[s[k]], cell_off[s[e] + 1], code[k]);
+                k = e + 1;
             }
         }
     }

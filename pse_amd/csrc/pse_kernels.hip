@@ -48,7 +48,8 @@ __global__ void k_cell_keys(const double4 *__restrict__ pos, const unsigned *__r
     double fx, fy, fz;
     frac_coords(box, p.x, p.y, p.z, fx, fy, fz);
     const int cx = cell_coord(fx, nc.nx), cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz);
-    const unsigned key = (unsigned)((cx * nc.ny + cy) * nc.nz + cz);
+    const int zb = cz / nc.bz;
+    const unsigned key = (unsigned)cell_slot(nc, cx, cy, zb, cz - zb * nc.bz);
     keys[g] = key;
     rank[g] = (unsigned)atomicAdd(&cnt[key], 1);
 }

@@ -224,4 +224,15 @@ __device__ __forceinline__ void for_each_run(const DCells &nc, const int *__rest
 }
 
 
+// slot and image code of the z neighbour cz + oz of cell (ax, ay, cz); zb0, zi0: block and offset of cz
+__device__ __forceinline__ void z_neighbour_slot(const DCells &nc, int ax, int ay, int cz, int zb0, int zi0, int oz, unsigned cxy,
+                                                 int &slot, unsigned &code) {
+    int az = cz + oz, wz = 0;
+    if (az < 0) { az += nc.nz; wz = -1; } else if (az >= nc.nz) { az -= nc.nz; wz = 1; }
+    int zb = zb0, zi = zi0 + oz;
+    if (wz != 0 || zi < 0 || zi >= nc.bz) { zb = az / nc.bz; zi = az - zb * nc.bz; }
+    slot = cell_slot(nc, ax, ay, zb, zi);
+    code = cxy + (unsigned)(wz + 1);
+}
+
 }  // namespace pse

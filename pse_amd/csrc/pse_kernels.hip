@@ -280,10 +280,8 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
     // trips at three waves per SIMD); the drain repeats the test in double precision, so the neighbour set is exactly
     // the fp64 one.
     constexpr int SU = 8;
-    for_each_run(nc, cell_off, cx, cy, cz, [&](int jb, int je, unsigned code) {
-        double sx, sy, sz;
-        image_shift(code, box, sx, sy, sz);
-        if (!shift_only) {   // fewer than three cells along some axis: minimum-image search in double precision
+    if (!shift_only) {   // fewer than three cells along some axis: minimum-image search in double precision
+        for_each_run(nc, cell_off, cx, cy, cz, [&](int jb, int je, unsigned code) {
             for (int j = jb; j < je; ++j) {
                 const double4 pj = pos_s[j];
                 double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -295,27 +293,79 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
                 }
                 if (__any(qn > QCAP - SU)) drain();
             }
-            return;
-        }
-        const float qx = (float)(pi.x - sx), qy = (float)(pi.y - sy), qz = (float)(pi.z - sz);
-        for (int j0 = jb; j0 < je; j0 += SU) {
+        });
+    } else {
+        // Every lane walks ITS runs at its own pace, SU candidates of one run per round (the bounds of the run after the current
+        // one are already loaded when the current one ends).  Stepping through "run k of all 64 lanes" together cost the longest
+        // run k of the wave nine times over: 288 load instructions per wave for 137 candidates per lane; this way ~200.
+        // the runs of this lane, one at a time (the order of for_each_run): up to three per (x, y) column.  Written out in place --
+        // one site, no closure: as a lambda called from two places the iterator state went to scratch memory.
+        const int zb0 = cz / nc.bz, zi0 = cz - zb0 * nc.bz;
+        int ox = -1, oy = -2, rk = 0, nparts = 0;
+        int f0 = 0, l0 = 0, f1 = 0, l1 = 0, f2 = 0, l2 = 0;
+        unsigned c0 = 13u, c1 = 13u, c2 = 13u;
+        int j = 0, je = 0, jn = 0, jen = 0;
+        unsigned code = 13u, code_n = 13u;
+        float qx = 0.f, qy = 0.f, qz = 0.f;
+        bool have_n = true;
+        int pend = 2;   // first round: prime the prefetch, then make the first run current
+        while (true) {
+            do {
+                if (j >= je && have_n) {   // the current run is used up: the prefetched one becomes current (an empty one is skipped next round)
+                    j = jn; je = jen; code = code_n;
+                    double sx, sy, sz;
+                    image_shift(code, box, sx, sy, sz);
+                    qx = (float)(pi.x - sx); qy = (float)(pi.y - sy); qz = (float)(pi.z - sz);
+                    if (rk >= nparts) {    // next (x, y) column
+                        if (++oy > 1) { oy = -1; ++ox; }
+                        if (ox > 1) have_n = false;
+                        else {
+                            int ax = cx + ox, wx = 0, ay = cy + oy, wy = 0;
+                            if (ax < 0) { ax += nc.nx; wx = -1; } else if (ax >= nc.nx) { ax -= nc.nx; wx = 1; }
+                            if (ay < 0) { ay += nc.ny; wy = -1; } else if (ay >= nc.ny) { ay -= nc.ny; wy = 1; }
+                            const unsigned cxy = (unsigned)((wx + 1) * 9 + (wy + 1) * 3);
+                            int s0, s1, s2; unsigned d0, d1, d2;
+                            z_neighbour_slot(nc, ax, ay, cz, zb0, zi0, -1, cxy, s0, d0);
+                            z_neighbour_slot(nc, ax, ay, cz, zb0, zi0, 0, cxy, s1, d1);
+                            z_neighbour_slot(nc, ax, ay, cz, zb0, zi0, 1, cxy, s2, d2);
+                            const bool m01 = s1 == s0 + 1 && d1 == d0, m12 = s2 == s1 + 1 && d2 == d1;
+                            f0 = s0; c0 = d0;
+                            if (m01 && m12) { l0 = s2; nparts = 1; }
+                            else if (m01) { l0 = s1; f1 = l1 = s2; c1 = d2; nparts = 2; }
+                            else if (m12) { l0 = s0; f1 = s1; l1 = s2; c1 = d1; nparts = 2; }
+                            else { l0 = s0; f1 = l1 = s1; c1 = d1; f2 = l2 = s2; c2 = d2; nparts = 3; }
+                            rk = 0;
+                        }
+                    }
+                    if (have_n) {
+                        const int sa = rk == 0 ? f0 : (rk == 1 ? f1 : f2), sb = (rk == 0 ? l0 : (rk == 1 ? l1 : l2)) + 1;
+                        code_n = rk == 0 ? c0 : (rk == 1 ? c1 : c2);
+                        ++rk;
+                        jn = cell_off[sa]; jen = cell_off[sb];   // consumed at the next switch
+                    }
+                }
+            } while (--pend > 0);
+            pend = 1;
+            const bool work = j < je;
+            if (!__any(work || have_n)) break;
             float4 pj[SU];
 #pragma unroll
-            for (int u = 0; u < SU; ++u) pj[u] = posf_s[min(j0 + u, je - 1)];   // independent loads in flight
+            for (int u = 0; u < SU; ++u) pj[u] = posf_s[work ? min(j + u, je - 1) : i];   // independent loads in flight
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
-                const int j = j0 + u;
+                const int jj = j + u;
                 const float dx = qx - pj[u].x, dy = qy - pj[u].y, dz = qz - pj[u].z;
                 const float r2 = dx * dx + dy * dy + dz * dz;
-                if (j < je && r2 < rcut2_pre && j != i) {
-                    queue[qn * TPB + tid] = (unsigned)j | (code << 27);
+                if (jj < je && r2 < rcut2_pre && jj != i) {
+                    queue[qn * TPB + tid] = (unsigned)jj | (code << 27);
                     ++qn;
                 }
             }
+            j += SU;
             // drain together: a lane-private "queue full" branch would serialise the wave once per lane
             if (__any(qn > QCAP - SU)) drain();
         }
-    });
+    }
     drain();
     out_s[i] = make_double4(ux, uy, uz, 0.0);
     if (TWO) out2_s[i] = make_double4(wx, wy, wz, 0.0);

@@ -960,7 +960,6 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
                        h->pos_build, 0.25 * h->skin * h->skin, h->vl.flags);
         HIPCHK(hipMemcpyAsync(h->flags_host, h->vl.flags, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        if (getenv("PSE_DEBUG_NLIST")) fprintf(stderr, "nlist check: moved %d overflow %d\n", h->flags_host[0], h->flags_host[1]);
         if (h->flags_host[0] == 0 && h->flags_host[1] == 0) {
             h->vl_use = true;
             ++h->nlist_reuses;

@@ -169,12 +169,17 @@ constexpr unsigned JMASK = (1u << 27) - 1;
 // group with one 16-byte load of the four entries and four 16-byte loads of (f, h): a coalesced dword or dwordx2 load
 // occupies the texture addresser as long as a dwordx4 load (tools/microbench/stream_widths: 8 / 16 / 16 clk), so the
 // twelve narrow loads of the former (entry | f | h) planes cost twice what these five do.
+template <bool STREAM = false>
 __device__ __forceinline__ void nb_store(char *rec, int slot, int lane, unsigned e, double f, double h) {
     char *r = rec + (size_t)(slot >> 2) * (4 * NB_REC);
-    typedef double d2v __attribute__((ext_vector_type(2)));
-    __builtin_nontemporal_store(e, (unsigned *)r + lane * 4 + (slot & 3));     // written once, read by later kernels
-    d2v fh; fh.x = f; fh.y = h;
-    __builtin_nontemporal_store(fh, (d2v *)(r + 1024) + (slot & 3) * 64 + lane);
+    // plain stores: a lane's 4- and 16-byte pieces reach a line at different times and the L2 merges them; as non-temporal stores
+    // every piece went to memory on its own (WRITE_SIZE of the build pass 548 -> 805 MB)
+    ((unsigned *)r)[lane * 4 + (slot & 3)] = e;
+    if (STREAM) {   // the cell pass: most lanes of a wave append in the same drain round, the (f, h) of a round are whole lines
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        d2v fh; fh.x = f; fh.y = h;
+        __builtin_nontemporal_store(fh, (d2v *)(r + 1024) + (slot & 3) * 64 + lane);
+    } else ((double2 *)(r + 1024))[(slot & 3) * 64 + lane] = make_double2(f, h);
 }
 
 __device__ __forceinline__ void vl_store(char *vrec, int slot, int lane, unsigned j) {
@@ -194,7 +199,10 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
               double4 *__restrict__ out_s, int lo, int hi, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2,
               float rcut2_pre, double self, const double *__restrict__ coef_g, int ncoef, NbList nb,
               const double4 *__restrict__ vec2_s, double4 *__restrict__ out2_s, VerletList vl) {
-    __shared__ unsigned queue[QCAP * TPB];
+    // the pass that also writes the kept neighbour list queues every pair within rcut + r_buff (28 per row instead of 21): a deeper
+    // queue, or half of the waves would stop for an extra, poorly filled drain in the middle of the walk
+    constexpr int QC = VL ? 64 : QCAP;
+    __shared__ unsigned queue[QC * TPB];
     extern __shared__ double scoef[];
     const int tid = threadIdx.x;
     if (CL) {
@@ -263,11 +271,11 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
             if (LIST) {
                 // 20 B per pair: (slot | image code), f, h; the mat-vecs redo the subtraction from the positions
                 if (in0) {
-                    if (total < nb.cap) nb_store(rec, total, lane, e0, f0, h0);
+                    if (total < nb.cap) nb_store<true>(rec, total, lane, e0, f0, h0);
                     ++total;
                 }
                 if (in1) {
-                    if (total < nb.cap) nb_store(rec, total, lane, e1, f1, h1);
+                    if (total < nb.cap) nb_store<true>(rec, total, lane, e1, f1, h1);
                     ++total;
                 }
             }
@@ -291,7 +299,7 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
                     queue[qn * TPB + tid] = (unsigned)j | (code << 27);
                     ++qn;
                 }
-                if (__any(qn > QCAP - SU)) drain();
+                if (__any(qn > QC - SU)) drain();
             }
         });
     } else {
@@ -363,7 +371,7 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
             }
             j += SU;
             // drain together: a lane-private "queue full" branch would serialise the wave once per lane
-            if (__any(qn > QCAP - SU)) drain();
+            if (__any(qn > QC - SU)) drain();
         }
     }
     drain();

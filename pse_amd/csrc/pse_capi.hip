@@ -555,7 +555,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         }
     } else h->skin = h->skin_max = 0.0;
     TRY(dmalloc(h, &h->pos_s, n)); TRY(dmalloc(h, &h->posf_s, n));
-    if (h->n_slabs == 1 && !h->nb.blk.on) TRY(dmalloc(h, &h->pv, 3 * n));   // legacy pair-list mat-vec: packed gather records
+    if (!h->nb.blk.on) TRY(dmalloc(h, &h->pv, 3 * n));   // pair-list mat-vec: packed gather records (slab ranks too: the update packs the own and the ghost rows)
     TRY(dmalloc(h, &h->f_s, n)); TRY(dmalloc(h, &h->uw_s, n)); TRY(dmalloc(h, &h->ur_s, n));
     TRY(dmalloc(h, &h->ub_s, n)); TRY(dmalloc(h, &h->psi_s, n)); TRY(dmalloc(h, &h->w_s, n));
 

@@ -116,7 +116,10 @@ struct pse_handle {
     // A list that is never reused costs a wider cell grid and its own writes at every build: after two builds in a row whose
     // list failed its first distance check (particles diffuse more than r_buff / 2 per call) the list is suspended for a while
     // -- builds then run exactly as with r_buff = 0 -- and tried again, with the pause doubling while it keeps failing.
-    int vl_reused_since_build = 0, vl_misses = 0, vl_suspend_left = 0, vl_suspend_len = 32;
+    // Kept per kind of call -- [1]: integrating steps (pse_step), [0]: evaluations (pse_mobility, pse_brownian_velocity, ...): a
+    // time-stepping loop that outruns the skin must not switch the list off for evaluations repeated at fixed positions.
+    int vl_reused_since_build = 0, vl_misses[2] = {0, 0}, vl_suspend_left[2] = {0, 0}, vl_suspend_len[2] = {32, 32};
+    int vl_kind = 0;             // kind of the call being prepared
     bool pv_is_f = false;        // the vector half of pv mirrors f_s (as the permute wrote it)
     DCells blk_nc = {0, 0, 0};   // cell grid the near-field blocks were planned for
     size_t blk_list_elems = 0;   // allocated 2-byte entries of the block pair list
@@ -655,7 +658,7 @@ extern "C" int pse_set_neighbor_skin(pse_handle *h, double r_buff) {
                     r_buff, h->skin_max);
     h->skin = r_buff;
     h->vl_valid = false;
-    h->vl_misses = 0; h->vl_suspend_left = 0; h->vl_suspend_len = 32;
+    for (int q = 0; q < 2; ++q) { h->vl_misses[q] = 0; h->vl_suspend_left[q] = 0; h->vl_suspend_len[q] = 32; }
     return 0;
 }
 extern "C" int pse_neighbor_stats(pse_handle *h, double *r_buff, unsigned long long *builds, unsigned long long *reuses) {
@@ -964,20 +967,21 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
             h->vl_use = true;
             ++h->nlist_reuses;
             ++h->vl_reused_since_build;
-            h->vl_misses = 0; h->vl_suspend_len = 32;
+            h->vl_misses[h->vl_kind] = 0; h->vl_suspend_len[h->vl_kind] = 32;
             TRY(te(h, PH_SORT));
             return 0;
         }
-        if (h->vl_reused_since_build == 0 && ++h->vl_misses >= 2) {   // built twice for nothing: pause
-            h->vl_suspend_left = h->vl_suspend_len;
-            h->vl_suspend_len = std::min(2 * h->vl_suspend_len, 4096);
-            h->vl_misses = 1;                                        // one more miss after the pause suspends again
+        const int q = h->vl_kind;
+        if (h->vl_reused_since_build == 0 && ++h->vl_misses[q] >= 2) {   // built twice for nothing: pause
+            h->vl_suspend_left[q] = h->vl_suspend_len[q];
+            h->vl_suspend_len[q] = std::min(2 * h->vl_suspend_len[q], 4096);
+            h->vl_misses[q] = 1;                                     // one more miss after the pause suspends again
         }
     }
     h->vl_valid = false;
     ++h->nlist_builds;
-    const bool with_list = h->skin > 0.0 && h->vl_suspend_left == 0;
-    if (h->skin > 0.0 && !with_list) --h->vl_suspend_left;
+    const bool with_list = h->skin > 0.0 && h->vl_suspend_left[h->vl_kind] == 0;
+    if (h->skin > 0.0 && !with_list) --h->vl_suspend_left[h->vl_kind];
     if (h->skin_max > 0.0) {   // cells as wide as this build reaches: rcut + r_buff with the list, rcut without
         const bool wide = h->nc_wide;
         if (wide != with_list) {
@@ -1453,7 +1457,10 @@ static int do_step(pse_team &T, const std::vector<StepArgs> &sa, const unsigned 
     if (kT < 0 || !(dt > 0)) return fail(PSE_ERR_INVALID, "need kT >= 0 and dt > 0");
     unsigned mask = (1u << PH_TOTAL) | (1u << PH_INTEG);
     for (pse_handle *h : T.m) TRY(ts(h, PH_TOTAL));
-    TRY(velocity(T, a, group, (int)N, 3, kT, dt, timestep, lanczos_m, &mask));
+    for (pse_handle *h : T.m) h->vl_kind = 1;   // an integrating step: its own neighbour-list suspension state
+    const int rc_v = velocity(T, a, group, (int)N, 3, kT, dt, timestep, lanczos_m, &mask);
+    for (pse_handle *h : T.m) h->vl_kind = 0;
+    if (rc_v) return rc_v;
     for (size_t r = 0; r < T.m.size(); ++r) {
         pse_handle *h = T.m[r];
         TRY(ts(h, PH_INTEG));

@@ -110,7 +110,14 @@ def test_trajectory_with_and_without_the_kept_list(torch_cuda, dt):
         for ts in range(30):
             m = eng.step(dpos, vel, accel, image, dF, kT, dt, ts, lanczos_m=m)
             ms.append(m)
-        out.append((dpos.cpu().numpy(), image.cpu().numpy(), ms, eng.neighbor_stats()))
+        stats = eng.neighbor_stats()
+        if skin > 0 and dt > 1e-3:
+            # the steps have suspended the list for steps only: evaluations repeated at fixed positions still keep and reuse it
+            for _ in range(3):
+                eng.mobility(dpos, dF)
+            after = eng.neighbor_stats()
+            assert (after[1] - stats[1], after[2] - stats[2]) == (1, 2), (stats, after)
+        out.append((dpos.cpu().numpy(), image.cpu().numpy(), ms, stats))
     (pa, ia, ma, sa), (pb, ib, mb, sb) = out
     assert sb[1:] == (30, 0)
     if dt < 1e-3:

@@ -374,6 +374,23 @@ def test_cell_block_near_field_opt_in(torch_cuda):
     assert r.returncode == 0, r.stdout[-3000:]
 
 
+def test_blocked_cell_order_opt_in(torch_cuda):
+    """PSE_CELL_BZ=b stores the cells in blocks of b along z (x, z block, y, z in block) so that a wavefront's rows form a squat
+    brick; every near-field path (cell pass, pair list, overflow rows, kept neighbour list, pair repulsion) must give the same
+    answers.  The switch is read once per process: the checks run in a child."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PSE_CELL_BZ="2")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        os.path.join(root, "tests", "test_gpu_nlist.py"), "-k",
+                        "mreal_matches_oracle or pair_list_overflow or brownian_velocity_matches_port or step_integrates or pair_repulsion "
+                        "or reused_list or overflow_rows"],
+                       env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
 @pytest.mark.parametrize("n,grid", [(4000, 0), (65_536, 64)])
 def test_mobility_graph_replay_matches_eager(torch_cuda, n, grid):
     """pse_mobility called again and again on the same arrays is captured into a hipGraph on the third call and replayed from

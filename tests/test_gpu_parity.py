@@ -217,7 +217,7 @@ def test_step_integrates_and_wraps(torch_cuda, oracle):
 def test_fused_x_pass_matches_port(torch_cuda, oracle, grid, xy, P):
     """Every Nx = 2^a 3^b 5^c (the reference's grid rule, PSEv1/Stokes.cc:147-199) takes the fused forward-x FFT + k-space scaling
     (+ noise) + inverse-x FFT kernel: radix 4/2 in LDS for powers of two, two radix-16 passes in registers at 256 (+ a radix-2 pass at 512), mixed
-    radix 5/4/3/2 otherwise (60 = 5 4 3, 45 = 5 3 3, 36 = 4 3 3, 90 = 5 3 3 2, 120 = 5 4 3 2, 50 = 5 5 2; 360 = 5 4 3 3 2 is the grid of the
+    radix 9/8/5/4/3/2 otherwise (60 = 5 4 3, 45 = 9 5, 36 = 9 4, 90 = 9 5 2, 120 = 8 5 3, 50 = 5 5 2; 360 = 9 8 5 is the grid of the
     reference's rule at the metric point and is timed by tools/perf.py --grid 0 --xi 0.5)."""
     import pse_amd
     n = 1200

@@ -165,3 +165,72 @@ def test_overflow_rows_on_the_kept_list(torch_cuda, oracle):
     mv2 = lambda v: oracle.mobility_real(pos2, np.ascontiguousarray(v), box, 0.5, rcut)
     up2, mp2 = oracle.lanczos_sqrt(mv2, psi, 2, 1e-3)
     assert m2 == mp2 and rel(out2.cpu().numpy()[:, :3], up2) < 1e-9
+
+
+def test_random_call_sequence_matches_fresh_engines(torch_cuda, oracle):
+    """One engine driven through a random sequence of calls -- small and large moves, M.F, Brownian velocities, near-field
+    square roots, repulsion (which walks the cells itself), real-space-only and wave-only evaluations, group subsets, tilt
+    changes, another N -- against an engine created fresh for every call with the list switched off.  Catches state that
+    one call leaves behind for the next (order of the last sort, kept list, suspended list, cell grid in use)."""
+    import torch
+    import pse_amd
+    rng = np.random.default_rng(2024)
+    n, seed = 1500, 3
+    pos, force, box = make_suspension(n, phi=0.12)
+    L = box[0]
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3, seed=seed)
+    group = torch.tensor(np.sort(rng.choice(n, size=1100, replace=False)).astype(np.int32), device="cuda")
+    cur, xy = pos.copy(), 0.0
+    kinds = ["mf", "brown", "mf_near", "mf_wave", "sqrt", "repulse", "group", "mf", "brown", "mf"]
+    for it in range(30):
+        what = kinds[it % len(kinds)] if it < 24 else "mf"
+        move = rng.choice(["none", "none", "small", "small", "small", "large", "tilt", "shrink"]) if it > 0 else "none"
+        if it % 5 == 0:
+            eng.set_neighbor_skin(0.4)   # re-arm a list that the large moves have suspended
+        nn = n
+        if move == "small":
+            cur = cur + 0.02 * rng.normal(size=cur.shape).clip(-3, 3)
+        elif move == "large":
+            cur = cur + 0.5 * rng.normal(size=cur.shape)
+        elif move == "tilt":
+            xy = float(rng.uniform(-0.3, 0.3))
+        elif move == "shrink":
+            nn = 1200
+        b = (L, L, L, xy)
+        if eng.box != b:
+            eng.set_box(*b)
+        cur = oracle.wrap(cur, np.zeros(cur.shape, dtype=np.int64), b)[0]
+        p, f = cur[:nn], force[:nn]
+        fresh = pse_amd.Engine(n, box, xi=0.5, error=1e-3, seed=seed)
+        fresh.set_neighbor_skin(0.0)
+        if fresh.box != b:
+            fresh.set_box(*b)
+        dp, df = to4(p, 1.0), to4(f)
+        tag = (it, what, move)
+        if what in ("mf", "mf_near", "mf_wave"):
+            parts = {"mf": 3, "mf_near": 1, "mf_wave": 2}[what]
+            a = eng.mobility(dp, df, parts=parts).cpu().numpy()[:, :3]
+            r = fresh.mobility(dp, df, parts=parts).cpu().numpy()[:, :3]
+            assert rel(a, r) < 1e-11, (tag, rel(a, r))
+        elif what == "brown":
+            a, ma = eng.brownian_velocity(dp, df, 1.0, 1e-3, it)
+            r, mr = fresh.brownian_velocity(dp, df, 1.0, 1e-3, it)
+            assert ma == mr and rel(a.cpu().numpy()[:, :3], r.cpu().numpy()[:, :3]) < 1e-10, tag
+        elif what == "sqrt":
+            a, ma = eng.sqrt_mreal(dp, df, tol=1e-3)
+            r, mr = fresh.sqrt_mreal(dp, df, tol=1e-3)
+            assert ma == mr and rel(a.cpu().numpy()[:, :3], r.cpu().numpy()[:, :3]) < 1e-10, tag
+        elif what == "repulse":
+            fa, fr = to4(np.zeros((nn, 3))), to4(np.zeros((nn, 3)))
+            eng.pair_repulsion(dp, fa, 10.0, sigma=2.0, accumulate=False)
+            fresh.pair_repulsion(dp, fr, 10.0, sigma=2.0, accumulate=False)
+            assert np.abs(fa.cpu().numpy() - fr.cpu().numpy()).max() < 1e-11, tag
+        else:   # a group subset of the full arrays
+            if nn != n:
+                continue
+            a = eng.mobility(dp, df, group=group).cpu().numpy()
+            r = fresh.mobility(dp, df, group=group).cpu().numpy()
+            g = group.cpu().numpy()
+            assert rel(a[g, :3], r[g, :3]) < 1e-11, tag
+    st = eng.neighbor_stats()
+    assert st[2] >= 3, st      # some of the calls did run on the kept list

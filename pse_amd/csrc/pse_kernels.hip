@@ -58,23 +58,18 @@ __global__ void k_cell_scatter(const unsigned *__restrict__ keys, const unsigned
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < N) slots[cell_off[keys[g]] + rank[g]] = (unsigned)g;
 }
-// one wave per cell: rank every member among the members of its cell (all-pairs through shuffles), write it in order
+// one thread per slot: rank its particle among the members of its cell (a handful: the loads of a cell's threads are the same
+// few words), write it in order.  (One wave per cell kept five of 64 lanes busy: 33 us at N = 1e6; this way 10.)
 __global__ void __launch_bounds__(TPB)
-k_cell_order(const int *__restrict__ cell_off, int ncell, const unsigned *__restrict__ slots, unsigned *__restrict__ perm) {
-    const int c = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (c >= ncell) return;
-    const int a = cell_off[c], n = cell_off[c + 1] - a;
-    for (int e0 = 0; e0 < n; e0 += 64) {
-        const bool mine = e0 + lane < n;
-        const unsigned v = mine ? slots[a + e0 + lane] : 0xFFFFFFFFu;
-        int smaller = 0;
-        for (int c0 = 0; c0 < n; c0 += 64) {
-            const unsigned cu = c0 + lane < n ? slots[a + c0 + lane] : 0xFFFFFFFFu;
-            const int m = min(64, n - c0);
-            for (int t = 0; t < m; ++t) smaller += __shfl(cu, t, 64) < v ? 1 : 0;
-        }
-        if (mine) perm[a + smaller] = v;
-    }
+k_cell_order(const int *__restrict__ cell_off, const unsigned *__restrict__ keys, int N, const unsigned *__restrict__ slots,
+             unsigned *__restrict__ perm) {
+    const int s = blockIdx.x * TPB + threadIdx.x;
+    if (s >= N) return;
+    const unsigned v = slots[s];
+    const int c = (int)keys[v], a = cell_off[c], n = cell_off[c + 1] - a;
+    int smaller = 0;
+    for (int t = 0; t < n; ++t) smaller += slots[a + t] < v ? 1 : 0;
+    perm[a + smaller] = v;
 }
 size_t cell_sort_temp_bytes(size_t ncell) {
     size_t bytes = 0;
@@ -87,7 +82,7 @@ void cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCell
     hipLaunchKernelGGL(k_cell_keys, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, group, N, box, nc, keys, rank, cnt);
     (void)hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt, cell_off, ncell + 1, s);   // cnt[ncell] = 0: cell_off[ncell] = N
     hipLaunchKernelGGL(k_cell_scatter, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, keys, rank, cell_off, N, slots);
-    hipLaunchKernelGGL(k_cell_order, dim3(nblocks(ncell, TPB / 64)), dim3(TPB), 0, s, cell_off, ncell, slots, perm);
+    hipLaunchKernelGGL(k_cell_order, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, cell_off, keys, N, slots, perm);
 }
 
 __global__ void k_permute(const double4 *__restrict__ pos, const double4 *__restrict__ vec,

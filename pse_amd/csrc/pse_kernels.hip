@@ -889,7 +889,10 @@ k_xfft_scale(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restri
     // layout [Nx][rows][Nzh] per component: all Ny rows on a single GPU, the nyl rows [y0, y0 + nyl) of this rank after
     // the slab transpose
     const int rows = a.transposed ? a.nyl : G.Ny;
-    const int jl = blockIdx.x / nkb, k0 = (blockIdx.x - jl * nkb) * KB;
+    // neighbouring kz blocks of a row share 128-byte lines (a block's pieces are 64 or 32 bytes): keep them on one XCD, so the
+    // second one finds the line in that XCD's L2 (round-robin placement fetched every line from memory twice)
+    const int bid = xcd_block(blockIdx.x, gridDim.x);
+    const int jl = bid / nkb, k0 = (bid - jl * nkb) * KB;
     const int j = a.transposed ? a.y0 + jl : jl;
     const int kv = min(KB, G.Nzh - k0);
     double2 *comp[3] = {X, Y, Z};
@@ -1092,7 +1095,10 @@ k_xfft_scale256(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__res
     const int tid = threadIdx.x;
     const int nkb = (G.Nzh + KB - 1) / KB;
     const int rows = a.transposed ? a.nyl : G.Ny;
-    const int jl = blockIdx.x / nkb, k0 = (blockIdx.x - jl * nkb) * KB;
+    // neighbouring kz blocks of a row share 128-byte lines (a block's pieces are 64 or 32 bytes): keep them on one XCD, so the
+    // second one finds the line in that XCD's L2 (round-robin placement fetched every line from memory twice)
+    const int bid = xcd_block(blockIdx.x, gridDim.x);
+    const int jl = bid / nkb, k0 = (bid - jl * nkb) * KB;
     const int j = a.transposed ? a.y0 + jl : jl;
     const int kv = min(KB, G.Nzh - k0);
     double2 *comp[3] = {X, Y, Z};
@@ -1293,7 +1299,10 @@ k_xfft_scale_mixed(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__
     const int tid = threadIdx.x;
     const int nkb = (G.Nzh + KB - 1) / KB;
     const int rows = a.transposed ? a.nyl : G.Ny;
-    const int jl = blockIdx.x / nkb, k0 = (blockIdx.x - jl * nkb) * KB;
+    // neighbouring kz blocks of a row share 128-byte lines (a block's pieces are 64 or 32 bytes): keep them on one XCD, so the
+    // second one finds the line in that XCD's L2 (round-robin placement fetched every line from memory twice)
+    const int bid = xcd_block(blockIdx.x, gridDim.x);
+    const int jl = bid / nkb, k0 = (bid - jl * nkb) * KB;
     const int j = a.transposed ? a.y0 + jl : jl;
     const int kv = min(KB, G.Nzh - k0);
     double2 *comp[3] = {X, Y, Z};

@@ -462,7 +462,9 @@ k_mreal_verlet(const double4 *__restrict__ pos_s, const double2 *__restrict__ pv
 // Lanczos epilogue (see LzFuse).
 // PACKED: neighbours are read from 48-byte (position, vector) records pv[j] = {(x,y), (z,vx), (vy,vz)}: three 16-byte
 // gathers per pair instead of the four of two 24-byte records (the kernel is bound by the L1 address path).
-template <bool FUSE, int UNROLL, int NT, bool PACKED>
+// WSP = 4: the four waves of a workgroup share ONE block of 64 rows and take every fourth group of slots each (partial sums
+// through LDS): the waves resident on a CU then gather from a quarter as many neighbourhoods (the kernel is bound by L1 misses).
+template <bool FUSE, int UNROLL, int NT, bool PACKED, int WSP = 1>
 __global__ void __launch_bounds__(NT)
 k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int lo,
              int hi, DBox box, int shift_only, double self, NbList nb, LzFuse lz, const double2 *__restrict__ pv,
@@ -475,7 +477,10 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
         shift[threadIdx.x * 3] = sx; shift[threadIdx.x * 3 + 1] = sy; shift[threadIdx.x * 3 + 2] = sz;
     }
     __syncthreads();
-    const int i = lo + xcd_block(blockIdx.x, gridDim.x) * NT + threadIdx.x;
+    static_assert(WSP == 1 || (NT == 64 * WSP && FUSE), "split rows: one wave per slot phase");
+    const int wv = WSP > 1 ? (int)(threadIdx.x >> 6) : 0;
+    const int i = WSP > 1 ? lo + xcd_block(blockIdx.x, gridDim.x) * 64 + (int)(threadIdx.x & 63)
+                          : lo + xcd_block(blockIdx.x, gridDim.x) * NT + (int)threadIdx.x;
     const bool active = i < hi;
     double ux = 0.0, uy = 0.0, uz = 0.0;
     double4 vi = make_double4(0.0, 0.0, 0.0, 0.0);
@@ -484,14 +489,14 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
         const int cnt = nb.cnt[i];
         if (cnt >= 0) {
             const double4 pi = pos_s[i];
-            ux = self * vi.x; uy = self * vi.y; uz = self * vi.z;
+            if (wv == 0) { ux = self * vi.x; uy = self * vi.y; uz = self * vi.z; }
             const int lane = (i - lo) & 63;
             const char *rec = nb.data + (size_t)((i - lo) >> 6) * nb.cap * NB_REC;
             // software-pipelined by hand: the list entries of UNROLL slots, then their 2 UNROLL gathers, then the arithmetic --
             // left to the compiler every slot waited for its own load -> gather chain (the kernel was latency-bound at
             // 1.9 TB/s).  Branch-free: slots past cnt re-read the last valid one with f = h = 0; image code 13 is a zero shift.
             static_assert(UNROLL == 4, "one list group per iteration");
-            for (int s0 = 0; s0 < cnt; s0 += UNROLL) {
+            for (int s0 = UNROLL * wv; s0 < cnt; s0 += UNROLL * WSP) {
                 const char *grp = rec + (size_t)(s0 >> 2) * (4 * NB_REC);
                 // streamed once: non-temporal, so the list does not evict the neighbour records the gathers reuse from L1
                 typedef unsigned u4v __attribute__((ext_vector_type(4)));
@@ -533,6 +538,8 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
                     uz += fu * Fj[u].z + rdF * dz;
                 }
             }
+        } else if (wv != 0) {
+            // overflow rows are computed whole by the first wave
         } else if (vl.idx) {
             // the row did not fit the pair list and the step runs on the kept neighbour list (the cells are those of its build)
             const double4 pi = pos_s[i];
@@ -581,6 +588,14 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
             });
         }
     }
+    if (WSP > 1) {   // the other waves' shares of the rows
+        __shared__ double red[WSP > 1 ? (WSP - 1) * 3 * 64 : 1];
+        const int ln = threadIdx.x & 63;
+        if (wv > 0) { red[((wv - 1) * 3 + 0) * 64 + ln] = ux; red[((wv - 1) * 3 + 1) * 64 + ln] = uy; red[((wv - 1) * 3 + 2) * 64 + ln] = uz; }
+        __syncthreads();
+        if (wv > 0) return;
+        for (int w = 0; w < WSP - 1; ++w) { ux += red[(w * 3 + 0) * 64 + ln]; uy += red[(w * 3 + 1) * 64 + ln]; uz += red[(w * 3 + 2) * 64 + ln]; }
+    }
     if (FUSE) {   // x = vec (unnormalised Lanczos vector), y = M x: partial sums of x.x, x.y, x.v_{j-1}
         double a = 0.0, b = 0.0, c = 0.0;
         if (active) {
@@ -591,7 +606,7 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
                 c = vi.x * m.x + vi.y * m.y + vi.z * m.z;
             }
         }
-        if (NT == 64) { a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); }
+        if (NT == 64 || WSP > 1) { a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); }
         else { a = block_sum(a, sh); __syncthreads(); b = block_sum(b, sh); __syncthreads(); c = block_sum(c, sh); }
         if (threadIdx.x == 0) {
             lz.partials[blockIdx.x] = a; lz.partials[lz.npart_cap + blockIdx.x] = b; lz.partials[2 * lz.npart_cap + blockIdx.x] = c;
@@ -643,7 +658,7 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
 }
 
 __global__ void __launch_bounds__(1024) k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, double *__restrict__ scal);
-int mreal_partials_needed(int rows) { return nblocks(std::max(rows, 1), TPB); }
+int mreal_partials_needed(int rows) { return nblocks(std::max(rows, 1), 64); }   // one per 64 rows (the split mat-vec); the plain one uses a quarter
 void launch_lz_reduce3(const double *partials, int npart, int cap, double *scal, hipStream_t s) {
     hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, partials, npart, cap, 3, scal);
 }
@@ -653,6 +668,16 @@ void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w
     const int so = (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1);
     const int nbk = nblocks(std::max(hi - lo, 1), TPB);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
+    // Four waves per block of 64 rows, each taking every fourth group of slots: 0.166 ms against 0.191 with four blocks of rows
+    // per workgroup (two waves: 0.182, eight: 0.196).  PSE_LIST_SPLIT=0 selects the one-wave-per-block kernel.
+    static const bool split = !(getenv("PSE_LIST_SPLIT") && atoi(getenv("PSE_LIST_SPLIT")) == 0);
+    if (pv && split) {
+        const int nb64 = nblocks(std::max(hi - lo, 1), 64);
+        hipLaunchKernelGGL((k_mreal_list<true, 4, 256, true, 4>), dim3(nb64), dim3(256), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, pv, cell_off, nc, rcut * rcut, coef, vl);
+        if (ev_end) (void)hipEventRecord(ev_end, s);
+        launch_lz_reduce3(lz.partials, nb64, lz.npart_cap, scal, s);
+        return;
+    }
     if (pv) hipLaunchKernelGGL((k_mreal_list<true, 4, TPB, true>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, pv, cell_off, nc, rcut * rcut, coef, vl);
     else hipLaunchKernelGGL((k_mreal_list<true, 4, TPB, false>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, nullptr, cell_off, nc, rcut * rcut, coef, vl);
     if (ev_end) (void)hipEventRecord(ev_end, s);

@@ -88,6 +88,44 @@ def test_hoomd_style_script_runs_on_the_shim():
     assert "hoomd-style run done: 20 steps" in r.stdout
 
 
+def test_shim_driven_run_matches_raw_engine(oracle):
+    """SURVEY 8 f3 with a result: the calls of the reference's example script made on the `hoomd` stand-in (lattice, mode_standard,
+    group.all, PSEv1.integrate.PSEv1 with a steady shear, hoomd.run), then the same steps through the raw C-ABI engine --
+    positions, image flags and the Lanczos count must agree."""
+    import math
+    import torch
+    import pse_amd
+    sys.path.insert(0, os.path.join(ROOT, "compat"))
+    import hoomd
+    import hoomd.PSEv1
+    from pse_amd import context as pctx
+    hoomd.context.initialize('')
+    dt, nrun, n1, a = 1e-3, 5, 7, 5.0
+    hoomd.init.create_lattice(unitcell=hoomd.lattice.sc(a=a), n=n1)
+    system = pctx.current
+    p0 = system.pos.cpu().numpy()[:, :3].copy()
+    n, box = p0.shape[0], tuple(system.box)
+    assert n == n1 ** 3 and abs(box[0] - n1 * a) < 1e-12 and box[3] == 0.0
+    function_form = hoomd.PSEv1.shear_function.steady(dt=dt, shear_rate=0.5)
+    hoomd.md.integrate.mode_standard(dt=dt)
+    pse = hoomd.PSEv1.integrate.PSEv1(group=hoomd.group.all(), seed=1, T=1.0, xi=0.5, error=1E-3, function_form=function_form)
+    os.environ.pop("PSE_EXAMPLE_STEPS", None)
+    hoomd.run(nrun)
+    # the raw engine: no box_resize in the script, so the box stays untilted and the steady rate enters the integration only
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3, seed=oracle.hash_seed(1))
+    rp, rv = to4(p0), to4(np.zeros((n, 3)), 1.0)
+    rF = torch.zeros((n, 4), dtype=torch.float64, device="cuda")
+    ra = torch.zeros((n, 3), dtype=torch.float64, device="cuda"); ri = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+    m = 2
+    for t in range(nrun):
+        m = eng.step(rp, rv, ra, ri, rF, 1.0, dt, t, shear_rate=0.5, lanczos_m=m)
+    assert system.timestep == nrun
+    assert np.abs(system.pos.cpu().numpy()[:, :3] - rp.cpu().numpy()[:, :3]).max() < 1e-12
+    assert np.array_equal(system.image.cpu().numpy(), ri.cpu().numpy())
+    assert pse.cpp_method.lanczosIterations() == m
+    assert np.abs(system.pos.cpu().numpy()[:, :3] - p0).max() > 1e-3     # it did move
+
+
 def test_force_provider_and_trajectory(tmp_path):
     """The steps either side of the path: a soft-repulsion force provider feeding net_force and a
     trajectory writer.  Overlapping random spheres at kT = 0 are pushed apart by M.F_repulsion; frames are written."""

@@ -184,10 +184,11 @@ static int cells_for(const Box &box, double rc, double gamma, int n_slabs, DCell
                     "the minimum-image near field needs rcut <= L/2; increase xi", rc, wx, wy, wz, gamma);
     auto n = [&](double w) { int c = (int)std::floor(w / rc); if (c < 3) c = 1; if (c > 1024) c = 1024; return c; };
     out = DCells{n(wx), n(wy), n(wz), 0, 1};
-    // PSE_CELL_BZ=b: blocks of b cells along z in the storage order (pse_device.h).  Off by default: measured at the metric point,
-    // blocks of 3..8 take the pair-list mat-vec from 0.187 to 0.175 ms (a wave's gathers come from ~95 cells instead of ~130) but
-    // the cell pass from 0.63 to 0.68 ms (lanes of a wave no longer walk the same z lines) -- a wash per step.
-    static const int bz_env = getenv("PSE_CELL_BZ") ? atoi(getenv("PSE_CELL_BZ")) : 0;
+    // Blocks of six cells along z in the storage order (pse_device.h; PSE_CELL_BZ=b overrides, 0 = plain (x, y, z) order).
+    // Measured at the metric point: the pair-list mat-vec 0.163 -> 0.153 ms (a wave's gathers come from ~95 cells instead of
+    // ~130), the cell pass 0.60 -> 0.62 ms (lanes of a wave no longer walk the same z lines): about 1 % per step in four of four
+    // paired bench runs.
+    static const int bz_env = getenv("PSE_CELL_BZ") ? atoi(getenv("PSE_CELL_BZ")) : 6;
     static const bool tiles = getenv("PSE_NEAR_BLOCKS") && atoi(getenv("PSE_NEAR_BLOCKS")) > 0;   // the LDS-tile near field indexes cells itself
     out.bz = (bz_env > 0 && !tiles && out.nz >= 2 * bz_env) ? bz_env : out.nz;
     out.nzb = (out.nz + out.bz - 1) / out.bz;

@@ -26,8 +26,8 @@ struct DGrid {
 };
 
 // Storage order of the cells: x slowest, then blocks of bz cells along z, then y, then z inside the block --
-// slot = ((cx nzb + cz / bz) ny + cy) bz + cz % bz.  With bz = nz (the default) this is the plain (x, y, z) order.  Blocks
-// (PSE_CELL_BZ) make 64 consecutive particles (a wavefront's rows) a squat 1 x 2 x 6-cell brick instead of a 12-cell needle
+// slot = ((cx nzb + cz / bz) ny + cy) bz + cz % bz.  With bz = nz this is the plain (x, y, z) order (PSE_CELL_BZ=0).  Blocks
+// (default: six cells) make 64 consecutive particles (a wavefront's rows) a squat 1 x 2 x 6-cell brick instead of a 12-cell needle
 // along z, so the neighbour records a wave gathers come from ~95 cells instead of ~130; x stays slowest, so a rank's cell
 // slab is still one contiguous row range.  The last block of a line is padded with empty cells when bz does not divide nz.
 struct DCells {

@@ -375,14 +375,17 @@ def test_cell_block_near_field_opt_in(torch_cuda):
     assert r.returncode == 0, r.stdout[-3000:]
 
 
-def test_blocked_cell_order_opt_in(torch_cuda):
-    """PSE_CELL_BZ=b stores the cells in blocks of b along z (x, z block, y, z in block) so that a wavefront's rows form a squat
-    brick; every near-field path (cell pass, pair list, overflow rows, kept neighbour list, pair repulsion) must give the same
-    answers.  The switch is read once per process: the checks run in a child."""
+@pytest.mark.parametrize("bz", ["0", "2"])
+def test_cell_storage_orders(torch_cuda, bz):
+    """The cells are stored in blocks of b along z (x, z block, y, z in block; default b = 6 where an axis has at least twelve
+    cells) so that a wavefront's rows form a squat brick; PSE_CELL_BZ=0 is the plain (x, y, z) order.  Every near-field path
+    (cell pass, pair list, overflow rows, kept neighbour list, pair repulsion) must give the same answers in either (the test
+    boxes have 6-8 cells per axis: default = plain there, so b = 2 is what exercises the blocks).  The switch is read once per
+    process: the checks run in a child."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, PSE_CELL_BZ="2")
+    env = dict(os.environ, PSE_CELL_BZ=bz)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
                         os.path.join(root, "tests", "test_gpu_nlist.py"), "-k",

@@ -6,13 +6,17 @@ in-k-space noise -> inverse FFT -> gather -> near-field M.F -> Lanczos M_real^{1
 synthetic random-sphere suspension of BASELINE.json's metric point (N = 1e6, phi = 0.1, 256^3 grid, fp64), inputs
 resident in HBM before the timed region.  value = particle-steps/s summed over all ranks.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--n PARTICLES] [--grid G] [--no-cpu]
-For N > 1 launch with torch.distributed.run (one rank per GPU); see DESIGN.md section "Multi-GPU".
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--n PARTICLES] [--grid G] [--no-cpu] [--traffic FILE] [--dry-run]
+With --gpus N > 1 and no torch.distributed environment the process launches the N ranks itself (a child
+`python -m torch.distributed.run ... bench.py`, one rank per GPU; the parent never touches the GPU) and relays rank 0's
+JSON line; started under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.  See DESIGN.md "Multi-GPU".
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -57,6 +61,44 @@ def cpu_baseline(budget_s=12.0):
     }
 
 
+def launch_ranks(args, argv):
+    """--gpus N without a torch.distributed environment: start the N ranks as a child torch.distributed.run and relay rank 0's
+    line.  This process has not initialised HIP (torch is not even imported yet) and never replaces itself: the ranks are
+    children, their exit code is ours."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    rest = [a for a in argv if a != "--dry-run"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + rest
+    if args.dry_run:
+        print(json.dumps({"launch": cmd, "n_gpus": args.gpus}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        try:
+            if "metric" in json.loads(out):
+                line = out
+                continue
+        except ValueError:
+            pass
+        print(out, file=sys.stderr)
+    rc = proc.wait()
+    if rc != 0:
+        print(f"bench.py: the {args.gpus}-rank run failed (exit code {rc})", file=sys.stderr)
+        return rc
+    if line is None:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        return 1
+    print(line)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,7 +111,16 @@ def main():
     ap.add_argument("--kT", type=float, default=1.0)
     ap.add_argument("--dt", type=float, default=1e-3)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "traffic.json"),
+                    help="HBM bytes per kernel from separate rocprofv3 --pmc passes of this command (tools/round_profile.sh)")
+    ap.add_argument("--no-ref-grid", action="store_true", help="skip the extra steps on the reference rule's 360^3 grid")
+    ap.add_argument("--dry-run", action="store_true", help="with --gpus N > 1: print the launch command and stop")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
+    if args.dry_run:
+        print(json.dumps({"launch": None, "n_gpus": args.gpus}))
+        return
 
     import torch
     import torch.distributed as dist
@@ -77,8 +128,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the torch.distributed environment has WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "PSE_FORCE_SHARDED" in os.environ
     if use_dist:
@@ -180,17 +231,20 @@ def main():
                  "t_real": "pse::k_mreal_cells<true", "t_matvec": "pse::k_mreal_list"}
     ach = alg[dom] / (per_launch_ms[dom] * 1e-3) / 1e9 if per_launch_ms[dom] > 0 else 0.0
     # HBM bytes of the dominant kernel: rocprofv3 counters cannot be collected from inside this process, so the figure comes
-    # from the committed counter passes of this same command (profiles/traffic.json: separate --pmc FETCH_SIZE and WRITE_SIZE
-    # runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide streaming reads) and is labelled as such
+    # from counter passes of this same command kept in a file (--traffic, default profiles/traffic.json: separate --pmc
+    # FETCH_SIZE and WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane reads -- the
+    # factor is calibrated for this kernel's non-temporal list loads by tools/microbench/nt_fetch) and carries the commit the
+    # passes were taken at, so a stale file shows
     traffic, traffic_src = None, None
-    tr_file = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tr_file) and world == 1 and n == 1_000_000 and grid == 256:
+    tr_file = args.traffic
+    if tr_file and os.path.exists(tr_file) and world == 1 and n == 1_000_000 and grid == 256:
         try:
             tj = json.load(open(tr_file))
             for k, v in tj.items():
                 if k.startswith(pmc_names.get(dom, "?")):
                     traffic = 2 * v["fetch_raw"] + v["write"]
-                    traffic_src = f"profiles/traffic.json ({tj.get('_source', 'separate rocprofv3 --pmc passes')}); not measured in this run"
+                    traffic_src = (f"{os.path.relpath(tr_file, ROOT)} ({tj.get('_source', 'separate rocprofv3 --pmc passes')}; "
+                                   f"kernels as of commit {tj.get('_commit', 'unrecorded')}); not measured in this run")
         except Exception:
             traffic = None
     sg_ms = per_launch_ms["t_spread"] + per_launch_ms["t_gather"]
@@ -225,6 +279,25 @@ def main():
                            for k in alg if per_launch_ms[k] > 0},
         "step_share_ms": {k[2:]: round(v, 4) for k, v in weight.items()},
     }
+    if world == 1 and not args.no_ref_grid and n == 1_000_000:
+        # the same suspension on the grid the REFERENCE's parameter rule picks at xi = 0.5 (360^3, PSEv1/Stokes.cc:135-199;
+        # BASELINE.md section 3): a separate engine, a few steps, reported beside the headline (never the headline)
+        del sim
+        torch.cuda.empty_cache()
+        ref = pdist.make_simulation(n, (L, L, L, 0.0), xi=0.5, error=args.error, seed=1, grid=(0, 0, 0), world=1, rank=0)
+        ref.load(pos, force, mass=1.0)
+        mr = 2
+        for it in range(3):
+            mr = ref.step(args.kT, args.dt, it, lanczos_m=mr)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_ref = 10
+        for it in range(n_ref):
+            mr = ref.step(args.kT, args.dt, 3 + it, lanczos_m=mr)
+        torch.cuda.synchronize()
+        ri = ref.info()
+        out["reference_rule_grid"] = {"grid": [ri["Nx"], ri["Ny"], ri["Nz"]], "xi": 0.5, "rcut": ri["rcut"], "P": ri["P"],
+                                      "ms_per_step": (time.perf_counter() - t0) / n_ref * 1e3, "steps": n_ref, "lanczos_m": mr}
     if not args.no_cpu and world == 1:     # the CPU baseline is reported with the single-GPU line only
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))

@@ -76,7 +76,12 @@ int pse_destroy(pse_handle *h);
  * (PSEv1/Helper.cu:285-332, called at PSEv1/Stokes.cu:298). Only xy may differ from the creation box by more
  * than round-off unless the cell grid still fits. */
 int pse_set_box(pse_handle *h, double Lx, double Ly, double Lz, double xy);
-/* run on this hipStream_t (default: the null stream, as the reference does) */
+/* run on this hipStream_t (default: the null stream, as the reference does).  The work of every entry point is ordered on
+ * this stream, but the entry points are NOT free of host synchronisation (so they cannot be captured into a hipGraph by the
+ * caller): (1) with a neighbour skin in use (the default, below) every evaluation whose kept list may still be valid waits
+ * for the stream and reads one flag back before it queues anything (the distance check HOOMD's NeighborList does on the
+ * host side too); (2) Brownian calls read the Lanczos scalars back once per convergence check, as the reference does per
+ * iteration (PSEv1/Brownian.cu:446-499).  pse_set_neighbor_skin(h, 0) removes (1). */
 int pse_set_stream(pse_handle *h, void *hip_stream);
 /* Neighbour list kept across calls: replaces the NeighborListGPUBinned(rcut, r_buff = 0.4) with setEvery(1, dist_check)
  * that PSEv1/integrate.py:60,79 builds and Stokes::integrateStepOne refreshes with m_nlist->compute (PSEv1/Stokes.cc:433).
@@ -159,6 +164,8 @@ int pse_debug_spread(pse_handle *h, const pse_double4 *pos, const pse_double4 *f
 typedef struct pse_team pse_team;
 int pse_team_unique_id(void *id128_host);   /* host buffer of 128 bytes, call on rank 0 and distribute */
 int pse_team_create(pse_handle **members, int n_members, const void *id128_host, pse_team **out);
+/* Destroy the team BEFORE its members: the members must outlive it (an in-process team lends member 0's side stream to the
+ * others and hands every member its own back here). */
 int pse_team_destroy(pse_team *team);
 /* the three hot-path entry points for a team; pointer arrays have one entry per local member, in members order */
 int pse_team_mobility(pse_team *team, const pse_double4 *const *pos, const pse_double4 *const *force,

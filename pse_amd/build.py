@@ -51,7 +51,7 @@ def build_lib(force=False):
     if not force and _newer(LIB, srcs):
         return LIB
     objs = []
-    for name, extra in (("pse_kernels.hip", HIPFLAGS), ("pse_farfield.hip", HIPFLAGS + FARFLAGS), ("pse_nearfield.hip", HIPFLAGS), ("pse_capi.hip", HIPFLAGS), ("pse_params.cpp", ["-x", "c++"])):
+    for name, extra in (("pse_kernels.hip", HIPFLAGS), ("pse_farfield.hip", HIPFLAGS + FARFLAGS), ("pse_capi.hip", HIPFLAGS), ("pse_params.cpp", ["-x", "c++"])):
         obj = os.path.join(CSRC, name.rsplit(".", 1)[0] + ".o")
         _run([HIPCC, *CXXFLAGS, *extra, "-c", os.path.join(CSRC, name), "-o", obj])
         objs.append(obj)

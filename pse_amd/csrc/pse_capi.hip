@@ -76,15 +76,17 @@ struct pse_handle {
     int *bounds_host = nullptr;      // pinned: slab row boundaries on their way back from the device
     hipEvent_t ev_bounds = nullptr;
     bool bounds_pending = false;
-    // hipGraph of the deterministic evaluation (pse_mobility): ~50 launches replayed as one (small systems are launch-bound)
-    struct MobilityGraph {
-        hipGraphExec_t exec = nullptr;
-        hipStream_t cap = nullptr;          // capture happens on an owned stream (the caller's may be the null stream)
-        const void *pos = nullptr, *force = nullptr, *vel = nullptr, *group = nullptr;
-        unsigned N = 0; int parts = 0; double xy = 0.0; hipStream_t user = nullptr;
-        int seen = 0;                       // consecutive calls with this key
-        bool off = false;                   // capture failed once, or PSE_GRAPH=0: stay eager
-    } mg;
+    // developer switches, read from the environment ONCE, in pse_create (nothing on the call path consults the environment)
+    struct Tuning {
+        int cell_bz = 6;          // PSE_CELL_BZ: height of the z blocks of the cell storage order (0: plain x, y, z order)
+        double skin = 0.4;        // PSE_SKIN: r_buff of the neighbour list kept across calls (0: off)
+        int overlap = 1;          // PSE_OVERLAP: 1 two chains for every call, 0 only for kT = 0, -1 never
+        bool no_xfuse = false;    // PSE_NO_XFUSE: rocFFT for the x pass
+        int wave_mode = 0;        // PSE_WAVE_MODE: 0 automatic, 1 slab, 2 replicated
+        int spread_tz = 0, spread_nw = 0;   // PSE_SPREAD_TZ, PSE_SPREAD_NW
+        bool verbose = false;     // PSE_VERBOSE
+        bool team_overlap = false;   // PSE_TEAM_OVERLAP: process-per-rank teams run the far-field chain on a second communicator
+    } tun;
     DCells bidx_nc = {0, 0, 0};      // cell grid the boundary-cell indices on the device belong to
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap_all = false;   // fork also for Brownian steps (PSE_OVERLAP=1)
@@ -121,8 +123,6 @@ struct pse_handle {
     int vl_reused_since_build = 0, vl_misses[2] = {0, 0}, vl_suspend_left[2] = {0, 0}, vl_suspend_len[2] = {32, 32};
     int vl_kind = 0;             // kind of the call being prepared
     bool pv_is_f = false;        // the vector half of pv mirrors f_s (as the permute wrote it)
-    DCells blk_nc = {0, 0, 0};   // cell grid the near-field blocks were planned for
-    size_t blk_list_elems = 0;   // allocated 2-byte entries of the block pair list
     bool w_is_mpsi = false;  // w_s already holds M_real psi_s (delivered by the pass that built the pair list)
     size_t n_cells_alloc = 0;
     float4 *posf_s = nullptr;   // single-precision copy of pos_s (cutoff pre-filter of the near field)
@@ -177,20 +177,18 @@ static void set_dbox(pse_handle *h) {
 }
 
 // cells of at least rcut perpendicular width for tilts up to gamma; a dimension with fewer than 3 cells uses 1
-static int cells_for(const Box &box, double rc, double gamma, int n_slabs, DCells &out) {
+static int cells_for(const Box &box, double rc, double gamma, int n_slabs, int bz_want, DCells &out) {
     const double wx = box.Lx / std::sqrt(1.0 + gamma * gamma), wy = box.Ly, wz = box.Lz;
     if (rc > 0.5 * wx * (1 + 1e-12) || rc > 0.5 * wy * (1 + 1e-12) || rc > 0.5 * wz * (1 + 1e-12))
         return fail(PSE_ERR_INVALID, "real-space cutoff %.4f exceeds half the box width (%.4f, %.4f, %.4f at tilt %.3f): "
                     "the minimum-image near field needs rcut <= L/2; increase xi", rc, wx, wy, wz, gamma);
     auto n = [&](double w) { int c = (int)std::floor(w / rc); if (c < 3) c = 1; if (c > 1024) c = 1024; return c; };
     out = DCells{n(wx), n(wy), n(wz), 0, 1};
-    // Blocks of six cells along z in the storage order (pse_device.h; PSE_CELL_BZ=b overrides, 0 = plain (x, y, z) order).
+    // Blocks of six cells along z in the storage order (pse_device.h; PSE_CELL_BZ=b at pse_create overrides, 0 = plain (x, y, z) order).
     // Measured at the metric point: the pair-list mat-vec 0.163 -> 0.153 ms (a wave's gathers come from ~95 cells instead of
     // ~130), the cell pass 0.60 -> 0.62 ms (lanes of a wave no longer walk the same z lines): about 1 % per step in four of four
     // paired bench runs.
-    static const int bz_env = getenv("PSE_CELL_BZ") ? atoi(getenv("PSE_CELL_BZ")) : 6;
-    static const bool tiles = getenv("PSE_NEAR_BLOCKS") && atoi(getenv("PSE_NEAR_BLOCKS")) > 0;   // the LDS-tile near field indexes cells itself
-    out.bz = (bz_env > 0 && !tiles && out.nz >= 2 * bz_env) ? bz_env : out.nz;
+    out.bz = (bz_want > 0 && out.nz >= 2 * bz_want) ? bz_want : out.nz;
     out.nzb = (out.nz + out.bz - 1) / out.bz;
     if (n_slabs > 1) {
         // cell slabs coincide with grid slabs: every rank owns ncx/G whole cell layers = one contiguous row range
@@ -205,7 +203,7 @@ static int cells_for(const Box &box, double rc, double gamma, int n_slabs, DCell
 static double near_radius(const pse_handle *h) { return h->d.rcut + h->skin_max; }   // cells are as wide as the kept list reaches
 static int set_cells(pse_handle *h, double gamma) {
     DCells nc;
-    TRY(cells_for(h->box, near_radius(h), gamma, h->n_slabs, nc));
+    TRY(cells_for(h->box, near_radius(h), gamma, h->n_slabs, h->tun.cell_bz, nc));
     h->nc = nc;
     h->cell_gamma = gamma;
     h->nc_wide = h->skin_max > 0.0;
@@ -294,7 +292,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->plan_x_inv) rocfft_plan_destroy(h->plan_x_inv);
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
-    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cell_cnt, h->sup_s, h->sw.rec_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->nb.data, h->nb.cnt, h->vl.idx, h->vl.cnt, h->vl.flags, h->pos_build, h->nb.blk.list, h->nb.blk.fh, h->pos_s, h->posf_s, h->pv,
+    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cell_cnt, h->sup_s, h->sw.rec_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->nb.data, h->nb.cnt, h->vl.idx, h->vl.cnt, h->vl.flags, h->pos_build, h->pos_s, h->posf_s, h->pv,
                     h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->twiddle, h->fft_work, h->V,
                     h->scal, h->partials};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -302,8 +300,6 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_scal) (void)hipEventDestroy(h->ev_scal);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    if (h->mg.exec) (void)hipGraphExecDestroy(h->mg.exec);
-    if (h->mg.cap) (void)hipStreamDestroy(h->mg.cap);
     if (h->side_owned) (void)hipStreamDestroy(h->side_owned);
     if (h->bounds_host) (void)hipHostFree(h->bounds_host);
     if (h->ev_bounds) (void)hipEventDestroy(h->ev_bounds);
@@ -317,7 +313,7 @@ static int make_plans(pse_handle *h) {
     std::call_once(g_fft_once, [] { rocfft_setup(); });
     const DGrid &G = h->G;
     size_t work = 0, w = 0;
-    h->xfuse = xfuse_supported(G.Nx) && !getenv("PSE_NO_XFUSE");   // x axis by k_xfft_scale (also after the slab transpose)
+    h->xfuse = xfuse_supported(G.Nx) && !h->tun.no_xfuse;   // x axis by k_xfft_scale (also after the slab transpose)
     if (h->xfuse) {
         std::vector<double2> tw(G.Nx);
         for (int m = 0; m < G.Nx; ++m) {
@@ -390,56 +386,6 @@ static int make_plans(pse_handle *h) {
     return 0;
 }
 
-// near-field cell blocks for the current cell grid: shape from the mean occupancy, pair list sized for it.  Re-planned when a
-// box change alters the cell grid (the list only grows).
-static int plan_blocks(pse_handle *h) {
-    const DCells &nc = h->nc;
-    if (nc.nx == h->blk_nc.nx && nc.ny == h->blk_nc.ny && nc.nz == h->blk_nc.nz) return 0;
-    h->blk_nc = nc;
-    const size_t n = (size_t)h->n_pad;
-    const double ncell = (double)nc.nx * nc.ny * nc.nz;
-    const double vol = h->box.Lx * h->box.Ly * h->box.Lz;
-    const double nbar = (double)n / vol * 4.18879020478639 * h->d.rcut * h->d.rcut * h->d.rcut;
-    NbBlocks B = h->nb.blk;
-    unsigned short *keep = B.list;
-    double2 *keep_fh = B.fh;
-    const int per = nc.nx / std::max(1, h->n_slabs);
-    B.cx0 = h->n_slabs > 1 ? h->slab_rank * per : 0;
-    B.ncx = h->n_slabs > 1 ? per : nc.nx;
-    (void)ncell;
-    // Opt-in (PSE_NEAR_BLOCKS=1): measured on MI355X at the metric point the LDS-tile mat-vec takes 0.246 ms against 0.213 ms of the
-    // pair-list mat-vec with global gathers, and its list-building pass 0.74 ms against 0.74 ms: the tile
-    // staging and its barriers cost what the gathers cost.  Kept for large cutoffs / future tuning, covered by the GPU tests.
-    static const bool want = getenv("PSE_NEAR_BLOCKS") && atoi(getenv("PSE_NEAR_BLOCKS")) > 0;
-    if (want) nb_blocks_plan(B, nc, B.ncx, (double)n, (int)std::ceil(nbar + 6.0 * std::sqrt(nbar) + 8.0), h->n_intervals);
-    else B.on = 0;
-    B.list = keep; B.fh = keep_fh;
-    if (B.on) {
-        const size_t need = (size_t)nb_blocks_count(B, nc, B.ncx) * B.cap * 256, each = sizeof(unsigned short) + sizeof(double2);
-        if (need * each > (size_t)64e9) B.on = 0;
-        else if (need > h->blk_list_elems) {
-            if (B.list) { (void)hipFree(B.list); (void)hipFree(B.fh); h->bytes -= h->blk_list_elems * each; }
-            B.list = nullptr; B.fh = nullptr;
-            HIPCHK(hipMalloc((void **)&B.list, need * sizeof(unsigned short)));
-            HIPCHK(hipMalloc((void **)&B.fh, need * sizeof(double2)));
-            h->bytes += need * each;
-            h->blk_list_elems = need;
-        }
-    }
-    h->nb.blk = B;
-    if (B.on) {
-        const int nblk = nb_blocks_count(B, nc, B.ncx);
-        if (nblk > h->npart_cap) {   // one partial-sum slot per block
-            if (h->partials) (void)hipFree(h->partials);
-            h->partials = nullptr;
-            h->npart_cap = std::max(std::max(nblk + 64, LZ_NPART), mreal_partials_needed((int)n));
-            HIPCHK(hipMalloc((void **)&h->partials, (size_t)3 * h->npart_cap * sizeof(double)));
-        }
-    }
-    h->nb_valid = false;
-    return 0;
-}
-
 static int create_impl(const pse_params *p, pse_handle *h) {
     h->par = *p;
     h->box = Box{p->Lx, p->Ly, p->Lz, p->xy};
@@ -452,16 +398,28 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     h->n_max = (int)p->n_max;
     set_dbox(h);
     h->n_slabs = std::max(1, p->n_slabs);
+    (void)roctx();   // PSE_ROCTX: looked up here, once per process
+    {   // the developer switches: the environment is read here and nowhere else
+        auto ienv = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
+        auto &t = h->tun;
+        t.cell_bz = std::min(16, std::max(0, ienv("PSE_CELL_BZ", 6)));   // n_cells_alloc pads every z line by up to 15 cells
+        if (const char *v = getenv("PSE_SKIN")) t.skin = atof(v);
+        t.overlap = ienv("PSE_OVERLAP", 1);
+        t.no_xfuse = getenv("PSE_NO_XFUSE") != nullptr;
+        if (const char *v = getenv("PSE_WAVE_MODE")) t.wave_mode = !strcmp(v, "slab") ? 1 : (!strcmp(v, "replicated") ? 2 : 0);
+        t.spread_tz = ienv("PSE_SPREAD_TZ", 0); t.spread_nw = ienv("PSE_SPREAD_NW", 0);
+        t.verbose = ienv("PSE_VERBOSE", 0) > 0;
+        t.team_overlap = ienv("PSE_TEAM_OVERLAP", 0) > 0;
+        h->sw.force_tz = t.spread_tz; h->sw.force_nw = t.spread_nw;
+    }
     {
         // Neighbour list across steps: on by default with the reference's r_buff = 0.4 (PSEv1/integrate.py:60), single GPU, table
         // in LDS, box wide enough for rcut + skin; PSE_SKIN overrides (0: off), pse_set_neighbor_skin may lower it later.
-        const char *e1 = getenv("PSE_SKIN"), *e2 = getenv("PSE_NEAR_BLOCKS"), *e3 = getenv("PSE_GRAPH");
-        double skin = e1 ? atof(e1) : 0.4;
+        double skin = h->tun.skin;
         const int nint = (int)std::ceil(d.rcut * RS_PER_UNIT) + 1;
         const double gam = std::max(std::fabs(p->xy), p->max_strain);
         const double wmin = std::min(std::min(h->box.Lx / std::sqrt(1.0 + gam * gam), h->box.Ly), h->box.Lz);
-        if (!(skin > 0.0) || h->n_slabs > 1 || !mreal_table_in_lds(nint * 2 * RS_NCOEF) || (e2 && atoi(e2) > 0) || (e3 && atoi(e3) > 0) ||
-            d.rcut + skin > 0.5 * wmin)
+        if (!(skin > 0.0) || h->n_slabs > 1 || !mreal_table_in_lds(nint * 2 * RS_NCOEF) || d.rcut + skin > 0.5 * wmin)
             skin = 0.0;
         h->skin = h->skin_max = skin;
     }
@@ -480,8 +438,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     // ~2 ms, longer than the far field itself), so two ranks replicate the far field; PSE_WAVE_MODE=slab|replicated overrides.
     h->grid_slabs = h->n_slabs;
     if (h->n_slabs > 1) {
-        const char *mode = getenv("PSE_WAVE_MODE");
-        const bool replicate = mode ? !strcmp(mode, "replicated") : h->n_slabs == 2;
+        const bool replicate = h->tun.wave_mode ? h->tun.wave_mode == 2 : h->n_slabs == 2;
         if (replicate) h->grid_slabs = 1;
     }
     if (h->grid_slabs > 1) {
@@ -513,7 +470,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     {
         const double rc = d.rcut;
         auto cnt = [&](double w) { int c2 = (int)std::floor(w / rc); if (c2 < 3) c2 = 1; if (c2 > 1024) c2 = 1024; return (size_t)c2; };
-        h->n_cells_alloc = cnt(h->box.Lx) * cnt(h->box.Ly) * (cnt(h->box.Lz) + 16);   // + the padding of the last z block
+        h->n_cells_alloc = cnt(h->box.Lx) * cnt(h->box.Ly) * (cnt(h->box.Lz) + 16);   // + the padding of the last z block (bz <= 16)
     }
     TRY(dmalloc(h, &h->cell_off, h->n_cells_alloc + 1)); TRY(dmalloc(h, &h->cell_cnt, h->n_cells_alloc + 1));
     h->sort_tmp_bytes = cell_sort_temp_bytes(h->n_cells_alloc);
@@ -528,14 +485,12 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         h->sw.fb.tmp_bytes = bin_scan_temp_bytes(nbins);
         TRY(dmalloc(h, (char **)&h->sw.fb.tmp, h->sw.fb.tmp_bytes));
     }
-    // real-space functions first: the block planner needs the table size
     std::vector<double> coef;
     build_realspace_table(d.xi, d.rcut, coef, h->n_intervals);
     TRY(dmalloc(h, &h->coef, coef.size()));
     HIPCHK(hipMemcpy(h->coef, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice));
     TRY(dmalloc(h, &h->nb.cnt, n));
-    TRY(plan_blocks(h));
-    if (!h->nb.blk.on) {   // legacy per-step pair list (an axis with fewer than three cells): capacity from the mean neighbour count
+    {   // per-step pair list: capacity from the mean neighbour count
         const double vol = h->box.Lx * h->box.Ly * h->box.Lz;
         const double nbar = (double)n / vol * 4.18879020478639 * d.rcut * d.rcut * d.rcut;
         int cap = (int)std::ceil(1.5 * nbar + 16.0);
@@ -557,9 +512,9 @@ static int create_impl(const pse_params *p, pse_handle *h) {
             TRY(dmalloc(h, &h->pos_build, n));
             HIPCHK(hipHostMalloc((void **)&h->flags_host, 2 * sizeof(int)));
         }
-    } else h->skin = h->skin_max = 0.0;
+    }
     TRY(dmalloc(h, &h->pos_s, n)); TRY(dmalloc(h, &h->posf_s, n));
-    if (!h->nb.blk.on) TRY(dmalloc(h, &h->pv, 3 * n));   // pair-list mat-vec: packed gather records (slab ranks too: the update packs the own and the ghost rows)
+    TRY(dmalloc(h, &h->pv, 3 * n));   // pair-list mat-vec: packed gather records (slab ranks too: the update packs the own and the ghost rows)
     TRY(dmalloc(h, &h->f_s, n)); TRY(dmalloc(h, &h->uw_s, n)); TRY(dmalloc(h, &h->ur_s, n));
     TRY(dmalloc(h, &h->ub_s, n)); TRY(dmalloc(h, &h->psi_s, n)); TRY(dmalloc(h, &h->w_s, n));
 
@@ -581,12 +536,12 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     // and the Lanczos iterations (both chains are latency- rather than bandwidth-bound, so they overlap well).  With
     // pse_set_timing on, everything runs on one stream and the far field is queued behind the Lanczos iterations: per-kernel
     // durations -- the roofline evidence -- are then those of the kernel alone.  PSE_OVERLAP=0 restricts the fork to kT = 0.
-    if (!(getenv("PSE_OVERLAP") && atoi(getenv("PSE_OVERLAP")) < 0)) {
+    if (h->tun.overlap >= 0) {
         HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
         h->side_owned = h->side;
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-        h->overlap_all = !(getenv("PSE_OVERLAP") && atoi(getenv("PSE_OVERLAP")) == 0);   // on unless PSE_OVERLAP=0
+        h->overlap_all = h->tun.overlap != 0;   // on unless PSE_OVERLAP=0
     }
     TRY(make_plans(h));
 
@@ -600,7 +555,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     }
     for (auto &ph : h->ph) { HIPCHK(hipEventCreate(&ph.a)); HIPCHK(hipEventCreate(&ph.b)); }
     h->info.device_bytes = h->bytes;
-    if (const char *v = getenv("PSE_VERBOSE"); v && atoi(v) > 0) {
+    if (h->tun.verbose) {
         // the parameter summary the reference prints at notice level 2 (PSEv1/Stokes.cc:241-252), one block on stderr
         fprintf(stderr, "--- NUFFT Hydrodynamics Statistics ---\nMx: %d\nMy: %d\nMz: %d\nrcut: %.6g\n"
                 "Points per radius (x,y,z): %.4g, %.4g, %.4g\n--- Gaussian Spreading Parameters ---\ngauss_m: %.4g\ngauss_P: %d\n"
@@ -630,18 +585,17 @@ extern "C" int pse_set_box(pse_handle *h, double Lx, double Ly, double Lz, doubl
     // recomputes wave vectors per step, PSEv1/Stokes.cu:298); lengths may change only by re-deriving h.
     const Box nb{Lx, Ly, Lz, xy};
     const double gamma = std::max(std::fabs(xy), h->par.max_strain);
-    DCells nc;
-    TRY(cells_for(nb, near_radius(h), gamma, h->n_slabs, nc));
-    if ((size_t)cells_total(nc) > h->n_cells_alloc)
+    DCells nc, nc_narrow;
+    TRY(cells_for(nb, near_radius(h), gamma, h->n_slabs, h->tun.cell_bz, nc));
+    // prepare() switches to the narrow grid (cells of width rcut: more of them) whenever the kept list is suspended or off
+    TRY(cells_for(nb, h->d.rcut, gamma, h->n_slabs, h->tun.cell_bz, nc_narrow));
+    if ((size_t)std::max(cells_total(nc), cells_total(nc_narrow)) > h->n_cells_alloc)
         return fail(PSE_ERR_INVALID, "box grew beyond the cell-list capacity sized at creation");
     h->box = nb;
     h->nc = nc;
     h->cell_gamma = gamma;
     h->nc_wide = h->skin_max > 0.0;
     // the kept neighbour list is tied to the box it was built in: prepare() compares vl_box with the box of the call
-    h->mg.seen = 0;
-    if (h->mg.exec) { (void)hipGraphExecDestroy(h->mg.exec); h->mg.exec = nullptr; }
-    if (h->nb.cnt) { HIPCHK(hipSetDevice(h->device)); TRY(plan_blocks(h)); }
     h->d.hx = Lx / h->d.Nx; h->d.hy = Ly / h->d.Ny; h->d.hz = Lz / h->d.Nz;
     h->G.hx = h->d.hx; h->G.hy = h->d.hy; h->G.hz = h->d.hz;
     set_dbox(h);
@@ -673,8 +627,6 @@ extern "C" int pse_neighbor_stats(pse_handle *h, double *r_buff, unsigned long l
 extern "C" int pse_set_stream(pse_handle *h, void *stream) {
     if (!h) return fail(PSE_ERR_INVALID, "null handle");
     h->stream = (hipStream_t)stream;
-    h->mg.seen = 0;
-    if (h->mg.exec) { (void)hipGraphExecDestroy(h->mg.exec); h->mg.exec = nullptr; }
     if (!h->side_on) {
         h->wstream = h->stream;
         FFTCHK(rocfft_execution_info_set_stream(h->info_fwd, h->wstream));
@@ -987,14 +939,16 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
         const bool wide = h->nc_wide;
         if (wide != with_list) {
             DCells nc;
-            TRY(cells_for(h->box, h->d.rcut + (with_list ? h->skin_max : 0.0), h->cell_gamma, h->n_slabs, nc));
+            TRY(cells_for(h->box, h->d.rcut + (with_list ? h->skin_max : 0.0), h->cell_gamma, h->n_slabs, h->tun.cell_bz, nc));
             h->nc = nc; h->nc_wide = with_list;
             h->info.ncell_x = nc.nx; h->info.ncell_y = nc.ny; h->info.ncell_z = nc.nz;
         }
     }
     const int ncell = cells_total(h->nc);
-    cell_sort(pos, group, N, h->dbox, h->nc, h->keys, h->vals, h->keys_s, h->cell_cnt, ncell, h->sort_tmp, h->sort_tmp_bytes,
-              h->cell_off, h->perm, h->stream);
+    if ((size_t)ncell > h->n_cells_alloc)   // pse_create and pse_set_box check both cell grids: cannot happen, must not pass silently
+        return fail(PSE_ERR_INVALID, "cell grid %d x %d x %d exceeds the capacity sized at creation", h->nc.nx, h->nc.ny, h->nc.nz);
+    HIPCHK(cell_sort(pos, group, N, h->dbox, h->nc, h->keys, h->vals, h->keys_s, h->cell_cnt, ncell, h->sort_tmp, h->sort_tmp_bytes,
+                     h->cell_off, h->perm, h->stream));
     launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream);
     h->sorted_N = N;
     if (with_list) {   // the first cell pass of this call writes the list (real())
@@ -1029,7 +983,7 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
         double *gx = h->rgrid, *gy = h->rgrid + nr, *gz = h->rgrid + 2 * nr;
         TRY(tsw(h, PH_SPREAD));
         if (spread_needs_zero(G)) HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->wstream));
-        launch_spread(h->pos_s, h->f_s, h->sup_s, N, gx, gy, gz, G, h->dbox, h->sw, h->wstream);
+        HIPCHK(launch_spread(h->pos_s, h->f_s, h->sup_s, N, gx, gy, gz, G, h->dbox, h->sw, h->wstream));
         TRY(tew(h, PH_SPREAD));
         TRY(tsw(h, PH_FFTF));
         if (GS == 1) {
@@ -1095,9 +1049,8 @@ static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned t
         const DGrid &G = h->G;
         const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz;
         TRY(tsw(h, PH_GATHER));
-        launch_gather(h->pos_s, h->sw, N, h->rgrid, h->rgrid + nr, h->rgrid + 2 * nr, G, h->dbox, h->uw_s, h->wstream);
+        HIPCHK(launch_gather(h->pos_s, h->sw, N, h->rgrid, h->rgrid + nr, h->rgrid + 2 * nr, G, h->dbox, h->uw_s, h->wstream));
         TRY(tew(h, PH_GATHER));
-        HIPCHK(hipGetLastError());
     }
     // every particle was gathered by the rank that owns its row (zeros elsewhere)
     return 0;
@@ -1109,15 +1062,6 @@ static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*ou
                 bool build_list, bool with_psi = false) {
     for (pse_handle *h : T.m) {
         h->w_is_mpsi = false;
-        if (h->nb.blk.on) {
-            // cell blocks: the first mat-vec of a step scans the tiles and writes the step's pair list (2 bytes per pair), every
-            // later one applies it; with_psi: M_real psi in the same pass (the first Lanczos mat-vec comes free)
-            const bool build = !h->nb_valid;
-            launch_mreal_blocks(h->pos_s, h->*vec + vec_off, h->*out + out_off, nullptr, nullptr,
-                                h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, h->n_intervals, h->nb, build, LzFuse{}, h->stream);
-            h->nb_valid = true;
-            continue;
-        }
         int mode = MREAL_CELLS;
         if (h->nb.cap > 0) {
             if (h->nb_valid) mode = MREAL_USE_LIST;
@@ -1180,7 +1124,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
         for (; done < target; ++done) {
             // iteration j = done on the unnormalised x_j (psi for j = 0, else parked in V[j]); see k_lz_update
             const bool have_y = done == 0 && h0->w_is_mpsi;      // M psi came with the pass that built the pair list
-            const bool fused = !have_y && (h0->nb.cap > 0 || h0->nb.blk.on) && h0->nb_valid;   // sums fused into the pair-list mat-vec
+            const bool fused = !have_y && h0->nb.cap > 0 && h0->nb_valid;   // sums fused into the pair-list mat-vec
             const bool timed = done == 1 && fused;               // one pair-list mat-vec kernel per call is timed on its own
             if (!fused && !have_y) TRY(real(T, done == 0 ? &pse_handle::psi_s : &pse_handle::V, &pse_handle::w_s, (size_t)done * stride, 0, N, true));
             for (pse_handle *h : T.m) {
@@ -1190,13 +1134,6 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
                 const double4 *vjm1 = done > 0 ? h->V + (size_t)(done - 1) * stride : nullptr;
                 if (fused) {
                     const bool ev = timed && h->timing;
-                    if (h->nb.blk.on) {
-                        if (ev) HIPCHK(hipEventRecord(h->ph[PH_MATVEC].a, h->stream));
-                        launch_mreal_blocks(h->pos_s, xj, h->w_s, nullptr, nullptr, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef,
-                                            h->n_intervals, h->nb, false, LzFuse{vjm1, h->partials, h->npart_cap}, h->stream);
-                        if (ev) HIPCHK(hipEventRecord(h->ph[PH_MATVEC].b, h->stream));
-                        launch_lz_reduce3(h->partials, nb_blocks_count(h->nb.blk, h->nc, h->nb.blk.ncx), h->npart_cap, h->scal, h->stream);
-                    } else
                     launch_mreal_lanczos(h->pos_s, xj, h->w_s, lo, hi, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef,
                                          h->nb, LzFuse{vjm1, h->partials, h->npart_cap}, h->scal,
                                          ev ? h->ph[PH_MATVEC].a : nullptr, ev ? h->ph[PH_MATVEC].b : nullptr, h->stream,
@@ -1291,7 +1228,10 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
     for (size_t r = 0; r < T.m.size(); ++r) TRY(prepare(T.m[r], a[r].pos, a[r].force, group, N, true));
     *mask |= 1u << PH_SORT;
     const bool noise = kT > 0.0;
-    const bool lanes = T.G == 1 || !T.nccl || T.nccl_w;   // a process-per-rank team forks only with its second communicator
+    // A process-per-rank team keeps ONE stream and ONE communicator unless PSE_TEAM_OVERLAP=1 was set at pse_create: two
+    // communicators on independent streams have no cross-rank launch order (the documented RCCL deadlock hazard when both
+    // kernels cannot make progress at once), and no multi-GPU node has run this path yet.
+    const bool lanes = T.G == 1 || !T.nccl || T.nccl_w;
     for (pse_handle *h : T.m) {   // where the wave chain of this call runs
         // the two chains share the chip whenever nothing is timed per kernel: with phase timing on, every kernel runs alone
         // on one stream (those durations are the roofline evidence)
@@ -1372,59 +1312,10 @@ static int team_of_one(pse_handle *h, pse_team &T) {
     return 0;
 }
 
-// The deterministic evaluation of a single GPU as a hipGraph: the third consecutive call with the same arrays, size, parts and box
-// is captured (on an owned stream: the caller's may be the null stream), later ones replay it.  Nothing in the evaluation depends
-// on host-side values that change between calls (all sizes follow from N), so a replay is exactly the eager sequence.
-static int mobility_graph(pse_team &T, const std::vector<Args> &a, const unsigned *group, unsigned N, int parts, bool &done) {
-    done = false;
-    pse_handle *h = T.m[0];
-    auto &g = h->mg;
-    // Opt-in (PSE_GRAPH=1): measured on MI355X it does not pay -- with the two chains of an evaluation on two streams the GPU is
-    // never waiting for the host (BASELINE config 2: 0.45 ms replayed, 0.41 ms eager; metric point 2.7 vs 2.6 ms).
-    const char *env = getenv("PSE_GRAPH");
-    if (g.off || !env || atoi(env) <= 0 || T.G != 1 || T.m.size() != 1 || h->timing || roctx().push) return 0;
-    const bool same = g.pos == a[0].pos && g.force == a[0].force && g.vel == a[0].vel && g.group == group && g.N == N && g.parts == parts &&
-                      g.xy == h->box.xy && g.user == h->stream;
-    if (!same) {
-        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
-        g.pos = a[0].pos; g.force = a[0].force; g.vel = a[0].vel; g.group = group; g.N = N; g.parts = parts; g.xy = h->box.xy; g.user = h->stream;
-        g.seen = 1;
-        return 0;
-    }
-    if (g.exec) {
-        HIPCHK(hipGraphLaunch(g.exec, h->stream));
-        h->sorted_N = (int)N; h->nb_valid = false; h->w_is_mpsi = false;
-        done = true;
-        return 0;
-    }
-    if (++g.seen < 3) return 0;   // the first calls run eagerly (they also do the one-time set-up some launches need)
-    if (!g.cap) HIPCHK(hipStreamCreateWithFlags(&g.cap, hipStreamNonBlocking));
-    hipStream_t user = h->stream;
-    HIPCHK(hipStreamSynchronize(user));
-    h->stream = g.cap;
-    hipGraph_t graph = nullptr;
-    unsigned mask = 0;
-    int rc = 0;
-    if (hipStreamBeginCapture(g.cap, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = 1;
-    if (!rc) rc = velocity(T, a, group, (int)N, parts, 0.0, 1.0, 0, nullptr, &mask) ? 2 : 0;
-    if (rc != 1 && hipStreamEndCapture(g.cap, &graph) != hipSuccess) rc = rc ? rc : 3;
-    h->stream = user;
-    if (!rc && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess) { g.exec = nullptr; rc = 4; }
-    if (graph) (void)hipGraphDestroy(graph);
-    (void)hipGetLastError();
-    if (rc) { g.off = true; return 0; }   // capture is not possible here: stay eager
-    HIPCHK(hipGraphLaunch(g.exec, h->stream));
-    done = true;
-    return 0;
-}
-
 static int do_mobility(pse_team &T, const std::vector<Args> &a, const unsigned *group, unsigned N, int parts) {
     for (pse_handle *h : T.m) TRY(check_n(h, N));
     for (auto &x : a) if (!x.pos || !x.force || !x.vel) return fail(PSE_ERR_INVALID, "null array");
     if (!(parts & 3)) return fail(PSE_ERR_INVALID, "parts must select real (1), wave (2) or both (3)");
-    bool replayed = false;
-    TRY(mobility_graph(T, a, group, N, parts, replayed));
-    if (replayed) return 0;
     unsigned mask = 1u << PH_TOTAL;
     for (pse_handle *h : T.m) TRY(ts(h, PH_TOTAL));
     TRY(velocity(T, a, group, (int)N, parts, 0.0, 1.0, 0, nullptr, &mask));
@@ -1573,8 +1464,7 @@ extern "C" int pse_debug_spread(pse_handle *h, const pse_double4 *pos, const pse
     const DGrid &G = h->G;
     const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz;
     if (spread_needs_zero(G)) HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->stream));
-    launch_spread(h->pos_s, h->f_s, h->sup_s, (int)N, h->rgrid, h->rgrid + nr, h->rgrid + 2 * nr, G, h->dbox, h->sw, h->stream);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_spread(h->pos_s, h->f_s, h->sup_s, (int)N, h->rgrid, h->rgrid + nr, h->rgrid + 2 * nr, G, h->dbox, h->sw, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -1611,7 +1501,9 @@ static int team_connect(pse_team *T, const void *id128_host) {
     HIPCHK(hipSetDevice(T->m[0]->device));
     NCCLCHK(ncclCommInitRank(&T->nccl, T->G, id, T->m[0]->slab_rank));
     // a second communicator for the far-field chain: its all-to-alls run on the side stream next to the Lanczos exchanges
-    if (T->G > 1 && ncclCommSplit(T->nccl, 0, T->m[0]->slab_rank, &T->nccl_w, nullptr) != ncclSuccess) T->nccl_w = nullptr;
+    // (opt-in, PSE_TEAM_OVERLAP=1 at pse_create: see velocity())
+    if (T->G > 1 && T->m[0]->tun.team_overlap && ncclCommSplit(T->nccl, 0, T->m[0]->slab_rank, &T->nccl_w, nullptr) != ncclSuccess)
+        T->nccl_w = nullptr;
     return 0;
 }
 
@@ -1647,6 +1539,9 @@ extern "C" int pse_team_create(pse_handle **members, int n_members, const void *
 
 extern "C" int pse_team_destroy(pse_team *T) {
     if (!T) return 0;
+    for (pse_handle *h : T->m) {   // members take their own side stream back (an in-process team shared member 0's)
+        if (h->side != h->side_owned) { h->side = h->side_owned; h->side_on = false; h->wstream = h->stream; }
+    }
     if (T->nccl_w) ncclCommDestroy(T->nccl_w);
     if (T->nccl) ncclCommDestroy(T->nccl);
     if (T->scratch) (void)hipFree(T->scratch);

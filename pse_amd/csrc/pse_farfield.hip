@@ -167,16 +167,19 @@ k_far_records(const int4 *__restrict__ sup_s, const double4 *__restrict__ d0_s, 
     o[3] = make_double2(G.prefac * F.y, G.prefac * F.z);
 }
 
-static void build_records(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, DGrid G, DBox box, SpreadWork &w,
-                          FarBins &fb, hipStream_t s) {
+static hipError_t build_records(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, DGrid G, DBox box, SpreadWork &w,
+                                FarBins &fb, hipStream_t s) {
     fb = w.fb;
     fb.nbx = bins_of(G.Nx); fb.nby = bins_of(G.Ny); fb.nbz = bins_of(G.Nz);
     const int nbins = fb.nbx * fb.nby * fb.nbz;
-    (void)hipMemsetAsync(fb.cnt, 0, (size_t)(nbins + 1) * sizeof(int), s);
+    hipError_t e = hipMemsetAsync(fb.cnt, 0, (size_t)(nbins + 1) * sizeof(int), s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_support, dim3(nblocks(N, 256)), dim3(256), 0, s, pos_s, N, G, box, sup_s, w.d0_s, fb);
     size_t tb = fb.tmp_bytes;
-    (void)hipcub::DeviceScan::ExclusiveSum(fb.tmp, tb, fb.cnt, fb.off, nbins + 1, s);   // cnt[nbins] = 0: off[nbins] = total
+    e = hipcub::DeviceScan::ExclusiveSum(fb.tmp, tb, fb.cnt, fb.off, nbins + 1, s);   // cnt[nbins] = 0: off[nbins] = total
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_far_records, dim3(nblocks(N, 256)), dim3(256), 0, s, sup_s, w.d0_s, f_s, N, G, fb, w.rec_t);
+    return hipSuccess;
 }
 
 // ---- spread ------------------------------------------------------------------------------------------------------
@@ -438,8 +441,7 @@ k_spread_atomic(const double4 *__restrict__ pos_s, const double4 *__restrict__ f
     }
 }
 
-static int spread_tz(const DGrid &G) {
-    static const int force = getenv("PSE_SPREAD_TZ") ? atoi(getenv("PSE_SPREAD_TZ")) : 0;
+static int spread_tz(const DGrid &G, int force) {
     if (force == 8 || force == 16) return G.Nz >= 2 * force ? force : 8;
     // a wave per block: small grids need the smaller blocks to occupy the chip at all
     const long blocks16 = (long)((G.nxl + 7) / 8) * ((G.Ny + 7) / 8) * ((G.Nz + 15) / 16);
@@ -466,30 +468,30 @@ static void launch_spread_pt(const FarRec *rec, FarBins fb, double *gx, double *
 constexpr int SPREAD_NW = 4;   // waves per block on small grids
 template <int P>
 static void launch_spread_p(const FarRec *rec, FarBins fb, double *gx, double *gy, double *gz, const DGrid &G, const GaussConsts &gc,
-                            hipStream_t s) {
-    static const int nw_env = getenv("PSE_SPREAD_NW") ? atoi(getenv("PSE_SPREAD_NW")) : 0;
+                            int force_tz, int nw_env, hipStream_t s) {
     const long blocks8 = (long)((G.nxl + 7) / 8) * ((G.Ny + 7) / 8) * ((G.Nz + 7) / 8);
-    if (spread_tz(G) == 16) launch_spread_pt<P, 16, 1>(rec, fb, gx, gy, gz, G, gc, s);
+    if (spread_tz(G, force_tz) == 16) launch_spread_pt<P, 16, 1>(rec, fb, gx, gy, gz, G, gc, s);
     else if (P <= 8 && (nw_env ? nw_env > 1 : blocks8 < 1024)) launch_spread_pt<P, 8, SPREAD_NW>(rec, fb, gx, gy, gz, G, gc, s);   // fewer blocks than SIMDs
     else launch_spread_pt<P, 8, 1>(rec, fb, gx, gy, gz, G, gc, s);
 }
 
-void launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, double *gx, double *gy, double *gz, DGrid G,
-                   DBox box, SpreadWork w, hipStream_t s) {
+hipError_t launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, double *gx, double *gy, double *gz, DGrid G,
+                         DBox box, SpreadWork w, hipStream_t s) {
     if (!farfield_fast_path(G) || !w.rec_t) {
         hipLaunchKernelGGL(k_spread_atomic, dim3(nblocks(N, 4)), dim3(256), 0, s, pos_s, f_s, N, gx, gy, gz, G, box);
-        return;
+        return hipGetLastError();
     }
     FarBins fb;
-    build_records(pos_s, f_s, sup_s, N, G, box, w, fb, s);
+    if (hipError_t e = build_records(pos_s, f_s, sup_s, N, G, box, w, fb, s); e != hipSuccess) return e;
     const GaussConsts gc = gauss_consts(G, box.xy);
     switch (G.P) {
-#define PSE_SPREAD_CASE(PV) case PV: launch_spread_p<PV>(w.rec_t, fb, gx, gy, gz, G, gc, s); break;
+#define PSE_SPREAD_CASE(PV) case PV: launch_spread_p<PV>(w.rec_t, fb, gx, gy, gz, G, gc, w.force_tz, w.force_nw, s); break;
         PSE_SPREAD_CASE(4) PSE_SPREAD_CASE(5) PSE_SPREAD_CASE(6) PSE_SPREAD_CASE(7) PSE_SPREAD_CASE(8) PSE_SPREAD_CASE(9)
         PSE_SPREAD_CASE(10) PSE_SPREAD_CASE(11) PSE_SPREAD_CASE(12) PSE_SPREAD_CASE(13)
-        default: launch_spread_p<14>(w.rec_t, fb, gx, gy, gz, G, gc, s); break;
+        default: launch_spread_p<14>(w.rec_t, fb, gx, gy, gz, G, gc, w.force_tz, w.force_nw, s); break;
 #undef PSE_SPREAD_CASE
     }
+    return hipGetLastError();
 }
 
 // ---- gather ------------------------------------------------------------------------------------------------------
@@ -703,18 +705,18 @@ static void launch_gather_p(const FarRec *rec, FarBins fb, int bx0, int nbx_l, c
     else hipLaunchKernelGGL((k_gather_bins<P, false>), g, b, 0, s, rec, fb, dz, dy, bx0, gx, gy, gz, G, gc, u_s);
 }
 
-void launch_gather(const double4 *pos_s, SpreadWork w, int N, const double *gx, const double *gy, const double *gz, DGrid G,
-                   DBox box, double4 *u_s, hipStream_t s) {
+hipError_t launch_gather(const double4 *pos_s, SpreadWork w, int N, const double *gx, const double *gy, const double *gz, DGrid G,
+                         DBox box, double4 *u_s, hipStream_t s) {
     if (!farfield_fast_path(G) || !w.rec_t || (G.Nz & 1)) {
         hipLaunchKernelGGL(k_gather, dim3(nblocks(N, 4)), dim3(256), 0, s, pos_s, N, gx, gy, gz, G, box, u_s);
-        return;
+        return hipGetLastError();
     }
     FarBins fb = w.fb;
     fb.nbx = bins_of(G.Nx); fb.nby = bins_of(G.Ny); fb.nbz = bins_of(G.Nz);
     int bx0 = 0, nbx_l = fb.nbx;
     if (G.nxl < G.Nx) {
         // a slab rank gathers the particles of its own planes (zeros elsewhere): their origins lie in [x0 - hl - 1, x0 + nxl)
-        (void)hipMemsetAsync(u_s, 0, (size_t)N * sizeof(double4), s);
+        if (hipError_t e = hipMemsetAsync(u_s, 0, (size_t)N * sizeof(double4), s); e != hipSuccess) return e;
         const int olo = ((G.x0 - G.hl - 1) % G.Nx + G.Nx) % G.Nx, ohi = (G.x0 + G.nxl - 1) % G.Nx;
         bx0 = olo / BIN;
         nbx_l = std::min(fb.nbx, ((ohi / BIN - bx0) % fb.nbx + fb.nbx) % fb.nbx + 1);
@@ -727,6 +729,7 @@ void launch_gather(const double4 *pos_s, SpreadWork w, int N, const double *gx, 
         default: launch_gather_p<14>(w.rec_t, fb, bx0, nbx_l, gx, gy, gz, G, gc, u_s, s); break;
 #undef PSE_GATHER_CASE
     }
+    return hipGetLastError();
 }
 
 }  // namespace pse

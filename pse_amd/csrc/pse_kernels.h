@@ -11,7 +11,7 @@ namespace pse {
 // counting sort by cell, equal to a stable sort by key: perm[slot] = input index, cell_off[c] = first slot of cell c.
 // keys, rank, slots: N unsigned each; cnt: ncell + 1 ints; tmp: cell_sort_temp_bytes(ncell)
 size_t cell_sort_temp_bytes(size_t ncell);
-void cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys, unsigned *rank,
+hipError_t cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys, unsigned *rank,
                unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s);
 // pos_s[i] = wrapped position of particle perm[i], vec_s[i] = vec[tag].xyz, tag_s[i] = its index in the caller's arrays
 // pos_build (nullable): the sorted positions the neighbour list was built at; a particle that has moved more than
@@ -26,23 +26,10 @@ void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double
 // contiguous 5120-byte group [64 lanes][4 x u32 (neighbour slot | image code << 27)][4 slots][64 x (f64 f, f64 h)], groups
 // of one wave back to back -- a wave streams one contiguous region with 16-byte loads only.
 // Row r = i - lo (lo: first row of the rank, fixed within a step); record (r / 64) * cap + slot.
-// Cell blocks of the near field (pse_nearfield.hip): a workgroup owns bx x by x bz cells, stages them and their one-cell halo in
-// LDS and keeps, per step, a pair list of 2-byte indices into that tile.
-struct NbBlocks {
-    int on;                    // 1: in use (every axis has >= 3 cells); 0: the legacy kernels below
-    int bx, by, bz;            // cells per block
-    int cap_st;                // particles a tile holds (LDS)
-    int cap;                   // list slots per lane
-    int tpr;                   // lanes per row (1, 2, 4): few long rows are split
-    int cx0, ncx;              // the rank's cell layers along x
-    unsigned short *list;      // [blocks][cap][256] tile index of the neighbour
-    double2 *fh;               // [blocks][cap][256] f(r), (g(r) - f(r))/r^2 of the pair
-};
 struct NbList {
     char *data;
     int *cnt;             // neighbour count per particle; -1 if it exceeded cap (dense cluster): that row walks the cells
     int cap;
-    NbBlocks blk;
 };
 // Neighbour (Verlet) list kept ACROSS steps, as the reference keeps HOOMD's NeighborListGPUBinned(rcut, r_buff = 0.4) with a
 // distance check every step (PSEv1/integrate.py:60,79; Stokes.cc:433): every pair closer than rcut + skin when it was built.
@@ -81,12 +68,6 @@ void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w
                           const double2 *pv = nullptr,    // packed (position, vector) records holding vec_s, or null
                           VerletList vl = VerletList{});  // in use this step: rows that overflowed the pair list walk it instead of the cells
 int mreal_partials_needed(int rows);
-// cell-block near field
-void nb_blocks_plan(NbBlocks &B, const DCells &nc, int ncx, double n, int slots_needed, int nint);
-int nb_blocks_count(const NbBlocks &B, const DCells &nc, int ncx);
-void launch_mreal_blocks(const double4 *pos_s, const double4 *vec_s, double4 *out_s, const double4 *vec2_s, double4 *out2_s,
-                         const int *cell_off, DBox box, DCells nc, double rcut, double self, const double *coef, int nint, NbList nb,
-                         bool build, LzFuse lz, hipStream_t s);
 void launch_lz_reduce3(const double *partials, int npart, int cap, double *scal, hipStream_t s);
 
 // ---- far field (K2-K8) -----------------------------------------------------------------------------------
@@ -104,6 +85,7 @@ struct SpreadWork {
     double4 *d0_s;              // [N] offset of the support origin from the particle, grid units (cell order)
     FarBins fb;
     FarRec *rec_t;              // [N] bin order: origin, sorted index (bit 31: owned by another slab rank), offset, prefac * force
+    int force_tz, force_nw;     // tuning switches of the handle (0: automatic): z depth of a spread block, waves per block
 };
 // per-step constants of the separable Gaussian weights: step ratios r_t = exp(-c h^2 (2t+1)) (y with the (1 + xy^2) of the
 // sheared lattice), ln K = -2 c xy hx hy, the tilt
@@ -112,7 +94,7 @@ struct GaussConsts { double rx[FAR_PMAX - 1], ry[FAR_PMAX - 1], rz[FAR_PMAX - 1]
 size_t farfield_bins(const DGrid &G);
 // true if the caller must zero the grids first (atomic fallback: P outside 4..8 or a grid smaller than two tiles)
 bool spread_needs_zero(const DGrid &G);
-void launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, double *gx, double *gy, double *gz, DGrid G,
+hipError_t launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, double *gx, double *gy, double *gz, DGrid G,
                    DBox box, SpreadWork w, hipStream_t s);
 struct ScaleArgs {
     double xi, eta;
@@ -127,7 +109,7 @@ void launch_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleAr
 bool xfuse_supported(int Nx);
 void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s);
 // the fast path reads the records written by launch_spread of the same step
-void launch_gather(const double4 *pos_s, SpreadWork w, int N, const double *gx, const double *gy, const double *gz, DGrid G,
+hipError_t launch_gather(const double4 *pos_s, SpreadWork w, int N, const double *gx, const double *gy, const double *gz, DGrid G,
                    DBox box, double4 *u_s, hipStream_t s);
 
 // ---- slab decomposition helpers

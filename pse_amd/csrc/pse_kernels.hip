@@ -76,13 +76,17 @@ size_t cell_sort_temp_bytes(size_t ncell) {
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int *)nullptr, (int *)nullptr, (int)(ncell + 1));
     return bytes;
 }
-void cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys, unsigned *rank,
-               unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s) {
-    (void)hipMemsetAsync(cnt, 0, (size_t)(ncell + 1) * sizeof(int), s);
+hipError_t cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys, unsigned *rank,
+                     unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(cnt, 0, (size_t)(ncell + 1) * sizeof(int), s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_cell_keys, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, group, N, box, nc, keys, rank, cnt);
-    (void)hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt, cell_off, ncell + 1, s);   // cnt[ncell] = 0: cell_off[ncell] = N
+    // cnt[ncell] = 0: cell_off[ncell] = N.  A failed scan (scratch too small for ncell) would leave garbage offsets: reported
+    e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt, cell_off, ncell + 1, s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_cell_scatter, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, keys, rank, cell_off, N, slots);
     hipLaunchKernelGGL(k_cell_order, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, cell_off, keys, N, slots, perm);
+    return hipGetLastError();
 }
 
 __global__ void k_permute(const double4 *__restrict__ pos, const double4 *__restrict__ vec,
@@ -669,17 +673,15 @@ void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w
     const int nbk = nblocks(std::max(hi - lo, 1), TPB);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     // Four waves per block of 64 rows, each taking every fourth group of slots: 0.166 ms against 0.191 with four blocks of rows
-    // per workgroup (two waves: 0.182, eight: 0.196).  PSE_LIST_SPLIT=0 selects the one-wave-per-block kernel.
-    static const bool split = !(getenv("PSE_LIST_SPLIT") && atoi(getenv("PSE_LIST_SPLIT")) == 0);
-    if (pv && split) {
+    // per workgroup (two waves: 0.182, eight: 0.196).
+    if (pv) {
         const int nb64 = nblocks(std::max(hi - lo, 1), 64);
         hipLaunchKernelGGL((k_mreal_list<true, 4, 256, true, 4>), dim3(nb64), dim3(256), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, pv, cell_off, nc, rcut * rcut, coef, vl);
         if (ev_end) (void)hipEventRecord(ev_end, s);
         launch_lz_reduce3(lz.partials, nb64, lz.npart_cap, scal, s);
         return;
     }
-    if (pv) hipLaunchKernelGGL((k_mreal_list<true, 4, TPB, true>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, pv, cell_off, nc, rcut * rcut, coef, vl);
-    else hipLaunchKernelGGL((k_mreal_list<true, 4, TPB, false>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, nullptr, cell_off, nc, rcut * rcut, coef, vl);
+    hipLaunchKernelGGL((k_mreal_list<true, 4, TPB, false>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, nullptr, cell_off, nc, rcut * rcut, coef, vl);
     if (ev_end) (void)hipEventRecord(ev_end, s);
     hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, lz.partials, nbk, lz.npart_cap, 3, scal);
 }
@@ -1424,25 +1426,9 @@ void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, Sc
         case 32: launch_xfft_t<5, 8, 256>(X, Y, Z, G, box, a, tw, s); break;
         case 64: launch_xfft_t<6, 8, 256>(X, Y, Z, G, box, a, tw, s); break;
         case 128: launch_xfft_t<7, 8, 512>(X, Y, Z, G, box, a, tw, s); break;
-        case 256: {
-            static const int cfg = getenv("PSE_XFUSE_CFG") ? atoi(getenv("PSE_XFUSE_CFG")) : 0;
-            if (cfg == 1) launch_xfft_t<8, 8, 1024>(X, Y, Z, G, box, a, tw, s);
-            else if (cfg == 2) launch_xfft_t<8, 6, 512>(X, Y, Z, G, box, a, tw, s);
-            else if (cfg == 3) launch_xfft_t<8, 4, 512>(X, Y, Z, G, box, a, tw, s);
-            else if (cfg == 4) launch_xfft_t<8, 2, 256>(X, Y, Z, G, box, a, tw, s);
-            else if (cfg == 5) launch_xfft_t<8, 4, 256>(X, Y, Z, G, box, a, tw, s);
-            else if (cfg == 6) launch_xfft256<8, 512, 2>(X, Y, Z, G, box, a, tw, s);
-            else if (cfg == 7) launch_xfft256<4, 256, 3>(X, Y, Z, G, box, a, tw, s);
-            else launch_xfft256<4, 256, 2>(X, Y, Z, G, box, a, tw, s);   // two radix-16 passes in registers
-            break;
-        }
-        default: {   // 512
-            static const int cfg = getenv("PSE_XFUSE_CFG") ? atoi(getenv("PSE_XFUSE_CFG")) : 0;
-            if (cfg == 1) launch_xfft_t<9, 4, 1024>(X, Y, Z, G, box, a, tw, s);
-            else if (cfg == 2) launch_xfft256<4, 384, 1, 512>(X, Y, Z, G, box, a, tw, s);
-            else launch_xfft256<2, 256, 1, 512>(X, Y, Z, G, box, a, tw, s);   // radix 16, 16, 2; two kz columns: three workgroups per CU (3.3 ms at 512^3; four columns, one workgroup: 3.8; radix 4/2 in LDS: 5.2)
-            break;
-        }
+        case 256: launch_xfft256<4, 256, 2>(X, Y, Z, G, box, a, tw, s); break;   // two radix-16 passes in registers
+        // 512: radix 16, 16, 2; two kz columns: three workgroups per CU (3.3 ms at 512^3; four columns, one workgroup: 3.8; radix 4/2 in LDS: 5.2)
+        default: launch_xfft256<2, 256, 1, 512>(X, Y, Z, G, box, a, tw, s); break;
     }
 }
 

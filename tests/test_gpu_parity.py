@@ -361,27 +361,13 @@ def test_pair_repulsion_matches_port(torch_cuda, oracle, xy):
         eng.pair_repulsion(to4(pos), f, 40.0, 2.0 * eng.info()["rcut"])
 
 
-def test_cell_block_near_field_opt_in(torch_cuda):
-    """The LDS-tile near field (PSE_NEAR_BLOCKS=1, off by default: measured slower) against the same checks as
-    the default path: the switch is read once per process, so the checks run in a child process."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, PSE_NEAR_BLOCKS="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"), "-k",
-                        "mreal_matches_oracle or lanczos_sqrt or pair_list_overflow or brownian_velocity_matches_port or step_integrates"],
-                       env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    assert r.returncode == 0, r.stdout[-3000:]
-
-
 @pytest.mark.parametrize("bz", ["0", "2"])
 def test_cell_storage_orders(torch_cuda, bz):
     """The cells are stored in blocks of b along z (x, z block, y, z in block; default b = 6 where an axis has at least twelve
     cells) so that a wavefront's rows form a squat brick; PSE_CELL_BZ=0 is the plain (x, y, z) order.  Every near-field path
     (cell pass, pair list, overflow rows, kept neighbour list, pair repulsion) must give the same answers in either (the test
-    boxes have 6-8 cells per axis: default = plain there, so b = 2 is what exercises the blocks).  The switch is read once per
-    process: the checks run in a child."""
+    boxes have 6-8 cells per axis: default = plain there, so b = 2 is what exercises the blocks).  The switch is read at pse_create;
+    the checks run in a child process with it set."""
     import os
     import subprocess
     import sys
@@ -393,29 +379,3 @@ def test_cell_storage_orders(torch_cuda, bz):
                         "or reused_list or overflow_rows"],
                        env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
-
-
-@pytest.mark.parametrize("n,grid", [(4000, 0), (65_536, 64)])
-def test_mobility_graph_replay_matches_eager(torch_cuda, n, grid):
-    """pse_mobility called again and again on the same arrays is captured into a hipGraph on the third call and replayed from
-    then on; the arrays' CONTENTS may change between calls.  Replays must equal eager evaluations (a second engine that is
-    always handed fresh arrays never leaves the eager path)."""
-    import math
-    import os
-    import torch
-    import pse_amd
-    os.environ["PSE_GRAPH"] = "1"          # opt-in switch, read at every call
-    pos, force, box = make_suspension(n, phi=0.1)
-    kw = dict(xi=0.5, error=1e-3) if not grid else dict(xi=math.pi * grid / (2.0 * box[0] * math.sqrt(-math.log(1e-3))), error=1e-3, grid=(grid,) * 3)
-    a, b = pse_amd.Engine(n, box, **kw), pse_amd.Engine(n, box, **kw)
-    dpos, dF, vel = to4(pos), to4(force), to4(np.zeros((n, 3)), 1.0)
-    rng = np.random.default_rng(3)
-    for it in range(6):
-        if it:   # new contents, same arrays
-            dpos[:, :3] += torch.tensor(rng.normal(scale=0.05, size=(n, 3)), device="cuda")
-            dF[:, :3] = torch.tensor(rng.normal(size=(n, 3)), device="cuda")
-        a.mobility(dpos, dF, vel=vel)
-        ref = b.mobility(dpos.clone(), dF.clone())
-        assert torch.equal(vel[:, 3], torch.ones(n, dtype=torch.float64, device="cuda"))
-        assert rel(vel.cpu().numpy()[:, :3], ref.cpu().numpy()[:, :3]) < 1e-12, it
-    os.environ.pop("PSE_GRAPH", None)

@@ -148,6 +148,12 @@ int pse_debug_copy_grid(pse_handle *h, int stage, double *host_out);
  * pse_debug_copy_grid, so the spread can be compared node by node and not only through the gather */
 int pse_debug_spread(pse_handle *h, const pse_double4 *pos, const pse_double4 *force, const unsigned int *group_members,
                      unsigned int N);
+/* the k-space operator of n grid nodes (i, j, k) (host array of 3 n ints, 0 <= k < Nz: any node of the reference's full C2C
+ * grid) exactly as the scaling kernels evaluate it, for the current box: out_host[5 t ..] = kx, ky, kz, w sinc^2,
+ * sqrt(w) sinc -- what gpu_stokes_SetGridk_kernel tabulates (PSEv1/Helper.cu:285-332: index folding, sheared ky, scale
+ * factor w) and gpu_stokes_Green_kernel / gpu_stokes_BrownianGridGenerate_kernel multiply by (PSEv1/Mobility.cu:290,
+ * PSEv1/Brownian.cu:274-276) */
+int pse_debug_kvector(pse_handle *h, int n, const int *ijk_host, double *out_host);
 
 /* -- multi-GPU: slab-decomposed far field + row-sharded near field (new design; the reference is single-GPU,
  *    PSEv1/Stokes.cc:104) ---------------------------------------------------------------------------------------

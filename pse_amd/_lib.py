@@ -70,6 +70,7 @@ SYMBOLS = {
     "pse_eval_realspace": (_i, [_vp, _dp, _i, _dp, _dp]),
     "pse_debug_copy_grid": (_i, [_vp, _i, _dp]),
     "pse_debug_spread": (_i, [_vp, _vp, _vp, _vp, _u]),
+    "pse_debug_kvector": (_i, [_vp, _i, _ip, _dp]),
     "pse_team_unique_id": (_i, [_vp]),
     "pse_team_create": (_i, [ctypes.POINTER(_vp), _i, _vp, ctypes.POINTER(_vp)]),
     "pse_team_destroy": (_i, [_vp]),

@@ -1456,6 +1456,29 @@ extern "C" int pse_eval_realspace(pse_handle *h, const double *r_host, int n, do
     return 0;
 }
 
+extern "C" int pse_debug_kvector(pse_handle *h, int n, const int *ijk_host, double *out_host) {
+    if (!h || !ijk_host || !out_host || n <= 0) return fail(PSE_ERR_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    for (int t = 0; t < n; ++t)
+        if (ijk_host[3 * t] < 0 || ijk_host[3 * t] >= h->G.Nx || ijk_host[3 * t + 1] < 0 || ijk_host[3 * t + 1] >= h->G.Ny ||
+            ijk_host[3 * t + 2] < 0 || ijk_host[3 * t + 2] >= h->G.Nz)
+            return fail(PSE_ERR_INVALID, "node %d outside the %d x %d x %d grid", t, h->G.Nx, h->G.Ny, h->G.Nz);
+    int *d_ijk = nullptr;
+    double *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_ijk, (size_t)3 * n * sizeof(int)));
+    hipError_t e = hipMalloc((void **)&d_out, (size_t)5 * n * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(d_ijk, ijk_host, (size_t)3 * n * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_debug_kop(d_ijk, n, h->G, h->dbox, h->d.xi, h->d.eta, d_out, h->stream);
+        e = hipStreamSynchronize(h->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out_host, d_out, (size_t)5 * n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d_ijk);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(PSE_ERR_HIP, "pse_debug_kvector: %s", hipGetErrorString(e));
+    return 0;
+}
+
 extern "C" int pse_debug_spread(pse_handle *h, const pse_double4 *pos, const pse_double4 *force, const unsigned *group, unsigned N) {
     TRY(check_n(h, N));
     if (!pos || !force) return fail(PSE_ERR_INVALID, "null array");

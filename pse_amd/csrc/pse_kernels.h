@@ -105,6 +105,8 @@ struct ScaleArgs {
     int y0, nyl;             // slab of y rows in transposed layout
 };
 void launch_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, hipStream_t s);
+// debug: kx, ky, kz, w sinc^2, sqrt(w) sinc of n nodes (i, j, k)
+void launch_debug_kop(const int *ijk, int n, DGrid G, DBox box, double xi, double eta, double *out, hipStream_t s);
 // fused forward-x FFT + scale + inverse-x FFT on [3][Nx][Ny][Nzh] (Nx a power of two, 16..512); tw[m] = exp(-2 pi i m/Nx)
 bool xfuse_supported(int Nx);
 void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s);

@@ -754,11 +754,14 @@ __device__ __forceinline__ void scale_node(int i, int j, int k, const double2 f[
                                            const ScaleArgs &a, double2 out[3]) {
     out[0] = out[1] = out[2] = make_double2(0, 0);
     if (i == 0 && j == 0 && k == 0) return;   // k = 0 mode is dropped (Helper.cu:321-323, Mobility.cu:287)
-    // Hermitian bookkeeping: on the planes kz = 0 and kz = Nz/2 (even Nz) node (i,j) and its partner (-i,-j) must
-    // carry conjugate values. The reference writes both explicitly and keeps the real part after a C2C inverse
-    // (PSEv1/Mobility.cu:447); the equivalent for a C2R inverse is to apply the symmetrised operator
-    // (S(k_node) + S(k_partner))/2, because the index-folding convention gives the Nyquist lines k vectors that
-    // are not exact negatives of each other.
+    // Hermitian bookkeeping.  The reference fills the FULL complex grid, every node with the folded wave vector of its own index
+    // (PSEv1/Helper.cu:307-315), transforms back with a C2C FFT and keeps the real part (PSEv1/Mobility.cu:447) -- i.e. the
+    // Hermitian part 1/2 (G(k) + conj G(partner)) of what it wrote.  The equivalent on the half spectrum of a C2R inverse is the
+    // symmetrised operator (S(k_node) + S(k_partner)) / 2, k_partner the folded wave vector of index (-i, -j, -k) mod N.
+    // Wherever an index is a Nyquist index (even N) the folding gives node and partner the SAME sign in that component, so the
+    // two operators differ (a whole x line for j = Ny/2, a node per line for i = Nx/2, the plane kz = Nz/2); elsewhere
+    // k_partner = -k_node, S is even in k, and one evaluation serves.  Held to the reference's kernels by
+    // tests/golden/reference_kernels.json.gz (Green and noise, even / odd / mixed grids).
     const bool plane = (k == 0) || ((G.Nz % 2 == 0) && (k == G.Nz / 2));
     const int ip = (G.Nx - i) % G.Nx, jp = (G.Ny - j) % G.Ny;
     double2 psi[3] = {{0, 0}, {0, 0}, {0, 0}};
@@ -784,13 +787,28 @@ __device__ __forceinline__ void scale_node(int i, int j, int k, const double2 f[
         }
     }
     const KOp o1 = make_kop(i, j, k, G, box, a.xi, a.eta, a.noise_fac);
-    if (plane) {
-        const KOp o2 = make_kop(ip, jp, k, G, box, a.xi, a.eta, a.noise_fac);
+    const bool nyq = plane || ((G.Nx % 2 == 0) && (i == G.Nx / 2)) || ((G.Ny % 2 == 0) && (j == G.Ny / 2));
+    if (nyq) {
+        const KOp o2 = make_kop(ip, jp, (G.Nz - k) % G.Nz, G, box, a.xi, a.eta, a.noise_fac);
         apply_kop(o1, f, psi, a.noise, 0.5, out);
         apply_kop(o2, f, psi, a.noise, 0.5, out);
     } else {
         apply_kop(o1, f, psi, a.noise, 1.0, out);
     }
+}
+
+// debug: the k-space operator of given nodes (i, j, k) as the scaling kernels evaluate it: kx, ky, kz, B = w sinc^2,
+// c / noise_fac = sqrt(w) sinc  (what K1 gpu_stokes_SetGridk_kernel tabulates and K5 / K6 apply, PSEv1/Helper.cu:300-327)
+__global__ void k_debug_kop(const int *__restrict__ ijk, int n, DGrid G, DBox box, double xi, double eta, double *__restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int i = ijk[3 * t], j = ijk[3 * t + 1], k = ijk[3 * t + 2];
+    KOp o = make_kop(i, j, k, G, box, xi, eta, 1.0);
+    if (i == 0 && j == 0 && k == 0) { o.B = 0.0; o.c = 0.0; }
+    out[5 * t] = o.kx; out[5 * t + 1] = o.ky; out[5 * t + 2] = o.kz; out[5 * t + 3] = o.B; out[5 * t + 4] = o.c;
+}
+void launch_debug_kop(const int *ijk, int n, DGrid G, DBox box, double xi, double eta, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_debug_kop, dim3(nblocks(n, TPB)), dim3(TPB), 0, s, ijk, n, G, box, xi, eta, out);
 }
 
 __global__ void __launch_bounds__(TPB)

@@ -183,6 +183,15 @@ class Engine:
         _lib.check(self._lib.pse_debug_spread(self._h, _ptr(pos), _ptr(force), _ptr(group), n))
         return self.debug_grid()
 
+    def debug_kvector(self, ijk):
+        """(n, 5): kx, ky, kz, w sinc^2, sqrt(w) sinc of the grid nodes ijk (n, 3) as the k-space kernels evaluate them."""
+        import numpy as np
+        ijk = np.ascontiguousarray(ijk, dtype=np.int32)
+        out = np.zeros((len(ijk), 5))
+        _lib.check(self._lib.pse_debug_kvector(self._h, len(ijk), ijk.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                                               out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+        return out
+
     def debug_grid(self):
         import numpy as np
         i = self.info()

@@ -46,14 +46,7 @@ def _worker(rank, world, port, out):
             recv[c] = b.numpy()
         tr = recv.reshape(3, Nx, nyl, Nzh)                                      # [3][Nx][nyl][Nzh], x-major
         tr = np.fft.fft(tr, axis=1)
-        kx, ky, kz, k2, w, sinc = pp.kvectors(box, p)
-        sl = (slice(None), slice(y0, y0 + nyl), slice(None))
-        with np.errstate(divide="ignore", invalid="ignore"):
-            kd = (kx[sl] * tr[0] + ky[sl] * tr[1] + kz[sl] * tr[2]) / k2[sl]
-        if y0 == 0:
-            kd[0, 0, 0] = 0.0
-        B = (w * sinc * sinc)[sl]
-        tr = np.stack([(tr[0] - kx[sl] * kd) * B, (tr[1] - ky[sl] * kd) * B, (tr[2] - kz[sl] * kd) * B])
+        tr = pp.wave_scale(tr, box, p, y0=y0, nyl=nyl)                         # the k-space operator on this rank's y rows
         tr = np.fft.ifft(tr, axis=1) * Nx                                       # unnormalised inverse
         back = np.empty_like(pack)
         send = tr.reshape(3, world, nxl, nyl, Nzh)

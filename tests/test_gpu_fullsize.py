@@ -237,3 +237,58 @@ def test_four_rank_team_at_metric_point():
     assert rel(vels[1].cpu().numpy()[:, :3], v_ref) < 1e-10 and rel(vels[2].cpu().numpy()[:, :3], v_ref) < 1e-10
     del sim
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("n,phi,grid,xy", [(1_000_000, 0.1, 256, 0.0),      # the metric point
+                                           (1_048_576, 0.2, 256, 0.3),      # config 3 geometry, sheared (config 5)
+                                           (4_194_304, 0.3, 512, 0.0)])     # config 4 on one GPU
+def test_fullsize_far_field_accuracy(oracle, n, phi, grid, xy):
+    """What the property set above cannot see: a stencil that is consistently wrong at a block, bin or
+    slab edge passes linearity, reciprocity and LATTICE-vector invariance.  (i) The wave part is a function of separations
+    only, so moving every particle by an off-grid vector changes it by the discretisation error alone: <= 5 x error.
+    (ii) The spread grid on sub-volumes (across the periodic wrap and across interior block / bin edges) against the port's
+    spread of exactly the particles that reach them (PSEv1/Mobility.cu:212-246)."""
+    import torch
+    eng, pos, F, box, xi = _engine(n, phi, grid, xy=xy)
+    info = eng.info()
+    h = np.array([box[0] / grid, box[1] / grid, box[2] / grid])
+    U = eng.mobility(to4(pos), to4(F), parts=2).cpu().numpy()[:, :3]
+    shift = np.array([0.37, -0.61, 0.23]) * h
+    moved = pos + shift
+    moved[:, 0] += box[3] * shift[1]                                     # the node lattice is sheared: (0.37, -0.61, 0.23) in lattice units
+    U2 = eng.mobility(to4(moved), to4(F), parts=2).cpu().numpy()[:, :3]
+    assert rel(U2, U) < 5e-3, rel(U2, U)
+    # (ii) sub-volumes of the force grid
+    p = oracle.select_params(box, xi, 1e-3, 0.5, grid=(grid,) * 3)
+    assert p["P"] == info["P"] and abs(p["eta"] - info["eta"]) < 1e-13
+    g = eng.debug_spread(to4(pos), to4(F))
+    idx, _ = oracle._support(pos, box, p)
+    P = p["P"]
+    for lo in ([grid - 6, grid - 5, grid - 7], [61, 125, 13], [120, 8, 250]):   # across the wrap; across 8- and 16-node block edges
+        ext = 14
+        sel = np.ones(n, dtype=bool)
+        for a in range(3):
+            d = (idx[a] - lo[a]) % grid                                   # (n, P): node offsets from the sub-volume's corner
+            sel &= (d < ext).any(axis=1)
+        sub = np.where(sel)[0]
+        assert len(sub) > 20
+        w, lin = oracle._weights(pos[sub], box, p)
+        ref = np.zeros((3, grid ** 3 if grid <= 256 else 1))
+        nodes = (np.arange(ext)[:, None, None] + lo[0]) % grid * grid * grid + (np.arange(ext)[None, :, None] + lo[1]) % grid * grid \
+            + (np.arange(ext)[None, None, :] + lo[2]) % grid
+        if grid <= 256:
+            for c in range(3):
+                np.add.at(ref[c], lin.ravel(), (w * F[sub, c][:, None, None, None]).ravel())
+            want = ref[:, nodes.ravel()]
+        else:                                                             # 512^3: accumulate on the sub-volume only
+            pos_of = {int(v): q for q, v in enumerate(nodes.ravel())}
+            want = np.zeros((3, nodes.size))
+            for q, v in enumerate(lin.ravel()):
+                t = pos_of.get(int(v))
+                if t is not None:
+                    s_ = q // (P ** 3)
+                    want[:, t] += w.ravel()[q] * F[sub[s_]]
+        got = g.reshape(3, -1)[:, nodes.ravel()]
+        assert np.abs(got - want).max() < 1e-12 * np.abs(want).max(), lo
+    del eng, g
+    torch.cuda.empty_cache()

@@ -131,6 +131,13 @@ def test_euler_step_and_wrap():
 
 
 # ------------------------------------------------------------------------------------------------ device vs reference kernels (GPU)
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
 def _engine(c, n_max):
     import pse_amd
     return pse_amd.Engine(n_max, tuple(c["box"]), xi=c["xi"], error=c["error"], max_strain=c["max_strain"], grid=tuple(c["grid"]),

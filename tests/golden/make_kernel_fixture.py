@@ -354,8 +354,8 @@ def main():
         n = {13: 3, 7: 4}.get(P, 5)                                             # P^3 nodes per particle are stored
         frac = rng.uniform(size=(n, 3))
         frac[0] = [0.001, 0.999, 0.5]                                           # supports that wrap around both ends
-        frac[1] = (np.floor(frac[1] * grid) + 0.5) / grid                       # exactly half-way between nodes (odd-P centring rule)
-        frac[2] = (np.floor(frac[2] * grid) + [0.4999999, 0.5000001, 0.0]) / grid
+        frac[1] = (np.floor(frac[1] * grid) + [0.4999999, 0.5000001, 0.0]) / grid  # either side of half-way between nodes (odd-P centring rule;
+        frac[2] = (np.floor(frac[2] * grid) + [0.5000001, 0.25, 0.4999999]) / grid  # an exact tie is decided by rounding, in any arithmetic)
         y = (frac[:, 1] - 0.5) * box[1]
         pos = np.stack([(frac[:, 0] - 0.5) * box[0] + box[3] * y, y, (frac[:, 2] - 0.5) * box[2]], axis=1)
         force = rng.normal(size=(n, 3))

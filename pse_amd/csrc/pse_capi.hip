@@ -892,8 +892,25 @@ static int slab_bounds_wait(pse_handle *h, int N) {
     return 0;
 }
 
-// bin + sort + gather into cell order (positions change every step, so this runs every call; every rank sorts all
-// particles: the state is replicated, the work of the later phases is what is sharded)
+// What a slab rank orders, gathers into cell order and keeps particle data for: its own cell layers and one ghost layer on either
+// side (CellRanges in pse_kernels.h).  Everything, when the far field is replicated on every rank, when the slab and its ghosts
+// cover all layers anyway, or when a support could reach further than a ghost layer is wide (a particle beyond the ghost layer
+// must not touch the slab's planes: (P/2 + 1) node planes against the width of a cell layer).
+static CellRanges slab_need(const pse_handle *h) {
+    CellRanges r{};
+    const int G = h->n_slabs, nx = h->nc.nx;
+    if (G == 1 || h->grid_slabs == 1) return r;
+    const int per = nx / G, layer = h->nc.nzb * h->nc.ny * h->nc.bz;
+    if (per + 2 >= nx) return r;
+    if ((h->G.P / 2 + 1.0) / h->G.Nx > 1.0 / nx) return r;
+    const int start = ((h->slab_rank * per - 1) % nx + nx) % nx, len = per + 2;
+    if (start + len <= nx) { r.n = 1; r.c0[0] = start * layer; r.c1[0] = (start + len) * layer; }
+    else { r.n = 2; r.c0[0] = start * layer; r.c1[0] = nx * layer; r.c0[1] = 0; r.c1[1] = (start + len - nx) * layer; }
+    return r;
+}
+
+// bin + sort + gather into cell order (positions change every step, so this runs every call; every rank COUNTS all particles
+// -- the state is replicated and the row offsets are global -- but orders and gathers only what slab_need() says)
 // need_cells: the caller walks the cell list itself (pair repulsion): sort even if the neighbour list could be kept.
 //
 // With a neighbour skin the sort and the cell walk run only when the distance check says so (the reference keeps HOOMD's
@@ -947,9 +964,12 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
     const int ncell = cells_total(h->nc);
     if ((size_t)ncell > h->n_cells_alloc)   // pse_create and pse_set_box check both cell grids: cannot happen, must not pass silently
         return fail(PSE_ERR_INVALID, "cell grid %d x %d x %d exceeds the capacity sized at creation", h->nc.nx, h->nc.ny, h->nc.nz);
+    const CellRanges need = slab_need(h);
+    h->sw.need = need; h->sw.cell_off = h->cell_off;
     HIPCHK(cell_sort(pos, group, N, h->dbox, h->nc, h->keys, h->vals, h->keys_s, h->cell_cnt, ncell, h->sort_tmp, h->sort_tmp_bytes,
-                     h->cell_off, h->perm, h->stream));
-    launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream);
+                     h->cell_off, h->perm, h->stream, need));
+    launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream, nullptr, 0.0, nullptr,
+                   need, h->cell_off);
     h->sorted_N = N;
     if (with_list) {   // the first cell pass of this call writes the list (real())
         HIPCHK(hipMemsetAsync(h->vl.flags, 0, 2 * sizeof(int), h->stream));
@@ -1261,7 +1281,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
     // the slab row boundaries are needed from here on; the far-field chain is already queued
     for (pse_handle *h : T.m) TRY(slab_bounds_wait(h, N));
     if (noise)   // psi first: the near-field pass that builds the pair list applies M_real to F and to psi together
-        for (pse_handle *h : T.m) launch_psi(h->psi_s, h->tag_s, N, h->par.seed, timestep, h->stream);
+        for (pse_handle *h : T.m) launch_psi(h->psi_s, h->tag_s, N, h->par.seed, timestep, h->stream, h->sw.need, h->cell_off);
     if (parts & 1) {
         for (pse_handle *h : T.m) TRY(ts(h, PH_REAL));
         TRY(real(T, &pse_handle::f_s, &pse_handle::ur_s, 0, 0, N, noise, noise));
@@ -1286,7 +1306,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
             int lo, hi;
             row_range(h, N, lo, hi);
             launch_sum_rows((parts & 2) ? h->uw_s : nullptr, (parts & 1) ? h->ur_s : nullptr, noise ? h->ub_s : nullptr,
-                            h->utot_s, lo, hi, h->stream);
+                            h->utot_s, lo, hi, h->stream, h->tag_s);   // the tags travel with the rows: no rank orders foreign rows
         }
         TRY(team_all_gather_rows(T, [](pse_handle *h) { return (double *)h->utot_s; }));
     }
@@ -1297,7 +1317,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
             HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         }
         if (T.G > 1)
-            launch_scatter_sum(h->utot_s, nullptr, nullptr, h->tag_s, N, a[r].vel, h->stream);
+            launch_scatter_sum(h->utot_s, nullptr, nullptr, nullptr, N, a[r].vel, h->stream);
         else
             launch_scatter_sum((parts & 2) ? h->uw_s : nullptr, (parts & 1) ? h->ur_s : nullptr, noise ? h->ub_s : nullptr,
                                h->tag_s, N, a[r].vel, h->stream);

@@ -97,10 +97,15 @@ __device__ __forceinline__ int fdiv(int n, FastDiv q, int &rem) {
 // support origin (wrapped into the grid), offset of the origin from the particle, the particle's own node plane, and its
 // rank inside its bin (-1: a slab rank never touches this particle)
 __global__ void k_support(const double4 *__restrict__ pos_s, int N, DGrid G, DBox box, int4 *__restrict__ sup_s,
-                          double4 *__restrict__ d0_s, FarBins fb) {
+                          double4 *__restrict__ d0_s, FarBins fb, CellRanges rows, const int *__restrict__ cell_off) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s - (int)(threadIdx.x & 63) >= N) return;          // whole wave past the end
-    const bool live = s < N;
+    const bool held = s < N && rows.row(s, cell_off);      // a slab rank holds particle data for its own and its ghost rows only
+    if (__ballot(held) == 0ull) {
+        if (s < N && fb.cnt) fb.rank_s[s] = -1;
+        return;
+    }
+    const bool live = held;
     const double4 p = pos_s[live ? s : N - 1];
     double fx, fy, fz;
     frac_coords(box, p.x, p.y, p.z, fx, fy, fz);
@@ -137,6 +142,7 @@ __global__ void k_support(const double4 *__restrict__ pos_s, int N, DGrid G, DBo
         if (need && leader == lane) base = atomicAdd(&fb.cnt[bin], count);
         base = __shfl(base, leader, 64);
         if (live) fb.rank_s[s] = need ? base + prefix : -1;
+        else if (s < N) fb.rank_s[s] = -1;
     }
 }
 
@@ -174,7 +180,7 @@ static hipError_t build_records(const double4 *pos_s, const double4 *f_s, int4 *
     const int nbins = fb.nbx * fb.nby * fb.nbz;
     hipError_t e = hipMemsetAsync(fb.cnt, 0, (size_t)(nbins + 1) * sizeof(int), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_support, dim3(nblocks(N, 256)), dim3(256), 0, s, pos_s, N, G, box, sup_s, w.d0_s, fb);
+    hipLaunchKernelGGL(k_support, dim3(nblocks(N, 256)), dim3(256), 0, s, pos_s, N, G, box, sup_s, w.d0_s, fb, w.need, w.cell_off);
     size_t tb = fb.tmp_bytes;
     e = hipcub::DeviceScan::ExclusiveSum(fb.tmp, tb, fb.cnt, fb.off, nbins + 1, s);   // cnt[nbins] = 0: off[nbins] = total
     if (e != hipSuccess) return e;

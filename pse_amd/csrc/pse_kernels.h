@@ -11,14 +11,33 @@ namespace pse {
 // counting sort by cell, equal to a stable sort by key: perm[slot] = input index, cell_off[c] = first slot of cell c.
 // keys, rank, slots: N unsigned each; cnt: ncell + 1 ints; tmp: cell_sort_temp_bytes(ncell)
 size_t cell_sort_temp_bytes(size_t ncell);
+// A slab rank of a team works on its own cell layers and the neighbouring ghost layer on either side only: up to three ranges
+// [c0, c1) of storage cells (x is the slowest cell index, so a range of layers is a range of cells and -- through cell_off -- a
+// range of rows).  n = 0: everything (single GPU).  EVERY particle is still counted (the row offsets are global); the ordering
+// inside the cells, the gather into cell order, the far-field records and the random vector are done for these rows alone.
+struct CellRanges {
+    int n, c0[3], c1[3];
+    __device__ __forceinline__ bool cell(int c) const {
+        if (n == 0) return true;
+        for (int q = 0; q < n; ++q) if (c >= c0[q] && c < c1[q]) return true;
+        return false;
+    }
+    __device__ __forceinline__ bool row(int s, const int *__restrict__ cell_off) const {
+        if (n == 0) return true;
+        for (int q = 0; q < n; ++q) if (s >= cell_off[c0[q]] && s < cell_off[c1[q]]) return true;
+        return false;
+    }
+};
 hipError_t cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys, unsigned *rank,
-               unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s);
+                     unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s,
+                     CellRanges need = CellRanges{});
 // pos_s[i] = wrapped position of particle perm[i], vec_s[i] = vec[tag].xyz, tag_s[i] = its index in the caller's arrays
 // pos_build (nullable): the sorted positions the neighbour list was built at; a particle that has moved more than
 // sqrt(half_skin2) from there (minimum image) sets flags[0] -- HOOMD's NeighborList distance check (r_buff / 2)
 void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm, int N, DBox box,
                     double4 *pos_s, float4 *posf_s, double2 *pv, double4 *vec_s, unsigned *tag_s, hipStream_t s,
-                    const double4 *pos_build = nullptr, double half_skin2 = 0.0, int *flags = nullptr);
+                    const double4 *pos_build = nullptr, double half_skin2 = 0.0, int *flags = nullptr,
+                    CellRanges need = CellRanges{}, const int *cell_off = nullptr);   // a slab rank: the needed rows only
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s);
 
 // ---- near field (K9) -------------------------------------------------------------------------------------
@@ -86,6 +105,8 @@ struct SpreadWork {
     FarBins fb;
     FarRec *rec_t;              // [N] bin order: origin, sorted index (bit 31: owned by another slab rank), offset, prefac * force
     int force_tz, force_nw;     // tuning switches of the handle (0: automatic): z depth of a spread block, waves per block
+    CellRanges need;            // a slab rank: rows outside hold no particle data (their support cannot reach the slab)
+    const int *cell_off;
 };
 // per-step constants of the separable Gaussian weights: step ratios r_t = exp(-c h^2 (2t+1)) (y with the (1 + xy^2) of the
 // sheared lattice), ln K = -2 c xy hx hy, the tilt
@@ -119,7 +140,8 @@ void launch_slab_pack(double2 *cgrid, double2 *buf, int nxl, int Ny, int Nzh, in
 void launch_add_inplace(double *a, const double *b, size_t n, hipStream_t s);
 
 // ---- vector kernels (K10-K14) ----------------------------------------------------------------------------
-void launch_psi(double4 *psi_s, const unsigned *tag_s, int N, uint32_t seed, uint32_t timestep, hipStream_t s);
+void launch_psi(double4 *psi_s, const unsigned *tag_s, int N, uint32_t seed, uint32_t timestep, hipStream_t s,
+                CellRanges need = CellRanges{}, const int *cell_off = nullptr);
 // scal layout (device doubles): [0..127] alpha, [128..255] beta, [256] psi norm, [257] scratch
 constexpr int LZ_ALPHA = 0, LZ_BETA = 128, LZ_NORM = 256, LZ_TMP = 257, LZ_NSCAL = 264;   // TMP: 3 sums
 constexpr int LZ_NPART = 1024;  // partial-sum slots
@@ -135,9 +157,11 @@ void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, in
                     double *scal, hipStream_t s);
 void launch_lz_update(const double4 *xin, const double4 *y, const double4 *vprev, double4 *vout, double4 *xnext, int j,
                       double *scal, const int (*row_ranges)[2], int n_ranges, hipStream_t s, double2 *pv = nullptr);   // up to three disjoint row ranges in one launch; pv: also refresh the packed records
-void launch_sum_rows(const double4 *a, const double4 *b, const double4 *c, double4 *out, int lo, int hi, hipStream_t s);
+// tag_s (nullable): out[i].w = the particle's index in the caller's arrays, so the rows can be scattered by ranks that did not sort them
+void launch_sum_rows(const double4 *a, const double4 *b, const double4 *c, double4 *out, int lo, int hi, hipStream_t s,
+                     const unsigned *tag_s = nullptr);
 void launch_pick(const int *cell_off, const int *idx, int n, int *out, hipStream_t s);
-// vel[tag].xyz = a + b + c (each may be null), keep w
+// vel[tag].xyz = a + b + c (each may be null), keep w;  tag_s = null: the tag travels in a[s].w (launch_sum_rows)
 void launch_scatter_sum(const double4 *a, const double4 *b, const double4 *c, const unsigned *tag_s, int N,
                         double4 *vel, hipStream_t s);
 void launch_integrate(double4 *pos, const double4 *vel, double3 *accel, int3 *image, const double4 *force,

@@ -39,8 +39,11 @@ __device__ __forceinline__ double reduce_partials(const double *partials, int n,
 // not reproducible, and every slab rank must end up with the SAME order (rows are exchanged by position), so a last
 // pass orders each cell by original index: the result equals a stable sort by key.  cell_off[c] = first slot of cell c
 // (c = 0..ncell): cell c owns [cell_off[c], cell_off[c+1]) and any run of consecutive cells is one contiguous slot range.
+constexpr unsigned KEY_FOREIGN = 0xFFFFFFFFu;   // a particle a slab rank counts but does not order
+// (Counting the foreign particles per x layer in an LDS histogram instead -- one global add per layer and workgroup, booked on
+// the layer's first cell -- was slower: 58 us against 45 us; the kernel is not bound by its global atomics.)
 __global__ void k_cell_keys(const double4 *__restrict__ pos, const unsigned *__restrict__ group, int N, DBox box,
-                            DCells nc, unsigned *__restrict__ keys, unsigned *__restrict__ rank, int *__restrict__ cnt) {
+                            DCells nc, unsigned *__restrict__ keys, unsigned *__restrict__ rank, int *__restrict__ cnt, CellRanges need) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
     const unsigned idx = group ? group[g] : (unsigned)g;
@@ -50,21 +53,26 @@ __global__ void k_cell_keys(const double4 *__restrict__ pos, const unsigned *__r
     const int cx = cell_coord(fx, nc.nx), cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz);
     const int zb = cz / nc.bz;
     const unsigned key = (unsigned)cell_slot(nc, cx, cy, zb, cz - zb * nc.bz);
-    keys[g] = key;
-    rank[g] = (unsigned)atomicAdd(&cnt[key], 1);
+    if (need.cell((int)key)) {
+        keys[g] = key;
+        rank[g] = (unsigned)atomicAdd(&cnt[key], 1);
+    } else {
+        keys[g] = KEY_FOREIGN;
+        atomicAdd(&cnt[key], 1);   // counted (the row offsets are global), not ranked
+    }
 }
 __global__ void k_cell_scatter(const unsigned *__restrict__ keys, const unsigned *__restrict__ rank,
                                const int *__restrict__ cell_off, int N, unsigned *__restrict__ slots) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < N) slots[cell_off[keys[g]] + rank[g]] = (unsigned)g;
+    if (g < N && keys[g] != KEY_FOREIGN) slots[cell_off[keys[g]] + rank[g]] = (unsigned)g;
 }
 // one thread per slot: rank its particle among the members of its cell (a handful: the loads of a cell's threads are the same
 // few words), write it in order.  (One wave per cell kept five of 64 lanes busy: 33 us at N = 1e6; this way 10.)
 __global__ void __launch_bounds__(TPB)
 k_cell_order(const int *__restrict__ cell_off, const unsigned *__restrict__ keys, int N, const unsigned *__restrict__ slots,
-             unsigned *__restrict__ perm) {
+             unsigned *__restrict__ perm, CellRanges need) {
     const int s = blockIdx.x * TPB + threadIdx.x;
-    if (s >= N) return;
+    if (s >= N || !need.row(s, cell_off)) return;
     const unsigned v = slots[s];
     const int c = (int)keys[v], a = cell_off[c], n = cell_off[c + 1] - a;
     int smaller = 0;
@@ -77,15 +85,16 @@ size_t cell_sort_temp_bytes(size_t ncell) {
     return bytes;
 }
 hipError_t cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys, unsigned *rank,
-                     unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s) {
+                     unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s,
+                     CellRanges need) {
     hipError_t e = hipMemsetAsync(cnt, 0, (size_t)(ncell + 1) * sizeof(int), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_cell_keys, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, group, N, box, nc, keys, rank, cnt);
+    hipLaunchKernelGGL(k_cell_keys, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, group, N, box, nc, keys, rank, cnt, need);
     // cnt[ncell] = 0: cell_off[ncell] = N.  A failed scan (scratch too small for ncell) would leave garbage offsets: reported
     e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt, cell_off, ncell + 1, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_cell_scatter, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, keys, rank, cell_off, N, slots);
-    hipLaunchKernelGGL(k_cell_order, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, cell_off, keys, N, slots, perm);
+    hipLaunchKernelGGL(k_cell_order, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, cell_off, keys, N, slots, perm, need);
     return hipGetLastError();
 }
 
@@ -93,9 +102,9 @@ __global__ void k_permute(const double4 *__restrict__ pos, const double4 *__rest
                           const unsigned *__restrict__ group, const unsigned *__restrict__ perm, int N, DBox box,
                           double4 *__restrict__ pos_s, float4 *__restrict__ posf_s, double2 *__restrict__ pv,
                           double4 *__restrict__ vec_s, unsigned *__restrict__ tag_s, const double4 *__restrict__ pos_build,
-                          double half_skin2, int *__restrict__ flags) {
+                          double half_skin2, int *__restrict__ flags, CellRanges need, const int *__restrict__ cell_off) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= N) return;
+    if (s >= N || !need.row(s, cell_off)) return;
     const unsigned g = perm[s];
     const unsigned idx = group ? group[g] : g;
     const double4 p = pos[idx];
@@ -143,9 +152,9 @@ __global__ void k_permute_vec(const double4 *__restrict__ vec, const unsigned *_
 
 void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm, int N, DBox box,
                     double4 *pos_s, float4 *posf_s, double2 *pv, double4 *vec_s, unsigned *tag_s, hipStream_t s,
-                    const double4 *pos_build, double half_skin2, int *flags) {
+                    const double4 *pos_build, double half_skin2, int *flags, CellRanges need, const int *cell_off) {
     hipLaunchKernelGGL(k_permute, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, vec, group, perm, N, box, pos_s, posf_s, pv, vec_s, tag_s,
-                       pos_build, half_skin2, flags);
+                       pos_build, half_skin2, flags, need, cell_off);
 }
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s) {
     hipLaunchKernelGGL(k_permute_vec, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, vec, tag_s, N, vec_s);
@@ -1484,16 +1493,17 @@ void launch_add_inplace(double *a, const double *b, size_t n, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------ vectors
 // K14 gpu_stokes_BrownianGenerate_kernel (PSEv1/Brownian.cu:99-130), keyed by the particle's global index
 __global__ void k_psi(double4 *__restrict__ psi_s, const unsigned *__restrict__ tag_s, int N, uint32_t seed,
-                      uint32_t timestep) {
+                      uint32_t timestep, CellRanges need, const int *__restrict__ cell_off) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= N) return;
+    if (s >= N || !need.row(s, cell_off)) return;
     uint32_t r[4];
     philox4x32(tag_s[s], 0u, timestep, DOMAIN_PARTICLE, seed, PHILOX_KEY1, r);
     const double q = 1.7320508075688772;  // sqrt(3): variance 1
     psi_s[s] = make_double4(uniform_pm(r[0], q), uniform_pm(r[1], q), uniform_pm(r[2], q), 0.0);
 }
-void launch_psi(double4 *psi_s, const unsigned *tag_s, int N, uint32_t seed, uint32_t timestep, hipStream_t s) {
-    hipLaunchKernelGGL(k_psi, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, psi_s, tag_s, N, seed, timestep);
+void launch_psi(double4 *psi_s, const unsigned *tag_s, int N, uint32_t seed, uint32_t timestep, hipStream_t s, CellRanges need,
+                const int *cell_off) {
+    hipLaunchKernelGGL(k_psi, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, psi_s, tag_s, N, seed, timestep, need, cell_off);
 }
 
 static inline int vec_grid(int N) { return std::min(LZ_NPART, std::max(1, nblocks(N, TPB))); }
@@ -1586,17 +1596,18 @@ void launch_lz_update(const double4 *xin, const double4 *y, const double4 *vprev
 }
 // out[i] = a[i] + b[i] + c[i] on rows [lo, hi)  (each may be null)
 __global__ void k_sum_rows(const double4 *__restrict__ a, const double4 *__restrict__ b, const double4 *__restrict__ c,
-                           double4 *__restrict__ out, int lo, int hi) {
+                           double4 *__restrict__ out, int lo, int hi, const unsigned *__restrict__ tag_s) {
     const int i = lo + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= hi) return;
     double x = 0, y = 0, z = 0;
     if (a) { const double4 v = a[i]; x += v.x; y += v.y; z += v.z; }
     if (b) { const double4 v = b[i]; x += v.x; y += v.y; z += v.z; }
     if (c) { const double4 v = c[i]; x += v.x; y += v.y; z += v.z; }
-    out[i] = make_double4(x, y, z, 0.0);
+    out[i] = make_double4(x, y, z, tag_s ? (double)tag_s[i] : 0.0);   // an index below 2^32 is exact in a double
 }
-void launch_sum_rows(const double4 *a, const double4 *b, const double4 *c, double4 *out, int lo, int hi, hipStream_t s) {
-    if (hi > lo) hipLaunchKernelGGL(k_sum_rows, dim3(nblocks(hi - lo, TPB)), dim3(TPB), 0, s, a, b, c, out, lo, hi);
+void launch_sum_rows(const double4 *a, const double4 *b, const double4 *c, double4 *out, int lo, int hi, hipStream_t s,
+                     const unsigned *tag_s) {
+    if (hi > lo) hipLaunchKernelGGL(k_sum_rows, dim3(nblocks(hi - lo, TPB)), dim3(TPB), 0, s, a, b, c, out, lo, hi, tag_s);
 }
 // row boundaries of the cell slabs: out[r] = cell_off[r * stride] for r = 0..n-1
 __global__ void k_pick(const int *__restrict__ cell_off, const int *__restrict__ idx, int n, int *__restrict__ out) {
@@ -1676,7 +1687,7 @@ __global__ void k_scatter_sum(const double4 *__restrict__ a, const double4 *__re
     if (a) { const double4 v = a[s]; x += v.x; y += v.y; z += v.z; }
     if (b) { const double4 v = b[s]; x += v.x; y += v.y; z += v.z; }
     if (c) { const double4 v = c[s]; x += v.x; y += v.y; z += v.z; }
-    const unsigned idx = tag_s[s];
+    const unsigned idx = tag_s ? tag_s[s] : (unsigned)a[s].w;
     double4 o = vel[idx];
     o.x = x; o.y = y; o.z = z;
     vel[idx] = o;

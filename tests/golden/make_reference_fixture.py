@@ -32,6 +32,15 @@ import mpmath as mp
 import numpy as np
 
 REF = os.environ.get("PSE_REFERENCE", "/root/reference")
+# The reference tree is untrusted content: whatever expression text is evaluated below sees NO Python builtins (no import, open,
+# getattr, ...) -- only the numeric names handed to it.  (The kernel-level fixture, make_kernel_fixture.py, does not evaluate
+# text at all: it interprets a parsed tree.)
+NO_BUILTINS = {"__builtins__": {}}
+CLASS_BUILTINS = {"__builtins__": {"__build_class__": __build_class__}, "__name__": "reference_fixture"}
+
+
+def safe_eval(code, env):
+    return eval(code, dict(NO_BUILTINS, **env))
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_arithmetic.json")
 
 
@@ -75,14 +84,14 @@ def realspace():
             b = branch(r)
             e64 = dict(env64, xi=xi, r=r)
             emp = dict(envmp, xi=mp.mpf(xi), r=mp.mpf(r))
-            f64, g64 = eval(code[b][0], e64), eval(code[b][1], e64)
-            fmp, gmp = eval(code[b][0], emp), eval(code[b][1], emp)
+            f64, g64 = safe_eval(code[b][0], e64), safe_eval(code[b][1], e64)
+            fmp, gmp = safe_eval(code[b][0], emp), safe_eval(code[b][1], emp)
             rows.append({"xi": xi, "r": r, "branch": b, "Imrr_fp64": f64, "rr_fp64": g64,
                          "Imrr_exact": float(fmp), "rr_exact": float(gmp)})
     selfs = []
     for xi in xis:
-        as_written = eval(self_code, {"exp": math.exp, "erfc": math.erfc, "pi12": 1.77245385091, "axi": xi, "axi2": xi * xi, "aa": 1.0})
-        exact = eval(self_code, {"exp": mp.exp, "erfc": mp.erfc, "pi12": mp.sqrt(mp.pi), "axi": mp.mpf(xi),
+        as_written = safe_eval(self_code, {"exp": math.exp, "erfc": math.erfc, "pi12": 1.77245385091, "axi": xi, "axi2": xi * xi, "aa": 1.0})
+        exact = safe_eval(self_code, {"exp": mp.exp, "erfc": mp.erfc, "pi12": mp.sqrt(mp.pi), "axi": mp.mpf(xi),
                                  "axi2": mp.mpf(xi) ** 2, "aa": mp.mpf(1)})
         selfs.append({"xi": xi, "as_written": as_written, "exact": float(exact)})
     return {"source": "PSEv1/Stokes.cc:319,348-406", "rows": rows, "self": selfs}
@@ -110,24 +119,24 @@ def parameter_rule():
     for (L, xi, err, ms) in [(64.0, 0.5, 1e-3, 0.5), (64.0, 0.5, 1e-3, 0.0), (43.756, 0.5, 1e-3, 0.5), (347.29, 0.5, 1e-3, 0.5),
                              (280.04, 0.546, 1e-3, 0.5), (30.0, 0.8, 1e-6, 0.3), (25.0, 0.7, 1e-9, 0.5), (100.0, 0.3, 1e-4, 0.1)]:
         env = dict(fns, m_error=err, m_xi=xi, m_max_strain=ms, L=V(L, L, L))
-        env["m_ewald_cut"] = eval(e_cut, env)
-        env["kmax"] = eval(e_kmax, env)
-        n_raw = eval(e_nx, env)
+        env["m_ewald_cut"] = safe_eval(e_cut, env)
+        env["kmax"] = safe_eval(e_kmax, env)
+        n_raw = safe_eval(e_nx, env)
         N = next(q for q in mlist if n_raw <= q)
         env["gamma"] = ms; env["gamma2"] = ms * ms
-        env["lambda_"] = lam = eval(e_lambda, env)
+        env["lambda_"] = lam = safe_eval(e_lambda, env)
         env["m_gaussm"] = 1.0
         # integer counter: the reference accumulates +0.01 in Scalar; the fp64 restatement counts steps
         steps = 0
-        while eval(e_while, env):
+        while safe_eval(e_while, env):
             steps += 1
             env["m_gaussm"] = 1.0 + 0.01 * steps
-            assert abs(eval(e_step, dict(env, m_gaussm=1.0 + 0.01 * (steps - 1))) - env["m_gaussm"]) < 1e-12
-        P = min(eval(e_P, env), N)
+            assert abs(safe_eval(e_step, dict(env, m_gaussm=1.0 + 0.01 * (steps - 1))) - env["m_gaussm"]) < 1e-12
+        P = min(safe_eval(e_P, env), N)
         env["m_gaussP"] = P; env["m_gridh"] = V(L / N, L / N, L / N); env["m_Nx"] = N
-        env["w"] = eval(e_w, env); env["xisq"] = xi * xi
+        env["w"] = safe_eval(e_w, env); env["xisq"] = xi * xi
         rows.append({"L": L, "xi": xi, "error": err, "max_strain": ms, "rcut": env["m_ewald_cut"], "kmax": env["kmax"],
-                     "N_raw": n_raw, "N": N, "lambda": lam, "gaussm": env["m_gaussm"], "P": P, "eta": eval(e_eta, env)})
+                     "N_raw": n_raw, "N": N, "lambda": lam, "gaussm": env["m_gaussm"], "P": P, "eta": safe_eval(e_eta, env)})
     return {"source": "PSEv1/Stokes.cc:135-236 (expressions as text, evaluated in fp64; pi as written 3.1415926536)", "rows": rows}
 
 
@@ -139,7 +148,7 @@ def seed_hash():
         v = seed
         for s in stmts:
             m = re.match(r"m_seed\s*(\^=|\*=|=)\s*(.*)", s)
-            val = eval(m.group(2).replace("m_seed", str(v))) & 0xFFFFFFFF
+            val = safe_eval(m.group(2).replace("m_seed", str(v)), {}) & 0xFFFFFFFF
             v = {"=": val, "^=": v ^ val, "*=": (v * val) & 0xFFFFFFFF}[m.group(1)]
         out.append({"seed": seed, "hashed": v})
     return {"source": "PSEv1/Stokes.cc:102", "rows": out}
@@ -152,8 +161,8 @@ def wave_scale():
     for (k2, xi, eta, ng) in [(0.01, 0.5, 0.5054, 64 ** 3), (0.37, 0.441, 0.72, 256 ** 3), (2.5, 0.8, 0.6, 45 ** 3), (9.0, 0.3, 0.3, 100 ** 3)]:
         n = round(ng ** (1 / 3))
         env = {"k2": k2, "xisq": xi * xi, "eta": eta, "Nx": n, "Ny": n, "Nz": n, "float": float}
-        as_written = eval(c_expr(expr), dict(env, expf=math.exp))
-        exact = eval(c_expr(expr.replace("3.1415926536", "pi")), dict(env, expf=math.exp, pi=math.pi))
+        as_written = safe_eval(c_expr(expr), dict(env, expf=math.exp))
+        exact = safe_eval(c_expr(expr.replace("3.1415926536", "pi")), dict(env, expf=math.exp, pi=math.pi))
         rows.append({"k2": k2, "xi": xi, "eta": eta, "Ng": n ** 3, "as_written": as_written, "exact_pi": exact})
     return {"source": "PSEv1/Helper.cu:326", "rows": rows}
 
@@ -218,7 +227,7 @@ def shear_functions():
 
     def build(exact):
         f32log = (lambda x: float(np.log(np.float32(x)))) if not exact else math.log
-        ns = {"cos": math.cos, "sin": math.sin, "exp": math.exp, "logf": f32log, "log": math.log}
+        ns = dict(CLASS_BUILTINS, cos=math.cos, sin=math.sin, exp=math.exp, logf=f32log, log=math.log)
         for k in ("SinShearFunction", "SteadyShearFunction", "ChirpShearFunction", "TukeyWindowFunction", "WindowedFunction"):
             exec(klass(k, exact), ns)
         return ns
@@ -244,7 +253,7 @@ def shear_functions():
     wrap = []
     for v in (-2.3, -0.5, -0.49999, 0.0, 0.2, 0.4999, 0.5, 0.77, 1.0, 3.21):
         wrap.append({"value": v, "min": -0.5, "range": 1.0,
-                     "wrapped": eval(c_expr(wrap_src), {"functionValue": v, "m_min_value": -0.5, "m_value_range": 1.0, "floor": math.floor})})
+                     "wrapped": safe_eval(c_expr(wrap_src), {"functionValue": v, "m_min_value": -0.5, "m_value_range": 1.0, "floor": math.floor})})
     return {"source": "PSEv1/SpecificShearFunction.h:16-223, PSEv1/VariantShearFunction.h:46-48", "dt": dt, "functions": out, "wrapValue": wrap}
 
 

@@ -234,3 +234,24 @@ def test_random_call_sequence_matches_fresh_engines(torch_cuda, oracle):
             assert rel(a[g, :3], r[g, :3]) < 1e-11, tag
     st = eng.neighbor_stats()
     assert st[2] >= 3, st      # some of the calls did run on the kept list
+
+
+def test_set_box_growth_is_checked_against_both_cell_grids(torch_cuda):
+    """pse_set_box validates the cell grid a later call may switch to, not only the one in use: with a neighbour skin the handle works
+    on cells of width rcut + r_buff, but prepare() falls back to cells of width rcut (more of them) whenever the list is suspended or
+    switched off.  A box that grew past the capacity sized at creation must be refused up front (before: a silent overrun of the
+    cell counters in the sort); one that still fits must work in both modes."""
+    import pse_amd
+    n = 3000
+    pos, force, _ = make_suspension(n, L=100.0)
+    box = (100.0, 100.0, 100.0, 0.0)
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3, grid=(48, 48, 48))          # rcut 5.26: 19 cells per axis at creation
+    with pytest.raises(pse_amd.PSEError):
+        eng.set_box(130.0, 130.0, 130.0, 0.0)                                     # wide grid 22^3 would fit, the narrow 24^3 does not
+    eng.set_box(115.0, 115.0, 115.0, 0.0)                                         # both fit
+    big = pos * 1.15
+    u1 = eng.mobility(to4(big), to4(force)).cpu().numpy()[:, :3]                  # builds the kept list on the wide grid
+    eng.set_neighbor_skin(0.0)                                                    # from now on: the narrow grid, every call
+    u2 = eng.mobility(to4(big), to4(force)).cpu().numpy()[:, :3]
+    assert rel(u2, u1) < 1e-11
+    assert np.isfinite(u2).all()

@@ -75,8 +75,10 @@ def test_total_mobility_against_direct_ewald(torch_cuda, oracle, err):
     u = eng.mobility(to4(pos), to4(force)).cpu().numpy()[:, :3]
     ref = oracle.mobility_direct(pos, force, box, 0.5)
     e = rel(u, ref)
-    # the NumPy restatement of the reference algorithm (same rcut/grid/P/eta) bounds what the method itself can reach:
-    # at error = 1e-9 the reference's parameter rule delivers ~1.5e-8, not 1e-9
+    # the NumPy restatement of the reference algorithm (same rcut/grid/P/eta; held to the reference's kernel text and parameter rule
+    # by tests/test_reference_kernels.py and tests/test_reference_pin.py) bounds what the method itself can reach: at
+    # error = 1e-9 the reference's parameter rule delivers ~1.5e-8, not 1e-9 (SURVEY.md 8c assumed 1e-8 before any restatement
+    # existed); the device is held to the restatement at 1e-10 and to the direct Ewald sum at what the restatement reaches
     p = oracle.select_params(box, 0.5, err, 0.5)
     e_port = rel(oracle.mobility(pos, force, box, p), ref)
     assert rel(u, oracle.mobility(pos, force, box, p)) < 1e-10
@@ -88,14 +90,21 @@ def test_xi_independence(torch_cuda, oracle):
     import pse_amd
     n = 800
     pos, force, box = make_suspension(n, phi=0.1)
-    us = []
+    us, ports = [], []
     for xi in (0.5, 0.75):
         eng = pse_amd.Engine(n, box, xi=xi, error=1e-7)
         us.append(eng.mobility(to4(pos), to4(force)).cpu().numpy()[:, :3])
         eng.close()
-    # the claim of examples/run.py:50 ("xi ... will not affect results, only speed") holds to the method's accuracy,
-    # which for the reference's parameter rule is ~50 x the nominal error at 1e-7
-    assert rel(us[0], us[1]) < 1e-5
+        # the same evaluation by the restatement of the reference's algorithm (held to the reference's kernel text and parameter
+        # rule by tests/test_reference_kernels.py and tests/test_reference_pin.py): what the METHOD gives at this xi
+        ports.append(oracle.mobility(pos, force, box, oracle.select_params(box, xi, 1e-7, 0.5)))
+        assert rel(us[-1], ports[-1]) < 1e-10
+    # the claim of examples/run.py:50 ("xi ... will not affect results, only speed") holds to the method's accuracy: how far the
+    # reference's own parameter rule lets two xi drift apart at error = 1e-7 is asked of the restatement, not assumed
+    drift = rel(ports[0], ports[1])
+    exact = oracle.mobility_direct(pos, force, box, 0.5)
+    assert rel(us[0], us[1]) < 1.05 * drift + 1e-10
+    assert drift < 1e-5 and max(rel(ports[0], exact), rel(ports[1], exact)) < 1e-5   # and both sit that close to the direct Ewald sum
 
 
 def test_group_members_and_w_preserved(torch_cuda, oracle):

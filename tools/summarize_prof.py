@@ -2,7 +2,7 @@
 """Turn rocprofv3 CSV output (gpurun_out/...) into the small summaries committed under profiles/.
 
   python tools/summarize_prof.py stats  <kernel_stats.csv> <out.csv> "<command line that was profiled>"
-  python tools/summarize_prof.py pmc    <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+  python tools/summarize_prof.py pmc    <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [commit] [command]
 """
 import collections
 import csv
@@ -23,7 +23,7 @@ def stats(src, dst, cmd):
             f.write(f"\"{short(r['Name'])}\",{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']}\n")
 
 
-def pmc(fetch_csv, write_csv, dst):
+def pmc(fetch_csv, write_csv, dst, commit="unrecorded", cmd=""):
     def agg(path, counter):
         d = collections.defaultdict(list)
         for r in csv.DictReader(open(path)):
@@ -33,8 +33,11 @@ def pmc(fetch_csv, write_csv, dst):
     f, w = agg(fetch_csv, "FETCH_SIZE"), agg(write_csv, "WRITE_SIZE")
     out = {"_note": "per-launch averages, bytes. FETCH_SIZE/WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts a 128-B "
                     "request as 64 B for wide (16 B/lane) streaming reads, so fetch_x2 is the corrected figure for kernels that read with "
-                    "dwordx4 (k_scale, k_lz_*, FFT); for 4/8-B-per-lane loads (k_mreal_list, k_gather_p) the factor is uncalibrated "
-                    "and both are given (/opt/skills/guides/MI355X_MICROARCH.md, HBM section)."}
+                    "dwordx4 (/opt/skills/guides/MI355X_MICROARCH.md, HBM section); calibrated in round 3 for plain and non-temporal 8- and "
+                    "16-byte-per-lane streams and for the ragged pair-list stream of k_mreal_list (tools/microbench/nt_fetch.hip, "
+                    "profiles/r03_fetch_size_calibration.txt: x2 in every case, 96 % of the lines touched for the list)."}
+    out["_commit"] = commit
+    out["_source"] = "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of: " + cmd
     for k in sorted(set(f) | set(w)):
         out[k] = {"fetch_raw": f.get(k, 0.0) * 1024, "fetch_x2": 2 * f.get(k, 0.0) * 1024, "write": w.get(k, 0.0) * 1024}
     json.dump(out, open(dst, "w"), indent=1)
@@ -44,4 +47,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], *(sys.argv[5:7]))

@@ -1151,7 +1151,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
                 int lo, hi;
                 row_range(h, N, lo, hi);
                 const double4 *xj = done == 0 ? h->psi_s : h->V + (size_t)done * stride;
-                const double4 *vjm1 = done > 0 ? h->V + (size_t)(done - 1) * stride : nullptr;
+                const double4 *vjm1 = done > 1 ? h->V + (size_t)(done - 1) * stride : (done == 1 ? h->psi_s : nullptr);   // x_{j-1}, unnormalised
                 if (fused) {
                     const bool ev = timed && h->timing;
                     launch_mreal_lanczos(h->pos_s, xj, h->w_s, lo, hi, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef,
@@ -1166,13 +1166,13 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
                 h->w_is_mpsi = false;
             }
             // the partial sums and the ghost rows of y = M x_j in one exchange; every rank then updates its own rows AND its ghost
-            // rows (it holds x_j and v_{j-1} there from the previous iteration), so x_{j+1} needs no exchange of its own
+            // rows (it holds x_j and x_{j-1} there from the previous iteration), so x_{j+1} needs no exchange of its own
             TRY(team_lanczos_exchange(T, [](pse_handle *h) { return h->scal + LZ_TMP; }, [](pse_handle *h) { return (double *)h->w_s; }));
             for (pse_handle *h : T.m) {
                 int rg[3][2];
                 const int nrg = update_ranges(h, N, rg);
                 const double4 *xj = done == 0 ? h->psi_s : h->V + (size_t)done * stride;
-                launch_lz_update(xj, h->w_s, done > 0 ? h->V + (size_t)(done - 1) * stride : nullptr, h->V + (size_t)done * stride,
+                launch_lz_update(xj, h->w_s, done > 1 ? h->V + (size_t)(done - 1) * stride : (done == 1 ? h->psi_s : nullptr),
                                  h->V + (size_t)(done + 1) * stride, done, h->scal, rg, nrg, h->stream, h->pv);
                 h->pv_is_f = false;   // the vector half of pv now holds x_{j+1}
             }
@@ -1227,11 +1227,11 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
             return fail(PSE_ERR_NUMERIC, "tridiagonal eigen-solve failed at m = %d", m_final);
     }
     for (pse_handle *h : T.m) {
-        BasisCoef tc{};
-        for (int q = 0; q < m_final; ++q) tc.t[q] = t_cur[q];
+        BasisCoef tc{};   // the basis holds the unnormalised x_q: v_q = x_q / |x_q|, |x_0| = the norm of psi, |x_q| = beta_q
+        for (int q = 0; q < m_final; ++q) tc.t[q] = t_cur[q] / (q == 0 ? sc[LZ_NORM] : sc[LZ_BETA + q]);
         int lo, hi;
         row_range(h, N, lo, hi);
-        launch_basis_combine(h->V, stride, tc, m_final, h->scal, scale, 1, h->ub_s, lo, hi, h->stream);   // Brownian.cu:716,739
+        launch_basis_combine(h->psi_s, h->V, stride, tc, m_final, h->scal, scale, 1, h->ub_s, lo, hi, h->stream);   // Brownian.cu:716,739
         h->info.lanczos_m = m_final; h->info.lanczos_matvecs = done; h->info.lanczos_stepnorm = stepnorm;
     }
     if (m_io) *m_io = m_final;

@@ -66,9 +66,9 @@ constexpr size_t NB_REC = 64 * 20;
 __host__ __device__ inline size_t nb_list_bytes(size_t rows, int cap) { return ((rows + 63) / 64) * (size_t)cap * NB_REC; }
 enum { MREAL_CELLS = 0, MREAL_BUILD_LIST = 1, MREAL_USE_LIST = 2 };
 // Lanczos sums fused into the pair-list mat-vec (see k_lz_update): with x = vec and y = M x the kernel also leaves the
-// per-block partial sums of x.x, x.y and x.v_{j-1}
+// per-block partial sums of x.x, x.y and x.x_{j-1}
 struct LzFuse {
-    const double4 *vprev;   // v_{j-1} (null for j = 0)
+    const double4 *vprev;   // x_{j-1}, unnormalised (null for j = 0)
     double *partials;       // [3][npart_cap]
     int npart_cap;
 };
@@ -145,17 +145,17 @@ void launch_psi(double4 *psi_s, const unsigned *tag_s, int N, uint32_t seed, uin
 // scal layout (device doubles): [0..127] alpha, [128..255] beta, [256] psi norm, [257] scratch
 constexpr int LZ_ALPHA = 0, LZ_BETA = 128, LZ_NORM = 256, LZ_TMP = 257, LZ_NSCAL = 264;   // TMP: 3 sums
 constexpr int LZ_NPART = 1024;  // partial-sum slots
-// out_s = scale * sum_q t[q] V[q]
+// out_s = scale * sum_q t[q] X[q], X[0] = x0, X[q] = V[q] (the UNNORMALISED Lanczos vectors: t carries the 1 / |x_q|)
 // rows [lo, hi)
 struct BasisCoef { double t[104]; };   // the m <= 100 coefficients of the final combination, passed by value
-void launch_basis_combine(const double4 *V, size_t stride, const BasisCoef &t, int m, const double *scal,
+void launch_basis_combine(const double4 *x0, const double4 *V, size_t stride, const BasisCoef &t, int m, const double *scal,
                           double scale, int use_norm, double4 *out_s, int lo, int hi, hipStream_t s);
 // Lanczos iteration on the own rows [lo, hi) (see k_lz_update in pse_kernels.hip).  dots: sums of x.x, x.y, x.vprev ->
 // scal[LZ_TMP..+2] (y = null: x.x only), for mat-vecs that did not fuse them; [all-reduce by the caller when sharded];
-// update: alpha_j, beta_j, v_j = x_j / beta_j -> vout, x_{j+1} -> xnext
+// update: alpha_j, beta_j -> scal, x_{j+1} -> xnext
 void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, int lo, int hi, double *partials, int cap,
                     double *scal, hipStream_t s);
-void launch_lz_update(const double4 *xin, const double4 *y, const double4 *vprev, double4 *vout, double4 *xnext, int j,
+void launch_lz_update(const double4 *xin, const double4 *y, const double4 *xprev, double4 *xnext, int j,
                       double *scal, const int (*row_ranges)[2], int n_ranges, hipStream_t s, double2 *pv = nullptr);   // up to three disjoint row ranges in one launch; pv: also refresh the packed records
 // tag_s (nullable): out[i].w = the particle's index in the caller's arrays, so the rows can be scattered by ranks that did not sort them
 void launch_sum_rows(const double4 *a, const double4 *b, const double4 *c, double4 *out, int lo, int hi, hipStream_t s,

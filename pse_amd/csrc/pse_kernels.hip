@@ -609,7 +609,7 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
         if (wv > 0) return;
         for (int w = 0; w < WSP - 1; ++w) { ux += red[(w * 3 + 0) * 64 + ln]; uy += red[(w * 3 + 1) * 64 + ln]; uz += red[(w * 3 + 2) * 64 + ln]; }
     }
-    if (FUSE) {   // x = vec (unnormalised Lanczos vector), y = M x: partial sums of x.x, x.y, x.v_{j-1}
+    if (FUSE) {   // x = vec (unnormalised Lanczos vector), y = M x: partial sums of x.x, x.y, x.x_{j-1}
         double a = 0.0, b = 0.0, c = 0.0;
         if (active) {
             a = vi.x * vi.x + vi.y * vi.y + vi.z * vi.z;
@@ -1511,11 +1511,12 @@ static inline int vec_grid(int N) { return std::min(LZ_NPART, std::max(1, nblock
 // Lanczos (PSEv1/Brownian.cu:440-521) with device-resident scalars: no host round trip inside an iteration.
 // ---- Lanczos iteration (PSEv1/Brownian.cu:440-521) with deferred normalisation --------------------------------------
 // Each rank owns rows [lo, hi) of every vector (a single GPU owns them all).  The mat-vec runs on the UNNORMALISED vector
-// x_j (v_j = x_j / beta_j, beta_j = |x_j|): with y = M x_j the three sums  s1 = x_j.x_j, s2 = x_j.y, s3 = x_j.v_{j-1}
-// give  beta_j = sqrt(s1)  and  alpha_j = v_j.(M v_j - beta_j v_{j-1}) = s2/s1 - s3  -- the reference's K10-K12
+// x_j (v_j = x_j / beta_j, beta_j = |x_j|): with y = M x_j the three sums  s1 = x_j.x_j, s2 = x_j.y, s3 = x_j.x_{j-1}
+// give  beta_j = sqrt(s1)  and  alpha_j = v_j.(M v_j - beta_j v_{j-1}) = s2/s1 - s3/beta_{j-1}  -- the reference's K10-K12
 // sequence (w = M v - beta v_prev; alpha = v.w; w -= alpha v; beta' = |w|) with ONE reduction per iteration (one 3-scalar
-// all-reduce when sharded) and one vector pass: v_j = x_j/beta_j, x_{j+1} = y/beta_j - beta_j v_{j-1} - alpha_j v_j.
-// beta_0 = |psi| is the norm the result is rescaled with (Brownian.cu:440-452,739).
+// all-reduce when sharded) and one vector pass: x_{j+1} = (y - alpha_j x_j)/beta_j - (beta_j/beta_{j-1}) x_{j-1}.
+// The normalised v_j are never stored (round 3): the basis keeps the x_j and the final combination divides by beta_j -- one
+// 32-byte write per row and iteration less.  beta_0 = |psi| is the norm the result is rescaled with (Brownian.cu:440-452,739).
 __global__ void __launch_bounds__(TPB)
 k_lz_dots(const double4 *__restrict__ x, const double4 *__restrict__ y, const double4 *__restrict__ vprev, int lo, int hi,
           double *__restrict__ partials, int cap) {
@@ -1551,28 +1552,28 @@ k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, d
         scal[LZ_TMP + q] = t;
     }
 }
-// alpha_j, beta_j from the reduced sums; v_j = x_j / beta_j (in place or from psi); x_{j+1} on the own rows
+// alpha_j, beta_j from the reduced sums; x_{j+1} on the given rows
 struct RowRanges { int n, lo[3], hi[3]; };   // up to three row ranges (own rows and the two ghost layers), disjoint
 __global__ void __launch_bounds__(TPB)
-k_lz_update(const double4 *xin /* may alias vout: normalised in place */, const double4 *__restrict__ y,
-            const double4 *__restrict__ vprev, double4 *vout, double4 *__restrict__ xnext, int j, double *__restrict__ scal,
-            RowRanges rg, double2 *__restrict__ pv) {
-    const double s1 = scal[LZ_TMP], s2 = scal[LZ_TMP + 1], s3 = scal[LZ_TMP + 2];
+k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, const double4 *__restrict__ xprev,
+            double4 *__restrict__ xnext, int j, double *__restrict__ scal, RowRanges rg, double2 *__restrict__ pv) {
+    const double s1 = scal[LZ_TMP], s2 = scal[LZ_TMP + 1], s3raw = scal[LZ_TMP + 2];
+    const double bprev = j == 1 ? scal[LZ_NORM] : (j > 1 ? scal[LZ_BETA + j - 1] : 0.0);   // |x_{j-1}|
+    const double ibprev = bprev > 0.0 ? 1.0 / bprev : 0.0;
     const double beta = s1 > 0.0 ? sqrt(s1) : 0.0;
     const double inv = beta > 0.0 ? 1.0 / beta : 0.0;
-    const double alpha = s1 > 0.0 ? s2 / s1 - s3 : 0.0;
+    const double alpha = s1 > 0.0 ? s2 / s1 - s3raw * ibprev : 0.0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         scal[LZ_ALPHA + j] = alpha;
         if (j == 0) { scal[LZ_NORM] = beta; scal[LZ_BETA] = 0.0; } else scal[LZ_BETA + j] = beta;
     }
+    const double cp = beta * ibprev;   // beta_j / beta_{j-1}
     const int n0 = rg.hi[0] - rg.lo[0], n1 = rg.n > 1 ? rg.hi[1] - rg.lo[1] : 0, n2 = rg.n > 2 ? rg.hi[2] - rg.lo[2] : 0;
     for (int t = blockIdx.x * TPB + threadIdx.x; t < n0 + n1 + n2; t += gridDim.x * TPB) {
         const int i = t < n0 ? rg.lo[0] + t : (t < n0 + n1 ? rg.lo[1] + (t - n0) : rg.lo[2] + (t - n0 - n1));
         const double4 p = xin[i], q = y[i];
-        const double vx = p.x * inv, vy = p.y * inv, vz = p.z * inv;
-        double nx = q.x * inv - alpha * vx, ny = q.y * inv - alpha * vy, nz = q.z * inv - alpha * vz;
-        if (vprev) { const double4 m = vprev[i]; nx -= beta * m.x; ny -= beta * m.y; nz -= beta * m.z; }
-        vout[i] = make_double4(vx, vy, vz, 0.0);
+        double nx = (q.x - alpha * p.x) * inv, ny = (q.y - alpha * p.y) * inv, nz = (q.z - alpha * p.z) * inv;
+        if (xprev) { const double4 m = xprev[i]; nx -= cp * m.x; ny -= cp * m.y; nz -= cp * m.z; }
         xnext[i] = make_double4(nx, ny, nz, 0.0);
         if (pv) {   // the vector half of the packed records the next mat-vec gathers
             ((double *)&pv[3 * (size_t)i + 1])[1] = nx;
@@ -1586,13 +1587,13 @@ void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, in
     hipLaunchKernelGGL(k_lz_dots, dim3(g), dim3(TPB), 0, s, x, y, vprev, lo, hi, partials, cap);
     hipLaunchKernelGGL(k_lz_reduce, dim3(y ? 3 : 1), dim3(1024), 0, s, partials, g, cap, y ? 3 : 1, scal);
 }
-void launch_lz_update(const double4 *xin, const double4 *y, const double4 *vprev, double4 *vout, double4 *xnext, int j,
+void launch_lz_update(const double4 *xin, const double4 *y, const double4 *xprev, double4 *xnext, int j,
                       double *scal, const int (*rg)[2], int nrg, hipStream_t s, double2 *pv) {
     RowRanges r{};
     r.n = nrg;
     int total = 0;
     for (int q = 0; q < nrg && q < 3; ++q) { r.lo[q] = rg[q][0]; r.hi[q] = rg[q][1]; total += rg[q][1] - rg[q][0]; }
-    hipLaunchKernelGGL(k_lz_update, dim3(vec_grid(std::max(1, total))), dim3(TPB), 0, s, xin, y, vprev, vout, xnext, j, scal, r, pv);
+    hipLaunchKernelGGL(k_lz_update, dim3(vec_grid(std::max(1, total))), dim3(TPB), 0, s, xin, y, xprev, xnext, j, scal, r, pv);
 }
 // out[i] = a[i] + b[i] + c[i] on rows [lo, hi)  (each may be null)
 __global__ void k_sum_rows(const double4 *__restrict__ a, const double4 *__restrict__ b, const double4 *__restrict__ c,
@@ -1620,23 +1621,23 @@ void launch_pick(const int *cell_off, const int *idx, int n, int *out, hipStream
 
 // K13 gpu_stokes_MatVecMultiply_kernel (PSEv1/Helper.cu:251-279) + the final rescale (PSEv1/Brownian.cu:739)
 __global__ void __launch_bounds__(TPB)
-k_basis_combine(const double4 *__restrict__ V, size_t stride, BasisCoef tc, int m,
+k_basis_combine(const double4 *__restrict__ x0, const double4 *__restrict__ V, size_t stride, BasisCoef tc, int m,
                 const double *__restrict__ scal, double scale, int use_norm, double4 *__restrict__ out, int lo, int N) {
     const double *t = tc.t;   // kernel arguments: no host-to-device copy whose source the host would have to keep alive
     const double sc = use_norm ? scale * scal[LZ_NORM] : scale;
     for (int i = lo + blockIdx.x * TPB + threadIdx.x; i < N; i += gridDim.x * TPB) {
         double x = 0, y = 0, z = 0;
         for (int q = 0; q < m; ++q) {
-            const double4 v = V[(size_t)q * stride + i];
+            const double4 v = q == 0 ? x0[i] : V[(size_t)q * stride + i];   // x_0 = psi was never copied into the basis
             const double tq = t[q];
             x += tq * v.x; y += tq * v.y; z += tq * v.z;
         }
         out[i] = make_double4(sc * x, sc * y, sc * z, 0.0);
     }
 }
-void launch_basis_combine(const double4 *V, size_t stride, const BasisCoef &t_dev, int m, const double *scal,
+void launch_basis_combine(const double4 *x0, const double4 *V, size_t stride, const BasisCoef &t_dev, int m, const double *scal,
                           double scale, int use_norm, double4 *out_s, int lo, int hi, hipStream_t s) {
-    hipLaunchKernelGGL(k_basis_combine, dim3(std::min(2048, std::max(1, nblocks(hi - lo, TPB)))), dim3(TPB), 0, s, V, stride,
+    hipLaunchKernelGGL(k_basis_combine, dim3(std::min(2048, std::max(1, nblocks(hi - lo, TPB)))), dim3(TPB), 0, s, x0, V, stride,
                        t_dev, m, scal, scale, use_norm, out_s, lo, hi);
 }
 

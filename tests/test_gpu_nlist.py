@@ -245,7 +245,7 @@ def test_set_box_growth_is_checked_against_both_cell_grids(torch_cuda):
     n = 3000
     pos, force, _ = make_suspension(n, L=100.0)
     box = (100.0, 100.0, 100.0, 0.0)
-    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3, grid=(48, 48, 48))          # rcut 5.26: 19 cells per axis at creation
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3)                              # rcut 5.26: 19 cells per axis at creation (grid 96^3)
     with pytest.raises(pse_amd.PSEError):
         eng.set_box(130.0, 130.0, 130.0, 0.0)                                     # wide grid 22^3 would fit, the narrow 24^3 does not
     eng.set_box(115.0, 115.0, 115.0, 0.0)                                         # both fit

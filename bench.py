@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="HBM bytes per kernel from separate rocprofv3 --pmc passes of this command (tools/round_profile.sh)")
     ap.add_argument("--no-ref-grid", action="store_true", help="skip the extra steps on the reference rule's 360^3 grid")
+    ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
+                    help="multi-rank runs: RCCL over xGMI (one GPU per rank), or the host-staged transport over gloo (ranks may "
+                         "share a GPU: exercises the process-per-rank driver on a one-GPU box; never the headline)")
     ap.add_argument("--dry-run", action="store_true", help="with --gpus N > 1: print the launch command and stop")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -130,12 +133,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the torch.distributed environment has WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
+    host_transport = args.transport == "host"
+    device = local_rank % torch.cuda.device_count() if host_transport else local_rank
+    torch.cuda.set_device(device)
     use_dist = world > 1 or "PSE_FORCE_SHARDED" in os.environ
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if host_transport:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
 
     import pse_amd
     from pse_amd import distributed as pdist
@@ -144,7 +152,7 @@ def main():
     pos, force, L = suspension(n, args.phi)
     xi = math.pi * grid / (2.0 * L * math.sqrt(-math.log(args.error)))      # xi from the fixed grid
     sim = pdist.make_simulation(n, (L, L, L, 0.0), xi=xi, error=args.error, seed=1, grid=(grid,) * 3,
-                                world=world, rank=rank)
+                                world=world, rank=rank, **({"transport": "host"} if host_transport and use_dist else {}))
     sim.load(pos, force, mass=1.0)
     info = sim.info()
 
@@ -197,7 +205,7 @@ def main():
             phase_sum[k] = phase_sum.get(k, 0.0) + v
     sim.set_timing(False)
     if world > 1:
-        t = torch.tensor([elapsed, t_mf], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, t_mf], dtype=torch.float64, device="cpu" if host_transport else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, t_mf = float(t[0]), float(t[1])
     info = sim.info()

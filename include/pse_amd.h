@@ -170,6 +170,23 @@ int pse_debug_kvector(pse_handle *h, int n, const int *ijk_host, double *out_hos
 typedef struct pse_team pse_team;
 int pse_team_unique_id(void *id128_host);   /* host buffer of 128 bytes, call on rank 0 and distribute */
 int pse_team_create(pse_handle **members, int n_members, const void *id128_host, pse_team **out);
+/* A third transport, supplied by the host program: one member per process as with RCCL, but every exchange is staged through
+ * pinned host memory and handed to two callbacks -- a list of point-to-point transfers between ranks (every rank of the team
+ * calls with its own list at the same point of the step; transfers between one pair of ranks match in list order) and a sum
+ * over all ranks.  Buffers are host memory, counts are in doubles, send_to / recv_from = -1 where an entry has no send / no
+ * receive; return 0 on success.  The exchanges are exactly those of the RCCL transport (same buffers, counts, peers and
+ * order: both run through one transfer list), which is what makes the process-per-rank driver testable where RCCL cannot run
+ * (two ranks on one GPU), e.g. over torch.distributed's gloo backend; it is also a fallback for nodes without xGMI. */
+typedef struct pse_host_xfer {
+    const double *send; size_t send_count; int send_to;
+    double *recv; size_t recv_count; int recv_from;
+} pse_host_xfer;
+typedef struct pse_transport {
+    void *user;
+    int (*exchange)(void *user, int n_xfers, const pse_host_xfer *xfers);
+    int (*allreduce_sum)(void *user, double *host_buf, size_t count);
+} pse_transport;
+int pse_team_create_transport(pse_handle *member, const pse_transport *transport, pse_team **out);
 /* Destroy the team BEFORE its members: the members must outlive it (an in-process team lends member 0's side stream to the
  * others and hands every member its own back here). */
 int pse_team_destroy(pse_team *team);

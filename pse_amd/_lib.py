@@ -47,6 +47,19 @@ class pse_info(ctypes.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+class pse_host_xfer(ctypes.Structure):
+    _fields_ = [("send", ctypes.POINTER(ctypes.c_double)), ("send_count", ctypes.c_size_t), ("send_to", ctypes.c_int),
+                ("recv", ctypes.POINTER(ctypes.c_double)), ("recv_count", ctypes.c_size_t), ("recv_from", ctypes.c_int)]
+
+
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(pse_host_xfer))
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_size_t)
+
+
+class pse_transport(ctypes.Structure):
+    _fields_ = [("user", ctypes.c_void_p), ("exchange", EXCHANGE_FN), ("allreduce_sum", ALLREDUCE_FN)]
+
+
 # every symbol include/pse_amd.h declares: name -> (restype, argtypes)
 _vp, _i, _u, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_double
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -73,6 +86,7 @@ SYMBOLS = {
     "pse_debug_kvector": (_i, [_vp, _i, _ip, _dp]),
     "pse_team_unique_id": (_i, [_vp]),
     "pse_team_create": (_i, [ctypes.POINTER(_vp), _i, _vp, ctypes.POINTER(_vp)]),
+    "pse_team_create_transport": (_i, [_vp, ctypes.POINTER(pse_transport), ctypes.POINTER(_vp)]),
     "pse_team_destroy": (_i, [_vp]),
     "pse_team_mobility": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _u, _i]),
     "pse_team_brownian_velocity": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _u, _d, _d, _u, _ip]),

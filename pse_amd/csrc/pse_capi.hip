@@ -656,6 +656,10 @@ struct pse_team {
     int G = 1;                   // ranks in the decomposition
     ncclComm_t nccl = nullptr;   // set when members.size() == 1 and G > 1: near field, Lanczos, final exchange (main stream)
     ncclComm_t nccl_w = nullptr; // its split: the far-field chain (all-to-alls, gather halo) on the side stream, concurrently
+    pse_transport cb = {};       // or: a transport supplied by the host program (host-staged; pse_team_create_transport)
+    bool has_cb = false;
+    double *stage = nullptr;     // pinned staging of the callback transport
+    size_t stage_n = 0;
     double *scratch = nullptr;   // loopback all-reduce scratch
     size_t scratch_n = 0;
 };
@@ -665,25 +669,87 @@ struct pse_team {
         if (r_ != ncclSuccess) return fail(PSE_ERR_COMM, "%s failed: %s (%s:%d)", #x, ncclGetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
 
-static bool loopback(const pse_team &T) { return T.G > 1 && !T.nccl; }
+static bool loopback(const pse_team &T) { return T.G > 1 && !T.nccl && !T.has_cb; }
+static bool remote(const pse_team &T) { return T.nccl || T.has_cb; }   // one member per process
 // communicator of the far-field chain: the split one when it exists (then the chain runs on the side stream), else the main one
 static ncclComm_t wave_comm(const pse_team &T) { return T.nccl_w ? T.nccl_w : T.nccl; }
 
-// all-to-all of equal blocks, nset sets at once (one RCCL group): member r sends block q of set c of send(r) to rank q,
+// One exchange of a process-per-rank team: a list of point-to-point transfers (counts in doubles; 0 = none) and, optionally, a
+// sum over all ranks -- ONE RCCL group, or one call of the host program's transport.  Every exchange of the team goes through
+// here, so what the RCCL path sends (buffers, counts, peers, order) is exactly what the callback transport sends -- and that
+// one runs between real processes in the tests (two ranks cannot share a GPU under RCCL).
+struct Xfer { const double *send; size_t ns; int to; double *recv; size_t nr; int from; };
+static int team_exchange(pse_team &T, const std::vector<Xfer> &ops, bool wave_lane, double *sum_buf = nullptr, size_t sum_n = 0) {
+    pse_handle *h = T.m[0];
+    hipStream_t s = wave_lane ? h->wstream : h->stream;
+    if (T.nccl) {
+        ncclComm_t comm = wave_lane ? wave_comm(T) : T.nccl;
+        NCCLCHK(ncclGroupStart());
+        if (sum_n) NCCLCHK(ncclAllReduce(sum_buf, sum_buf, sum_n, ncclDouble, ncclSum, comm, s));
+        for (const Xfer &x : ops) if (x.ns) NCCLCHK(ncclSend(x.send, x.ns, ncclDouble, x.to, comm, s));
+        for (const Xfer &x : ops) if (x.nr) NCCLCHK(ncclRecv(x.recv, x.nr, ncclDouble, x.from, comm, s));
+        NCCLCHK(ncclGroupEnd());
+        return 0;
+    }
+    // host-staged transport: device -> pinned host, the host program moves the bytes, pinned host -> device
+    const int me = h->slab_rank;
+    size_t need = sum_n;
+    for (const Xfer &x : ops) need += (x.to == me ? 0 : x.ns) + (x.from == me ? 0 : x.nr);
+    if (need > T.stage_n) {
+        if (T.stage) (void)hipHostFree(T.stage);
+        T.stage = nullptr; T.stage_n = 0;
+        HIPCHK(hipHostMalloc((void **)&T.stage, (need + 1024) * sizeof(double), hipHostMallocDefault));
+        T.stage_n = need + 1024;
+    }
+    std::vector<pse_host_xfer> hx;
+    size_t off = 0;
+    double *sum_host = nullptr;
+    if (sum_n) { sum_host = T.stage; HIPCHK(hipMemcpyAsync(sum_host, sum_buf, sum_n * sizeof(double), hipMemcpyDeviceToHost, s)); off = sum_n; }
+    std::vector<std::pair<double *, const double *>> back;   // (device destination, host source) of what arrives
+    std::vector<size_t> back_n;
+    // a rank's sends to itself and its receives from itself pair up in order (the all-to-all's diagonal block)
+    std::vector<const Xfer *> self_send, self_recv;
+    for (const Xfer &x : ops) {
+        pse_host_xfer e{};
+        if (x.ns && x.to == me) self_send.push_back(&x);
+        else if (x.ns) { e.send = T.stage + off; e.send_count = x.ns; e.send_to = x.to; HIPCHK(hipMemcpyAsync(T.stage + off, x.send, x.ns * sizeof(double), hipMemcpyDeviceToHost, s)); off += x.ns; }
+        if (x.nr && x.from == me) self_recv.push_back(&x);
+        else if (x.nr) { e.recv = T.stage + off; e.recv_count = x.nr; e.recv_from = x.from; back.push_back({x.recv, T.stage + off}); back_n.push_back(x.nr); off += x.nr; }
+        if (e.send_count || e.recv_count) {
+            if (!e.send_count) e.send_to = -1;
+            if (!e.recv_count) e.recv_from = -1;
+            hx.push_back(e);
+        }
+    }
+    if (self_send.size() != self_recv.size()) return fail(PSE_ERR_COMM, "unpaired self transfer");
+    for (size_t q = 0; q < self_send.size(); ++q) {
+        if (self_send[q]->ns != self_recv[q]->nr) return fail(PSE_ERR_COMM, "self transfer of unequal sizes");
+        if (self_recv[q]->recv != self_send[q]->send)
+            HIPCHK(hipMemcpyAsync(self_recv[q]->recv, self_send[q]->send, self_send[q]->ns * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    if (sum_n && T.cb.allreduce_sum(T.cb.user, sum_host, sum_n)) return fail(PSE_ERR_COMM, "transport: all-reduce failed");
+    if (!hx.empty() && T.cb.exchange(T.cb.user, (int)hx.size(), hx.data())) return fail(PSE_ERR_COMM, "transport: exchange failed");
+    if (sum_n) HIPCHK(hipMemcpyAsync(sum_buf, sum_host, sum_n * sizeof(double), hipMemcpyHostToDevice, s));
+    for (size_t q = 0; q < back.size(); ++q)
+        HIPCHK(hipMemcpyAsync(back[q].first, back[q].second, back_n[q] * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // the staging buffer is reused by the next exchange
+    return 0;
+}
+
+// all-to-all of equal blocks, nset sets at once (one group): member r sends block q of set c of send(r) to rank q,
 // which stores it as block r of set c of recv(q); sets are set_stride doubles apart
 template <class FS, class FR>
 static int team_all_to_all(pse_team &T, FS send, FR recv, size_t blk_doubles, int nset, size_t set_stride) {
     if (T.G == 1) return 0;
-    if (T.nccl) {
+    if (remote(T)) {
         pse_handle *h = T.m[0];
-        NCCLCHK(ncclGroupStart());
+        std::vector<Xfer> ops;
         for (int c = 0; c < nset; ++c)
-            for (int q = 0; q < T.G; ++q) {
-                NCCLCHK(ncclSend(send(h) + c * set_stride + (size_t)q * blk_doubles, blk_doubles, ncclDouble, q, wave_comm(T), h->wstream));
-                NCCLCHK(ncclRecv(recv(h) + c * set_stride + (size_t)q * blk_doubles, blk_doubles, ncclDouble, q, wave_comm(T), h->wstream));
-            }
-        NCCLCHK(ncclGroupEnd());
-        return 0;
+            for (int q = 0; q < T.G; ++q)
+                ops.push_back(Xfer{send(h) + c * set_stride + (size_t)q * blk_doubles, blk_doubles, q,
+                                   recv(h) + c * set_stride + (size_t)q * blk_doubles, blk_doubles, q});
+        return team_exchange(T, ops, true);
     }
     for (int c = 0; c < nset; ++c)
         for (pse_handle *src : T.m)
@@ -693,30 +759,10 @@ static int team_all_to_all(pse_team &T, FS send, FR recv, size_t blk_doubles, in
                                       blk_doubles * sizeof(double), hipMemcpyDeviceToDevice, dst->wstream));
     return 0;
 }
-// every rank's chunk [rank*chunk, (rank+1)*chunk) of buf becomes visible in every rank's buf
-template <class FB>
-static int team_all_gather(pse_team &T, FB buf, size_t chunk_doubles) {
-    if (T.G == 1) return 0;
-    if (T.nccl) {
-        pse_handle *h = T.m[0];
-        NCCLCHK(ncclAllGather(buf(h) + (size_t)h->slab_rank * chunk_doubles, buf(h), chunk_doubles, ncclDouble, T.nccl, h->stream));
-        return 0;
-    }
-    for (pse_handle *src : T.m)
-        for (pse_handle *dst : T.m)
-            if (src != dst)
-                HIPCHK(hipMemcpyAsync(buf(dst) + (size_t)src->slab_rank * chunk_doubles, buf(src) + (size_t)src->slab_rank * chunk_doubles,
-                                      chunk_doubles * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
-    return 0;
-}
 template <class FB>
 static int team_all_reduce_sum(pse_team &T, FB buf, size_t n_doubles) {
     if (T.G == 1) return 0;
-    if (T.nccl) {
-        pse_handle *h = T.m[0];
-        NCCLCHK(ncclAllReduce(buf(h), buf(h), n_doubles, ncclDouble, ncclSum, T.nccl, h->stream));
-        return 0;
-    }
+    if (remote(T)) return team_exchange(T, {}, false, buf(T.m[0]), n_doubles);
     if (T.scratch_n < n_doubles) {
         if (T.scratch) (void)hipFree(T.scratch);
         HIPCHK(hipMalloc((void **)&T.scratch, n_doubles * sizeof(double)));
@@ -733,21 +779,19 @@ static int team_all_reduce_sum(pse_team &T, FB buf, size_t n_doubles) {
 static int team_halo_exchange(pse_team &T) {
     if (T.G == 1) return 0;
     auto comp = [](pse_handle *h, int c) { return h->rgrid + (size_t)c * (h->G.nxl + h->G.hl + h->G.nhalo) * h->G.Ny * h->G.Nz; };
-    if (T.nccl) {
+    if (remote(T)) {
         pse_handle *h = T.m[0];
         const DGrid &G = h->G;
         const size_t plane = (size_t)G.Ny * G.Nz;
         const int left = (h->slab_rank + T.G - 1) % T.G, right = (h->slab_rank + 1) % T.G;
-        NCCLCHK(ncclGroupStart());
+        std::vector<Xfer> ops;
         for (int c = 0; c < 3; ++c) {
             double *own = comp(h, c) + plane * G.hl;
-            NCCLCHK(ncclSend(own, plane * G.nhalo, ncclDouble, left, wave_comm(T), h->wstream));                          // my first planes
-            NCCLCHK(ncclSend(own + plane * (G.nxl - G.hl), plane * G.hl, ncclDouble, right, wave_comm(T), h->wstream));   // my last planes
-            NCCLCHK(ncclRecv(own + plane * G.nxl, plane * G.nhalo, ncclDouble, right, wave_comm(T), h->wstream));
-            NCCLCHK(ncclRecv(comp(h, c), plane * G.hl, ncclDouble, left, wave_comm(T), h->wstream));
+            // my first planes go left and arrive above the left neighbour's slab; my last planes go right and arrive below the right one's
+            ops.push_back(Xfer{own, plane * G.nhalo, left, own + plane * G.nxl, plane * G.nhalo, right});
+            ops.push_back(Xfer{own + plane * (G.nxl - G.hl), plane * G.hl, right, comp(h, c), plane * G.hl, left});
         }
-        NCCLCHK(ncclGroupEnd());
-        return 0;
+        return team_exchange(T, ops, true);
     }
     auto member = [&](int r) { for (pse_handle *h : T.m) if (h->slab_rank == r) return h; return (pse_handle *)nullptr; };
     for (pse_handle *dst : T.m) {
@@ -766,23 +810,22 @@ static int team_halo_exchange(pse_team &T) {
 
 // ghost rows of a distributed vector: every rank receives its right neighbour's first cell layer and its left
 // neighbour's last cell layer (the near-field mat-vec of the own rows reads exactly those besides the own rows)
+static std::vector<Xfer> ghost_ops(pse_team &T, double *buf) {
+    pse_handle *h = T.m[0];
+    const std::vector<int> &lo = h->row_lo, &fe = h->first_end, &lb = h->last_begin;
+    auto cnt = [](int a, int b) { return (size_t)std::max(0, b - a) * 4; };
+    const int r = h->slab_rank, L = (r + T.G - 1) % T.G, R = (r + 1) % T.G;
+    // my first layer goes left (the left neighbour's right ghost), my last layer goes right
+    return {Xfer{buf + (size_t)lo[r] * 4, cnt(lo[r], fe[r]), L, buf + (size_t)lo[R] * 4, cnt(lo[R], fe[R]), R},
+            Xfer{buf + (size_t)lb[r] * 4, cnt(lb[r], lo[r + 1]), R, buf + (size_t)lb[L] * 4, cnt(lb[L], lo[L + 1]), L}};
+}
 template <class FB>
 static int team_ghost_exchange(pse_team &T, FB buf) {
     if (T.G == 1) return 0;
+    if (remote(T)) return team_exchange(T, ghost_ops(T, buf(T.m[0])), false);
     pse_handle *h0 = T.m[0];
     const std::vector<int> &lo = h0->row_lo, &fe = h0->first_end, &lb = h0->last_begin;
     auto cnt = [](int a, int b) { return (size_t)std::max(0, b - a) * 4; };
-    if (T.nccl) {
-        pse_handle *h = T.m[0];
-        const int r = h->slab_rank, L = (r + T.G - 1) % T.G, R = (r + 1) % T.G;
-        NCCLCHK(ncclGroupStart());
-        NCCLCHK(ncclSend(buf(h) + (size_t)lo[r] * 4, cnt(lo[r], fe[r]), ncclDouble, L, T.nccl, h->stream));
-        NCCLCHK(ncclSend(buf(h) + (size_t)lb[r] * 4, cnt(lb[r], lo[r + 1]), ncclDouble, R, T.nccl, h->stream));
-        NCCLCHK(ncclRecv(buf(h) + (size_t)lo[R] * 4, cnt(lo[R], fe[R]), ncclDouble, R, T.nccl, h->stream));
-        NCCLCHK(ncclRecv(buf(h) + (size_t)lb[L] * 4, cnt(lb[L], lo[L + 1]), ncclDouble, L, T.nccl, h->stream));
-        NCCLCHK(ncclGroupEnd());
-        return 0;
-    }
     auto member = [&](int r) { for (pse_handle *h : T.m) if (h->slab_rank == r) return h; return (pse_handle *)nullptr; };
     for (pse_handle *dst : T.m) {
         const int r = dst->slab_rank, L = (r + T.G - 1) % T.G, R = (r + 1) % T.G;
@@ -795,24 +838,11 @@ static int team_ghost_exchange(pse_team &T, FB buf) {
 }
 
 // One exchange per Lanczos iteration: the three partial sums (all-reduce) and the ghost rows of y = M x (every rank receives its
-// right neighbour's first cell layer and its left neighbour's last one) travel in ONE RCCL group.
+// right neighbour's first cell layer and its left neighbour's last one) travel in ONE group.
 template <class FS, class FB>
 static int team_lanczos_exchange(pse_team &T, FS sums, FB buf) {
     if (T.G == 1) return 0;
-    if (T.nccl) {
-        pse_handle *h = T.m[0];
-        const std::vector<int> &lo = h->row_lo, &fe = h->first_end, &lb = h->last_begin;
-        auto cnt = [](int a, int b) { return (size_t)std::max(0, b - a) * 4; };
-        const int r = h->slab_rank, L = (r + T.G - 1) % T.G, R = (r + 1) % T.G;
-        NCCLCHK(ncclGroupStart());
-        NCCLCHK(ncclAllReduce(sums(h), sums(h), 3, ncclDouble, ncclSum, T.nccl, h->stream));
-        NCCLCHK(ncclSend(buf(h) + (size_t)lo[r] * 4, cnt(lo[r], fe[r]), ncclDouble, L, T.nccl, h->stream));
-        NCCLCHK(ncclSend(buf(h) + (size_t)lb[r] * 4, cnt(lb[r], lo[r + 1]), ncclDouble, R, T.nccl, h->stream));
-        NCCLCHK(ncclRecv(buf(h) + (size_t)lo[R] * 4, cnt(lo[R], fe[R]), ncclDouble, R, T.nccl, h->stream));
-        NCCLCHK(ncclRecv(buf(h) + (size_t)lb[L] * 4, cnt(lb[L], lo[L + 1]), ncclDouble, L, T.nccl, h->stream));
-        NCCLCHK(ncclGroupEnd());
-        return 0;
-    }
+    if (remote(T)) return team_exchange(T, ghost_ops(T, buf(T.m[0])), false, sums(T.m[0]), 3);
     TRY(team_all_reduce_sum(T, sums, 3));
     return team_ghost_exchange(T, buf);
 }
@@ -822,17 +852,15 @@ template <class FB>
 static int team_all_gather_rows(pse_team &T, FB buf) {
     if (T.G == 1) return 0;
     const std::vector<int> &lo = T.m[0]->row_lo;
-    if (T.nccl) {
+    if (remote(T)) {
         pse_handle *h = T.m[0];
         const int r = h->slab_rank;
-        NCCLCHK(ncclGroupStart());
-        for (int q = 0; q < T.G; ++q) {
-            if (q == r) continue;
-            NCCLCHK(ncclSend(buf(h) + (size_t)lo[r] * 4, (size_t)(lo[r + 1] - lo[r]) * 4, ncclDouble, q, T.nccl, h->stream));
-            NCCLCHK(ncclRecv(buf(h) + (size_t)lo[q] * 4, (size_t)(lo[q + 1] - lo[q]) * 4, ncclDouble, q, T.nccl, h->stream));
-        }
-        NCCLCHK(ncclGroupEnd());
-        return 0;
+        std::vector<Xfer> ops;
+        for (int q = 0; q < T.G; ++q)
+            if (q != r)
+                ops.push_back(Xfer{buf(h) + (size_t)lo[r] * 4, (size_t)(lo[r + 1] - lo[r]) * 4, q,
+                                   buf(h) + (size_t)lo[q] * 4, (size_t)(lo[q + 1] - lo[q]) * 4, q});
+        return team_exchange(T, ops, false);
     }
     for (pse_handle *src : T.m)
         for (pse_handle *dst : T.m)
@@ -1251,7 +1279,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
     // A process-per-rank team keeps ONE stream and ONE communicator unless PSE_TEAM_OVERLAP=1 was set at pse_create: two
     // communicators on independent streams have no cross-rank launch order (the documented RCCL deadlock hazard when both
     // kernels cannot make progress at once), and no multi-GPU node has run this path yet.
-    const bool lanes = T.G == 1 || !T.nccl || T.nccl_w;
+    const bool lanes = T.G == 1 || loopback(T) || T.nccl_w;
     for (pse_handle *h : T.m) {   // where the wave chain of this call runs
         // the two chains share the chip whenever nothing is timed per kernel: with phase timing on, every kernel runs alone
         // on one stream (those durations are the roofline evidence)
@@ -1580,6 +1608,19 @@ extern "C" int pse_team_create(pse_handle **members, int n_members, const void *
     return 0;
 }
 
+extern "C" int pse_team_create_transport(pse_handle *member, const pse_transport *transport, pse_team **out) {
+    if (!member || !transport || !out || !transport->exchange || !transport->allreduce_sum) return fail(PSE_ERR_INVALID, "bad argument");
+    *out = nullptr;
+    if (member->n_slabs < 2) return fail(PSE_ERR_INVALID, "a team needs handles created with n_slabs >= 2");
+    pse_team *T = new pse_team();
+    T->m = {member};
+    T->G = member->n_slabs;
+    T->cb = *transport;
+    T->has_cb = true;
+    *out = T;
+    return 0;
+}
+
 extern "C" int pse_team_destroy(pse_team *T) {
     if (!T) return 0;
     for (pse_handle *h : T->m) {   // members take their own side stream back (an in-process team shared member 0's)
@@ -1588,6 +1629,7 @@ extern "C" int pse_team_destroy(pse_team *T) {
     if (T->nccl_w) ncclCommDestroy(T->nccl_w);
     if (T->nccl) ncclCommDestroy(T->nccl);
     if (T->scratch) (void)hipFree(T->scratch);
+    if (T->stage) (void)hipHostFree(T->stage);
     delete T;
     return 0;
 }

@@ -203,13 +203,44 @@ class Engine:
 class Team:
     """A pse_team: the local slab ranks bound to a transport (RCCL across processes, or in-process loopback)."""
 
-    def __init__(self, engines, unique_id=None):
+    def __init__(self, engines, unique_id=None, transport=None):
+        """transport: an object with exchange(xfers) and allreduce_sum(array) (see pse_amd.sharded.TorchTransport): the
+        host-staged third transport of include/pse_amd.h, one member per process."""
         self._lib = _lib.load()
         self.engines = list(engines)
-        arr = (ctypes.c_void_p * len(self.engines))(*[e._h for e in self.engines])
         self._t = ctypes.c_void_p()
+        if transport is not None:
+            self._transport = transport              # the callbacks must outlive the team
+            self._cb = _lib.pse_transport(None, _lib.EXCHANGE_FN(self._exchange), _lib.ALLREDUCE_FN(self._allreduce))
+            _lib.check(self._lib.pse_team_create_transport(self.engines[0]._h, ctypes.byref(self._cb), ctypes.byref(self._t)))
+            return
+        arr = (ctypes.c_void_p * len(self.engines))(*[e._h for e in self.engines])
         idbuf = ctypes.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
         _lib.check(self._lib.pse_team_create(arr, len(self.engines), idbuf, ctypes.byref(self._t)))
+
+    def _exchange(self, _user, n, xfers):
+        import numpy as np
+        try:
+            ops = []
+            for q in range(n):
+                x = xfers[q]
+                send = np.ctypeslib.as_array(x.send, shape=(x.send_count,)) if x.send_count else None
+                recv = np.ctypeslib.as_array(x.recv, shape=(x.recv_count,)) if x.recv_count else None
+                ops.append((send, x.send_to, recv, x.recv_from))
+            self._transport.exchange(ops)
+            return 0
+        except Exception as e:   # noqa: BLE001  (an exception must not unwind through the C caller)
+            print("pse_amd transport: exchange failed:", repr(e))
+            return 1
+
+    def _allreduce(self, _user, buf, n):
+        import numpy as np
+        try:
+            self._transport.allreduce_sum(np.ctypeslib.as_array(buf, shape=(n,)))
+            return 0
+        except Exception as e:   # noqa: BLE001
+            print("pse_amd transport: all-reduce failed:", repr(e))
+            return 1
 
     @staticmethod
     def unique_id():

@@ -44,6 +44,31 @@ def exchange_unique_id(rank, make_id, dist):
     return box[0]
 
 
+class TorchTransport:
+    """The host-staged transport of a process-per-rank team over ANY torch.distributed backend (gloo on CPU tensors here): what
+    the C++ team hands over is host memory, so the exchange is a batch of isend / irecv on tensors that alias it.  Transfers
+    between one pair of ranks match in list order on both sides (the team builds its lists that way)."""
+
+    def __init__(self, dist, group=None):
+        self.dist, self.group = dist, group
+
+    def exchange(self, ops):
+        import torch
+        reqs = []
+        for send, to, recv, frm in ops:          # receives first: nothing blocks on an unposted receive
+            if recv is not None:
+                reqs.append(self.dist.irecv(torch.from_numpy(recv), src=frm, group=self.group))
+        for send, to, recv, frm in ops:
+            if send is not None:
+                reqs.append(self.dist.isend(torch.from_numpy(send), dst=to, group=self.group))
+        for r in reqs:
+            r.wait()
+
+    def allreduce_sum(self, buf):
+        import torch
+        self.dist.all_reduce(torch.from_numpy(buf), op=self.dist.ReduceOp.SUM, group=self.group)
+
+
 class _State:
     def __init__(self, n, pos, force, mass):
         import torch
@@ -55,16 +80,24 @@ class _State:
 
 
 class ShardedSimulation:
-    def __init__(self, n, box, world, rank, **kw):
+    def __init__(self, n, box, world, rank, transport="rccl", **kw):
+        """transport: "rccl" (one GPU per rank, xGMI) or "host" (staged through host memory over torch.distributed's default group:
+        any backend, ranks may even share a GPU -- the process-per-rank driver is tested that way on a one-GPU box)."""
         import torch.distributed as dist
         self.n, self.world, self.rank = n, world, rank
         self.engine = Engine(n, box, n_slabs=world, slab_rank=rank, **kw)
-        uid = exchange_unique_id(rank, Team.unique_id, dist)
-        self.team = Team([self.engine], unique_id=uid)
+        if transport == "host":
+            self.team = Team([self.engine], transport=TorchTransport(dist))
+        else:
+            uid = exchange_unique_id(rank, Team.unique_id, dist)
+            self.team = Team([self.engine], unique_id=uid)
 
     def describe(self):
         import os
         mode = os.environ.get("PSE_WAVE_MODE") or ("replicated" if self.world == 2 else "slab")
+        if getattr(self.team, "_transport", None) is not None:
+            return (f"{self.world} ranks over the HOST-STAGED transport (torch.distributed gloo, not RCCL): a functional run of the "
+                    f"process-per-rank driver, far field {mode}; not a scaling number")
         if mode == "replicated":
             return (f"{self.world} GPUs: far field kept whole on every rank (at two ranks the all-to-all would cross one xGMI link "
                     f"each way), near field / Lanczos vectors owned by the rank whose cell slab holds the particle (neighbour "
@@ -90,6 +123,10 @@ class ShardedSimulation:
     def mobility(self):
         self.team.mobility([self.s.pos], [self.s.force], [self.s.vel])
         return self.s.vel
+
+    def brownian_velocity(self, kT, dt, timestep, lanczos_m=2):
+        s = self.s
+        return self.team.brownian_velocity([s.pos], [s.force], [s.vel], kT, dt, timestep, lanczos_m=lanczos_m)
 
     def step(self, kT, dt, timestep, shear_rate=0.0, lanczos_m=2):
         s = self.s

@@ -105,3 +105,47 @@ def test_slab_plan_and_cell_slabs():
     assert cell_slabs(58, 8) == [(7 * r, 7 * r + 7) for r in range(8)]
     with pytest.raises(ValueError):
         cell_slabs(5, 8)
+
+
+def _transport_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from pse_amd.sharded import TorchTransport
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tr = TorchTransport(dist)
+        peer = 1 - rank
+        # two transfers to the same peer in one exchange (the ghost exchange of a two-rank team): they must arrive in list order
+        a, b = np.full(5, 10.0 + rank), np.full(3, 20.0 + rank)
+        ra, rb = np.zeros(5), np.zeros(3)
+        tr.exchange([(a, peer, ra, peer), (b, peer, rb, peer), (None, -1, None, -1)])
+        assert np.all(ra == 10.0 + peer) and np.all(rb == 20.0 + peer)
+        # a send without a receive and a receive without a send
+        if rank == 0:
+            tr.exchange([(np.arange(4.0), 1, None, -1)])
+        else:
+            r = np.zeros(4); tr.exchange([(None, -1, r, 0)]); assert np.all(r == np.arange(4.0))
+        s = np.array([1.0 + rank, 2.0, -3.0 * rank])
+        tr.allreduce_sum(s)
+        assert np.allclose(s, [3.0, 4.0, -3.0])
+        out.put((rank, "ok"))
+    except Exception as e:   # noqa: BLE001
+        out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_host_staged_transport_over_gloo():
+    """pse_amd.sharded.TorchTransport: the Python half of the team's third transport (include/pse_amd.h pse_transport)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_transport_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

@@ -1,0 +1,105 @@
+"""The process-per-rank team driven by REAL processes ("weak" 9): G ranks = G processes on the one-GPU box, every
+exchange of the C++ team carried by the host-staged transport over torch.distributed (gloo).  The transfer lists are the ones the
+RCCL transport posts (one code path builds them: team_exchange in csrc/pse_capi.hip), so buffers, counts, peers and order of
+every all-to-all, halo exchange, ghost-row exchange, Lanczos exchange and row all-gather run between separate address spaces
+here -- what RCCL refuses to do on a single device ("Duplicate GPU detected")."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, mode, xy, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    if mode:
+        os.environ["PSE_WAVE_MODE"] = mode
+    try:
+        import torch
+        import torch.distributed as dist
+        from conftest import make_suspension, to4
+        import pse_amd
+        from pse_amd.sharded import ShardedSimulation
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        n, grid = 24_000, 64
+        pos, force, box = make_suspension(n, phi=0.1, xy=xy)
+        import math
+        xi = math.pi * grid / (2.0 * box[0] * math.sqrt(-math.log(1e-3)))       # xi from the fixed grid
+        kw = dict(xi=xi, error=1e-3, seed=5, grid=(grid,) * 3)
+        sim = ShardedSimulation(n, box, world, rank, transport="host", **kw)
+        sim.load(pos, force)
+        u_mf = sim.mobility().cpu().numpy()[:, :3].copy()
+        _, m = sim.brownian_velocity(1.0, 1e-3, 7, lanczos_m=2)
+        u_b = sim.s.vel.cpu().numpy()[:, :3].copy()
+        m2 = sim.step(1.0, 1e-3, 8, shear_rate=0.3, lanczos_m=m)
+        p_new = sim.s.pos.cpu().numpy()[:, :3].copy()
+        # every rank ends with the same arrays
+        for a in (u_mf, u_b, p_new):
+            t = torch.from_numpy(a.copy()); ref = t.clone()
+            dist.broadcast(ref, src=0)
+            assert torch.equal(t, ref), "ranks disagree"
+        if rank == 0:   # and they are the single-GPU engine's
+            eng = pse_amd.Engine(n, box, **kw)
+            dpos, dF = to4(pos), to4(force)
+            r_mf = eng.mobility(dpos, dF).cpu().numpy()[:, :3]
+            vel = to4(np.zeros((n, 3)), 1.0)
+            _, mr = eng.brownian_velocity(dpos, dF, 1.0, 1e-3, 7, vel=vel, lanczos_m=2)
+            r_b = vel.cpu().numpy()[:, :3].copy()
+            accel = torch.zeros((n, 3), dtype=torch.float64, device="cuda"); image = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+            mr2 = eng.step(dpos, vel, accel, image, dF, 1.0, 1e-3, 8, shear_rate=0.3, lanczos_m=mr)
+            rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)   # noqa: E731
+            assert rel(u_mf, r_mf) < 1e-11, rel(u_mf, r_mf)
+            assert m == mr and rel(u_b, r_b) < 1e-9, (m, mr, rel(u_b, r_b))
+            assert m2 == mr2 and np.abs(p_new - dpos.cpu().numpy()[:, :3]).max() < 1e-9
+        dist.barrier()
+        out.put((rank, "ok"))
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        out.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))[-1500:]))
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:   # noqa: BLE001
+            pass
+
+
+@pytest.mark.parametrize("world,mode,xy", [(2, "", 0.0), (2, "slab", 0.2), (4, "", 0.25), (8, "", 0.0)])
+def test_team_of_processes_matches_single_gpu(world, mode, xy):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, xy, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` as the driver calls it: the parent starts the two ranks itself and relays rank 0's line.  On the
+    one-GPU box the ranks share the device through the host-staged transport (RCCL needs a GPU per rank)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "host", "--steps", "2", "--warmup", "1",
+                        "--no-cpu", "--n", "100000", "--grid", "128"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert "HOST-STAGED" in d["config"]["parallelism"]

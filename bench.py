@@ -61,6 +61,44 @@ def cpu_baseline(budget_s=12.0):
     }
 
 
+def measure_traffic(kernel_prefix, args):
+    """HBM bytes per launch of one kernel, measured NOW: two child runs of this same script (a few steps, one stream, no
+    extras) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, as MI355X_MICROARCH.md prescribes; the
+    counters cannot be read from inside a process.  2 x FETCH_SIZE + WRITE_SIZE (the x2 of the guide, calibrated for every access
+    shape in use by tools/microbench/nt_fetch.hip).  None if the profiler is not there or a pass fails: the caller falls back to
+    the --traffic file and says so."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    env = dict(os.environ, TMPDIR="/tmp", PSE_OVERLAP="0")
+    py = os.path.realpath(sys.executable)
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pse_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", py, os.path.abspath(__file__),
+               "--steps", "3", "--warmup", "1", "--no-cpu", "--no-ref-grid", "--no-traffic", "--n", str(args.n), "--phi", str(args.phi),
+               "--grid", str(args.grid), "--error", str(args.error), "--kT", str(args.kT), "--dt", str(args.dt)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            v = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                 if row["Counter_Name"] == counter and row["Kernel_Name"].replace("void ", "").startswith(kernel_prefix)]
+            if not v:
+                return None
+            vals[counter] = sum(v) / len(v) * 1024.0            # the counters are reported in KiB
+        except Exception:   # noqa: BLE001  (a profiler hiccup must not cost the bench line)
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]
+
+
 def launch_ranks(args, argv):
     """--gpus N without a torch.distributed environment: start the N ranks as a child torch.distributed.run and relay rank 0's
     line.  This process has not initialised HIP (torch is not even imported yet) and never replaces itself: the ranks are
@@ -113,6 +151,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="HBM bytes per kernel from separate rocprofv3 --pmc passes of this command (tools/round_profile.sh)")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure the dominant kernel's HBM bytes with rocprofv3 child passes")
     ap.add_argument("--no-ref-grid", action="store_true", help="skip the extra steps on the reference rule's 360^3 grid")
     ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
                     help="multi-rank runs: RCCL over xGMI (one GPU per rank), or the host-staged transport over gloo (ranks may "
@@ -244,8 +283,13 @@ def main():
     # factor is calibrated for this kernel's non-temporal list loads by tools/microbench/nt_fetch) and carries the commit the
     # passes were taken at, so a stale file shows
     traffic, traffic_src = None, None
+    if world == 1 and not args.no_traffic and dom in pmc_names:
+        traffic = measure_traffic(pmc_names[dom], args)       # child processes with their own engine (this one idles meanwhile)
+        if traffic is not None:
+            traffic_src = ("measured in this run: 2 x FETCH_SIZE + WRITE_SIZE of that kernel, per launch, from two rocprofv3 --pmc child "
+                           "passes of this command (3 steps, one stream)")
     tr_file = args.traffic
-    if tr_file and os.path.exists(tr_file) and world == 1 and n == 1_000_000 and grid == 256:
+    if traffic is None and tr_file and os.path.exists(tr_file) and world == 1 and n == 1_000_000 and grid == 256:
         try:
             tj = json.load(open(tr_file))
             for k, v in tj.items():

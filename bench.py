@@ -18,6 +18,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -99,34 +100,59 @@ def measure_traffic(kernel_prefix, args):
     return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]
 
 
-def launch_ranks(args, argv):
-    """--gpus N without a torch.distributed environment: start the N ranks as a child torch.distributed.run and relay rank 0's
-    line.  This process has not initialised HIP (torch is not even imported yet) and never replaces itself: the ranks are
-    children, their exit code is ours."""
+def launch_ranks(args, argv, script=None):
+    """--gpus N without a torch.distributed environment: start the N ranks as children (one process per GPU, the environment
+    torch.distributed.run would give them: RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT) and relay
+    rank 0's line.  This process has not initialised HIP (torch is not even imported yet) and never replaces itself: the ranks
+    are children, the first non-zero exit code among them is ours, and when one fails the others (exactly those PIDs) are ended."""
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
     rest = [a for a in argv if a != "--dry-run"]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + rest
+    cmd = [sys.executable, script or os.path.abspath(__file__)] + rest
+    rank_env = {"WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
     if args.dry_run:
-        print(json.dumps({"launch": cmd, "n_gpus": args.gpus}))
+        print(json.dumps({"launch": cmd, "env": dict(rank_env, RANK="<r>", LOCAL_RANK="<r>"), "n_gpus": args.gpus}))
         return 0
-    env = dict(os.environ)
+    env = dict(os.environ, **rank_env)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
-    line = None
-    for out in proc.stdout:
-        out = out.rstrip("\n")
-        try:
-            if "metric" in json.loads(out):
-                line = out
+    env.setdefault("OMP_NUM_THREADS", "1")
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True, env=e))
+    found = []
+
+    def relay():
+        for out in procs[0].stdout:
+            out = out.rstrip("\n")
+            try:
+                if "metric" in json.loads(out):
+                    found.append(out)
+                    continue
+            except ValueError:
+                pass
+            print(out, file=sys.stderr)
+
+    reader = threading.Thread(target=relay, daemon=True)      # rank 0 may be the one left waiting when another rank dies
+    reader.start()
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
                 continue
-        except ValueError:
-            pass
-        print(out, file=sys.stderr)
-    rc = proc.wait()
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:                       # a rank failed: the rest would wait in a collective for ever
+                    q.terminate()
+        if pending:
+            time.sleep(0.05)
+    reader.join(timeout=30)
+    line = found[-1] if found else None
     if rc != 0:
         print(f"bench.py: the {args.gpus}-rank run failed (exit code {rc})", file=sys.stderr)
         return rc

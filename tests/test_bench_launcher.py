@@ -1,6 +1,9 @@
 """bench.py --gpus N must be runnable exactly as the driver runs it (`python3 bench.py --gpus N`): the parent process starts
-the N ranks as a child torch.distributed.run and relays rank 0's line; it never initialises the GPU and never replaces
-itself.  CPU only: --dry-run stops before anything is launched; a fake rank script stands in for the real ranks."""
+the N ranks itself (one child per GPU with the environment torch.distributed.run would give them), relays rank 0's line and
+the first failing exit code; it never initialises the GPU and never replaces itself.  CPU only: --dry-run stops before
+anything is launched; a stand-in script plays the ranks."""
+import argparse
+import importlib.util
 import json
 import os
 import subprocess
@@ -19,17 +22,14 @@ def _run(args, env=None):
 
 
 def test_dry_run_prints_the_launch_command():
-    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"])
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--n", "1000", "--dry-run"])
     assert r.returncode == 0, r.stderr
     d = json.loads(r.stdout.strip().splitlines()[-1])
     cmd = d["launch"]
     assert d["n_gpus"] == 2
-    assert cmd[1:3] == ["-m", "torch.distributed.run"]
-    assert "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
-    assert int(cmd[cmd.index("--master-port") + 1]) > 0
-    i = cmd.index(BENCH)
-    assert cmd[i + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]       # the ranks get the same arguments, minus --dry-run
+    assert cmd[1] == BENCH
+    assert cmd[2:] == ["--gpus", "2", "--steps", "3", "--warmup", "1", "--n", "1000"]   # the ranks get the same arguments, minus --dry-run
+    assert d["env"]["MASTER_ADDR"] == "127.0.0.1" and int(d["env"]["MASTER_PORT"]) > 0 and d["env"]["WORLD_SIZE"] == "2"
 
 
 def test_single_gpu_does_not_launch():
@@ -43,22 +43,45 @@ def test_rank_refuses_a_world_that_disagrees_with_gpus():
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
 
 
-def test_launcher_relays_rank0_line_and_exit_code(tmp_path):
-    """The relay logic with stand-in ranks: python -m torch.distributed.run is replaced by a stub module on PYTHONPATH."""
-    pkg = tmp_path / "torch" / "distributed"
-    pkg.mkdir(parents=True)
-    (tmp_path / "torch" / "__init__.py").write_text("")
-    (pkg / "__init__.py").write_text("")
-    (pkg / "run.py").write_text(
-        "import json, os, sys\n"
-        "print('rank noise that is not the result line')\n"
-        "if os.environ.get('FAKE_FAIL'): sys.exit(3)\n"
-        "print(json.dumps({'metric': 'm', 'value': 1.0, 'n_gpus': int(sys.argv[sys.argv.index('--gpus') + 1])}))\n")
-    env = {"PYTHONPATH": str(tmp_path)}
-    r = _run(["--gpus", "2", "--steps", "1"], env=env)
-    assert r.returncode == 0, r.stderr
-    lines = r.stdout.strip().splitlines()
-    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2          # exactly one JSON line on stdout
-    assert "rank noise" in r.stderr
-    r = _run(["--gpus", "2", "--steps", "1"], env={**env, "FAKE_FAIL": "1"})
-    assert r.returncode == 3 and r.stdout.strip() == ""
+STAND_IN = """
+import json, os, sys, time
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+assert os.environ['LOCAL_RANK'] == os.environ['RANK'] and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0
+print(f'noise from rank {rank}')
+mode = os.environ.get('FAKE', '')
+if mode == 'fail' and rank == 1:
+    sys.exit(3)
+if mode == 'fail':
+    time.sleep(600)            # a rank waiting in a collective for the one that died: the launcher must end it
+if rank == 0:
+    print(json.dumps({'metric': 'm', 'value': 1.0, 'n_gpus': world, 'argv': sys.argv[1:]}))
+"""
+
+
+def _bench_module():
+    spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_launcher_relays_rank0_line_and_exit_code(tmp_path, capfd, monkeypatch):
+    script = tmp_path / "rank.py"
+    script.write_text(STAND_IN)
+    bench = _bench_module()
+    args = argparse.Namespace(gpus=3, dry_run=False)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    rc = bench.launch_ranks(args, ["--gpus", "3", "--n", "1000", "--dry-run"], script=str(script))
+    out, err = capfd.readouterr()
+    assert rc == 0
+    lines = out.strip().splitlines()
+    d = json.loads(lines[-1])
+    assert len(lines) == 1 and d["n_gpus"] == 3 and d["argv"] == ["--gpus", "3", "--n", "1000"]     # exactly one JSON line on stdout
+    assert all(f"noise from rank {r}" in err for r in range(3))
+    import time
+    monkeypatch.setenv("FAKE", "fail")
+    t0 = time.time()
+    rc = bench.launch_ranks(args, ["--gpus", "3"], script=str(script))
+    out, err = capfd.readouterr()
+    assert rc == 3 and out.strip() == "" and time.time() - t0 < 60

@@ -7,9 +7,9 @@ synthetic random-sphere suspension of BASELINE.json's metric point (N = 1e6, phi
 resident in HBM before the timed region.  value = particle-steps/s summed over all ranks.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--n PARTICLES] [--grid G] [--no-cpu] [--traffic FILE] [--dry-run]
-With --gpus N > 1 and no torch.distributed environment the process launches the N ranks itself (a child
-`python -m torch.distributed.run ... bench.py`, one rank per GPU; the parent never touches the GPU) and relays rank 0's
-JSON line; started under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.  See DESIGN.md "Multi-GPU".
+With --gpus N > 1 and no torch.distributed environment the process launches the N ranks itself (one child
+`python bench.py ...` per GPU with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set; the parent never touches the GPU) and relays
+rank 0's JSON line; started under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.  See DESIGN.md "Multi-GPU".
 """
 import argparse
 import json

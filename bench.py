@@ -168,7 +168,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--n", "--particles", dest="n", type=int, default=1_000_000,
+                    help="(--particles under torch.distributed.run, whose parser reads a bare --n as an abbreviation of its own options)")
     ap.add_argument("--phi", type=float, default=0.1)
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--error", type=float, default=1e-3)
@@ -199,7 +200,13 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the torch.distributed environment has WORLD_SIZE={world}")
     host_transport = args.transport == "host"
-    device = local_rank % torch.cuda.device_count() if host_transport else local_rank
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    if not host_transport and local_rank >= n_dev:
+        raise SystemExit(f"--gpus {args.gpus} over RCCL needs one GPU per rank and this node has {n_dev}; "
+                         "--transport host lets ranks share a device (never the headline)")
+    device = local_rank % n_dev if host_transport else local_rank
     torch.cuda.set_device(device)
     use_dist = world > 1 or "PSE_FORCE_SHARDED" in os.environ
     if use_dist:

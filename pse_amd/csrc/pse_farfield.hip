@@ -533,7 +533,8 @@ k_gather_bins(const FarRec *__restrict__ rec, FarBins fb, FastDiv dz, FastDiv dy
     __shared__ double s_w[NW * PPP];          // ax[P], ay[P], z-window weights[ZW] of the pass's particles: [t][particle]
     __shared__ int s_o[PPP];                  // row of the window's first node inside the region
     __shared__ unsigned s_id[PPP];            // sorted index | not-owned flag
-    __shared__ double s_k[SHEAR ? P * 8 : 1];
+    constexpr int KS = P <= 8 ? 8 : 16;   // row stride of the shear table K[tx][ty] (ty < P)
+    __shared__ double s_k[SHEAR ? P * KS : 1];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // One (bin, component) per workgroup: a 19 KB region instead of 57 KB, so eight workgroups share a CU and their
     // load -> wait -> compute phases overlap (what a CU can have in flight is bounded by the LDS it can fill).
@@ -547,7 +548,8 @@ k_gather_bins(const FarRec *__restrict__ rec, FarBins fb, FastDiv dz, FastDiv dy
     if (n == 0) return;
     const double *g = cmp == 0 ? gx : (cmp == 1 ? gy : gz);
     const int t0[3] = {bx * BIN, by * BIN, bz * BIN};
-    if (SHEAR && tid < P * 8) s_k[tid] = exp_lean(gc.lnk * (double)((tid >> 3) * (tid & 7)));
+    static_assert(P <= 16 && P * KS <= NT, "one table entry per thread");
+    if (SHEAR && tid < P * KS) s_k[tid] = exp_lean(gc.lnk * (double)((tid / KS) * (tid % KS)));
     // Piece e of the region = 16 bytes (qx, qy, 2 hz .. 2 hz + 1), stored in that order.
     const bool windowed = G.nxl < G.Nx;
     // first plane of the region in the stored array (a slab rank stores planes x0 - hl .. x0 + nxl + nhalo - 1)
@@ -632,7 +634,7 @@ k_gather_bins(const FarRec *__restrict__ rec, FarBins fb, FastDiv dz, FastDiv dy
 #pragma unroll
                 for (int ty = 0; ty < P; ++ty) {
                     double w = ay[ty];
-                    if (SHEAR) w *= s_k[tx * 8 + ty];
+                    if (SHEAR) w *= s_k[tx * KS + ty];
                     const double *r = r0 + tx * ROW + ty * EZ;
                     if (ZPL == 2) {
                         const double2 a = *reinterpret_cast<const double2 *>(r);

@@ -1,0 +1,73 @@
+"""Parity on configurations nobody picked by hand: seeded random boxes (three different edge lengths, any tilt the reference
+allows), particle counts around the wave and block sizes (1, 2, 63, 64, 65, ...), grids from the reference's rule and explicit ones
+with odd / non-2-3-5 sizes (which take the rocFFT x pass instead of the fused one), several accuracies.  Every case holds the
+three parts of the path to the oracle: near field <= 1e-12 (C direct sum over minimum images), far field <= 1e-10 and the
+Brownian velocity <= 1e-9 with the same Lanczos count (NumPy restatement of the reference algorithm)."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import to4
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def config(seed):
+    rng = np.random.default_rng(1000 + seed)
+    err = [1e-3, 1e-4, 1e-6][seed % 3]
+    xi = rng.uniform(0.45, 0.7)
+    rcut = math.sqrt(-math.log(err)) / xi
+    lo = 2.3 * rcut                                                  # the minimum image needs rcut < half the narrowest width
+    Lx, Ly, Lz = (float(rng.uniform(lo, lo + 14.0)) for _ in range(3))
+    xy = float(rng.uniform(-0.5, 0.5)) if seed % 4 else 0.0
+    n = [1, 2, 63, 64, 65, 127, 129, 300, 777, 1500, 2049, 2500][seed % 12]
+    grid = None
+    if seed % 3 == 1:                                                # explicit grid: odd and prime sizes included
+        pick = rng.choice([22, 27, 31, 33, 36, 40, 45, 49, 50], 3)
+        grid = tuple(int(g) for g in pick)
+    box = (Lx, Ly, Lz, xy)
+    f = rng.uniform(-0.5, 0.5, (n, 3))
+    pos = np.empty((n, 3))
+    pos[:, 1] = f[:, 1] * Ly
+    pos[:, 2] = f[:, 2] * Lz
+    pos[:, 0] = f[:, 0] * Lx + xy * pos[:, 1]
+    if n > 2:                                                        # a particle on a face and two nearly touching across a face
+        pos[0] = (-0.5 * Lx + xy * pos[0, 1], pos[0, 1], pos[0, 2])
+        pos[1] = (pos[2, 0] + Lx - 2.05, pos[2, 1], pos[2, 2]) if pos[2, 0] < 0 else (pos[2, 0] - Lx + 2.05, pos[2, 1], pos[2, 2])
+        fx = (pos[1, 0] - xy * pos[1, 1]) / Lx
+        pos[1, 0] -= round(fx) * Lx                                  # back into the box
+    force = rng.normal(size=(n, 3))
+    return dict(box=box, xi=xi, err=err, grid=grid, pos=pos, force=force, n=n, seed=int(rng.integers(1, 2 ** 31)))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configuration(oracle, seed):
+    import torch
+    import pse_amd
+    assert torch.cuda.is_available()
+    c = config(seed)
+    p = oracle.select_params(c["box"], c["xi"], c["err"], 0.5, grid=c["grid"])
+    if p["eta"] >= 1.0:
+        pytest.skip("the drawn grid is too coarse for this xi (eta >= 1: the engine refuses it, as the rule demands)")
+    eng = pse_amd.Engine(max(c["n"], 8), c["box"], xi=c["xi"], error=c["err"], grid=c["grid"] or (0, 0, 0), seed=c["seed"])
+    i = eng.info()
+    assert (i["Nx"], i["Ny"], i["Nz"]) == p["grid"] and i["P"] == p["P"] and abs(i["eta"] - p["eta"]) < 1e-13
+    pos, force = c["pos"], c["force"]
+    ur = eng.mobility(to4(pos), to4(force), parts=1).cpu().numpy()[:, :3]
+    ref_r = oracle.mobility_real(pos, force, c["box"], c["xi"], i["rcut"])
+    assert rel(ur, ref_r) < 1e-12, ("near field", seed, rel(ur, ref_r))
+    uw = eng.mobility(to4(pos), to4(force), parts=2).cpu().numpy()[:, :3]
+    ref_w = oracle.mobility_wave(pos, force, c["box"], p)
+    assert rel(uw, ref_w) < 1e-10, ("far field", seed, rel(uw, ref_w))
+    u = eng.mobility(to4(pos), to4(force)).cpu().numpy()[:, :3]
+    assert rel(u, ref_r + ref_w) < 1e-10
+    vel, m = eng.brownian_velocity(to4(pos), to4(force), 0.7, 2e-3, 5 + seed)
+    ref, mref = oracle.brownian_velocity(pos, force, c["box"], p, 0.7, 2e-3, c["seed"], 5 + seed)
+    assert m == mref, (seed, m, mref)
+    assert rel(vel.cpu().numpy()[:, :3], ref) < 1e-9, ("Brownian", seed, rel(vel.cpu().numpy()[:, :3], ref))
+    eng.close()

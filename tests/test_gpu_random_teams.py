@@ -21,7 +21,7 @@ def config(seed):
     err = [1e-3, 1e-4, 1e-5, 1e-6][seed % 4]
     s = math.sqrt(-math.log(err))
     nx = int(rng.choice([48, 60, 72, 96])) if world != 4 else int(rng.choice([64, 80, 96]))     # slabs of whole planes, wider than a support
-    grid = (nx, int(rng.choice([32, 36, 40, 48])), int(rng.choice([32, 36, 40, 48])))
+    grid = (nx, int(rng.choice([36, 48] if world == 3 else [32, 36, 40, 48])), int(rng.choice([32, 36, 40, 48])))   # Nx, Ny: multiples of the rank count
     h = rng.uniform(0.65, 0.9, 3)
     box = tuple(float(grid[a] * h[a]) for a in range(3)) + (float(rng.uniform(-0.45, 0.45)) if seed % 2 else 0.0,)
     xi = float(0.9 * min(math.pi / (2.0 * h[a] * s) for a in range(3)))

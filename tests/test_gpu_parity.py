@@ -332,16 +332,16 @@ def test_fluctuation_dissipation(torch_cuda, oracle):
     assert np.linalg.norm(C - M) / np.linalg.norm(M) < 0.1
 
 
-@pytest.mark.parametrize("xy", [0.0, 0.3])
-def test_both_halves_symmetric_positive_definite(torch_cuda, xy):
+@pytest.mark.parametrize("xy,err,L", [(0.0, 1e-3, 18.0), (0.3, 1e-3, 18.0), (0.3, 1e-6, 24.0), (-0.4, 1e-5, 24.0)])   # P = 6, 6, 13, 11 (binned far field)
+def test_both_halves_symmetric_positive_definite(torch_cuda, xy, err, L):
     """The "positively split" claim (SURVEY.md 8c property ii): M_real and M_wave are separately symmetric positive
     definite.  Symmetry of the wave half is the adjointness of the spread and gather kernels (same weights) through the
     real-to-complex transforms: exact to rounding."""
     import pse_amd
-    n, L = 30, 18.0
+    n = 30
     box = (L, L, L, xy)
     pos, _, _ = make_suspension(n, L=L, xy=xy)
-    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3)
+    eng = pse_amd.Engine(n, box, xi=0.5, error=err)
     dpos = to4(pos)
     eye = np.eye(3 * n)
     for parts, tol in ((1, 1e-13), (2, 1e-12)):

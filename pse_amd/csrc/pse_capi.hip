@@ -82,6 +82,7 @@ struct pse_handle {
         double skin = 0.4;        // PSE_SKIN: r_buff of the neighbour list kept across calls (0: off)
         int overlap = 1;          // PSE_OVERLAP: 1 two chains for every call, 0 only for kT = 0, -1 never
         bool no_xfuse = false;    // PSE_NO_XFUSE: rocFFT for the x pass
+        bool team_fused_group = false;   // PSE_TEAM_FUSED_GROUP: RCCL teams put the Lanczos sum into the group of the ghost transfers
         int wave_mode = 0;        // PSE_WAVE_MODE: 0 automatic, 1 slab, 2 replicated
         int spread_tz = 0, spread_nw = 0;   // PSE_SPREAD_TZ, PSE_SPREAD_NW
         bool verbose = false;     // PSE_VERBOSE
@@ -406,6 +407,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         if (const char *v = getenv("PSE_SKIN")) t.skin = atof(v);
         t.overlap = ienv("PSE_OVERLAP", 1);
         t.no_xfuse = getenv("PSE_NO_XFUSE") != nullptr;
+        if (const char *v = getenv("PSE_TEAM_FUSED_GROUP")) t.team_fused_group = atoi(v) != 0;
         if (const char *v = getenv("PSE_WAVE_MODE")) t.wave_mode = !strcmp(v, "slab") ? 1 : (!strcmp(v, "replicated") ? 2 : 0);
         t.spread_tz = ienv("PSE_SPREAD_TZ", 0); t.spread_nw = ienv("PSE_SPREAD_NW", 0);
         t.verbose = ienv("PSE_VERBOSE", 0) > 0;
@@ -682,17 +684,37 @@ struct Xfer { const double *send; size_t ns; int to; double *recv; size_t nr; in
 static int team_exchange(pse_team &T, const std::vector<Xfer> &ops, bool wave_lane, double *sum_buf = nullptr, size_t sum_n = 0) {
     pse_handle *h = T.m[0];
     hipStream_t s = wave_lane ? h->wstream : h->stream;
+    const int me = h->slab_rank;
+    // a rank's sends to itself and its receives from itself pair up in order (the all-to-all's diagonal block): local copies in
+    // every transport (nothing of the exchange depends on how a library treats a send to the calling rank)
+    std::vector<const Xfer *> self_send, self_recv;
+    for (const Xfer &x : ops) {
+        if (x.ns && x.to == me) self_send.push_back(&x);
+        if (x.nr && x.from == me) self_recv.push_back(&x);
+    }
+    if (self_send.size() != self_recv.size()) return fail(PSE_ERR_COMM, "unpaired self transfer");
+    for (size_t q = 0; q < self_send.size(); ++q) {
+        if (self_send[q]->ns != self_recv[q]->nr) return fail(PSE_ERR_COMM, "self transfer of unequal sizes");
+        if (self_recv[q]->recv != self_send[q]->send)
+            HIPCHK(hipMemcpyAsync(self_recv[q]->recv, self_send[q]->send, self_send[q]->ns * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
     if (T.nccl) {
         ncclComm_t comm = wave_lane ? wave_comm(T) : T.nccl;
+        // the sum travels as its own collective unless PSE_TEAM_FUSED_GROUP=1 puts it into the group of the transfers (one launch
+        // less per Lanczos iteration; a collective and point-to-point calls in one group have never run here: ADVICE r2)
+        const bool fused = h->tun.team_fused_group;
+        if (sum_n && !fused) NCCLCHK(ncclAllReduce(sum_buf, sum_buf, sum_n, ncclDouble, ncclSum, comm, s));
+        bool any = sum_n && fused;
+        for (const Xfer &x : ops) any = any || (x.ns && x.to != me) || (x.nr && x.from != me);
+        if (!any) return 0;
         NCCLCHK(ncclGroupStart());
-        if (sum_n) NCCLCHK(ncclAllReduce(sum_buf, sum_buf, sum_n, ncclDouble, ncclSum, comm, s));
-        for (const Xfer &x : ops) if (x.ns) NCCLCHK(ncclSend(x.send, x.ns, ncclDouble, x.to, comm, s));
-        for (const Xfer &x : ops) if (x.nr) NCCLCHK(ncclRecv(x.recv, x.nr, ncclDouble, x.from, comm, s));
+        if (sum_n && fused) NCCLCHK(ncclAllReduce(sum_buf, sum_buf, sum_n, ncclDouble, ncclSum, comm, s));
+        for (const Xfer &x : ops) if (x.ns && x.to != me) NCCLCHK(ncclSend(x.send, x.ns, ncclDouble, x.to, comm, s));
+        for (const Xfer &x : ops) if (x.nr && x.from != me) NCCLCHK(ncclRecv(x.recv, x.nr, ncclDouble, x.from, comm, s));
         NCCLCHK(ncclGroupEnd());
         return 0;
     }
     // host-staged transport: device -> pinned host, the host program moves the bytes, pinned host -> device
-    const int me = h->slab_rank;
     size_t need = sum_n;
     for (const Xfer &x : ops) need += (x.to == me ? 0 : x.ns) + (x.from == me ? 0 : x.nr);
     if (need > T.stage_n) {
@@ -707,25 +729,15 @@ static int team_exchange(pse_team &T, const std::vector<Xfer> &ops, bool wave_la
     if (sum_n) { sum_host = T.stage; HIPCHK(hipMemcpyAsync(sum_host, sum_buf, sum_n * sizeof(double), hipMemcpyDeviceToHost, s)); off = sum_n; }
     std::vector<std::pair<double *, const double *>> back;   // (device destination, host source) of what arrives
     std::vector<size_t> back_n;
-    // a rank's sends to itself and its receives from itself pair up in order (the all-to-all's diagonal block)
-    std::vector<const Xfer *> self_send, self_recv;
     for (const Xfer &x : ops) {
         pse_host_xfer e{};
-        if (x.ns && x.to == me) self_send.push_back(&x);
-        else if (x.ns) { e.send = T.stage + off; e.send_count = x.ns; e.send_to = x.to; HIPCHK(hipMemcpyAsync(T.stage + off, x.send, x.ns * sizeof(double), hipMemcpyDeviceToHost, s)); off += x.ns; }
-        if (x.nr && x.from == me) self_recv.push_back(&x);
-        else if (x.nr) { e.recv = T.stage + off; e.recv_count = x.nr; e.recv_from = x.from; back.push_back({x.recv, T.stage + off}); back_n.push_back(x.nr); off += x.nr; }
+        if (x.ns && x.to != me) { e.send = T.stage + off; e.send_count = x.ns; e.send_to = x.to; HIPCHK(hipMemcpyAsync(T.stage + off, x.send, x.ns * sizeof(double), hipMemcpyDeviceToHost, s)); off += x.ns; }
+        if (x.nr && x.from != me) { e.recv = T.stage + off; e.recv_count = x.nr; e.recv_from = x.from; back.push_back({x.recv, T.stage + off}); back_n.push_back(x.nr); off += x.nr; }
         if (e.send_count || e.recv_count) {
             if (!e.send_count) e.send_to = -1;
             if (!e.recv_count) e.recv_from = -1;
             hx.push_back(e);
         }
-    }
-    if (self_send.size() != self_recv.size()) return fail(PSE_ERR_COMM, "unpaired self transfer");
-    for (size_t q = 0; q < self_send.size(); ++q) {
-        if (self_send[q]->ns != self_recv[q]->nr) return fail(PSE_ERR_COMM, "self transfer of unequal sizes");
-        if (self_recv[q]->recv != self_send[q]->send)
-            HIPCHK(hipMemcpyAsync(self_recv[q]->recv, self_send[q]->send, self_send[q]->ns * sizeof(double), hipMemcpyDeviceToDevice, s));
     }
     HIPCHK(hipStreamSynchronize(s));
     if (sum_n && T.cb.allreduce_sum(T.cb.user, sum_host, sum_n)) return fail(PSE_ERR_COMM, "transport: all-reduce failed");

@@ -97,4 +97,23 @@ def test_random_configuration(oracle, seed):
     ref, mref = oracle.brownian_velocity(pos, force, c["box"], p, 0.7, 2e-3, c["seed"], 5 + seed)
     assert m == mref, (seed, m, mref)
     assert rel(vel.cpu().numpy()[:, :3], ref) < 1e-9, ("Brownian", seed, rel(vel.cpu().numpy()[:, :3], ref))
+    if seed % 2 == 0 and c["n"] >= 8:
+        # the force provider on the same cell grid (soft repulsion, O(N^2) port) and one full sheared step: Euler update and the
+        # triclinic wrap in a box with three different edges (PSEv1/Stokes.cu:156-190)
+        n = c["n"]
+        fr = eng.pair_repulsion(to4(pos), to4(np.zeros((n, 3))), 25.0, 2.0, accumulate=False).cpu().numpy()[:, :3]
+        fr_ref = oracle.pair_repulsion(pos, c["box"], 25.0, 2.0)
+        assert np.abs(fr - fr_ref).max() < 1e-11 * max(1.0, np.abs(fr_ref).max()), ("repulsion", seed)
+        dt, rate, ts = 0.05, 0.6, 40 + seed
+        dpos, dvel = to4(pos, w=3.0), to4(np.zeros((n, 3)), w=2.0)           # velocity.w carries the mass (HOOMD)
+        accel = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+        image = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+        eng.step(dpos, dvel, accel, image, to4(force, w=0.5), 0.7, dt, ts, shear_rate=rate)
+        u, _ = oracle.brownian_velocity(pos, force, c["box"], p, 0.7, dt, c["seed"], ts)
+        newpos, newimg = oracle.integrate(pos, np.zeros((n, 3), dtype=np.int64), u, c["box"], dt, rate)
+        got = dpos.cpu().numpy()
+        same = np.all(image.cpu().numpy() == newimg, axis=1)          # a particle that lands within rounding of a face may wrap either way
+        assert same.sum() >= n - 1, ("images", seed, n - same.sum())
+        assert np.abs(got[same, :3] - newpos[same]).max() < 1e-8, ("step", seed, np.abs(got[same, :3] - newpos[same]).max())
+        assert np.all(got[:, 3] == 3.0) and np.abs(accel.cpu().numpy() - force / 2.0).max() < 1e-15
     eng.close()

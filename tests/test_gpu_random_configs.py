@@ -59,7 +59,7 @@ def config_fast(seed):
     Lx, Ly, Lz = (float(grid[a] * h[a]) for a in range(3))
     xi = float(0.9 * min(math.pi / (2.0 * h[a] * s) for a in range(3)))
     xy = float(rng.uniform(-0.5, 0.5)) if seed % 3 else 0.0
-    n = int(rng.integers(200, 4000))
+    n = int(rng.integers(200, 2500))                                 # the O(N^2) oracle times the Lanczos count bounds the size
     f = rng.uniform(-0.5, 0.5, (n, 3))
     pos = np.empty((n, 3))
     pos[:, 1] = f[:, 1] * Ly

@@ -415,10 +415,11 @@ k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ 
 // v0 / generic support: one wave per particle, hardware fp64 atomics into the three real grids (zeroed by the caller).
 __global__ void __launch_bounds__(256)
 k_spread_atomic(const double4 *__restrict__ pos_s, const double4 *__restrict__ f_s, int N, double *__restrict__ gx,
-                double *__restrict__ gy, double *__restrict__ gz, DGrid G, DBox box) {
+                double *__restrict__ gy, double *__restrict__ gz, DGrid G, DBox box, CellRanges rows,
+                const int *__restrict__ cell_off) {
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (p >= N) return;
+    if (p >= N || !rows.row(p, cell_off)) return;   // a slab rank holds particle data for its own and its ghost rows only
     const double4 pp = pos_s[p];
     const double4 F = f_s[p];
     double fx, fy, fz;
@@ -484,7 +485,7 @@ static void launch_spread_p(const FarRec *rec, FarBins fb, double *gx, double *g
 hipError_t launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, double *gx, double *gy, double *gz, DGrid G,
                          DBox box, SpreadWork w, hipStream_t s) {
     if (!farfield_fast_path(G) || !w.rec_t) {
-        hipLaunchKernelGGL(k_spread_atomic, dim3(nblocks(N, 4)), dim3(256), 0, s, pos_s, f_s, N, gx, gy, gz, G, box);
+        hipLaunchKernelGGL(k_spread_atomic, dim3(nblocks(N, 4)), dim3(256), 0, s, pos_s, f_s, N, gx, gy, gz, G, box, w.need, w.cell_off);
         return hipGetLastError();
     }
     FarBins fb;
@@ -661,10 +662,15 @@ k_gather_bins(const FarRec *__restrict__ rec, FarBins fb, FastDiv dz, FastDiv dy
 // generic support size: one exponential per node
 __global__ void __launch_bounds__(256)
 k_gather(const double4 *__restrict__ pos_s, int N, const double *__restrict__ gx, const double *__restrict__ gy,
-         const double *__restrict__ gz, DGrid G, DBox box, double4 *__restrict__ u_s) {
+         const double *__restrict__ gz, DGrid G, DBox box, double4 *__restrict__ u_s, CellRanges rows,
+         const int *__restrict__ cell_off) {
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= N) return;
+    if (!rows.row(p, cell_off)) {                   // no particle data on this rank for the row (another slab's, beyond the ghost layers)
+        if (lane == 0) u_s[p] = make_double4(0.0, 0.0, 0.0, 0.0);
+        return;
+    }
     const double4 pp = pos_s[p];
     double fx, fy, fz;
     frac_coords(box, pp.x, pp.y, pp.z, fx, fy, fz);
@@ -716,7 +722,7 @@ static void launch_gather_p(const FarRec *rec, FarBins fb, int bx0, int nbx_l, c
 hipError_t launch_gather(const double4 *pos_s, SpreadWork w, int N, const double *gx, const double *gy, const double *gz, DGrid G,
                          DBox box, double4 *u_s, hipStream_t s) {
     if (!farfield_fast_path(G) || !w.rec_t || (G.Nz & 1)) {
-        hipLaunchKernelGGL(k_gather, dim3(nblocks(N, 4)), dim3(256), 0, s, pos_s, N, gx, gy, gz, G, box, u_s);
+        hipLaunchKernelGGL(k_gather, dim3(nblocks(N, 4)), dim3(256), 0, s, pos_s, N, gx, gy, gz, G, box, u_s, w.need, w.cell_off);
         return hipGetLastError();
     }
     FarBins fb = w.fb;

@@ -122,3 +122,70 @@ def test_bench_as_ranks_of_torch_distributed_run():
     assert len(lines) == 1                                      # rank 0 only
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
+
+
+def _random_worker(rank, seed, port, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    try:
+        import torch
+        import torch.distributed as dist
+        from conftest import to4
+        import pse_amd
+        from pse_amd.sharded import ShardedSimulation
+        from test_gpu_random_teams import config
+        c = config(seed)
+        world = c["world"]
+        if c["mode"]:
+            os.environ["PSE_WAVE_MODE"] = c["mode"]
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        kw = dict(xi=c["xi"], error=c["err"], seed=c["seed"], grid=c["grid"])
+        sim = ShardedSimulation(c["n"], c["box"], world, rank, transport="host", **kw)
+        sim.load(c["pos"], c["force"])
+        u_mf = sim.mobility().cpu().numpy()[:, :3].copy()
+        _, m = sim.brownian_velocity(0.8, 1e-3, 3 + seed, lanczos_m=2)
+        u_b = sim.s.vel.cpu().numpy()[:, :3].copy()
+        for a in (u_mf, u_b):
+            t = torch.from_numpy(a.copy()); ref = t.clone()
+            dist.broadcast(ref, src=0)
+            assert torch.equal(t, ref), "ranks disagree"
+        if rank == 0:
+            eng = pse_amd.Engine(c["n"], c["box"], **kw)
+            dpos, dF = to4(c["pos"]), to4(c["force"])
+            r_mf = eng.mobility(dpos, dF).cpu().numpy()[:, :3]
+            r_b, mr = eng.brownian_velocity(dpos, dF, 0.8, 1e-3, 3 + seed, lanczos_m=2)
+            rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)   # noqa: E731
+            assert rel(u_mf, r_mf) < 1e-11, rel(u_mf, r_mf)
+            assert m == mr and rel(u_b, r_b.cpu().numpy()[:, :3]) < 1e-9, (m, mr)
+        dist.barrier()
+        out.put((rank, "ok"))
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        out.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))[-1500:]))
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:   # noqa: BLE001
+            pass
+
+
+@pytest.mark.parametrize("seed", [5, 7, 16, 18, 20, 22])
+def test_random_team_of_processes(seed):
+    """Shapes of tests/test_gpu_random_teams.py (non-cubic, sheared, supports up to 13, odd Nz, grids on the generic far-field
+    kernels, 240-point mixed-radix x pass) between real processes: the transfer lists of the process-per-rank branch -- the ones
+    RCCL posts -- with halo widths and block sizes the 64^3 cases above do not have."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_random_teams import config
+    world = config(seed)["world"]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_random_worker, args=(r, seed, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res

@@ -167,7 +167,8 @@ def test_overflow_rows_on_the_kept_list(torch_cuda, oracle):
     assert m2 == mp2 and rel(out2.cpu().numpy()[:, :3], up2) < 1e-9
 
 
-def test_random_call_sequence_matches_fresh_engines(torch_cuda, oracle):
+@pytest.mark.parametrize("edges,err", [(None, 1e-3), ((1.0, 1.35, 0.8), 1e-4)])
+def test_random_call_sequence_matches_fresh_engines(torch_cuda, oracle, edges, err):
     """One engine driven through a random sequence of calls -- small and large moves, M.F, Brownian velocities, near-field
     square roots, repulsion (which walks the cells itself), real-space-only and wave-only evaluations, group subsets, tilt
     changes, another N -- against an engine created fresh for every call with the list switched off.  Catches state that
@@ -178,7 +179,11 @@ def test_random_call_sequence_matches_fresh_engines(torch_cuda, oracle):
     n, seed = 1500, 3
     pos, force, box = make_suspension(n, phi=0.12)
     L = box[0]
-    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3, seed=seed)
+    Ls = (L, L, L) if edges is None else tuple(L * e for e in edges)      # second case: three different edges, P = 8
+    if edges is not None:
+        pos = pos * np.array(edges)
+        box = Ls + (0.0,)
+    eng = pse_amd.Engine(n, box, xi=0.5, error=err, seed=seed)
     group = torch.tensor(np.sort(rng.choice(n, size=1100, replace=False)).astype(np.int32), device="cuda")
     cur, xy = pos.copy(), 0.0
     kinds = ["mf", "brown", "mf_near", "mf_wave", "sqrt", "repulse", "group", "mf", "brown", "mf"]
@@ -196,12 +201,12 @@ def test_random_call_sequence_matches_fresh_engines(torch_cuda, oracle):
             xy = float(rng.uniform(-0.3, 0.3))
         elif move == "shrink":
             nn = 1200
-        b = (L, L, L, xy)
+        b = Ls + (xy,)
         if eng.box != b:
             eng.set_box(*b)
         cur = oracle.wrap(cur, np.zeros(cur.shape, dtype=np.int64), b)[0]
         p, f = cur[:nn], force[:nn]
-        fresh = pse_amd.Engine(n, box, xi=0.5, error=1e-3, seed=seed)
+        fresh = pse_amd.Engine(n, box, xi=0.5, error=err, seed=seed)
         fresh.set_neighbor_skin(0.0)
         if fresh.box != b:
             fresh.set_box(*b)

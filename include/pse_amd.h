@@ -43,7 +43,7 @@ enum pse_status {
  * overrides the reference's rule cannot express. Zero means "use the reference rule". */
 typedef struct pse_params {
     unsigned int n_max;      /* capacity in particles (N_total of the reference) */
-    double Lx, Ly, Lz, xy;   /* box */
+    double Lx, Ly, Lz, xy;   /* box; |xy| <= 0.5 (HOOMD flips the box there; beyond it the minimum image is not exact): else PSE_ERR_INVALID */
     double xi;               /* Ewald splitting parameter (PSEv1/Stokes.cc:91) */
     double error;            /* tolerance for all approximations (m_error) */
     double max_strain;       /* largest |xy| the box will take; sizes P (PSEv1/Stokes.cc:217-229) */

@@ -393,6 +393,9 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     std::string e = select_params(h->box, p->xi, p->error, p->max_strain, p->Nx, p->Ny, p->Nz, p->P, p->rcut, h->d);
     if (!e.empty()) return fail(PSE_ERR_INVALID, "%s", e.c_str());
     if (p->n_max == 0) return fail(PSE_ERR_INVALID, "n_max must be positive");
+    if (!(std::fabs(p->xy) <= 0.5 * (1.0 + 1e-9)))
+        return fail(PSE_ERR_INVALID, "tilt xy = %g outside [-0.5, 0.5]: HOOMD flips the box there, and the sequential minimum image "
+                    "(PSEv1/Mobility.cu:648) is exact only up to that tilt", p->xy);
     const Derived &d = h->d;
     if (p->device >= 0) { HIPCHK(hipSetDevice(p->device)); h->device = p->device; }
     else HIPCHK(hipGetDevice(&h->device));
@@ -582,6 +585,9 @@ extern "C" int pse_create(const pse_params *p, pse_handle **out) {
 extern "C" int pse_set_box(pse_handle *h, double Lx, double Ly, double Lz, double xy) {
     if (!h) return fail(PSE_ERR_INVALID, "null handle");
     if (!(Lx > 0 && Ly > 0 && Lz > 0)) return fail(PSE_ERR_INVALID, "box lengths must be positive");
+    if (!(std::fabs(xy) <= 0.5 * (1.0 + 1e-9)))
+        return fail(PSE_ERR_INVALID, "tilt xy = %g outside [-0.5, 0.5]: HOOMD flips the box there, and the sequential minimum image "
+                    "(PSEv1/Mobility.cu:648) is exact only up to that tilt", xy);
     // Nothing of the handle changes unless every check passes: the candidate cell grid is computed on the side.
     // The grid, P and eta were chosen for the creation box (the reference also fixes them in setParams and only
     // recomputes wave vectors per step, PSEv1/Stokes.cu:298); lengths may change only by re-deriving h.

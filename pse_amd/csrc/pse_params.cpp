@@ -29,6 +29,9 @@ std::string select_params(const Box &box, double xi, double error, double max_st
     if (!(error > 0.0 && error < 1.0)) return "error must be in (0,1)";
     if (!(box.Lx > 0 && box.Ly > 0 && box.Lz > 0)) return "box lengths must be positive";
     if (max_strain < 0) return "max_strain must be non-negative";
+    if (P < 0) return "P override must be positive (0: the rule of Stokes.cc:225-233)";
+    if (Nx < 0 || Ny < 0 || Nz < 0) return "grid override must be positive (0: the rule of Stokes.cc:143-199)";
+    if (rcut < 0) return "rcut override must be positive (0: the rule of Stokes.cc:135)";
     o.xi = xi; o.error = error; o.max_strain = max_strain;
     const double s = std::sqrt(-std::log(error));
     o.rcut = rcut > 0 ? rcut : s / xi;                                   // Stokes.cc:135

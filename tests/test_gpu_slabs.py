@@ -135,3 +135,57 @@ def test_loopback_team_of_eight():
         m2 = sim.step(1.0, 1e-3, ts, lanczos_m=m2)
     for r in range(world):
         assert float((sim.s[r].pos - p_ref).abs().max()) < 1e-10, r
+
+
+@pytest.mark.parametrize("world,mode", [(2, "replicated"), (3, "slab"), (4, "slab")])
+def test_loopback_team_on_a_particle_group(world, mode, monkeypatch):
+    """group_members on a team (d_group_members / group_size of the reference, PSEv1/Stokes.cc:436-470): only the listed particles
+    interact and move; the others' velocities, positions and images stay as they were -- on every rank, as on a single GPU."""
+    import torch
+    import pse_amd
+    from pse_amd.engine import Team
+    monkeypatch.setenv("PSE_WAVE_MODE", mode)
+    n_total, n = 3000, 1900
+    pos, force, box = make_suspension(n_total, phi=0.1, xy=0.2)
+    members = np.sort(np.random.default_rng(11).choice(n_total, n, replace=False)).astype(np.int32)
+    kw = dict(xi=0.5, error=1e-3, seed=21, grid=(48, 48, 36))
+    ref = pse_amd.Engine(n_total, box, **kw)
+    g = torch.tensor(members, dtype=torch.int32, device="cuda")
+
+    def state():
+        return dict(pos=to4(pos, 1.0), force=to4(force), vel=to4(-np.ones((n_total, 3)), 2.5),
+                    accel=torch.zeros((n_total, 3), dtype=torch.float64, device="cuda"),
+                    image=torch.zeros((n_total, 3), dtype=torch.int32, device="cuda"))
+
+    r = state()
+    engines = [pse_amd.Engine(n_total, box, n_slabs=world, slab_rank=k, **kw) for k in range(world)]
+    team = Team(engines)
+    S = [state() for _ in range(world)]
+    col = lambda key: [s[key] for s in S]            # noqa: E731
+    others = np.setdiff1d(np.arange(n_total), members)
+    # M.F
+    ref.mobility(r["pos"], r["force"], vel=r["vel"], group=g)
+    team.mobility(col("pos"), col("force"), col("vel"), group=g)
+    for k in range(world):
+        v = S[k]["vel"].cpu().numpy()
+        assert rel(v[members, :3], r["vel"].cpu().numpy()[members, :3]) < 1e-12, k
+        assert np.all(v[others, :3] == -1.0) and np.all(v[:, 3] == 2.5), k
+    # Brownian velocity
+    _, m_ref = ref.brownian_velocity(r["pos"], r["force"], 1.0, 1e-3, 4, vel=r["vel"], group=g)
+    _, m = team.brownian_velocity(col("pos"), col("force"), col("vel"), 1.0, 1e-3, 4, group=g)
+    assert m == m_ref
+    for k in range(world):
+        v = S[k]["vel"].cpu().numpy()
+        assert rel(v[members, :3], r["vel"].cpu().numpy()[members, :3]) < 1e-11, k
+        assert np.all(v[others, :3] == -1.0), k
+    # a sheared step
+    m_ref = ref.step(r["pos"], r["vel"], r["accel"], r["image"], r["force"], 1.0, 2e-2, 5, shear_rate=0.4, group=g, lanczos_m=m_ref)
+    m = team.step(col("pos"), col("vel"), col("accel"), col("image"), col("force"), 1.0, 2e-2, 5, shear_rate=0.4, group=g, lanczos_m=m)
+    assert m == m_ref
+    for k in range(world):
+        p = S[k]["pos"].cpu().numpy()
+        assert np.abs(p - r["pos"].cpu().numpy()).max() < 1e-10, k
+        assert np.array_equal(p[others, :3], pos[others]), k
+        assert np.array_equal(S[k]["image"].cpu().numpy(), r["image"].cpu().numpy()), k
+        assert np.abs(S[k]["accel"].cpu().numpy() - r["accel"].cpu().numpy()).max() < 1e-15, k
+    team.close()

@@ -189,3 +189,35 @@ def test_loopback_team_on_a_particle_group(world, mode, monkeypatch):
         assert np.array_equal(S[k]["image"].cpu().numpy(), r["image"].cpu().numpy()), k
         assert np.abs(S[k]["accel"].cpu().numpy() - r["accel"].cpu().numpy()).max() < 1e-15, k
     team.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_loopback_team_follows_tilt_and_particle_count(world):
+    """Lees-Edwards on a team: every rank's handle takes pse_set_box with the new tilt between calls (what the host class does once
+    per step, PSEv1/Stokes.cu:298), and the next call may bring fewer particles than the last."""
+    import pse_amd
+    from pse_amd.engine import Team
+    n_max = 3000
+    pos, force, box = make_suspension(n_max, phi=0.1)
+    L = box[0]
+    kw = dict(xi=0.5, error=1e-3, seed=2, grid=(48, 48, 40))
+    ref = pse_amd.Engine(n_max, box, **kw)
+    engines = [pse_amd.Engine(n_max, box, n_slabs=world, slab_rank=k, **kw) for k in range(world)]
+    team = Team(engines)
+    for xy, n in ((0.0, n_max), (0.27, n_max), (-0.41, 2200), (0.5, 2999), (0.1, 64)):
+        b = (L, L, L, xy)
+        p = pos[:n].copy()
+        p[:, 0] += xy * p[:, 1]                                      # the same fractional coordinates in the tilted cell
+        for e in engines + [ref]:
+            e.set_box(*b)
+        u_ref = ref.mobility(to4(p), to4(force[:n])).cpu().numpy()[:, :3]
+        vels = [to4(np.zeros((n, 3))) for _ in range(world)]
+        team.mobility([to4(p) for _ in range(world)], [to4(force[:n]) for _ in range(world)], vels)
+        for k in range(world):
+            assert rel(vels[k].cpu().numpy()[:, :3], u_ref) < 1e-11, (xy, n, k)
+        v_ref, m_ref = ref.brownian_velocity(to4(p), to4(force[:n]), 1.0, 1e-3, 9)
+        _, m = team.brownian_velocity([to4(p) for _ in range(world)], [to4(force[:n]) for _ in range(world)], vels, 1.0, 1e-3, 9)
+        assert m == m_ref
+        for k in range(world):
+            assert rel(vels[k].cpu().numpy()[:, :3], v_ref.cpu().numpy()[:, :3]) < 1e-10, (xy, n, k)
+    team.close()

@@ -1,10 +1,12 @@
-"""A small interpreter for the C subset the reference's CUDA kernels are written in -- test infrastructure of the fixture
-generator (tests/golden/make_reference_fixture.py), nothing else imports it.
+"""A small interpreter for the C subset the reference's CUDA kernels -- and the host function that drives its Lanczos iteration -- are
+written in: test infrastructure of the fixture generators (tests/golden/make_kernel_fixture.py, make_lanczos_fixture.py), nothing
+else imports it.
 
 Why: the reference cannot be compiled here (CUDA + HOOMD headers absent) and ships no golden vectors, but the per-thread
 arithmetic of its kernels is plain C.  The generator READS a kernel's text from /root/reference at generation time, this
 module executes that text one thread at a time with C semantics (truncating integer division, C remainder, typed
-declarations, ?:, && / ||, structs with .x .y .z .w, pointers into arrays, for / if / else), and the numbers it produces are
+declarations, ?:, && / ||, shifts, structs with .x .y .z .w, pointers into arrays, casts, sizeof, for / while / break / if / else,
+string and character literals), and the numbers it produces are
 what gets committed.  No reference text is stored; nothing is passed to eval()/exec(): the text is tokenised, parsed into a
 tree of a fixed set of node kinds and walked, and every name it may call comes from a table the caller supplies.
 
@@ -75,16 +77,17 @@ class Ref:
 
 # ------------------------------------------------------------------------------------------------ tokens
 TOKEN = re.compile(r"""
-    (?P<num>(?:\d+\.\d*|\.\d+|\d+)(?:[eE][+-]?\d+)?[fFuUlL]*)
+    (?P<str>"(?:[^"\\]|\\.)*")
+  | (?P<chr>'(?:[^'\\]|\\.)')
+  | (?P<num>(?:\d+\.\d*|\.\d+|\d+)(?:[eE][+-]?\d+)?[fFuUlL]*)
   | (?P<id>[A-Za-z_]\w*(?:::[A-Za-z_]\w*)*)
-  | (?P<op>\+\+|--|->|\+=|-=|\*=|/=|==|!=|<=|>=|&&|\|\||[-+*/%<>=!&?:;,.(){}\[\]])
+  | (?P<op>>>=|<<=|<<|>>|\+\+|--|->|\+=|-=|\*=|/=|==|!=|<=|>=|&&|\|\||[-+*/%<>=!&?:;,.(){}\[\]])
   | (?P<ws>\s+)
 """, re.X)
 
 
 def tokenize(text):
-    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
-    text = re.sub(r"//[^\n]*", " ", text)
+    text = re.sub(r'''("(?:[^"\\]|\\.)*")|/\*.*?\*/|//[^\n]*''', lambda m: m.group(1) or " ", text, flags=re.S)
     out, i = [], 0
     while i < len(text):
         m = TOKEN.match(text, i)
@@ -182,6 +185,13 @@ class Parser:
             e = None if self.peek()[1] == ";" else self.expr()
             self.expect(";")
             return ("return", e)
+        if v == "while" and k == "id":
+            self.next(); self.expect("(")
+            c = self.expr(); self.expect(")")
+            return ("while", c, self.statement())
+        if v in ("break", "continue") and k == "id":
+            self.next(); self.expect(";")
+            return (v,)
         if self.at_type():
             # a type name followed by '(' is a function-style cast in an expression statement, not a declaration
             if not (self.peek(1)[1] == "(" and self.peek()[1] not in ("const", "unsigned", "__shared__")):
@@ -232,7 +242,7 @@ class Parser:
     def assign(self):
         left = self.ternary()
         k, v = self.peek()
-        if k == "op" and v in ("=", "+=", "-=", "*=", "/="):
+        if k == "op" and v in ("=", "+=", "-=", "*=", "/=", ">>=", "<<="):
             self.next()
             return ("assign", v, left, self.assign())
         return left
@@ -244,7 +254,7 @@ class Parser:
             return ("cond", c, a, self.assign())
         return c
 
-    LEVELS = [("||",), ("&&",), ("==", "!="), ("<", ">", "<=", ">="), ("+", "-"), ("*", "/", "%")]
+    LEVELS = [("||",), ("&&",), ("==", "!="), ("<", ">", "<=", ">="), ("<<", ">>"), ("+", "-"), ("*", "/", "%")]
 
     def binary(self, lvl):
         if lvl == len(self.LEVELS):
@@ -260,11 +270,25 @@ class Parser:
         if k == "op" and v in ("-", "+", "!", "&", "*", "++", "--"):
             self.next()
             return ("un", v, self.unary())
-        if v == "(" and self.peek(1)[0] == "id" and self.peek(1)[1] in self.types | {"unsigned"} and (
-                self.peek(2)[1] == ")" or (self.peek(1)[1] == "unsigned" and self.peek(3)[1] == ")")):
-            self.next()
-            tname = self.parse_type(); self.expect(")")
-            return ("cast", tname, self.unary())
+        if v == "(" and self.peek(1)[0] == "id" and self.peek(1)[1] in self.types | {"unsigned", "void"}:
+            j = 3 if (self.peek(1)[1] == "unsigned" and self.peek(2)[1] == "int") else 2
+            stars = 0
+            while self.peek(j + stars)[1] == "*":
+                stars += 1
+            if self.peek(j + stars)[1] == ")":                # (T) x, (unsigned int) x, (T *) p, (void **) &p
+                self.next()
+                tname = self.next()[1] if self.peek()[1] == "void" else self.parse_type()
+                for _ in range(stars):
+                    self.expect("*")
+                self.expect(")")
+                return ("cast", "ptr" if stars else tname, self.unary())
+        if k == "id" and v == "sizeof" and self.peek(1)[1] == "(":
+            self.next(); self.next()
+            tname = self.parse_type()
+            while self.accept("*"):
+                tname = "ptr"
+            self.expect(")")
+            return ("sizeof", tname)
         return self.postfix()
 
     def postfix(self):
@@ -272,6 +296,10 @@ class Parser:
         if k == "num":
             txt = v.rstrip("fFuUlL")
             e = ("num", float(txt) if re.search(r"[.eE]", txt) else int(txt))
+        elif k == "str":
+            e = ("num", v[1:-1])
+        elif k == "chr":
+            e = ("num", v[1:-1])
         elif k == "id":
             e = ("name", v)
         elif v == "(":
@@ -297,6 +325,26 @@ class Parser:
 class _Return(Exception):
     def __init__(self, value=None):
         self.value = value
+
+
+class _Break(Exception):
+    pass
+
+
+class _Continue(Exception):
+    pass
+
+
+class SizeOf(int):
+    """sizeof(T) counts ELEMENTS (value 1) and remembers T, so `n * sizeof(T)` handed to an allocator stub says what to allocate."""
+    def __new__(cls, count, tname):
+        o = int.__new__(cls, count)
+        o.tname = tname
+        return o
+
+    def __mul__(self, other):
+        return SizeOf(int(self) * int(other), self.tname) if isinstance(other, int) else NotImplemented
+    __rmul__ = __mul__
 
 
 # ------------------------------------------------------------------------------------------------ interpreter
@@ -420,13 +468,38 @@ class Machine:
                     self.exec(s[1])
                 guard = 0
                 while self.truth(self.val(s[2])):
-                    self.exec(s[4])
+                    depth = len(self.scopes)
+                    try:
+                        self.exec(s[4])
+                    except _Break:
+                        del self.scopes[depth:], self.types[depth:]
+                        break
+                    except _Continue:
+                        del self.scopes[depth:], self.types[depth:]
                     self.val(s[3])
                     guard += 1
                     if guard > 10_000_000:
                         raise CError("runaway loop")
             finally:
                 self.scopes.pop(); self.types.pop()
+        elif kind == "while":
+            guard = 0
+            while self.truth(self.val(s[1])):
+                depth = len(self.scopes)
+                try:
+                    self.exec(s[2])
+                except _Break:
+                    del self.scopes[depth:], self.types[depth:]
+                    break
+                except _Continue:
+                    del self.scopes[depth:], self.types[depth:]
+                guard += 1
+                if guard > 10_000_000:
+                    raise CError("runaway loop")
+        elif kind == "break":
+            raise _Break()
+        elif kind == "continue":
+            raise _Continue()
         elif kind == "return":
             raise _Return(None if s[1] is None else self.val(s[1]))
         else:
@@ -510,6 +583,8 @@ class Machine:
             raise CError("call of a non-function")
         if kind == "cast":
             return self.coerce(e[1], self.val(e[2]))
+        if kind == "sizeof":
+            return SizeOf(1, e[1])
         if kind == "cond":
             return self.val(e[2]) if self.truth(self.val(e[1])) else self.val(e[3])
         if kind == "comma":
@@ -519,7 +594,7 @@ class Machine:
             r = self.ref(e[2])
             v = self.val(e[3])
             if e[1] != "=":
-                v = self.arith(e[1][0], r.get(), v)
+                v = self.arith(e[1][:-1], r.get(), v)
             r.put(v)
             return r.get()
         if kind == "post":
@@ -585,6 +660,10 @@ class Machine:
             if not both_int:
                 raise CError("% on non-integers")
             return int(math.fmod(a, b))                      # sign of the dividend
+        if op in ("<<", ">>"):
+            if not both_int:
+                raise CError("shift of non-integers")
+            return a << b if op == "<<" else a >> b
         if op == "<":
             return 1 if a < b else 0
         if op == ">":

@@ -66,6 +66,30 @@ def test_for_loops_compound_assignment_and_return():
     assert Machine({"pow": math.pow}).evaluate("pow(2.0, 3) / 4 + 7 / 2", {}) == 2.0 + 3
 
 
+def test_host_code_constructs():
+    """What the Lanczos driver needs beyond kernel bodies: while / break / continue, shifts, string and character literals (with
+    comment markers inside strings), casts to pointer types, sizeof as an element count that remembers its type, &variable."""
+    from cmini import SizeOf
+    seen = []
+
+    def alloc(ref, count):
+        seen.append((int(count), count.tname))
+        ref.put([0.0] * int(count))
+    m = Machine({"printf": lambda *a: seen.append(a[0]), "cudaMalloc": alloc, "malloc": lambda c: [float("nan")] * int(c)})
+    out = m.run(m.parse("""
+    float *a; a = (float *)malloc( 6*sizeof(float) );
+    Scalar *d; cudaMalloc( (void**)&d, n_el*sizeof(Scalar) );
+    while ( n < 10 ) { n++; if (n == 3) { continue; } if (n > 6) { break; } s += n; a[n-1] = n / 2.0; d[0] += 1; }
+    int offs = 512 >> 1; offs >>= 2;
+    printf("text with // and /* inside */ %i \\n", n); /* a comment */ // another
+    res[0] = 'I'; res[1] = offs; res[2] = a[5]; res[3] = d[0]; res[4] = 1 << 4;
+    """), {"res": [None] * 5, "n": 0, "s": 0, "n_el": 3})
+    assert (out["n"], out["s"]) == (7, 18)
+    assert out["res"] == ["I", 64, 3.0, 5.0, 16]
+    assert seen[0] == (3, "Scalar") and seen[1].startswith("text with // and /* inside */")
+    assert isinstance(SizeOf(1, "float") * 4, SizeOf) and int(3 * SizeOf(1, "float")) == 3
+
+
 def test_unknown_names_are_errors_not_python():
     m = Machine({})
     with pytest.raises(cmini.CError):
@@ -83,6 +107,10 @@ def test_committed_fixtures_are_what_the_generators_produce(tmp_path, monkeypatc
     mk.main()
     with gzip.open(tmp_path / "k.json.gz") as f, gzip.open(os.path.join(golden, "reference_kernels.json.gz")) as g:
         assert json.load(f) == json.load(g)
+    ml = importlib.import_module("make_lanczos_fixture")
+    monkeypatch.setattr(ml, "OUT", str(tmp_path / "l.json"))
+    ml.main()
+    assert json.load(open(tmp_path / "l.json")) == json.load(open(os.path.join(golden, "reference_lanczos.json")))
     mr = importlib.import_module("make_reference_fixture")
     monkeypatch.setattr(mr, "OUT", str(tmp_path / "a.json"))
     mr.main()

@@ -111,6 +111,11 @@ def test_committed_fixtures_are_what_the_generators_produce(tmp_path, monkeypatc
     monkeypatch.setattr(ml, "OUT", str(tmp_path / "l.json"))
     ml.main()
     assert json.load(open(tmp_path / "l.json")) == json.load(open(os.path.join(golden, "reference_lanczos.json")))
+    md = importlib.import_module("make_driver_fixture")
+    monkeypatch.setattr(md, "OUT", str(tmp_path / "d.json.gz"))
+    md.main()
+    with gzip.open(tmp_path / "d.json.gz") as f, gzip.open(os.path.join(golden, "reference_driver.json.gz")) as g:
+        assert json.load(f) == json.load(g)
     mr = importlib.import_module("make_reference_fixture")
     monkeypatch.setattr(mr, "OUT", str(tmp_path / "a.json"))
     mr.main()

@@ -24,9 +24,17 @@ real-to-complex half spectrum; random numbers from Philox4x32-10 keyed (seed, ti
 domain) instead of HOOMD's Saru (not in the reference tree -> RNG stream parity is unpinned;
 the *distribution* -- uniform, variance-matched -- is the reference's).
 
-Parity pin: select_params, hash_seed, the k-space factor and the shear classes are held to the values the reference's
-own expression text takes (tests/golden/reference_arithmetic.json, generated by tests/golden/make_reference_fixture.py
-from /root/reference; checked in tests/test_reference_pin.py).
+Parity pin (all fixtures are numbers generated in the build container from the reference's own text; no text travels):
+  * select_params, hash_seed, the k-space factor, the real-space closed forms and the shear classes: the values the reference's
+    expression text takes (tests/golden/reference_arithmetic.json <- make_reference_fixture.py; tests/test_reference_pin.py);
+  * spread, kvectors / wave_scale, noise_k, the pair formula, integrate: the bodies of the reference's kernels executed thread by
+    thread by the C-subset interpreter tests/golden/cmini.py (reference_kernels.json.gz <- make_kernel_fixture.py;
+    tests/test_reference_kernels.py);
+  * gather, and the constants and order of the combined step: gpu_stokes_Contract_kernel run with real barriers, the host wrapper
+    run with recording stubs (reference_driver.json.gz <- make_driver_fixture.py; tests/test_reference_driver.py);
+  * lanczos_sqrt: the host driver gpu_stokes_BrealLanczos_wrap executed on dense operators -- same m, same vector
+    (reference_lanczos.json <- make_lanczos_fixture.py; tests/test_reference_lanczos.py).
+Unpinned by construction: the random STREAM (Saru is not in the reference tree).
 """
 import ctypes
 import math

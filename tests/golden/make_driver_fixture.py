@@ -7,7 +7,9 @@
     The text is executed by tests/golden/cmini.py with every kernel / cuFFT / cudaMalloc call replaced by a recorder;
   * gpu_stokes_Contract_kernel (PSEv1/Mobility.cu:325-477; K8, the gather): support centring and wrap, sheared node position,
     weight, and its shared-memory tree reduction -- the text runs one Python thread per GPU thread with a real barrier for
-    __syncthreads (blocks of 4^3 ... 10^3 threads, the latter with two support nodes per thread along each axis: P = 13).
+    __syncthreads (blocks of 4^3 ... 10^3 threads, the latter with two support nodes per thread along each axis: P = 13);
+  * gpu_stokes_BrownianGenerate_kernel (PSEv1/Brownian.cu:99-130; K14): the key of a particle's random numbers, their interval,
+    the components written.
 
 Runs in the build container only; reads /root/reference at run time; the fixture (tests/golden/reference_driver.json.gz) holds inputs
 and results only.  HOOMD's BoxDim, texFetchScalar4 and make_scalar* are restated as in make_kernel_fixture.py.
@@ -110,10 +112,42 @@ def run_contract(pos, ugrid, grid, box, P, xi, eta):
     return [[v.f[k] for k in "xyzw"] for v in d_vel]
 
 
+# ---------------------------------------------------------------------------------------------- the particle noise kernel (K14)
+def run_psi(n_total, members, seed, timestep):
+    """gpu_stokes_BrownianGenerate_kernel (PSEv1/Brownian.cu:99-130) from its text.  Saru is not in the tree: the stand-in hands
+    particle idx the uniforms the port's Philox stream assigns to that particle, so what is pinned is what the kernel DOES with them
+    -- the key (GLOBAL particle index, timestep + seed), the interval, which components are written."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import pse_port
+    _, body = function_source(read("PSEv1/Brownian.cu"), "void gpu_stokes_BrownianGenerate_kernel")
+    keys = []
+
+    class Saru:
+        def __init__(self, idx, key):
+            keys.append((int(idx), int(key)))
+            r = pse_port.philox4x32(np.uint64(idx) & np.uint64(0xFFFFFFFF), np.uint64(idx) >> np.uint64(32), timestep, pse_port.DOMAIN_PARTICLE,
+                                    seed, pse_port.KEY1)
+            self.u = [(float(x) + 0.5) * 2.0 ** -32 for x in r]
+            self.k = 0
+
+        def f(self, a, b):
+            self.k += 1
+            return a + (b - a) * self.u[self.k - 1]
+
+    m = Machine(dict(BUILTINS, **{"detail::Saru": Saru}), extra_types=("detail::Saru",))
+    tree = m.parse(body)
+    d_psi = [Vec("Scalar4", -9.0, -9.0, -9.0, 4.5) for _ in range(n_total)]
+    for t in range(len(members) + 5):
+        m.run(tree, dict(d_psi=d_psi, group_size=len(members), d_group_members=members, timestep=timestep, seed=seed,
+                         blockDim=Vec("dim3", 32, 1, 1), blockIdx=Vec("dim3", t // 32, 0, 0), threadIdx=Vec("dim3", t % 32, 0, 0)))
+    assert sorted(keys) == sorted((i, timestep + seed) for i in members)
+    return [[v.f[k] for k in "xyzw"] for v in d_psi]
+
+
 def main():
     threading.stack_size(512 * 1024)
     out = {"_source": "tests/golden/make_driver_fixture.py: PSEv1/Brownian.cu gpu_stokes_CombinedMobilityBrownian_wrap and PSEv1/Mobility.cu "
-                      "gpu_stokes_Contract_kernel executed by tests/golden/cmini.py", "wrapper": [], "contract": []}
+                      "gpu_stokes_Contract_kernel executed by tests/golden/cmini.py", "wrapper": [], "contract": [], "psi": None}
     for xi, eta, P, gridh, T in ((0.5, 0.47, 6, (0.8, 0.9, 1.0), 1.0), (0.5, 0.47, 6, (0.8, 0.9, 1.0), 0.0), (0.31, 0.72, 13, (1.1, 1.1, 1.3), 0.5)):
         out["wrapper"].append(dict(xi=xi, eta=eta, P=P, gridh=gridh, T=T, calls=run_wrapper(xi, eta, P, gridh, T)))
     rng = np.random.default_rng(77)
@@ -127,6 +161,8 @@ def main():
         vel = run_contract(pos, ug, grid, box, P, xi, eta)
         out["contract"].append(dict(grid=grid, box=box, P=P, xi=xi, eta=eta, pos=pos.tolist(), ugrid=ug.tolist(), vel=vel))
         print("contract", grid, "P", P, "done", flush=True)
+    members = [0, 3, 4, 9, 17, 18, 40]
+    out["psi"] = dict(n_total=41, members=members, seed=987654, timestep=12, psi=run_psi(41, members, 987654, 12))
     with gzip.GzipFile(OUT, "wb", mtime=0) as f:
         f.write(json.dumps(out).encode())
     print("wrote", OUT, os.path.getsize(OUT), "bytes")

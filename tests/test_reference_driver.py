@@ -3,7 +3,8 @@ reference_driver.json.gz, written by tests/golden/make_driver_fixture.py from th
 
   * the host wrapper gpu_stokes_CombinedMobilityBrownian_wrap (PSEv1/Brownian.cu:772-923): order of the kernels with and without
     temperature and the constants the host hands them (prefac, expfac, the gather weight quadW prefac, the (1, 1) sums);
-  * the gather kernel gpu_stokes_Contract_kernel (PSEv1/Mobility.cu:325-477), run with real barriers for its tree reduction."""
+  * the gather kernel gpu_stokes_Contract_kernel (PSEv1/Mobility.cu:325-477), run with real barriers for its tree reduction;
+  * the particle-noise kernel gpu_stokes_BrownianGenerate_kernel (PSEv1/Brownian.cu:99-130)."""
 import gzip
 import json
 import math
@@ -58,3 +59,16 @@ def test_gather_against_the_contract_kernel(c):
     ref = np.array(c["vel"])
     assert np.abs(u - ref[:, :3]).max() < 1e-13 * np.abs(ref[:, :3]).max()
     assert np.all(ref[:, 3] == 7.0)                                               # d_vel.w is kept (Mobility.cu:473-475)
+
+
+def test_particle_noise_kernel():
+    """gpu_stokes_BrownianGenerate_kernel (PSEv1/Brownian.cu:99-130): psi of a particle is keyed by its GLOBAL index (not its place in
+    the group) and by timestep + seed, uniform on (-sqrt 3, sqrt 3) (the reference's literal 1.73205080757: 3e-12 off), .w kept,
+    particles outside the group untouched."""
+    c = FIX["psi"]
+    got = np.array(c["psi"])
+    want = oracle.psi_particles(c["n_total"], c["seed"], c["timestep"])
+    mem = np.array(c["members"])
+    assert np.abs(got[mem, :3] - want[mem]).max() < 1e-11
+    others = np.setdiff1d(np.arange(c["n_total"]), mem)
+    assert np.all(got[others, :3] == -9.0) and np.all(got[:, 3] == 4.5)

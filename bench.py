@@ -356,7 +356,10 @@ def main():
         "neighbor_list": nl_note,
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": alg[dom], "ms_per_launch": per_launch_ms[dom]},
+                     "algorithmic_bytes_per_launch": alg[dom], "ms_per_launch": per_launch_ms[dom],
+                     # what the kernel really moves, as a rate: how close it runs to the memory system on its own traffic
+                     "traffic_rate": (traffic / (per_launch_ms[dom] * 1e-3) / 1e9) if traffic and per_launch_ms[dom] > 0 else None,
+                     "traffic_rate_frac_of_peak": (traffic / (per_launch_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and per_launch_ms[dom] > 0 else None},
         "spread_plus_gather": {"ms": sg_ms, "algorithmic_bytes": sg_bytes,
                                "frac_of_hbm_peak": (sg_bytes / (sg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sg_ms > 0 else 0.0},
         "phases_ms_per_step": {k[2:]: round(v, 4) for k, v in phases.items()},

@@ -97,6 +97,24 @@ def test_random_configuration(oracle, seed):
     ref, mref = oracle.brownian_velocity(pos, force, c["box"], p, 0.7, 2e-3, c["seed"], 5 + seed)
     assert m == mref, (seed, m, mref)
     assert rel(vel.cpu().numpy()[:, :3], ref) < 1e-9, ("Brownian", seed, rel(vel.cpu().numpy()[:, :3], ref))
+    if seed % 3 == 0 and c["n"] >= 64:
+        # a particle GROUP (d_group_members / group_size of the reference): the listed particles interact among themselves only, the
+        # others keep what they had; and the stand-alone near-field square root on the same group
+        n = c["n"]
+        members = np.sort(np.random.default_rng(seed).choice(n, size=(2 * n) // 3, replace=False)).astype(np.int32)
+        g = torch.tensor(members, dtype=torch.int32, device="cuda")
+        vel = to4(np.full((n, 3), -3.0), w=1.25)
+        eng.mobility(to4(pos), to4(force), vel=vel, group=g)
+        v = vel.cpu().numpy()
+        sub_ref = oracle.mobility_real(pos[members], force[members], c["box"], c["xi"], i["rcut"]) + oracle.mobility_wave(pos[members], force[members], c["box"], p)
+        assert rel(v[members, :3], sub_ref) < 1e-10, ("group", seed)
+        others = np.setdiff1d(np.arange(n), members)
+        assert np.all(v[others, :3] == -3.0) and np.all(v[:, 3] == 1.25)
+        psi = np.random.default_rng(seed + 1).normal(size=(n, 3))
+        out, ms = eng.sqrt_mreal(to4(pos), to4(psi), tol=1e-4, group=g)
+        mv = lambda x: oracle.mobility_real(pos[members], np.ascontiguousarray(x), c["box"], c["xi"], i["rcut"])   # noqa: E731
+        up, mp = oracle.lanczos_sqrt(mv, psi[members], 2, 1e-4)
+        assert ms == mp and rel(out.cpu().numpy()[members, :3], up) < 1e-9, ("sqrt on a group", seed, ms, mp)
     if seed % 2 == 0 and c["n"] >= 8:
         # the force provider on the same cell grid (soft repulsion, O(N^2) port) and one full sheared step: Euler update and the
         # triclinic wrap in a box with three different edges (PSEv1/Stokes.cu:156-190)

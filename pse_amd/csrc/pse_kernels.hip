@@ -170,7 +170,8 @@ void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double
 // transcendental work; (2) drain the queue densely: every lane evaluates f, g for a real neighbour.  With LIST the
 // drained pairs (j, f, (g-f)/r^2, r) are also written to a per-step ELL pair list that the Lanczos mat-vecs reuse
 // (positions do not change inside a step, PSEv1/Brownian.cu:473-521 recomputes them every iteration).
-constexpr int QCAP = 48;
+// 44 entries per thread: 44 KB of queue + the 8 KB table of the metric point let THREE workgroups share a CU (48: two)
+constexpr int QCAP = 44;
 constexpr unsigned JMASK = (1u << 27) - 1;
 
 // Four slots of the 64 rows of a wave form one 5120-byte group: [lane][4] entries, then [slot][lane] (f, h).  A mat-vec reads a
@@ -202,7 +203,7 @@ __device__ __forceinline__ void vl_store(char *vrec, int slot, int lane, unsigne
 // VL: the pass also writes the neighbour list kept across steps -- every pair closer than vl.rskin = rcut + skin (the
 // pre-filter and the queue work with that radius; f, g and the pair list still stop at rcut).
 template <bool LIST, bool CL, bool TWO, bool VL>
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TPB, ((LIST && CL && !VL) ? 3 : 1))   // the list-building pass of every step: <= 168 VGPRs (it takes 166)
 k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf_s, const double4 *__restrict__ vec_s,
               double4 *__restrict__ out_s, int lo, int hi, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2,
               float rcut2_pre, double self, const double *__restrict__ coef_g, int ncoef, NbList nb,
@@ -237,53 +238,47 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
     char *vrec = VL ? (char *)vl.idx + (size_t)((i - lo) >> 6) * (vl.cap / 4) * 1024 : nullptr;
     const double rq2 = VL ? vl.rskin * vl.rskin : rcut2;   // what enters the queue
 
-    // two queue entries per iteration: their load -> distance -> table -> force chains are independent, which doubles the
-    // memory requests in flight of this latency-bound phase (57 % of its wave-cycles were s_waitcnt)
+    // DU queue entries per iteration: their load -> distance -> table -> force chains are independent (one entry at a time the phase
+    // was latency-bound: 57 % of its wave-cycles were s_waitcnt; three or four buy nothing more).  Written as loops over small arrays:
+    // the compiler then keeps the pass at 166 VGPRs (the hand-interleaved form it replaces took 200), which together with the
+    // 44-entry queue is what lets a third workgroup onto the CU: 0.64 -> 0.56 ms.
     auto drain = [&]() {
-        for (int q = 0; q < qn; q += 2) {
-            const bool two = q + 1 < qn;
-            const unsigned e0 = queue[q * TPB + tid], e1 = queue[(two ? q + 1 : q) * TPB + tid];
-            const int j0 = (int)(e0 & JMASK), j1 = (int)(e1 & JMASK);
-            const double4 p0 = pos_s[j0], p1 = pos_s[j1];
-            const double4 F0 = vec_s[j0], F1 = vec_s[j1];
-            double s0x, s0y, s0z, s1x, s1y, s1z;
-            image_shift(e0 >> 27, box, s0x, s0y, s0z);
-            image_shift(e1 >> 27, box, s1x, s1y, s1z);
-            double d0x = pi.x - p0.x - s0x, d0y = pi.y - p0.y - s0y, d0z = pi.z - p0.z - s0z;
-            double d1x = pi.x - p1.x - s1x, d1y = pi.y - p1.y - s1y, d1z = pi.z - p1.z - s1z;
-            if (!shift_only) { min_image(box, d0x, d0y, d0z); min_image(box, d1x, d1y, d1z); }
-            const double r20 = d0x * d0x + d0y * d0y + d0z * d0z, r21 = d1x * d1x + d1y * d1y + d1z * d1z;
-            double f0, h0, f1, h1;
-            if (VL) {
-                if (r20 < rq2 && r20 > 0.0) { if (vtotal < vl.cap) vl_store(vrec, vtotal, lane, (unsigned)j0); ++vtotal; }
-                if (two && r21 < rq2 && r21 > 0.0) { if (vtotal < vl.cap) vl_store(vrec, vtotal, lane, (unsigned)j1); ++vtotal; }
+        constexpr int DU = 2;
+        for (int q = 0; q < qn; q += DU) {
+            unsigned e[DU]; int j[DU]; bool live[DU];
+            double4 p[DU], F[DU], G[DU];
+#pragma unroll
+            for (int u = 0; u < DU; ++u) {
+                live[u] = q + u < qn;
+                e[u] = queue[(live[u] ? q + u : q) * TPB + tid];
+                j[u] = (int)(e[u] & JMASK);
             }
-            const double t0 = VL ? fmin(r20, rcut2) : r20, t1 = VL ? fmin(r21, rcut2) : r21;   // the table ends at rcut
-            if (CL) { eval_fg<2 * RS_NCOEF + 1>(t0, coef, f0, h0); eval_fg<2 * RS_NCOEF + 1>(t1, coef, f1, h1); }
-            else { eval_fg(t0, coef, f0, h0); eval_fg(t1, coef, f1, h1); }
-            const bool in0 = r20 < rcut2 && r20 > 0.0, in1 = two && r21 < rcut2 && r21 > 0.0;   // the fp64 cutoff decides
-            if (!in0) { f0 = 0.0; h0 = 0.0; }
-            if (!in1) { f1 = 0.0; h1 = 0.0; }
-            const double rd0 = (d0x * F0.x + d0y * F0.y + d0z * F0.z) * h0;
-            const double rd1 = (d1x * F1.x + d1y * F1.y + d1z * F1.z) * h1;
-            ux += f0 * F0.x + rd0 * d0x + f1 * F1.x + rd1 * d1x;
-            uy += f0 * F0.y + rd0 * d0y + f1 * F1.y + rd1 * d1y;
-            uz += f0 * F0.z + rd0 * d0z + f1 * F1.z + rd1 * d1z;
-            if (TWO) {
-                const double4 G0 = vec2_s[j0], G1 = vec2_s[j1];
-                const double s0 = (d0x * G0.x + d0y * G0.y + d0z * G0.z) * h0, s1 = (d1x * G1.x + d1y * G1.y + d1z * G1.z) * h1;
-                wx += f0 * G0.x + s0 * d0x + f1 * G1.x + s1 * d1x;
-                wy += f0 * G0.y + s0 * d0y + f1 * G1.y + s1 * d1y;
-                wz += f0 * G0.z + s0 * d0z + f1 * G1.z + s1 * d1z;
-            }
-            if (LIST) {
-                // 20 B per pair: (slot | image code), f, h; the mat-vecs redo the subtraction from the positions
-                if (in0) {
-                    if (total < nb.cap) nb_store<true>(rec, total, lane, e0, f0, h0);
-                    ++total;
+#pragma unroll
+            for (int u = 0; u < DU; ++u) { p[u] = pos_s[j[u]]; F[u] = vec_s[j[u]]; if (TWO) G[u] = vec2_s[j[u]]; }
+#pragma unroll
+            for (int u = 0; u < DU; ++u) {
+                double sx, sy, sz;
+                image_shift(e[u] >> 27, box, sx, sy, sz);
+                double dx = pi.x - p[u].x - sx, dy = pi.y - p[u].y - sy, dz = pi.z - p[u].z - sz;
+                if (!shift_only) min_image(box, dx, dy, dz);
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                if (VL) {
+                    if (live[u] && r2 < rq2 && r2 > 0.0) { if (vtotal < vl.cap) vl_store(vrec, vtotal, lane, (unsigned)j[u]); ++vtotal; }
                 }
-                if (in1) {
-                    if (total < nb.cap) nb_store<true>(rec, total, lane, e1, f1, h1);
+                const double t = VL ? fmin(r2, rcut2) : r2;   // the table ends at rcut
+                double f, h;
+                if (CL) eval_fg<2 * RS_NCOEF + 1>(t, coef, f, h);
+                else eval_fg(t, coef, f, h);
+                const bool in = live[u] && r2 < rcut2 && r2 > 0.0;   // the fp64 cutoff decides
+                if (!in) { f = 0.0; h = 0.0; }
+                const double rd = (dx * F[u].x + dy * F[u].y + dz * F[u].z) * h;
+                ux += f * F[u].x + rd * dx; uy += f * F[u].y + rd * dy; uz += f * F[u].z + rd * dz;
+                if (TWO) {
+                    const double sd = (dx * G[u].x + dy * G[u].y + dz * G[u].z) * h;
+                    wx += f * G[u].x + sd * dx; wy += f * G[u].y + sd * dy; wz += f * G[u].z + sd * dz;
+                }
+                if (LIST && in) {   // 20 B per pair: (slot | image code), f, h; the mat-vecs redo the subtraction from the positions
+                    if (total < nb.cap) nb_store<true>(rec, total, lane, e[u], f, h);
                     ++total;
                 }
             }
@@ -629,7 +624,7 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
 }
 
 static size_t mreal_lds_bytes(int ncoef) { return (size_t)(ncoef / (2 * RS_NCOEF)) * (2 * RS_NCOEF + 1) * sizeof(double); }   // padded copy
-bool mreal_table_in_lds(int ncoef) { return mreal_lds_bytes(ncoef) <= 14 * 1024; }   // with the 48 KB queue: two workgroups per CU
+bool mreal_table_in_lds(int ncoef) { return mreal_lds_bytes(ncoef) <= 14 * 1024; }   // with the 44 KB queue: three workgroups per CU up to 9 KB of table, two beyond
 
 void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec_s, double4 *out_s, int lo, int hi,
                   const int *cell_off, DBox box, DCells nc, double rcut, double self, const double *coef, int ncoef, NbList nb,

@@ -316,7 +316,8 @@ def main():
     # factor is calibrated for this kernel's non-temporal list loads by tools/microbench/nt_fetch) and carries the commit the
     # passes were taken at, so a stale file shows
     traffic, traffic_src = None, None
-    if world == 1 and not args.no_traffic and dom in pmc_names:
+    under_profiler = any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+    if world == 1 and not args.no_traffic and not under_profiler and dom in pmc_names:      # no profiler inside a profiled run
         traffic = measure_traffic(pmc_names[dom], args)       # child processes with their own engine (this one idles meanwhile)
         if traffic is not None:
             traffic_src = ("measured in this run: 2 x FETCH_SIZE + WRITE_SIZE of that kernel, per launch, from two rocprofv3 --pmc child "

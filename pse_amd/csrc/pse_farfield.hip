@@ -223,7 +223,7 @@ template <int P, int TZ, bool SHEAR, int NW>
 __global__ void __launch_bounds__(64 * NW)
 k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ gx, double *__restrict__ gy,
                double *__restrict__ gz, DGrid G, GaussConsts gc, FastDiv dz, FastDiv dy) {
-    constexpr int TX = 8, TY = 8, PT = P + 2, LS = 65, RMAX = P <= 8 ? 20 : 32;   // runs: bins in x times bins in y times z parts
+    constexpr int TX = 8, TY = 8, PT = P + 1, LS = 65, RMAX = P <= 8 ? 20 : 32;   // runs: bins in x times bins in y times z parts
     constexpr int UB = (P + 4) & ~1;          // doubles per particle of the wave-uniform block: az[P], force[3], pad to 16 bytes
     constexpr int WB = 2 * PT * LS + UB * 64 + ((2 * PT * LS) & 1);   // doubles of one wave's tables (s_u 16-byte aligned)
     constexpr int RED = (NW - 1) * TZ * 3 * 64;                        // the other waves' accumulators, parked over the tables
@@ -244,8 +244,8 @@ k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ 
     const int Nn[3] = {G.Nx, G.Ny, G.Nz};
     const int nb[3] = {fb.nbx, fb.nby, fb.nbz};
 
-    if (SHEAR)   // K[t][v] = exp(-2 c s hx hy t v) on the padded index grid (the pads multiply a zero)
-        for (int e = threadIdx.x; e < PT * 16; e += 64 * NW) s_k[e] = exp_lean(gc.lnk * (double)(((e >> 4) - 1) * ((e & 15) - 1)));
+    if (SHEAR)   // K[t][v] = exp(-2 c s hx hy t v) on the padded index grid (the pad row / column P multiplies a zero)
+        for (int e = threadIdx.x; e < PT * 16; e += 64 * NW) s_k[e] = exp_lean(gc.lnk * (double)((e >> 4) * (e & 15)));
     // bins whose origins [t0 - P + 1, t0 + ext - 1] (cyclic) can reach the block; consecutive z bins are one record range
     int blo[3], bcnt[3];
 #pragma unroll
@@ -276,7 +276,7 @@ k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ 
     double acc[TZ][3];
     static_for<TZ>([&](auto zc) __attribute__((always_inline)) { constexpr int z = decltype(zc)::value; acc[z][0] = acc[z][1] = acc[z][2] = 0.0; });
 
-    const unsigned lxb = (unsigned)((lx + 1) * LS * 8), lyb = (unsigned)((ly + 1) * LS * 8);   // byte offset of row lx + 1 / ly + 1
+    const unsigned lxb = (unsigned)(lx * LS * 8), lyb = (unsigned)(ly * LS * 8);   // byte offset of row lx / ly
     // record of candidate k: the runs are few, a scan of independent (broadcast) LDS reads finds its run
     double2 n0, n1, n2, n3;
     auto fetch = [&](int c0) __attribute__((always_inline)) {
@@ -312,15 +312,15 @@ k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ 
             double a[P];
             gauss_axis<P>(-c * u * u, -2.0 * c * G.hx * u, gc.rx, a);
             if (hit) {
-                s_ax[lane] = 0.0; s_ax[(P + 1) * LS + lane] = 0.0;
+                s_ax[P * LS + lane] = 0.0;
 #pragma unroll
-                for (int t = 0; t < P; ++t) s_ax[(t + 1) * LS + lane] = a[t];
+                for (int t = 0; t < P; ++t) s_ax[t * LS + lane] = a[t];
             }
             gauss_axis<P>(-c * Y0 * Y0, -2.0 * c * G.hy * (Y0 + gc.s * u), gc.ry, a);
             if (hit) {
-                s_ay[lane] = 0.0; s_ay[(P + 1) * LS + lane] = 0.0;
+                s_ay[P * LS + lane] = 0.0;
 #pragma unroll
-                for (int t = 0; t < P; ++t) s_ay[(t + 1) * LS + lane] = a[t];
+                for (int t = 0; t < P; ++t) s_ay[t * LS + lane] = a[t];
             }
             gauss_axis<P>(-c * Z0 * Z0, -2.0 * c * G.hz * Z0, gc.rz, a);
             if (hit) {
@@ -333,7 +333,7 @@ k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ 
                 for (int t = 0; t < UB / 2; ++t) up[t] = make_double2(ub[2 * t], ub[2 * t + 1]);
             }
         }
-        // byte offsets of the particle's table rows relative to lane 0's view: row (lx + 1 - ox) of column `lane`
+        // byte offsets of the particle's table rows relative to lane 0's view: row (lx - ox) of column `lane`
         const int metax = rel[0] * (LS * 8) - lane * 8, metay = rel[1] * (LS * 8) - lane * 8;
         const int kzl = hit ? rel[2] + P - 1 : -1;                    // z offset class of this lane's particle
         wave_sync();
@@ -346,10 +346,11 @@ k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ 
             while (m) {
                 const int p = __ffsll((long long)m) - 1;
                 m &= m - 1ull;
-                // byte address of this lane's row in the particle's padded column: rows 0 and P + 1 are the zero pads; a row
-                // below 0 wraps to a huge unsigned and is clamped to the upper pad like a row above P
+                // byte address of this lane's row in the particle's column: rows 0 .. P - 1 hold the weights, row P is the zero pad; a
+                // row below 0 wraps to a huge unsigned and is clamped to the pad like a row above P - 1 (one pad row: the table of a
+                // wave is 1 KB smaller than with a pad at either end, and twelve workgroups share a CU instead of eleven)
                 const unsigned mx = (unsigned)__builtin_amdgcn_readlane(metax, p), my = (unsigned)__builtin_amdgcn_readlane(metay, p);
-                const unsigned cap = (unsigned)((P + 1) * LS * 8 + p * 8);
+                const unsigned cap = (unsigned)(P * LS * 8 + p * 8);
                 const unsigned bxo = min(lxb - mx, cap), byo = min(lyb - my, cap);
                 double w = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(s_ax) + bxo) *
                            *reinterpret_cast<const double *>(reinterpret_cast<const char *>(s_ay) + byo);

@@ -80,7 +80,7 @@ struct pse_handle {
     struct Tuning {
         int cell_bz = 6;          // PSE_CELL_BZ: height of the z blocks of the cell storage order (0: plain x, y, z order)
         double skin = 0.4;        // PSE_SKIN: r_buff of the neighbour list kept across calls (0: off)
-        int overlap = 1;          // PSE_OVERLAP: 1 two chains for every call, 0 only for kT = 0, -1 never
+        int overlap = 0;          // PSE_OVERLAP: 1 two chains for every call, 0 (default) only for kT = 0, -1 never
         bool no_xfuse = false;    // PSE_NO_XFUSE: rocFFT for the x pass
         bool team_fused_group = false;   // PSE_TEAM_FUSED_GROUP: RCCL teams put the Lanczos sum into the group of the ghost transfers
         int wave_mode = 0;        // PSE_WAVE_MODE: 0 automatic, 1 slab, 2 replicated
@@ -408,7 +408,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         auto &t = h->tun;
         t.cell_bz = std::min(16, std::max(0, ienv("PSE_CELL_BZ", 6)));   // n_cells_alloc pads every z line by up to 15 cells
         if (const char *v = getenv("PSE_SKIN")) t.skin = atof(v);
-        t.overlap = ienv("PSE_OVERLAP", 1);
+        t.overlap = ienv("PSE_OVERLAP", 0);
         t.no_xfuse = getenv("PSE_NO_XFUSE") != nullptr;
         if (const char *v = getenv("PSE_TEAM_FUSED_GROUP")) t.team_fused_group = atoi(v) != 0;
         if (const char *v = getenv("PSE_WAVE_MODE")) t.wave_mode = !strcmp(v, "slab") ? 1 : (!strcmp(v, "replicated") ? 2 : 0);
@@ -537,16 +537,18 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     // final sum: on a single GPU they run on two streams, so latency-bound kernels of one chain fill the gaps of the
     // other and the Lanczos host checks do not stall the far field.  (Teams keep one stream: one RCCL communicator.)
     h->wstream = h->stream;
-    // Evaluations fork whenever no phase timing is requested: the far-field chain runs on a side stream next to the near field
-    // and the Lanczos iterations (both chains are latency- rather than bandwidth-bound, so they overlap well).  With
-    // pse_set_timing on, everything runs on one stream and the far field is queued behind the Lanczos iterations: per-kernel
-    // durations -- the roofline evidence -- are then those of the kernel alone.  PSE_OVERLAP=0 restricts the fork to kT = 0.
+    // Deterministic evaluations (kT = 0) fork whenever no phase timing is requested: the far-field chain runs on a side stream next
+    // to the near field (+3.5 % M.F evaluations per second).  Brownian steps stay on ONE stream by default since the end of round 3:
+    // with the build pass at three workgroups per CU, the gather at six and the spread at twelve, every kernel fills the chip on
+    // its own and a second chain only gets in its way (paired runs in one box: 3.63 ms one stream, 3.65 - 3.69 forked;
+    // PSE_OVERLAP=1 forks them too, -1 never forks).  With pse_set_timing on, everything runs on one stream: per-kernel
+    // durations -- the roofline evidence -- are then those of the kernel alone.
     if (h->tun.overlap >= 0) {
         HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
         h->side_owned = h->side;
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-        h->overlap_all = h->tun.overlap != 0;   // on unless PSE_OVERLAP=0
+        h->overlap_all = h->tun.overlap > 0;    // Brownian steps fork only with PSE_OVERLAP=1
     }
     TRY(make_plans(h));
 

@@ -540,7 +540,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     // Deterministic evaluations (kT = 0) fork whenever no phase timing is requested: the far-field chain runs on a side stream next
     // to the near field (+3.5 % M.F evaluations per second).  Brownian steps stay on ONE stream by default since the end of round 3:
     // with the build pass at three workgroups per CU, the gather at six and the spread at twelve, every kernel fills the chip on
-    // its own and a second chain only gets in its way (paired runs in one box: 3.63 ms one stream, 3.65 - 3.69 forked;
+    // its own and a second chain buys nothing measurable (six paired runs: forked minus one stream between -1.2 % and +1.8 %;
     // PSE_OVERLAP=1 forks them too, -1 never forks).  With pse_set_timing on, everything runs on one stream: per-kernel
     // durations -- the roofline evidence -- are then those of the kernel alone.
     if (h->tun.overlap >= 0) {

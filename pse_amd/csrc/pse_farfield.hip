@@ -228,7 +228,9 @@ k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ 
     constexpr int WB = 2 * PT * LS + UB * 64 + ((2 * PT * LS) & 1);   // doubles of one wave's tables (s_u 16-byte aligned)
     constexpr int RED = (NW - 1) * TZ * 3 * 64;                        // the other waves' accumulators, parked over the tables
     __shared__ __attribute__((aligned(16))) double s_tab[NW * WB > RED ? NW * WB : RED];
-    __shared__ double s_k[SHEAR ? PT * 16 : 1];
+    constexpr int KS = PT <= 8 ? 8 : 16;      // row stride of the shear table (columns 0 .. P): 448 bytes at P = 6, so that the sheared
+                                              // kernel keeps the twelve workgroups per CU of the unsheared one
+    __shared__ double s_k[SHEAR ? PT * KS : 1];
     __shared__ int s_rb[RMAX], s_ro[RMAX + 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lx = lane & 7, ly = lane >> 3;
     double *const s_ax = s_tab + wv * WB, *const s_ay = s_ax + PT * LS, *const s_u = s_tab + wv * WB + (WB - UB * 64);
@@ -245,7 +247,7 @@ k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ 
     const int nb[3] = {fb.nbx, fb.nby, fb.nbz};
 
     if (SHEAR)   // K[t][v] = exp(-2 c s hx hy t v) on the padded index grid (the pad row / column P multiplies a zero)
-        for (int e = threadIdx.x; e < PT * 16; e += 64 * NW) s_k[e] = exp_lean(gc.lnk * (double)((e >> 4) * (e & 15)));
+        for (int e = threadIdx.x; e < PT * KS; e += 64 * NW) s_k[e] = exp_lean(gc.lnk * (double)((e / KS) * (e % KS)));
     // bins whose origins [t0 - P + 1, t0 + ext - 1] (cyclic) can reach the block; consecutive z bins are one record range
     int blo[3], bcnt[3];
 #pragma unroll
@@ -354,7 +356,7 @@ k_spread_tiles(const FarRec *__restrict__ rec, FarBins fb, double *__restrict__ 
                 const unsigned bxo = min(lxb - mx, cap), byo = min(lyb - my, cap);
                 double w = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(s_ax) + bxo) *
                            *reinterpret_cast<const double *>(reinterpret_cast<const char *>(s_ay) + byo);
-                if (SHEAR) w *= s_k[(bxo - p * 8) / (LS * 8) * 16 + (byo - p * 8) / (LS * 8)];
+                if (SHEAR) w *= s_k[(bxo - p * 8) / (LS * 8) * KS + (byo - p * 8) / (LS * 8)];
                 // the particle's wave-uniform block: 16-byte broadcast reads, only the pairs this class needs
                 const double2 *up = reinterpret_cast<const double2 *>(s_u + p * UB);
                 double ub[UB];

@@ -1185,7 +1185,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
     double *sc = h0->sc_host;   // pinned: the read-back of the device scalars is one DMA, no staging copy
     int done = 0;                         // iterations launched so far
     int target = std::max(m_in, 2);       // first convergence check is at m = max(m_in, 2)   (Brownian.cu:465-466,606)
-    int m_final = 0, checked = 0;
+    int m_final = 0, checked = 0, pending_beta = 0;
     double stepnorm = 1.0;
     bool hook_done = false;
     while (true) {
@@ -1216,22 +1216,19 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
             // the partial sums and the ghost rows of y = M x_j in one exchange; every rank then updates its own rows AND its ghost
             // rows (it holds x_j and x_{j-1} there from the previous iteration), so x_{j+1} needs no exchange of its own
             TRY(team_lanczos_exchange(T, [](pse_handle *h) { return h->scal + LZ_TMP; }, [](pse_handle *h) { return (double *)h->w_s; }));
+            // The LAST iteration of a batch only derives its scalars (alpha_j, beta_j): whether x_{j+1} is needed at all is what the
+            // check below decides -- in the steady state of a time-stepping loop (m_in = m) it is not, and the step saves one vector
+            // pass and the reduction of |x_{j+1}| (0.04 ms at the metric point).  If the iteration goes on, the vector part follows.
+            const bool scalars_only = done == target - 1;
             for (pse_handle *h : T.m) {
                 int rg[3][2];
-                const int nrg = update_ranges(h, N, rg);
+                const int nrg = scalars_only ? 0 : update_ranges(h, N, rg);
                 const double4 *xj = done == 0 ? h->psi_s : h->V + (size_t)done * stride;
                 launch_lz_update(xj, h->w_s, done > 1 ? h->V + (size_t)(done - 1) * stride : (done == 1 ? h->psi_s : nullptr),
                                  h->V + (size_t)(done + 1) * stride, done, h->scal, rg, nrg, h->stream, h->pv);
-                h->pv_is_f = false;   // the vector half of pv now holds x_{j+1}
+                if (!scalars_only) h->pv_is_f = false;   // the vector half of pv now holds x_{j+1}
             }
         }
-        // beta_done = |x_done| is not known yet (the next mat-vec would deliver it): one extra reduction per check
-        for (pse_handle *h : T.m) {
-            int lo, hi;
-            row_range(h, N, lo, hi);
-            launch_lz_dots(h->V + (size_t)done * stride, nullptr, nullptr, lo, hi, h->partials, h->npart_cap, h->scal, h->stream);
-        }
-        TRY(team_all_reduce_sum(T, [](pse_handle *h) { return h->scal + LZ_TMP; }, 1));
         HIPCHK(hipMemcpyAsync(sc, h0->scal, LZ_NSCAL * sizeof(double), hipMemcpyDeviceToHost, h0->stream));
         HIPCHK(hipEventRecord(h0->ev_scal, h0->stream));
         if (!hook_done) {   // independent work queued behind the read-back keeps the GPU busy while the host decides
@@ -1240,8 +1237,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
             if (before_first_wait) TRY(before_first_wait());
         }
         HIPCHK(hipEventSynchronize(h0->ev_scal));
-        sc[LZ_BETA + done] = sc[LZ_TMP] > 0.0 ? std::sqrt(sc[LZ_TMP]) : 0.0;
-        const double *alpha = &sc[LZ_ALPHA], *beta = &sc[LZ_BETA];
+        const double *alpha = &sc[LZ_ALPHA], *beta = &sc[LZ_BETA];   // alpha_0 .. alpha_{done-1}, beta_1 .. beta_{done-1}; beta_done not yet
         if (!(sc[LZ_NORM] > 0.0) || !std::isfinite(sc[LZ_NORM])) {   // psi == 0 -> result 0
             for (pse_handle *h : T.m) {
                 HIPCHK(hipMemsetAsync(h->ub_s, 0, (size_t)N * sizeof(double4), h->stream));
@@ -1250,13 +1246,17 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
             if (m_io) *m_io = m_in;
             return 0;
         }
+        // |x_m| of the vector the previous batch ended on arrives with this batch's first mat-vec: its breakdown test comes first
+        if (pending_beta && beta[pending_beta] < 1e-8) { m_final = pending_beta; stepnorm = 0.0; t_cur = t_prev; break; }
+        pending_beta = 0;
         // walk m upward exactly as the reference's while loop does, one vector at a time
         for (int m = std::max(checked + 1, std::max(m_in - 1, 1)); m <= done && !m_final; ++m) {
-            if (!std::isfinite(alpha[m - 1]) || !std::isfinite(beta[m]))
+            const bool last = m == done;                                          // beta_done = |x_done| does not exist yet
+            if (!std::isfinite(alpha[m - 1]) || (!last && !std::isfinite(beta[m])))
                 return fail(PSE_ERR_NUMERIC, "Lanczos produced a non-finite coefficient at iteration %d", m - 1);
             if (!lanczos_sqrt_e1(m, alpha, beta, t_cur))
                 return fail(PSE_ERR_NUMERIC, "tridiagonal eigen-solve failed at m = %d", m);
-            if (beta[m] < 1e-8) { m_final = m; stepnorm = 0.0; break; }          // invariant subspace (Brownian.cu:503)
+            if (!last && beta[m] < 1e-8) { m_final = m; stepnorm = 0.0; break; }  // invariant subspace (Brownian.cu:503)
             if (!t_prev.empty() && (int)t_prev.size() == m - 1) {
                 double s2 = t_cur[m - 1] * t_cur[m - 1];
                 for (int q = 0; q < m - 1; ++q) s2 += (t_cur[q] - t_prev[q]) * (t_cur[q] - t_prev[q]);
@@ -1268,6 +1268,18 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
         }
         if (m_final) break;
         if (done >= M_MAX) { m_final = M_MAX; break; }
+        // not converged: the vector part of the last iteration (its sums are still in place), then the next batch; an x_done that
+        // vanishes (invariant subspace) shows in the first sums of that batch
+        for (pse_handle *h : T.m) {
+            int rg[3][2];
+            const int nrg = update_ranges(h, N, rg);
+            const int j = done - 1;
+            const double4 *xj = j == 0 ? h->psi_s : h->V + (size_t)j * stride;
+            launch_lz_update(xj, h->w_s, j > 1 ? h->V + (size_t)(j - 1) * stride : (j == 1 ? h->psi_s : nullptr),
+                             h->V + (size_t)(j + 1) * stride, j, h->scal, rg, nrg, h->stream, h->pv);
+            h->pv_is_f = false;
+        }
+        pending_beta = done;
         target = std::min(M_MAX, done + std::max(2, done / 4));
     }
     if ((int)t_cur.size() != m_final) {

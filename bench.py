@@ -128,10 +128,11 @@ def launch_ranks(args, argv, script=None):
         for out in procs[0].stdout:
             out = out.rstrip("\n")
             try:
-                if "metric" in json.loads(out):
+                obj = json.loads(out)
+                if isinstance(obj, dict) and "metric" in obj:      # a bare JSON scalar ("0", "true") is just a line of output
                     found.append(out)
                     continue
-            except ValueError:
+            except Exception:   # noqa: BLE001  (whatever rank 0 prints, this thread must keep draining its pipe)
                 pass
             print(out, file=sys.stderr)
 
@@ -139,6 +140,8 @@ def launch_ranks(args, argv, script=None):
     reader.start()
     rc = 0
     pending = list(procs)
+    t_all = time.time() + float(os.environ.get("PSE_BENCH_LAUNCH_TIMEOUT", "3600"))   # the whole run
+    t_kill = None                                       # once ranks were told to end: when the survivors are killed
     while pending:
         for p in list(pending):
             code = p.poll()
@@ -149,6 +152,18 @@ def launch_ranks(args, argv, script=None):
                 rc = code
                 for q in pending:                       # a rank failed: the rest would wait in a collective for ever
                     q.terminate()
+                t_kill = time.time() + 20.0
+        now = time.time()
+        if pending and t_kill is None and now > t_all:
+            rc = rc or 124
+            print(f"bench.py: the ranks did not finish within PSE_BENCH_LAUNCH_TIMEOUT: ending them", file=sys.stderr)
+            for q in pending:
+                q.terminate()
+            t_kill = now + 20.0
+        elif pending and t_kill is not None and now > t_kill:
+            for q in pending:                           # SIGTERM was not enough (stuck in a driver or RCCL call): exactly these PIDs
+                q.kill()
+            t_kill = now + 20.0
         if pending:
             time.sleep(0.05)
     reader.join(timeout=30)
@@ -166,8 +181,8 @@ def launch_ranks(args, argv, script=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50, help="timed steps (BASELINE.md section 4: >= 50)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", "--particles", dest="n", type=int, default=1_000_000,
                     help="(--particles under torch.distributed.run, whose parser reads a bare --n as an abbreviation of its own options)")
     ap.add_argument("--phi", type=float, default=0.1)
@@ -244,6 +259,25 @@ def main():
         sim.mobility()
     barrier()
     t_mf = (time.perf_counter() - t0) / n_mf
+    # the same evaluation with MOVING particles: every call sees positions displaced by more than r_buff / 2 from the last one, so
+    # the kept neighbour list is never reused and every call sorts and walks the cells (single GPU; slab ranks keep no list)
+    t_mf_moving = None
+    if world == 1 and hasattr(sim, "engine") and hasattr(sim, "pos"):
+        rng = np.random.default_rng(99)
+        moved = []
+        for k in range(4):
+            p = sim.pos.clone()
+            p[:, :3] += torch.tensor(rng.uniform(-0.5, 0.5, (n, 3)), dtype=torch.float64, device="cuda")
+            moved.append(p)
+        for k in range(2):
+            sim.engine.mobility(moved[k], sim.force, vel=sim.vel)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in range(n_mf):
+            sim.engine.mobility(moved[it % 4], sim.force, vel=sim.vel)
+        torch.cuda.synchronize()
+        t_mf_moving = (time.perf_counter() - t0) / n_mf
+        del moved
 
     # headline: EXACTLY --steps steps, nothing else inside the timed region (no phase timing, no host synchronisation beyond
     # what the step itself needs: the Lanczos convergence check)
@@ -333,8 +367,12 @@ def main():
                                    f"kernels as of commit {tj.get('_commit', 'unrecorded')}); not measured in this run")
         except Exception:
             traffic = None
-    sg_ms = per_launch_ms["t_spread"] + per_launch_ms["t_gather"]
+    # spread + gather: with the binning and the 64-byte records both kernels read (ms), and the two kernels alone (kernels_ms)
+    rec_ms = phases.get("t_records", 0.0)
+    sg_ms = per_launch_ms["t_spread"] + per_launch_ms["t_gather"] + rec_ms
+    sg_kernels_ms = per_launch_ms["t_spread"] + per_launch_ms["t_gather"]
     sg_bytes = alg["t_spread"] + alg["t_gather"]
+    a_step = (192.0 * ng + 224.0 * n) + 32.0 * n + (m_avg + 1.0) * 256.0 * n + 32.0 * n * m_avg + 160.0 * n
     # what the kept neighbour list did in this run (the M.F evaluations repeat at fixed positions and reuse it; the Brownian steps
     # at this kT dt outrun r_buff / 2 every step, so every step sorts and walks the cells, as with PSE_SKIN=0)
     nl_note = None
@@ -353,6 +391,10 @@ def main():
                                f"xi={xi:.4f}, rcut={info['rcut']:.3f}, P={info['P']}, error={args.error}, kT={args.kT}, "
                                f"dt={args.dt}", "parallelism": sim.describe()},
         "steps_per_s": 1.0 / t_step, "mf_evals_per_s": 1.0 / t_mf, "mf_particle_evals_per_s": n / t_mf,
+        "mf_evals_per_s_moving": (1.0 / t_mf_moving) if t_mf_moving else None,
+        # the whole step against the roofline: SURVEY.md 8(d) A_step = A_MF + 32 N + (m + 1) 256 N + 32 N m + 160 N over all ranks
+        "step_roofline": {"algorithmic_bytes": a_step, "ms": t_step * 1e3, "lanczos_m": m_avg,
+                          "frac_of_hbm_peak": a_step / t_step / 1e9 / (HBM_PEAK_GBS * world)},
         "lanczos_m": m_avg, "lanczos_matvecs_per_step": info["lanczos_matvecs"],
         "neighbor_list": nl_note,
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -362,7 +404,9 @@ def main():
                      "traffic_rate": (traffic / (per_launch_ms[dom] * 1e-3) / 1e9) if traffic and per_launch_ms[dom] > 0 else None,
                      "traffic_rate_frac_of_peak": (traffic / (per_launch_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and per_launch_ms[dom] > 0 else None},
         "spread_plus_gather": {"ms": sg_ms, "algorithmic_bytes": sg_bytes,
-                               "frac_of_hbm_peak": (sg_bytes / (sg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sg_ms > 0 else 0.0},
+                               "frac_of_hbm_peak": (sg_bytes / (sg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sg_ms > 0 else 0.0,
+                               "kernels_ms": sg_kernels_ms, "records_ms": rec_ms,
+                               "kernels_frac_of_hbm_peak": (sg_bytes / (sg_kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sg_kernels_ms > 0 else 0.0},
         "phases_ms_per_step": {k[2:]: round(v, 4) for k, v in phases.items()},
         "phase_hbm_frac": {k[2:]: round(alg[k] / (per_launch_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                            for k in alg if per_launch_ms[k] > 0},

@@ -50,7 +50,8 @@ def lib():
     """ctypes handle of the C oracle (built by `make -C oracle`)."""
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libpse_oracle.so")
+        # PSE_ASAN_DIR: the -fsanitize=address,undefined build of this same source (python -m pse_amd.build --asan-test)
+        path = os.path.join(os.environ.get("PSE_ASAN_DIR") or _HERE, "libpse_oracle.so")
         if not os.path.exists(path):
             import subprocess
             subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)

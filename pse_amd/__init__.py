@@ -3,7 +3,12 @@
 Layout: csrc/ (HIP kernels + C-ABI + C++ host classes), engine.py (ctypes owner of a handle),
 integrate.py / shear_function.py / variant.py (mirror of the reference's Python UI, PSEv1/*.py).
 """
+import os as _os
+if _os.environ.get("PSE_ASAN_DIR"):   # the CPU sanitizer run (pse_amd.build --asan-test): its _PSEv1 module shadows the product's
+    __path__.insert(0, _os.environ["PSE_ASAN_DIR"])
 try:   # torch first: its bundled HIP/rocFFT/RCCL (same SONAMEs) must be the copies libpse_amd.so and _PSEv1 bind to
+    if _os.environ.get("PSE_ASAN_DIR"):
+        raise ImportError   # the sanitizer build links no device library (and torch under a preloaded ASan takes minutes to load)
     import torch as _torch  # noqa: F401
 except ImportError:  # pragma: no cover - the C-ABI itself does not need torch
     _torch = None

@@ -7,7 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpse_amd.so")
+# PSE_ASAN_DIR (set by `python -m pse_amd.build --asan-test` only): the CPU sanitizer build, whose device entry points are stubs
+_ASAN_DIR = os.environ.get("PSE_ASAN_DIR")
+LIB_PATH = os.path.join(_ASAN_DIR or _HERE, "libpse_amd.so")
 
 PSE_OK = 0
 
@@ -111,10 +113,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise PSEError(f"{LIB_PATH} not found: build it with `python -m pse_amd.build` "
                        "(there is no CPU fallback for the PSE hot path)")
-    try:
-        import torch  # noqa: F401  (loads libamdhip64/librocfft with the SONAMEs our library needs)
-    except ImportError:
-        pass
+    if not _ASAN_DIR:
+        try:
+            import torch  # noqa: F401  (loads libamdhip64/librocfft with the SONAMEs our library needs)
+        except ImportError:
+            pass
     lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)

@@ -6,6 +6,7 @@ import os
 import subprocess
 import sys
 import sysconfig
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -46,18 +47,36 @@ def _all_sources():
     return out
 
 
+LIB_UNITS = (("pse_kernels.hip", HIPFLAGS), ("pse_farfield.hip", HIPFLAGS + FARFLAGS), ("pse_capi.hip", HIPFLAGS),
+             ("pse_params.cpp", ["-x", "c++"]), ("pse_host_api.cpp", ["-x", "c++"]))
+_report = []   # what build_all did, one entry per artefact: (name, "compiled" | "reused")
+
+
 def build_lib(force=False):
-    srcs = _all_sources()
+    srcs = [x for x in _all_sources() if not x.endswith("asan_stub.cpp")]
     if not force and _newer(LIB, srcs):
+        _report.append(("libpse_amd.so", "reused"))
         return LIB
-    objs = []
-    for name, extra in (("pse_kernels.hip", HIPFLAGS), ("pse_farfield.hip", HIPFLAGS + FARFLAGS), ("pse_capi.hip", HIPFLAGS), ("pse_params.cpp", ["-x", "c++"])):
-        obj = os.path.join(CSRC, name.rsplit(".", 1)[0] + ".o")
-        _run([HIPCC, *CXXFLAGS, *extra, "-c", os.path.join(CSRC, name), "-o", obj])
-        objs.append(obj)
+    from concurrent.futures import ThreadPoolExecutor
+    objs = [os.path.join(CSRC, name.rsplit(".", 1)[0] + ".o") for name, _ in LIB_UNITS]
+
+    def unit(k):   # a unit whose object is newer than every source is kept (the units share the headers: any header rebuilds all)
+        name, extra = LIB_UNITS[k]
+        deps = [os.path.join(CSRC, name)] + [x for x in srcs if x.endswith(".h") or x.endswith("build.py")]
+        if force or not _newer(objs[k], deps):
+            _run([HIPCC, *CXXFLAGS, *extra, "-c", os.path.join(CSRC, name), "-o", objs[k]])
+    with ThreadPoolExecutor(max_workers=min(len(LIB_UNITS), os.cpu_count() or 1)) as pool:
+        list(pool.map(unit, range(len(LIB_UNITS))))
     _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs,
           f"-L{ROCM}/lib", "-lrocfft", "-lrccl", "-lpthread", "-ldl", f"-Wl,-rpath,{ROCM}/lib"])
+    _report.append(("libpse_amd.so", "compiled"))
     return LIB
+
+
+def _module_sources():
+    host = os.path.join(CSRC, "host")
+    srcs = [os.path.join(host, f) for f in sorted(os.listdir(host)) if f.endswith(".cc")]
+    return srcs, srcs + [os.path.join(host, f) for f in os.listdir(host)]
 
 
 def build_module(force=False):
@@ -65,23 +84,60 @@ def build_module(force=False):
     import pybind11
     ext = sysconfig.get_config_var("EXT_SUFFIX")
     target = os.path.join(HERE, "_PSEv1" + ext)
-    host = os.path.join(CSRC, "host")
-    if not os.path.isdir(host):
+    if not os.path.isdir(os.path.join(CSRC, "host")):
         return None
-    srcs = [os.path.join(host, f) for f in sorted(os.listdir(host)) if f.endswith(".cc")]
-    deps = srcs + [os.path.join(host, f) for f in os.listdir(host)] + [LIB]
-    if not force and _newer(target, deps):
+    srcs, deps = _module_sources()
+    if not force and _newer(target, deps + [LIB]):
+        _report.append(("_PSEv1", "reused"))
         return target
     inc = ["-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], "-I" + os.path.join(HERE, "..", "include")]
     _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", *inc, *srcs, "-o", target,
           f"-L{HERE}", "-lpse_amd", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{ROCM}/lib"])
+    _report.append(("_PSEv1", "compiled"))
     return target
 
 
-def build_all(force=False):
+def build_all(force=None):
+    """force=None: PSE_BUILD_FORCE=1 in the environment compiles everything again; otherwise artefacts newer than every source
+    (the ones that travel with a gpurun push are) are reused.  Prints one line saying which it was."""
+    if force is None:
+        force = os.environ.get("PSE_BUILD_FORCE", "") not in ("", "0")
+    del _report[:]
+    t0 = time.time()
     build_lib(force)
     build_module(force)
+    print("pse_amd.build: " + ", ".join(f"{n} {how}" for n, how in _report) + f" ({time.time() - t0:.1f} s"
+          + (", forced" if force else "") + ")", flush=True)
+
+
+# ---- CPU sanitizer build (VERDICT r3 item 7): never on the GPU, never the product --------------------------------------------
+ASAN_DIR = os.path.join(HERE, "..", "build", "asan")
+SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
+
+
+def build_asan():
+    """g++ -fsanitize=address,undefined builds of everything of the product that runs on the host: the parameter rule + table
+    builder (pse_params.cpp), the host-only C-ABI incl. the Lanczos tridiagonal solver (pse_host_api.cpp), the C++ host classes
+    and their pybind11 module (csrc/host/*, against csrc/asan_stub.cpp standing in for the device entry points).
+    Output: build/asan/{libpse_amd.so,_PSEv1*.so}; tools/asan.py adds the checker and runs the CPU tests on them."""
+    import pybind11
+    out = os.path.abspath(ASAN_DIR)
+    os.makedirs(out, exist_ok=True)
+    inc = ["-I" + os.path.join(HERE, "..", "include")]
+    lib = os.path.join(out, "libpse_amd.so")
+    _run(["g++", "-std=c++17", "-fPIC", "-shared", "-Wall", *SAN, *inc, os.path.join(CSRC, "pse_params.cpp"),
+          os.path.join(CSRC, "pse_host_api.cpp"), os.path.join(CSRC, "asan_stub.cpp"), "-o", lib])
+    ext = sysconfig.get_config_var("EXT_SUFFIX")
+    srcs, _ = _module_sources()
+    _run(["g++", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", *SAN, *inc, "-I" + pybind11.get_include(),
+          "-I" + sysconfig.get_paths()["include"], *srcs, "-o", os.path.join(out, "_PSEv1" + ext), f"-L{out}", "-lpse_amd",
+          "-Wl,-rpath,$ORIGIN"])
+    print("pse_amd.build: sanitizer build in " + out, flush=True)
+    return out
 
 
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv)
+    if "--asan" in sys.argv:
+        build_asan()
+    else:
+        build_all(force=True if "--force" in sys.argv else None)

@@ -22,21 +22,12 @@
 #include <vector>
 
 #include "../../include/pse_amd.h"
+#include "pse_err.h"
 #include "pse_host.h"
 #include "pse_kernels.h"
 
 using namespace pse;
 
-static thread_local std::string g_err;
-static int fail(int code, const char *fmt, ...) {
-    char buf[1024];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    return code;
-}
 #define HIPCHK(x)                                                                                      \
     do {                                                                                               \
         hipError_t e_ = (x);                                                                           \
@@ -253,33 +244,6 @@ static int collect_times(pse_handle *h, unsigned mask) {
             if (hipEventElapsedTime(&ms, h->ph[p].a, h->ph[p].b) == hipSuccess) *dst[p] = ms;
         }
     }
-    return 0;
-}
-
-extern "C" const char *pse_last_error(void) { return g_err.c_str(); }
-
-static void fill_info(const Derived &d, pse_info *o) {
-    memset(o, 0, sizeof *o);
-    o->Nx = d.Nx; o->Ny = d.Ny; o->Nz = d.Nz; o->P = d.P;
-    o->rcut = d.rcut; o->xi = d.xi; o->eta = d.eta; o->gaussm = d.gaussm; o->lambda = d.lambda;
-    o->self_mobility = d.self; o->hx = d.hx; o->hy = d.hy; o->hz = d.hz;
-}
-
-extern "C" int pse_host_select_params(const pse_params *p, pse_info *info) {
-    if (!p || !info) return fail(PSE_ERR_INVALID, "null argument");
-    Derived d;
-    std::string e = select_params(Box{p->Lx, p->Ly, p->Lz, p->xy}, p->xi, p->error, p->max_strain, p->Nx, p->Ny, p->Nz,
-                                  p->P, p->rcut, d);
-    if (!e.empty()) return fail(PSE_ERR_INVALID, "%s", e.c_str());
-    fill_info(d, info);
-    return 0;
-}
-
-extern "C" int pse_host_lanczos_sqrt_e1(int m, const double *alpha, const double *beta, double *t) {
-    if (m < 1 || m > 4096 || !alpha || !beta || !t) return fail(PSE_ERR_INVALID, "bad argument");
-    std::vector<double> tv;
-    if (!lanczos_sqrt_e1(m, alpha, beta, tv)) return fail(PSE_ERR_NUMERIC, "tridiagonal eigen-solve did not converge");
-    std::copy(tv.begin(), tv.end(), t);
     return 0;
 }
 
@@ -579,7 +543,7 @@ extern "C" int pse_create(const pse_params *p, pse_handle **out) {
     *out = nullptr;
     pse_handle *h = new pse_handle();
     int r = create_impl(p, h);
-    if (r) { std::string keep = g_err; pse_destroy(h); g_err = keep; return r; }
+    if (r) { std::string keep = error_text(); pse_destroy(h); error_text() = keep; return r; }
     *out = h;
     return 0;
 }
@@ -1635,7 +1599,7 @@ extern "C" int pse_team_create(pse_handle **members, int n_members, const void *
     if (n_members > 1)   // in-process team: one side stream for all members, so every lane is ordered by its stream alone
         for (int i = 1; i < n_members; ++i) members[i]->side = members[0]->side;
     int rc = team_connect(T, id128_host);
-    if (rc) { std::string keep = g_err; pse_team_destroy(T); g_err = keep; return rc; }
+    if (rc) { std::string keep = error_text(); pse_team_destroy(T); error_text() = keep; return rc; }
     *out = T;
     return 0;
 }
@@ -1656,7 +1620,13 @@ extern "C" int pse_team_create_transport(pse_handle *member, const pse_transport
 extern "C" int pse_team_destroy(pse_team *T) {
     if (!T) return 0;
     for (pse_handle *h : T->m) {   // members take their own side stream back (an in-process team shared member 0's)
-        if (h->side != h->side_owned) { h->side = h->side_owned; h->side_on = false; h->wstream = h->stream; }
+        if (h->side != h->side_owned) {
+            h->side = h->side_owned; h->side_on = false; h->wstream = h->stream;
+            // the rocFFT execution infos were bound to member 0's side stream: rebind, or the next call with the wave chain on
+            // the main stream finds (side_on, wstream) already as it wants them and the transforms run on the stale stream
+            if (h->info_fwd) (void)rocfft_execution_info_set_stream(h->info_fwd, h->wstream);
+            if (h->info_inv) (void)rocfft_execution_info_set_stream(h->info_inv, h->wstream);
+        }
     }
     if (T->nccl_w) ncclCommDestroy(T->nccl_w);
     if (T->nccl) ncclCommDestroy(T->nccl);

@@ -32,15 +32,68 @@ import mpmath as mp
 import numpy as np
 
 REF = os.environ.get("PSE_REFERENCE", "/root/reference")
-# The reference tree is untrusted content: whatever expression text is evaluated below sees NO Python builtins (no import, open,
-# getattr, ...) -- only the numeric names handed to it.  (The kernel-level fixture, make_kernel_fixture.py, does not evaluate
-# text at all: it interprets a parsed tree.)
+# The reference tree is untrusted content.  An empty __builtins__ is NOT a sandbox (any callable handed to the text leads back to
+# the real builtins through its __globals__), so whatever text is taken from the tree is first parsed and held to a whitelist:
+# arithmetic, comparisons, calls of plain NAMES, numeric constants -- no attribute access, no subscripts, no lambdas, no
+# comprehensions, no strings.  Only a tree that passes is compiled.  The class bodies built from SpecificShearFunction.h pass a
+# second whitelist that also admits `self.m_*` / `self.get*` and the handful of statements a getter is made of.  (The
+# kernel-level fixture, make_kernel_fixture.py, does not evaluate text at all: it interprets a parsed tree.)
+import ast
+
 NO_BUILTINS = {"__builtins__": {}}
 CLASS_BUILTINS = {"__builtins__": {"__build_class__": __build_class__}, "__name__": "reference_fixture"}
+_EXPR_NODES = (ast.Expression, ast.BinOp, ast.UnaryOp, ast.BoolOp, ast.Compare, ast.IfExp, ast.Call, ast.Name, ast.Load, ast.Constant,
+               ast.Add, ast.Sub, ast.Mult, ast.Div, ast.Mod, ast.Pow, ast.FloorDiv, ast.USub, ast.UAdd, ast.Not, ast.And, ast.Or,
+               ast.Lt, ast.LtE, ast.Gt, ast.GtE, ast.Eq, ast.NotEq, ast.BitXor, ast.BitAnd, ast.BitOr, ast.LShift, ast.RShift)
+_STMT_NODES = (ast.Module, ast.ClassDef, ast.FunctionDef, ast.arguments, ast.arg, ast.Assign, ast.AugAssign, ast.Return, ast.If,
+               ast.Expr, ast.Store, ast.Pass)
+
+
+def _check_tree(tree, what, allow_self):
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Attribute) and isinstance(node.value, ast.Name) and node.attr in ("x", "y", "z") and node.value.id != "self":
+            continue   # a component of a Scalar3 (L.x): the struct handed in holds three numbers and nothing else
+        if isinstance(node, ast.Attribute) and allow_self:
+            chain = node   # self.m_x, self.getY, self.m_x.getY: rooted at `self`, every link a member or a getter
+            while isinstance(chain, ast.Attribute) and re.fullmatch(r"(m_\w+|get\w+)", chain.attr):
+                chain = chain.value
+            if not (isinstance(chain, ast.Name) and chain.id == "self"):
+                raise ValueError(f"{what}: attribute access other than self.m_* / self.get* in reference text")
+            continue
+        if isinstance(node, ast.Constant):
+            if not isinstance(node.value, (int, float)) or isinstance(node.value, bool):
+                raise ValueError(f"{what}: non-numeric constant {node.value!r} in reference text")
+            continue
+        if isinstance(node, ast.Call):
+            ok = isinstance(node.func, ast.Name) or (allow_self and isinstance(node.func, ast.Attribute))
+            if not ok or node.keywords:
+                raise ValueError(f"{what}: call of something that is not a plain name in reference text")
+            continue
+        if isinstance(node, ast.Name) and node.id.startswith("__"):
+            raise ValueError(f"{what}: dunder name {node.id} in reference text")
+        if not isinstance(node, _EXPR_NODES + (_STMT_NODES if allow_self else ())):
+            raise ValueError(f"{what}: {type(node).__name__} is not allowed in reference text")
+
+
+def safe_compile(text, what):
+    """Expression text from the reference tree -> code object, after the whitelist."""
+    tree = ast.parse(text.strip(), what, "eval")
+    _check_tree(tree, what, allow_self=False)
+    return compile(tree, what, "eval")
 
 
 def safe_eval(code, env):
+    if isinstance(code, str):
+        code = safe_compile(code, "reference expression")
     return eval(code, dict(NO_BUILTINS, **env))
+
+
+def safe_exec_class(text, ns, what):
+    tree = ast.parse(text, what, "exec")
+    _check_tree(tree, what, allow_self=True)
+    exec(compile(tree, what, "exec"), ns)
+
+
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_arithmetic.json")
 
 
@@ -65,9 +118,9 @@ def realspace():
     found = [(n, e) for n, e in found if e.strip() not in ("0", "0, rr = 0")]
     assert [n for n, _ in found] == ["Imrr", "rr"] * 3, [n for n, _ in found]
     exprs = {"gt": (found[0][1], found[1][1]), "eq": (found[2][1], found[3][1]), "lt": (found[4][1], found[5][1])}
-    code = {k: tuple(compile(c_expr(e), f"Stokes.cc:{k}", "eval") for e in v) for k, v in exprs.items()}
+    code = {k: tuple(safe_compile(c_expr(e), f"Stokes.cc:{k}") for e in v) for k, v in exprs.items()}
     self_src = re.search(r"m_self\s*=\s*(.*?);", lines("PSEv1/Stokes.cc", 315, 320), flags=re.S).group(1)
-    self_code = compile(c_expr(self_src), "Stokes.cc:319", "eval")
+    self_code = safe_compile(c_expr(self_src), "Stokes.cc:319")
 
     def branch(r):
         return "gt" if r > 2.0 else ("eq" if r == 2.0 else "lt")
@@ -104,11 +157,11 @@ def parameter_rule():
     def rhs(name):
         m = re.search(r"(?:\b(?:Scalar|int|double)\s+)?" + re.escape(name) + r"\s*=\s*(.*?);", src, flags=re.S)
         assert m, name
-        return compile(c_expr(m.group(1)), "Stokes.cc:" + name, "eval")
+        return safe_compile(c_expr(m.group(1)), "Stokes.cc:" + name)
     e_cut, e_kmax, e_nx = rhs("m_ewald_cut"), rhs("kmax"), rhs("m_Nx")
     e_lambda, e_P, e_w, e_eta = rhs("lambda"), rhs("m_gaussP"), rhs("w"), rhs("m_eta")
     m = re.search(r"while\s*\((.*?)\)\s*\{\s*m_gaussm\s*=\s*(.*?);", src, flags=re.S)
-    e_while, e_step = compile(c_expr(m.group(1)), "while", "eval"), compile(c_expr(m.group(2)), "step", "eval")
+    e_while, e_step = safe_compile(c_expr(m.group(1)), "while"), safe_compile(c_expr(m.group(2)), "step")
     mlist = sorted({2 ** a * 3 ** b * 5 ** c for a in range(13) for b in range(8) for c in range(6)
                     if 8 <= 2 ** a * 3 ** b * 5 ** c <= 4096})     # the loop bounds of Stokes.cc:153-175
 
@@ -229,7 +282,7 @@ def shear_functions():
         f32log = (lambda x: float(np.log(np.float32(x)))) if not exact else math.log
         ns = dict(CLASS_BUILTINS, cos=math.cos, sin=math.sin, exp=math.exp, logf=f32log, log=math.log)
         for k in ("SinShearFunction", "SteadyShearFunction", "ChirpShearFunction", "TukeyWindowFunction", "WindowedFunction"):
-            exec(klass(k, exact), ns)
+            safe_exec_class(klass(k, exact), ns, "SpecificShearFunction.h:" + k)
         return ns
     dt = 1e-3
     cases = {

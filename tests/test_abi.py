@@ -88,3 +88,24 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.PSEError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_sanitizer_build_is_in_use():
+    """Under tools/asan.py (PSE_ASAN_DIR set) the libraries this suite exercises are the -fsanitize=address,undefined builds: the
+    product's host side over the device stub, and the checker.  Skipped in the ordinary run."""
+    import ctypes
+    d = os.environ.get("PSE_ASAN_DIR")
+    if not d:
+        pytest.skip("not the sanitizer run (python tools/asan.py)")
+    from pse_amd import _lib, _PSEv1
+    from oracle import pse_port
+    assert os.path.dirname(os.path.realpath(_lib.LIB_PATH)) == os.path.realpath(d)
+    assert os.path.dirname(os.path.realpath(_PSEv1.__file__)) == os.path.realpath(d)
+    assert os.path.realpath(pse_port.lib()._name).startswith(os.path.realpath(d))
+    lib = _lib.load()
+    with open("/proc/self/maps") as f:
+        maps = f.read()
+    assert "libasan" in maps and "libubsan" in maps
+    # a device entry point of the stub says what it is
+    assert lib.pse_set_timing(None, 1) != 0 and b"sanitizer build" in lib.pse_last_error()
+    assert isinstance(lib, ctypes.CDLL)

@@ -221,3 +221,34 @@ def test_loopback_team_follows_tilt_and_particle_count(world):
         for k in range(world):
             assert rel(vels[k].cpu().numpy()[:, :3], v_ref.cpu().numpy()[:, :3]) < 1e-10, (xy, n, k)
     team.close()
+
+
+def test_reteamed_engines_after_team_destroy():
+    """a team is destroyed and a new one is built from the same engines.  The first team's deterministic call ran the
+    far-field chain on member 0's shared side stream; the second team's Brownian call keeps it on the main stream -- the rocFFT
+    execution infos of members >= 1 must follow (pse_team_destroy rebinds them), or their transforms run unordered on a stale stream."""
+    import pse_amd
+    from pse_amd.engine import Team
+    n, world = 3000, 3
+    pos, force, box = make_suspension(n, phi=0.1, xy=0.1)
+    kw = dict(xi=0.5, error=1e-3, seed=9, grid=(48, 48, 40))
+    ref = pse_amd.Engine(n, box, **kw)
+    engines = [pse_amd.Engine(n, box, n_slabs=world, slab_rank=r, **kw) for r in range(world)]
+    P, F = [to4(pos) for _ in range(world)], [to4(force) for _ in range(world)]
+    V = [to4(np.zeros((n, 3))) for _ in range(world)]
+    u_ref = ref.mobility(to4(pos), to4(force)).cpu().numpy()[:, :3]
+    v_ref, m_ref = ref.brownian_velocity(to4(pos), to4(force), 1.0, 1e-3, 3)
+    for cycle in range(3):
+        team = Team(engines)
+        team.mobility(P, F, V)                                   # kT = 0: the wave chain forks onto the shared side stream
+        for r in range(world):
+            assert rel(V[r].cpu().numpy()[:, :3], u_ref) < 1e-12, (cycle, r)
+        team.close()
+        team = Team(engines[::-1] if cycle == 1 else engines)    # members in another order: another member 0 lends its stream
+        order = engines[::-1] if cycle == 1 else engines
+        _, m = team.brownian_velocity(P, F, V, 1.0, 1e-3, 3)
+        assert m == m_ref
+        for r in range(world):
+            assert rel(V[r].cpu().numpy()[:, :3], v_ref.cpu().numpy()[:, :3]) < 1e-11, (cycle, r)
+        team.close()
+        del order

@@ -73,6 +73,43 @@ def _worker(rank, world, port, mode, xy, out):
             pass
 
 
+def _run_ranks(procs, out, deadline_s=600):
+    """Start the rank processes and collect one result each.  A rank that dies without reporting fails the test at once (its exit
+    code is polled), and whatever happens no rank is left behind blocked in a collective while it holds the GPU."""
+    import queue
+    import time
+    for p in procs:
+        p.start()
+    res, t_end = [], time.time() + deadline_s
+    try:
+        while len(res) < len(procs):
+            try:
+                res.append(out.get(timeout=1.0))
+                continue
+            except queue.Empty:
+                pass
+            reported = {r for r, _ in res}
+            dead = [i for i, p in enumerate(procs) if p.exitcode not in (None, 0) and i not in reported]
+            if dead:
+                res += [(i, f"rank process exited with code {procs[i].exitcode} without a result") for i in dead]
+                break
+            if time.time() > t_end:
+                res.append((-1, "timed out waiting for the ranks"))
+                break
+        return res
+    finally:
+        for p in procs:
+            p.join(timeout=30 if len(res) >= len(procs) else 1)
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            if p.is_alive():
+                p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+
+
 @pytest.mark.parametrize("world,mode,xy", [(2, "", 0.0), (2, "slab", 0.2), (4, "", 0.25), (8, "", 0.0)])
 def test_team_of_processes_matches_single_gpu(world, mode, xy):
     import torch.multiprocessing as mp
@@ -80,11 +117,7 @@ def test_team_of_processes_matches_single_gpu(world, mode, xy):
     out = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, mode, xy, out)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [out.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(timeout=120)
+    res = _run_ranks(procs, out)
     assert sorted(res) == [(r, "ok") for r in range(world)], res
 
 
@@ -183,9 +216,5 @@ def test_random_team_of_processes(seed):
     out = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_random_worker, args=(r, seed, port, out)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [out.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(timeout=120)
+    res = _run_ranks(procs, out)
     assert sorted(res) == [(r, "ok") for r in range(world)], res

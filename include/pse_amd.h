@@ -67,6 +67,9 @@ typedef struct pse_info {
     double t_sort, t_spread, t_fft_fwd, t_scale, t_fft_inv, t_gather, t_real, t_lanczos, t_integrate, t_comm, t_total;
     unsigned long long device_bytes;  /* workspace owned by the handle */
     double t_matvec;                  /* one near-field mat-vec from the per-step pair list (inside t_lanczos) */
+    double t_records;                 /* binning + the 64-byte far-field particle records (t_spread is the spread kernel alone) */
+    int lanczos_exchanges;            /* team calls: exchanges the last Brownian call's Lanczos iteration issued (two iterations
+                                         per exchange where the decomposition allows: ceil(m / 2) instead of m) */
 } pse_info;
 
 /* -- life cycle: replaces Stokes::Stokes/setParams/~Stokes (PSEv1/Stokes.cc:85-118,129-424) ------------- */
@@ -199,6 +202,13 @@ int pse_team_brownian_velocity(pse_team *team, const pse_double4 *const *pos, co
 int pse_team_step(pse_team *team, pse_double4 *const *pos, pse_double4 *const *vel, pse_double3 *const *accel,
                   pse_int3 *const *image, const pse_double4 *const *net_force, const unsigned int *group_members,
                   unsigned int N, double kT, double dt, unsigned int timestep, double shear_rate, int *lanczos_m);
+
+/* Developer switch for an IN-PROCESS team (measurement, not a result): from now on the team queues the work of the one member
+ * with this slab rank only -- its kernels on both lanes and the copies that stand for what it receives; the other members'
+ * buffers keep what the last full call left there.  The wall time of a call is then that rank's critical path with a GPU to
+ * itself, lanes overlapping as they would (tools/perf_team.py --solo); the numbers it returns are not meaningful.  Call with the
+ * same positions as the last full call and do not integrate; slab_rank < 0 switches it off. */
+int pse_team_debug_solo(pse_team *team, int slab_rank);
 
 /* host-only: t = T^{1/2} e_1 of the Lanczos tridiagonal (alpha[0..m), beta[1..m)); replaces LAPACKE_spteqr +
  * the host loops at PSEv1/Brownian.cu:540-582. Exposed so the eigen-solver can be tested without a GPU. */

@@ -43,6 +43,8 @@ class pse_info(ctypes.Structure):
         ("t_comm", ctypes.c_double), ("t_total", ctypes.c_double),
         ("device_bytes", ctypes.c_ulonglong),
         ("t_matvec", ctypes.c_double),
+        ("t_records", ctypes.c_double),
+        ("lanczos_exchanges", ctypes.c_int),
     ]
 
     def as_dict(self):
@@ -90,6 +92,7 @@ SYMBOLS = {
     "pse_team_create": (_i, [ctypes.POINTER(_vp), _i, _vp, ctypes.POINTER(_vp)]),
     "pse_team_create_transport": (_i, [_vp, ctypes.POINTER(pse_transport), ctypes.POINTER(_vp)]),
     "pse_team_destroy": (_i, [_vp]),
+    "pse_team_debug_solo": (_i, [_vp, _i]),
     "pse_team_mobility": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _u, _i]),
     "pse_team_brownian_velocity": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _u, _d, _d, _u, _ip]),
     "pse_team_step": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),

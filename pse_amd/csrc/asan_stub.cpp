@@ -72,7 +72,6 @@ int pse_pair_repulsion(pse_handle *h, const pse_double4 *, pse_double4 *, const 
 int pse_set_stream(pse_handle *, void *) { return no_device("pse_set_stream"); }
 int pse_set_timing(pse_handle *, int) { return no_device("pse_set_timing"); }
 int pse_set_neighbor_skin(pse_handle *, double) { return no_device("pse_set_neighbor_skin"); }
-int pse_set_async(pse_handle *, int) { return no_device("pse_set_async"); }
 int pse_neighbor_stats(pse_handle *, double *, unsigned long long *, unsigned long long *) { return no_device("pse_neighbor_stats"); }
 int pse_mobility(pse_handle *, const pse_double4 *, const pse_double4 *, pse_double4 *, const unsigned int *, unsigned int, int) { return no_device("pse_mobility"); }
 int pse_brownian_velocity(pse_handle *, const pse_double4 *, const pse_double4 *, pse_double4 *, const unsigned int *, unsigned int, double,
@@ -87,6 +86,7 @@ int pse_team_unique_id(void *) { return no_device("pse_team_unique_id"); }
 int pse_team_create(pse_handle **, int, const void *, pse_team **) { return no_device("pse_team_create"); }
 int pse_team_create_transport(pse_handle *, const pse_transport *, pse_team **) { return no_device("pse_team_create_transport"); }
 int pse_team_destroy(pse_team *) { return 0; }
+int pse_team_debug_solo(pse_team *, int) { return no_device("pse_team_debug_solo"); }
 int pse_team_mobility(pse_team *, const pse_double4 *const *, const pse_double4 *const *, pse_double4 *const *, const unsigned int *, unsigned int, int) { return no_device("pse_team_mobility"); }
 int pse_team_brownian_velocity(pse_team *, const pse_double4 *const *, const pse_double4 *const *, pse_double4 *const *, const unsigned int *,
                                unsigned int, double, double, unsigned int, int *) { return no_device("pse_team_brownian_velocity"); }

@@ -77,7 +77,8 @@ struct pse_handle {
         int wave_mode = 0;        // PSE_WAVE_MODE: 0 automatic, 1 slab, 2 replicated
         int spread_tz = 0, spread_nw = 0;   // PSE_SPREAD_TZ, PSE_SPREAD_NW
         bool verbose = false;     // PSE_VERBOSE
-        bool team_overlap = false;   // PSE_TEAM_OVERLAP: process-per-rank teams run the far-field chain on a second communicator
+        bool team_sstep = true;      // PSE_TEAM_SSTEP=0: teams run one Lanczos iteration per exchange (default: two, see lanczos_team)
+        int team_sched[3] = {1, 2, 3};   // PSE_TEAM_SCHED=a,b,c: far-field exchange k of a team step is issued before Lanczos exchange sched[k]
     } tun;
     DCells bidx_nc = {0, 0, 0};      // cell grid the boundary-cell indices on the device belong to
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -134,6 +135,9 @@ struct pse_handle {
     double2 *sendbuf = nullptr, *recvbuf = nullptr;          // [3][n_slabs][nxl][nyl][Nzh] each
     int *d_bidx = nullptr, *d_bounds = nullptr;              // slab mode: cell indices / row offsets of the cell-slab boundaries
     std::vector<int> row_lo, first_end, last_begin;          // per rank: own rows [row_lo[r], row_lo[r+1]), first / last cell layer
+    std::vector<int> first2_end, last2_begin;                // ... and its first / last TWO cell layers (two-step Lanczos of a team)
+    double4 *w2_s = nullptr, *u_s = nullptr;                 // two-step Lanczos: w2 = M M v_j, u = M v_{j-1}
+    double2 *pv2 = nullptr;                                  // second set of packed (position, vector) records: holds w1 = M v_j
     double4 *utot_s = nullptr;                               // slab mode: summed velocity of the own rows, all-gathered
     bool xfuse = false;                                      // power-of-two Nx: fused x pass (k_xfft_scale)
     int grid_slabs = 1;   // slabs the far-field grid is cut into: n_slabs, or 1 when every rank keeps the whole grid
@@ -258,7 +262,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
     void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cell_cnt, h->sup_s, h->sw.rec_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->nb.data, h->nb.cnt, h->vl.idx, h->vl.cnt, h->vl.flags, h->pos_build, h->pos_s, h->posf_s, h->pv,
-                    h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->twiddle, h->fft_work, h->V,
+                    h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->w2_s, h->u_s, h->pv2, h->twiddle, h->fft_work, h->V,
                     h->scal, h->partials};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &p : h->ph) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
@@ -378,7 +382,11 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         if (const char *v = getenv("PSE_WAVE_MODE")) t.wave_mode = !strcmp(v, "slab") ? 1 : (!strcmp(v, "replicated") ? 2 : 0);
         t.spread_tz = ienv("PSE_SPREAD_TZ", 0); t.spread_nw = ienv("PSE_SPREAD_NW", 0);
         t.verbose = ienv("PSE_VERBOSE", 0) > 0;
-        t.team_overlap = ienv("PSE_TEAM_OVERLAP", 0) > 0;
+        t.team_sstep = ienv("PSE_TEAM_SSTEP", 1) > 0;
+        if (const char *v = getenv("PSE_TEAM_SCHED")) {
+            int a = 1, b = 2, c = 3;
+            if (sscanf(v, "%d,%d,%d", &a, &b, &c) == 3) { t.team_sched[0] = a; t.team_sched[1] = b; t.team_sched[2] = c; }
+        }
         h->sw.force_tz = t.spread_tz; h->sw.force_nw = t.spread_nw;
     }
     {
@@ -468,7 +476,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         if (bytes > 32e9 || n >= ((size_t)1 << 27)) cap = 0;   // too large: mat-vecs always walk the cells
         h->nb.cap = cap;
         if (cap > 0) {
-            TRY(dmalloc(h, &h->nb.data, nb_list_bytes(n + 64, cap)));   // + one wave: rows are blocked from the rank's first row
+            TRY(dmalloc(h, &h->nb.data, nb_list_bytes(n + 1024, cap)));   // + the padding of up to three row ranges to whole workgroups (RowMap)
         }
         if (cap == 0) h->skin = h->skin_max = 0.0;
         if (h->skin_max > 0.0) {
@@ -492,10 +500,13 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     TRY(dmalloc(h, &h->cgrid, 3 * ncx));
     if (h->grid_slabs > 1) { TRY(dmalloc(h, &h->sendbuf, 3 * ncx)); TRY(dmalloc(h, &h->recvbuf, 3 * ncx)); }
     if (h->n_slabs > 1) {
-        HIPCHK(hipHostMalloc((void **)&h->bounds_host, ((size_t)3 * h->n_slabs + 1) * sizeof(int), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&h->bounds_host, ((size_t)5 * h->n_slabs + 1) * sizeof(int), hipHostMallocDefault));
         HIPCHK(hipEventCreateWithFlags(&h->ev_bounds, hipEventDisableTiming));
-        TRY(dmalloc(h, &h->d_bidx, (size_t)3 * h->n_slabs + 1)); TRY(dmalloc(h, &h->d_bounds, (size_t)3 * h->n_slabs + 1));
+        TRY(dmalloc(h, &h->d_bidx, (size_t)5 * h->n_slabs + 1)); TRY(dmalloc(h, &h->d_bounds, (size_t)5 * h->n_slabs + 1));
         TRY(dmalloc(h, &h->utot_s, n));
+        if (h->tun.team_sstep && h->nb.cap > 0) {
+            TRY(dmalloc(h, &h->w2_s, n)); TRY(dmalloc(h, &h->u_s, n)); TRY(dmalloc(h, &h->pv2, 3 * n));
+        }
     }
     // The wave-space chain (spread -> FFTs -> gather) and the real-space chain (near field + Lanczos) only meet in the
     // final sum: on a single GPU they run on two streams, so latency-bound kernels of one chain fill the gaps of the
@@ -521,8 +532,8 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     HIPCHK(hipHostMalloc((void **)&h->sc_host, LZ_NSCAL * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipEventCreateWithFlags(&h->ev_scal, hipEventDisableTiming)); 
     if (!h->partials) {
-        h->npart_cap = std::max(LZ_NPART, mreal_partials_needed((int)n));
-        TRY(dmalloc(h, &h->partials, (size_t)3 * h->npart_cap));
+        h->npart_cap = std::max(LZ_NPART, mreal_partials_needed((int)n + 1024));   // + the padding of the row ranges (RowMap)
+        TRY(dmalloc(h, &h->partials, (size_t)LZ_NGRAM * h->npart_cap));
     }
     for (auto &ph : h->ph) { HIPCHK(hipEventCreate(&ph.a)); HIPCHK(hipEventCreate(&ph.b)); }
     h->info.device_bytes = h->bytes;
@@ -628,15 +639,27 @@ extern "C" int pse_get_info(pse_handle *h, pse_info *info) {
 struct pse_team {
     std::vector<pse_handle *> m;
     int G = 1;                   // ranks in the decomposition
-    ncclComm_t nccl = nullptr;   // set when members.size() == 1 and G > 1: near field, Lanczos, final exchange (main stream)
-    ncclComm_t nccl_w = nullptr; // its split: the far-field chain (all-to-alls, gather halo) on the side stream, concurrently
+    ncclComm_t nccl = nullptr;   // set when members.size() == 1 and G > 1: ONE communicator for every exchange of the team
+    // ... and ONE stream all its RCCL calls are issued on, in program order -- the same order on every rank (SPMD code, host-side
+    // decisions taken from identical all-reduced numbers).  The two compute lanes (main: sort, near field, Lanczos, update; side:
+    // the far-field chain) hand their buffers to it and take them back through events, so the lanes overlap while no two
+    // collectives of one communicator are ever in flight in an order that could differ between ranks.
+    hipStream_t comm = nullptr;
+    std::vector<hipEvent_t> evs; // ring of events for those hand-overs
+    size_t ev_next = 0;
     pse_transport cb = {};       // or: a transport supplied by the host program (host-staged; pse_team_create_transport)
     bool has_cb = false;
     double *stage = nullptr;     // pinned staging of the callback transport
     size_t stage_n = 0;
     double *scratch = nullptr;   // loopback all-reduce scratch
     size_t scratch_n = 0;
+    // developer switch (pse_team_debug_solo): an in-process team queues the work of ONE member only -- its kernels on both lanes,
+    // the copies that stand for what it receives -- so that the wall time of a call is that rank's critical path on a GPU of its
+    // own (the other members' buffers keep what the last full call left there: the numbers are not meaningful, the timing is)
+    int solo = -1;
+    std::vector<pse_handle *> solo_m;
 };
+static const std::vector<pse_handle *> &act(const pse_team &T) { return T.solo >= 0 ? T.solo_m : T.m; }
 #define NCCLCHK(x)                                                                                              \
     do {                                                                                                        \
         ncclResult_t r_ = (x);                                                                                  \
@@ -645,8 +668,7 @@ struct pse_team {
 
 static bool loopback(const pse_team &T) { return T.G > 1 && !T.nccl && !T.has_cb; }
 static bool remote(const pse_team &T) { return T.nccl || T.has_cb; }   // one member per process
-// communicator of the far-field chain: the split one when it exists (then the chain runs on the side stream), else the main one
-static ncclComm_t wave_comm(const pse_team &T) { return T.nccl_w ? T.nccl_w : T.nccl; }
+static hipEvent_t team_event(pse_team &T) { hipEvent_t e = T.evs[T.ev_next]; T.ev_next = (T.ev_next + 1) % T.evs.size(); return e; }
 
 // One exchange of a process-per-rank team: a list of point-to-point transfers (counts in doubles; 0 = none) and, optionally, a
 // sum over all ranks -- ONE RCCL group, or one call of the host program's transport.  Every exchange of the team goes through
@@ -671,19 +693,28 @@ static int team_exchange(pse_team &T, const std::vector<Xfer> &ops, bool wave_la
             HIPCHK(hipMemcpyAsync(self_recv[q]->recv, self_send[q]->send, self_send[q]->ns * sizeof(double), hipMemcpyDeviceToDevice, s));
     }
     if (T.nccl) {
-        ncclComm_t comm = wave_lane ? wave_comm(T) : T.nccl;
+        ncclComm_t comm = T.nccl;
         // the sum travels as its own collective unless PSE_TEAM_FUSED_GROUP=1 puts it into the group of the transfers (one launch
-        // less per Lanczos iteration; a collective and point-to-point calls in one group have never run here: ADVICE r2)
+        // less per Lanczos exchange; a collective and point-to-point calls in one group have never run here: ADVICE r2)
         const bool fused = h->tun.team_fused_group;
-        if (sum_n && !fused) NCCLCHK(ncclAllReduce(sum_buf, sum_buf, sum_n, ncclDouble, ncclSum, comm, s));
-        bool any = sum_n && fused;
+        bool any = sum_n != 0;
         for (const Xfer &x : ops) any = any || (x.ns && x.to != me) || (x.nr && x.from != me);
         if (!any) return 0;
-        NCCLCHK(ncclGroupStart());
-        if (sum_n && fused) NCCLCHK(ncclAllReduce(sum_buf, sum_buf, sum_n, ncclDouble, ncclSum, comm, s));
-        for (const Xfer &x : ops) if (x.ns && x.to != me) NCCLCHK(ncclSend(x.send, x.ns, ncclDouble, x.to, comm, s));
-        for (const Xfer &x : ops) if (x.nr && x.from != me) NCCLCHK(ncclRecv(x.recv, x.nr, ncclDouble, x.from, comm, s));
-        NCCLCHK(ncclGroupEnd());
+        // hand-over lane -> communication stream (what the lane has queued so far produces the buffers) ...
+        hipStream_t cs = T.comm ? T.comm : s;
+        if (T.comm) { hipEvent_t e = team_event(T); HIPCHK(hipEventRecord(e, s)); HIPCHK(hipStreamWaitEvent(T.comm, e, 0)); }
+        if (sum_n && !fused) NCCLCHK(ncclAllReduce(sum_buf, sum_buf, sum_n, ncclDouble, ncclSum, comm, cs));
+        bool grp = sum_n && fused;
+        for (const Xfer &x : ops) grp = grp || (x.ns && x.to != me) || (x.nr && x.from != me);
+        if (grp) {
+            NCCLCHK(ncclGroupStart());
+            if (sum_n && fused) NCCLCHK(ncclAllReduce(sum_buf, sum_buf, sum_n, ncclDouble, ncclSum, comm, cs));
+            for (const Xfer &x : ops) if (x.ns && x.to != me) NCCLCHK(ncclSend(x.send, x.ns, ncclDouble, x.to, comm, cs));
+            for (const Xfer &x : ops) if (x.nr && x.from != me) NCCLCHK(ncclRecv(x.recv, x.nr, ncclDouble, x.from, comm, cs));
+            NCCLCHK(ncclGroupEnd());
+        }
+        // ... and back: the lane goes on when the exchange has completed
+        if (T.comm) { hipEvent_t e = team_event(T); HIPCHK(hipEventRecord(e, T.comm)); HIPCHK(hipStreamWaitEvent(s, e, 0)); }
         return 0;
     }
     // host-staged transport: device -> pinned host, the host program moves the bytes, pinned host -> device
@@ -721,6 +752,24 @@ static int team_exchange(pse_team &T, const std::vector<Xfer> &ops, bool wave_la
     return 0;
 }
 
+// the device copies of an in-process exchange, batched into as few launches as the argument space allows
+struct CopyBatch {
+    CopyList l{};
+    hipStream_t s;
+    explicit CopyBatch(hipStream_t st) : s(st) { l.n = 0; }
+    void add(double *dst, const double *src, size_t n) {
+        if (!n || dst == src) return;
+        while (n) {   // counts are 32-bit
+            const size_t c = std::min<size_t>(n, 0x40000000u);
+            l.src[l.n] = src; l.dst[l.n] = dst; l.cnt[l.n] = (unsigned)c;
+            if (++l.n == 40) flush();
+            src += c; dst += c; n -= c;
+        }
+    }
+    void flush() { if (l.n) launch_copy_list(l, s); l.n = 0; }
+    ~CopyBatch() { flush(); }
+};
+
 // all-to-all of equal blocks, nset sets at once (one group): member r sends block q of set c of send(r) to rank q,
 // which stores it as block r of set c of recv(q); sets are set_stride doubles apart
 template <class FS, class FR>
@@ -735,27 +784,22 @@ static int team_all_to_all(pse_team &T, FS send, FR recv, size_t blk_doubles, in
                                    recv(h) + c * set_stride + (size_t)q * blk_doubles, blk_doubles, q});
         return team_exchange(T, ops, true);
     }
+    CopyBatch cb(act(T)[0]->wstream);   // an in-process team shares one stream per lane
     for (int c = 0; c < nset; ++c)
         for (pse_handle *src : T.m)
-            for (pse_handle *dst : T.m)
-                HIPCHK(hipMemcpyAsync(recv(dst) + c * set_stride + (size_t)src->slab_rank * blk_doubles,
-                                      send(src) + c * set_stride + (size_t)dst->slab_rank * blk_doubles,
-                                      blk_doubles * sizeof(double), hipMemcpyDeviceToDevice, dst->wstream));
+            for (pse_handle *dst : act(T))
+                cb.add(recv(dst) + c * set_stride + (size_t)src->slab_rank * blk_doubles,
+                       send(src) + c * set_stride + (size_t)dst->slab_rank * blk_doubles, blk_doubles);
     return 0;
 }
 template <class FB>
 static int team_all_reduce_sum(pse_team &T, FB buf, size_t n_doubles) {
     if (T.G == 1) return 0;
     if (remote(T)) return team_exchange(T, {}, false, buf(T.m[0]), n_doubles);
-    if (T.scratch_n < n_doubles) {
-        if (T.scratch) (void)hipFree(T.scratch);
-        HIPCHK(hipMalloc((void **)&T.scratch, n_doubles * sizeof(double)));
-        T.scratch_n = n_doubles;
-    }
-    hipStream_t s = T.m[0]->stream;
-    HIPCHK(hipMemsetAsync(T.scratch, 0, n_doubles * sizeof(double), s));
-    for (pse_handle *h : T.m) launch_add_inplace(T.scratch, buf(h), n_doubles, s);   // rank order: deterministic
-    for (pse_handle *h : T.m) HIPCHK(hipMemcpyAsync(buf(h), T.scratch, n_doubles * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (T.G > 64) return fail(PSE_ERR_INVALID, "in-process teams hold at most 64 ranks");
+    SumList l{};
+    for (pse_handle *h : act(T)) { l.src[l.nsrc++] = buf(h); l.dst[l.ndst++] = buf(h); }   // rank order: deterministic
+    launch_sum_list(l, (int)n_doubles, T.m[0]->stream);
     return 0;
 }
 // gather halo: every rank stores copies of its left neighbour's last hl planes below its slab and of its right
@@ -778,57 +822,73 @@ static int team_halo_exchange(pse_team &T) {
         return team_exchange(T, ops, true);
     }
     auto member = [&](int r) { for (pse_handle *h : T.m) if (h->slab_rank == r) return h; return (pse_handle *)nullptr; };
-    for (pse_handle *dst : T.m) {
+    CopyBatch cb(act(T)[0]->wstream);
+    for (pse_handle *dst : act(T)) {
         const DGrid &G = dst->G;
         const size_t plane = (size_t)G.Ny * G.Nz;
         pse_handle *L = member((dst->slab_rank + T.G - 1) % T.G), *R = member((dst->slab_rank + 1) % T.G);
         for (int c = 0; c < 3; ++c) {
-            HIPCHK(hipMemcpyAsync(comp(dst, c) + plane * (G.hl + G.nxl), comp(R, c) + plane * G.hl, plane * G.nhalo * sizeof(double),
-                                  hipMemcpyDeviceToDevice, dst->wstream));
-            HIPCHK(hipMemcpyAsync(comp(dst, c), comp(L, c) + plane * (G.hl + G.nxl - G.hl), plane * G.hl * sizeof(double),
-                                  hipMemcpyDeviceToDevice, dst->wstream));
+            cb.add(comp(dst, c) + plane * (G.hl + G.nxl), comp(R, c) + plane * G.hl, plane * G.nhalo);
+            cb.add(comp(dst, c), comp(L, c) + plane * (G.hl + G.nxl - G.hl), plane * G.hl);
         }
     }
     return 0;
 }
 
-// ghost rows of a distributed vector: every rank receives its right neighbour's first cell layer and its left
-// neighbour's last cell layer (the near-field mat-vec of the own rows reads exactly those besides the own rows)
-static std::vector<Xfer> ghost_ops(pse_team &T, double *buf) {
-    pse_handle *h = T.m[0];
-    const std::vector<int> &lo = h->row_lo, &fe = h->first_end, &lb = h->last_begin;
+// ghost rows of distributed vectors: for every buffer, a rank receives its right neighbour's first `depth` cell layers and its left
+// neighbour's last `depth` layers (the near-field mat-vec of the own rows reads one layer besides the own rows; the two-step
+// Lanczos block keeps two).  Row numbers are global, so a block lands at the position it was sent from.
+static std::vector<Xfer> ghost_ops(const pse_handle *h, int G, std::initializer_list<double *> bufs, int depth = 1) {
+    const std::vector<int> &lo = h->row_lo;
+    const std::vector<int> &fe = depth == 1 ? h->first_end : h->first2_end, &lb = depth == 1 ? h->last_begin : h->last2_begin;
     auto cnt = [](int a, int b) { return (size_t)std::max(0, b - a) * 4; };
-    const int r = h->slab_rank, L = (r + T.G - 1) % T.G, R = (r + 1) % T.G;
-    // my first layer goes left (the left neighbour's right ghost), my last layer goes right
-    return {Xfer{buf + (size_t)lo[r] * 4, cnt(lo[r], fe[r]), L, buf + (size_t)lo[R] * 4, cnt(lo[R], fe[R]), R},
-            Xfer{buf + (size_t)lb[r] * 4, cnt(lb[r], lo[r + 1]), R, buf + (size_t)lb[L] * 4, cnt(lb[L], lo[L + 1]), L}};
+    const int r = h->slab_rank, L = (r + G - 1) % G, R = (r + 1) % G;
+    std::vector<Xfer> ops;
+    for (double *buf : bufs) {
+        if (!buf) continue;
+        // my first layers go left (the left neighbour's right ghost), my last layers go right
+        ops.push_back(Xfer{buf + (size_t)lo[r] * 4, cnt(lo[r], fe[r]), L, buf + (size_t)lo[R] * 4, cnt(lo[R], fe[R]), R});
+        ops.push_back(Xfer{buf + (size_t)lb[r] * 4, cnt(lb[r], lo[r + 1]), R, buf + (size_t)lb[L] * 4, cnt(lb[L], lo[L + 1]), L});
+    }
+    return ops;
+}
+// An exchange given as one transfer list per rank (+ an optional sum over the ranks), in any of the three transports.  In-process
+// teams execute the receives as device copies: the k-th receive of dst from src pairs with the k-th send of src to dst -- the
+// matching rule of the message transports.
+template <class FOPS, class FSUM>
+static int team_run_exchange(pse_team &T, FOPS make_ops, bool wave_lane, FSUM sums, size_t sum_n) {
+    if (T.G == 1) return 0;
+    if (remote(T)) return team_exchange(T, make_ops(T.m[0]), wave_lane, sum_n ? sums(T.m[0]) : nullptr, sum_n);
+    if (sum_n) TRY(team_all_reduce_sum(T, sums, sum_n));
+    std::vector<std::vector<Xfer>> all(T.G);
+    for (pse_handle *h : T.m) all[h->slab_rank] = make_ops(h);
+    CopyBatch cb(wave_lane ? act(T)[0]->wstream : act(T)[0]->stream);
+    for (pse_handle *dst : act(T)) {
+        const int d = dst->slab_rank;
+        std::vector<size_t> taken(T.G, 0);   // sends of each source already paired with a receive of dst
+        for (const Xfer &rx : all[d]) {
+            if (!rx.nr) continue;
+            const std::vector<Xfer> &so = all[rx.from];
+            size_t &k = taken[rx.from];
+            while (k < so.size() && !(so[k].ns && so[k].to == d)) ++k;
+            if (k == so.size() || so[k].ns != rx.nr) return fail(PSE_ERR_COMM, "in-process exchange: unmatched transfer");
+            cb.add(rx.recv, so[k].send, rx.nr);
+            ++k;
+        }
+    }
+    return 0;
 }
 template <class FB>
 static int team_ghost_exchange(pse_team &T, FB buf) {
-    if (T.G == 1) return 0;
-    if (remote(T)) return team_exchange(T, ghost_ops(T, buf(T.m[0])), false);
-    pse_handle *h0 = T.m[0];
-    const std::vector<int> &lo = h0->row_lo, &fe = h0->first_end, &lb = h0->last_begin;
-    auto cnt = [](int a, int b) { return (size_t)std::max(0, b - a) * 4; };
-    auto member = [&](int r) { for (pse_handle *h : T.m) if (h->slab_rank == r) return h; return (pse_handle *)nullptr; };
-    for (pse_handle *dst : T.m) {
-        const int r = dst->slab_rank, L = (r + T.G - 1) % T.G, R = (r + 1) % T.G;
-        HIPCHK(hipMemcpyAsync(buf(dst) + (size_t)lo[R] * 4, buf(member(R)) + (size_t)lo[R] * 4, cnt(lo[R], fe[R]) * sizeof(double),
-                              hipMemcpyDeviceToDevice, dst->stream));
-        HIPCHK(hipMemcpyAsync(buf(dst) + (size_t)lb[L] * 4, buf(member(L)) + (size_t)lb[L] * 4, cnt(lb[L], lo[L + 1]) * sizeof(double),
-                              hipMemcpyDeviceToDevice, dst->stream));
-    }
-    return 0;
+    auto none = [](pse_handle *) { return (double *)nullptr; };
+    return team_run_exchange(T, [&](pse_handle *h) { return ghost_ops(h, T.G, {buf(h)}); }, false, none, 0);
 }
 
 // One exchange per Lanczos iteration: the three partial sums (all-reduce) and the ghost rows of y = M x (every rank receives its
 // right neighbour's first cell layer and its left neighbour's last one) travel in ONE group.
 template <class FS, class FB>
 static int team_lanczos_exchange(pse_team &T, FS sums, FB buf) {
-    if (T.G == 1) return 0;
-    if (remote(T)) return team_exchange(T, ghost_ops(T, buf(T.m[0])), false, sums(T.m[0]), 3);
-    TRY(team_all_reduce_sum(T, sums, 3));
-    return team_ghost_exchange(T, buf);
+    return team_run_exchange(T, [&](pse_handle *h) { return ghost_ops(h, T.G, {buf(h)}); }, false, sums, 3);
 }
 
 // every rank's own rows [row_lo[r], row_lo[r+1]) of buf become visible on every rank (blocks of different sizes)
@@ -846,12 +906,12 @@ static int team_all_gather_rows(pse_team &T, FB buf) {
                                    buf(h) + (size_t)lo[q] * 4, (size_t)(lo[q + 1] - lo[q]) * 4, q});
         return team_exchange(T, ops, false);
     }
+    CopyBatch cb(act(T)[0]->stream);
     for (pse_handle *src : T.m)
-        for (pse_handle *dst : T.m)
+        for (pse_handle *dst : act(T))
             if (src != dst) {
                 const int r = src->slab_rank;
-                HIPCHK(hipMemcpyAsync(buf(dst) + (size_t)lo[r] * 4, buf(src) + (size_t)lo[r] * 4,
-                                      (size_t)(lo[r + 1] - lo[r]) * 4 * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+                cb.add(buf(dst) + (size_t)lo[r] * 4, buf(src) + (size_t)lo[r] * 4, (size_t)(lo[r + 1] - lo[r]) * 4);
             }
     return 0;
 }
@@ -877,9 +937,14 @@ static int slab_bounds_issue(pse_handle *h) {
     const int G = h->n_slabs;
     if (G == 1) return 0;
     const int layer = h->nc.nzb * h->nc.ny * h->nc.bz, per = h->nc.nx / G;   // storage cells of one x layer
-    std::vector<int> idx(3 * G + 1);
+    std::vector<int> idx(5 * G + 1);
     for (int r = 0; r <= G; ++r) idx[r] = r * per * layer;
-    for (int r = 0; r < G; ++r) { idx[G + 1 + r] = (r * per + 1) * layer; idx[2 * G + 1 + r] = ((r + 1) * per - 1) * layer; }
+    for (int r = 0; r < G; ++r) {
+        idx[G + 1 + r] = (r * per + 1) * layer;                       // end of the first layer, begin of the last
+        idx[2 * G + 1 + r] = ((r + 1) * per - 1) * layer;
+        idx[3 * G + 1 + r] = (r * per + std::min(2, per)) * layer;    // ... of the first / last two layers
+        idx[4 * G + 1 + r] = ((r + 1) * per - std::min(2, per)) * layer;
+    }
     if (h->bidx_nc.nx != h->nc.nx || h->bidx_nc.ny != h->nc.ny || h->bidx_nc.nz != h->nc.nz) {   // once per cell grid
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipMemcpy(h->d_bidx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -900,8 +965,18 @@ static int slab_bounds_wait(pse_handle *h, int N) {
     h->row_lo.assign(out, out + G + 1);
     h->first_end.assign(out + G + 1, out + 2 * G + 1);
     h->last_begin.assign(out + 2 * G + 1, out + 3 * G + 1);
+    h->first2_end.assign(out + 3 * G + 1, out + 4 * G + 1);
+    h->last2_begin.assign(out + 4 * G + 1, out + 5 * G + 1);
     if (h->row_lo[0] != 0 || h->row_lo[G] != N) return fail(PSE_ERR_NUMERIC, "inconsistent cell offsets after the sort");
     return 0;
+}
+
+// Two Lanczos iterations per exchange (lanczos_team): needs the pair list, the table in LDS (the pass that builds the list then
+// delivers M psi with it), at least two cell layers per rank and two ghost layers on either side that are not the rank's own.
+static bool team_sstep(const pse_handle *h) {
+    const int G = h->n_slabs, per = h->nc.nx / std::max(1, G);
+    return G > 1 && h->tun.team_sstep && h->w2_s && h->nb.cap > 0 && mreal_table_in_lds(h->n_intervals * 2 * RS_NCOEF) && per >= 2 &&
+           h->nc.nx >= per + 4;
 }
 
 // What a slab rank orders, gathers into cell order and keeps particle data for: its own cell layers and one ghost layer on either
@@ -913,9 +988,10 @@ static CellRanges slab_need(const pse_handle *h) {
     const int G = h->n_slabs, nx = h->nc.nx;
     if (G == 1 || h->grid_slabs == 1) return r;
     const int per = nx / G, layer = h->nc.nzb * h->nc.ny * h->nc.bz;
-    if (per + 2 >= nx) return r;
+    const int depth = team_sstep(h) ? 2 : 1;   // ghost layers kept on either side
+    if (per + 2 * depth >= nx) return r;
     if ((h->G.P / 2 + 1.0) / h->G.Nx > 1.0 / nx) return r;
-    const int start = ((h->slab_rank * per - 1) % nx + nx) % nx, len = per + 2;
+    const int start = ((h->slab_rank * per - depth) % nx + nx) % nx, len = per + 2 * depth;
     if (start + len <= nx) { r.n = 1; r.c0[0] = start * layer; r.c1[0] = (start + len) * layer; }
     else { r.n = 2; r.c0[0] = start * layer; r.c1[0] = nx * layer; r.c0[1] = 0; r.c1[1] = (start + len - nx) * layer; }
     return r;
@@ -978,10 +1054,21 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
         return fail(PSE_ERR_INVALID, "cell grid %d x %d x %d exceeds the capacity sized at creation", h->nc.nx, h->nc.ny, h->nc.nz);
     const CellRanges need = slab_need(h);
     h->sw.need = need; h->sw.cell_off = h->cell_off;
+    SlabBook sb{};
+    if (need.n > 0 && h->n_slabs <= 64) {   // where the particles of the layers this rank does not keep are counted (cell_sort)
+        auto kept = [&](int c) { for (int q = 0; q < need.n; ++q) if (c >= need.c0[q] && c < need.c1[q]) return true; return false; };
+        const int layer = h->nc.nzb * h->nc.ny * h->nc.bz, per = h->nc.nx / h->n_slabs;
+        sb.n = h->n_slabs; sb.cells_per_slab = per * layer; sb.spread = std::max(1, std::min(1024, layer));
+        for (int q = 0; q < h->n_slabs; ++q) {
+            sb.book[q] = q * per * layer;   // (a slab kept whole has no foreign particles: never used)
+            for (int l = 0; l < per; ++l)
+                if (!kept((q * per + l) * layer)) { sb.book[q] = (q * per + l) * layer; break; }
+        }
+    }
     HIPCHK(cell_sort(pos, group, N, h->dbox, h->nc, h->keys, h->vals, h->keys_s, h->cell_cnt, ncell, h->sort_tmp, h->sort_tmp_bytes,
-                     h->cell_off, h->perm, h->stream, need));
+                     h->cell_off, h->perm, h->stream, need, sb));
     launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream, nullptr, 0.0, nullptr,
-                   need, h->cell_off);
+                   need, h->cell_off, team_sstep(h) ? h->pv2 : nullptr);
     h->sorted_N = N;
     if (with_list) {   // the first cell pass of this call writes the list (real())
         HIPCHK(hipMemsetAsync(h->vl.flags, 0, 2 * sizeof(int), h->stream));
@@ -1006,110 +1093,169 @@ static ScaleArgs scale_args(pse_handle *h, bool noise, double kT, double dt, uns
     return a;
 }
 
-// wave-space part: spread -> FFT -> scale (+ noise) -> inverse FFT -> gather  (PSEv1/Brownian.cu:836-872)
-static int wave(pse_team &T, int N, bool noise, double kT, double dt, unsigned timestep) {
+// wave-space part: spread -> FFT -> scale (+ noise) -> inverse FFT -> gather  (PSEv1/Brownian.cu:836-872), cut where a
+// slab-decomposed team exchanges data: compute part k, exchange k, compute part k + 1, ...
+//   part 0  records, spread, 2-D forward transforms (+ pack)         exchange 0  all-to-all (y rows of every x plane -> their rank)
+//   part 1  x transforms + k-space scaling (+ noise)                 exchange 1  all-to-all back
+//   part 2  (unpack +) 2-D inverse transforms                        exchange 2  plane halo of the gather
+//   part 3  gather
+// A single GPU, or a team that keeps the whole grid on every rank, has no exchanges: the parts simply follow one another.
+struct WaveArgs { int N; bool noise; double kT, dt; unsigned timestep; };
+static int wave_compute(pse_team &T, const WaveArgs &a, int part) {
     const int GS = T.m[0]->grid_slabs;   // 1: every rank transforms the whole grid (single GPU, or a team that replicates it)
-    for (pse_handle *h : T.m) {
+    for (pse_handle *h : act(T)) {
         const DGrid &G = h->G;
         const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzp;
-        double *gx = h->rgrid, *gy = h->rgrid + nr, *gz = h->rgrid + 2 * nr;
-        TRY(tsw(h, PH_SPREAD));
-        if (spread_needs_zero(G)) HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->wstream));
-        HIPCHK(launch_spread(h->pos_s, h->f_s, h->sup_s, N, gx, gy, gz, G, h->dbox, h->sw, h->wstream));
-        TRY(tew(h, PH_SPREAD));
-        TRY(tsw(h, PH_FFTF));
-        if (GS == 1) {
-            void *in[1] = {h->rgrid}, *out[1] = {h->cgrid};
-            FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
-        } else {
-            for (int c = 0; c < 3; ++c) {   // 2-D (y,z) transforms of the local planes, one component at a time
-                void *in[1] = {h->rgrid + c * nr + (size_t)G.hl * G.Ny * G.Nz}, *out[1] = {h->cgrid + c * ncx};
+        if (part == 0) {
+            double *gx = h->rgrid, *gy = h->rgrid + nr, *gz = h->rgrid + 2 * nr;
+            TRY(tsw(h, PH_SPREAD));
+            if (spread_needs_zero(G)) HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->wstream));
+            HIPCHK(launch_spread(h->pos_s, h->f_s, h->sup_s, a.N, gx, gy, gz, G, h->dbox, h->sw, h->wstream));
+            TRY(tew(h, PH_SPREAD));
+            TRY(tsw(h, PH_FFTF));
+            if (GS == 1) {
+                void *in[1] = {h->rgrid}, *out[1] = {h->cgrid};
                 FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
+            } else {
+                for (int c = 0; c < 3; ++c) {   // 2-D (y,z) transforms of the local planes, one component at a time
+                    void *in[1] = {h->rgrid + c * nr + (size_t)G.hl * G.Ny * G.Nz}, *out[1] = {h->cgrid + c * ncx};
+                    FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
+                }
+                launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzp, h->nyl, 0, h->wstream);
             }
-            launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzp, h->nyl, 0, h->wstream);
-        }
-        TRY(tew(h, PH_FFTF));
-    }
-    if (GS > 1) {
-        for (pse_handle *h : T.m) TRY(tsw(h, PH_COMM));
-        pse_handle *h0 = T.m[0];
-        const size_t blk = (size_t)h0->G.nxl * h0->nyl * h0->G.Nzp * 2, comp = blk * GS;
-        TRY(team_all_to_all(T, [&](pse_handle *h) { return (double *)h->sendbuf; }, [&](pse_handle *h) { return (double *)h->recvbuf; },
-                            blk, 3, comp));
-        for (pse_handle *h : T.m) TRY(tew(h, PH_COMM));
-    }
-    for (pse_handle *h : T.m) {
-        const DGrid &G = h->G;
-        const size_t ncx = (size_t)G.nxl * G.Ny * G.Nzp;
-        double2 *sp = GS == 1 ? h->cgrid : h->recvbuf;   // [3][Nx][nyl][Nzh] after the transpose
-        TRY(tsw(h, PH_SCALE));
-        if (h->xfuse) {
-            launch_xfft_scale(sp, sp + ncx, sp + 2 * ncx, G, h->dbox, scale_args(h, noise, kT, dt, timestep), h->twiddle, h->wstream);
-        } else {
-            if (GS > 1)
-                for (int c = 0; c < 3; ++c) { void *io[1] = {sp + c * ncx}; FFTCHK(rocfft_execute(h->plan_x_fwd, io, nullptr, h->info_fwd)); }
-            launch_scale(sp, sp + ncx, sp + 2 * ncx, G, h->dbox, scale_args(h, noise, kT, dt, timestep), h->wstream);
-            if (GS > 1)
-                for (int c = 0; c < 3; ++c) { void *io[1] = {sp + c * ncx}; FFTCHK(rocfft_execute(h->plan_x_inv, io, nullptr, h->info_inv)); }
-        }
-        TRY(tew(h, PH_SCALE));
-    }
-    if (GS > 1) {
-        pse_handle *h0 = T.m[0];
-        const size_t blk = (size_t)h0->G.nxl * h0->nyl * h0->G.Nzp * 2, comp = blk * GS;
-        TRY(team_all_to_all(T, [&](pse_handle *h) { return (double *)h->recvbuf; }, [&](pse_handle *h) { return (double *)h->sendbuf; },
-                            blk, 3, comp));
-    }
-    for (pse_handle *h : T.m) {
-        const DGrid &G = h->G;
-        const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzp;
-        TRY(tsw(h, PH_FFTI));
-        if (GS == 1) {
-            void *in[1] = {h->cgrid}, *out[1] = {h->rgrid};
-            FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv));
-        } else {
-            launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzp, h->nyl, 1, h->wstream);
-            for (int c = 0; c < 3; ++c) {
-                void *in[1] = {h->cgrid + c * ncx}, *out[1] = {h->rgrid + c * nr + (size_t)G.hl * G.Ny * G.Nz};
+            TRY(tew(h, PH_FFTF));
+        } else if (part == 1) {
+            double2 *sp = GS == 1 ? h->cgrid : h->recvbuf;   // [3][Nx][nyl][Nzh] after the transpose
+            TRY(tsw(h, PH_SCALE));
+            const ScaleArgs sa = scale_args(h, a.noise, a.kT, a.dt, a.timestep);
+            if (h->xfuse) {
+                launch_xfft_scale(sp, sp + ncx, sp + 2 * ncx, G, h->dbox, sa, h->twiddle, h->wstream);
+            } else {
+                if (GS > 1)
+                    for (int c = 0; c < 3; ++c) { void *io[1] = {sp + c * ncx}; FFTCHK(rocfft_execute(h->plan_x_fwd, io, nullptr, h->info_fwd)); }
+                launch_scale(sp, sp + ncx, sp + 2 * ncx, G, h->dbox, sa, h->wstream);
+                if (GS > 1)
+                    for (int c = 0; c < 3; ++c) { void *io[1] = {sp + c * ncx}; FFTCHK(rocfft_execute(h->plan_x_inv, io, nullptr, h->info_inv)); }
+            }
+            TRY(tew(h, PH_SCALE));
+        } else if (part == 2) {
+            TRY(tsw(h, PH_FFTI));
+            if (GS == 1) {
+                void *in[1] = {h->cgrid}, *out[1] = {h->rgrid};
                 FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv));
+            } else {
+                launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzp, h->nyl, 1, h->wstream);
+                for (int c = 0; c < 3; ++c) {
+                    void *in[1] = {h->cgrid + c * ncx}, *out[1] = {h->rgrid + c * nr + (size_t)G.hl * G.Ny * G.Nz};
+                    FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv));
+                }
             }
+            TRY(tew(h, PH_FFTI));
+        } else {
+            TRY(tsw(h, PH_GATHER));
+            HIPCHK(launch_gather(h->pos_s, h->sw, a.N, h->rgrid, h->rgrid + nr, h->rgrid + 2 * nr, G, h->dbox, h->uw_s, h->wstream));
+            TRY(tew(h, PH_GATHER));
+            // every particle was gathered by the rank that owns its row (zeros elsewhere)
         }
-        TRY(tew(h, PH_FFTI));
     }
-    if (GS > 1) TRY(team_halo_exchange(T));
-    for (pse_handle *h : T.m) {
-        const DGrid &G = h->G;
-        const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz;
-        TRY(tsw(h, PH_GATHER));
-        HIPCHK(launch_gather(h->pos_s, h->sw, N, h->rgrid, h->rgrid + nr, h->rgrid + 2 * nr, G, h->dbox, h->uw_s, h->wstream));
-        TRY(tew(h, PH_GATHER));
-    }
-    // every particle was gathered by the rank that owns its row (zeros elsewhere)
     return 0;
 }
+static int wave_exchange(pse_team &T, int k) {
+    pse_handle *h0 = T.m[0];
+    if (h0->grid_slabs == 1) return 0;
+    const size_t blk = (size_t)h0->G.nxl * h0->nyl * h0->G.Nzp * 2, comp = blk * h0->grid_slabs;
+    if (k == 0) {
+        for (pse_handle *h : act(T)) TRY(tsw(h, PH_COMM));
+        TRY(team_all_to_all(T, [&](pse_handle *h) { return (double *)h->sendbuf; }, [&](pse_handle *h) { return (double *)h->recvbuf; }, blk, 3, comp));
+        for (pse_handle *h : act(T)) TRY(tew(h, PH_COMM));
+        return 0;
+    }
+    if (k == 1)
+        return team_all_to_all(T, [&](pse_handle *h) { return (double *)h->recvbuf; }, [&](pse_handle *h) { return (double *)h->sendbuf; }, blk, 3, comp);
+    return team_halo_exchange(T);
+}
+// The far-field chain as the main lane's driver sees it: compute parts are queued as early as the data allows, exchange k of the
+// chain is ISSUED when the driver reaches its slot -- just before Lanczos exchange number slot[k] -- so that the order of the
+// collectives on the team's one communication stream is a fixed interleaving of the two lanes, the same on every rank.
+struct WavePump {
+    pse_team *T = nullptr;
+    WaveArgs a{};
+    int next = 4;                   // next compute part to queue (4: the chain is complete, or not part of this call)
+    int slot[3] = {0, 0, 0};
+    unsigned *mask = nullptr;
+    int start(pse_team &team, const WaveArgs &args, const int sched[3], unsigned *m) {
+        T = &team; a = args; mask = m;
+        for (int k = 0; k < 3; ++k) slot[k] = sched[k];
+        for (pse_handle *h : act(*T))
+            if (h->side_on) {   // fork: the wave chain starts once the sorted arrays exist
+                HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+                HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+            }
+        *mask |= (1u << PH_SPREAD) | (1u << PH_FFTF) | (1u << PH_SCALE) | (1u << PH_FFTI) | (1u << PH_GATHER);
+        if (T->m[0]->grid_slabs > 1) *mask |= 1u << PH_COMM;
+        TRY(wave_compute(*T, a, 0));
+        next = 1;
+        if (T->m[0]->grid_slabs == 1) return upto(1 << 30);   // no exchanges: the whole chain is queued at once
+        return 0;
+    }
+    // called before Lanczos exchange e is issued (and with a huge e to finish the chain)
+    int upto(int e) {
+        while (T && next <= 3 && slot[next - 1] <= e) {
+            TRY(wave_exchange(*T, next - 1));
+            TRY(wave_compute(*T, a, next));
+            ++next;
+        }
+        return 0;
+    }
+    int drain() { return upto(1 << 30); }
+};
 
-// near-field mat-vec out = M_real vec (PSEv1/Mobility.cu:594-687) on the rows this rank owns; vec must be valid on those
-// rows and on the neighbouring cell layers.  build_list: also record the pair list for later mat-vecs of this step.
+// rows of a rank with `depth` ghost cell layers on either side: its own rows first, then its left neighbour's last layers and its
+// right neighbour's first layers (duplicates dropped: with two ranks and one layer each, both ghosts are the same rows)
+static int row_ranges(const pse_handle *h, int N, int depth, int rg[3][2]) {
+    if (h->n_slabs == 1) { rg[0][0] = 0; rg[0][1] = N; return 1; }
+    const int G = h->n_slabs, r = h->slab_rank, L = (r + G - 1) % G, R = (r + 1) % G;
+    int n = 0;
+    auto add = [&](int a, int b) {
+        if (b <= a) return;
+        for (int q = 0; q < n; ++q) if (rg[q][0] == a && rg[q][1] == b) return;
+        rg[n][0] = a; rg[n][1] = b; ++n;
+    };
+    rg[0][0] = h->row_lo[r]; rg[0][1] = h->row_lo[r + 1]; n = 1;   // the own rows are range 0 even when empty (list rows start there)
+    if (depth >= 1) {
+        add((depth == 1 ? h->last_begin : h->last2_begin)[L], h->row_lo[L + 1]);
+        add(h->row_lo[R], (depth == 1 ? h->first_end : h->first2_end)[R]);
+    }
+    return n;
+}
+static RowMap rank_rows(const pse_handle *h, int N, int depth) {
+    int rg[3][2];
+    const int n = row_ranges(h, N, depth, rg);
+    return row_map(rg, n);
+}
+
+// near-field mat-vec out = M_real vec (PSEv1/Mobility.cu:594-687) on the rows this rank owns (+ `depth` ghost layers); vec must be
+// valid on those rows and on the cell layer beyond them.  build_list: also record the pair list for later mat-vecs of this step.
 static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*out, size_t vec_off, size_t out_off, int N,
-                bool build_list, bool with_psi = false) {
-    for (pse_handle *h : T.m) {
+                bool build_list, bool with_psi = false, int depth = 0) {
+    for (pse_handle *h : act(T)) {
         h->w_is_mpsi = false;
         int mode = MREAL_CELLS;
         if (h->nb.cap > 0) {
             if (h->nb_valid) mode = MREAL_USE_LIST;
             else if (build_list) mode = MREAL_BUILD_LIST;
         }
-        int lo, hi;
-        row_range(h, N, lo, hi);
         // the kept neighbour list: used when this call runs on it, written by the first cell pass after a sort
         int vlm = VL_NONE;
         if (h->vl_use) vlm = VL_USE;
         else if (h->vl_pending && mode != MREAL_USE_LIST) vlm = VL_WRITE;
         const double4 *v = h->*vec + vec_off;
-        launch_mreal(h->pos_s, h->posf_s, v, h->*out + out_off, lo, hi, h->cell_off, h->dbox, h->nc, h->d.rcut,
-                     h->d.self, h->coef, h->n_intervals * 2 * RS_NCOEF, h->nb, mode, h->stream,
-                     with_psi && mode == MREAL_BUILD_LIST ? h->psi_s : nullptr, h->w_s, h->vl, vlm,
-                     vlm == VL_USE && v == h->f_s && h->pv_is_f ? h->pv : nullptr);
+        const bool psi = with_psi && mode == MREAL_BUILD_LIST;
+        launch_mreal(h->pos_s, h->posf_s, v, h->*out + out_off, rank_rows(h, N, mode == MREAL_BUILD_LIST ? depth : 0), h->cell_off, h->dbox,
+                     h->nc, h->d.rcut, h->d.self, h->coef, h->n_intervals * 2 * RS_NCOEF, h->nb, mode, h->stream,
+                     psi ? h->psi_s : nullptr, h->w_s, h->vl, vlm,
+                     vlm == VL_USE && v == h->f_s && h->pv_is_f ? h->pv : nullptr,
+                     psi && depth > 0 ? h->pv2 : nullptr);   // two-step Lanczos: the next mat-vec gathers w = M psi from the second records
         if (vlm == VL_WRITE) {   // the list now matches perm, pos_s and the box of this call
             HIPCHK(hipMemcpyAsync(h->pos_build, h->pos_s, (size_t)N * sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
             h->vl_pending = false; h->vl_valid = true; h->vl_box = h->box;
@@ -1119,27 +1265,15 @@ static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*ou
     return 0;
 }
 
-// rows a rank updates in a Lanczos iteration: its own and the ghost layers its next mat-vec reads (the neighbours' nearest cell
-// layers; duplicates dropped: the update normalises in place)
-static int update_ranges(const pse_handle *h, int N, int rg[3][2]) {
-    if (h->n_slabs == 1) { rg[0][0] = 0; rg[0][1] = N; return 1; }
-    const int G = h->n_slabs, r = h->slab_rank, L = (r + G - 1) % G, R = (r + 1) % G;
-    int n = 0;
-    auto add = [&](int a, int b) {
-        if (b <= a) return;
-        for (int q = 0; q < n; ++q) if (rg[q][0] == a && rg[q][1] == b) return;
-        rg[n][0] = a; rg[n][1] = b; ++n;
-    };
-    add(h->row_lo[r], h->row_lo[r + 1]);
-    add(h->last_begin[L], h->row_lo[L + 1]);
-    add(h->row_lo[R], h->first_end[R]);
-    return n;
-}
+// rows a rank updates in a Lanczos iteration: its own and the ghost layers its next mat-vec reads
+static int update_ranges(const pse_handle *h, int N, int rg[3][2]) { return row_ranges(h, N, 1, rg); }
 
 // M_real^{1/2} psi by Lanczos (PSEv1/Brownian.cu:357-765): psi_s (sorted order, replicated on every rank) ->
 // ub_s = scale |psi| V t on the rows this rank owns.  Scalars are replicated; vectors are valid on the own rows (+ the
 // neighbouring cell layers for the vector the next mat-vec reads).
-static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, const std::function<int()> &before_first_wait = nullptr) {
+static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, const std::function<int()> &before_first_wait = nullptr,
+                   WavePump *pump = nullptr) {
+    int n_exchanges = 0;
     pse_handle *h0 = T.m[0];
     const size_t stride = h0->n_pad;
     int m_in = m_io ? *m_io : 2;
@@ -1159,15 +1293,15 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
             const bool fused = !have_y && h0->nb.cap > 0 && h0->nb_valid;   // sums fused into the pair-list mat-vec
             const bool timed = done == 1 && fused;               // one pair-list mat-vec kernel per call is timed on its own
             if (!fused && !have_y) TRY(real(T, done == 0 ? &pse_handle::psi_s : &pse_handle::V, &pse_handle::w_s, (size_t)done * stride, 0, N, true));
-            for (pse_handle *h : T.m) {
+            for (pse_handle *h : act(T)) {
                 int lo, hi;
                 row_range(h, N, lo, hi);
                 const double4 *xj = done == 0 ? h->psi_s : h->V + (size_t)done * stride;
                 const double4 *vjm1 = done > 1 ? h->V + (size_t)(done - 1) * stride : (done == 1 ? h->psi_s : nullptr);   // x_{j-1}, unnormalised
                 if (fused) {
                     const bool ev = timed && h->timing;
-                    launch_mreal_lanczos(h->pos_s, xj, h->w_s, lo, hi, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef,
-                                         h->nb, LzFuse{vjm1, h->partials, h->npart_cap}, h->scal,
+                    launch_mreal_lanczos(h->pos_s, xj, h->w_s, row_map(lo, hi), h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef,
+                                         h->nb, LzFuse{vjm1, h->partials, h->npart_cap, nullptr, nullptr, nullptr}, h->scal,
                                          ev ? h->ph[PH_MATVEC].a : nullptr, ev ? h->ph[PH_MATVEC].b : nullptr, h->stream,
                                          done > 0 ? h->pv : nullptr,   // x_j (j > 0) was packed by the previous update
                                          h->vl_use ? h->vl : VerletList{});
@@ -1179,12 +1313,14 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
             }
             // the partial sums and the ghost rows of y = M x_j in one exchange; every rank then updates its own rows AND its ghost
             // rows (it holds x_j and x_{j-1} there from the previous iteration), so x_{j+1} needs no exchange of its own
+            if (pump) TRY(pump->upto(n_exchanges));   // the far-field exchanges whose slot has come go first
+            ++n_exchanges;
             TRY(team_lanczos_exchange(T, [](pse_handle *h) { return h->scal + LZ_TMP; }, [](pse_handle *h) { return (double *)h->w_s; }));
             // The LAST iteration of a batch only derives its scalars (alpha_j, beta_j): whether x_{j+1} is needed at all is what the
             // check below decides -- in the steady state of a time-stepping loop (m_in = m) it is not, and the step saves one vector
             // pass and the reduction of |x_{j+1}| (0.04 ms at the metric point).  If the iteration goes on, the vector part follows.
             const bool scalars_only = done == target - 1;
-            for (pse_handle *h : T.m) {
+            for (pse_handle *h : act(T)) {
                 int rg[3][2];
                 const int nrg = scalars_only ? 0 : update_ranges(h, N, rg);
                 const double4 *xj = done == 0 ? h->psi_s : h->V + (size_t)done * stride;
@@ -1197,13 +1333,14 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
         HIPCHK(hipEventRecord(h0->ev_scal, h0->stream));
         if (!hook_done) {   // independent work queued behind the read-back keeps the GPU busy while the host decides
             hook_done = true;
-            for (pse_handle *h : T.m) TRY(te(h, PH_LANCZOS));
+            for (pse_handle *h : act(T)) TRY(te(h, PH_LANCZOS));
             if (before_first_wait) TRY(before_first_wait());
         }
         HIPCHK(hipEventSynchronize(h0->ev_scal));
+        if (T.solo >= 0) { m_final = done; t_cur.assign(m_final, 0.0); break; }   // timing only (pse_team_debug_solo)
         const double *alpha = &sc[LZ_ALPHA], *beta = &sc[LZ_BETA];   // alpha_0 .. alpha_{done-1}, beta_1 .. beta_{done-1}; beta_done not yet
         if (!(sc[LZ_NORM] > 0.0) || !std::isfinite(sc[LZ_NORM])) {   // psi == 0 -> result 0
-            for (pse_handle *h : T.m) {
+            for (pse_handle *h : act(T)) {
                 HIPCHK(hipMemsetAsync(h->ub_s, 0, (size_t)N * sizeof(double4), h->stream));
                 h->info.lanczos_m = 0; h->info.lanczos_matvecs = done; h->info.lanczos_stepnorm = 0.0;
             }
@@ -1234,7 +1371,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
         if (done >= M_MAX) { m_final = M_MAX; break; }
         // not converged: the vector part of the last iteration (its sums are still in place), then the next batch; an x_done that
         // vanishes (invariant subspace) shows in the first sums of that batch
-        for (pse_handle *h : T.m) {
+        for (pse_handle *h : act(T)) {
             int rg[3][2];
             const int nrg = update_ranges(h, N, rg);
             const int j = done - 1;
@@ -1250,13 +1387,138 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
         if (!lanczos_sqrt_e1(m_final, &sc[LZ_ALPHA], &sc[LZ_BETA], t_cur))
             return fail(PSE_ERR_NUMERIC, "tridiagonal eigen-solve failed at m = %d", m_final);
     }
-    for (pse_handle *h : T.m) {
+    for (pse_handle *h : act(T)) {
         BasisCoef tc{};   // the basis holds the unnormalised x_q: v_q = x_q / |x_q|, |x_0| = the norm of psi, |x_q| = beta_q
         for (int q = 0; q < m_final; ++q) tc.t[q] = t_cur[q] / (q == 0 ? sc[LZ_NORM] : sc[LZ_BETA + q]);
         int lo, hi;
         row_range(h, N, lo, hi);
         launch_basis_combine(h->psi_s, h->V, stride, tc, m_final, h->scal, scale, 1, h->ub_s, lo, hi, h->stream);   // Brownian.cu:716,739
         h->info.lanczos_m = m_final; h->info.lanczos_matvecs = done; h->info.lanczos_stepnorm = stepnorm;
+        h->info.lanczos_exchanges = T.G > 1 ? n_exchanges : 0;
+    }
+    if (m_io) *m_io = m_final;
+    return 0;
+}
+
+// M_real^{1/2} psi for a team, TWO Lanczos iterations per exchange (k_lz_block in pse_kernels.hip has the algebra).  Per block:
+// w1 = M v_j on the own rows + one ghost layer, w2 = M w1 on the own rows with the Gram sums fused in, ONE exchange (all-reduce
+// of the sums + two ghost layers of w1 and w2 to either neighbour), then every rank forms v_{j+1}, v_{j+2} and M v_{j+1} on its own
+// and its ghost rows.  An odd tail is a single step (scalars only unless the iteration goes on).  The alpha, beta the host checks
+// are the reference's (PSEv1/Brownian.cu:440-521) to rounding, so m is -- the tests hold it to the port's.  The first w1 = M psi
+// comes with the pass that built the pair list.  Exchanges per step at m = 7: 4 (one-step driver: 7).
+static int lanczos_team(pse_team &T, int N, double tol, double scale, int *m_io, const std::function<int()> &before_first_wait,
+                        WavePump *pump) {
+    pse_handle *h0 = T.m[0];
+    const size_t stride = h0->n_pad;
+    int m_in = m_io ? *m_io : 2;
+    m_in = std::min(std::max(m_in, 1), M_MAX);
+    std::vector<double> t_prev, t_cur;
+    double *sc = h0->sc_host;
+    int done = 0, target = std::max(m_in, 2), m_final = 0, checked = 0, n_exchanges = 0, matvecs = 0;
+    int half_pending = -1;                // j of a single step whose vectors have not been formed yet
+    double stepnorm = 1.0;
+    bool hook_done = false;
+    auto vec = [&](pse_handle *h, int q) { return q == 0 ? h->psi_s : h->V + (size_t)q * stride; };
+    auto block_args = [&](pse_handle *h, int j, bool full) {
+        LzBlockArgs a{};
+        a.q = vec(h, j); a.p = j > 0 ? vec(h, j - 1) : nullptr; a.w1 = h->w_s; a.w2 = full ? h->w2_s : nullptr;
+        a.u = h->u_s; a.v1 = h->V + (size_t)(j + 1) * stride; a.v2 = full ? h->V + (size_t)(j + 2) * stride : nullptr;
+        a.pv = h->pv; a.j = j;
+        return a;
+    };
+    while (true) {
+        while (done < target) {
+            if (half_pending >= 0) {      // the iteration goes on past a single step: its vector part (w1 is there on two ghost layers)
+                for (pse_handle *h : act(T)) {
+                    int rg[3][2];
+                    const int nrg = row_ranges(h, N, 2, rg);
+                    launch_lz_block(block_args(h, half_pending, false), false, h->scal, rg, nrg, h->stream);
+                }
+                half_pending = -1;
+            }
+            const int j = done;
+            const bool full = target - done >= 2 && j + 2 <= M_MAX;
+            for (pse_handle *h : act(T)) {
+                const LzFuse lz{nullptr, h->partials, h->npart_cap, vec(h, j), j > 0 ? vec(h, j - 1) : nullptr, j > 0 ? h->u_s : nullptr};
+                if (j == 0 && !h->w_is_mpsi) return fail(PSE_ERR_NUMERIC, "two-step Lanczos: M psi did not come with the pair list");
+                if (!(j == 0 && h->w_is_mpsi)) {   // w1 = M v_j: own rows + one ghost layer for a block, own rows for a single step
+                    launch_mreal_lanczos(h->pos_s, vec(h, j), h->w_s, rank_rows(h, N, full ? 1 : 0), h->cell_off, h->dbox, h->nc, h->d.rcut,
+                                         h->d.self, h->coef, h->nb, lz, h->scal, nullptr, nullptr, h->stream, h->pv, VerletList{},
+                                         full ? 0 : 3, full ? h->pv2 : nullptr);
+                    ++matvecs;
+                } else if (!full) {
+                    return fail(PSE_ERR_NUMERIC, "two-step Lanczos: a single step cannot start at j = 0");
+                }
+                h->w_is_mpsi = false;
+                if (full) {                        // w2 = M w1 on the own rows, Gram sums fused
+                    launch_mreal_lanczos(h->pos_s, h->w_s, h->w2_s, rank_rows(h, N, 0), h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self,
+                                         h->coef, h->nb, lz, h->scal, nullptr, nullptr, h->stream, h->pv2, VerletList{}, 2, nullptr);
+                    ++matvecs;
+                }
+            }
+            if (pump) TRY(pump->upto(n_exchanges));
+            ++n_exchanges;
+            TRY(team_run_exchange(T, [&](pse_handle *h) { return ghost_ops(h, T.G, {(double *)h->w_s, full ? (double *)h->w2_s : nullptr}, 2); },
+                                  false, [](pse_handle *h) { return h->scal + LZ_TMP; }, (size_t)LZ_NGRAM));
+            for (pse_handle *h : act(T)) {
+                int rg[3][2];
+                const int nrg = full ? row_ranges(h, N, 2, rg) : 0;   // a single step derives its scalars only, for now
+                launch_lz_block(block_args(h, j, full), full, h->scal, rg, nrg, h->stream);
+            }
+            if (full) done += 2; else { done += 1; half_pending = j; }
+        }
+        HIPCHK(hipMemcpyAsync(sc, h0->scal, LZ_NSCAL * sizeof(double), hipMemcpyDeviceToHost, h0->stream));
+        HIPCHK(hipEventRecord(h0->ev_scal, h0->stream));
+        if (!hook_done) {   // independent work queued behind the read-back keeps the GPU busy while the host decides
+            hook_done = true;
+            for (pse_handle *h : act(T)) TRY(te(h, PH_LANCZOS));
+            if (before_first_wait) TRY(before_first_wait());
+        }
+        HIPCHK(hipEventSynchronize(h0->ev_scal));
+        if (T.solo >= 0) { m_final = done; t_cur.assign(m_final, 0.0); break; }   // timing only (pse_team_debug_solo)
+        const double *alpha = &sc[LZ_ALPHA], *beta = &sc[LZ_BETA];   // alpha_0 .. alpha_{done-1}, beta_1 .. beta_done
+        if (!(sc[LZ_NORM] > 0.0) || !std::isfinite(sc[LZ_NORM])) {   // psi == 0 -> result 0
+            for (pse_handle *h : act(T)) {
+                HIPCHK(hipMemsetAsync(h->ub_s, 0, (size_t)N * sizeof(double4), h->stream));
+                h->info.lanczos_m = 0; h->info.lanczos_matvecs = matvecs; h->info.lanczos_stepnorm = 0.0;
+            }
+            if (m_io) *m_io = m_in;
+            return 0;
+        }
+        // walk m upward exactly as the reference's while loop does, one vector at a time
+        for (int m = std::max(checked + 1, std::max(m_in - 1, 1)); m <= done && !m_final; ++m) {
+            if (!std::isfinite(alpha[m - 1]) || !std::isfinite(beta[m]))
+                return fail(PSE_ERR_NUMERIC, "Lanczos produced a non-finite coefficient at iteration %d", m - 1);
+            if (!lanczos_sqrt_e1(m, alpha, beta, t_cur))
+                return fail(PSE_ERR_NUMERIC, "tridiagonal eigen-solve failed at m = %d", m);
+            if (m < done && beta[m] < 1e-8) { m_final = m; stepnorm = 0.0; break; }  // invariant subspace (Brownian.cu:503)
+            if (!t_prev.empty() && (int)t_prev.size() == m - 1) {
+                double s2 = t_cur[m - 1] * t_cur[m - 1];
+                for (int q = 0; q < m - 1; ++q) s2 += (t_cur[q] - t_prev[q]) * (t_cur[q] - t_prev[q]);
+                stepnorm = std::sqrt(s2 / alpha[0]);                               // Brownian.cu:719-724; psi.M.psi/|psi|^2 = alpha_0
+                if (stepnorm <= tol || m >= M_MAX) { m_final = m; break; }
+            }
+            if (m == done && beta[m] < 1e-8) { m_final = m; stepnorm = 0.0; break; }   // the one-step driver sees this with its next sums
+            t_prev = t_cur;
+            checked = m;
+        }
+        if (m_final) break;
+        if (done >= M_MAX) { m_final = M_MAX; break; }
+        target = std::min(M_MAX, done + std::max(2, done / 4));
+    }
+    if ((int)t_cur.size() != m_final) {
+        if (!lanczos_sqrt_e1(m_final, &sc[LZ_ALPHA], &sc[LZ_BETA], t_cur))
+            return fail(PSE_ERR_NUMERIC, "tridiagonal eigen-solve failed at m = %d", m_final);
+    }
+    if (half_pending >= 0 && m_final > half_pending + 1) return fail(PSE_ERR_NUMERIC, "two-step Lanczos: basis vector %d was never formed", half_pending + 1);
+    for (pse_handle *h : act(T)) {
+        BasisCoef tc{};   // the basis holds NORMALISED v_q here, except v_0 = psi / |psi|
+        for (int q = 0; q < m_final; ++q) tc.t[q] = q == 0 ? t_cur[q] / sc[LZ_NORM] : t_cur[q];
+        int lo, hi;
+        row_range(h, N, lo, hi);
+        launch_basis_combine(h->psi_s, h->V, stride, tc, m_final, h->scal, scale, 1, h->ub_s, lo, hi, h->stream);   // Brownian.cu:716,739
+        h->info.lanczos_m = m_final; h->info.lanczos_matvecs = matvecs; h->info.lanczos_stepnorm = stepnorm;
+        h->info.lanczos_exchanges = n_exchanges;
     }
     if (m_io) *m_io = m_final;
     return 0;
@@ -1267,19 +1529,26 @@ struct Args {
     const double4 *pos; const double4 *force; double4 *vel;
 };
 
+// what pse_step does after the velocity is known (K15 gpu_stokes_step_one_kernel, PSEv1/Stokes.cu:137-192): handed to velocity()
+// so that the final un-sort and the Euler update are one pass over the particles
+struct StepArgs {
+    double4 *pos; double4 *vel; double3 *accel; int3 *image; const double4 *force;
+};
+struct StepTail { const std::vector<StepArgs> *sa; double dt, shear_rate; };
+
 static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *group, int N, int parts, double kT, double dt,
-                    unsigned timestep, int *m_io, unsigned *mask) {
-    for (size_t r = 0; r < T.m.size(); ++r) TRY(prepare(T.m[r], a[r].pos, a[r].force, group, N, true));
+                    unsigned timestep, int *m_io, unsigned *mask, const StepTail *tail = nullptr) {
+    for (size_t r = 0; r < T.m.size(); ++r)
+        if (T.solo < 0 || T.m[r]->slab_rank == T.solo) TRY(prepare(T.m[r], a[r].pos, a[r].force, group, N, true));
     *mask |= 1u << PH_SORT;
     const bool noise = kT > 0.0;
-    // A process-per-rank team keeps ONE stream and ONE communicator unless PSE_TEAM_OVERLAP=1 was set at pse_create: two
-    // communicators on independent streams have no cross-rank launch order (the documented RCCL deadlock hazard when both
-    // kernels cannot make progress at once), and no multi-GPU node has run this path yet.
-    const bool lanes = T.G == 1 || loopback(T) || T.nccl_w;
-    for (pse_handle *h : T.m) {   // where the wave chain of this call runs
-        // the two chains share the chip whenever nothing is timed per kernel: with phase timing on, every kernel runs alone
-        // on one stream (those durations are the roofline evidence)
-        const bool on = h->side && lanes && parts == 3 && !h->timing && (h->overlap_all || !noise);
+    const bool sstep = T.G > 1 && noise && (parts & 1) && team_sstep(T.m[0]);   // two Lanczos iterations per exchange
+    for (pse_handle *h : act(T)) {   // where the wave chain of this call runs
+        // The two chains share the chip whenever nothing is timed per kernel (with phase timing on, every kernel runs alone on one
+        // stream: those durations are the roofline evidence).  A single GPU forks for deterministic evaluations only (Brownian
+        // steps gain nothing there); a TEAM always forks: at 1 / G of the rows no kernel fills the chip, and the
+        // far-field exchanges travel while the Lanczos iterations compute (one communicator, one communication stream: pse_team).
+        const bool on = h->side && parts == 3 && !h->timing && (h->overlap_all || !noise || T.G > 1);
         if (on != h->side_on || h->wstream != (on ? h->side : h->stream)) {
             h->side_on = on;
             h->wstream = on ? h->side : h->stream;
@@ -1287,46 +1556,45 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
             FFTCHK(rocfft_execution_info_set_stream(h->info_inv, h->wstream));
         }
     }
-    auto wave_chain = [&]() -> int {
-        for (pse_handle *h : T.m)
-            if (h->side_on) {   // fork: the wave chain starts once the sorted arrays exist
-                HIPCHK(hipEventRecord(h->ev_fork, h->stream));
-                HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-            }
-        TRY(wave(T, N, noise, kT, dt, timestep));
-        *mask |= (1u << PH_SPREAD) | (1u << PH_FFTF) | (1u << PH_SCALE) | (1u << PH_FFTI) | (1u << PH_GATHER);
-        if (T.m[0]->grid_slabs > 1) *mask |= 1u << PH_COMM;
-        return 0;
-    };
+    WavePump pump;
+    const WaveArgs wa{N, noise, kT, dt, timestep};
+    auto wave_start = [&]() -> int { return pump.start(T, wa, T.m[0]->tun.team_sched, mask); };
     // With noise on one stream the wave chain is queued BEHIND the Lanczos iterations: the host has to read their scalars
     // back before it can finish the Brownian part, and meanwhile the GPU works through the far field instead of idling.
     const bool wave_behind = noise && (parts & 2) && (parts & 1) && !T.m[0]->side_on;
-    if ((parts & 2) && !wave_behind) TRY(wave_chain());
-    // the slab row boundaries are needed from here on; the far-field chain is already queued
-    for (pse_handle *h : T.m) TRY(slab_bounds_wait(h, N));
+    if ((parts & 2) && !wave_behind) TRY(wave_start());
     if (noise)   // psi first: the near-field pass that builds the pair list applies M_real to F and to psi together
-        for (pse_handle *h : T.m) launch_psi(h->psi_s, h->tag_s, N, h->par.seed, timestep, h->stream, h->sw.need, h->cell_off);
+        for (pse_handle *h : act(T)) launch_psi(h->psi_s, h->tag_s, N, h->par.seed, timestep, h->stream, h->sw.need, h->cell_off);
+    // the slab row boundaries are needed from here on (a host round trip); the first part of the far-field chain and psi are queued
+    for (pse_handle *h : act(T)) TRY(slab_bounds_wait(h, N));
     if (parts & 1) {
-        for (pse_handle *h : T.m) TRY(ts(h, PH_REAL));
-        TRY(real(T, &pse_handle::f_s, &pse_handle::ur_s, 0, 0, N, noise, noise));
-        for (pse_handle *h : T.m) TRY(te(h, PH_REAL));
+        for (pse_handle *h : act(T)) TRY(ts(h, PH_REAL));
+        TRY(real(T, &pse_handle::f_s, &pse_handle::ur_s, 0, 0, N, noise, noise, sstep ? 1 : 0));
+        for (pse_handle *h : act(T)) TRY(te(h, PH_REAL));
         *mask |= 1u << PH_REAL;
     }
     if (noise) {
-        for (pse_handle *h : T.m) TRY(ts(h, PH_LANCZOS));   // closed inside lanczos(), after the first batch of iterations
-        for (pse_handle *h : T.m) h->matvec_timed = false;
-        TRY(lanczos(T, N, T.m[0]->d.error, std::sqrt(2.0 * kT / dt), m_io, wave_behind ? std::function<int()>(wave_chain) : nullptr));
+        for (pse_handle *h : act(T)) TRY(ts(h, PH_LANCZOS));   // closed inside the Lanczos driver, after the first batch of iterations
+        for (pse_handle *h : act(T)) h->matvec_timed = false;
+        const std::function<int()> hook = [&]() -> int {    // before the host first waits for the Lanczos scalars: everything else is queued
+            if (wave_behind) TRY(wave_start());
+            return pump.drain();
+        };
+        const double tol = T.m[0]->d.error, scale = std::sqrt(2.0 * kT / dt);
+        if (sstep) TRY(lanczos_team(T, N, tol, scale, m_io, hook, &pump));
+        else TRY(lanczos(T, N, tol, scale, m_io, hook, &pump));
         *mask |= 1u << PH_LANCZOS;
         if (T.m[0]->matvec_timed) *mask |= 1u << PH_MATVEC;
     }
+    TRY(pump.drain());   // (kT = 0: the exchanges of the far-field chain are issued here, one after the other)
     if (T.G > 1) {
         // every rank has all three contributions for the rows it owns: add them, exchange the row blocks once
-        for (pse_handle *h : T.m)
+        for (pse_handle *h : act(T))
             if ((parts & 2) && h->side_on) {   // join: the gathered far-field velocity is needed now
                 HIPCHK(hipEventRecord(h->ev_join, h->side));
                 HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
             }
-        for (pse_handle *h : T.m) {
+        for (pse_handle *h : act(T)) {
             int lo, hi;
             row_range(h, N, lo, hi);
             launch_sum_rows((parts & 2) ? h->uw_s : nullptr, (parts & 1) ? h->ur_s : nullptr, noise ? h->ub_s : nullptr,
@@ -1336,15 +1604,24 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
     }
     for (size_t r = 0; r < T.m.size(); ++r) {
         pse_handle *h = T.m[r];
+        if (T.solo >= 0 && h->slab_rank != T.solo) continue;
         if ((parts & 2) && h->side_on && T.G == 1) {   // join
             HIPCHK(hipEventRecord(h->ev_join, h->side));
             HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         }
-        if (T.G > 1)
-            launch_scatter_sum(h->utot_s, nullptr, nullptr, nullptr, N, a[r].vel, h->stream);
-        else
-            launch_scatter_sum((parts & 2) ? h->uw_s : nullptr, (parts & 1) ? h->ur_s : nullptr, noise ? h->ub_s : nullptr,
-                               h->tag_s, N, a[r].vel, h->stream);
+        const double4 *ua = T.G > 1 ? h->utot_s : ((parts & 2) ? h->uw_s : nullptr);
+        const double4 *ub = T.G > 1 ? nullptr : ((parts & 1) ? h->ur_s : nullptr), *uc = T.G > 1 ? nullptr : (noise ? h->ub_s : nullptr);
+        const unsigned *tags = T.G > 1 ? nullptr : h->tag_s;     // a team: the tag travels in the fourth component of its row
+        launch_scatter_sum(ua, ub, uc, tags, N, a[r].vel, h->stream);
+        if (tail) {
+            // The Euler update stays its own pass in the CALLER's order (replicated state: every rank updates every particle,
+            // bit-identically).  Fused into the un-sort it ran over the sorted rows and made five arrays scattered instead of
+            // one: 152 us against 29 + 35 per rank at the metric point (profiles/r04_team8_notes.txt).
+            const StepArgs &x = (*tail->sa)[r];
+            TRY(ts(h, PH_INTEG));
+            launch_integrate(x.pos, x.vel, x.accel, x.image, x.force, group, N, h->dbox, tail->dt, tail->shear_rate, h->stream);
+            TRY(te(h, PH_INTEG));
+        }
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -1361,30 +1638,27 @@ static int do_mobility(pse_team &T, const std::vector<Args> &a, const unsigned *
     for (auto &x : a) if (!x.pos || !x.force || !x.vel) return fail(PSE_ERR_INVALID, "null array");
     if (!(parts & 3)) return fail(PSE_ERR_INVALID, "parts must select real (1), wave (2) or both (3)");
     unsigned mask = 1u << PH_TOTAL;
-    for (pse_handle *h : T.m) TRY(ts(h, PH_TOTAL));
+    for (pse_handle *h : act(T)) TRY(ts(h, PH_TOTAL));
     TRY(velocity(T, a, group, (int)N, parts, 0.0, 1.0, 0, nullptr, &mask));
-    for (pse_handle *h : T.m) { TRY(te(h, PH_TOTAL)); TRY(collect_times(h, mask)); }
+    for (pse_handle *h : act(T)) { TRY(te(h, PH_TOTAL)); TRY(collect_times(h, mask)); }
     return 0;
 }
 
 static int do_brownian(pse_team &T, const std::vector<Args> &a, const unsigned *group, unsigned N, double kT, double dt,
                        unsigned timestep, int *lanczos_m) {
-    for (pse_handle *h : T.m) TRY(check_n(h, N));
+    for (pse_handle *h : act(T)) TRY(check_n(h, N));
     for (auto &x : a) if (!x.pos || !x.force || !x.vel) return fail(PSE_ERR_INVALID, "null array");
     if (kT < 0 || !(dt > 0)) return fail(PSE_ERR_INVALID, "need kT >= 0 and dt > 0");
     unsigned mask = 1u << PH_TOTAL;
-    for (pse_handle *h : T.m) TRY(ts(h, PH_TOTAL));
+    for (pse_handle *h : act(T)) TRY(ts(h, PH_TOTAL));
     TRY(velocity(T, a, group, (int)N, 3, kT, dt, timestep, lanczos_m, &mask));
-    for (pse_handle *h : T.m) { TRY(te(h, PH_TOTAL)); TRY(collect_times(h, mask)); }
+    for (pse_handle *h : act(T)) { TRY(te(h, PH_TOTAL)); TRY(collect_times(h, mask)); }
     return 0;
 }
 
-struct StepArgs {
-    double4 *pos; double4 *vel; double3 *accel; int3 *image; const double4 *force;
-};
 static int do_step(pse_team &T, const std::vector<StepArgs> &sa, const unsigned *group, unsigned N, double kT, double dt,
                    unsigned timestep, double shear_rate, int *lanczos_m) {
-    for (pse_handle *h : T.m) TRY(check_n(h, N));
+    for (pse_handle *h : act(T)) TRY(check_n(h, N));
     std::vector<Args> a;
     for (auto &x : sa) {
         if (!x.pos || !x.vel || !x.accel || !x.image || !x.force) return fail(PSE_ERR_INVALID, "null array");
@@ -1392,17 +1666,13 @@ static int do_step(pse_team &T, const std::vector<StepArgs> &sa, const unsigned 
     }
     if (kT < 0 || !(dt > 0)) return fail(PSE_ERR_INVALID, "need kT >= 0 and dt > 0");
     unsigned mask = (1u << PH_TOTAL) | (1u << PH_INTEG);
-    for (pse_handle *h : T.m) TRY(ts(h, PH_TOTAL));
-    for (pse_handle *h : T.m) h->vl_kind = 1;   // an integrating step: its own neighbour-list suspension state
-    const int rc_v = velocity(T, a, group, (int)N, 3, kT, dt, timestep, lanczos_m, &mask);
-    for (pse_handle *h : T.m) h->vl_kind = 0;
+    for (pse_handle *h : act(T)) TRY(ts(h, PH_TOTAL));
+    for (pse_handle *h : act(T)) h->vl_kind = 1;   // an integrating step: its own neighbour-list suspension state
+    const StepTail tail{&sa, dt, shear_rate};
+    const int rc_v = velocity(T, a, group, (int)N, 3, kT, dt, timestep, lanczos_m, &mask, &tail);
+    for (pse_handle *h : act(T)) h->vl_kind = 0;
     if (rc_v) return rc_v;
-    for (size_t r = 0; r < T.m.size(); ++r) {
-        pse_handle *h = T.m[r];
-        TRY(ts(h, PH_INTEG));
-        launch_integrate(sa[r].pos, sa[r].vel, sa[r].accel, sa[r].image, sa[r].force, group, (int)N, h->dbox, dt, shear_rate,
-                         h->stream);
-        TRY(te(h, PH_INTEG));
+    for (pse_handle *h : act(T)) {
         TRY(te(h, PH_TOTAL));
         HIPCHK(hipGetLastError());
         TRY(collect_times(h, mask));
@@ -1567,10 +1837,11 @@ static int team_connect(pse_team *T, const void *id128_host) {
     memcpy(&id, id128_host, sizeof id);
     HIPCHK(hipSetDevice(T->m[0]->device));
     NCCLCHK(ncclCommInitRank(&T->nccl, T->G, id, T->m[0]->slab_rank));
-    // a second communicator for the far-field chain: its all-to-alls run on the side stream next to the Lanczos exchanges
-    // (opt-in, PSE_TEAM_OVERLAP=1 at pse_create: see velocity())
-    if (T->G > 1 && T->m[0]->tun.team_overlap && ncclCommSplit(T->nccl, 0, T->m[0]->slab_rank, &T->nccl_w, nullptr) != ncclSuccess)
-        T->nccl_w = nullptr;
+    if (T->G > 1) {   // the one stream every RCCL call of the team is issued on (see pse_team)
+        HIPCHK(hipStreamCreateWithFlags(&T->comm, hipStreamNonBlocking));
+        T->evs.resize(32);
+        for (hipEvent_t &e : T->evs) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     return 0;
 }
 
@@ -1628,12 +1899,23 @@ extern "C" int pse_team_destroy(pse_team *T) {
             if (h->info_inv) (void)rocfft_execution_info_set_stream(h->info_inv, h->wstream);
         }
     }
-    if (T->nccl_w) ncclCommDestroy(T->nccl_w);
+    if (T->comm) { (void)hipStreamSynchronize(T->comm); }
     if (T->nccl) ncclCommDestroy(T->nccl);
+    for (hipEvent_t e : T->evs) if (e) (void)hipEventDestroy(e);
+    if (T->comm) (void)hipStreamDestroy(T->comm);
     if (T->scratch) (void)hipFree(T->scratch);
     if (T->stage) (void)hipHostFree(T->stage);
     delete T;
     return 0;
+}
+
+extern "C" int pse_team_debug_solo(pse_team *T, int slab_rank) {
+    if (!T) return fail(PSE_ERR_INVALID, "null team");
+    if (slab_rank < 0) { T->solo = -1; T->solo_m.clear(); return 0; }
+    if (!loopback(*T)) return fail(PSE_ERR_INVALID, "pse_team_debug_solo needs an in-process team");
+    for (pse_handle *h : T->m)
+        if (h->slab_rank == slab_rank) { T->solo = slab_rank; T->solo_m = {h}; return 0; }
+    return fail(PSE_ERR_INVALID, "no member with slab rank %d", slab_rank);
 }
 
 extern "C" int pse_team_mobility(pse_team *T, const pse_double4 *const *pos, const pse_double4 *const *force,

@@ -28,16 +28,45 @@ struct CellRanges {
         return false;
     }
 };
+// Rows a near-field pass works on: up to three ranges [lo, hi) of sorted rows (a slab rank's own rows FIRST, then the ghost cell
+// layers of its neighbours -- the last layers of the box wrap round to rank 0, hence three), laid out back to back in "list rows":
+// range k starts at list row base[k], a multiple of 256, so that no workgroup straddles two ranges.  The per-step pair list is
+// stored by list row; a pass over the own rows alone (n = 1) therefore reads the list a pass over all ranges wrote.
+struct RowMap {
+    int n, lo[3], hi[3], base[3];
+    __host__ __device__ int list_rows() const { return n ? base[n - 1] + ((hi[n - 1] - lo[n - 1] + 255) & ~255) : 0; }
+    // sorted row of list row lr, or -1 (padding)
+    __device__ __forceinline__ int row(int lr) const {
+        int k = 0;
+        if (n > 1 && lr >= base[1]) k = 1;
+        if (n > 2 && lr >= base[2]) k = 2;
+        const int i = lo[k] + (lr - base[k]);
+        return i < hi[k] ? i : -1;
+    }
+};
+inline RowMap row_map(int lo, int hi) { return RowMap{1, {lo, 0, 0}, {hi, 0, 0}, {0, 0, 0}}; }
+inline RowMap row_map(const int (*rg)[2], int n) {
+    RowMap m{};
+    m.n = n;
+    int base = 0;
+    for (int k = 0; k < n; ++k) { m.lo[k] = rg[k][0]; m.hi[k] = rg[k][1]; m.base[k] = base; base += (rg[k][1] - rg[k][0] + 255) & ~255; }
+    return m;
+}
+
+// n > 0 (a slab rank that keeps only some cell layers): the particles of cells it does not keep are counted per slab of
+// cells_per_slab storage cells, on cell book[slab] -- the first cell of that slab the rank does not keep
+struct SlabBook { int n, cells_per_slab, spread, book[64]; };   // spread: the counts go to cells book[slab] .. book[slab] + spread - 1 (one layer)
 hipError_t cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys, unsigned *rank,
                      unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s,
-                     CellRanges need = CellRanges{});
+                     CellRanges need = CellRanges{}, SlabBook sb = SlabBook{});
 // pos_s[i] = wrapped position of particle perm[i], vec_s[i] = vec[tag].xyz, tag_s[i] = its index in the caller's arrays
 // pos_build (nullable): the sorted positions the neighbour list was built at; a particle that has moved more than
 // sqrt(half_skin2) from there (minimum image) sets flags[0] -- HOOMD's NeighborList distance check (r_buff / 2)
 void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm, int N, DBox box,
                     double4 *pos_s, float4 *posf_s, double2 *pv, double4 *vec_s, unsigned *tag_s, hipStream_t s,
                     const double4 *pos_build = nullptr, double half_skin2 = 0.0, int *flags = nullptr,
-                    CellRanges need = CellRanges{}, const int *cell_off = nullptr);   // a slab rank: the needed rows only
+                    CellRanges need = CellRanges{}, const int *cell_off = nullptr,    // a slab rank: the needed rows only
+                    double2 *pv2 = nullptr);                                          // second set of packed records (position half)
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s);
 
 // ---- near field (K9) -------------------------------------------------------------------------------------
@@ -69,23 +98,31 @@ enum { MREAL_CELLS = 0, MREAL_BUILD_LIST = 1, MREAL_USE_LIST = 2 };
 // per-block partial sums of x.x, x.y and x.x_{j-1}
 struct LzFuse {
     const double4 *vprev;   // x_{j-1}, unnormalised (null for j = 0)
-    double *partials;       // [3][npart_cap]
+    double *partials;       // [LZ_NGRAM][npart_cap]
     int npart_cap;
+    const double4 *q, *p, *u;   // two-step blocks of a team (sums = 2, 3): v_j, v_{j-1} (nullable), M v_{j-1} (nullable)
 };
+// slots of the Gram sums of a two-step block (k_lz_block): products of q = v_j, p = v_{j-1}, u = M p, w1 = M q, w2 = M w1
+// -- the eight that M = M^T leaves independent: q.w2 = w1.w1, u.w1 = p.w2, q.u = p.w1 (the pair list holds every pair twice with
+// bit-identical coefficients, so the products agree to summation rounding), and u.u is carried over from the block that made u
+enum { LZG_QW1 = 0, LZG_W1W1, LZG_W1W2, LZG_W2W2, LZG_PW1, LZG_PW2, LZG_UW2, LZG_QQ, LZ_NGRAM };
 // out = M_real . vec (+ self). mode: cells only / cells + write the pair list / use the pair list
 // rows [lo, hi) of the mat-vec (the whole vector is read; multi-GPU ranks each take a row range)
-void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec_s, double4 *out_s, int lo, int hi,
+void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec_s, double4 *out_s, RowMap rows,
                   const int *cell_off, DBox box, DCells nc, double rcut, double self, const double *coef, int ncoef, NbList nb,
                   int mode, hipStream_t s, const double4 *vec2_s = nullptr, double4 *out2_s = nullptr,   // BUILD_LIST: a second vector rides along
                   VerletList vl = VerletList{}, int vl_mode = VL_NONE,   // VL_WRITE: the cell pass also writes the neighbour list; VL_USE: no cell walk
-                  const double2 *pv = nullptr);                          // VL_USE: packed (position, vec_s) records
+                  const double2 *pv = nullptr,                           // VL_USE: packed (position, vec_s) records
+                  double2 *pv_out = nullptr);                            // BUILD_LIST with a second vector: out2 also goes into these records
 bool mreal_table_in_lds(int ncoef);   // the neighbour list across steps needs the LDS copy of the table
 // pair-list mat-vec + Lanczos sums; leaves the three reduced sums in scal[LZ_TMP .. LZ_TMP + 2]
-void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, int lo, int hi, const int *cell_off,
+void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, RowMap rows, const int *cell_off,
                           DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,
                           double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s,   // events (nullable) bracket the mat-vec kernel
                           const double2 *pv = nullptr,    // packed (position, vector) records holding vec_s, or null
-                          VerletList vl = VerletList{});  // in use this step: rows that overflowed the pair list walk it instead of the cells
+                          VerletList vl = VerletList{},   // in use this step: rows that overflowed the pair list walk it instead of the cells
+                          int sums = 1,                   // 0 none, 1 one-step Lanczos sums, 2 Gram sums of a two-step block, 3 single step of that driver
+                          double2 *pv_out = nullptr);     // the result also goes into the vector half of these records
 int mreal_partials_needed(int rows);
 void launch_lz_reduce3(const double *partials, int npart, int cap, double *scal, hipStream_t s);
 
@@ -138,12 +175,18 @@ hipError_t launch_gather(const double4 *pos_s, SpreadWork w, int N, const double
 // ---- slab decomposition helpers
 void launch_slab_pack(double2 *cgrid, double2 *buf, int nxl, int Ny, int Nzh, int nyl, int unpack, hipStream_t s);
 void launch_add_inplace(double *a, const double *b, size_t n, hipStream_t s);
+// in-process teams: the device copies that stand for one exchange, as ONE launch (a message transport posts one group too)
+struct CopyList { int n; const double *src[40]; double *dst[40]; unsigned cnt[40]; };   // counts in doubles
+void launch_copy_list(const CopyList &l, hipStream_t s);
+// dst_q[i] = sum over the n sources of src_r[i] for every destination q: the in-process stand-in of a small all-reduce
+struct SumList { int nsrc, ndst; const double *src[64]; double *dst[64]; };
+void launch_sum_list(const SumList &l, int n, hipStream_t s);
 
 // ---- vector kernels (K10-K14) ----------------------------------------------------------------------------
 void launch_psi(double4 *psi_s, const unsigned *tag_s, int N, uint32_t seed, uint32_t timestep, hipStream_t s,
                 CellRanges need = CellRanges{}, const int *cell_off = nullptr);
 // scal layout (device doubles): [0..127] alpha, [128..255] beta, [256] psi norm, [257] scratch
-constexpr int LZ_ALPHA = 0, LZ_BETA = 128, LZ_NORM = 256, LZ_TMP = 257, LZ_NSCAL = 264;   // TMP: 3 sums
+constexpr int LZ_ALPHA = 0, LZ_BETA = 128, LZ_NORM = 256, LZ_TMP = 257, LZ_UU = 272, LZ_NSCAL = 400;   // TMP: 3 sums (one-step) or the LZ_NGRAM sums of a two-step block; UU[j] = |M v_{j-1}|^2 of the block that starts at j
 constexpr int LZ_NPART = 1024;  // partial-sum slots
 // out_s = scale * sum_q t[q] X[q], X[0] = x0, X[q] = V[q] (the UNNORMALISED Lanczos vectors: t carries the 1 / |x_q|)
 // rows [lo, hi)
@@ -155,6 +198,15 @@ void launch_basis_combine(const double4 *x0, const double4 *V, size_t stride, co
 // update: alpha_j, beta_j -> scal, x_{j+1} -> xnext
 void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, int lo, int hi, double *partials, int cap,
                     double *scal, hipStream_t s);
+// one block of the two-iterations-per-exchange Lanczos of a team (k_lz_block in pse_kernels.hip)
+struct LzBlockArgs {
+    const double4 *q, *p, *w1, *w2;   // p null for j = 0; w2 null: a single step (scalars alpha_j, beta_{j+1} only)
+    double4 *u;                       // in: M p (not read for j = 0); out: M v_{j+1} (two steps) or M v_j = w1 (one step)
+    double4 *v1, *v2;                 // V[j + 1], V[j + 2]
+    double2 *pv;                      // packed records of the next mat-vec: vector half <- the new q
+    int j;
+};
+void launch_lz_block(const LzBlockArgs &a, bool full, double *scal, const int (*row_ranges)[2], int n_ranges, hipStream_t s);
 void launch_lz_update(const double4 *xin, const double4 *y, const double4 *xprev, double4 *xnext, int j,
                       double *scal, const int (*row_ranges)[2], int n_ranges, hipStream_t s, double2 *pv = nullptr);   // up to three disjoint row ranges in one launch; pv: also refresh the packed records
 // tag_s (nullable): out[i].w = the particle's index in the caller's arrays, so the rows can be scattered by ranks that did not sort them

@@ -43,22 +43,47 @@ constexpr unsigned KEY_FOREIGN = 0xFFFFFFFFu;   // a particle a slab rank counts
 // (Counting the foreign particles per x layer in an LDS histogram instead -- one global add per layer and workgroup, booked on
 // the layer's first cell -- was slower: 58 us against 45 us; the kernel is not bound by its global atomics.)
 __global__ void k_cell_keys(const double4 *__restrict__ pos, const unsigned *__restrict__ group, int N, DBox box,
-                            DCells nc, unsigned *__restrict__ keys, unsigned *__restrict__ rank, int *__restrict__ cnt, CellRanges need) {
+                            DCells nc, unsigned *__restrict__ keys, unsigned *__restrict__ rank, int *__restrict__ cnt, CellRanges need,
+                            SlabBook sb) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= N) return;
-    const unsigned idx = group ? group[g] : (unsigned)g;
-    const double4 p = pos[idx];
-    double fx, fy, fz;
-    frac_coords(box, p.x, p.y, p.z, fx, fy, fz);
-    const int cx = cell_coord(fx, nc.nx), cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz);
-    const int zb = cz / nc.bz;
-    const unsigned key = (unsigned)cell_slot(nc, cx, cy, zb, cz - zb * nc.bz);
-    if (need.cell((int)key)) {
-        keys[g] = key;
-        rank[g] = (unsigned)atomicAdd(&cnt[key], 1);
-    } else {
-        keys[g] = KEY_FOREIGN;
-        atomicAdd(&cnt[key], 1);   // counted (the row offsets are global), not ranked
+    const bool live = g < N;
+    unsigned key = 0;
+    bool mine = false;
+    if (live) {
+        const unsigned idx = group ? group[g] : (unsigned)g;
+        const double4 p = pos[idx];
+        double fx, fy, fz;
+        frac_coords(box, p.x, p.y, p.z, fx, fy, fz);
+        const int cx = cell_coord(fx, nc.nx), cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz);
+        const int zb = cz / nc.bz;
+        key = (unsigned)cell_slot(nc, cx, cy, zb, cz - zb * nc.bz);
+        mine = need.cell((int)key);
+        if (mine) {
+            keys[g] = key;
+            rank[g] = (unsigned)atomicAdd(&cnt[key], 1);
+        } else {
+            keys[g] = KEY_FOREIGN;
+            if (sb.n == 0) atomicAdd(&cnt[key], 1);   // counted (the row offsets are global), not ranked
+        }
+    }
+    if (sb.n > 0) {
+        // A slab rank needs the row offsets of its own and its ghost cells and of every slab boundary -- not of the cells in
+        // between.  The particles of another rank's cells are therefore counted per SLAB, on the first cell of that slab the rank
+        // does not keep (all of them lie before or after the kept layers of that slab, so every offset that is used comes out
+        // right), one atomic per distinct slab of a wavefront: device-scope atomics run at ~20 G/s however they are addressed
+        // (MI355X_MICROARCH.md), and 80 % of the particles are foreign to a rank of eight.
+        const int slab = live && !mine ? (int)(key / (unsigned)sb.cells_per_slab) : -1;
+        unsigned long long todo = __ballot(slab >= 0);
+        const int lane = threadIdx.x & 63;
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            const int s0 = __shfl(slab, src, 64);
+            const unsigned long long m = __ballot(slab == s0) & todo;
+            // spread over `spread` cells of that layer by workgroup: one word takes ~88 atomics per microsecond, and a step has
+            // 15 000 wavefronts x 7 foreign slabs (all on ONE cell per slab the kernel took 195 us instead of 45)
+            if (lane == src) atomicAdd(&cnt[sb.book[s0] + (int)((blockIdx.x * 4u + (threadIdx.x >> 6)) % (unsigned)sb.spread)], __popcll(m));
+            todo &= ~m;
+        }
     }
 }
 __global__ void k_cell_scatter(const unsigned *__restrict__ keys, const unsigned *__restrict__ rank,
@@ -86,10 +111,10 @@ size_t cell_sort_temp_bytes(size_t ncell) {
 }
 hipError_t cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys, unsigned *rank,
                      unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s,
-                     CellRanges need) {
+                     CellRanges need, SlabBook sb) {
     hipError_t e = hipMemsetAsync(cnt, 0, (size_t)(ncell + 1) * sizeof(int), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_cell_keys, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, group, N, box, nc, keys, rank, cnt, need);
+    hipLaunchKernelGGL(k_cell_keys, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, group, N, box, nc, keys, rank, cnt, need, sb);
     // cnt[ncell] = 0: cell_off[ncell] = N.  A failed scan (scratch too small for ncell) would leave garbage offsets: reported
     e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt, cell_off, ncell + 1, s);
     if (e != hipSuccess) return e;
@@ -102,7 +127,8 @@ __global__ void k_permute(const double4 *__restrict__ pos, const double4 *__rest
                           const unsigned *__restrict__ group, const unsigned *__restrict__ perm, int N, DBox box,
                           double4 *__restrict__ pos_s, float4 *__restrict__ posf_s, double2 *__restrict__ pv,
                           double4 *__restrict__ vec_s, unsigned *__restrict__ tag_s, const double4 *__restrict__ pos_build,
-                          double half_skin2, int *__restrict__ flags, CellRanges need, const int *__restrict__ cell_off) {
+                          double half_skin2, int *__restrict__ flags, CellRanges need, const int *__restrict__ cell_off,
+                          double2 *__restrict__ pv2) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N || !need.row(s, cell_off)) return;
     const unsigned g = perm[s];
@@ -122,6 +148,10 @@ __global__ void k_permute(const double4 *__restrict__ pos, const double4 *__rest
     if (pv) {   // packed 48-byte (position, vector) records of the pair-list mat-vec: the position half
         pv[3 * (size_t)s] = make_double2(q.x, q.y);
         ((double *)&pv[3 * (size_t)s + 1])[0] = q.z;
+    }
+    if (pv2) {   // a team's second set of records (the two-step Lanczos gathers q from one and w1 = M q from the other)
+        pv2[3 * (size_t)s] = make_double2(q.x, q.y);
+        ((double *)&pv2[3 * (size_t)s + 1])[0] = q.z;
     }
     tag_s[s] = idx;
     if (vec) {
@@ -152,9 +182,9 @@ __global__ void k_permute_vec(const double4 *__restrict__ vec, const unsigned *_
 
 void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm, int N, DBox box,
                     double4 *pos_s, float4 *posf_s, double2 *pv, double4 *vec_s, unsigned *tag_s, hipStream_t s,
-                    const double4 *pos_build, double half_skin2, int *flags, CellRanges need, const int *cell_off) {
+                    const double4 *pos_build, double half_skin2, int *flags, CellRanges need, const int *cell_off, double2 *pv2) {
     hipLaunchKernelGGL(k_permute, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, vec, group, perm, N, box, pos_s, posf_s, pv, vec_s, tag_s,
-                       pos_build, half_skin2, flags, need, cell_off);
+                       pos_build, half_skin2, flags, need, cell_off, pv2);
 }
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s) {
     hipLaunchKernelGGL(k_permute_vec, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, vec, tag_s, N, vec_s);
@@ -205,9 +235,9 @@ __device__ __forceinline__ void vl_store(char *vrec, int slot, int lane, unsigne
 template <bool LIST, bool CL, bool TWO, bool VL>
 __global__ void __launch_bounds__(TPB, ((LIST && CL && !VL) ? 3 : 1))   // the list-building pass of every step: <= 168 VGPRs (it takes 166)
 k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf_s, const double4 *__restrict__ vec_s,
-              double4 *__restrict__ out_s, int lo, int hi, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2,
+              double4 *__restrict__ out_s, RowMap rm, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2,
               float rcut2_pre, double self, const double *__restrict__ coef_g, int ncoef, NbList nb,
-              const double4 *__restrict__ vec2_s, double4 *__restrict__ out2_s, VerletList vl) {
+              const double4 *__restrict__ vec2_s, double4 *__restrict__ out2_s, VerletList vl, double2 *__restrict__ pv_out) {
     // the pass that also writes the kept neighbour list queues every pair within rcut + r_buff (28 per row instead of 21): a deeper
     // queue, or half of the waves would stop for an extra, poorly filled drain in the middle of the walk
     constexpr int QC = VL ? 64 : QCAP;
@@ -221,8 +251,9 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
         __syncthreads();
     }
     const double *coef = CL ? scoef : coef_g;
-    const int i = lo + xcd_block(blockIdx.x, gridDim.x) * TPB + tid;   // rows [lo, hi) of the mat-vec
-    if (i >= hi) return;
+    const int lr = xcd_block(blockIdx.x, gridDim.x) * TPB + tid;       // list row -> sorted row (own rows, then ghost layers)
+    const int i = rm.row(lr);
+    if (i < 0) return;
     const double4 pi = pos_s[i];
     const double4 vi = vec_s[i];
     double ux = self * vi.x, uy = self * vi.y, uz = self * vi.z;
@@ -233,9 +264,9 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
     const int cx = cell_coord(fx, nc.nx), cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz);
     const bool shift_only = nc.nx > 1 && nc.ny > 1 && nc.nz > 1;   // otherwise finish with the rint minimum image
     int qn = 0, total = 0, vtotal = 0;
-    const int lane = (i - lo) & 63;
-    char *rec = LIST ? nb.data + (size_t)((i - lo) >> 6) * nb.cap * NB_REC : nullptr;
-    char *vrec = VL ? (char *)vl.idx + (size_t)((i - lo) >> 6) * (vl.cap / 4) * 1024 : nullptr;
+    const int lane = lr & 63;
+    char *rec = LIST ? nb.data + (size_t)(lr >> 6) * nb.cap * NB_REC : nullptr;
+    char *vrec = VL ? (char *)vl.idx + (size_t)(lr >> 6) * (vl.cap / 4) * 1024 : nullptr;
     const double rq2 = VL ? vl.rskin * vl.rskin : rcut2;   // what enters the queue
 
     // DU queue entries per iteration: their load -> distance -> table -> force chains are independent (one entry at a time the phase
@@ -379,7 +410,13 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
     }
     drain();
     out_s[i] = make_double4(ux, uy, uz, 0.0);
-    if (TWO) out2_s[i] = make_double4(wx, wy, wz, 0.0);
+    if (TWO) {
+        out2_s[i] = make_double4(wx, wy, wz, 0.0);
+        if (pv_out) {   // the vector half of the packed records the NEXT mat-vec gathers (two-step Lanczos of a team: w = M psi)
+            ((double *)&pv_out[3 * (size_t)i + 1])[1] = wx;
+            pv_out[3 * (size_t)i + 2] = make_double2(wy, wz);
+        }
+    }
     if (LIST) {
         if (total > nb.cap) total = -1;   // the row did not fit: the mat-vecs of this step walk the cells for it
         nb.cnt[i] = total;
@@ -472,11 +509,14 @@ k_mreal_verlet(const double4 *__restrict__ pos_s, const double2 *__restrict__ pv
 // gathers per pair instead of the four of two 24-byte records (the kernel is bound by the L1 address path).
 // WSP = 4: the four waves of a workgroup share ONE block of 64 rows and take every fourth group of slots each (partial sums
 // through LDS): the waves resident on a CU then gather from a quarter as many neighbourhoods (the kernel is bound by L1 misses).
-template <bool FUSE, int UNROLL, int NT, bool PACKED, int WSP = 1>
+// FUSE: 0 none; 1 the three sums of the one-step iteration; 2 the Gram sums of a two-step block (this launch is its SECOND
+// mat-vec: vec = w1 = M q, result w2); 3 the sums of a single step in the two-step driver (vec = q, result w1).
+template <int FUSE, int UNROLL, int NT, bool PACKED, int WSP = 1>
 __global__ void __launch_bounds__(NT)
-k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, int lo,
-             int hi, DBox box, int shift_only, double self, NbList nb, LzFuse lz, const double2 *__restrict__ pv,
-             const int *__restrict__ cell_off, DCells nc, double rcut2, const double *__restrict__ coef, VerletList vl) {
+k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, RowMap rm,
+             DBox box, int shift_only, double self, NbList nb, LzFuse lz, const double2 *__restrict__ pv,
+             const int *__restrict__ cell_off, DCells nc, double rcut2, const double *__restrict__ coef, VerletList vl,
+             double2 *__restrict__ pv_out) {
     __shared__ double shift[27 * 3];
     __shared__ double sh[4];
     if (threadIdx.x < 27) {
@@ -485,11 +525,12 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
         shift[threadIdx.x * 3] = sx; shift[threadIdx.x * 3 + 1] = sy; shift[threadIdx.x * 3 + 2] = sz;
     }
     __syncthreads();
-    static_assert(WSP == 1 || (NT == 64 * WSP && FUSE), "split rows: one wave per slot phase");
+    static_assert(WSP == 1 || NT == 64 * WSP, "split rows: one wave per slot phase");
     const int wv = WSP > 1 ? (int)(threadIdx.x >> 6) : 0;
-    const int i = WSP > 1 ? lo + xcd_block(blockIdx.x, gridDim.x) * 64 + (int)(threadIdx.x & 63)
-                          : lo + xcd_block(blockIdx.x, gridDim.x) * NT + (int)threadIdx.x;
-    const bool active = i < hi;
+    const int lr = WSP > 1 ? xcd_block(blockIdx.x, gridDim.x) * 64 + (int)(threadIdx.x & 63)
+                           : xcd_block(blockIdx.x, gridDim.x) * NT + (int)threadIdx.x;
+    const int i = rm.row(lr);
+    const bool active = i >= 0;
     double ux = 0.0, uy = 0.0, uz = 0.0;
     double4 vi = make_double4(0.0, 0.0, 0.0, 0.0);
     if (active) {
@@ -498,8 +539,8 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
         if (cnt >= 0) {
             const double4 pi = pos_s[i];
             if (wv == 0) { ux = self * vi.x; uy = self * vi.y; uz = self * vi.z; }
-            const int lane = (i - lo) & 63;
-            const char *rec = nb.data + (size_t)((i - lo) >> 6) * nb.cap * NB_REC;
+            const int lane = lr & 63;
+            const char *rec = nb.data + (size_t)(lr >> 6) * nb.cap * NB_REC;
             // software-pipelined by hand: the list entries of UNROLL slots, then their 2 UNROLL gathers, then the arithmetic --
             // left to the compiler every slot waited for its own load -> gather chain (the kernel was latency-bound at
             // 1.9 TB/s).  Branch-free: slots past cnt re-read the last valid one with f = h = 0; image code 13 is a zero shift.
@@ -604,7 +645,32 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
         if (wv > 0) return;
         for (int w = 0; w < WSP - 1; ++w) { ux += red[(w * 3 + 0) * 64 + ln]; uy += red[(w * 3 + 1) * 64 + ln]; uz += red[(w * 3 + 2) * 64 + ln]; }
     }
-    if (FUSE) {   // x = vec (unnormalised Lanczos vector), y = M x: partial sums of x.x, x.y, x.x_{j-1}
+    if (FUSE >= 2) {   // two-step driver: the sums the block scalars are derived from (see k_lz_block), slots LZG_*
+        double g[LZ_NGRAM];
+#pragma unroll
+        for (int t = 0; t < LZ_NGRAM; ++t) g[t] = 0.0;
+        if (active) {
+            auto dot = [](const double4 &x, double yx, double yy, double yz) { return x.x * yx + x.y * yy + x.z * yz; };
+            const double4 z4 = make_double4(0.0, 0.0, 0.0, 0.0);
+            const double4 p = lz.p ? lz.p[i] : z4;
+            if (FUSE == 2) {   // vi = w1, (ux, uy, uz) = w2
+                const double4 q = lz.q[i], u = lz.u ? lz.u[i] : z4;
+                g[LZG_QW1] = dot(q, vi.x, vi.y, vi.z); g[LZG_W1W1] = dot(vi, vi.x, vi.y, vi.z); g[LZG_W1W2] = dot(vi, ux, uy, uz);
+                g[LZG_W2W2] = ux * ux + uy * uy + uz * uz; g[LZG_PW1] = dot(p, vi.x, vi.y, vi.z);
+                g[LZG_PW2] = dot(p, ux, uy, uz); g[LZG_UW2] = dot(u, ux, uy, uz); g[LZG_QQ] = dot(q, q.x, q.y, q.z);
+            } else {           // vi = q, (ux, uy, uz) = w1
+                g[LZG_QW1] = dot(vi, ux, uy, uz); g[LZG_W1W1] = ux * ux + uy * uy + uz * uz; g[LZG_PW1] = dot(p, ux, uy, uz);
+                g[LZG_QQ] = dot(vi, vi.x, vi.y, vi.z);
+            }
+        }
+        static_assert(FUSE < 2 || NT == 64 || WSP > 1, "Gram sums: one wave per block of rows");
+#pragma unroll
+        for (int t = 0; t < LZ_NGRAM; ++t) {
+            if (FUSE == 3 && t != LZG_QW1 && t != LZG_W1W1 && t != LZG_PW1 && t != LZG_QQ) { if (threadIdx.x == 0) lz.partials[(size_t)t * lz.npart_cap + blockIdx.x] = 0.0; continue; }   // (compile-time: the loop is unrolled)
+            const double v = wave_sum(g[t]);
+            if (threadIdx.x == 0) lz.partials[(size_t)t * lz.npart_cap + blockIdx.x] = v;
+        }
+    } else if (FUSE) {   // x = vec (unnormalised Lanczos vector), y = M x: partial sums of x.x, x.y, x.x_{j-1}
         double a = 0.0, b = 0.0, c = 0.0;
         if (active) {
             a = vi.x * vi.x + vi.y * vi.y + vi.z * vi.z;
@@ -620,27 +686,36 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
             lz.partials[blockIdx.x] = a; lz.partials[lz.npart_cap + blockIdx.x] = b; lz.partials[2 * lz.npart_cap + blockIdx.x] = c;
         }
     }
-    if (active) out_s[i] = make_double4(ux, uy, uz, 0.0);
+    if (active) {
+        out_s[i] = make_double4(ux, uy, uz, 0.0);
+        if (pv_out) {   // the vector half of the records the next mat-vec gathers
+            ((double *)&pv_out[3 * (size_t)i + 1])[1] = ux;
+            pv_out[3 * (size_t)i + 2] = make_double2(uy, uz);
+        }
+    }
 }
 
 static size_t mreal_lds_bytes(int ncoef) { return (size_t)(ncoef / (2 * RS_NCOEF)) * (2 * RS_NCOEF + 1) * sizeof(double); }   // padded copy
 bool mreal_table_in_lds(int ncoef) { return mreal_lds_bytes(ncoef) <= 14 * 1024; }   // with the 44 KB queue: three workgroups per CU up to 9 KB of table, two beyond
 
-void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec_s, double4 *out_s, int lo, int hi,
+void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec_s, double4 *out_s, RowMap rm,
                   const int *cell_off, DBox box, DCells nc, double rcut, double self, const double *coef, int ncoef, NbList nb,
-                  int mode, hipStream_t s, const double4 *vec2_s, double4 *out2_s, VerletList vl, int vl_mode, const double2 *pv) {
-    if (hi <= lo) return;
-    const dim3 g(nblocks(hi - lo, TPB)), b(TPB);
+                  int mode, hipStream_t s, const double4 *vec2_s, double4 *out2_s, VerletList vl, int vl_mode, const double2 *pv,
+                  double2 *pv_out) {
+    const int rows = rm.list_rows();
+    if (rows <= 0) return;
+    const dim3 g(nblocks(rows, TPB)), b(TPB);
     const size_t cb = mreal_lds_bytes(ncoef);
     const bool cl = mreal_table_in_lds(ncoef);
     if (mode == MREAL_USE_LIST) {
-        hipLaunchKernelGGL((k_mreal_list<false, 4, TPB, false>), g, b, 0, s, pos_s, vec_s, out_s, lo, hi, box,
+        hipLaunchKernelGGL((k_mreal_list<0, 4, TPB, false>), g, b, 0, s, pos_s, vec_s, out_s, rm, box,
                            (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1), self, nb, LzFuse{}, nullptr, cell_off, nc, rcut * rcut, coef,
-                           vl_mode == VL_USE ? vl : VerletList{});
+                           vl_mode == VL_USE ? vl : VerletList{}, nullptr);
         return;
     }
     const bool list = mode == MREAL_BUILD_LIST, two = list && vec2_s != nullptr;
     if (vl_mode == VL_USE) {   // rows [0, N) of a single rank; the table is in LDS (the caller checked mreal_table_in_lds)
+        const int hi = rm.hi[0];
 #define PSE_VERLET(L, T) do { if (pv) hipLaunchKernelGGL((k_mreal_verlet<L, T, true>), g, b, cb, s, pos_s, pv, vec_s, out_s, hi, box, rcut * rcut, self, coef, ncoef, nb, vl, two ? vec2_s : nullptr, out2_s); \
         else hipLaunchKernelGGL((k_mreal_verlet<L, T, false>), g, b, cb, s, pos_s, pv, vec_s, out_s, hi, box, rcut * rcut, self, coef, ncoef, nb, vl, two ? vec2_s : nullptr, out2_s); } while (0)
         if (list && two) PSE_VERLET(true, true);
@@ -655,7 +730,7 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
     const double cmax = 1.5 * (box.Lx + std::fabs(box.xy) * box.Ly + box.Ly + box.Lz);
     const double rpre = (wr ? vl.rskin : rcut) + 16.0 * cmax * 5.97e-8;
     const float rcut2_pre = (float)(rpre * rpre * (1.0 + 1e-6));
-#define PSE_CELLS(L, C, T, V) hipLaunchKernelGGL((k_mreal_cells<L, C, T, V>), g, b, (C) ? cb : 0, s, pos_s, posf_s, vec_s, out_s, lo, hi, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, two ? vec2_s : nullptr, out2_s, vl)
+#define PSE_CELLS(L, C, T, V) hipLaunchKernelGGL((k_mreal_cells<L, C, T, V>), g, b, (C) ? cb : 0, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, two ? vec2_s : nullptr, out2_s, vl, two ? pv_out : nullptr)
     if (list) {
         if (cl && two) { if (wr) PSE_CELLS(true, true, true, true); else PSE_CELLS(true, true, true, false); }
         else if (cl) { if (wr) PSE_CELLS(true, true, false, true); else PSE_CELLS(true, true, false, false); }
@@ -670,22 +745,27 @@ int mreal_partials_needed(int rows) { return nblocks(std::max(rows, 1), 64); }  
 void launch_lz_reduce3(const double *partials, int npart, int cap, double *scal, hipStream_t s) {
     hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, partials, npart, cap, 3, scal);
 }
-void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, int lo, int hi, const int *cell_off,
+void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, RowMap rm, const int *cell_off,
                           DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,
-                          double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s, const double2 *pv, VerletList vl) {
+                          double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s, const double2 *pv, VerletList vl,
+                          int sums, double2 *pv_out) {
     const int so = (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1);
-    const int nbk = nblocks(std::max(hi - lo, 1), TPB);
+    const int rows = std::max(rm.list_rows(), 1);
+    const int nbk = nblocks(rows, TPB);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     // Four waves per block of 64 rows, each taking every fourth group of slots: 0.166 ms against 0.191 with four blocks of rows
     // per workgroup (two waves: 0.182, eight: 0.196).
     if (pv) {
-        const int nb64 = nblocks(std::max(hi - lo, 1), 64);
-        hipLaunchKernelGGL((k_mreal_list<true, 4, 256, true, 4>), dim3(nb64), dim3(256), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, pv, cell_off, nc, rcut * rcut, coef, vl);
+        const int nb64 = nblocks(rows, 64);
+#define PSE_LIST(F) hipLaunchKernelGGL((k_mreal_list<F, 4, 256, true, 4>), dim3(nb64), dim3(256), 0, s, pos_s, vec_s, w, rm, box, so, self, nb, lz, pv, cell_off, nc, rcut * rcut, coef, vl, pv_out)
+        if (sums == 0) PSE_LIST(0); else if (sums == 1) PSE_LIST(1); else if (sums == 2) PSE_LIST(2); else PSE_LIST(3);
+#undef PSE_LIST
         if (ev_end) (void)hipEventRecord(ev_end, s);
-        launch_lz_reduce3(lz.partials, nb64, lz.npart_cap, scal, s);
+        if (sums == 1) launch_lz_reduce3(lz.partials, nb64, lz.npart_cap, scal, s);
+        else if (sums >= 2) hipLaunchKernelGGL(k_lz_reduce, dim3(LZ_NGRAM), dim3(1024), 0, s, lz.partials, nb64, lz.npart_cap, LZ_NGRAM, scal);
         return;
     }
-    hipLaunchKernelGGL((k_mreal_list<true, 4, TPB, false>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, lo, hi, box, so, self, nb, lz, nullptr, cell_off, nc, rcut * rcut, coef, vl);
+    hipLaunchKernelGGL((k_mreal_list<1, 4, TPB, false>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, rm, box, so, self, nb, lz, nullptr, cell_off, nc, rcut * rcut, coef, vl, nullptr);
     if (ev_end) (void)hipEventRecord(ev_end, s);
     hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, lz.partials, nbk, lz.npart_cap, 3, scal);
 }
@@ -1481,6 +1561,38 @@ void launch_slab_pack(double2 *cgrid, double2 *buf, int nxl, int Ny, int Nzh, in
 __global__ void k_axpy_inplace(double *__restrict__ a, const double *__restrict__ b, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] += b[i];
 }
+__global__ void __launch_bounds__(TPB) k_copy_list(CopyList l) {
+    const int it = blockIdx.y;
+    const double *__restrict__ src = l.src[it];
+    double *__restrict__ dst = l.dst[it];
+    const unsigned n = l.cnt[it];
+    if ((((size_t)src | (size_t)dst) & 15) == 0) {   // 16-byte pieces where both ends allow
+        const unsigned n2 = n >> 1;
+        for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < n2; i += gridDim.x * TPB) ((double2 *)dst)[i] = ((const double2 *)src)[i];
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1];
+    } else {
+        for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) dst[i] = src[i];
+    }
+}
+void launch_copy_list(const CopyList &l, hipStream_t s) {
+    if (l.n <= 0) return;
+    unsigned mx = 0;
+    for (int i = 0; i < l.n; ++i) mx = std::max(mx, l.cnt[i]);
+    const int gx = std::max(1, std::min(256, nblocks((long)(mx / 2 + 1), TPB)));
+    hipLaunchKernelGGL(k_copy_list, dim3(gx, l.n), dim3(TPB), 0, s, l);
+}
+__global__ void __launch_bounds__(TPB) k_sum_list(SumList l, int n) {
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+        double v = 0.0;
+        for (int r = 0; r < l.nsrc; ++r) v += l.src[r][i];   // rank order: deterministic
+        for (int q = 0; q < l.ndst; ++q) l.dst[q][i] = v;
+    }
+}
+void launch_sum_list(const SumList &l, int n, hipStream_t s) {
+    // ONE workgroup: sources and destinations are the same buffers, so every element must be read from all sources before it is
+    // written anywhere -- true within a thread (the loops above), and no other thread touches element i
+    hipLaunchKernelGGL(k_sum_list, dim3(nblocks(n, TPB)), dim3(TPB), 0, s, l, n);
+}
 void launch_add_inplace(double *a, const double *b, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_axpy_inplace, dim3(std::min<long>(2048, nblocks((long)n, TPB))), dim3(TPB), 0, s, a, b, n);
 }
@@ -1576,6 +1688,90 @@ k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, cons
         }
     }
 }
+// ---- two Lanczos iterations per exchange (teams) ---------------------------------------------------------------------------
+// A slab rank pays one exchange (an all-reduce of the sums + the ghost rows of the mat-vec results) per Lanczos iteration, and at
+// 1/8 of the rows an exchange costs as much as the mat-vec.  The two-step block needs ONE per two iterations: with q = v_j,
+// p = v_{j-1}, u = M p known on the own rows and TWO ghost cell layers,
+//     w1 = M q   on the own rows and one ghost layer (redundantly: the neighbours compute those rows too),
+//     w2 = M w1  on the own rows,
+// the Gram sums of {p, q, u, w1, w2} over the own rows (one all-reduce of LZ_NGRAM numbers) give alpha_j, beta_{j+1}, alpha_{j+1},
+// beta_{j+2} in closed form (M is symmetric: q.w2 = w1.w1, p.w2 = u.w1, ...; every product is summed explicitly all the same):
+//     r1 = w1 - alpha q - beta p,            beta'^2 = w1.w1 - alpha^2 - 2 beta p.w1 + beta^2,        v' = r1 / beta'
+//     z1 = M v' = (w2 - alpha w1 - beta u) / beta',   alpha' = v'.z1,
+//     r2 = z1 - alpha' v' - beta' q,         beta''^2 = z1.z1 - alpha'^2 - 2 beta' q.z1 + beta'^2,    v'' = r2 / beta''
+// and with the ghost rows of w1, w2 (the same exchange) every rank forms v', v'', z1 on its own AND its ghost rows -- the state
+// of the next block (p = v', q = v'', u = z1).  In exact arithmetic these are the alpha, beta of PSEv1/Brownian.cu:440-521; the
+// sums cost a relative 1e-14 in beta (cancellation against O(1) terms).  q of block 0 is psi unnormalised: s = 1 / |q| from q.q.
+// The basis V holds the NORMALISED v_j here (the one-step path keeps unnormalised x_j).
+template <bool FULL>
+__global__ void __launch_bounds__(TPB)
+k_lz_block(LzBlockArgs a, double *__restrict__ scal, RowRanges rg) {
+    const double *G = scal + LZ_TMP;
+    const int j = a.j;
+    const double n0 = G[LZG_QQ], s2 = n0 > 0.0 ? 1.0 / n0 : 0.0, sc = sqrt(s2);
+    const double beta = j > 0 ? scal[LZ_BETA + j] : 0.0, alpha_prev = j > 0 ? scal[LZ_ALPHA + j - 1] : 0.0;
+    const double ga = G[LZG_QW1] * s2, gb = G[LZG_W1W1] * s2, gf = G[LZG_PW1] * sc;   // q.w1, w1.w1, p.w1 (= q.u) of the normalised q
+    const double alpha = ga;
+    const double bp2 = gb - alpha * alpha - 2.0 * beta * gf + beta * beta;
+    const double bp = bp2 > 0.0 ? sqrt(bp2) : 0.0, ibp = bp > 1e-12 ? 1.0 / bp : 0.0;
+    double alpha1 = 0.0, bpp = 0.0, ibpp = 0.0, uu_next = 0.0;
+    if (FULL) {
+        const double gc = G[LZG_W1W2] * s2, gd = G[LZG_W2W2] * s2, ge = gb /* q.w2 = w1.w1 */, gg = G[LZG_PW2] * sc, gg2 = gg /* u.w1 = p.w2 */,
+                     gh = G[LZG_UW2] * sc, gk = j > 0 ? scal[LZ_UU + j] : 0.0, gf2 = gf /* q.u = p.w1 */;
+        const double r1w2 = gc - alpha * ge - beta * gg, r1w1 = gb - alpha * ga - beta * gf, r1u = gg2 - alpha * gf2 - beta * alpha_prev;
+        alpha1 = (r1w2 - alpha * r1w1 - beta * r1u) * ibp * ibp;
+        const double zz = (gd + alpha * alpha * gb + beta * beta * gk - 2.0 * alpha * gc - 2.0 * beta * gh + 2.0 * alpha * beta * gg2) * ibp * ibp;
+        const double qz = (ge - alpha * ga - beta * gf2) * ibp;
+        const double bpp2 = zz - alpha1 * alpha1 - 2.0 * bp * qz + bp * bp;
+        bpp = bpp2 > 0.0 ? sqrt(bpp2) : 0.0;
+        ibpp = bpp > 1e-12 ? 1.0 / bpp : 0.0;
+        uu_next = zz;                              // |M v_{j+1}|^2: the u.u of the block that starts at j + 2
+    } else {
+        uu_next = gb;                              // a single step leaves u = M v_j = w1
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (j == 0) { scal[LZ_NORM] = n0 > 0.0 ? sqrt(n0) : 0.0; scal[LZ_BETA] = 0.0; }
+        scal[LZ_ALPHA + j] = alpha;
+        scal[LZ_BETA + j + 1] = bp;
+        if (FULL) { scal[LZ_ALPHA + j + 1] = alpha1; scal[LZ_BETA + j + 2] = bpp; }
+        scal[LZ_UU + j + (FULL ? 2 : 1)] = uu_next;   // another slot than the one this launch reads
+    }
+    const int n0r = rg.n > 0 ? rg.hi[0] - rg.lo[0] : 0, n1r = rg.n > 1 ? rg.hi[1] - rg.lo[1] : 0, n2r = rg.n > 2 ? rg.hi[2] - rg.lo[2] : 0;
+    for (int t = blockIdx.x * TPB + threadIdx.x; t < n0r + n1r + n2r; t += gridDim.x * TPB) {
+        const int i = t < n0r ? rg.lo[0] + t : (t < n0r + n1r ? rg.lo[1] + (t - n0r) : rg.lo[2] + (t - n0r - n1r));
+        const double4 q = a.q[i], w1 = a.w1[i];
+        double4 p = make_double4(0.0, 0.0, 0.0, 0.0), u = p;
+        if (j > 0) { p = a.p[i]; if (FULL) u = a.u[i]; }
+        const double qx = sc * q.x, qy = sc * q.y, qz_ = sc * q.z, ax = sc * w1.x, ay = sc * w1.y, az = sc * w1.z;
+        const double v1x = (ax - alpha * qx - beta * p.x) * ibp, v1y = (ay - alpha * qy - beta * p.y) * ibp, v1z = (az - alpha * qz_ - beta * p.z) * ibp;
+        a.v1[i] = make_double4(v1x, v1y, v1z, 0.0);
+        double nx = v1x, ny = v1y, nz = v1z;
+        if (FULL) {
+            const double4 w2 = a.w2[i];
+            const double z1x = (sc * w2.x - alpha * ax - beta * u.x) * ibp, z1y = (sc * w2.y - alpha * ay - beta * u.y) * ibp,
+                         z1z = (sc * w2.z - alpha * az - beta * u.z) * ibp;
+            nx = (z1x - alpha1 * v1x - bp * qx) * ibpp; ny = (z1y - alpha1 * v1y - bp * qy) * ibpp; nz = (z1z - alpha1 * v1z - bp * qz_) * ibpp;
+            a.v2[i] = make_double4(nx, ny, nz, 0.0);
+            a.u[i] = make_double4(z1x, z1y, z1z, 0.0);
+        } else {
+            a.u[i] = make_double4(ax, ay, az, 0.0);   // M v_j: the u of a block that starts at j + 1
+        }
+        if (a.pv) {
+            ((double *)&a.pv[3 * (size_t)i + 1])[1] = nx;
+            a.pv[3 * (size_t)i + 2] = make_double2(ny, nz);
+        }
+    }
+}
+void launch_lz_block(const LzBlockArgs &a, bool full, double *scal, const int (*rg)[2], int nrg, hipStream_t s) {
+    RowRanges r{};
+    r.n = nrg;
+    int total = 0;
+    for (int q = 0; q < nrg && q < 3; ++q) { r.lo[q] = rg[q][0]; r.hi[q] = rg[q][1]; total += rg[q][1] - rg[q][0]; }
+    const dim3 g(vec_grid(std::max(1, total)));
+    if (full) hipLaunchKernelGGL(k_lz_block<true>, g, dim3(TPB), 0, s, a, scal, r);
+    else hipLaunchKernelGGL(k_lz_block<false>, g, dim3(TPB), 0, s, a, scal, r);
+}
+
 void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, int lo, int hi, double *partials, int cap,
                     double *scal, hipStream_t s) {
     const int g = vec_grid(std::max(1, hi - lo));

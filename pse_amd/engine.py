@@ -248,6 +248,10 @@ class Team:
         _lib.check(_lib.load().pse_team_unique_id(buf))
         return buf.raw
 
+    def debug_solo(self, slab_rank):
+        """Developer switch: queue the work of one member only (see include/pse_amd.h); -1 switches it off."""
+        _lib.check(self._lib.pse_team_debug_solo(self._t, int(slab_rank)))
+
     def close(self):
         if getattr(self, "_t", None) is not None and self._t.value:
             self._lib.pse_team_destroy(self._t)

@@ -40,6 +40,36 @@ def test_loopback_team_matches_single_gpu(world, xy, mode, monkeypatch):
     assert m == m_ref
     for r in range(world):
         assert rel(vels[r].cpu().numpy()[:, :3], v_ref.cpu().numpy()[:, :3]) < 1e-11, r
+    # two Lanczos iterations per exchange: the first batch covers max(m_in, 2) = 5 iterations in 3 exchanges, any further batch
+    # max(2, done / 4) = 2 iterations in one (the one-step driver needs one exchange per iteration)
+    i = sim.engines[0].info()
+    assert i["lanczos_m"] == m and i["lanczos_exchanges"] <= 3 + max(0, (m - 5 + 1) // 2), i
+
+
+@pytest.mark.parametrize("world,m_in", [(2, 2), (3, 3), (4, 6), (4, 11)])
+def test_two_step_and_one_step_lanczos_agree(world, m_in, monkeypatch):
+    """The team's two-iterations-per-exchange Lanczos (default) against the one-iteration driver (PSE_TEAM_SSTEP=0) and the single
+    GPU: the same m, the same velocities -- from any starting count (even, odd, beyond convergence)."""
+    import pse_amd
+    from pse_amd.sharded import LoopbackSimulation
+    n = 3000
+    pos, force, box = make_suspension(n, phi=0.1, xy=0.15)
+    kw = dict(xi=0.5, error=1e-3, seed=3, grid=(48, 48, 48))
+    ref = pse_amd.Engine(n, box, **kw)
+    v_ref, m_ref = ref.brownian_velocity(to4(pos), to4(force), 1.0, 1e-3, 9, lanczos_m=m_in)
+    out = {}
+    for sstep in ("1", "0"):
+        monkeypatch.setenv("PSE_TEAM_SSTEP", sstep)
+        sim = LoopbackSimulation(n, box, world, **kw)
+        sim.load(pos, force)
+        vels, m = sim.brownian_velocity(1.0, 1e-3, 9, lanczos_m=m_in)
+        i = sim.engines[0].info()
+        out[sstep] = (m, i["lanczos_exchanges"], i["lanczos_matvecs"])
+        assert m == m_ref, (sstep, m, m_ref)
+        for r in range(world):
+            assert rel(vels[r].cpu().numpy()[:, :3], v_ref.cpu().numpy()[:, :3]) < 1e-10, (sstep, r)
+    assert out["0"][1] == out["0"][2]                     # one exchange per iteration
+    assert out["1"][1] < out["0"][1], out                 # fewer with two per exchange
 
 
 def test_loopback_step_keeps_replicas_identical():

@@ -80,12 +80,22 @@ int pse_destroy(pse_handle *h);
  * than round-off unless the cell grid still fits. */
 int pse_set_box(pse_handle *h, double Lx, double Ly, double Lz, double xy);
 /* run on this hipStream_t (default: the null stream, as the reference does).  The work of every entry point is ordered on
- * this stream, but the entry points are NOT free of host synchronisation (so they cannot be captured into a hipGraph by the
- * caller): (1) with a neighbour skin in use (the default, below) every evaluation whose kept list may still be valid waits
- * for the stream and reads one flag back before it queues anything (the distance check HOOMD's NeighborList does on the
- * host side too); (2) Brownian calls read the Lanczos scalars back once per convergence check, as the reference does per
- * iteration (PSEv1/Brownian.cu:446-499).  pse_set_neighbor_skin(h, 0) removes (1). */
+ * this stream.  By default the entry points are not free of host synchronisation: (1) with a neighbour skin in use (the
+ * default, below) every evaluation whose kept list may still be valid waits for the stream and reads one flag back before it
+ * queues anything (the distance check HOOMD's NeighborList does on the host side too); (2) Brownian calls read the Lanczos
+ * scalars back once per convergence check, as the reference does per iteration (PSEv1/Brownian.cu:446-499).
+ * pse_set_async(h, 1) (or pse_set_neighbor_skin(h, 0)) removes (1): deterministic evaluations then only queue work. */
 int pse_set_stream(pse_handle *h, void *hip_stream);
+/* Asynchronous submission (off by default).  With it on, the deterministic entry points (pse_mobility, pse_pair_repulsion) only
+ * QUEUE work on the handle's stream and return: nothing is read back, the host never waits, so a call can be captured into a
+ * hipGraph by the caller (hipStreamBeginCapture on the handle's stream ... pse_mobility ... hipStreamEndCapture) and replayed
+ * with new positions and forces in the same arrays -- tests/test_gpu_async.py does exactly that.  The price: whether a kept
+ * neighbour list is still valid is a fact that lives on the device, so in this mode the list is NOT kept -- every call sorts and
+ * walks the cells, as with r_buff = 0 (never a stale list).  Brownian calls still read the Lanczos scalars back once per
+ * convergence check (the tridiagonal square root is a host computation, as in the reference: PSEv1/Brownian.cu:540-582) and
+ * cannot be captured; per-phase timing (pse_set_timing) synchronises by definition.  One warm-up call outside the capture first
+ * (kernels set their shared-memory attributes on first use). */
+int pse_set_async(pse_handle *h, int enabled);
 /* Neighbour list kept across calls: replaces the NeighborListGPUBinned(rcut, r_buff = 0.4) with setEvery(1, dist_check)
  * that PSEv1/integrate.py:60,79 builds and Stokes::integrateStepOne refreshes with m_nlist->compute (PSEv1/Stokes.cc:433).
  * Pairs closer than rcut + r_buff are remembered at a build; later calls with the same N, group and box first check that no

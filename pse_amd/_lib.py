@@ -74,6 +74,7 @@ SYMBOLS = {
     "pse_set_box": (_i, [_vp, _d, _d, _d, _d]),
     "pse_set_stream": (_i, [_vp, _vp]),
     "pse_set_timing": (_i, [_vp, _i]),
+    "pse_set_async": (_i, [_vp, _i]),
     "pse_set_neighbor_skin": (_i, [_vp, _d]),
     "pse_neighbor_stats": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]),
     "pse_get_info": (_i, [_vp, ctypes.POINTER(pse_info)]),

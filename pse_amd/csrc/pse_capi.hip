@@ -46,6 +46,7 @@ using namespace pse;
     } while (0)
 
 constexpr int M_MAX = 100;   // Lanczos basis cap (PSEv1/Brownian.cu:397)
+constexpr int PH_COUNT_ = 13;   // timed phases (enum PH_* below)
 
 struct Phase {
     hipEvent_t a = nullptr, b = nullptr;
@@ -92,7 +93,8 @@ struct pse_handle {
     int *cell_cnt = nullptr;
     size_t sort_tmp_bytes = 0;
     int *cell_off = nullptr;
-    int4 *sup_s = nullptr;    // support origin of each sorted particle (node indices)
+    int *cnt_block = nullptr; // [far-field bin counts | the two flags of the kept neighbour list | cell counts]: zeroed by ONE memset per call
+    size_t cnt_bins = 0;      // ints of the bin counts (incl. the sentinel)
     SpreadWork sw = {};       // far-field bins and the bin-ordered particle records (origins, prefac * force, separable weights)
     NbList nb = {};
     bool nb_valid = false;   // the pair list matches the current sorted positions
@@ -117,6 +119,8 @@ struct pse_handle {
     int vl_kind = 0;             // kind of the call being prepared
     bool pv_is_f = false;        // the vector half of pv mirrors f_s (as the permute wrote it)
     bool w_is_mpsi = false;  // w_s already holds M_real psi_s (delivered by the pass that built the pair list)
+    bool sums0_done = false; // ... and scal[LZ_TMP ..] the sums psi.psi, psi.M psi of Lanczos iteration 0
+    bool async_mode = false; // pse_set_async: deterministic evaluations queue their work and return -- no flag read-back, capturable
     size_t n_cells_alloc = 0;
     float4 *posf_s = nullptr;   // single-precision copy of pos_s (cutoff pre-filter of the near field)
     double2 *pv = nullptr;      // [N][3] packed (position, Lanczos vector) records gathered by the pair-list mat-vec (single GPU)
@@ -152,7 +156,7 @@ struct pse_handle {
     // bookkeeping
     pse_info info;
     bool timing = false;
-    Phase ph[12];
+    Phase ph[PH_COUNT_];
     unsigned long long bytes = 0;
     int sorted_N = 0;
     bool matvec_timed = false;
@@ -206,7 +210,7 @@ static int set_cells(pse_handle *h, double gamma) {
     return 0;
 }
 
-enum { PH_SORT, PH_SPREAD, PH_FFTF, PH_SCALE, PH_FFTI, PH_GATHER, PH_REAL, PH_LANCZOS, PH_INTEG, PH_COMM, PH_TOTAL, PH_MATVEC };
+enum { PH_SORT, PH_SPREAD, PH_FFTF, PH_SCALE, PH_FFTI, PH_GATHER, PH_REAL, PH_LANCZOS, PH_INTEG, PH_COMM, PH_TOTAL, PH_MATVEC, PH_RECORDS, PH_COUNT };
 // Phase ranges for rocprofv3 --marker-trace (PSE_ROCTX=1): host-side roctx ranges around the launches of each phase (the
 // reference has one HOOMD Profiler push/pop around the whole step, PSEv1/Stokes.cc:450-451,519-521).  libroctx64 is
 // looked up at run time: no link dependency, nothing happens unless the switch is set.
@@ -225,8 +229,10 @@ struct Roctx {
     }
 };
 static const Roctx &roctx() { static Roctx r; return r; }
-static const char *const PH_NAME[12] = {"pse:sort", "pse:spread", "pse:fft_forward", "pse:kspace_scale", "pse:fft_inverse", "pse:gather",
-                                        "pse:near_field", "pse:lanczos", "pse:integrate", "pse:exchange", "pse:total", "pse:matvec"};
+static_assert(PH_COUNT == PH_COUNT_, "phase table");
+static const char *const PH_NAME[PH_COUNT] = {"pse:sort", "pse:spread", "pse:fft_forward", "pse:kspace_scale", "pse:fft_inverse", "pse:gather",
+                                              "pse:near_field", "pse:lanczos", "pse:integrate", "pse:exchange", "pse:total", "pse:matvec",
+                                              "pse:far_records"};
 static void range_push(int p) { if (roctx().push) roctx().push(PH_NAME[p]); }
 static void range_pop() { if (roctx().pop) roctx().pop(); }
 static int ts(pse_handle *h, int p) { range_push(p); if (h->timing) HIPCHK(hipEventRecord(h->ph[p].a, h->stream)); return 0; }
@@ -238,10 +244,10 @@ static int collect_times(pse_handle *h, unsigned mask) {
     if (!h->timing) return 0;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->side) HIPCHK(hipStreamSynchronize(h->side));
-    double *dst[12] = {&h->info.t_sort, &h->info.t_spread, &h->info.t_fft_fwd, &h->info.t_scale, &h->info.t_fft_inv,
-                       &h->info.t_gather, &h->info.t_real, &h->info.t_lanczos, &h->info.t_integrate, &h->info.t_comm,
-                       &h->info.t_total, &h->info.t_matvec};
-    for (int p = 0; p < 12; ++p) {
+    double *dst[PH_COUNT] = {&h->info.t_sort, &h->info.t_spread, &h->info.t_fft_fwd, &h->info.t_scale, &h->info.t_fft_inv,
+                             &h->info.t_gather, &h->info.t_real, &h->info.t_lanczos, &h->info.t_integrate, &h->info.t_comm,
+                             &h->info.t_total, &h->info.t_matvec, &h->info.t_records};
+    for (int p = 0; p < PH_COUNT; ++p) {
         *dst[p] = 0.0;
         if (mask & (1u << p)) {
             float ms = 0;
@@ -261,7 +267,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->plan_x_inv) rocfft_plan_destroy(h->plan_x_inv);
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
-    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cell_cnt, h->sup_s, h->sw.rec_t, h->sw.d0_s, h->sw.fb.cnt, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->nb.data, h->nb.cnt, h->vl.idx, h->vl.cnt, h->vl.flags, h->pos_build, h->pos_s, h->posf_s, h->pv,
+    void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cnt_block, h->sw.rec_t, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->nb.data, h->nb.cnt, h->vl.idx, h->vl.cnt, h->pos_build, h->pos_s, h->posf_s, h->pv,
                     h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->w2_s, h->u_s, h->pv2, h->twiddle, h->fft_work, h->V,
                     h->scal, h->partials};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -449,16 +455,22 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         auto cnt = [&](double w) { int c2 = (int)std::floor(w / rc); if (c2 < 3) c2 = 1; if (c2 > 1024) c2 = 1024; return (size_t)c2; };
         h->n_cells_alloc = cnt(h->box.Lx) * cnt(h->box.Ly) * (cnt(h->box.Lz) + 16);   // + the padding of the last z block (bz <= 16)
     }
-    TRY(dmalloc(h, &h->cell_off, h->n_cells_alloc + 1)); TRY(dmalloc(h, &h->cell_cnt, h->n_cells_alloc + 1));
+    TRY(dmalloc(h, &h->cell_off, h->n_cells_alloc + 1));
     h->sort_tmp_bytes = cell_sort_temp_bytes(h->n_cells_alloc);
     TRY(dmalloc(h, (char **)&h->sort_tmp, h->sort_tmp_bytes));
-    TRY(dmalloc(h, &h->sup_s, n));
-    if (d.P >= 4 && d.P <= FAR_PMAX) {   // fast far-field path: support offsets + separable weights 
-        TRY(dmalloc(h, &h->sw.d0_s, n));
+    // the counters every call starts from zero, side by side: [bin counts | flags[0], flags[1] | cell counts] -- one memset
+    // covers what a call needs (a call that checks the kept list stops after flags[0]: flags[1] is the mark of its build)
+    const size_t nbins = (size_t)((d.Nx + 7) / 8) * ((d.Ny + 7) / 8) * ((d.Nz + 7) / 8);
+    const bool fast_far = d.P >= 4 && d.P <= FAR_PMAX;
+    h->cnt_bins = fast_far ? nbins + 1 : 0;
+    TRY(dmalloc(h, &h->cnt_block, h->cnt_bins + 2 + h->n_cells_alloc + 1));
+    h->vl.flags = h->cnt_block + h->cnt_bins;
+    h->cell_cnt = h->vl.flags + 2;
+    if (fast_far) {   // fast far-field path: bin-ordered 64-byte records
+        h->sw.fb.cnt = h->cnt_block;
         TRY(dmalloc(h, (char **)&h->sw.rec_t, (n + 64) * 64));   // 64-byte records (idle lanes read past the last one)
         TRY(dmalloc(h, &h->sw.fb.rank_s, n));
-        const size_t nbins = (size_t)((d.Nx + 7) / 8) * ((d.Ny + 7) / 8) * ((d.Nz + 7) / 8);
-        TRY(dmalloc(h, &h->sw.fb.cnt, nbins + 1)); TRY(dmalloc(h, &h->sw.fb.off, nbins + 1));
+        TRY(dmalloc(h, &h->sw.fb.off, nbins + 1));
         h->sw.fb.tmp_bytes = bin_scan_temp_bytes(nbins);
         TRY(dmalloc(h, (char **)&h->sw.fb.tmp, h->sw.fb.tmp_bytes));
     }
@@ -483,9 +495,8 @@ static int create_impl(const pse_params *p, pse_handle *h) {
             const double rs = d.rcut + h->skin_max, nbar_v = (double)n / vol * 4.18879020478639 * rs * rs * rs;
             h->vl.cap = (std::max(16, std::min((int)std::ceil(2.0 * nbar_v + 32.0), 512)) + 3) & ~3;   // 4 bytes per slot: generous
             h->vl.rskin = rs;
-            TRY(dmalloc(h, (char **)&h->vl.idx, verlet_list_bytes(n + 64, h->vl.cap)));
+            TRY(dmalloc(h, (char **)&h->vl.idx, verlet_list_bytes(n + 1024, h->vl.cap)));   // + padding rows (the lanes past the last row of the build pass write there)
             TRY(dmalloc(h, &h->vl.cnt, n));
-            TRY(dmalloc(h, &h->vl.flags, 2));
             TRY(dmalloc(h, &h->pos_build, n));
             HIPCHK(hipHostMalloc((void **)&h->flags_host, 2 * sizeof(int)));
         }
@@ -617,6 +628,12 @@ extern "C" int pse_set_stream(pse_handle *h, void *stream) {
         FFTCHK(rocfft_execution_info_set_stream(h->info_fwd, h->wstream));
         FFTCHK(rocfft_execution_info_set_stream(h->info_inv, h->wstream));
     }
+    return 0;
+}
+extern "C" int pse_set_async(pse_handle *h, int enabled) {
+    if (!h) return fail(PSE_ERR_INVALID, "null handle");
+    h->async_mode = enabled != 0;
+    h->vl_valid = false;
     return 0;
 }
 extern "C" int pse_set_timing(pse_handle *h, int enabled) {
@@ -1006,19 +1023,22 @@ static CellRanges slab_need(const pse_handle *h) {
 // step, Stokes.cc:433): the particles are gathered into the order of the last sort, every one is compared with where it
 // was at the build, and one flag comes back to the host.  Kept: perm, the neighbour list; rebuilt as before: the far-field
 // records, the per-step (f, h) pair list.
+struct PrepExtra { bool psi; unsigned timestep; };   // psi: the pass also draws the particle noise of this step into psi_s
 static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const unsigned *group, int N, bool defer_bounds = false,
-                   bool need_cells = false) {
+                   bool need_cells = false, PrepExtra px = PrepExtra{false, 0}) {
     TRY(ts(h, PH_SORT));
+    const FarBinArgs far = far_bin_args(h->G, h->sw);
+    double4 *psi_out = px.psi ? h->psi_s : nullptr;
     h->nb_valid = false;
-    h->w_is_mpsi = false;
+    h->w_is_mpsi = false; h->sums0_done = false;
     h->vl_use = false;
     h->vl_pending = false;
     h->pv_is_f = vec != nullptr && h->pv != nullptr;
     const bool same_box = h->vl_box.Lx == h->box.Lx && h->vl_box.Ly == h->box.Ly && h->vl_box.Lz == h->box.Lz && h->vl_box.xy == h->box.xy;
-    if (h->skin > 0.0 && h->vl_valid && !need_cells && h->vl_N == N && h->vl_group == group && same_box && h->sorted_N == N) {
-        HIPCHK(hipMemsetAsync(h->vl.flags, 0, sizeof(int), h->stream));   // [0] only: [1] is the build's overflow mark
+    if (h->skin > 0.0 && !h->async_mode && h->vl_valid && !need_cells && h->vl_N == N && h->vl_group == group && same_box && h->sorted_N == N) {
+        HIPCHK(hipMemsetAsync(h->cnt_block, 0, (h->cnt_bins + 1) * sizeof(int), h->stream));   // bin counts + flags[0] ([1] is the build's overflow mark)
         launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream,
-                       h->pos_build, 0.25 * h->skin * h->skin, h->vl.flags);
+                       h->pos_build, 0.25 * h->skin * h->skin, h->vl.flags, CellRanges{}, nullptr, nullptr, &far, psi_out, h->par.seed, px.timestep);
         HIPCHK(hipMemcpyAsync(h->flags_host, h->vl.flags, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->flags_host[0] == 0 && h->flags_host[1] == 0) {
@@ -1038,8 +1058,9 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
     }
     h->vl_valid = false;
     ++h->nlist_builds;
-    const bool with_list = h->skin > 0.0 && h->vl_suspend_left[h->vl_kind] == 0;
-    if (h->skin > 0.0 && !with_list) --h->vl_suspend_left[h->vl_kind];
+    // (asynchronous mode: whether the kept list is still good is known on the device only -- it is not kept, every call builds)
+    const bool with_list = h->skin > 0.0 && !h->async_mode && h->vl_suspend_left[h->vl_kind] == 0;
+    if (h->skin > 0.0 && !h->async_mode && !with_list) --h->vl_suspend_left[h->vl_kind];
     if (h->skin_max > 0.0) {   // cells as wide as this build reaches: rcut + r_buff with the list, rcut without
         const bool wide = h->nc_wide;
         if (wide != with_list) {
@@ -1065,13 +1086,14 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
                 if (!kept((q * per + l) * layer)) { sb.book[q] = (q * per + l) * layer; break; }
         }
     }
+    // one memset: the bin counts, both flags of the kept list, the cell counts (+ the sentinel)
+    HIPCHK(hipMemsetAsync(h->cnt_block, 0, (h->cnt_bins + 2 + (size_t)ncell + 1) * sizeof(int), h->stream));
     HIPCHK(cell_sort(pos, group, N, h->dbox, h->nc, h->keys, h->vals, h->keys_s, h->cell_cnt, ncell, h->sort_tmp, h->sort_tmp_bytes,
-                     h->cell_off, h->perm, h->stream, need, sb));
+                     h->cell_off, h->perm, h->stream, need, sb, true));
     launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream, nullptr, 0.0, nullptr,
-                   need, h->cell_off, team_sstep(h) ? h->pv2 : nullptr);
+                   need, h->cell_off, team_sstep(h) ? h->pv2 : nullptr, &far, psi_out, h->par.seed, px.timestep);
     h->sorted_N = N;
     if (with_list) {   // the first cell pass of this call writes the list (real())
-        HIPCHK(hipMemsetAsync(h->vl.flags, 0, 2 * sizeof(int), h->stream));
         h->vl_pending = true; h->vl_N = N; h->vl_group = group;
         h->vl.rskin = h->d.rcut + h->skin;
         h->vl_reused_since_build = 0;
@@ -1108,9 +1130,12 @@ static int wave_compute(pse_team &T, const WaveArgs &a, int part) {
         const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzp;
         if (part == 0) {
             double *gx = h->rgrid, *gy = h->rgrid + nr, *gz = h->rgrid + 2 * nr;
+            TRY(tsw(h, PH_RECORDS));
+            HIPCHK(launch_far_records(h->pos_s, h->f_s, a.N, G, h->dbox, h->sw, h->wstream));
+            TRY(tew(h, PH_RECORDS));
             TRY(tsw(h, PH_SPREAD));
             if (spread_needs_zero(G)) HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->wstream));
-            HIPCHK(launch_spread(h->pos_s, h->f_s, h->sup_s, a.N, gx, gy, gz, G, h->dbox, h->sw, h->wstream));
+            HIPCHK(launch_spread(h->pos_s, h->f_s, a.N, gx, gy, gz, G, h->dbox, h->sw, h->wstream));
             TRY(tew(h, PH_SPREAD));
             TRY(tsw(h, PH_FFTF));
             if (GS == 1) {
@@ -1191,7 +1216,7 @@ struct WavePump {
                 HIPCHK(hipEventRecord(h->ev_fork, h->stream));
                 HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
             }
-        *mask |= (1u << PH_SPREAD) | (1u << PH_FFTF) | (1u << PH_SCALE) | (1u << PH_FFTI) | (1u << PH_GATHER);
+        *mask |= (1u << PH_SPREAD) | (1u << PH_FFTF) | (1u << PH_SCALE) | (1u << PH_FFTI) | (1u << PH_GATHER) | (1u << PH_RECORDS);
         if (T->m[0]->grid_slabs > 1) *mask |= 1u << PH_COMM;
         TRY(wave_compute(*T, a, 0));
         next = 1;
@@ -1255,7 +1280,9 @@ static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*ou
                      h->nc, h->d.rcut, h->d.self, h->coef, h->n_intervals * 2 * RS_NCOEF, h->nb, mode, h->stream,
                      psi ? h->psi_s : nullptr, h->w_s, h->vl, vlm,
                      vlm == VL_USE && v == h->f_s && h->pv_is_f ? h->pv : nullptr,
-                     psi && depth > 0 ? h->pv2 : nullptr);   // two-step Lanczos: the next mat-vec gathers w = M psi from the second records
+                     psi && depth > 0 ? h->pv2 : nullptr,    // two-step Lanczos: the next mat-vec gathers w = M psi from the second records
+                     psi && h->n_slabs == 1 ? h->partials : nullptr, h->npart_cap, h->scal);   // single GPU: + the sums of Lanczos iteration 0
+        h->sums0_done = psi && h->n_slabs == 1 && vlm != VL_USE && mreal_table_in_lds(h->n_intervals * 2 * RS_NCOEF);
         if (vlm == VL_WRITE) {   // the list now matches perm, pos_s and the box of this call
             HIPCHK(hipMemcpyAsync(h->pos_build, h->pos_s, (size_t)N * sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
             h->vl_pending = false; h->vl_valid = true; h->vl_box = h->box;
@@ -1306,10 +1333,10 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
                                          done > 0 ? h->pv : nullptr,   // x_j (j > 0) was packed by the previous update
                                          h->vl_use ? h->vl : VerletList{});
                     if (timed) h->matvec_timed = true;
-                } else {
+                } else if (!(done == 0 && h->sums0_done)) {   // (iteration 0: the sums came with the pass that built the pair list)
                     launch_lz_dots(xj, h->w_s, vjm1, lo, hi, h->partials, h->npart_cap, h->scal, h->stream);
                 }
-                h->w_is_mpsi = false;
+                h->w_is_mpsi = false; h->sums0_done = false;
             }
             // the partial sums and the ghost rows of y = M x_j in one exchange; every rank then updates its own rows AND its ghost
             // rows (it holds x_j and x_{j-1} there from the previous iteration), so x_{j+1} needs no exchange of its own
@@ -1539,7 +1566,8 @@ struct StepTail { const std::vector<StepArgs> *sa; double dt, shear_rate; };
 static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *group, int N, int parts, double kT, double dt,
                     unsigned timestep, int *m_io, unsigned *mask, const StepTail *tail = nullptr) {
     for (size_t r = 0; r < T.m.size(); ++r)
-        if (T.solo < 0 || T.m[r]->slab_rank == T.solo) TRY(prepare(T.m[r], a[r].pos, a[r].force, group, N, true));
+        if (T.solo < 0 || T.m[r]->slab_rank == T.solo)   // psi rides with the gather into cell order: the near-field pass that
+            TRY(prepare(T.m[r], a[r].pos, a[r].force, group, N, true, false, PrepExtra{kT > 0.0, timestep}));   // builds the pair list applies M_real to F and psi together
     *mask |= 1u << PH_SORT;
     const bool noise = kT > 0.0;
     const bool sstep = T.G > 1 && noise && (parts & 1) && team_sstep(T.m[0]);   // two Lanczos iterations per exchange
@@ -1563,9 +1591,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
     // back before it can finish the Brownian part, and meanwhile the GPU works through the far field instead of idling.
     const bool wave_behind = noise && (parts & 2) && (parts & 1) && !T.m[0]->side_on;
     if ((parts & 2) && !wave_behind) TRY(wave_start());
-    if (noise)   // psi first: the near-field pass that builds the pair list applies M_real to F and to psi together
-        for (pse_handle *h : act(T)) launch_psi(h->psi_s, h->tag_s, N, h->par.seed, timestep, h->stream, h->sw.need, h->cell_off);
-    // the slab row boundaries are needed from here on (a host round trip); the first part of the far-field chain and psi are queued
+    // the slab row boundaries are needed from here on (a host round trip); the first part of the far-field chain is queued
     for (pse_handle *h : act(T)) TRY(slab_bounds_wait(h, N));
     if (parts & 1) {
         for (pse_handle *h : act(T)) TRY(ts(h, PH_REAL));
@@ -1801,7 +1827,8 @@ extern "C" int pse_debug_spread(pse_handle *h, const pse_double4 *pos, const pse
     const DGrid &G = h->G;
     const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz;
     if (spread_needs_zero(G)) HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->stream));
-    HIPCHK(launch_spread(h->pos_s, h->f_s, h->sup_s, (int)N, h->rgrid, h->rgrid + nr, h->rgrid + 2 * nr, G, h->dbox, h->sw, h->stream));
+    HIPCHK(launch_far_records(h->pos_s, h->f_s, (int)N, G, h->dbox, h->sw, h->stream));
+    HIPCHK(launch_spread(h->pos_s, h->f_s, (int)N, h->rgrid, h->rgrid + nr, h->rgrid + 2 * nr, G, h->dbox, h->sw, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }

@@ -14,6 +14,7 @@
 //   az[t] = exp(-c (Z0 + hz t)^2)                      K[t][v] = exp(-2 c s hx hy t v)   (the same for every particle)
 // and each of ax, ay, az obeys E(t+1) = E(t) q r_t with r_t independent of the particle (GaussConsts).
 #include "pse_kernels.h"
+#include "pse_farbin.h"
 
 #include <hipcub/hipcub.hpp>
 #include <type_traits>
@@ -22,11 +23,6 @@ namespace pse {
 
 static inline int nblocks(long n, int tpb) { return (int)((n + tpb - 1) / tpb); }
 
-constexpr int BIN = 8;
-__host__ __device__ inline int bins_of(int n) { return (n + BIN - 1) / BIN; }
-__device__ __forceinline__ int bin_index(int ox, int oy, int oz, const FarBins &fb) {
-    return ((ox / BIN) * fb.nby + (oy / BIN)) * fb.nbz + (oz / BIN);
-}
 
 struct FarRec {
     int ox, oy, oz;          // support origin (first node per axis), wrapped into the grid
@@ -35,15 +31,6 @@ struct FarRec {
     double fx, fy, fz;       // prefac * force
 };
 static_assert(sizeof(FarRec) == 64, "record is four 16-byte loads");
-
-// Support of a particle (PSEv1/Mobility.cu:173-219): first node index per axis (unwrapped) and the offset of
-// that node from the particle in grid units.
-__device__ __forceinline__ void support_start(double f, int n, int P, int &start, double &delta0) {
-    const double s = f * n;
-    const int i0 = (int)s;
-    start = i0 - P / 2 + 1 - ((P & 1) && (s - i0 < 0.5) ? 1 : 0);
-    delta0 = start - s;
-}
 
 // one axis: E(t) for t = 0..P-1 from E(0) = exp(e0), ratio exp(lq) r_t
 template <int P>
@@ -93,75 +80,28 @@ __device__ __forceinline__ int fdiv(int n, FastDiv q, int &rem) {
     return k;
 }
 
-// ---- binning -----------------------------------------------------------------------------------------------------
-// support origin (wrapped into the grid), offset of the origin from the particle, the particle's own node plane, and its
-// rank inside its bin (-1: a slab rank never touches this particle)
-__global__ void k_support(const double4 *__restrict__ pos_s, int N, DGrid G, DBox box, int4 *__restrict__ sup_s,
-                          double4 *__restrict__ d0_s, FarBins fb, CellRanges rows, const int *__restrict__ cell_off) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s - (int)(threadIdx.x & 63) >= N) return;          // whole wave past the end
-    const bool held = s < N && rows.row(s, cell_off);      // a slab rank holds particle data for its own and its ghost rows only
-    if (__ballot(held) == 0ull) {
-        if (s < N && fb.cnt) fb.rank_s[s] = -1;
-        return;
-    }
-    const bool live = held;
-    const double4 p = pos_s[live ? s : N - 1];
-    double fx, fy, fz;
-    frac_coords(box, p.x, p.y, p.z, fx, fy, fz);
-    int4 o;
-    double4 d;
-    support_start(fx, G.Nx, G.P, o.x, d.x);   // PSEv1/Mobility.cu:212-214
-    support_start(fy, G.Ny, G.P, o.y, d.y);
-    support_start(fz, G.Nz, G.P, o.z, d.z);
-    o.x = wrapi(o.x, G.Nx); o.y = wrapi(o.y, G.Ny); o.z = wrapi(o.z, G.Nz);
-    o.w = min((int)(fx * G.Nx), G.Nx - 1);   // the node plane the particle sits in: decides which slab owns it
-    d.w = 0.0;
-    if (live) {
-        sup_s[s] = o;
-        if (d0_s) d0_s[s] = d;
-    }
-    if (fb.cnt) {
-        bool need = live;
-        if (G.nxl < G.Nx) need = need && wrapi(o.w - (G.x0 - G.P), G.Nx) < G.nxl + 2 * G.P;   // within a support of the slab's planes
-        // Neighbouring lanes are neighbouring particles and mostly share a bin: one atomic per distinct bin of the wave
-        // (the leader adds the group's size, members take consecutive ranks) instead of 64 same-address atomics.
-        const int bin = need ? bin_index(o.x, o.y, o.z, fb) : -1;
-        const int lane = threadIdx.x & 63;
-        const unsigned long long below = (1ull << lane) - 1ull;
-        unsigned long long todo = __ballot(need);
-        int prefix = 0, count = 0, leader = lane;
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            const int b0 = __shfl(bin, src, 64);
-            const unsigned long long m = __ballot(bin == b0) & todo;
-            if (bin == b0) { prefix = __popcll(m & below); count = __popcll(m); leader = src; }
-            todo &= ~m;
-        }
-        int base = 0;
-        if (need && leader == lane) base = atomicAdd(&fb.cnt[bin], count);
-        base = __shfl(base, leader, 64);
-        if (live) fb.rank_s[s] = need ? base + prefix : -1;
-        else if (s < N) fb.rank_s[s] = -1;
-    }
-}
-
+// ---- binning: far_bin_particle (pse_farbin.h), called by the gather-into-cell-order pass k_permute -------------------------
 size_t bin_scan_temp_bytes(size_t nbins) {
     size_t bytes = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int *)nullptr, (int *)nullptr, (int)(nbins + 1));
     return bytes;
 }
 
-// the records, in bin order
+bool farfield_fast_path(const DGrid &G);
+// the records, in bin order (the support is recomputed from the sorted position: nothing was parked for this kernel)
 __global__ void __launch_bounds__(256)
-k_far_records(const int4 *__restrict__ sup_s, const double4 *__restrict__ d0_s, const double4 *__restrict__ f_s, int N, DGrid G,
+k_far_records(const double4 *__restrict__ pos_s, const double4 *__restrict__ f_s, int N, DGrid G, DBox box,
               FarBins fb, FarRec *__restrict__ rec) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
     const int rank = fb.rank_s[p];
     if (rank < 0) return;
-    const int4 sp = sup_s[p];
-    const double4 d0 = d0_s[p];
+    const double4 q = pos_s[p];
+    double fx, fy, fz;
+    frac_coords(box, q.x, q.y, q.z, fx, fy, fz);
+    int4 sp;
+    double4 d0;
+    far_support(fx, fy, fz, G, sp, d0);
     const double4 F = f_s[p];
     const int slot = fb.off[bin_index(sp.x, sp.y, sp.z, fb)] + rank;
     const bool owned = G.nxl == G.Nx || wrapi(sp.w - G.x0, G.Nx) < G.nxl;
@@ -173,20 +113,28 @@ k_far_records(const int4 *__restrict__ sup_s, const double4 *__restrict__ d0_s, 
     o[3] = make_double2(G.prefac * F.y, G.prefac * F.z);
 }
 
-static hipError_t build_records(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, DGrid G, DBox box, SpreadWork &w,
-                                FarBins &fb, hipStream_t s) {
-    fb = w.fb;
+// bin offsets + records; the bin counts and ranks come from the gather-into-cell-order pass (far_bin_args / k_permute)
+hipError_t launch_far_records(const double4 *pos_s, const double4 *f_s, int N, DGrid G, DBox box, SpreadWork w, hipStream_t s) {
+    if (!farfield_fast_path(G) || !w.rec_t) return hipSuccess;
+    FarBins fb = w.fb;
     fb.nbx = bins_of(G.Nx); fb.nby = bins_of(G.Ny); fb.nbz = bins_of(G.Nz);
     const int nbins = fb.nbx * fb.nby * fb.nbz;
-    hipError_t e = hipMemsetAsync(fb.cnt, 0, (size_t)(nbins + 1) * sizeof(int), s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_support, dim3(nblocks(N, 256)), dim3(256), 0, s, pos_s, N, G, box, sup_s, w.d0_s, fb, w.need, w.cell_off);
     size_t tb = fb.tmp_bytes;
-    e = hipcub::DeviceScan::ExclusiveSum(fb.tmp, tb, fb.cnt, fb.off, nbins + 1, s);   // cnt[nbins] = 0: off[nbins] = total
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(fb.tmp, tb, fb.cnt, fb.off, nbins + 1, s);   // cnt[nbins] = 0: off[nbins] = total
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_far_records, dim3(nblocks(N, 256)), dim3(256), 0, s, sup_s, w.d0_s, f_s, N, G, fb, w.rec_t);
-    return hipSuccess;
+    hipLaunchKernelGGL(k_far_records, dim3(nblocks(N, 256)), dim3(256), 0, s, pos_s, f_s, N, G, box, fb, w.rec_t);
+    return hipGetLastError();
 }
+// what the gather-into-cell-order pass needs to rank the particles in their bins (on = false: the generic far field, no bins)
+FarBinArgs far_bin_args(const DGrid &G, const SpreadWork &w) {
+    FarBinArgs a{};
+    a.on = farfield_fast_path(G) && w.rec_t != nullptr;
+    a.G = G;
+    a.fb = w.fb;
+    a.fb.nbx = bins_of(G.Nx); a.fb.nby = bins_of(G.Ny); a.fb.nbz = bins_of(G.Nz);
+    return a;
+}
+size_t far_bin_count(const DGrid &G) { return (size_t)bins_of(G.Nx) * bins_of(G.Ny) * bins_of(G.Nz) + 1; }
 
 // ---- spread ------------------------------------------------------------------------------------------------------
 // Register-accumulating spread: a wavefront owns an 8 x 8 x TZ block of grid nodes -- lane = (x,y) column, TZ x 3
@@ -485,14 +433,14 @@ static void launch_spread_p(const FarRec *rec, FarBins fb, double *gx, double *g
     else launch_spread_pt<P, 8, 1>(rec, fb, gx, gy, gz, G, gc, s);
 }
 
-hipError_t launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, double *gx, double *gy, double *gz, DGrid G,
+hipError_t launch_spread(const double4 *pos_s, const double4 *f_s, int N, double *gx, double *gy, double *gz, DGrid G,
                          DBox box, SpreadWork w, hipStream_t s) {
     if (!farfield_fast_path(G) || !w.rec_t) {
         hipLaunchKernelGGL(k_spread_atomic, dim3(nblocks(N, 4)), dim3(256), 0, s, pos_s, f_s, N, gx, gy, gz, G, box, w.need, w.cell_off);
         return hipGetLastError();
     }
-    FarBins fb;
-    if (hipError_t e = build_records(pos_s, f_s, sup_s, N, G, box, w, fb, s); e != hipSuccess) return e;
+    FarBins fb = w.fb;   // the records of this step are in place (launch_far_records)
+    fb.nbx = bins_of(G.Nx); fb.nby = bins_of(G.Ny); fb.nbz = bins_of(G.Nz);
     const GaussConsts gc = gauss_consts(G, box.xy);
     switch (G.P) {
 #define PSE_SPREAD_CASE(PV) case PV: launch_spread_p<PV>(w.rec_t, fb, gx, gy, gz, G, gc, w.force_tz, w.force_nw, s); break;

@@ -36,6 +36,7 @@ struct RowMap {
     int n, lo[3], hi[3], base[3];
     __host__ __device__ int list_rows() const { return n ? base[n - 1] + ((hi[n - 1] - lo[n - 1] + 255) & ~255) : 0; }
     // sorted row of list row lr, or -1 (padding)
+    __device__ __forceinline__ int first_row() const { return hi[0] > lo[0] ? lo[0] : (n > 1 && hi[1] > lo[1] ? lo[1] : lo[2]); }
     __device__ __forceinline__ int row(int lr) const {
         int k = 0;
         if (n > 1 && lr >= base[1]) k = 1;
@@ -58,7 +59,7 @@ inline RowMap row_map(const int (*rg)[2], int n) {
 struct SlabBook { int n, cells_per_slab, spread, book[64]; };   // spread: the counts go to cells book[slab] .. book[slab] + spread - 1 (one layer)
 hipError_t cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys, unsigned *rank,
                      unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s,
-                     CellRanges need = CellRanges{}, SlabBook sb = SlabBook{});
+                     CellRanges need = CellRanges{}, SlabBook sb = SlabBook{}, bool cnt_is_zero = false);   // cnt[0 .. ncell] already zeroed by the caller
 // pos_s[i] = wrapped position of particle perm[i], vec_s[i] = vec[tag].xyz, tag_s[i] = its index in the caller's arrays
 // pos_build (nullable): the sorted positions the neighbour list was built at; a particle that has moved more than
 // sqrt(half_skin2) from there (minimum image) sets flags[0] -- HOOMD's NeighborList distance check (r_buff / 2)
@@ -66,7 +67,9 @@ void launch_permute(const double4 *pos, const double4 *vec, const unsigned *grou
                     double4 *pos_s, float4 *posf_s, double2 *pv, double4 *vec_s, unsigned *tag_s, hipStream_t s,
                     const double4 *pos_build = nullptr, double half_skin2 = 0.0, int *flags = nullptr,
                     CellRanges need = CellRanges{}, const int *cell_off = nullptr,    // a slab rank: the needed rows only
-                    double2 *pv2 = nullptr);                                          // second set of packed records (position half)
+                    double2 *pv2 = nullptr,                                           // second set of packed records (position half)
+                    const struct FarBinArgs *far = nullptr,                           // rank the particles in their far-field bins
+                    double4 *psi_s = nullptr, uint32_t seed = 0, uint32_t timestep = 0);   // draw the particle noise of this step (K14)
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s);
 
 // ---- near field (K9) -------------------------------------------------------------------------------------
@@ -113,7 +116,8 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
                   int mode, hipStream_t s, const double4 *vec2_s = nullptr, double4 *out2_s = nullptr,   // BUILD_LIST: a second vector rides along
                   VerletList vl = VerletList{}, int vl_mode = VL_NONE,   // VL_WRITE: the cell pass also writes the neighbour list; VL_USE: no cell walk
                   const double2 *pv = nullptr,                           // VL_USE: packed (position, vec_s) records
-                  double2 *pv_out = nullptr);                            // BUILD_LIST with a second vector: out2 also goes into these records
+                  double2 *pv_out = nullptr,                             // BUILD_LIST with a second vector: out2 also goes into these records
+                  double *sums0 = nullptr, int sums0_cap = 0, double *scal = nullptr);   // ... and the sums vec2.vec2, vec2.out2 are left in scal[LZ_TMP ..] (Lanczos iteration 0)
 bool mreal_table_in_lds(int ncoef);   // the neighbour list across steps needs the LDS copy of the table
 // pair-list mat-vec + Lanczos sums; leaves the three reduced sums in scal[LZ_TMP .. LZ_TMP + 2]
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, RowMap rows, const int *cell_off,
@@ -138,7 +142,6 @@ struct FarBins {
 size_t bin_scan_temp_bytes(size_t nbins);
 struct FarRec;                  // 64-byte bin-ordered particle record (pse_farfield.hip)
 struct SpreadWork {
-    double4 *d0_s;              // [N] offset of the support origin from the particle, grid units (cell order)
     FarBins fb;
     FarRec *rec_t;              // [N] bin order: origin, sorted index (bit 31: owned by another slab rank), offset, prefac * force
     int force_tz, force_nw;     // tuning switches of the handle (0: automatic): z depth of a spread block, waves per block
@@ -152,7 +155,14 @@ struct GaussConsts { double rx[FAR_PMAX - 1], ry[FAR_PMAX - 1], rz[FAR_PMAX - 1]
 size_t farfield_bins(const DGrid &G);
 // true if the caller must zero the grids first (atomic fallback: P outside 4..8 or a grid smaller than two tiles)
 bool spread_needs_zero(const DGrid &G);
-hipError_t launch_spread(const double4 *pos_s, const double4 *f_s, int4 *sup_s, int N, double *gx, double *gy, double *gz, DGrid G,
+// The far field of a step: (1) the pass that gathers the particles into cell order (launch_permute) ranks every particle inside
+// its bin (FarBinArgs; the bin counts are zeroed by the caller before it); (2) launch_far_records: bin offsets + the 64-byte
+// records in bin order; (3) launch_spread; ... (4) launch_gather, which reads the same records.
+struct FarBinArgs { bool on; DGrid G; FarBins fb; };
+FarBinArgs far_bin_args(const DGrid &G, const SpreadWork &w);
+size_t far_bin_count(const DGrid &G);   // ints of fb.cnt to zero
+hipError_t launch_far_records(const double4 *pos_s, const double4 *f_s, int N, DGrid G, DBox box, SpreadWork w, hipStream_t s);
+hipError_t launch_spread(const double4 *pos_s, const double4 *f_s, int N, double *gx, double *gy, double *gz, DGrid G,
                    DBox box, SpreadWork w, hipStream_t s);
 struct ScaleArgs {
     double xi, eta;

@@ -1,6 +1,7 @@
 // HIP kernels of the PSE engine for gfx950 (CDNA4, wave64).  Each kernel names the reference kernel it
 // replaces.  All arithmetic is fp64.
 #include "pse_kernels.h"
+#include "pse_farbin.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -111,8 +112,8 @@ size_t cell_sort_temp_bytes(size_t ncell) {
 }
 hipError_t cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys, unsigned *rank,
                      unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s,
-                     CellRanges need, SlabBook sb) {
-    hipError_t e = hipMemsetAsync(cnt, 0, (size_t)(ncell + 1) * sizeof(int), s);
+                     CellRanges need, SlabBook sb, bool cnt_is_zero) {
+    hipError_t e = cnt_is_zero ? hipSuccess : hipMemsetAsync(cnt, 0, (size_t)(ncell + 1) * sizeof(int), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_cell_keys, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, group, N, box, nc, keys, rank, cnt, need, sb);
     // cnt[ncell] = 0: cell_off[ncell] = N.  A failed scan (scratch too small for ncell) would leave garbage offsets: reported
@@ -123,51 +124,81 @@ hipError_t cell_sort(const double4 *pos, const unsigned *group, int N, DBox box,
     return hipGetLastError();
 }
 
-__global__ void k_permute(const double4 *__restrict__ pos, const double4 *__restrict__ vec,
+// Gather into cell order: wrapped sorted positions (+ the float copy and the packed records of the near field), the vector, the tags
+// -- and, since round 4, what used to be two more launches over the same rows: the rank of every particle inside its far-field bin
+// (far.on; was k_support) and the particle noise of the step (psi_s; K14 gpu_stokes_BrownianGenerate_kernel, PSEv1/Brownian.cu:99-130).
+__global__ void __launch_bounds__(TPB)
+k_permute(const double4 *__restrict__ pos, const double4 *__restrict__ vec,
                           const unsigned *__restrict__ group, const unsigned *__restrict__ perm, int N, DBox box,
                           double4 *__restrict__ pos_s, float4 *__restrict__ posf_s, double2 *__restrict__ pv,
                           double4 *__restrict__ vec_s, unsigned *__restrict__ tag_s, const double4 *__restrict__ pos_build,
                           double half_skin2, int *__restrict__ flags, CellRanges need, const int *__restrict__ cell_off,
-                          double2 *__restrict__ pv2) {
+                          double2 *__restrict__ pv2, FarBinArgs far, double4 *__restrict__ psi_s, uint32_t seed, uint32_t timestep) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= N || !need.row(s, cell_off)) return;
-    const unsigned g = perm[s];
-    const unsigned idx = group ? group[g] : g;
-    const double4 p = pos[idx];
-    // wrap into the primary cell (keeps sheared images consistent: y images shift x by xy*Ly)
-    double fx, fy, fz;
-    frac_coords(box, p.x, p.y, p.z, fx, fy, fz);
-    const double y = (fy - 0.5) * box.Ly;
-    double4 q;
-    q.x = (fx - 0.5) * box.Lx + box.xy * y;
-    q.y = y;
-    q.z = (fz - 0.5) * box.Lz;
-    q.w = 0.0;
-    pos_s[s] = q;
-    posf_s[s] = make_float4((float)q.x, (float)q.y, (float)q.z, 0.0f);   // single-precision copy for the cutoff pre-filter
-    if (pv) {   // packed 48-byte (position, vector) records of the pair-list mat-vec: the position half
-        pv[3 * (size_t)s] = make_double2(q.x, q.y);
-        ((double *)&pv[3 * (size_t)s + 1])[0] = q.z;
-    }
-    if (pv2) {   // a team's second set of records (the two-step Lanczos gathers q from one and w1 = M q from the other)
-        pv2[3 * (size_t)s] = make_double2(q.x, q.y);
-        ((double *)&pv2[3 * (size_t)s + 1])[0] = q.z;
-    }
-    tag_s[s] = idx;
-    if (vec) {
-        double4 v = vec[idx];
-        v.w = 0.0;
-        vec_s[s] = v;
-        if (pv) {   // the vector half: the neighbour-list pass gathers (position, force) as one record
-            ((double *)&pv[3 * (size_t)s + 1])[1] = v.x;
-            pv[3 * (size_t)s + 2] = make_double2(v.y, v.z);
+    if (s - (int)(threadIdx.x & 63) >= N) return;            // whole wave past the end
+    const bool live = s < N && need.row(s, cell_off);        // a slab rank holds particle data for its own and its ghost rows only
+    bool bin_need = false;
+    int bin = -1;
+    if (live) {
+        const unsigned g = perm[s];
+        const unsigned idx = group ? group[g] : g;
+        const double4 p = pos[idx];
+        // wrap into the primary cell (keeps sheared images consistent: y images shift x by xy*Ly)
+        double fx, fy, fz;
+        frac_coords(box, p.x, p.y, p.z, fx, fy, fz);
+        const double y = (fy - 0.5) * box.Ly;
+        double4 q;
+        q.x = (fx - 0.5) * box.Lx + box.xy * y;
+        q.y = y;
+        q.z = (fz - 0.5) * box.Lz;
+        q.w = 0.0;
+        pos_s[s] = q;
+        posf_s[s] = make_float4((float)q.x, (float)q.y, (float)q.z, 0.0f);   // single-precision copy for the cutoff pre-filter
+        if (pv) {   // packed 48-byte (position, vector) records of the pair-list mat-vec: the position half
+            pv[3 * (size_t)s] = make_double2(q.x, q.y);
+            ((double *)&pv[3 * (size_t)s + 1])[0] = q.z;
+        }
+        if (pv2) {   // a team's second set of records (the two-step Lanczos gathers q from one and w1 = M q from the other)
+            pv2[3 * (size_t)s] = make_double2(q.x, q.y);
+            ((double *)&pv2[3 * (size_t)s + 1])[0] = q.z;
+        }
+        tag_s[s] = idx;
+        if (vec) {
+            double4 v = vec[idx];
+            v.w = 0.0;
+            vec_s[s] = v;
+            if (pv) {   // the vector half: the neighbour-list pass gathers (position, force) as one record
+                ((double *)&pv[3 * (size_t)s + 1])[1] = v.x;
+                pv[3 * (size_t)s + 2] = make_double2(v.y, v.z);
+            }
+        }
+        if (pos_build) {   // distance check of the kept neighbour list
+            const double4 b = pos_build[s];
+            double dx = q.x - b.x, dy = q.y - b.y, dz = q.z - b.z;
+            min_image(box, dx, dy, dz);
+            if (dx * dx + dy * dy + dz * dz > half_skin2) flags[0] = 1;
+        }
+        if (psi_s) {       // K14, keyed by the particle's global index
+            uint32_t r[4];
+            philox4x32(idx, 0u, timestep, DOMAIN_PARTICLE, seed, PHILOX_KEY1, r);
+            const double c = 1.7320508075688772;  // sqrt(3): variance 1
+            psi_s[s] = make_double4(uniform_pm(r[0], c), uniform_pm(r[1], c), uniform_pm(r[2], c), 0.0);
+        }
+        if (far.on) {      // the far-field bin of the particle, from the fractional coordinates of the STORED position (as k_far_records
+                           // recomputes them: both must name the same bin)
+            double gx, gy, gz;
+            frac_coords(box, q.x, q.y, q.z, gx, gy, gz);
+            int4 o;
+            double4 d;
+            far_support(gx, gy, gz, far.G, o, d);
+            bin_need = true;
+            if (far.G.nxl < far.G.Nx) bin_need = wrapi(o.w - (far.G.x0 - far.G.P), far.G.Nx) < far.G.nxl + 2 * far.G.P;   // within a support of the slab's planes
+            bin = bin_index(o.x, o.y, o.z, far.fb);
         }
     }
-    if (pos_build) {   // distance check of the kept neighbour list
-        const double4 b = pos_build[s];
-        double dx = q.x - b.x, dy = q.y - b.y, dz = q.z - b.z;
-        min_image(box, dx, dy, dz);
-        if (dx * dx + dy * dy + dz * dz > half_skin2) flags[0] = 1;
+    if (far.on) {
+        const int rk = far_bin_rank(bin_need, bin, far.fb.cnt);
+        if (s < N) far.fb.rank_s[s] = rk;
     }
 }
 
@@ -182,9 +213,10 @@ __global__ void k_permute_vec(const double4 *__restrict__ vec, const unsigned *_
 
 void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm, int N, DBox box,
                     double4 *pos_s, float4 *posf_s, double2 *pv, double4 *vec_s, unsigned *tag_s, hipStream_t s,
-                    const double4 *pos_build, double half_skin2, int *flags, CellRanges need, const int *cell_off, double2 *pv2) {
+                    const double4 *pos_build, double half_skin2, int *flags, CellRanges need, const int *cell_off, double2 *pv2,
+                    const FarBinArgs *far, double4 *psi_s, uint32_t seed, uint32_t timestep) {
     hipLaunchKernelGGL(k_permute, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, vec, group, perm, N, box, pos_s, posf_s, pv, vec_s, tag_s,
-                       pos_build, half_skin2, flags, need, cell_off, pv2);
+                       pos_build, half_skin2, flags, need, cell_off, pv2, far ? *far : FarBinArgs{}, psi_s, seed, timestep);
 }
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s) {
     hipLaunchKernelGGL(k_permute_vec, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, vec, tag_s, N, vec_s);
@@ -237,7 +269,8 @@ __global__ void __launch_bounds__(TPB, ((LIST && CL && !VL) ? 3 : 1))   // the l
 k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf_s, const double4 *__restrict__ vec_s,
               double4 *__restrict__ out_s, RowMap rm, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2,
               float rcut2_pre, double self, const double *__restrict__ coef_g, int ncoef, NbList nb,
-              const double4 *__restrict__ vec2_s, double4 *__restrict__ out2_s, VerletList vl, double2 *__restrict__ pv_out) {
+              const double4 *__restrict__ vec2_s, double4 *__restrict__ out2_s, VerletList vl, double2 *__restrict__ pv_out,
+              double *__restrict__ sums0, int sums0_cap) {
     // the pass that also writes the kept neighbour list queues every pair within rcut + r_buff (28 per row instead of 21): a deeper
     // queue, or half of the waves would stop for an extra, poorly filled drain in the middle of the walk
     constexpr int QC = VL ? 64 : QCAP;
@@ -252,8 +285,12 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
     }
     const double *coef = CL ? scoef : coef_g;
     const int lr = xcd_block(blockIdx.x, gridDim.x) * TPB + tid;       // list row -> sorted row (own rows, then ghost layers)
-    const int i = rm.row(lr);
-    if (i < 0) return;
+    const int i_own = rm.row(lr);
+    // a padding lane repeats the first row (identical stores, into the same places or into padding list rows) instead of leaving:
+    // the wave-level sums at the end then see every lane
+    const bool padding = i_own < 0;
+    if (padding && !(TWO && sums0)) return;
+    const int i = padding ? rm.first_row() : i_own;
     const double4 pi = pos_s[i];
     const double4 vi = vec_s[i];
     double ux = self * vi.x, uy = self * vi.y, uz = self * vi.z;
@@ -415,6 +452,15 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
         if (pv_out) {   // the vector half of the packed records the NEXT mat-vec gathers (two-step Lanczos of a team: w = M psi)
             ((double *)&pv_out[3 * (size_t)i + 1])[1] = wx;
             pv_out[3 * (size_t)i + 2] = make_double2(wy, wz);
+        }
+        if (sums0) {    // the sums of Lanczos iteration 0 (x = psi, y = M psi): x.x and x.y per wavefront (was k_lz_dots: one more pass over both)
+            const double4 v2 = vec2_s[i];
+            const double a = padding ? 0.0 : v2.x * v2.x + v2.y * v2.y + v2.z * v2.z, b = padding ? 0.0 : v2.x * wx + v2.y * wy + v2.z * wz;
+            const double sa = wave_sum(a), sb = wave_sum(b);
+            if ((tid & 63) == 0) {
+                const int slot = blockIdx.x * (TPB / 64) + (tid >> 6);
+                sums0[slot] = sa; sums0[sums0_cap + slot] = sb; sums0[2 * sums0_cap + slot] = 0.0;
+            }
         }
     }
     if (LIST) {
@@ -695,13 +741,14 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
     }
 }
 
+__global__ void __launch_bounds__(1024) k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, double *__restrict__ scal);
 static size_t mreal_lds_bytes(int ncoef) { return (size_t)(ncoef / (2 * RS_NCOEF)) * (2 * RS_NCOEF + 1) * sizeof(double); }   // padded copy
 bool mreal_table_in_lds(int ncoef) { return mreal_lds_bytes(ncoef) <= 14 * 1024; }   // with the 44 KB queue: three workgroups per CU up to 9 KB of table, two beyond
 
 void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec_s, double4 *out_s, RowMap rm,
                   const int *cell_off, DBox box, DCells nc, double rcut, double self, const double *coef, int ncoef, NbList nb,
                   int mode, hipStream_t s, const double4 *vec2_s, double4 *out2_s, VerletList vl, int vl_mode, const double2 *pv,
-                  double2 *pv_out) {
+                  double2 *pv_out, double *sums0, int sums0_cap, double *scal) {
     const int rows = rm.list_rows();
     if (rows <= 0) return;
     const dim3 g(nblocks(rows, TPB)), b(TPB);
@@ -730,7 +777,7 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
     const double cmax = 1.5 * (box.Lx + std::fabs(box.xy) * box.Ly + box.Ly + box.Lz);
     const double rpre = (wr ? vl.rskin : rcut) + 16.0 * cmax * 5.97e-8;
     const float rcut2_pre = (float)(rpre * rpre * (1.0 + 1e-6));
-#define PSE_CELLS(L, C, T, V) hipLaunchKernelGGL((k_mreal_cells<L, C, T, V>), g, b, (C) ? cb : 0, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, two ? vec2_s : nullptr, out2_s, vl, two ? pv_out : nullptr)
+#define PSE_CELLS(L, C, T, V) hipLaunchKernelGGL((k_mreal_cells<L, C, T, V>), g, b, (C) ? cb : 0, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, two ? vec2_s : nullptr, out2_s, vl, two ? pv_out : nullptr, (two && (C)) ? sums0 : nullptr, sums0_cap)
     if (list) {
         if (cl && two) { if (wr) PSE_CELLS(true, true, true, true); else PSE_CELLS(true, true, true, false); }
         else if (cl) { if (wr) PSE_CELLS(true, true, false, true); else PSE_CELLS(true, true, false, false); }
@@ -738,6 +785,8 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
     } else if (cl) { if (wr) PSE_CELLS(false, true, false, true); else PSE_CELLS(false, true, false, false); }
     else PSE_CELLS(false, false, false, false);
 #undef PSE_CELLS
+    if (sums0 && list && two && cl)   // one partial per wavefront of the pass -> scal[LZ_TMP .. LZ_TMP + 2]
+        hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, sums0, (int)g.x * (TPB / 64), sums0_cap, 3, scal);
 }
 
 __global__ void __launch_bounds__(1024) k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, double *__restrict__ scal);

@@ -94,6 +94,10 @@ class Engine:
     def set_timing(self, on=True):
         _lib.check(self._lib.pse_set_timing(self._h, 1 if on else 0))
 
+    def set_async(self, on=True):
+        """Deterministic evaluations only queue work (no read-back, capturable into a hipGraph); the neighbour list is not kept."""
+        _lib.check(self._lib.pse_set_async(self._h, 1 if on else 0))
+
     def set_neighbor_skin(self, r_buff):
         """r_buff of the neighbour list kept across calls (HOOMD's nlist r_buff, PSEv1/integrate.py:60); 0 rebuilds every call."""
         _lib.check(self._lib.pse_set_neighbor_skin(self._h, float(r_buff)))

@@ -74,6 +74,8 @@ struct pse_handle {
         double skin = 0.4;        // PSE_SKIN: r_buff of the neighbour list kept across calls (0: off)
         int overlap = 0;          // PSE_OVERLAP: 1 two chains for every call, 0 (default) only for kT = 0, -1 never
         bool no_xfuse = false;    // PSE_NO_XFUSE: rocFFT for the x pass
+        int own_y = 1;            // PSE_OWN_Y=0: rocFFT's 2-D (y, z) transforms also where the own y pass applies
+        int yfft_kb = 4;          // PSE_YFFT_KB: kz columns per workgroup of the own y pass (2, 4, 8)
         bool team_fused_group = false;   // PSE_TEAM_FUSED_GROUP: RCCL teams put the Lanczos sum into the group of the ghost transfers
         int wave_mode = 0;        // PSE_WAVE_MODE: 0 automatic, 1 slab, 2 replicated
         int spread_tz = 0, spread_nw = 0;   // PSE_SPREAD_TZ, PSE_SPREAD_NW
@@ -144,6 +146,9 @@ struct pse_handle {
     double2 *pv2 = nullptr;                                  // second set of packed (position, vector) records: holds w1 = M v_j
     double4 *utot_s = nullptr;                               // slab mode: summed velocity of the own rows, all-gathered
     bool xfuse = false;                                      // power-of-two Nx: fused x pass (k_xfft_scale)
+    bool own_y = false;                                      // y transforms by k_fft_cols, rocFFT does the z transforms only
+    double2 *twiddle_y = nullptr;                            // [Ny] exp(-2 pi i m / Ny) (== twiddle when Ny == Nx)
+    double2 *twiddle_y_owned = nullptr;
     int grid_slabs = 1;   // slabs the far-field grid is cut into: n_slabs, or 1 when every rank keeps the whole grid
     double2 *twiddle = nullptr;                              // [Nx] exp(-2 pi i m / Nx)
     void *fft_work = nullptr;
@@ -268,7 +273,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
     void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cnt_block, h->sw.rec_t, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->nb.data, h->nb.cnt, h->vl.idx, h->vl.cnt, h->pos_build, h->pos_s, h->posf_s, h->pv,
-                    h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->w2_s, h->u_s, h->pv2, h->twiddle, h->fft_work, h->V,
+                    h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->w2_s, h->u_s, h->pv2, h->twiddle, h->twiddle_y_owned, h->fft_work, h->V,
                     h->scal, h->partials};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &p : h->ph) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
@@ -298,11 +303,26 @@ static int make_plans(pse_handle *h) {
         TRY(dmalloc(h, &h->twiddle, (size_t)G.Nx));
         HIPCHK(hipMemcpy(h->twiddle, tw.data(), G.Nx * sizeof(double2), hipMemcpyHostToDevice));
     }
+    // the y transforms of a single GPU's grid by the own in-place pass where rocFFT's strided pass is slow (not a power of two)
+    h->own_y = h->xfuse && h->grid_slabs == 1 && h->tun.own_y > 0 && yfft_supported(G.Ny);
+    if (h->own_y) {
+        if (G.Ny == G.Nx) h->twiddle_y = h->twiddle;
+        else {
+            std::vector<double2> tw(G.Ny);
+            for (int m = 0; m < G.Ny; ++m) {
+                const long double ang = -2.0L * 3.14159265358979323846264338327950288L * m / G.Ny;
+                tw[m] = make_double2((double)cosl(ang), (double)sinl(ang));
+            }
+            TRY(dmalloc(h, &h->twiddle_y_owned, (size_t)G.Ny));
+            HIPCHK(hipMemcpy(h->twiddle_y_owned, tw.data(), G.Ny * sizeof(double2), hipMemcpyHostToDevice));
+            h->twiddle_y = h->twiddle_y_owned;
+        }
+    }
     // real grid rows hold Nz doubles, spectrum rows Nzp >= Nz/2 + 1 complex numbers (padded to 128 bytes)
     auto real_plans = [&](size_t dims, const size_t *len, size_t batch) -> int {
         size_t rs[3] = {1, (size_t)G.Nz, (size_t)G.Ny * G.Nz}, cs[3] = {1, (size_t)G.Nzp, (size_t)G.Ny * G.Nzp};
-        const size_t rdist = dims == 2 ? (size_t)G.Ny * G.Nz : (size_t)G.Nx * G.Ny * G.Nz;
-        const size_t cdist = dims == 2 ? (size_t)G.Ny * G.Nzp : (size_t)G.Nx * G.Ny * G.Nzp;
+        const size_t rdist = dims == 1 ? (size_t)G.Nz : (dims == 2 ? (size_t)G.Ny * G.Nz : (size_t)G.Nx * G.Ny * G.Nz);
+        const size_t cdist = dims == 1 ? (size_t)G.Nzp : (dims == 2 ? (size_t)G.Ny * G.Nzp : (size_t)G.Nx * G.Ny * G.Nzp);
         rocfft_plan_description df = nullptr, di = nullptr;
         FFTCHK(rocfft_plan_description_create(&df));
         FFTCHK(rocfft_plan_description_create(&di));
@@ -318,7 +338,11 @@ static int make_plans(pse_handle *h) {
         rocfft_plan_description_destroy(di);
         return 0;
     };
-    if (h->xfuse && h->grid_slabs == 1) {
+    if (h->own_y) {
+        // 1-D real transforms along z of every row; the y transforms are k_fft_cols', the x transforms k_xfft_scale's
+        const size_t len1[1] = {(size_t)G.Nz};
+        TRY(real_plans(1, len1, (size_t)3 * G.Nx * G.Ny));
+    } else if (h->xfuse && h->grid_slabs == 1) {
         // 2-D (y,z) real transforms of all 3 Nx planes in one batch
         const size_t len2[2] = {(size_t)G.Nz, (size_t)G.Ny};
         TRY(real_plans(2, len2, (size_t)3 * G.Nx));
@@ -384,6 +408,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         if (const char *v = getenv("PSE_SKIN")) t.skin = atof(v);
         t.overlap = ienv("PSE_OVERLAP", 0);
         t.no_xfuse = getenv("PSE_NO_XFUSE") != nullptr;
+        t.own_y = ienv("PSE_OWN_Y", 1); t.yfft_kb = ienv("PSE_YFFT_KB", 4);
         if (const char *v = getenv("PSE_TEAM_FUSED_GROUP")) t.team_fused_group = atoi(v) != 0;
         if (const char *v = getenv("PSE_WAVE_MODE")) t.wave_mode = !strcmp(v, "slab") ? 1 : (!strcmp(v, "replicated") ? 2 : 0);
         t.spread_tz = ienv("PSE_SPREAD_TZ", 0); t.spread_nw = ienv("PSE_SPREAD_NW", 0);
@@ -1141,6 +1166,7 @@ static int wave_compute(pse_team &T, const WaveArgs &a, int part) {
             if (GS == 1) {
                 void *in[1] = {h->rgrid}, *out[1] = {h->cgrid};
                 FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
+                if (h->own_y) launch_yfft(h->cgrid, G, false, h->twiddle_y, h->wstream, h->tun.yfft_kb);
             } else {
                 for (int c = 0; c < 3; ++c) {   // 2-D (y,z) transforms of the local planes, one component at a time
                     void *in[1] = {h->rgrid + c * nr + (size_t)G.hl * G.Ny * G.Nz}, *out[1] = {h->cgrid + c * ncx};
@@ -1166,6 +1192,7 @@ static int wave_compute(pse_team &T, const WaveArgs &a, int part) {
         } else if (part == 2) {
             TRY(tsw(h, PH_FFTI));
             if (GS == 1) {
+                if (h->own_y) launch_yfft(h->cgrid, G, true, h->twiddle_y, h->wstream, h->tun.yfft_kb);
                 void *in[1] = {h->cgrid}, *out[1] = {h->rgrid};
                 FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv));
             } else {

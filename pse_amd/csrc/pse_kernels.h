@@ -177,6 +177,10 @@ void launch_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleAr
 void launch_debug_kop(const int *ijk, int n, DGrid G, DBox box, double xi, double eta, double *out, hipStream_t s);
 // fused forward-x FFT + scale + inverse-x FFT on [3][Nx][Ny][Nzh] (Nx a power of two, 16..512); tw[m] = exp(-2 pi i m/Nx)
 bool xfuse_supported(int Nx);
+// own in-place y transforms of the half spectra [3 nxl][Ny][Nzp] (Ny = 2^a 3^b 5^c, not a power of two); tw[m] = exp(-2 pi i m / Ny);
+// kb: consecutive kz per workgroup (2, 4 or 8)
+bool yfft_supported(int Ny);
+void launch_yfft(double2 *spectra, DGrid G, bool inverse, const double2 *tw, hipStream_t s, int kb = 4);
 void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s);
 // the fast path reads the records written by launch_spread of the same step
 hipError_t launch_gather(const double4 *pos_s, SpreadWork w, int N, const double *gx, const double *gy, const double *gz, DGrid G,

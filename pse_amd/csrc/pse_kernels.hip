@@ -1430,14 +1430,17 @@ __device__ __forceinline__ void fft_pass(const double2 *__restrict__ in, double2
         const int col = fast_quot(bfly, mnr), jj = bfly - col * nr, kk = ns == 1 ? 0 : jj - fast_quot(jj, mns) * ns;   // no runtime divisions (ns = 1: the reciprocal 2^32 does not fit)
         const double2 *src = in + col * cs + jj;
         double2 v[9];
-        const int step = kk * tstep;                                 // < n; twiddle index r * step mod n without a division
-        int ti = 0;
+        // W^{r kk tstep} for r = 1 .. R - 1 as powers of ONE table entry: a read of the twiddle table per point was a third of the
+        // LDS traffic of a pass, and the passes are what bounds the mixed-radix kernels (error: R - 2 <= 7 roundings)
+        double2 w1 = tw[kk * tstep];                                 // kk * tstep < n
+        if (INVERSE) w1.y = -w1.y;
+        double2 w = w1;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             double2 x = src[r * nr];
             if (r) {
-                ti += step; if (ti >= n) ti -= n;
-                double2 w = tw[ti]; if (INVERSE) w.y = -w.y; x = cmul(x, w);
+                x = cmul(x, w);
+                if (r + 1 < R) w = cmul(w, w1);
             }
             v[r] = x;
         }
@@ -1525,6 +1528,9 @@ static bool plan_x(int n, FftPlanX &pl) {
     int m = n;
     for (int r : {9, 8, 5, 4, 3, 2})   // few, wide passes: 360 = 9 8 5
         while (m % r == 0) { if (pl.nstage == 10) return false; pl.radix[pl.nstage++] = r; m /= r; }
+    // the first pass scatters with a stride of R points: free of LDS bank conflicts for odd R only -- lead with an odd radix if there is one
+    for (int st = 1; st < pl.nstage && (pl.radix[0] & 1) == 0; ++st)
+        if (pl.radix[st] & 1) std::swap(pl.radix[0], pl.radix[st]);
     unsigned ns = 1;
     for (int st = 0; st < pl.nstage; ++st) {
         const unsigned nr = (unsigned)n / (unsigned)pl.radix[st];
@@ -1543,6 +1549,76 @@ static void launch_xfft_mixed(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox 
     const int nkb = (G.Nzh + KB - 1) / KB;
     const int rows = a.transposed ? a.nyl : G.Ny;
     hipLaunchKernelGGL((k_xfft_scale_mixed<KB, NTH>), dim3(rows * nkb), dim3(NTH), lds, s, X, Y, Z, G, box, a, tw, pl);
+}
+
+// ---- own y pass (round 4): complex transforms along y of the half spectra, in place, for grids 2^a 3^b 5^c that are not powers of
+// two.  rocFFT's strided pass over y is its slow one there (360^2: 0.93 ms of the 1.40 ms of its 2-D transform, the z pass takes
+// 0.48 ms = what its bytes cost); here a workgroup takes KB consecutive kz of one x plane (KB * 16-byte pieces, neighbouring blocks on
+// one XCD as in the x pass) and all Ny rows, through the same mixed-radix passes as the x pass.  The z passes stay rocFFT's (1-D).
+template <int KB, int NTH, bool INVERSE>
+__global__ void __launch_bounds__(NTH)
+k_fft_cols(double2 *__restrict__ data, FftPlanX pl, const double2 *__restrict__ twiddle, int nkb, int Nzh, int Nzp, size_t plane_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int N = pl.n, CS = N + 1;
+    double2 *bufa = reinterpret_cast<double2 *>(smem_raw), *bufb = bufa + KB * CS;   // [KB][N + 1] each
+    double2 *tw = bufb + KB * CS;                                                     // [N]
+    const int tid = threadIdx.x;
+    const int bid = xcd_block(blockIdx.x, gridDim.x);
+    const int plane = bid / nkb, k0 = (bid - plane * nkb) * KB;
+    const int kv = min(KB, Nzh - k0);
+    double2 *base = data + (size_t)plane * plane_stride + k0;
+    for (int e = tid; e < N; e += NTH) tw[e] = twiddle[e];
+    const int total = N * KB;
+    constexpr int U = 6;                                       // loads of a lane in flight at a time
+    for (int e0 = 0; e0 < total; e0 += U * NTH) {
+        double2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * NTH + tid, y = e / KB, q = e - y * KB;
+            v[u] = make_double2(0, 0);
+            if (e < total && q < kv) v[u] = base[(size_t)y * Nzp + q];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * NTH + tid, y = e / KB, q = e - y * KB;
+            if (e < total) bufa[q * CS + y] = v[u];
+        }
+    }
+    __syncthreads();
+    const double2 *d = fft_mixed<INVERSE>(bufa, bufb, tw, pl, CS, KB, NTH);
+    for (int e = tid; e < total; e += NTH) {
+        const int y = e / KB, q = e - y * KB;
+        if (q < kv) base[(size_t)y * Nzp + q] = d[q * CS + y];
+    }
+}
+bool yfft_supported(int Ny) {   // 2^a 3^b 5^c, 16..512, not a power of two (rocFFT's 2-D kernels are good at those)
+    FftPlanX pl;
+    return Ny >= 16 && Ny <= 512 && (Ny & (Ny - 1)) != 0 && plan_x(Ny, pl);
+}
+template <int KB, int NTH>
+static void launch_fft_cols(double2 *data, const FftPlanX &pl, const double2 *tw, int nplanes, int Nzh, int Nzp, size_t plane_stride,
+                            bool inverse, hipStream_t s) {
+    const size_t lds = (size_t)(2 * KB * (pl.n + 1) + pl.n) * sizeof(double2);
+    static size_t attr_lds[2] = {48 * 1024, 48 * 1024};
+    if (lds > attr_lds[inverse]) {
+        if (inverse) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<KB, NTH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<KB, NTH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds[inverse] = lds;
+    }
+    const int nkb = (Nzh + KB - 1) / KB;
+    const dim3 g(nplanes * nkb), b(NTH);
+    if (inverse) hipLaunchKernelGGL((k_fft_cols<KB, NTH, true>), g, b, lds, s, data, pl, tw, nkb, Nzh, Nzp, plane_stride);
+    else hipLaunchKernelGGL((k_fft_cols<KB, NTH, false>), g, b, lds, s, data, pl, tw, nkb, Nzh, Nzp, plane_stride);
+}
+// all three components: [3 Nx] planes of [Ny][Nzp]; tw[m] = exp(-2 pi i m / Ny)
+void launch_yfft(double2 *spectra, DGrid G, bool inverse, const double2 *tw, hipStream_t s, int kb) {
+    FftPlanX pl;
+    plan_x(G.Ny, pl);
+    const int nplanes = 3 * G.nxl;
+    const size_t ps = (size_t)G.Ny * G.Nzp;
+    if (kb == 8) launch_fft_cols<8, 256>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);
+    else if (kb == 2) launch_fft_cols<2, 256>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);
+    else launch_fft_cols<4, 256>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);
 }
 
 bool xfuse_supported(int Nx) {   // 2^a 3^b 5^c, 16..512

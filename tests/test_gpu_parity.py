@@ -223,12 +223,15 @@ def test_step_integrates_and_wraps(torch_cuda, oracle):
 @pytest.mark.parametrize("grid,xy,P", [((32, 32, 32), 0.0, 0), ((64, 48, 40), 0.3, 0), ((16, 36, 30), -0.2, 4), ((128, 32, 32), 0.1, 5),
                                        ((60, 48, 40), 0.25, 0), ((45, 45, 45), 0.0, 0), ((36, 30, 48), -0.3, 0), ((90, 40, 36), 0.1, 0), ((120, 36, 40), -0.15, 0),
                                        ((50, 32, 36), 0.0, 5), ((256, 32, 32), 0.2, 4), ((240, 32, 32), 0.15, 4), ((225, 32, 36), 0.0, 4),
+                                       ((32, 360, 36), 0.1, 4), ((32, 270, 32), 0.0, 4), ((36, 375, 30), 0.0, 4), ((32, 500, 32), -0.2, 4),   # the own y pass (round 4)
                                        ((512, 32, 32), -0.1, 4)])  # the last in a box twice as long in x
 def test_fused_x_pass_matches_port(torch_cuda, oracle, grid, xy, P):
     """Every Nx = 2^a 3^b 5^c (the reference's grid rule, PSEv1/Stokes.cc:147-199) takes the fused forward-x FFT + k-space scaling
     (+ noise) + inverse-x FFT kernel: radix 4/2 in LDS for powers of two, two radix-16 passes in registers at 256 (+ a radix-2 pass at 512), mixed
     radix 9/8/5/4/3/2 otherwise (60 = 5 4 3, 45 = 9 5, 36 = 9 4, 90 = 9 5 2, 120 = 8 5 3, 50 = 5 5 2; 240 = 8 5 3 2 and 225 = 9 5 5 are grids above 200 (two kz columns per workgroup); 360 = 9 8 5 is the grid of the
-    reference's rule at the metric point and is timed by tools/perf.py --grid 0 --xi 0.5)."""
+    reference's rule at the metric point and is timed by tools/perf.py --grid 0 --xi 0.5).  Since round 4 every Ny = 2^a 3^b 5^c that is
+    not a power of two takes the own in-place y pass (k_fft_cols: 48, 36, 30, 40, 45 above; 360 = 9 8 5, 270 = 9 5 3 2, 375 = 5 5 5 3 and
+    500 = 5 5 5 4 are the sizes of the reference's rule at BASELINE configs 3 and 4), rocFFT keeping the 1-D z transforms."""
     import pse_amd
     n = 1200
     pos, force, box = make_suspension(n, L=24.0, xy=xy)

@@ -1648,6 +1648,20 @@ void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, Sc
         else launch_xfft_mixed<2, 256>(X, Y, Z, G, box, a, tw, pl, s);   // four columns, 512 threads, one workgroup per CU: 1.61 against 1.38 ms at 360^3
         return;
     }
+    // small grids (BASELINE config 2: 64^3): with eight kz columns per workgroup the launch is a single, partly filled wave of
+    // workgroups and its duration is one workgroup's latency chain (34 us at 64^3); two columns per workgroup give four times as
+    // many, shorter chains (the 32-byte pieces of a line are fetched by neighbouring workgroups of one XCD)
+    const int rows_ = a.transposed ? a.nyl : G.Ny;
+    static const int small_kb = [] { const char *e = getenv("PSE_XFFT_SMALL_KB"); return e ? atoi(e) : 2; }();
+    if (G.Nx <= 128 && (long)rows_ * ((G.Nzh + 7) / 8) < 1024 && small_kb == 2) {
+        switch (G.Nx) {
+            case 16: launch_xfft_t<4, 2, 64>(X, Y, Z, G, box, a, tw, s); return;
+            case 32: launch_xfft_t<5, 2, 64>(X, Y, Z, G, box, a, tw, s); return;
+            case 64: launch_xfft_t<6, 2, 128>(X, Y, Z, G, box, a, tw, s); return;
+            case 128: launch_xfft_t<7, 2, 256>(X, Y, Z, G, box, a, tw, s); return;
+            default: break;
+        }
+    }
     switch (G.Nx) {   // 8 kz columns per workgroup = 128-byte pieces; LDS = 3*KB*(N+1)*16 B
         case 16: launch_xfft_t<4, 8, 256>(X, Y, Z, G, box, a, tw, s); break;
         case 32: launch_xfft_t<5, 8, 256>(X, Y, Z, G, box, a, tw, s); break;

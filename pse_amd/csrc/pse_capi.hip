@@ -555,7 +555,15 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     // PSE_OVERLAP=1 forks them too, -1 never forks).  With pse_set_timing on, everything runs on one stream: per-kernel
     // durations -- the roofline evidence -- are then those of the kernel alone.
     if (h->tun.overlap >= 0) {
-        HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        {   // PSE_SIDE_PRIORITY=low|high: the far-field lane at the lowest / highest stream priority (default: the default priority)
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo: numerically largest = lowest priority
+            const char *pr = getenv("PSE_SIDE_PRIORITY");
+            if (pr && (!strcmp(pr, "low") || !strcmp(pr, "high")))
+                HIPCHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, !strcmp(pr, "low") ? lo : hi));
+            else
+                HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        }
         h->side_owned = h->side;
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));

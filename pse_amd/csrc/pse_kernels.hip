@@ -1469,12 +1469,71 @@ __device__ __forceinline__ double2 *fft_mixed(double2 *a, double2 *b, const doub
     return a;                                                        // the buffer that holds the result
 }
 
-template <int KB, int NTH>
+// The same passes with the length and the radices known at compile time (the sizes the reference's rule picks at the BASELINE
+// configurations: 360, 270, 180, 375, 500, ...).  The fused x pass is bound by vector-instruction issue (57 % of the cycles, 3 170
+// instructions per wave at 360: profiles/r04_x360_counters.txt); here the index arithmetic is constant-folded, the butterflies of a
+// lane are unrolled so that the loads of the second are in flight during the first, the first pass (all twiddles 1) multiplies
+// nothing, and later passes read their twiddles from the table (no product chain: arithmetic is what this kernel is short of).
+template <int N_, int R0, int R1 = 1, int R2 = 1, int R3 = 1>
+struct CtPlan { static constexpr int N = N_, NST = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1); };
+struct RtPlan { static constexpr int N = 0; };
+
+template <int R, bool INVERSE, int N, int NS, int NCOL, int NTH>
+__device__ __forceinline__ void fft_pass_ct(const double2 *__restrict__ in, double2 *__restrict__ out, const double2 *__restrict__ tw) {
+    constexpr int NR = N / R, NB = NCOL * NR, TSTEP = N / (NS * R), CS = N + 1, ITER = (NB + NTH - 1) / NTH;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int bfly = (int)threadIdx.x + it * NTH;
+        if (NB % NTH == 0 || bfly < NB) {
+            const int col = bfly / NR, jj = bfly - col * NR, kk = NS == 1 ? 0 : jj % NS;
+            const double2 *src = in + col * CS + jj;
+            double2 v[9];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                double2 x = src[r * NR];
+                if (r && NS > 1) {
+                    double2 w = tw[r * kk * TSTEP];              // r kk TSTEP < R NS TSTEP = N
+                    if (INVERSE) w.y = -w.y;
+                    x = cmul(x, w);
+                }
+                v[r] = x;
+            }
+            dft_small<R, INVERSE>(v);
+            double2 *dst = out + col * CS + (jj - kk) * R + kk;
+#pragma unroll
+            for (int r = 0; r < R; ++r) dst[r * NS] = v[r];
+        }
+    }
+}
+template <int R, bool INVERSE, int N, int NS, int NCOL, int NTH>
+__device__ __forceinline__ void fft_stage_ct(double2 *&a, double2 *&b, const double2 *tw) {
+    if constexpr (R > 1) {
+        fft_pass_ct<R, INVERSE, N, NS, NCOL, NTH>(a, b, tw);
+        __syncthreads();
+        double2 *t = a; a = b; b = t;
+    }
+}
+template <class P> struct CtRadices;
+template <int N_, int R0, int R1, int R2, int R3>
+struct CtRadices<CtPlan<N_, R0, R1, R2, R3>> { static constexpr int r0 = R0, r1 = R1, r2 = R2, r3 = R3; };
+template <class P, bool INVERSE, int NCOL, int NTH>
+__device__ __forceinline__ double2 *fft_mixed_ct(double2 *a, double2 *b, const double2 *tw) {
+    using Rd = CtRadices<P>;
+    fft_stage_ct<Rd::r0, INVERSE, P::N, 1, NCOL, NTH>(a, b, tw);
+    fft_stage_ct<Rd::r1, INVERSE, P::N, Rd::r0, NCOL, NTH>(a, b, tw);
+    fft_stage_ct<Rd::r2, INVERSE, P::N, Rd::r0 * Rd::r1, NCOL, NTH>(a, b, tw);
+    fft_stage_ct<Rd::r3, INVERSE, P::N, Rd::r0 * Rd::r1 * Rd::r2, NCOL, NTH>(a, b, tw);
+    return a;
+}
+
+template <int KB, int NTH, class PLAN = RtPlan>
 __global__ void __launch_bounds__(NTH)
 k_xfft_scale_mixed(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ Z, DGrid G, DBox box, ScaleArgs a,
                    const double2 *__restrict__ twiddle, FftPlanX pl) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int N = pl.n, CS = N + 1, NCOL = 3 * KB;
+    constexpr bool CT = PLAN::N > 0;
+    const int N = CT ? PLAN::N : pl.n, CS = N + 1;
+    constexpr int NCOL = 3 * KB;
     double2 *bufa = reinterpret_cast<double2 *>(smem_raw), *bufb = bufa + NCOL * CS;   // [3][KB][N + 1] each
     double2 *tw = bufb + NCOL * CS;                                                     // [N]
     const int tid = threadIdx.x;
@@ -1505,7 +1564,9 @@ k_xfft_scale_mixed(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__
         }
     }
     __syncthreads();
-    double2 *d = fft_mixed<false>(bufa, bufb, tw, pl, CS, NCOL, NTH);
+    double2 *d;
+    if constexpr (CT) d = fft_mixed_ct<PLAN, false, NCOL, NTH>(bufa, bufb, tw);
+    else d = fft_mixed<false>(bufa, bufb, tw, pl, CS, NCOL, NTH);
     for (int e = tid; e < N * KB; e += NTH) {
         const int x = e / KB, q = e - x * KB;
         if (q < kv) {
@@ -1516,7 +1577,8 @@ k_xfft_scale_mixed(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__
         }
     }
     __syncthreads();
-    d = fft_mixed<true>(d, d == bufa ? bufb : bufa, tw, pl, CS, NCOL, NTH);
+    if constexpr (CT) d = fft_mixed_ct<PLAN, true, NCOL, NTH>(d, d == bufa ? bufb : bufa, tw);
+    else d = fft_mixed<true>(d, d == bufa ? bufb : bufa, tw, pl, CS, NCOL, NTH);
     for (int e = tid; e < total; e += NTH) {
         const int c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
         if (q < kv) comp[c][(size_t)x * xstride + base + q] = d[(c * KB + q) * CS + x];
@@ -1541,14 +1603,14 @@ static bool plan_x(int n, FftPlanX &pl) {
     return m == 1;
 }
 
-template <int KB, int NTH>
+template <int KB, int NTH, class PLAN = RtPlan>
 static void launch_xfft_mixed(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, const FftPlanX &pl, hipStream_t s) {
     const size_t lds = (size_t)(2 * 3 * KB * (pl.n + 1) + pl.n) * sizeof(double2);
     static size_t attr_lds = 48 * 1024;
-    if (lds > attr_lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xfft_scale_mixed<KB, NTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_lds = lds; }
+    if (lds > attr_lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xfft_scale_mixed<KB, NTH, PLAN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_lds = lds; }
     const int nkb = (G.Nzh + KB - 1) / KB;
     const int rows = a.transposed ? a.nyl : G.Ny;
-    hipLaunchKernelGGL((k_xfft_scale_mixed<KB, NTH>), dim3(rows * nkb), dim3(NTH), lds, s, X, Y, Z, G, box, a, tw, pl);
+    hipLaunchKernelGGL((k_xfft_scale_mixed<KB, NTH, PLAN>), dim3(rows * nkb), dim3(NTH), lds, s, X, Y, Z, G, box, a, tw, pl);
 }
 
 // ---- own y pass (round 4): complex transforms along y of the half spectra, in place, for grids 2^a 3^b 5^c that are not powers of
@@ -1644,6 +1706,21 @@ void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, Sc
     if (G.Nx & (G.Nx - 1)) {   // not a power of two: mixed-radix passes; 4 kz columns per workgroup while two buffers fit
         FftPlanX pl;
         plan_x(G.Nx, pl);
+        static const int var = [] { const char *e = getenv("PSE_XMIX"); return e ? atoi(e) : 0; }();   // experiment: columns x threads
+        if (var == 1128) { launch_xfft_mixed<1, 128>(X, Y, Z, G, box, a, tw, pl, s); return; }
+        if (var == 1256) { launch_xfft_mixed<1, 256>(X, Y, Z, G, box, a, tw, pl, s); return; }
+        if (var == 2128) { launch_xfft_mixed<2, 128>(X, Y, Z, G, box, a, tw, pl, s); return; }
+        if (var == 2192) { launch_xfft_mixed<2, 192>(X, Y, Z, G, box, a, tw, pl, s); return; }
+        if (var != 1) {   // compile-time plans for the sizes of the reference's rule at the BASELINE configurations (PSE_XMIX=1: runtime plan)
+            switch (G.Nx) {
+                case 360: launch_xfft_mixed<2, 256, CtPlan<360, 9, 8, 5>>(X, Y, Z, G, box, a, tw, pl, s); return;
+                case 270: launch_xfft_mixed<2, 256, CtPlan<270, 9, 5, 3, 2>>(X, Y, Z, G, box, a, tw, pl, s); return;
+                case 375: launch_xfft_mixed<2, 256, CtPlan<375, 5, 5, 5, 3>>(X, Y, Z, G, box, a, tw, pl, s); return;
+                case 500: launch_xfft_mixed<2, 256, CtPlan<500, 5, 5, 5, 4>>(X, Y, Z, G, box, a, tw, pl, s); return;
+                case 180: launch_xfft_mixed<4, 256, CtPlan<180, 9, 5, 4>>(X, Y, Z, G, box, a, tw, pl, s); return;
+                default: break;
+            }
+        }
         if (G.Nx <= 200) launch_xfft_mixed<4, 256>(X, Y, Z, G, box, a, tw, pl, s);
         else launch_xfft_mixed<2, 256>(X, Y, Z, G, box, a, tw, pl, s);   // four columns, 512 threads, one workgroup per CU: 1.61 against 1.38 ms at 360^3
         return;

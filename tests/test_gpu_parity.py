@@ -223,6 +223,7 @@ def test_step_integrates_and_wraps(torch_cuda, oracle):
 @pytest.mark.parametrize("grid,xy,P", [((32, 32, 32), 0.0, 0), ((64, 48, 40), 0.3, 0), ((16, 36, 30), -0.2, 4), ((128, 32, 32), 0.1, 5),
                                        ((60, 48, 40), 0.25, 0), ((45, 45, 45), 0.0, 0), ((36, 30, 48), -0.3, 0), ((90, 40, 36), 0.1, 0), ((120, 36, 40), -0.15, 0),
                                        ((50, 32, 36), 0.0, 5), ((256, 32, 32), 0.2, 4), ((240, 32, 32), 0.15, 4), ((225, 32, 36), 0.0, 4),
+                                       ((360, 32, 32), 0.1, 4), ((270, 32, 36), -0.1, 4), ((375, 32, 32), 0.0, 4), ((500, 32, 32), 0.2, 4), ((180, 36, 32), 0.0, 4),   # compile-time radix plans (round 4)
                                        ((32, 360, 36), 0.1, 4), ((32, 270, 32), 0.0, 4), ((36, 375, 30), 0.0, 4), ((32, 500, 32), -0.2, 4),   # the own y pass (round 4)
                                        ((512, 32, 32), -0.1, 4)])  # the last in a box twice as long in x
 def test_fused_x_pass_matches_port(torch_cuda, oracle, grid, xy, P):
@@ -238,6 +239,10 @@ def test_fused_x_pass_matches_port(torch_cuda, oracle, grid, xy, P):
     if grid[0] == 512:   # keep hx / hy where the 256 case has it
         pos = np.concatenate([pos[: n // 2] - [12.0, 0, 0], pos[n // 2:] + [12.0, 0, 0]])
         box = (48.0, 24.0, 24.0, xy)
+    elif grid[0] > 256:  # likewise: a box stretched along x so that hx stays at the 256 case's 24 / 256
+        Lx = grid[0] * 24.0 / 256.0
+        pos[:, 0] = (pos[:, 0] - xy * pos[:, 1]) * (Lx / 24.0) + xy * pos[:, 1]
+        box = (Lx, 24.0, 24.0, xy)
     seed, ts, kT, dt = 31, 4, 1.0, 1e-3
     eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3, seed=seed, grid=grid, P=P)
     p = oracle.select_params(box, 0.5, 1e-3, 0.5, grid=grid, P=P or None)

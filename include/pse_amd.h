@@ -197,7 +197,8 @@ typedef struct pse_host_xfer {
 typedef struct pse_transport {
     void *user;
     int (*exchange)(void *user, int n_xfers, const pse_host_xfer *xfers);
-    int (*allreduce_sum)(void *user, double *host_buf, size_t count);
+    int (*allreduce_sum)(void *user, double *host_buf, size_t count);   /* not called since round 4 (may be NULL): the Lanczos sums
+                                                                           travel as small blocks inside `exchange` */
 } pse_transport;
 int pse_team_create_transport(pse_handle *member, const pse_transport *transport, pse_team **out);
 /* Destroy the team BEFORE its members: the members must outlive it (an in-process team lends member 0's side stream to the

@@ -76,7 +76,6 @@ struct pse_handle {
         bool no_xfuse = false;    // PSE_NO_XFUSE: rocFFT for the x pass
         int own_y = 1;            // PSE_OWN_Y=0: rocFFT's 2-D (y, z) transforms also where the own y pass applies
         int yfft_kb = 4;          // PSE_YFFT_KB: kz columns per workgroup of the own y pass (2, 4, 8)
-        bool team_fused_group = false;   // PSE_TEAM_FUSED_GROUP: RCCL teams put the Lanczos sum into the group of the ghost transfers
         int wave_mode = 0;        // PSE_WAVE_MODE: 0 automatic, 1 slab, 2 replicated
         int spread_tz = 0, spread_nw = 0;   // PSE_SPREAD_TZ, PSE_SPREAD_NW
         bool verbose = false;     // PSE_VERBOSE
@@ -143,6 +142,7 @@ struct pse_handle {
     std::vector<int> row_lo, first_end, last_begin;          // per rank: own rows [row_lo[r], row_lo[r+1]), first / last cell layer
     std::vector<int> first2_end, last2_begin;                // ... and its first / last TWO cell layers (two-step Lanczos of a team)
     double4 *w2_s = nullptr, *u_s = nullptr;                 // two-step Lanczos: w2 = M M v_j, u = M v_{j-1}
+    double *sums_all = nullptr;                              // [n_slabs][LZ_NGRAM]: every rank's partial Lanczos sums (they travel with the ghost rows)
     double2 *pv2 = nullptr;                                  // second set of packed (position, vector) records: holds w1 = M v_j
     double4 *utot_s = nullptr;                               // slab mode: summed velocity of the own rows, all-gathered
     bool xfuse = false;                                      // power-of-two Nx: fused x pass (k_xfft_scale)
@@ -273,7 +273,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
     void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cnt_block, h->sw.rec_t, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->nb.data, h->nb.cnt, h->vl.idx, h->vl.cnt, h->pos_build, h->pos_s, h->posf_s, h->pv,
-                    h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->w2_s, h->u_s, h->pv2, h->twiddle, h->twiddle_y_owned, h->fft_work, h->V,
+                    h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->w2_s, h->u_s, h->pv2, h->sums_all, h->twiddle, h->twiddle_y_owned, h->fft_work, h->V,
                     h->scal, h->partials};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &p : h->ph) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
@@ -409,7 +409,6 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         t.overlap = ienv("PSE_OVERLAP", 0);
         t.no_xfuse = getenv("PSE_NO_XFUSE") != nullptr;
         t.own_y = ienv("PSE_OWN_Y", 1); t.yfft_kb = ienv("PSE_YFFT_KB", 4);
-        if (const char *v = getenv("PSE_TEAM_FUSED_GROUP")) t.team_fused_group = atoi(v) != 0;
         if (const char *v = getenv("PSE_WAVE_MODE")) t.wave_mode = !strcmp(v, "slab") ? 1 : (!strcmp(v, "replicated") ? 2 : 0);
         t.spread_tz = ienv("PSE_SPREAD_TZ", 0); t.spread_nw = ienv("PSE_SPREAD_NW", 0);
         t.verbose = ienv("PSE_VERBOSE", 0) > 0;
@@ -540,6 +539,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         HIPCHK(hipEventCreateWithFlags(&h->ev_bounds, hipEventDisableTiming));
         TRY(dmalloc(h, &h->d_bidx, (size_t)5 * h->n_slabs + 1)); TRY(dmalloc(h, &h->d_bounds, (size_t)5 * h->n_slabs + 1));
         TRY(dmalloc(h, &h->utot_s, n));
+        TRY(dmalloc(h, &h->sums_all, (size_t)h->n_slabs * LZ_NGRAM));
         if (h->tun.team_sstep && h->nb.cap > 0) {
             TRY(dmalloc(h, &h->w2_s, n)); TRY(dmalloc(h, &h->u_s, n)); TRY(dmalloc(h, &h->pv2, 3 * n));
         }
@@ -701,8 +701,6 @@ struct pse_team {
     bool has_cb = false;
     double *stage = nullptr;     // pinned staging of the callback transport
     size_t stage_n = 0;
-    double *scratch = nullptr;   // loopback all-reduce scratch
-    size_t scratch_n = 0;
     // developer switch (pse_team_debug_solo): an in-process team queues the work of ONE member only -- its kernels on both lanes,
     // the copies that stand for what it receives -- so that the wall time of a call is that rank's critical path on a GPU of its
     // own (the other members' buffers keep what the last full call left there: the numbers are not meaningful, the timing is)
@@ -720,12 +718,13 @@ static bool loopback(const pse_team &T) { return T.G > 1 && !T.nccl && !T.has_cb
 static bool remote(const pse_team &T) { return T.nccl || T.has_cb; }   // one member per process
 static hipEvent_t team_event(pse_team &T) { hipEvent_t e = T.evs[T.ev_next]; T.ev_next = (T.ev_next + 1) % T.evs.size(); return e; }
 
-// One exchange of a process-per-rank team: a list of point-to-point transfers (counts in doubles; 0 = none) and, optionally, a
-// sum over all ranks -- ONE RCCL group, or one call of the host program's transport.  Every exchange of the team goes through
-// here, so what the RCCL path sends (buffers, counts, peers, order) is exactly what the callback transport sends -- and that
+// One exchange of a process-per-rank team: a list of point-to-point transfers (counts in doubles; 0 = none) -- ONE RCCL group, or one
+// call of the host program's transport.  Every exchange of the team goes through here -- also the partial sums of the Lanczos
+// iteration, which travel as small blocks to every rank in the group of the ghost rows (no collective of another kind is ever
+// posted) -- so what the RCCL path sends (buffers, counts, peers, order) is exactly what the callback transport sends -- and that
 // one runs between real processes in the tests (two ranks cannot share a GPU under RCCL).
 struct Xfer { const double *send; size_t ns; int to; double *recv; size_t nr; int from; };
-static int team_exchange(pse_team &T, const std::vector<Xfer> &ops, bool wave_lane, double *sum_buf = nullptr, size_t sum_n = 0) {
+static int team_exchange(pse_team &T, const std::vector<Xfer> &ops, bool wave_lane) {
     pse_handle *h = T.m[0];
     hipStream_t s = wave_lane ? h->wstream : h->stream;
     const int me = h->slab_rank;
@@ -742,33 +741,24 @@ static int team_exchange(pse_team &T, const std::vector<Xfer> &ops, bool wave_la
         if (self_recv[q]->recv != self_send[q]->send)
             HIPCHK(hipMemcpyAsync(self_recv[q]->recv, self_send[q]->send, self_send[q]->ns * sizeof(double), hipMemcpyDeviceToDevice, s));
     }
+    bool any = false;
+    for (const Xfer &x : ops) any = any || (x.ns && x.to != me) || (x.nr && x.from != me);
+    if (!any) return 0;
     if (T.nccl) {
         ncclComm_t comm = T.nccl;
-        // the sum travels as its own collective unless PSE_TEAM_FUSED_GROUP=1 puts it into the group of the transfers (one launch
-        // less per Lanczos exchange; a collective and point-to-point calls in one group have never run here: ADVICE r2)
-        const bool fused = h->tun.team_fused_group;
-        bool any = sum_n != 0;
-        for (const Xfer &x : ops) any = any || (x.ns && x.to != me) || (x.nr && x.from != me);
-        if (!any) return 0;
         // hand-over lane -> communication stream (what the lane has queued so far produces the buffers) ...
         hipStream_t cs = T.comm ? T.comm : s;
         if (T.comm) { hipEvent_t e = team_event(T); HIPCHK(hipEventRecord(e, s)); HIPCHK(hipStreamWaitEvent(T.comm, e, 0)); }
-        if (sum_n && !fused) NCCLCHK(ncclAllReduce(sum_buf, sum_buf, sum_n, ncclDouble, ncclSum, comm, cs));
-        bool grp = sum_n && fused;
-        for (const Xfer &x : ops) grp = grp || (x.ns && x.to != me) || (x.nr && x.from != me);
-        if (grp) {
-            NCCLCHK(ncclGroupStart());
-            if (sum_n && fused) NCCLCHK(ncclAllReduce(sum_buf, sum_buf, sum_n, ncclDouble, ncclSum, comm, cs));
-            for (const Xfer &x : ops) if (x.ns && x.to != me) NCCLCHK(ncclSend(x.send, x.ns, ncclDouble, x.to, comm, cs));
-            for (const Xfer &x : ops) if (x.nr && x.from != me) NCCLCHK(ncclRecv(x.recv, x.nr, ncclDouble, x.from, comm, cs));
-            NCCLCHK(ncclGroupEnd());
-        }
+        NCCLCHK(ncclGroupStart());
+        for (const Xfer &x : ops) if (x.ns && x.to != me) NCCLCHK(ncclSend(x.send, x.ns, ncclDouble, x.to, comm, cs));
+        for (const Xfer &x : ops) if (x.nr && x.from != me) NCCLCHK(ncclRecv(x.recv, x.nr, ncclDouble, x.from, comm, cs));
+        NCCLCHK(ncclGroupEnd());
         // ... and back: the lane goes on when the exchange has completed
         if (T.comm) { hipEvent_t e = team_event(T); HIPCHK(hipEventRecord(e, T.comm)); HIPCHK(hipStreamWaitEvent(s, e, 0)); }
         return 0;
     }
     // host-staged transport: device -> pinned host, the host program moves the bytes, pinned host -> device
-    size_t need = sum_n;
+    size_t need = 0;
     for (const Xfer &x : ops) need += (x.to == me ? 0 : x.ns) + (x.from == me ? 0 : x.nr);
     if (need > T.stage_n) {
         if (T.stage) (void)hipHostFree(T.stage);
@@ -778,8 +768,6 @@ static int team_exchange(pse_team &T, const std::vector<Xfer> &ops, bool wave_la
     }
     std::vector<pse_host_xfer> hx;
     size_t off = 0;
-    double *sum_host = nullptr;
-    if (sum_n) { sum_host = T.stage; HIPCHK(hipMemcpyAsync(sum_host, sum_buf, sum_n * sizeof(double), hipMemcpyDeviceToHost, s)); off = sum_n; }
     std::vector<std::pair<double *, const double *>> back;   // (device destination, host source) of what arrives
     std::vector<size_t> back_n;
     for (const Xfer &x : ops) {
@@ -793,9 +781,7 @@ static int team_exchange(pse_team &T, const std::vector<Xfer> &ops, bool wave_la
         }
     }
     HIPCHK(hipStreamSynchronize(s));
-    if (sum_n && T.cb.allreduce_sum(T.cb.user, sum_host, sum_n)) return fail(PSE_ERR_COMM, "transport: all-reduce failed");
     if (!hx.empty() && T.cb.exchange(T.cb.user, (int)hx.size(), hx.data())) return fail(PSE_ERR_COMM, "transport: exchange failed");
-    if (sum_n) HIPCHK(hipMemcpyAsync(sum_buf, sum_host, sum_n * sizeof(double), hipMemcpyHostToDevice, s));
     for (size_t q = 0; q < back.size(); ++q)
         HIPCHK(hipMemcpyAsync(back[q].first, back[q].second, back_n[q] * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));   // the staging buffer is reused by the next exchange
@@ -840,16 +826,6 @@ static int team_all_to_all(pse_team &T, FS send, FR recv, size_t blk_doubles, in
             for (pse_handle *dst : act(T))
                 cb.add(recv(dst) + c * set_stride + (size_t)src->slab_rank * blk_doubles,
                        send(src) + c * set_stride + (size_t)dst->slab_rank * blk_doubles, blk_doubles);
-    return 0;
-}
-template <class FB>
-static int team_all_reduce_sum(pse_team &T, FB buf, size_t n_doubles) {
-    if (T.G == 1) return 0;
-    if (remote(T)) return team_exchange(T, {}, false, buf(T.m[0]), n_doubles);
-    if (T.G > 64) return fail(PSE_ERR_INVALID, "in-process teams hold at most 64 ranks");
-    SumList l{};
-    for (pse_handle *h : act(T)) { l.src[l.nsrc++] = buf(h); l.dst[l.ndst++] = buf(h); }   // rank order: deterministic
-    launch_sum_list(l, (int)n_doubles, T.m[0]->stream);
     return 0;
 }
 // gather halo: every rank stores copies of its left neighbour's last hl planes below its slab and of its right
@@ -902,14 +878,19 @@ static std::vector<Xfer> ghost_ops(const pse_handle *h, int G, std::initializer_
     }
     return ops;
 }
+// The partial Lanczos sums of a rank (n numbers at scal[LZ_TMP ..]) go to every rank -- point-to-point blocks in the SAME group as the
+// ghost rows (round 4: no separate all-reduce collective; the kernels that consume the sums add the ranks' blocks in rank order)
+static void sum_ops(const pse_handle *h, int G, int n, std::vector<Xfer> &ops) {
+    for (int q = 0; q < G; ++q)
+        ops.push_back(Xfer{h->scal + LZ_TMP, (size_t)n, q, h->sums_all + (size_t)q * LZ_NGRAM, (size_t)n, q});
+}
 // An exchange given as one transfer list per rank (+ an optional sum over the ranks), in any of the three transports.  In-process
 // teams execute the receives as device copies: the k-th receive of dst from src pairs with the k-th send of src to dst -- the
 // matching rule of the message transports.
-template <class FOPS, class FSUM>
-static int team_run_exchange(pse_team &T, FOPS make_ops, bool wave_lane, FSUM sums, size_t sum_n) {
+template <class FOPS>
+static int team_run_exchange(pse_team &T, FOPS make_ops, bool wave_lane) {
     if (T.G == 1) return 0;
-    if (remote(T)) return team_exchange(T, make_ops(T.m[0]), wave_lane, sum_n ? sums(T.m[0]) : nullptr, sum_n);
-    if (sum_n) TRY(team_all_reduce_sum(T, sums, sum_n));
+    if (remote(T)) return team_exchange(T, make_ops(T.m[0]), wave_lane);
     std::vector<std::vector<Xfer>> all(T.G);
     for (pse_handle *h : T.m) all[h->slab_rank] = make_ops(h);
     CopyBatch cb(wave_lane ? act(T)[0]->wstream : act(T)[0]->stream);
@@ -930,15 +911,14 @@ static int team_run_exchange(pse_team &T, FOPS make_ops, bool wave_lane, FSUM su
 }
 template <class FB>
 static int team_ghost_exchange(pse_team &T, FB buf) {
-    auto none = [](pse_handle *) { return (double *)nullptr; };
-    return team_run_exchange(T, [&](pse_handle *h) { return ghost_ops(h, T.G, {buf(h)}); }, false, none, 0);
+    return team_run_exchange(T, [&](pse_handle *h) { return ghost_ops(h, T.G, {buf(h)}); }, false);
 }
 
 // One exchange per Lanczos iteration: the three partial sums (all-reduce) and the ghost rows of y = M x (every rank receives its
 // right neighbour's first cell layer and its left neighbour's last one) travel in ONE group.
-template <class FS, class FB>
-static int team_lanczos_exchange(pse_team &T, FS sums, FB buf) {
-    return team_run_exchange(T, [&](pse_handle *h) { return ghost_ops(h, T.G, {buf(h)}); }, false, sums, 3);
+template <class FB>
+static int team_lanczos_exchange(pse_team &T, FB buf) {
+    return team_run_exchange(T, [&](pse_handle *h) { auto ops = ghost_ops(h, T.G, {buf(h)}); sum_ops(h, T.G, 3, ops); return ops; }, false);
 }
 
 // every rank's own rows [row_lo[r], row_lo[r+1]) of buf become visible on every rank (blocks of different sizes)
@@ -1377,7 +1357,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
             // rows (it holds x_j and x_{j-1} there from the previous iteration), so x_{j+1} needs no exchange of its own
             if (pump) TRY(pump->upto(n_exchanges));   // the far-field exchanges whose slot has come go first
             ++n_exchanges;
-            TRY(team_lanczos_exchange(T, [](pse_handle *h) { return h->scal + LZ_TMP; }, [](pse_handle *h) { return (double *)h->w_s; }));
+            TRY(team_lanczos_exchange(T, [](pse_handle *h) { return (double *)h->w_s; }));
             // The LAST iteration of a batch only derives its scalars (alpha_j, beta_j): whether x_{j+1} is needed at all is what the
             // check below decides -- in the steady state of a time-stepping loop (m_in = m) it is not, and the step saves one vector
             // pass and the reduction of |x_{j+1}| (0.04 ms at the metric point).  If the iteration goes on, the vector part follows.
@@ -1387,7 +1367,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
                 const int nrg = scalars_only ? 0 : update_ranges(h, N, rg);
                 const double4 *xj = done == 0 ? h->psi_s : h->V + (size_t)done * stride;
                 launch_lz_update(xj, h->w_s, done > 1 ? h->V + (size_t)(done - 1) * stride : (done == 1 ? h->psi_s : nullptr),
-                                 h->V + (size_t)(done + 1) * stride, done, h->scal, rg, nrg, h->stream, h->pv);
+                                 h->V + (size_t)(done + 1) * stride, done, h->scal, rg, nrg, h->stream, h->pv, h->sums_all, T.G > 1 ? T.G : 0);
                 if (!scalars_only) h->pv_is_f = false;   // the vector half of pv now holds x_{j+1}
             }
         }
@@ -1439,7 +1419,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
             const int j = done - 1;
             const double4 *xj = j == 0 ? h->psi_s : h->V + (size_t)j * stride;
             launch_lz_update(xj, h->w_s, j > 1 ? h->V + (size_t)(j - 1) * stride : (j == 1 ? h->psi_s : nullptr),
-                             h->V + (size_t)(j + 1) * stride, j, h->scal, rg, nrg, h->stream, h->pv);
+                             h->V + (size_t)(j + 1) * stride, j, h->scal, rg, nrg, h->stream, h->pv, h->sums_all, T.G > 1 ? T.G : 0);
             h->pv_is_f = false;
         }
         pending_beta = done;
@@ -1494,7 +1474,7 @@ static int lanczos_team(pse_team &T, int N, double tol, double scale, int *m_io,
                 for (pse_handle *h : act(T)) {
                     int rg[3][2];
                     const int nrg = row_ranges(h, N, 2, rg);
-                    launch_lz_block(block_args(h, half_pending, false), false, h->scal, rg, nrg, h->stream);
+                    launch_lz_block(block_args(h, half_pending, false), false, h->scal, rg, nrg, h->stream, h->sums_all, T.G);
                 }
                 half_pending = -1;
             }
@@ -1520,12 +1500,15 @@ static int lanczos_team(pse_team &T, int N, double tol, double scale, int *m_io,
             }
             if (pump) TRY(pump->upto(n_exchanges));
             ++n_exchanges;
-            TRY(team_run_exchange(T, [&](pse_handle *h) { return ghost_ops(h, T.G, {(double *)h->w_s, full ? (double *)h->w2_s : nullptr}, 2); },
-                                  false, [](pse_handle *h) { return h->scal + LZ_TMP; }, (size_t)LZ_NGRAM));
+            TRY(team_run_exchange(T, [&](pse_handle *h) {
+                                      auto ops = ghost_ops(h, T.G, {(double *)h->w_s, full ? (double *)h->w2_s : nullptr}, 2);
+                                      sum_ops(h, T.G, LZ_NGRAM, ops);
+                                      return ops; },
+                                  false));
             for (pse_handle *h : act(T)) {
                 int rg[3][2];
                 const int nrg = full ? row_ranges(h, N, 2, rg) : 0;   // a single step derives its scalars only, for now
-                launch_lz_block(block_args(h, j, full), full, h->scal, rg, nrg, h->stream);
+                launch_lz_block(block_args(h, j, full), full, h->scal, rg, nrg, h->stream, h->sums_all, T.G);
             }
             if (full) done += 2; else { done += 1; half_pending = j; }
         }
@@ -1938,7 +1921,7 @@ extern "C" int pse_team_create(pse_handle **members, int n_members, const void *
 }
 
 extern "C" int pse_team_create_transport(pse_handle *member, const pse_transport *transport, pse_team **out) {
-    if (!member || !transport || !out || !transport->exchange || !transport->allreduce_sum) return fail(PSE_ERR_INVALID, "bad argument");
+    if (!member || !transport || !out || !transport->exchange) return fail(PSE_ERR_INVALID, "bad argument");
     *out = nullptr;
     if (member->n_slabs < 2) return fail(PSE_ERR_INVALID, "a team needs handles created with n_slabs >= 2");
     pse_team *T = new pse_team();
@@ -1965,7 +1948,6 @@ extern "C" int pse_team_destroy(pse_team *T) {
     if (T->nccl) ncclCommDestroy(T->nccl);
     for (hipEvent_t e : T->evs) if (e) (void)hipEventDestroy(e);
     if (T->comm) (void)hipStreamDestroy(T->comm);
-    if (T->scratch) (void)hipFree(T->scratch);
     if (T->stage) (void)hipHostFree(T->stage);
     delete T;
     return 0;

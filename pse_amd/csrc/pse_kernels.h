@@ -192,9 +192,6 @@ void launch_add_inplace(double *a, const double *b, size_t n, hipStream_t s);
 // in-process teams: the device copies that stand for one exchange, as ONE launch (a message transport posts one group too)
 struct CopyList { int n; const double *src[40]; double *dst[40]; unsigned cnt[40]; };   // counts in doubles
 void launch_copy_list(const CopyList &l, hipStream_t s);
-// dst_q[i] = sum over the n sources of src_r[i] for every destination q: the in-process stand-in of a small all-reduce
-struct SumList { int nsrc, ndst; const double *src[64]; double *dst[64]; };
-void launch_sum_list(const SumList &l, int n, hipStream_t s);
 
 // ---- vector kernels (K10-K14) ----------------------------------------------------------------------------
 void launch_psi(double4 *psi_s, const unsigned *tag_s, int N, uint32_t seed, uint32_t timestep, hipStream_t s,
@@ -220,9 +217,12 @@ struct LzBlockArgs {
     double2 *pv;                      // packed records of the next mat-vec: vector half <- the new q
     int j;
 };
-void launch_lz_block(const LzBlockArgs &a, bool full, double *scal, const int (*row_ranges)[2], int n_ranges, hipStream_t s);
+// sums_all / nranks (teams): [nranks][LZ_NGRAM] partial sums of all ranks, added in rank order by the kernel; nranks = 0: scal[LZ_TMP ..]
+void launch_lz_block(const LzBlockArgs &a, bool full, double *scal, const int (*row_ranges)[2], int n_ranges, hipStream_t s,
+                     const double *sums_all = nullptr, int nranks = 0);
 void launch_lz_update(const double4 *xin, const double4 *y, const double4 *xprev, double4 *xnext, int j,
-                      double *scal, const int (*row_ranges)[2], int n_ranges, hipStream_t s, double2 *pv = nullptr);   // up to three disjoint row ranges in one launch; pv: also refresh the packed records
+                      double *scal, const int (*row_ranges)[2], int n_ranges, hipStream_t s, double2 *pv = nullptr,   // up to three disjoint row ranges in one launch; pv: also refresh the packed records
+                      const double *sums_all = nullptr, int nranks = 0);
 // tag_s (nullable): out[i].w = the particle's index in the caller's arrays, so the rows can be scattered by ranks that did not sort them
 void launch_sum_rows(const double4 *a, const double4 *b, const double4 *c, double4 *out, int lo, int hi, hipStream_t s,
                      const unsigned *tag_s = nullptr);

@@ -1797,18 +1797,6 @@ void launch_copy_list(const CopyList &l, hipStream_t s) {
     const int gx = std::max(1, std::min(256, nblocks((long)(mx / 2 + 1), TPB)));
     hipLaunchKernelGGL(k_copy_list, dim3(gx, l.n), dim3(TPB), 0, s, l);
 }
-__global__ void __launch_bounds__(TPB) k_sum_list(SumList l, int n) {
-    for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
-        double v = 0.0;
-        for (int r = 0; r < l.nsrc; ++r) v += l.src[r][i];   // rank order: deterministic
-        for (int q = 0; q < l.ndst; ++q) l.dst[q][i] = v;
-    }
-}
-void launch_sum_list(const SumList &l, int n, hipStream_t s) {
-    // ONE workgroup: sources and destinations are the same buffers, so every element must be read from all sources before it is
-    // written anywhere -- true within a thread (the loops above), and no other thread touches element i
-    hipLaunchKernelGGL(k_sum_list, dim3(nblocks(n, TPB)), dim3(TPB), 0, s, l, n);
-}
 void launch_add_inplace(double *a, const double *b, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_axpy_inplace, dim3(std::min<long>(2048, nblocks((long)n, TPB))), dim3(TPB), 0, s, a, b, n);
 }
@@ -1879,8 +1867,13 @@ k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, d
 struct RowRanges { int n, lo[3], hi[3]; };   // up to three row ranges (own rows and the two ghost layers), disjoint
 __global__ void __launch_bounds__(TPB)
 k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, const double4 *__restrict__ xprev,
-            double4 *__restrict__ xnext, int j, double *__restrict__ scal, RowRanges rg, double2 *__restrict__ pv) {
-    const double s1 = scal[LZ_TMP], s2 = scal[LZ_TMP + 1], s3raw = scal[LZ_TMP + 2];
+            double4 *__restrict__ xnext, int j, double *__restrict__ scal, RowRanges rg, double2 *__restrict__ pv,
+            const double *__restrict__ sums_all, int nranks) {
+    // the three sums: this GPU's (single GPU), or the ranks' partial sums added in rank order -- every rank holds all of them
+    // (they travel with the ghost rows: no separate all-reduce) and adds them in the same order: identical scalars everywhere
+    double s1 = 0.0, s2 = 0.0, s3raw = 0.0;
+    if (nranks > 0) for (int r = 0; r < nranks; ++r) { s1 += sums_all[r * LZ_NGRAM]; s2 += sums_all[r * LZ_NGRAM + 1]; s3raw += sums_all[r * LZ_NGRAM + 2]; }
+    else { s1 = scal[LZ_TMP]; s2 = scal[LZ_TMP + 1]; s3raw = scal[LZ_TMP + 2]; }
     const double bprev = j == 1 ? scal[LZ_NORM] : (j > 1 ? scal[LZ_BETA + j - 1] : 0.0);   // |x_{j-1}|
     const double ibprev = bprev > 0.0 ? 1.0 / bprev : 0.0;
     const double beta = s1 > 0.0 ? sqrt(s1) : 0.0;
@@ -1921,8 +1914,14 @@ k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, cons
 // The basis V holds the NORMALISED v_j here (the one-step path keeps unnormalised x_j).
 template <bool FULL>
 __global__ void __launch_bounds__(TPB)
-k_lz_block(LzBlockArgs a, double *__restrict__ scal, RowRanges rg) {
-    const double *G = scal + LZ_TMP;
+k_lz_block(LzBlockArgs a, double *__restrict__ scal, RowRanges rg, const double *__restrict__ sums_all, int nranks) {
+    double G[LZ_NGRAM];   // the ranks' partial sums added in rank order (they came with the ghost rows: see k_lz_update)
+#pragma unroll
+    for (int t = 0; t < LZ_NGRAM; ++t) {
+        double v = 0.0;
+        for (int r = 0; r < nranks; ++r) v += sums_all[r * LZ_NGRAM + t];
+        G[t] = nranks > 0 ? v : scal[LZ_TMP + t];
+    }
     const int j = a.j;
     const double n0 = G[LZG_QQ], s2 = n0 > 0.0 ? 1.0 / n0 : 0.0, sc = sqrt(s2);
     const double beta = j > 0 ? scal[LZ_BETA + j] : 0.0, alpha_prev = j > 0 ? scal[LZ_ALPHA + j - 1] : 0.0;
@@ -1978,14 +1977,14 @@ k_lz_block(LzBlockArgs a, double *__restrict__ scal, RowRanges rg) {
         }
     }
 }
-void launch_lz_block(const LzBlockArgs &a, bool full, double *scal, const int (*rg)[2], int nrg, hipStream_t s) {
+void launch_lz_block(const LzBlockArgs &a, bool full, double *scal, const int (*rg)[2], int nrg, hipStream_t s, const double *sums_all, int nranks) {
     RowRanges r{};
     r.n = nrg;
     int total = 0;
     for (int q = 0; q < nrg && q < 3; ++q) { r.lo[q] = rg[q][0]; r.hi[q] = rg[q][1]; total += rg[q][1] - rg[q][0]; }
     const dim3 g(vec_grid(std::max(1, total)));
-    if (full) hipLaunchKernelGGL(k_lz_block<true>, g, dim3(TPB), 0, s, a, scal, r);
-    else hipLaunchKernelGGL(k_lz_block<false>, g, dim3(TPB), 0, s, a, scal, r);
+    if (full) hipLaunchKernelGGL(k_lz_block<true>, g, dim3(TPB), 0, s, a, scal, r, sums_all, nranks);
+    else hipLaunchKernelGGL(k_lz_block<false>, g, dim3(TPB), 0, s, a, scal, r, sums_all, nranks);
 }
 
 void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, int lo, int hi, double *partials, int cap,
@@ -1995,12 +1994,12 @@ void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, in
     hipLaunchKernelGGL(k_lz_reduce, dim3(y ? 3 : 1), dim3(1024), 0, s, partials, g, cap, y ? 3 : 1, scal);
 }
 void launch_lz_update(const double4 *xin, const double4 *y, const double4 *xprev, double4 *xnext, int j,
-                      double *scal, const int (*rg)[2], int nrg, hipStream_t s, double2 *pv) {
+                      double *scal, const int (*rg)[2], int nrg, hipStream_t s, double2 *pv, const double *sums_all, int nranks) {
     RowRanges r{};
     r.n = nrg;
     int total = 0;
     for (int q = 0; q < nrg && q < 3; ++q) { r.lo[q] = rg[q][0]; r.hi[q] = rg[q][1]; total += rg[q][1] - rg[q][0]; }
-    hipLaunchKernelGGL(k_lz_update, dim3(vec_grid(std::max(1, total))), dim3(TPB), 0, s, xin, y, xprev, xnext, j, scal, r, pv);
+    hipLaunchKernelGGL(k_lz_update, dim3(vec_grid(std::max(1, total))), dim3(TPB), 0, s, xin, y, xprev, xnext, j, scal, r, pv, sums_all, nranks);
 }
 // out[i] = a[i] + b[i] + c[i] on rows [lo, hi)  (each may be null)
 __global__ void k_sum_rows(const double4 *__restrict__ a, const double4 *__restrict__ b, const double4 *__restrict__ c,

@@ -175,18 +175,22 @@ int pse_debug_kvector(pse_handle *h, int n, const int *ijk_host, double *out_hos
  * transforms are slab-local, an all-to-all transposes to y-slabs for the 1-D x transforms and the k-space scaling,
  * and back; the gather takes (P-1)/2 halo planes from the previous slab and (P+1)/2 from the next.  The near-field cell
  * layers along x are split the same way, so a rank owns one contiguous block of the cell-sorted rows: its near field,
- * its rows of every Lanczos vector (one ghost cell layer per neighbour and one 3-scalar all-reduce per iteration) and
- * its gathered velocities, exchanged once per call.  Particle arrays are replicated: every rank passes the same
- * pos/force and ends the call with the same vel/pos.
+ * its rows of every Lanczos vector and its gathered velocities, exchanged once per call.  The Lanczos iteration of a team
+ * runs TWO iterations per exchange where the decomposition allows (two ghost cell layers per neighbour, the second near-field
+ * product of a block on the own rows, the recurrence coefficients from eight summed products: pse_info.lanczos_exchanges),
+ * one per iteration otherwise; every exchange of a team -- ghost rows with the ranks' partial sums, all-to-alls, plane halos,
+ * the final row all-gather -- is ONE group of point-to-point transfers, all posted on one communication stream in program
+ * order, while the far-field chain and the near field / Lanczos chain run on two compute streams next to each other.
+ * Particle arrays are replicated: every rank passes the same pos/force and ends the call with the same vel/pos.
  * A team binds the local ranks to a transport: one member per process + the RCCL unique id of rank 0 (production, one
  * process per GPU), or all G members in one process with id = NULL (in-process loopback on one device, for tests). */
 typedef struct pse_team pse_team;
 int pse_team_unique_id(void *id128_host);   /* host buffer of 128 bytes, call on rank 0 and distribute */
 int pse_team_create(pse_handle **members, int n_members, const void *id128_host, pse_team **out);
 /* A third transport, supplied by the host program: one member per process as with RCCL, but every exchange is staged through
- * pinned host memory and handed to two callbacks -- a list of point-to-point transfers between ranks (every rank of the team
- * calls with its own list at the same point of the step; transfers between one pair of ranks match in list order) and a sum
- * over all ranks.  Buffers are host memory, counts are in doubles, send_to / recv_from = -1 where an entry has no send / no
+ * pinned host memory and handed to a callback -- a list of point-to-point transfers between ranks (every rank of the team
+ * calls with its own list at the same point of the step; transfers between one pair of ranks match in list order).  Buffers are
+ * host memory, counts are in doubles, send_to / recv_from = -1 where an entry has no send / no
  * receive; return 0 on success.  The exchanges are exactly those of the RCCL transport (same buffers, counts, peers and
  * order: both run through one transfer list), which is what makes the process-per-rank driver testable where RCCL cannot run
  * (two ranks on one GPU), e.g. over torch.distributed's gloo backend; it is also a fallback for nodes without xGMI. */

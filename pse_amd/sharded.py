@@ -100,13 +100,13 @@ class ShardedSimulation:
                     f"process-per-rank driver, far field {mode}; not a scaling number")
         if mode == "replicated":
             return (f"{self.world} GPUs: far field kept whole on every rank (at two ranks the all-to-all would cross one xGMI link "
-                    f"each way), near field / Lanczos vectors owned by the rank whose cell slab holds the particle (neighbour "
-                    f"ghost-layer exchange + 3-scalar all-reduce per iteration), one velocity all-gather per step; particle "
-                    f"arrays replicated")
+                    f"each way), near field / Lanczos vectors owned by the rank whose cell slab holds the particle (two Lanczos "
+                    f"iterations per exchange: two ghost cell layers + the partial sums in one send/recv group), one velocity "
+                    f"all-gather per step; particle arrays replicated")
         return (f"{self.world} GPUs: far-field grid in {self.world} x-slabs (RCCL all-to-all transpose, two-sided plane halo for "
-                f"the gather), near field / Lanczos vectors / gather owned by the rank whose cell slab holds the particle "
-                f"(neighbour ghost-layer exchange + 3-scalar all-reduce per iteration), one velocity all-gather per step; "
-                f"particle arrays replicated")
+                f"the gather) on a side lane next to the near field / Lanczos vectors owned by the rank whose cell slab holds "
+                f"the particle (two Lanczos iterations per exchange: two ghost cell layers + the partial sums in one send/recv "
+                f"group; all RCCL calls on one communication stream), one velocity all-gather per step; particle arrays replicated")
 
     def load(self, pos, force, mass=1.0):
         self.s = _State(self.n, pos, force, mass)

@@ -121,6 +121,8 @@ struct pse_handle {
     bool pv_is_f = false;        // the vector half of pv mirrors f_s (as the permute wrote it)
     bool w_is_mpsi = false;  // w_s already holds M_real psi_s (delivered by the pass that built the pair list)
     bool sums0_done = false; // ... and scal[LZ_TMP ..] the sums psi.psi, psi.M psi of Lanczos iteration 0
+    CombineSink sink = {};   // where the final Lanczos combination of this call sends its rows (velocity() sets it; off: ub_s)
+    bool tail_done = false;  // ... and it did: the sum of the three contributions has reached its destination
     bool async_mode = false; // pse_set_async: deterministic evaluations queue their work and return -- no flag read-back, capturable
     size_t n_cells_alloc = 0;
     float4 *posf_s = nullptr;   // single-precision copy of pos_s (cutoff pre-filter of the near field)
@@ -156,7 +158,9 @@ struct pse_handle {
     // Lanczos
     double4 *V = nullptr;        // [M_MAX + 1][n_max]
     double *scal = nullptr, *partials = nullptr;
-    double *sc_host = nullptr;   // pinned host copy of scal
+    double *sc_host = nullptr;   // pinned host copy of scal, mapped: the Lanczos kernels write alpha, beta, the norm there as well
+    double *sc_host_dev = nullptr;   // its device address
+    int *bounds_host_dev = nullptr;  // device address of bounds_host (mapped pinned): k_pick writes the row boundaries straight to the host
     int npart_cap = 0;
     // bookkeeping
     pse_info info;
@@ -486,10 +490,12 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     // covers what a call needs (a call that checks the kept list stops after flags[0]: flags[1] is the mark of its build)
     const size_t nbins = (size_t)((d.Nx + 7) / 8) * ((d.Ny + 7) / 8) * ((d.Nz + 7) / 8);
     const bool fast_far = d.P >= 4 && d.P <= FAR_PMAX;
-    h->cnt_bins = fast_far ? nbins + 1 : 0;
-    TRY(dmalloc(h, &h->cnt_block, h->cnt_bins + 2 + h->n_cells_alloc + 1));
-    h->vl.flags = h->cnt_block + h->cnt_bins;
-    h->cell_cnt = h->vl.flags + 2;
+    // layout in ints: [0, B - 1) bin counts (incl. sentinel, padded) | B - 1: flags[0] | B: flags[1] | B + 4 ...: cell counts.  B and every
+    // memset size are multiples of four ints: a memset that is not a multiple of 16 bytes takes two fill kernels.
+    h->cnt_bins = ((fast_far ? nbins + 1 : 0) + 1 + 3) & ~(size_t)3;   // B
+    TRY(dmalloc(h, &h->cnt_block, h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8));
+    h->vl.flags = h->cnt_block + h->cnt_bins - 1;
+    h->cell_cnt = h->cnt_block + h->cnt_bins + 4;
     if (fast_far) {   // fast far-field path: bin-ordered 64-byte records
         h->sw.fb.cnt = h->cnt_block;
         TRY(dmalloc(h, (char **)&h->sw.rec_t, (n + 64) * 64));   // 64-byte records (idle lanes read past the last one)
@@ -535,7 +541,8 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     TRY(dmalloc(h, &h->cgrid, 3 * ncx));
     if (h->grid_slabs > 1) { TRY(dmalloc(h, &h->sendbuf, 3 * ncx)); TRY(dmalloc(h, &h->recvbuf, 3 * ncx)); }
     if (h->n_slabs > 1) {
-        HIPCHK(hipHostMalloc((void **)&h->bounds_host, ((size_t)5 * h->n_slabs + 1) * sizeof(int), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&h->bounds_host, ((size_t)5 * h->n_slabs + 1) * sizeof(int), hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void **)&h->bounds_host_dev, h->bounds_host, 0));
         HIPCHK(hipEventCreateWithFlags(&h->ev_bounds, hipEventDisableTiming));
         TRY(dmalloc(h, &h->d_bidx, (size_t)5 * h->n_slabs + 1)); TRY(dmalloc(h, &h->d_bounds, (size_t)5 * h->n_slabs + 1));
         TRY(dmalloc(h, &h->utot_s, n));
@@ -573,7 +580,9 @@ static int create_impl(const pse_params *p, pse_handle *h) {
 
     TRY(dmalloc(h, &h->V, (size_t)(M_MAX + 1) * n));
     TRY(dmalloc(h, &h->scal, (size_t)LZ_NSCAL));
-    HIPCHK(hipHostMalloc((void **)&h->sc_host, LZ_NSCAL * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&h->sc_host, LZ_NSCAL * sizeof(double), hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void **)&h->sc_host_dev, h->sc_host, 0));
+    memset(h->sc_host, 0, LZ_NSCAL * sizeof(double));
     HIPCHK(hipEventCreateWithFlags(&h->ev_scal, hipEventDisableTiming)); 
     if (!h->partials) {
         h->npart_cap = std::max(LZ_NPART, mreal_partials_needed((int)n + 1024));   // + the padding of the row ranges (RowMap)
@@ -980,8 +989,7 @@ static int slab_bounds_issue(pse_handle *h) {
         HIPCHK(hipMemcpy(h->d_bidx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
         h->bidx_nc = h->nc;
     }
-    launch_pick(h->cell_off, h->d_bidx, (int)idx.size(), h->d_bounds, h->stream);
-    HIPCHK(hipMemcpyAsync(h->bounds_host, h->d_bounds, idx.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    launch_pick(h->cell_off, h->d_bidx, (int)idx.size(), h->bounds_host_dev, h->stream);   // straight into the mapped host buffer: no copy to queue
     HIPCHK(hipEventRecord(h->ev_bounds, h->stream));
     h->bounds_pending = true;
     return 0;
@@ -1049,7 +1057,7 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
     h->pv_is_f = vec != nullptr && h->pv != nullptr;
     const bool same_box = h->vl_box.Lx == h->box.Lx && h->vl_box.Ly == h->box.Ly && h->vl_box.Lz == h->box.Lz && h->vl_box.xy == h->box.xy;
     if (h->skin > 0.0 && !h->async_mode && h->vl_valid && !need_cells && h->vl_N == N && h->vl_group == group && same_box && h->sorted_N == N) {
-        HIPCHK(hipMemsetAsync(h->cnt_block, 0, (h->cnt_bins + 1) * sizeof(int), h->stream));   // bin counts + flags[0] ([1] is the build's overflow mark)
+        HIPCHK(hipMemsetAsync(h->cnt_block, 0, h->cnt_bins * sizeof(int), h->stream));   // bin counts + flags[0] ([1] is the build's overflow mark)
         launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream,
                        h->pos_build, 0.25 * h->skin * h->skin, h->vl.flags, CellRanges{}, nullptr, nullptr, &far, psi_out, h->par.seed, px.timestep);
         HIPCHK(hipMemcpyAsync(h->flags_host, h->vl.flags, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1100,7 +1108,7 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
         }
     }
     // one memset: the bin counts, both flags of the kept list, the cell counts (+ the sentinel)
-    HIPCHK(hipMemsetAsync(h->cnt_block, 0, (h->cnt_bins + 2 + (size_t)ncell + 1) * sizeof(int), h->stream));
+    HIPCHK(hipMemsetAsync(h->cnt_block, 0, ((h->cnt_bins + 4 + (size_t)ncell + 1 + 3) & ~(size_t)3) * sizeof(int), h->stream));   // (rounded up into the padding)
     HIPCHK(cell_sort(pos, group, N, h->dbox, h->nc, h->keys, h->vals, h->keys_s, h->cell_cnt, ncell, h->sort_tmp, h->sort_tmp_bytes,
                      h->cell_off, h->perm, h->stream, need, sb, true));
     launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream, nullptr, 0.0, nullptr,
@@ -1314,7 +1322,7 @@ static int update_ranges(const pse_handle *h, int N, int rg[3][2]) { return row_
 // ub_s = scale |psi| V t on the rows this rank owns.  Scalars are replicated; vectors are valid on the own rows (+ the
 // neighbouring cell layers for the vector the next mat-vec reads).
 static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, const std::function<int()> &before_first_wait = nullptr,
-                   WavePump *pump = nullptr) {
+                   WavePump *pump = nullptr, const std::function<int()> &before_combine = nullptr) {
     int n_exchanges = 0;
     pse_handle *h0 = T.m[0];
     const size_t stride = h0->n_pad;
@@ -1367,11 +1375,11 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
                 const int nrg = scalars_only ? 0 : update_ranges(h, N, rg);
                 const double4 *xj = done == 0 ? h->psi_s : h->V + (size_t)done * stride;
                 launch_lz_update(xj, h->w_s, done > 1 ? h->V + (size_t)(done - 1) * stride : (done == 1 ? h->psi_s : nullptr),
-                                 h->V + (size_t)(done + 1) * stride, done, h->scal, rg, nrg, h->stream, h->pv, h->sums_all, T.G > 1 ? T.G : 0);
+                                 h->V + (size_t)(done + 1) * stride, done, h->scal, rg, nrg, h->stream, h->pv, h->sums_all, T.G > 1 ? T.G : 0, h == h0 ? h->sc_host_dev : nullptr);
                 if (!scalars_only) h->pv_is_f = false;   // the vector half of pv now holds x_{j+1}
             }
         }
-        HIPCHK(hipMemcpyAsync(sc, h0->scal, LZ_NSCAL * sizeof(double), hipMemcpyDeviceToHost, h0->stream));
+        // (alpha, beta and the norm are already on their way: the update kernels write them to the mapped host buffer as well)
         HIPCHK(hipEventRecord(h0->ev_scal, h0->stream));
         if (!hook_done) {   // independent work queued behind the read-back keeps the GPU busy while the host decides
             hook_done = true;
@@ -1419,7 +1427,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
             const int j = done - 1;
             const double4 *xj = j == 0 ? h->psi_s : h->V + (size_t)j * stride;
             launch_lz_update(xj, h->w_s, j > 1 ? h->V + (size_t)(j - 1) * stride : (j == 1 ? h->psi_s : nullptr),
-                             h->V + (size_t)(j + 1) * stride, j, h->scal, rg, nrg, h->stream, h->pv, h->sums_all, T.G > 1 ? T.G : 0);
+                             h->V + (size_t)(j + 1) * stride, j, h->scal, rg, nrg, h->stream, h->pv, h->sums_all, T.G > 1 ? T.G : 0, h == h0 ? h->sc_host_dev : nullptr);
             h->pv_is_f = false;
         }
         pending_beta = done;
@@ -1429,12 +1437,14 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
         if (!lanczos_sqrt_e1(m_final, &sc[LZ_ALPHA], &sc[LZ_BETA], t_cur))
             return fail(PSE_ERR_NUMERIC, "tridiagonal eigen-solve failed at m = %d", m_final);
     }
+    if (before_combine) TRY(before_combine());   // (the far-field velocities must be in place if the combination adds them)
     for (pse_handle *h : act(T)) {
         BasisCoef tc{};   // the basis holds the unnormalised x_q: v_q = x_q / |x_q|, |x_0| = the norm of psi, |x_q| = beta_q
         for (int q = 0; q < m_final; ++q) tc.t[q] = t_cur[q] / (q == 0 ? sc[LZ_NORM] : sc[LZ_BETA + q]);
         int lo, hi;
         row_range(h, N, lo, hi);
-        launch_basis_combine(h->psi_s, h->V, stride, tc, m_final, h->scal, scale, 1, h->ub_s, lo, hi, h->stream);   // Brownian.cu:716,739
+        launch_basis_combine(h->psi_s, h->V, stride, tc, m_final, h->scal, scale, 1, h->ub_s, lo, hi, h->stream, h->sink);   // Brownian.cu:716,739
+        h->tail_done = h->sink.on;
         h->info.lanczos_m = m_final; h->info.lanczos_matvecs = done; h->info.lanczos_stepnorm = stepnorm;
         h->info.lanczos_exchanges = T.G > 1 ? n_exchanges : 0;
     }
@@ -1449,7 +1459,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
 // are the reference's (PSEv1/Brownian.cu:440-521) to rounding, so m is -- the tests hold it to the port's.  The first w1 = M psi
 // comes with the pass that built the pair list.  Exchanges per step at m = 7: 4 (one-step driver: 7).
 static int lanczos_team(pse_team &T, int N, double tol, double scale, int *m_io, const std::function<int()> &before_first_wait,
-                        WavePump *pump) {
+                        WavePump *pump, const std::function<int()> &before_combine = nullptr) {
     pse_handle *h0 = T.m[0];
     const size_t stride = h0->n_pad;
     int m_in = m_io ? *m_io : 2;
@@ -1474,7 +1484,7 @@ static int lanczos_team(pse_team &T, int N, double tol, double scale, int *m_io,
                 for (pse_handle *h : act(T)) {
                     int rg[3][2];
                     const int nrg = row_ranges(h, N, 2, rg);
-                    launch_lz_block(block_args(h, half_pending, false), false, h->scal, rg, nrg, h->stream, h->sums_all, T.G);
+                    launch_lz_block(block_args(h, half_pending, false), false, h->scal, rg, nrg, h->stream, h->sums_all, T.G, h == h0 ? h->sc_host_dev : nullptr);
                 }
                 half_pending = -1;
             }
@@ -1508,11 +1518,11 @@ static int lanczos_team(pse_team &T, int N, double tol, double scale, int *m_io,
             for (pse_handle *h : act(T)) {
                 int rg[3][2];
                 const int nrg = full ? row_ranges(h, N, 2, rg) : 0;   // a single step derives its scalars only, for now
-                launch_lz_block(block_args(h, j, full), full, h->scal, rg, nrg, h->stream, h->sums_all, T.G);
+                launch_lz_block(block_args(h, j, full), full, h->scal, rg, nrg, h->stream, h->sums_all, T.G, h == h0 ? h->sc_host_dev : nullptr);
             }
             if (full) done += 2; else { done += 1; half_pending = j; }
         }
-        HIPCHK(hipMemcpyAsync(sc, h0->scal, LZ_NSCAL * sizeof(double), hipMemcpyDeviceToHost, h0->stream));
+        // (alpha, beta and the norm are already on their way: the update kernels write them to the mapped host buffer as well)
         HIPCHK(hipEventRecord(h0->ev_scal, h0->stream));
         if (!hook_done) {   // independent work queued behind the read-back keeps the GPU busy while the host decides
             hook_done = true;
@@ -1556,12 +1566,14 @@ static int lanczos_team(pse_team &T, int N, double tol, double scale, int *m_io,
             return fail(PSE_ERR_NUMERIC, "tridiagonal eigen-solve failed at m = %d", m_final);
     }
     if (half_pending >= 0 && m_final > half_pending + 1) return fail(PSE_ERR_NUMERIC, "two-step Lanczos: basis vector %d was never formed", half_pending + 1);
+    if (before_combine) TRY(before_combine());   // (the far-field velocities must be in place if the combination adds them)
     for (pse_handle *h : act(T)) {
         BasisCoef tc{};   // the basis holds NORMALISED v_q here, except v_0 = psi / |psi|
         for (int q = 0; q < m_final; ++q) tc.t[q] = q == 0 ? t_cur[q] / sc[LZ_NORM] : t_cur[q];
         int lo, hi;
         row_range(h, N, lo, hi);
-        launch_basis_combine(h->psi_s, h->V, stride, tc, m_final, h->scal, scale, 1, h->ub_s, lo, hi, h->stream);   // Brownian.cu:716,739
+        launch_basis_combine(h->psi_s, h->V, stride, tc, m_final, h->scal, scale, 1, h->ub_s, lo, hi, h->stream, h->sink);   // Brownian.cu:716,739
+        h->tail_done = h->sink.on;
         h->info.lanczos_m = m_final; h->info.lanczos_matvecs = matvecs; h->info.lanczos_stepnorm = stepnorm;
         h->info.lanczos_exchanges = n_exchanges;
     }
@@ -1625,8 +1637,26 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
             return pump.drain();
         };
         const double tol = T.m[0]->d.error, scale = std::sqrt(2.0 * kT / dt);
-        if (sstep) TRY(lanczos_team(T, N, tol, scale, m_io, hook, &pump));
-        else TRY(lanczos(T, N, tol, scale, m_io, hook, &pump));
+        // The final combination of the Lanczos vectors adds the far-field and the near-field velocity of its row and sends the sum
+        // where the step wants it: one pass and one launch less than combination -> ub_s -> sum / un-sort.
+        for (size_t r = 0; r < T.m.size(); ++r) {
+            pse_handle *h = T.m[r];
+            h->tail_done = false;
+            h->sink = CombineSink{};
+            if (parts == 3) h->sink = CombineSink{true, h->uw_s, h->ur_s, h->tag_s, T.G == 1 ? a[r].vel : nullptr, T.G == 1 ? nullptr : h->utot_s};
+        }
+        const std::function<int()> join = [&]() -> int {   // the gathered far-field velocity is needed by the combination
+            TRY(pump.drain());
+            for (pse_handle *h : act(T))
+                if (h->side_on && h->sink.on) {
+                    HIPCHK(hipEventRecord(h->ev_join, h->side));
+                    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+                }
+            return 0;
+        };
+        if (sstep) TRY(lanczos_team(T, N, tol, scale, m_io, hook, &pump, join));
+        else TRY(lanczos(T, N, tol, scale, m_io, hook, &pump, join));
+        for (pse_handle *h : act(T)) h->sink = CombineSink{};
         *mask |= 1u << PH_LANCZOS;
         if (T.m[0]->matvec_timed) *mask |= 1u << PH_MATVEC;
     }
@@ -1639,6 +1669,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
                 HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
             }
         for (pse_handle *h : act(T)) {
+            if (noise && h->tail_done) continue;   // the Lanczos combination has written the summed rows already
             int lo, hi;
             row_range(h, N, lo, hi);
             launch_sum_rows((parts & 2) ? h->uw_s : nullptr, (parts & 1) ? h->ur_s : nullptr, noise ? h->ub_s : nullptr,
@@ -1656,7 +1687,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
         const double4 *ua = T.G > 1 ? h->utot_s : ((parts & 2) ? h->uw_s : nullptr);
         const double4 *ub = T.G > 1 ? nullptr : ((parts & 1) ? h->ur_s : nullptr), *uc = T.G > 1 ? nullptr : (noise ? h->ub_s : nullptr);
         const unsigned *tags = T.G > 1 ? nullptr : h->tag_s;     // a team: the tag travels in the fourth component of its row
-        launch_scatter_sum(ua, ub, uc, tags, N, a[r].vel, h->stream);
+        if (!(T.G == 1 && noise && h->tail_done)) launch_scatter_sum(ua, ub, uc, tags, N, a[r].vel, h->stream);   // (single GPU: the Lanczos combination has un-sorted the sum)
         if (tail) {
             // The Euler update stays its own pass in the CALLER's order (replicated state: every rank updates every particle,
             // bit-identically).  Fused into the un-sort it ran over the sorted rows and made five arrays scattered instead of

@@ -202,8 +202,11 @@ constexpr int LZ_NPART = 1024;  // partial-sum slots
 // out_s = scale * sum_q t[q] X[q], X[0] = x0, X[q] = V[q] (the UNNORMALISED Lanczos vectors: t carries the 1 / |x_q|)
 // rows [lo, hi)
 struct BasisCoef { double t[104]; };   // the m <= 100 coefficients of the final combination, passed by value
+// sink.on: the result is not stored in out_s but added to add_a + add_b (nullable) of the row and sent on: vel[tag].xyz (single GPU) or
+// rows[i] = (sum, tag) (a team's all-gathered array)
+struct CombineSink { bool on; const double4 *add_a, *add_b; const unsigned *tag_s; double4 *vel; double4 *rows; };
 void launch_basis_combine(const double4 *x0, const double4 *V, size_t stride, const BasisCoef &t, int m, const double *scal,
-                          double scale, int use_norm, double4 *out_s, int lo, int hi, hipStream_t s);
+                          double scale, int use_norm, double4 *out_s, int lo, int hi, hipStream_t s, CombineSink sink = CombineSink{});
 // Lanczos iteration on the own rows [lo, hi) (see k_lz_update in pse_kernels.hip).  dots: sums of x.x, x.y, x.vprev ->
 // scal[LZ_TMP..+2] (y = null: x.x only), for mat-vecs that did not fuse them; [all-reduce by the caller when sharded];
 // update: alpha_j, beta_j -> scal, x_{j+1} -> xnext
@@ -218,11 +221,12 @@ struct LzBlockArgs {
     int j;
 };
 // sums_all / nranks (teams): [nranks][LZ_NGRAM] partial sums of all ranks, added in rank order by the kernel; nranks = 0: scal[LZ_TMP ..]
+// sch: the host's copy of the scalars (device pointer of mapped pinned memory, nullable): alpha, beta, the norm are written there too
 void launch_lz_block(const LzBlockArgs &a, bool full, double *scal, const int (*row_ranges)[2], int n_ranges, hipStream_t s,
-                     const double *sums_all = nullptr, int nranks = 0);
+                     const double *sums_all = nullptr, int nranks = 0, double *sch = nullptr);
 void launch_lz_update(const double4 *xin, const double4 *y, const double4 *xprev, double4 *xnext, int j,
                       double *scal, const int (*row_ranges)[2], int n_ranges, hipStream_t s, double2 *pv = nullptr,   // up to three disjoint row ranges in one launch; pv: also refresh the packed records
-                      const double *sums_all = nullptr, int nranks = 0);
+                      const double *sums_all = nullptr, int nranks = 0, double *sch = nullptr);
 // tag_s (nullable): out[i].w = the particle's index in the caller's arrays, so the rows can be scattered by ranks that did not sort them
 void launch_sum_rows(const double4 *a, const double4 *b, const double4 *c, double4 *out, int lo, int hi, hipStream_t s,
                      const unsigned *tag_s = nullptr);

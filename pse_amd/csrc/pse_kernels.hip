@@ -1868,7 +1868,7 @@ struct RowRanges { int n, lo[3], hi[3]; };   // up to three row ranges (own rows
 __global__ void __launch_bounds__(TPB)
 k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, const double4 *__restrict__ xprev,
             double4 *__restrict__ xnext, int j, double *__restrict__ scal, RowRanges rg, double2 *__restrict__ pv,
-            const double *__restrict__ sums_all, int nranks) {
+            const double *__restrict__ sums_all, int nranks, double *__restrict__ sch) {
     // the three sums: this GPU's (single GPU), or the ranks' partial sums added in rank order -- every rank holds all of them
     // (they travel with the ghost rows: no separate all-reduce) and adds them in the same order: identical scalars everywhere
     double s1 = 0.0, s2 = 0.0, s3raw = 0.0;
@@ -1882,6 +1882,10 @@ k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, cons
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         scal[LZ_ALPHA + j] = alpha;
         if (j == 0) { scal[LZ_NORM] = beta; scal[LZ_BETA] = 0.0; } else scal[LZ_BETA + j] = beta;
+        if (sch) {   // the host's copy (mapped pinned memory): what the convergence check reads -- no device-to-host copy is queued
+            sch[LZ_ALPHA + j] = alpha;
+            if (j == 0) { sch[LZ_NORM] = beta; sch[LZ_BETA] = 0.0; } else sch[LZ_BETA + j] = beta;
+        }
     }
     const double cp = beta * ibprev;   // beta_j / beta_{j-1}
     const int n0 = rg.hi[0] - rg.lo[0], n1 = rg.n > 1 ? rg.hi[1] - rg.lo[1] : 0, n2 = rg.n > 2 ? rg.hi[2] - rg.lo[2] : 0;
@@ -1914,7 +1918,7 @@ k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, cons
 // The basis V holds the NORMALISED v_j here (the one-step path keeps unnormalised x_j).
 template <bool FULL>
 __global__ void __launch_bounds__(TPB)
-k_lz_block(LzBlockArgs a, double *__restrict__ scal, RowRanges rg, const double *__restrict__ sums_all, int nranks) {
+k_lz_block(LzBlockArgs a, double *__restrict__ scal, RowRanges rg, const double *__restrict__ sums_all, int nranks, double *__restrict__ sch) {
     double G[LZ_NGRAM];   // the ranks' partial sums added in rank order (they came with the ghost rows: see k_lz_update)
 #pragma unroll
     for (int t = 0; t < LZ_NGRAM; ++t) {
@@ -1950,6 +1954,12 @@ k_lz_block(LzBlockArgs a, double *__restrict__ scal, RowRanges rg, const double 
         scal[LZ_BETA + j + 1] = bp;
         if (FULL) { scal[LZ_ALPHA + j + 1] = alpha1; scal[LZ_BETA + j + 2] = bpp; }
         scal[LZ_UU + j + (FULL ? 2 : 1)] = uu_next;   // another slot than the one this launch reads
+        if (sch) {   // the host's copy (mapped pinned memory)
+            if (j == 0) { sch[LZ_NORM] = n0 > 0.0 ? sqrt(n0) : 0.0; sch[LZ_BETA] = 0.0; }
+            sch[LZ_ALPHA + j] = alpha;
+            sch[LZ_BETA + j + 1] = bp;
+            if (FULL) { sch[LZ_ALPHA + j + 1] = alpha1; sch[LZ_BETA + j + 2] = bpp; }
+        }
     }
     const int n0r = rg.n > 0 ? rg.hi[0] - rg.lo[0] : 0, n1r = rg.n > 1 ? rg.hi[1] - rg.lo[1] : 0, n2r = rg.n > 2 ? rg.hi[2] - rg.lo[2] : 0;
     for (int t = blockIdx.x * TPB + threadIdx.x; t < n0r + n1r + n2r; t += gridDim.x * TPB) {
@@ -1977,14 +1987,14 @@ k_lz_block(LzBlockArgs a, double *__restrict__ scal, RowRanges rg, const double 
         }
     }
 }
-void launch_lz_block(const LzBlockArgs &a, bool full, double *scal, const int (*rg)[2], int nrg, hipStream_t s, const double *sums_all, int nranks) {
+void launch_lz_block(const LzBlockArgs &a, bool full, double *scal, const int (*rg)[2], int nrg, hipStream_t s, const double *sums_all, int nranks, double *sch) {
     RowRanges r{};
     r.n = nrg;
     int total = 0;
     for (int q = 0; q < nrg && q < 3; ++q) { r.lo[q] = rg[q][0]; r.hi[q] = rg[q][1]; total += rg[q][1] - rg[q][0]; }
     const dim3 g(vec_grid(std::max(1, total)));
-    if (full) hipLaunchKernelGGL(k_lz_block<true>, g, dim3(TPB), 0, s, a, scal, r, sums_all, nranks);
-    else hipLaunchKernelGGL(k_lz_block<false>, g, dim3(TPB), 0, s, a, scal, r, sums_all, nranks);
+    if (full) hipLaunchKernelGGL(k_lz_block<true>, g, dim3(TPB), 0, s, a, scal, r, sums_all, nranks, sch);
+    else hipLaunchKernelGGL(k_lz_block<false>, g, dim3(TPB), 0, s, a, scal, r, sums_all, nranks, sch);
 }
 
 void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, int lo, int hi, double *partials, int cap,
@@ -1994,12 +2004,12 @@ void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, in
     hipLaunchKernelGGL(k_lz_reduce, dim3(y ? 3 : 1), dim3(1024), 0, s, partials, g, cap, y ? 3 : 1, scal);
 }
 void launch_lz_update(const double4 *xin, const double4 *y, const double4 *xprev, double4 *xnext, int j,
-                      double *scal, const int (*rg)[2], int nrg, hipStream_t s, double2 *pv, const double *sums_all, int nranks) {
+                      double *scal, const int (*rg)[2], int nrg, hipStream_t s, double2 *pv, const double *sums_all, int nranks, double *sch) {
     RowRanges r{};
     r.n = nrg;
     int total = 0;
     for (int q = 0; q < nrg && q < 3; ++q) { r.lo[q] = rg[q][0]; r.hi[q] = rg[q][1]; total += rg[q][1] - rg[q][0]; }
-    hipLaunchKernelGGL(k_lz_update, dim3(vec_grid(std::max(1, total))), dim3(TPB), 0, s, xin, y, xprev, xnext, j, scal, r, pv, sums_all, nranks);
+    hipLaunchKernelGGL(k_lz_update, dim3(vec_grid(std::max(1, total))), dim3(TPB), 0, s, xin, y, xprev, xnext, j, scal, r, pv, sums_all, nranks, sch);
 }
 // out[i] = a[i] + b[i] + c[i] on rows [lo, hi)  (each may be null)
 __global__ void k_sum_rows(const double4 *__restrict__ a, const double4 *__restrict__ b, const double4 *__restrict__ c,
@@ -2025,10 +2035,13 @@ void launch_pick(const int *cell_off, const int *idx, int n, int *out, hipStream
     hipLaunchKernelGGL(k_pick, dim3(nblocks(n, TPB)), dim3(TPB), 0, s, cell_off, idx, n, out);
 }
 
-// K13 gpu_stokes_MatVecMultiply_kernel (PSEv1/Helper.cu:251-279) + the final rescale (PSEv1/Brownian.cu:739)
+// K13 gpu_stokes_MatVecMultiply_kernel (PSEv1/Helper.cu:251-279) + the final rescale (PSEv1/Brownian.cu:739) -- and, round 4, what used to
+// be the next launch: with a sink the Brownian part is added to the far-field and near-field velocities of the row on the fly and
+// goes straight to where the step wants the sum (a team: the row of the all-gathered array, tag in .w; a single GPU: vel[tag].xyz),
+// so ub_s is neither written nor read back (K10 gpu_stokes_LinearCombination_kernel, PSEv1/Helper.cu:113-133)
 __global__ void __launch_bounds__(TPB)
 k_basis_combine(const double4 *__restrict__ x0, const double4 *__restrict__ V, size_t stride, BasisCoef tc, int m,
-                const double *__restrict__ scal, double scale, int use_norm, double4 *__restrict__ out, int lo, int N) {
+                const double *__restrict__ scal, double scale, int use_norm, double4 *__restrict__ out, int lo, int N, CombineSink sink) {
     const double *t = tc.t;   // kernel arguments: no host-to-device copy whose source the host would have to keep alive
     const double sc = use_norm ? scale * scal[LZ_NORM] : scale;
     for (int i = lo + blockIdx.x * TPB + threadIdx.x; i < N; i += gridDim.x * TPB) {
@@ -2038,13 +2051,22 @@ k_basis_combine(const double4 *__restrict__ x0, const double4 *__restrict__ V, s
             const double tq = t[q];
             x += tq * v.x; y += tq * v.y; z += tq * v.z;
         }
-        out[i] = make_double4(sc * x, sc * y, sc * z, 0.0);
+        x *= sc; y *= sc; z *= sc;
+        if (!sink.on) { out[i] = make_double4(x, y, z, 0.0); continue; }
+        // a + b + c in the order the separate pass added them: far field, near field, Brownian
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        if (sink.add_a) { const double4 v = sink.add_a[i]; sx += v.x; sy += v.y; sz += v.z; }
+        if (sink.add_b) { const double4 v = sink.add_b[i]; sx += v.x; sy += v.y; sz += v.z; }
+        sx += x; sy += y; sz += z;
+        const unsigned idx = sink.tag_s[i];
+        if (sink.vel) { double4 o = sink.vel[idx]; o.x = sx; o.y = sy; o.z = sz; sink.vel[idx] = o; }
+        else sink.rows[i] = make_double4(sx, sy, sz, (double)idx);
     }
 }
 void launch_basis_combine(const double4 *x0, const double4 *V, size_t stride, const BasisCoef &t_dev, int m, const double *scal,
-                          double scale, int use_norm, double4 *out_s, int lo, int hi, hipStream_t s) {
+                          double scale, int use_norm, double4 *out_s, int lo, int hi, hipStream_t s, CombineSink sink) {
     hipLaunchKernelGGL(k_basis_combine, dim3(std::min(2048, std::max(1, nblocks(hi - lo, TPB)))), dim3(TPB), 0, s, x0, V, stride,
-                       t_dev, m, scal, scale, use_norm, out_s, lo, hi);
+                       t_dev, m, scal, scale, use_norm, out_s, lo, hi, sink);
 }
 
 // Force provider next to the path (the step consumes net_force, PSEv1/Stokes.cc:447): soft repulsion

@@ -37,6 +37,59 @@ def cell_slabs(ncx, world):
     return [(r * per, (r + 1) * per) for r in range(world)]
 
 
+def kept_layers(ncx, world, rank, depth):
+    """Cell layers along x a slab rank orders and keeps particle data for: its own and `depth` ghost layers on either side (two with
+    the two-step Lanczos, one otherwise) -- or all of them when that covers the box (slab_need in csrc/pse_capi.hip)."""
+    per = ncx // world
+    if world == 1 or per + 2 * depth >= ncx:
+        return list(range(ncx))
+    return sorted({(rank * per - depth + k) % ncx for k in range(per + 2 * depth)})
+
+
+def slab_book(ncx, world, rank, depth):
+    """Where a rank counts the particles of layers it does not keep (prepare() / k_cell_keys in csrc/): per slab, on the first layer
+    of that slab the rank does not keep -- every kept layer of a slab lies before or after all of its unkept layers, so the prefix
+    sums of all kept cells and of every slab boundary come out global.  Returns {slab: layer} (None: the slab is kept whole)."""
+    per = ncx // world
+    kept = set(kept_layers(ncx, world, rank, depth))
+    out = {}
+    for q in range(world):
+        out[q] = next((l for l in range(q * per, (q + 1) * per) if l not in kept), None)
+    return out
+
+
+def row_map(ranges):
+    """List-row layout of up to three row ranges (own rows first): range k starts at list row base[k], a multiple of 256 (RowMap in
+    csrc/pse_kernels.h).  Returns (bases, total list rows)."""
+    bases, base = [], 0
+    for lo, hi in ranges:
+        bases.append(base)
+        base += (hi - lo + 255) // 256 * 256
+    return bases, base
+
+
+def two_step_block(G, alpha_prev, beta, uu, first):
+    """The scalars of one two-iteration Lanczos block from its Gram sums (k_lz_block in csrc/pse_kernels.hip), for tests: G =
+    dict with the eight sums qw1, w1w1, w1w2, w2w2, pw1, pw2, uw2, qq of q = v_j (unnormalised in the first block), p = v_{j-1},
+    u = M p, w1 = M q, w2 = M w1.  Returns alpha_j, beta_{j+1}, alpha_{j+1}, beta_{j+2}, |M v_{j+1}|^2."""
+    import math
+    s2 = 1.0 / G["qq"]; sc = math.sqrt(s2)
+    a, b, f = G["qw1"] * s2, G["w1w1"] * s2, G["pw1"] * sc
+    if first:
+        beta, alpha_prev, uu = 0.0, 0.0, 0.0
+    alpha = a
+    bp = math.sqrt(b - alpha * alpha - 2.0 * beta * f + beta * beta)
+    c, d, e, g, h = G["w1w2"] * s2, G["w2w2"] * s2, b, G["pw2"] * sc, G["uw2"] * sc
+    r1w2 = c - alpha * e - beta * g
+    r1w1 = b - alpha * a - beta * f
+    r1u = g - alpha * f - beta * alpha_prev
+    alpha1 = (r1w2 - alpha * r1w1 - beta * r1u) / (bp * bp)
+    zz = (d + alpha * alpha * b + beta * beta * uu - 2.0 * alpha * c - 2.0 * beta * h + 2.0 * alpha * beta * g) / (bp * bp)
+    qz = (e - alpha * a - beta * f) / bp
+    bpp = math.sqrt(max(zz - alpha1 * alpha1 - 2.0 * bp * qz + bp * bp, 0.0))
+    return alpha, bp, alpha1, bpp, zz
+
+
 def exchange_unique_id(rank, make_id, dist):
     """Rank 0 creates the RCCL unique id; everyone receives it (works on any torch.distributed backend)."""
     box = [make_id() if rank == 0 else None]

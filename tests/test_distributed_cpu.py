@@ -149,3 +149,76 @@ def test_host_staged_transport_over_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+# ---- round 4: host logic of the two-step Lanczos and of the per-slab counting (mirrors in pse_amd/sharded.py) ---------------------
+@pytest.mark.parametrize("ncx,world,depth", [(56, 8, 2), (8, 2, 2), (9, 3, 2), (8, 4, 2), (12, 4, 1), (6, 2, 1), (24, 8, 2), (5, 1, 2)])
+def test_per_slab_counting_gives_global_offsets_of_kept_cells(ncx, world, depth):
+    """A rank counts the particles of layers it does not keep per slab, on the first unkept layer of that slab: the prefix sums of
+    every kept cell and of every slab boundary must equal those of the full per-cell count (csrc: prepare() + k_cell_keys)."""
+    from pse_amd.sharded import kept_layers, slab_book
+    rng = np.random.default_rng(ncx * 100 + world)
+    cells_per_layer = 7
+    ncell = ncx * cells_per_layer
+    cell_of = rng.integers(0, ncell, 5000)
+    full = np.bincount(cell_of, minlength=ncell)
+    off_full = np.concatenate([[0], np.cumsum(full)])
+    per = ncx // world
+    for rank in range(world):
+        kept = set(kept_layers(ncx, world, rank, depth))
+        book = slab_book(ncx, world, rank, depth)
+        cnt = np.zeros(ncell, dtype=np.int64)
+        for c in cell_of:
+            layer = c // cells_per_layer
+            if layer in kept:
+                cnt[c] += 1
+            else:
+                b = book[layer // per]
+                assert b is not None and b not in kept
+                cnt[b * cells_per_layer + int(rng.integers(0, cells_per_layer))] += 1     # spread over the cells of that layer
+        off = np.concatenate([[0], np.cumsum(cnt)])
+        for layer in kept:                                            # every kept cell: begin and end
+            lo, hi = layer * cells_per_layer, (layer + 1) * cells_per_layer
+            assert np.array_equal(off[lo:hi + 1], off_full[lo:hi + 1]), (rank, layer)
+        for q in range(world + 1):                                    # every slab boundary
+            assert off[q * per * cells_per_layer] == off_full[q * per * cells_per_layer]
+
+
+def test_row_map_layout():
+    from pse_amd.sharded import row_map
+    bases, total = row_map([(1000, 1700), (5000, 5010), (0, 300)])
+    assert bases == [0, 768, 1024] and total == 1024 + 512
+    assert row_map([(0, 1_000_000)]) == ([0], 1_000_192)
+    assert row_map([(10, 10), (20, 21)]) == ([0, 0], 256)             # an empty own range takes no list rows
+
+
+def test_two_step_block_reproduces_lanczos():
+    """The closed-form scalars of a two-iteration block (Gram sums of {p, q, u, w1, w2}) against the textbook three-term recurrence on
+    a random symmetric positive definite matrix -- including the first block with an unnormalised start vector."""
+    from pse_amd.sharded import two_step_block
+    rng = np.random.default_rng(3)
+    n = 60
+    A = rng.normal(size=(n, n)); M = A @ A.T / n + 0.3 * np.eye(n)
+    psi = rng.normal(size=n)
+    # reference: plain Lanczos
+    V = [psi / np.linalg.norm(psi)]; al, be = [], [0.0]
+    for j in range(8):
+        w = M @ V[j] - (be[j] * V[j - 1] if j else 0.0)
+        al.append(V[j] @ w); w = w - al[j] * V[j]
+        be.append(np.linalg.norm(w)); V.append(w / be[-1])
+    # two-step blocks
+    q, p, u = psi.copy(), np.zeros(n), np.zeros(n)
+    alpha_prev, beta, uu = 0.0, 0.0, 0.0
+    got_a, got_b = [], [0.0]
+    for blk in range(4):
+        w1 = M @ q; w2 = M @ w1
+        G = dict(qw1=q @ w1, w1w1=w1 @ w1, w1w2=w1 @ w2, w2w2=w2 @ w2, pw1=p @ w1, pw2=p @ w2, uw2=u @ w2, qq=q @ q)
+        a0, b1, a1, b2, zz = two_step_block(G, alpha_prev, beta, uu, first=blk == 0)
+        sc = 1.0 / np.sqrt(G["qq"])
+        v1 = (sc * w1 - a0 * sc * q - beta * p) / b1
+        z1 = (sc * w2 - a0 * sc * w1 - beta * u) / b1
+        v2 = (z1 - a1 * v1 - b1 * sc * q) / b2
+        got_a += [a0, a1]; got_b += [b1, b2]
+        p, q, u, alpha_prev, beta, uu = v1, v2, z1, a1, b2, zz
+    assert np.allclose(got_a, al, rtol=1e-9) and np.allclose(got_b[1:], be[1:], rtol=1e-9)
+    assert abs(abs(q @ V[8]) - 1.0) < 1e-9                            # v_8 up to sign

@@ -1919,13 +1919,16 @@ k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, cons
 template <bool FULL>
 __global__ void __launch_bounds__(TPB)
 k_lz_block(LzBlockArgs a, double *__restrict__ scal, RowRanges rg, const double *__restrict__ sums_all, int nranks, double *__restrict__ sch) {
-    double G[LZ_NGRAM];   // the ranks' partial sums added in rank order (they came with the ghost rows: see k_lz_update)
-#pragma unroll
-    for (int t = 0; t < LZ_NGRAM; ++t) {
+    __shared__ double sG[LZ_NGRAM];   // the ranks' partial sums added in rank order (they came with the ghost rows: see k_lz_update):
+    if (threadIdx.x < LZ_NGRAM) {     // one lane per sum, once per workgroup
         double v = 0.0;
-        for (int r = 0; r < nranks; ++r) v += sums_all[r * LZ_NGRAM + t];
-        G[t] = nranks > 0 ? v : scal[LZ_TMP + t];
+        for (int r = 0; r < nranks; ++r) v += sums_all[r * LZ_NGRAM + threadIdx.x];
+        sG[threadIdx.x] = nranks > 0 ? v : scal[LZ_TMP + threadIdx.x];
     }
+    __syncthreads();
+    double G[LZ_NGRAM];
+#pragma unroll
+    for (int t = 0; t < LZ_NGRAM; ++t) G[t] = sG[t];
     const int j = a.j;
     const double n0 = G[LZG_QQ], s2 = n0 > 0.0 ? 1.0 / n0 : 0.0, sc = sqrt(s2);
     const double beta = j > 0 ? scal[LZ_BETA + j] : 0.0, alpha_prev = j > 0 ? scal[LZ_ALPHA + j - 1] : 0.0;

@@ -149,6 +149,7 @@ struct pse_handle {
     double4 *utot_s = nullptr;                               // slab mode: summed velocity of the own rows, all-gathered
     bool xfuse = false;                                      // power-of-two Nx: fused x pass (k_xfft_scale)
     bool own_y = false;                                      // y transforms by k_fft_cols, rocFFT does the z transforms only
+    bool own_y_slab = false;                                 // ... on a slab rank, with the all-to-all block layout as its output / input
     double2 *twiddle_y = nullptr;                            // [Ny] exp(-2 pi i m / Ny) (== twiddle when Ny == Nx)
     double2 *twiddle_y_owned = nullptr;
     int grid_slabs = 1;   // slabs the far-field grid is cut into: n_slabs, or 1 when every rank keeps the whole grid
@@ -309,7 +310,9 @@ static int make_plans(pse_handle *h) {
     }
     // the y transforms of a single GPU's grid by the own in-place pass where rocFFT's strided pass is slow (not a power of two)
     h->own_y = h->xfuse && h->grid_slabs == 1 && h->tun.own_y > 0 && yfft_supported(G.Ny);
-    if (h->own_y) {
+    // a slab rank: the own y pass for ANY smooth Ny -- it writes the all-to-all blocks directly (no pack / unpack pass)
+    h->own_y_slab = h->xfuse && h->grid_slabs > 1 && h->tun.own_y > 0 && yfft_possible(G.Ny);
+    if (h->own_y || h->own_y_slab) {
         if (G.Ny == G.Nx) h->twiddle_y = h->twiddle;
         else {
             std::vector<double2> tw(G.Ny);
@@ -358,7 +361,9 @@ static int make_plans(pse_handle *h) {
         // slab mode: 2-D (y,z) real transforms of the nxl local planes of one component, then (after the transpose)
         // 1-D complex transforms along x on [Nx][nyl][Nzp]: stride nyl*Nzp, one transform per (y,kz) column
         const size_t len2[2] = {(size_t)G.Nz, (size_t)G.Ny};
-        TRY(real_plans(2, len2, (size_t)G.nxl));
+        const size_t len1[1] = {(size_t)G.Nz};
+        if (h->own_y_slab) TRY(real_plans(1, len1, (size_t)G.nxl * G.Ny));   // z transforms only; the y transforms are k_fft_cols'
+        else TRY(real_plans(2, len2, (size_t)G.nxl));
         const size_t lenx[1] = {(size_t)G.Nx};
         size_t stride[1] = {(size_t)h->nyl * G.Nzp};
         rocfft_plan_description desc = nullptr;
@@ -1168,7 +1173,8 @@ static int wave_compute(pse_team &T, const WaveArgs &a, int part) {
                     void *in[1] = {h->rgrid + c * nr + (size_t)G.hl * G.Ny * G.Nz}, *out[1] = {h->cgrid + c * ncx};
                     FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
                 }
-                launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzp, h->nyl, 0, h->wstream);
+                if (h->own_y_slab) launch_yfft_slab(h->cgrid, h->sendbuf, G, h->nyl, false, h->twiddle_y, h->wstream);
+                else launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzp, h->nyl, 0, h->wstream);
             }
             TRY(tew(h, PH_FFTF));
         } else if (part == 1) {
@@ -1192,7 +1198,8 @@ static int wave_compute(pse_team &T, const WaveArgs &a, int part) {
                 void *in[1] = {h->cgrid}, *out[1] = {h->rgrid};
                 FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv));
             } else {
-                launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzp, h->nyl, 1, h->wstream);
+                if (h->own_y_slab) launch_yfft_slab(h->cgrid, h->sendbuf, G, h->nyl, true, h->twiddle_y, h->wstream);
+                else launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzp, h->nyl, 1, h->wstream);
                 for (int c = 0; c < 3; ++c) {
                     void *in[1] = {h->cgrid + c * ncx}, *out[1] = {h->rgrid + c * nr + (size_t)G.hl * G.Ny * G.Nz};
                     FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv));

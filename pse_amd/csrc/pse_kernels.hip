@@ -1617,9 +1617,13 @@ static void launch_xfft_mixed(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox 
 // two.  rocFFT's strided pass over y is its slow one there (360^2: 0.93 ms of the 1.40 ms of its 2-D transform, the z pass takes
 // 0.48 ms = what its bytes cost); here a workgroup takes KB consecutive kz of one x plane (KB * 16-byte pieces, neighbouring blocks on
 // one XCD as in the x pass) and all Ny rows, through the same mixed-radix passes as the x pass.  The z passes stay rocFFT's (1-D).
-template <int KB, int NTH, bool INVERSE>
+// MAP (slab ranks of a team): the transform also does the reordering between the plane layout [3][nxl][Ny][Nzp] and the layout of the
+// all-to-all blocks [3][G][nxl][nyl][Nzp] (y = q nyl + jl goes to rank q) -- 1: plane layout in, block layout out (forward: what
+// k_slab_pack did in a pass of its own); 2: block layout in, plane layout out (inverse: the unpack).  0: in place, plane layout.
+template <int KB, int NTH, bool INVERSE, int MAP = 0>
 __global__ void __launch_bounds__(NTH)
-k_fft_cols(double2 *__restrict__ data, FftPlanX pl, const double2 *__restrict__ twiddle, int nkb, int Nzh, int Nzp, size_t plane_stride) {
+k_fft_cols(double2 *__restrict__ data, FftPlanX pl, const double2 *__restrict__ twiddle, int nkb, int Nzh, int Nzp, size_t plane_stride,
+           double2 *__restrict__ other = nullptr, int nxl = 0, int nyl = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int N = pl.n, CS = N + 1;
     double2 *bufa = reinterpret_cast<double2 *>(smem_raw), *bufb = bufa + KB * CS;   // [KB][N + 1] each
@@ -1629,6 +1633,12 @@ k_fft_cols(double2 *__restrict__ data, FftPlanX pl, const double2 *__restrict__ 
     const int plane = bid / nkb, k0 = (bid - plane * nkb) * KB;
     const int kv = min(KB, Nzh - k0);
     double2 *base = data + (size_t)plane * plane_stride + k0;
+    // the same (plane, y) in the block layout: component c = plane / nxl, plane lx = plane % nxl of this rank, block q = y / nyl
+    const int pc = MAP ? plane / nxl : 0, plx = MAP ? plane - pc * nxl : 0;
+    auto blk = [&](int y) -> size_t {
+        const int q = y / nyl, jl = y - q * nyl;
+        return (size_t)pc * nxl * plane_stride + (((size_t)q * nxl + plx) * nyl + jl) * Nzp + k0;
+    };
     for (int e = tid; e < N; e += NTH) tw[e] = twiddle[e];
     const int total = N * KB;
     constexpr int U = 6;                                       // loads of a lane in flight at a time
@@ -1638,7 +1648,7 @@ k_fft_cols(double2 *__restrict__ data, FftPlanX pl, const double2 *__restrict__ 
         for (int u = 0; u < U; ++u) {
             const int e = e0 + u * NTH + tid, y = e / KB, q = e - y * KB;
             v[u] = make_double2(0, 0);
-            if (e < total && q < kv) v[u] = base[(size_t)y * Nzp + q];
+            if (e < total && q < kv) v[u] = MAP == 2 ? other[blk(y) + q] : base[(size_t)y * Nzp + q];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1650,8 +1660,15 @@ k_fft_cols(double2 *__restrict__ data, FftPlanX pl, const double2 *__restrict__ 
     const double2 *d = fft_mixed<INVERSE>(bufa, bufb, tw, pl, CS, KB, NTH);
     for (int e = tid; e < total; e += NTH) {
         const int y = e / KB, q = e - y * KB;
-        if (q < kv) base[(size_t)y * Nzp + q] = d[q * CS + y];
+        if (q < kv) {
+            if (MAP == 1) other[blk(y) + q] = d[q * CS + y];
+            else base[(size_t)y * Nzp + q] = d[q * CS + y];
+        }
     }
+}
+bool yfft_possible(int Ny) {    // any 2^a 3^b 5^c, 16..512 (slab ranks: the pass also packs / unpacks the all-to-all blocks)
+    FftPlanX pl;
+    return Ny >= 16 && Ny <= 512 && plan_x(Ny, pl);
 }
 bool yfft_supported(int Ny) {   // 2^a 3^b 5^c, 16..512, not a power of two (rocFFT's 2-D kernels are good at those)
     FftPlanX pl;
@@ -1671,6 +1688,24 @@ static void launch_fft_cols(double2 *data, const FftPlanX &pl, const double2 *tw
     const dim3 g(nplanes * nkb), b(NTH);
     if (inverse) hipLaunchKernelGGL((k_fft_cols<KB, NTH, true>), g, b, lds, s, data, pl, tw, nkb, Nzh, Nzp, plane_stride);
     else hipLaunchKernelGGL((k_fft_cols<KB, NTH, false>), g, b, lds, s, data, pl, tw, nkb, Nzh, Nzp, plane_stride);
+}
+// slab ranks: forward = planes (cgrid) -> transformed blocks (blocks); inverse = blocks -> transformed planes
+void launch_yfft_slab(double2 *cgrid, double2 *blocks, DGrid G, int nyl, bool inverse, const double2 *tw, hipStream_t s) {
+    FftPlanX pl;
+    plan_x(G.Ny, pl);
+    constexpr int KB = 4, NTH = 256;
+    const size_t lds = (size_t)(2 * KB * (pl.n + 1) + pl.n) * sizeof(double2);
+    static size_t attr_lds[2] = {48 * 1024, 48 * 1024};
+    if (lds > attr_lds[inverse]) {
+        if (inverse) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<KB, NTH, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<KB, NTH, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds[inverse] = lds;
+    }
+    const int nkb = (G.Nzh + KB - 1) / KB, nplanes = 3 * G.nxl;
+    const size_t ps = (size_t)G.Ny * G.Nzp;
+    const dim3 g(nplanes * nkb), b(NTH);
+    if (inverse) hipLaunchKernelGGL((k_fft_cols<KB, NTH, true, 2>), g, b, lds, s, cgrid, pl, tw, nkb, G.Nzh, G.Nzp, ps, blocks, G.nxl, nyl);
+    else hipLaunchKernelGGL((k_fft_cols<KB, NTH, false, 1>), g, b, lds, s, cgrid, pl, tw, nkb, G.Nzh, G.Nzp, ps, blocks, G.nxl, nyl);
 }
 // all three components: [3 Nx] planes of [Ny][Nzp]; tw[m] = exp(-2 pi i m / Ny)
 void launch_yfft(double2 *spectra, DGrid G, bool inverse, const double2 *tw, hipStream_t s, int kb) {

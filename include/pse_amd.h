@@ -89,13 +89,18 @@ int pse_set_stream(pse_handle *h, void *hip_stream);
 /* Asynchronous submission (off by default).  With it on, the deterministic entry points (pse_mobility, pse_pair_repulsion) only
  * QUEUE work on the handle's stream and return: nothing is read back, the host never waits, so a call can be captured into a
  * hipGraph by the caller (hipStreamBeginCapture on the handle's stream ... pse_mobility ... hipStreamEndCapture) and replayed
- * with new positions and forces in the same arrays -- tests/test_gpu_async.py does exactly that.  The price: whether a kept
- * neighbour list is still valid is a fact that lives on the device, so in this mode the list is NOT kept -- every call sorts and
- * walks the cells, as with r_buff = 0 (never a stale list).  Brownian calls still read the Lanczos scalars back once per
+ * with new positions and forces in the same arrays -- tests/test_gpu_async.py does exactly that.  Whether the kept neighbour list
+ * is still valid is then decided ON THE DEVICE: a call gathers the particles into the order of the last build, checks every
+ * displacement against r_buff / 2, and queues BOTH chains -- sort + cell walk + new list, and the kept-list pass -- whose kernels
+ * read the outcome and leave at once if it is not theirs (never a stale list, no round trip; about eight empty launches per
+ * call are the price).  Brownian calls rebuild every time in this mode and still read the Lanczos scalars back once per
  * convergence check (the tridiagonal square root is a host computation, as in the reference: PSEv1/Brownian.cu:540-582) and
  * cannot be captured; per-phase timing (pse_set_timing) synchronises by definition.  One warm-up call outside the capture first
  * (kernels set their shared-memory attributes on first use). */
 int pse_set_async(pse_handle *h, int enabled);
+/* test hook: the device-side decision of the most recent deterministic evaluation in asynchronous mode (synchronises):
+ * 0 the kept list was reused, != 0 it was rebuilt, -1 the call did not take the two-chain path */
+int pse_debug_last_gate(pse_handle *h, int *gate);
 /* Neighbour list kept across calls: replaces the NeighborListGPUBinned(rcut, r_buff = 0.4) with setEvery(1, dist_check)
  * that PSEv1/integrate.py:60,79 builds and Stokes::integrateStepOne refreshes with m_nlist->compute (PSEv1/Stokes.cc:433).
  * Pairs closer than rcut + r_buff are remembered at a build; later calls with the same N, group and box first check that no

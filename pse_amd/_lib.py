@@ -75,6 +75,7 @@ SYMBOLS = {
     "pse_set_stream": (_i, [_vp, _vp]),
     "pse_set_timing": (_i, [_vp, _i]),
     "pse_set_async": (_i, [_vp, _i]),
+    "pse_debug_last_gate": (_i, [_vp, _ip]),
     "pse_set_neighbor_skin": (_i, [_vp, _d]),
     "pse_neighbor_stats": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]),
     "pse_get_info": (_i, [_vp, ctypes.POINTER(pse_info)]),

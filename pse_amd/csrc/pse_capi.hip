@@ -124,6 +124,8 @@ struct pse_handle {
     CombineSink sink = {};   // where the final Lanczos combination of this call sends its rows (velocity() sets it; off: ub_s)
     bool tail_done = false;  // ... and it did: the sum of the three contributions has reached its destination
     bool async_mode = false; // pse_set_async: deterministic evaluations queue their work and return -- no flag read-back, capturable
+    bool gated = false;      // this call decides between the kept list and a rebuild ON THE DEVICE: both chains are queued (gate_word)
+    int *gate_word = nullptr;   // (cnt_block): flags[0] | flags[1] of this call, read by the kernels of both chains
     size_t n_cells_alloc = 0;
     float4 *posf_s = nullptr;   // single-precision copy of pos_s (cutoff pre-filter of the near field)
     double2 *pv = nullptr;      // [N][3] packed (position, Lanczos vector) records gathered by the pair-list mat-vec (single GPU)
@@ -500,6 +502,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     h->cnt_bins = ((fast_far ? nbins + 1 : 0) + 1 + 3) & ~(size_t)3;   // B
     TRY(dmalloc(h, &h->cnt_block, h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8));
     h->vl.flags = h->cnt_block + h->cnt_bins - 1;
+    h->gate_word = h->cnt_block + h->cnt_bins + 1;   // (B + 1: between flags[1] and the cell counts; no memset covers it alone)
     h->cell_cnt = h->cnt_block + h->cnt_bins + 4;
     if (fast_far) {   // fast far-field path: bin-ordered 64-byte records
         h->sw.fb.cnt = h->cnt_block;
@@ -681,6 +684,14 @@ extern "C" int pse_set_async(pse_handle *h, int enabled) {
     if (!h) return fail(PSE_ERR_INVALID, "null handle");
     h->async_mode = enabled != 0;
     h->vl_valid = false;
+    return 0;
+}
+extern "C" int pse_debug_last_gate(pse_handle *h, int *gate) {
+    if (!h || !gate) return fail(PSE_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *gate = -1;
+    if (h->gated) HIPCHK(hipMemcpy(gate, h->gate_word, sizeof(int), hipMemcpyDeviceToHost));
     return 0;
 }
 extern "C" int pse_set_timing(pse_handle *h, int enabled) {
@@ -1061,6 +1072,35 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
     h->vl_pending = false;
     h->pv_is_f = vec != nullptr && h->pv != nullptr;
     const bool same_box = h->vl_box.Lx == h->box.Lx && h->vl_box.Ly == h->box.Ly && h->vl_box.Lz == h->box.Lz && h->vl_box.xy == h->box.xy;
+    h->gated = false;
+    if (h->async_mode && !px.psi && h->skin > 0.0 && h->vl_valid && !need_cells && h->vl_N == N && h->vl_group == group && same_box &&
+        h->sorted_N == N && h->nc_wide && h->n_slabs == 1) {
+        // Asynchronous mode, a deterministic evaluation, a kept list exists: the decision "reuse or rebuild" is taken on the device and
+        // BOTH chains are queued -- the kernels of the chain not taken read the gate word and leave at once.  No read-back, nothing
+        // host-side depends on the outcome, so the call can be captured into a hipGraph and replayed with any positions.
+        //   ungated: gather into the order of the last build + distance check -> flags; decide -> gate word
+        //   rebuild chain (gate != 0): zero the bin and cell counts, cell sort, gather into the new order, [real(): cell pass that
+        //                              writes the list, positions of the build]
+        //   reuse chain (gate == 0):   [real(): the kept-list pass]
+        const int ncell = cells_total(h->nc);
+        HIPCHK(hipMemsetAsync(h->cnt_block, 0, h->cnt_bins * sizeof(int), h->stream));   // bin counts + flags[0]
+        launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream,
+                       h->pos_build, 0.25 * h->skin * h->skin, h->vl.flags, CellRanges{}, nullptr, nullptr, &far, nullptr, 0, 0);
+        launch_gate_decide(h->vl.flags, h->gate_word, h->stream);
+        const Gate rb{h->gate_word, 1};
+        launch_gate_zero(rb, h->cnt_block, h->cnt_bins - 1, h->cell_cnt, (size_t)ncell + 1, h->stream);   // (not the flags)
+        HIPCHK(cell_sort(pos, group, N, h->dbox, h->nc, h->keys, h->vals, h->keys_s, h->cell_cnt, ncell, h->sort_tmp, h->sort_tmp_bytes,
+                         h->cell_off, h->perm, h->stream, CellRanges{}, SlabBook{}, true, rb));
+        launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream, nullptr, 0.0, nullptr,
+                       CellRanges{}, h->cell_off, nullptr, &far, nullptr, 0, 0, rb);
+        h->gated = true;
+        h->vl.rskin = h->d.rcut + h->skin;
+        h->sw.need = CellRanges{}; h->sw.cell_off = h->cell_off;
+        ++h->nlist_builds;   // (counted as a build: which chain ran is known on the device only)
+        TRY(te(h, PH_SORT));
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (h->skin > 0.0 && !h->async_mode && h->vl_valid && !need_cells && h->vl_N == N && h->vl_group == group && same_box && h->sorted_N == N) {
         HIPCHK(hipMemsetAsync(h->cnt_block, 0, h->cnt_bins * sizeof(int), h->stream));   // bin counts + flags[0] ([1] is the build's overflow mark)
         launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream,
@@ -1084,8 +1124,9 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
     }
     h->vl_valid = false;
     ++h->nlist_builds;
-    // (asynchronous mode: whether the kept list is still good is known on the device only -- it is not kept, every call builds)
-    const bool with_list = h->skin > 0.0 && !h->async_mode && h->vl_suspend_left[h->vl_kind] == 0;
+    // (asynchronous mode: no host-side feedback, hence no suspension logic -- deterministic evaluations always keep the list, for the
+    // device-side decision of the next call; Brownian calls, which cannot take that path, do not)
+    const bool with_list = h->skin > 0.0 && (h->async_mode ? !px.psi : h->vl_suspend_left[h->vl_kind] == 0);
     if (h->skin > 0.0 && !h->async_mode && !with_list) --h->vl_suspend_left[h->vl_kind];
     if (h->skin_max > 0.0) {   // cells as wide as this build reaches: rcut + r_buff with the list, rcut without
         const bool wide = h->nc_wide;
@@ -1305,6 +1346,19 @@ static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*ou
         if (h->vl_use) vlm = VL_USE;
         else if (h->vl_pending && mode != MREAL_USE_LIST) vlm = VL_WRITE;
         const double4 *v = h->*vec + vec_off;
+        if (h->gated && mode == MREAL_CELLS) {   // both chains, gated on the device-side decision of prepare()
+            const RowMap rows = rank_rows(h, N, 0);
+            const int nco = h->n_intervals * 2 * RS_NCOEF;
+            const Gate rb{h->gate_word, 1}, ru{h->gate_word, 0};
+            launch_mreal(h->pos_s, h->posf_s, v, h->*out + out_off, rows, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, nco,
+                         h->nb, MREAL_CELLS, h->stream, nullptr, nullptr, h->vl, VL_WRITE, nullptr, nullptr, nullptr, 0, nullptr, rb);
+            launch_gate_copy(rb, h->pos_build, h->pos_s, (size_t)N, h->stream);
+            launch_mreal(h->pos_s, h->posf_s, v, h->*out + out_off, rows, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, nco,
+                         h->nb, MREAL_CELLS, h->stream, nullptr, nullptr, h->vl, VL_USE,
+                         v == h->f_s && h->pv_is_f ? h->pv : nullptr, nullptr, nullptr, 0, nullptr, ru);
+            h->vl_valid = true; h->vl_box = h->box;
+            continue;
+        }
         const bool psi = with_psi && mode == MREAL_BUILD_LIST;
         launch_mreal(h->pos_s, h->posf_s, v, h->*out + out_off, rank_rows(h, N, mode == MREAL_BUILD_LIST ? depth : 0), h->cell_off, h->dbox,
                      h->nc, h->d.rcut, h->d.self, h->coef, h->n_intervals * 2 * RS_NCOEF, h->nb, mode, h->stream,

@@ -54,12 +54,24 @@ inline RowMap row_map(const int (*rg)[2], int n) {
     return m;
 }
 
+// A launch that runs only on one outcome of a decision taken ON THE DEVICE earlier in the stream (asynchronous mode: whether the kept
+// neighbour list may be reused): every workgroup reads the word and leaves at once when the gate is closed.  word = null: always open.
+struct Gate {
+    const int *word;
+    int want;   // 1: run if *word != 0 (rebuild), 0: run if *word == 0 (reuse)
+    __device__ __forceinline__ bool closed() const { return word != nullptr && ((*word != 0) != (want != 0)); }
+};
+// gate word <- flags[0] | flags[1] (moved beyond the skin | a row overflowed at the build); a rebuild starts with flags[1] cleared
+void launch_gate_decide(int *flags, int *word, hipStream_t s);
+void launch_gate_zero(Gate g, int *a, size_t na, int *b, size_t nb, hipStream_t s);          // two int ranges zeroed if the gate is open
+void launch_gate_copy(Gate g, double4 *dst, const double4 *src, size_t n, hipStream_t s);    // dst <- src if the gate is open
 // n > 0 (a slab rank that keeps only some cell layers): the particles of cells it does not keep are counted per slab of
 // cells_per_slab storage cells, on cell book[slab] -- the first cell of that slab the rank does not keep
 struct SlabBook { int n, cells_per_slab, spread, book[64]; };   // spread: the counts go to cells book[slab] .. book[slab] + spread - 1 (one layer)
 hipError_t cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys, unsigned *rank,
                      unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s,
-                     CellRanges need = CellRanges{}, SlabBook sb = SlabBook{}, bool cnt_is_zero = false);   // cnt[0 .. ncell] already zeroed by the caller
+                     CellRanges need = CellRanges{}, SlabBook sb = SlabBook{}, bool cnt_is_zero = false,   // cnt[0 .. ncell] already zeroed by the caller
+                     Gate gate = Gate{});
 // pos_s[i] = wrapped position of particle perm[i], vec_s[i] = vec[tag].xyz, tag_s[i] = its index in the caller's arrays
 // pos_build (nullable): the sorted positions the neighbour list was built at; a particle that has moved more than
 // sqrt(half_skin2) from there (minimum image) sets flags[0] -- HOOMD's NeighborList distance check (r_buff / 2)
@@ -69,7 +81,8 @@ void launch_permute(const double4 *pos, const double4 *vec, const unsigned *grou
                     CellRanges need = CellRanges{}, const int *cell_off = nullptr,    // a slab rank: the needed rows only
                     double2 *pv2 = nullptr,                                           // second set of packed records (position half)
                     const struct FarBinArgs *far = nullptr,                           // rank the particles in their far-field bins
-                    double4 *psi_s = nullptr, uint32_t seed = 0, uint32_t timestep = 0);   // draw the particle noise of this step (K14)
+                    double4 *psi_s = nullptr, uint32_t seed = 0, uint32_t timestep = 0,    // draw the particle noise of this step (K14)
+                    Gate gate = Gate{});
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s);
 
 // ---- near field (K9) -------------------------------------------------------------------------------------
@@ -117,7 +130,8 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
                   VerletList vl = VerletList{}, int vl_mode = VL_NONE,   // VL_WRITE: the cell pass also writes the neighbour list; VL_USE: no cell walk
                   const double2 *pv = nullptr,                           // VL_USE: packed (position, vec_s) records
                   double2 *pv_out = nullptr,                             // BUILD_LIST with a second vector: out2 also goes into these records
-                  double *sums0 = nullptr, int sums0_cap = 0, double *scal = nullptr);   // ... and the sums vec2.vec2, vec2.out2 are left in scal[LZ_TMP ..] (Lanczos iteration 0)
+                  double *sums0 = nullptr, int sums0_cap = 0, double *scal = nullptr,    // ... and the sums vec2.vec2, vec2.out2 are left in scal[LZ_TMP ..] (Lanczos iteration 0)
+                  Gate gate = Gate{});                                   // cell pass / kept-list pass without a pair list: run on one outcome of the device-side list check only
 bool mreal_table_in_lds(int ncoef);   // the neighbour list across steps needs the LDS copy of the table
 // pair-list mat-vec + Lanczos sums; leaves the three reduced sums in scal[LZ_TMP .. LZ_TMP + 2]
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, RowMap rows, const int *cell_off,

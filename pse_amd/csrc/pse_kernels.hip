@@ -45,7 +45,8 @@ constexpr unsigned KEY_FOREIGN = 0xFFFFFFFFu;   // a particle a slab rank counts
 // the layer's first cell -- was slower: 58 us against 45 us; the kernel is not bound by its global atomics.)
 __global__ void k_cell_keys(const double4 *__restrict__ pos, const unsigned *__restrict__ group, int N, DBox box,
                             DCells nc, unsigned *__restrict__ keys, unsigned *__restrict__ rank, int *__restrict__ cnt, CellRanges need,
-                            SlabBook sb) {
+                            SlabBook sb, Gate gate) {
+    if (gate.closed()) return;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = g < N;
     unsigned key = 0;
@@ -88,7 +89,8 @@ __global__ void k_cell_keys(const double4 *__restrict__ pos, const unsigned *__r
     }
 }
 __global__ void k_cell_scatter(const unsigned *__restrict__ keys, const unsigned *__restrict__ rank,
-                               const int *__restrict__ cell_off, int N, unsigned *__restrict__ slots) {
+                               const int *__restrict__ cell_off, int N, unsigned *__restrict__ slots, Gate gate) {
+    if (gate.closed()) return;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < N && keys[g] != KEY_FOREIGN) slots[cell_off[keys[g]] + rank[g]] = (unsigned)g;
 }
@@ -96,7 +98,8 @@ __global__ void k_cell_scatter(const unsigned *__restrict__ keys, const unsigned
 // few words), write it in order.  (One wave per cell kept five of 64 lanes busy: 33 us at N = 1e6; this way 10.)
 __global__ void __launch_bounds__(TPB)
 k_cell_order(const int *__restrict__ cell_off, const unsigned *__restrict__ keys, int N, const unsigned *__restrict__ slots,
-             unsigned *__restrict__ perm, CellRanges need) {
+             unsigned *__restrict__ perm, CellRanges need, Gate gate) {
+    if (gate.closed()) return;
     const int s = blockIdx.x * TPB + threadIdx.x;
     if (s >= N || !need.row(s, cell_off)) return;
     const unsigned v = slots[s];
@@ -112,15 +115,15 @@ size_t cell_sort_temp_bytes(size_t ncell) {
 }
 hipError_t cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys, unsigned *rank,
                      unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s,
-                     CellRanges need, SlabBook sb, bool cnt_is_zero) {
+                     CellRanges need, SlabBook sb, bool cnt_is_zero, Gate gate) {
     hipError_t e = cnt_is_zero ? hipSuccess : hipMemsetAsync(cnt, 0, (size_t)(ncell + 1) * sizeof(int), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_cell_keys, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, group, N, box, nc, keys, rank, cnt, need, sb);
+    hipLaunchKernelGGL(k_cell_keys, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, group, N, box, nc, keys, rank, cnt, need, sb, gate);
     // cnt[ncell] = 0: cell_off[ncell] = N.  A failed scan (scratch too small for ncell) would leave garbage offsets: reported
     e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt, cell_off, ncell + 1, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_cell_scatter, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, keys, rank, cell_off, N, slots);
-    hipLaunchKernelGGL(k_cell_order, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, cell_off, keys, N, slots, perm, need);
+    hipLaunchKernelGGL(k_cell_scatter, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, keys, rank, cell_off, N, slots, gate);
+    hipLaunchKernelGGL(k_cell_order, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, cell_off, keys, N, slots, perm, need, gate);
     return hipGetLastError();
 }
 
@@ -133,7 +136,8 @@ k_permute(const double4 *__restrict__ pos, const double4 *__restrict__ vec,
                           double4 *__restrict__ pos_s, float4 *__restrict__ posf_s, double2 *__restrict__ pv,
                           double4 *__restrict__ vec_s, unsigned *__restrict__ tag_s, const double4 *__restrict__ pos_build,
                           double half_skin2, int *__restrict__ flags, CellRanges need, const int *__restrict__ cell_off,
-                          double2 *__restrict__ pv2, FarBinArgs far, double4 *__restrict__ psi_s, uint32_t seed, uint32_t timestep) {
+                          double2 *__restrict__ pv2, FarBinArgs far, double4 *__restrict__ psi_s, uint32_t seed, uint32_t timestep, Gate gate) {
+    if (gate.closed()) return;
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s - (int)(threadIdx.x & 63) >= N) return;            // whole wave past the end
     const bool live = s < N && need.row(s, cell_off);        // a slab rank holds particle data for its own and its ghost rows only
@@ -214,9 +218,31 @@ __global__ void k_permute_vec(const double4 *__restrict__ vec, const unsigned *_
 void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm, int N, DBox box,
                     double4 *pos_s, float4 *posf_s, double2 *pv, double4 *vec_s, unsigned *tag_s, hipStream_t s,
                     const double4 *pos_build, double half_skin2, int *flags, CellRanges need, const int *cell_off, double2 *pv2,
-                    const FarBinArgs *far, double4 *psi_s, uint32_t seed, uint32_t timestep) {
+                    const FarBinArgs *far, double4 *psi_s, uint32_t seed, uint32_t timestep, Gate gate) {
     hipLaunchKernelGGL(k_permute, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, vec, group, perm, N, box, pos_s, posf_s, pv, vec_s, tag_s,
-                       pos_build, half_skin2, flags, need, cell_off, pv2, far ? *far : FarBinArgs{}, psi_s, seed, timestep);
+                       pos_build, half_skin2, flags, need, cell_off, pv2, far ? *far : FarBinArgs{}, psi_s, seed, timestep, gate);
+}
+__global__ void k_gate_decide(int *__restrict__ flags, int *__restrict__ word) {
+    const int f = flags[0] | flags[1];
+    *word = f;
+    if (f) flags[1] = 0;   // the build that follows sets it again if a row overflows
+}
+void launch_gate_decide(int *flags, int *word, hipStream_t s) { hipLaunchKernelGGL(k_gate_decide, dim3(1), dim3(1), 0, s, flags, word); }
+__global__ void k_gate_zero(Gate g, int *__restrict__ a, size_t na, int *__restrict__ b, size_t nb) {
+    if (g.closed()) return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < na) a[i] = 0; else b[i - na] = 0;
+    }
+}
+void launch_gate_zero(Gate g, int *a, size_t na, int *b, size_t nb, hipStream_t s) {
+    hipLaunchKernelGGL(k_gate_zero, dim3(std::max(1, std::min(1024, nblocks((long)(na + nb), TPB)))), dim3(TPB), 0, s, g, a, na, b, nb);
+}
+__global__ void k_gate_copy(Gate g, double4 *__restrict__ dst, const double4 *__restrict__ src, size_t n) {
+    if (g.closed()) return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void launch_gate_copy(Gate g, double4 *dst, const double4 *src, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_gate_copy, dim3(std::max(1, std::min(4096, nblocks((long)n, TPB)))), dim3(TPB), 0, s, g, dst, src, n);
 }
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s) {
     hipLaunchKernelGGL(k_permute_vec, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, vec, tag_s, N, vec_s);
@@ -270,7 +296,8 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
               double4 *__restrict__ out_s, RowMap rm, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2,
               float rcut2_pre, double self, const double *__restrict__ coef_g, int ncoef, NbList nb,
               const double4 *__restrict__ vec2_s, double4 *__restrict__ out2_s, VerletList vl, double2 *__restrict__ pv_out,
-              double *__restrict__ sums0, int sums0_cap) {
+              double *__restrict__ sums0, int sums0_cap, Gate gate) {
+    if (gate.closed()) return;
     // the pass that also writes the kept neighbour list queues every pair within rcut + r_buff (28 per row instead of 21): a deeper
     // queue, or half of the waves would stop for an extra, poorly filled drain in the middle of the walk
     constexpr int QC = VL ? 64 : QCAP;
@@ -482,7 +509,8 @@ template <bool LIST, bool TWO, bool PK>
 __global__ void __launch_bounds__(TPB)
 k_mreal_verlet(const double4 *__restrict__ pos_s, const double2 *__restrict__ pv, const double4 *__restrict__ vec_s,
                double4 *__restrict__ out_s, int N, DBox box, double rcut2, double self, const double *__restrict__ coef_g, int ncoef,
-               NbList nb, VerletList vl, const double4 *__restrict__ vec2_s, double4 *__restrict__ out2_s) {
+               NbList nb, VerletList vl, const double4 *__restrict__ vec2_s, double4 *__restrict__ out2_s, Gate gate) {
+    if (gate.closed()) return;
     extern __shared__ double scoef[];
     const int tid = threadIdx.x;
     for (int q = tid; q < ncoef; q += TPB) scoef[(q / (2 * RS_NCOEF)) * (2 * RS_NCOEF + 1) + q % (2 * RS_NCOEF)] = coef_g[q];
@@ -748,7 +776,7 @@ bool mreal_table_in_lds(int ncoef) { return mreal_lds_bytes(ncoef) <= 14 * 1024;
 void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec_s, double4 *out_s, RowMap rm,
                   const int *cell_off, DBox box, DCells nc, double rcut, double self, const double *coef, int ncoef, NbList nb,
                   int mode, hipStream_t s, const double4 *vec2_s, double4 *out2_s, VerletList vl, int vl_mode, const double2 *pv,
-                  double2 *pv_out, double *sums0, int sums0_cap, double *scal) {
+                  double2 *pv_out, double *sums0, int sums0_cap, double *scal, Gate gate) {
     const int rows = rm.list_rows();
     if (rows <= 0) return;
     const dim3 g(nblocks(rows, TPB)), b(TPB);
@@ -763,8 +791,8 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
     const bool list = mode == MREAL_BUILD_LIST, two = list && vec2_s != nullptr;
     if (vl_mode == VL_USE) {   // rows [0, N) of a single rank; the table is in LDS (the caller checked mreal_table_in_lds)
         const int hi = rm.hi[0];
-#define PSE_VERLET(L, T) do { if (pv) hipLaunchKernelGGL((k_mreal_verlet<L, T, true>), g, b, cb, s, pos_s, pv, vec_s, out_s, hi, box, rcut * rcut, self, coef, ncoef, nb, vl, two ? vec2_s : nullptr, out2_s); \
-        else hipLaunchKernelGGL((k_mreal_verlet<L, T, false>), g, b, cb, s, pos_s, pv, vec_s, out_s, hi, box, rcut * rcut, self, coef, ncoef, nb, vl, two ? vec2_s : nullptr, out2_s); } while (0)
+#define PSE_VERLET(L, T) do { if (pv) hipLaunchKernelGGL((k_mreal_verlet<L, T, true>), g, b, cb, s, pos_s, pv, vec_s, out_s, hi, box, rcut * rcut, self, coef, ncoef, nb, vl, two ? vec2_s : nullptr, out2_s, gate); \
+        else hipLaunchKernelGGL((k_mreal_verlet<L, T, false>), g, b, cb, s, pos_s, pv, vec_s, out_s, hi, box, rcut * rcut, self, coef, ncoef, nb, vl, two ? vec2_s : nullptr, out2_s, gate); } while (0)
         if (list && two) PSE_VERLET(true, true);
         else if (list) PSE_VERLET(true, false);
         else PSE_VERLET(false, false);
@@ -777,7 +805,7 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
     const double cmax = 1.5 * (box.Lx + std::fabs(box.xy) * box.Ly + box.Ly + box.Lz);
     const double rpre = (wr ? vl.rskin : rcut) + 16.0 * cmax * 5.97e-8;
     const float rcut2_pre = (float)(rpre * rpre * (1.0 + 1e-6));
-#define PSE_CELLS(L, C, T, V) hipLaunchKernelGGL((k_mreal_cells<L, C, T, V>), g, b, (C) ? cb : 0, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, two ? vec2_s : nullptr, out2_s, vl, two ? pv_out : nullptr, (two && (C)) ? sums0 : nullptr, sums0_cap)
+#define PSE_CELLS(L, C, T, V) hipLaunchKernelGGL((k_mreal_cells<L, C, T, V>), g, b, (C) ? cb : 0, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, two ? vec2_s : nullptr, out2_s, vl, two ? pv_out : nullptr, (two && (C)) ? sums0 : nullptr, sums0_cap, gate)
     if (list) {
         if (cl && two) { if (wr) PSE_CELLS(true, true, true, true); else PSE_CELLS(true, true, true, false); }
         else if (cl) { if (wr) PSE_CELLS(true, true, false, true); else PSE_CELLS(true, true, false, false); }

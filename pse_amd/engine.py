@@ -95,8 +95,15 @@ class Engine:
         _lib.check(self._lib.pse_set_timing(self._h, 1 if on else 0))
 
     def set_async(self, on=True):
-        """Deterministic evaluations only queue work (no read-back, capturable into a hipGraph); the neighbour list is not kept."""
+        """Deterministic evaluations only queue work (no read-back, capturable into a hipGraph); reuse or rebuild of the kept
+        neighbour list is decided on the device."""
         _lib.check(self._lib.pse_set_async(self._h, 1 if on else 0))
+
+    def debug_last_gate(self):
+        """0: the last asynchronous evaluation reused the kept list, != 0: it rebuilt, -1: it did not take the two-chain path."""
+        g = ctypes.c_int(-2)
+        _lib.check(self._lib.pse_debug_last_gate(self._h, ctypes.byref(g)))
+        return g.value
 
     def set_neighbor_skin(self, r_buff):
         """r_buff of the neighbour list kept across calls (HOOMD's nlist r_buff, PSEv1/integrate.py:60); 0 rebuilds every call."""

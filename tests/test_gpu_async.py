@@ -51,9 +51,48 @@ def test_mobility_captured_into_a_graph_replays_the_computation(n, grid, xy):
         assert np.all(out[:, 3] == 7.0)                    # vel.w is preserved
 
 
+@pytest.mark.parametrize("xy", [0.0, 0.25])
+def test_device_side_list_decision_in_a_captured_graph(xy):
+    """Asynchronous mode keeps the neighbour list and decides on the device whether a call may reuse it: ONE captured graph replays
+    small moves (reuse chain), moves beyond r_buff / 2 (rebuild chain) and small moves again, each time equal to an eager call."""
+    import torch
+    import pse_amd
+    n = 20000
+    pos, force, box = make_suspension(n, phi=0.15, xy=xy)
+    kw = dict(xi=0.5, error=1e-3, seed=2)
+    ref = pse_amd.Engine(n, box, **kw)
+    ref.set_neighbor_skin(0.0)                             # the checker rebuilds every call
+    eng = pse_amd.Engine(n, box, **kw)
+    eng.set_async(True)
+    s = torch.cuda.Stream()
+    eng.set_stream(s.cuda_stream)
+    dpos, dF, vel = to4(pos), to4(force), to4(np.zeros((n, 3)), 1.0)
+    with torch.cuda.stream(s):
+        eng.mobility(dpos, dF, vel=vel)                    # builds the list (eager, ungated)
+        assert eng.debug_last_gate() == -1
+        eng.mobility(dpos, dF, vel=vel)                    # two chains, eager: same positions -> reuse
+        assert eng.debug_last_gate() == 0
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+        eng.mobility(dpos, dF, vel=vel)
+    rng = np.random.default_rng(8)
+    cur = pos.copy()
+    for trial, (amp, want_rebuild) in enumerate([(0.05, False), (0.05, False), (1.0, True), (0.03, False), (0.9, True), (0.0, False)]):
+        cur = cur + rng.uniform(-amp, amp, cur.shape)      # r_buff / 2 = 0.2: 0.05 per axis stays inside, 1.0 does not
+        f2 = rng.normal(size=force.shape)
+        dpos.copy_(to4(cur)); dF.copy_(to4(f2)); vel[:, :3] = 0.0
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        gate = eng.debug_last_gate()
+        assert (gate != 0) == want_rebuild, (trial, gate)
+        u = ref.mobility(to4(cur), to4(f2)).cpu().numpy()[:, :3]
+        assert rel(vel.cpu().numpy()[:, :3], u) < 1e-12, trial
+
+
 def test_async_mode_never_reads_back():
-    """With asynchronous submission on, repeated evaluations at fixed positions build every time (the kept list's validity is a
-    device-side fact); with it off again the list is kept and reused."""
+    """With asynchronous submission on nothing is read back: the host-side counters cannot tell reuse from rebuild (the device-side
+    gate can); with it off again the list is kept and reused the host-side way."""
     import pse_amd
     n = 3000
     pos, force, box = make_suspension(n, phi=0.1)
@@ -62,7 +101,9 @@ def test_async_mode_never_reads_back():
     eng.set_async(True)
     u = [eng.mobility(dpos, dF).cpu().numpy()[:, :3] for _ in range(3)]
     _, builds, reuses = eng.neighbor_stats()
-    assert builds == 3 and reuses == 0
+    assert builds == 3 and reuses == 0                     # host-side counters: which chain ran is a device-side fact ...
+    assert eng.debug_last_gate() == 0                      # ... and it was the reuse chain
+    assert rel(u[2], u[0]) < 1e-12
     eng.set_async(False)
     for _ in range(3):
         v = eng.mobility(dpos, dF).cpu().numpy()[:, :3]

@@ -472,19 +472,23 @@ __device__ __forceinline__ double dpp_quad(double v) {   // the value another la
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
-template <int P, bool SHEAR>
+// BZ (round 4): bins along z a workgroup takes together (their records are consecutive: z is the fastest bin index).  The cost of
+// this kernel follows the GRID -- 0.30 ms at 256^3 with 30 particles per bin, 0.76 ms at 360^3 with 11: it is bound by the rate at
+// which regions are loaded -- so where bins hold few particles two bins share a region of 13 x 13 x 22 nodes (0.79 of the loads per
+// bin, 30 KB: five workgroups per CU).  At 30 particles per bin the single-bin shape wins (0.337 against 0.352 ms, round 2).
+template <int P, bool SHEAR, int BZ = 1>
 __global__ void __launch_bounds__(256)
 k_gather_bins(const FarRec *__restrict__ rec, FarBins fb, FastDiv dz, FastDiv dy, int bx0, const double *__restrict__ gx,
               const double *__restrict__ gy, const double *__restrict__ gz, DGrid G, GaussConsts gc, double4 *__restrict__ u_s) {
-    constexpr int NT = 256, E = BIN + P - 1;
+    constexpr int NT = 256, E = BIN + P - 1, BINZ = BIN * BZ;
     constexpr int ZPL = 2, LPP = P <= 7 ? 4 : 8, ZW = ZPL * LPP;      // z offsets per lane, lanes per particle, z window (>= P + 1)
-    constexpr int EZ = (E > BIN - 2 + ZW ? E + 1 : BIN - 2 + ZW) & ~1, HZ = EZ / 2, ROW = E * EZ, E3 = E * ROW, NW = 2 * P + ZW;
+    constexpr int EZ = (BINZ + P - 1 > BINZ - 2 + ZW ? BINZ + P : BINZ - 2 + ZW) & ~1, HZ = EZ / 2, ROW = E * EZ, E3 = E * ROW, NW = 2 * P + ZW;
     // particles per pass: 40, not the 64 the lanes could take -- a bin holds ~30, and the 3.8 KB of weight tables this saves bring the
     // workgroup under 26 KB, so SIX share a CU instead of five (0.319 -> 0.297 ms; 48 still allocates for five; the 4 % of bins with
     // more than 40 particles take a second pass)
     constexpr int PPP = (NT / LPP) < 40 ? (NT / LPP) : 40;
     constexpr int NPC = E * E * HZ, ITER = (NPC + NT - 1) / NT;       // 16-byte pieces of the region, per thread
-    static_assert(EZ >= E && BIN - 2 + ZW <= EZ, "z window inside the padded row");
+    static_assert(EZ >= BINZ + P - 1 && BINZ - 2 + ZW <= EZ, "z window inside the padded row");
     __shared__ __attribute__((aligned(16))) double reg[E3];
     __shared__ double s_w[NW * PPP];          // ax[P], ay[P], z-window weights[ZW] of the pass's particles: [t][particle]
     __shared__ int s_o[PPP];                  // row of the window's first node inside the region
@@ -499,11 +503,11 @@ k_gather_bins(const FarRec *__restrict__ rec, FarBins fb, FastDiv dz, FastDiv dy
     b = fdiv(b, dz, bz);
     b = fdiv(b, dy, by);
     int bx = bx0 + b; if (bx >= fb.nbx) bx -= fb.nbx;
-    const int bin = (bx * fb.nby + by) * fb.nbz + bz;
-    const int base = fb.off[bin], n = fb.off[bin + 1] - base;
+    const int bin = (bx * fb.nby + by) * fb.nbz + bz * BZ;            // dz counts groups of BZ bins along z (the last may be short)
+    const int base = fb.off[bin], n = fb.off[bin + min(BZ, fb.nbz - bz * BZ)] - base;
     if (n == 0) return;
     const double *g = cmp == 0 ? gx : (cmp == 1 ? gy : gz);
-    const int t0[3] = {bx * BIN, by * BIN, bz * BIN};
+    const int t0[3] = {bx * BIN, by * BIN, bz * BINZ};
     static_assert(P <= 16 && P * KS <= NT, "one table entry per thread");
     if (SHEAR && tid < P * KS) s_k[tid] = exp_lean(gc.lnk * (double)((tid / KS) * (tid % KS)));
     // Piece e of the region = 16 bytes (qx, qy, 2 hz .. 2 hz + 1), stored in that order.
@@ -667,7 +671,18 @@ k_gather(const double4 *__restrict__ pos_s, int N, const double *__restrict__ gx
 
 template <int P>
 static void launch_gather_p(const FarRec *rec, FarBins fb, int bx0, int nbx_l, const double *gx, const double *gy, const double *gz,
-                            const DGrid &G, const GaussConsts &gc, double4 *u_s, hipStream_t s) {
+                            const DGrid &G, const GaussConsts &gc, double4 *u_s, hipStream_t s, int bz) {
+    if constexpr (P <= 7) {
+        if (bz == 2) {   // few particles per bin: two bins along z share a region (four: 51 KB, three workgroups per CU -- 0.79 ms
+                         // against 0.63 at 360^3, 2.33 against 1.92 at 512^3: measured, not kept)
+            const int ngz = (fb.nbz + 1) / 2;
+            const dim3 g(3 * nbx_l * fb.nby * ngz), b(256);
+            const FastDiv dz = fast_div(ngz), dy = fast_div(fb.nby);
+            if (gc.s != 0.0) hipLaunchKernelGGL((k_gather_bins<P, true, 2>), g, b, 0, s, rec, fb, dz, dy, bx0, gx, gy, gz, G, gc, u_s);
+            else hipLaunchKernelGGL((k_gather_bins<P, false, 2>), g, b, 0, s, rec, fb, dz, dy, bx0, gx, gy, gz, G, gc, u_s);
+            return;
+        }
+    }
     const dim3 g(3 * nbx_l * fb.nby * fb.nbz), b(256);
     const FastDiv dz = fast_div(fb.nbz), dy = fast_div(fb.nby);
     if (gc.s != 0.0) hipLaunchKernelGGL((k_gather_bins<P, true>), g, b, 0, s, rec, fb, dz, dy, bx0, gx, gy, gz, G, gc, u_s);
@@ -691,11 +706,15 @@ hipError_t launch_gather(const double4 *pos_s, SpreadWork w, int N, const double
         nbx_l = std::min(fb.nbx, ((ohi / BIN - bx0) % fb.nbx + fb.nbx) % fb.nbx + 1);
     }
     const GaussConsts gc = gauss_consts(G, box.xy);
+    // bins per workgroup along z: two where a bin holds fewer than ~20 particles on average (PSE_GATHER_BZ=1|2 overrides)
+    static const int bz_env = [] { const char *e = getenv("PSE_GATHER_BZ"); return e ? atoi(e) : 0; }();
+    const double per_bin = (double)N / ((double)fb.nbx * fb.nby * fb.nbz);
+    const int bz = (G.Nz >= 32 && (bz_env ? bz_env == 2 : per_bin < 20.0)) ? 2 : 1;
     switch (G.P) {
-#define PSE_GATHER_CASE(PV) case PV: launch_gather_p<PV>(w.rec_t, fb, bx0, nbx_l, gx, gy, gz, G, gc, u_s, s); break;
+#define PSE_GATHER_CASE(PV) case PV: launch_gather_p<PV>(w.rec_t, fb, bx0, nbx_l, gx, gy, gz, G, gc, u_s, s, bz); break;
         PSE_GATHER_CASE(4) PSE_GATHER_CASE(5) PSE_GATHER_CASE(6) PSE_GATHER_CASE(7) PSE_GATHER_CASE(8) PSE_GATHER_CASE(9)
         PSE_GATHER_CASE(10) PSE_GATHER_CASE(11) PSE_GATHER_CASE(12) PSE_GATHER_CASE(13)
-        default: launch_gather_p<14>(w.rec_t, fb, bx0, nbx_l, gx, gy, gz, G, gc, u_s, s); break;
+        default: launch_gather_p<14>(w.rec_t, fb, bx0, nbx_l, gx, gy, gz, G, gc, u_s, s, bz); break;
 #undef PSE_GATHER_CASE
     }
     return hipGetLastError();

@@ -78,6 +78,9 @@ struct pse_handle {
         int yfft_kb = 4;          // PSE_YFFT_KB: kz columns per workgroup of the own y pass (2, 4, 8)
         int wave_mode = 0;        // PSE_WAVE_MODE: 0 automatic, 1 slab, 2 replicated
         int spread_tz = 0, spread_nw = 0;   // PSE_SPREAD_TZ, PSE_SPREAD_NW
+        int gather_bz = 0;        // PSE_GATHER_BZ=1|2: bins along z per gather workgroup (0: by the particles per bin)
+        int xmix_runtime = 0;     // PSE_XMIX=1: runtime radix plan of the mixed x pass also where a compile-time plan exists
+        int xfft_small_wide = 0;  // PSE_XFFT_SMALL_KB=8: the eight-column x pass also on small grids
         bool verbose = false;     // PSE_VERBOSE
         bool team_sstep = true;      // PSE_TEAM_SSTEP=0: teams run one Lanczos iteration per exchange (default: two, see lanczos_team)
         int team_sched[3] = {1, 2, 3};   // PSE_TEAM_SCHED=a,b,c: far-field exchange k of a team step is issued before Lanczos exchange sched[k]
@@ -422,13 +425,14 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         t.own_y = ienv("PSE_OWN_Y", 1); t.yfft_kb = ienv("PSE_YFFT_KB", 4);
         if (const char *v = getenv("PSE_WAVE_MODE")) t.wave_mode = !strcmp(v, "slab") ? 1 : (!strcmp(v, "replicated") ? 2 : 0);
         t.spread_tz = ienv("PSE_SPREAD_TZ", 0); t.spread_nw = ienv("PSE_SPREAD_NW", 0);
+        t.gather_bz = ienv("PSE_GATHER_BZ", 0); t.xmix_runtime = ienv("PSE_XMIX", 0) == 1; t.xfft_small_wide = ienv("PSE_XFFT_SMALL_KB", 2) == 8;
         t.verbose = ienv("PSE_VERBOSE", 0) > 0;
         t.team_sstep = ienv("PSE_TEAM_SSTEP", 1) > 0;
         if (const char *v = getenv("PSE_TEAM_SCHED")) {
             int a = 1, b = 2, c = 3;
             if (sscanf(v, "%d,%d,%d", &a, &b, &c) == 3) { t.team_sched[0] = a; t.team_sched[1] = b; t.team_sched[2] = c; }
         }
-        h->sw.force_tz = t.spread_tz; h->sw.force_nw = t.spread_nw;
+        h->sw.force_tz = t.spread_tz; h->sw.force_nw = t.spread_nw; h->sw.force_bz = t.gather_bz;
     }
     {
         // Neighbour list across steps: on by default with the reference's r_buff = 0.4 (PSEv1/integrate.py:60), single GPU, table
@@ -1179,6 +1183,7 @@ static ScaleArgs scale_args(pse_handle *h, bool noise, double kT, double dt, uns
     a.noise_fac = noise ? std::sqrt(2.0 * kT / dt / (G.hx * G.hy * G.hz)) : 0.0;   // PSEv1/Brownian.cu:197
     a.seed = h->par.seed; a.timestep = timestep;
     a.transposed = h->grid_slabs > 1 ? 1 : 0; a.y0 = h->y0; a.nyl = h->grid_slabs > 1 ? h->nyl : G.Ny;
+    a.runtime_plan = h->tun.xmix_runtime; a.wide_small = h->tun.xfft_small_wide;
     return a;
 }
 

@@ -707,7 +707,7 @@ hipError_t launch_gather(const double4 *pos_s, SpreadWork w, int N, const double
     }
     const GaussConsts gc = gauss_consts(G, box.xy);
     // bins per workgroup along z: two where a bin holds fewer than ~20 particles on average (PSE_GATHER_BZ=1|2 overrides)
-    static const int bz_env = [] { const char *e = getenv("PSE_GATHER_BZ"); return e ? atoi(e) : 0; }();
+    const int bz_env = w.force_bz;
     const double per_bin = (double)N / ((double)fb.nbx * fb.nby * fb.nbz);
     const int bz = (G.Nz >= 32 && (bz_env ? bz_env == 2 : per_bin < 20.0)) ? 2 : 1;
     switch (G.P) {

@@ -159,6 +159,7 @@ struct SpreadWork {
     FarBins fb;
     FarRec *rec_t;              // [N] bin order: origin, sorted index (bit 31: owned by another slab rank), offset, prefac * force
     int force_tz, force_nw;     // tuning switches of the handle (0: automatic): z depth of a spread block, waves per block
+    int force_bz;               // ... bins along z per gather workgroup (PSE_GATHER_BZ=1|2)
     CellRanges need;            // a slab rank: rows outside hold no particle data (their support cannot reach the slab)
     const int *cell_off;
 };
@@ -185,6 +186,8 @@ struct ScaleArgs {
     uint32_t seed, timestep;
     int transposed;          // layout [Nx][ny_local][Nzh] (slab mode, after the transpose) instead of [nx_local][Ny][Nzh]
     int y0, nyl;             // slab of y rows in transposed layout
+    int runtime_plan;        // PSE_XMIX=1: the runtime radix plan also where a compile-time one exists (A/B)
+    int wide_small;          // PSE_XFFT_SMALL_KB=8: eight kz columns per workgroup also on small grids (A/B)
 };
 void launch_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, hipStream_t s);
 // debug: kx, ky, kz, w sinc^2, sqrt(w) sinc of n nodes (i, j, k)

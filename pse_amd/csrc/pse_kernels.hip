@@ -1769,12 +1769,9 @@ void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, Sc
     if (G.Nx & (G.Nx - 1)) {   // not a power of two: mixed-radix passes; 4 kz columns per workgroup while two buffers fit
         FftPlanX pl;
         plan_x(G.Nx, pl);
-        static const int var = [] { const char *e = getenv("PSE_XMIX"); return e ? atoi(e) : 0; }();   // experiment: columns x threads
-        if (var == 1128) { launch_xfft_mixed<1, 128>(X, Y, Z, G, box, a, tw, pl, s); return; }
-        if (var == 1256) { launch_xfft_mixed<1, 256>(X, Y, Z, G, box, a, tw, pl, s); return; }
-        if (var == 2128) { launch_xfft_mixed<2, 128>(X, Y, Z, G, box, a, tw, pl, s); return; }
-        if (var == 2192) { launch_xfft_mixed<2, 192>(X, Y, Z, G, box, a, tw, pl, s); return; }
-        if (var != 1) {   // compile-time plans for the sizes of the reference's rule at the BASELINE configurations (PSE_XMIX=1: runtime plan)
+        // (one kz column per workgroup, 128 or 256 threads: 1.34 / 1.35 ms at 360^3 against 1.34 with two columns and 256 threads; two
+        // columns with 128 / 192 threads: 1.90 / 1.52 ms -- the pass is bound by instruction issue, not occupancy; variants removed)
+        if (!a.runtime_plan) {   // compile-time plans for the sizes of the reference's rule at the BASELINE configurations (PSE_XMIX=1: runtime plan)
             switch (G.Nx) {
                 case 360: launch_xfft_mixed<2, 256, CtPlan<360, 9, 8, 5>>(X, Y, Z, G, box, a, tw, pl, s); return;
                 case 270: launch_xfft_mixed<2, 256, CtPlan<270, 9, 5, 3, 2>>(X, Y, Z, G, box, a, tw, pl, s); return;
@@ -1792,8 +1789,7 @@ void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, Sc
     // workgroups and its duration is one workgroup's latency chain (34 us at 64^3); two columns per workgroup give four times as
     // many, shorter chains (the 32-byte pieces of a line are fetched by neighbouring workgroups of one XCD)
     const int rows_ = a.transposed ? a.nyl : G.Ny;
-    static const int small_kb = [] { const char *e = getenv("PSE_XFFT_SMALL_KB"); return e ? atoi(e) : 2; }();
-    if (G.Nx <= 128 && (long)rows_ * ((G.Nzh + 7) / 8) < 1024 && small_kb == 2) {
+    if (G.Nx <= 128 && (long)rows_ * ((G.Nzh + 7) / 8) < 1024 && !a.wide_small) {
         switch (G.Nx) {
             case 16: launch_xfft_t<4, 2, 64>(X, Y, Z, G, box, a, tw, s); return;
             case 32: launch_xfft_t<5, 2, 64>(X, Y, Z, G, box, a, tw, s); return;

@@ -1648,12 +1648,13 @@ static void launch_xfft_mixed(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox 
 // MAP (slab ranks of a team): the transform also does the reordering between the plane layout [3][nxl][Ny][Nzp] and the layout of the
 // all-to-all blocks [3][G][nxl][nyl][Nzp] (y = q nyl + jl goes to rank q) -- 1: plane layout in, block layout out (forward: what
 // k_slab_pack did in a pass of its own); 2: block layout in, plane layout out (inverse: the unpack).  0: in place, plane layout.
-template <int KB, int NTH, bool INVERSE, int MAP = 0>
+template <int KB, int NTH, bool INVERSE, int MAP = 0, class PLAN = RtPlan>
 __global__ void __launch_bounds__(NTH)
 k_fft_cols(double2 *__restrict__ data, FftPlanX pl, const double2 *__restrict__ twiddle, int nkb, int Nzh, int Nzp, size_t plane_stride,
            double2 *__restrict__ other = nullptr, int nxl = 0, int nyl = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int N = pl.n, CS = N + 1;
+    constexpr bool CT = PLAN::N > 0;
+    const int N = CT ? PLAN::N : pl.n, CS = N + 1;
     double2 *bufa = reinterpret_cast<double2 *>(smem_raw), *bufb = bufa + KB * CS;   // [KB][N + 1] each
     double2 *tw = bufb + KB * CS;                                                     // [N]
     const int tid = threadIdx.x;
@@ -1685,7 +1686,9 @@ k_fft_cols(double2 *__restrict__ data, FftPlanX pl, const double2 *__restrict__ 
         }
     }
     __syncthreads();
-    const double2 *d = fft_mixed<INVERSE>(bufa, bufb, tw, pl, CS, KB, NTH);
+    const double2 *d;
+    if constexpr (CT) d = fft_mixed_ct<PLAN, INVERSE, KB, NTH>(bufa, bufb, tw);
+    else d = fft_mixed<INVERSE>(bufa, bufb, tw, pl, CS, KB, NTH);
     for (int e = tid; e < total; e += NTH) {
         const int y = e / KB, q = e - y * KB;
         if (q < kv) {
@@ -1702,20 +1705,20 @@ bool yfft_supported(int Ny) {   // 2^a 3^b 5^c, 16..512, not a power of two (roc
     FftPlanX pl;
     return Ny >= 16 && Ny <= 512 && (Ny & (Ny - 1)) != 0 && plan_x(Ny, pl);
 }
-template <int KB, int NTH>
+template <int KB, int NTH, class PLAN = RtPlan>
 static void launch_fft_cols(double2 *data, const FftPlanX &pl, const double2 *tw, int nplanes, int Nzh, int Nzp, size_t plane_stride,
                             bool inverse, hipStream_t s) {
     const size_t lds = (size_t)(2 * KB * (pl.n + 1) + pl.n) * sizeof(double2);
     static size_t attr_lds[2] = {48 * 1024, 48 * 1024};
     if (lds > attr_lds[inverse]) {
-        if (inverse) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<KB, NTH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        else (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<KB, NTH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (inverse) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<KB, NTH, true, 0, PLAN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<KB, NTH, false, 0, PLAN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds[inverse] = lds;
     }
     const int nkb = (Nzh + KB - 1) / KB;
     const dim3 g(nplanes * nkb), b(NTH);
-    if (inverse) hipLaunchKernelGGL((k_fft_cols<KB, NTH, true>), g, b, lds, s, data, pl, tw, nkb, Nzh, Nzp, plane_stride);
-    else hipLaunchKernelGGL((k_fft_cols<KB, NTH, false>), g, b, lds, s, data, pl, tw, nkb, Nzh, Nzp, plane_stride);
+    if (inverse) hipLaunchKernelGGL((k_fft_cols<KB, NTH, true, 0, PLAN>), g, b, lds, s, data, pl, tw, nkb, Nzh, Nzp, plane_stride);
+    else hipLaunchKernelGGL((k_fft_cols<KB, NTH, false, 0, PLAN>), g, b, lds, s, data, pl, tw, nkb, Nzh, Nzp, plane_stride);
 }
 // slab ranks: forward = planes (cgrid) -> transformed blocks (blocks); inverse = blocks -> transformed planes
 void launch_yfft_slab(double2 *cgrid, double2 *blocks, DGrid G, int nyl, bool inverse, const double2 *tw, hipStream_t s) {
@@ -1743,6 +1746,10 @@ void launch_yfft(double2 *spectra, DGrid G, bool inverse, const double2 *tw, hip
     const size_t ps = (size_t)G.Ny * G.Nzp;
     if (kb == 8) launch_fft_cols<8, 256>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);
     else if (kb == 2) launch_fft_cols<2, 256>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);
+    else if (kb == 4 && G.Ny == 360) launch_fft_cols<4, 256, CtPlan<360, 9, 8, 5>>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);   // compile-time plans, as in the x pass
+    else if (kb == 4 && G.Ny == 270) launch_fft_cols<4, 256, CtPlan<270, 9, 5, 3, 2>>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);
+    else if (kb == 4 && G.Ny == 375) launch_fft_cols<4, 256, CtPlan<375, 5, 5, 5, 3>>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);
+    else if (kb == 4 && G.Ny == 500) launch_fft_cols<4, 256, CtPlan<500, 5, 5, 5, 4>>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);
     else launch_fft_cols<4, 256>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);
 }
 

@@ -779,9 +779,12 @@ static int team_exchange(pse_team &T, const std::vector<Xfer> &ops, bool wave_la
         hipStream_t cs = T.comm ? T.comm : s;
         if (T.comm) { hipEvent_t e = team_event(T); HIPCHK(hipEventRecord(e, s)); HIPCHK(hipStreamWaitEvent(T.comm, e, 0)); }
         NCCLCHK(ncclGroupStart());
-        for (const Xfer &x : ops) if (x.ns && x.to != me) NCCLCHK(ncclSend(x.send, x.ns, ncclDouble, x.to, comm, cs));
-        for (const Xfer &x : ops) if (x.nr && x.from != me) NCCLCHK(ncclRecv(x.recv, x.nr, ncclDouble, x.from, comm, cs));
-        NCCLCHK(ncclGroupEnd());
+        ncclResult_t bad = ncclSuccess;   // a failing call must not leave the library inside an open group
+        for (const Xfer &x : ops) if (bad == ncclSuccess && x.ns && x.to != me) bad = ncclSend(x.send, x.ns, ncclDouble, x.to, comm, cs);
+        for (const Xfer &x : ops) if (bad == ncclSuccess && x.nr && x.from != me) bad = ncclRecv(x.recv, x.nr, ncclDouble, x.from, comm, cs);
+        const ncclResult_t end = ncclGroupEnd();
+        if (bad != ncclSuccess || end != ncclSuccess)
+            return fail(PSE_ERR_COMM, "RCCL exchange failed: %s", ncclGetErrorString(bad != ncclSuccess ? bad : end));
         // ... and back: the lane goes on when the exchange has completed
         if (T.comm) { hipEvent_t e = team_event(T); HIPCHK(hipEventRecord(e, T.comm)); HIPCHK(hipStreamWaitEvent(s, e, 0)); }
         return 0;

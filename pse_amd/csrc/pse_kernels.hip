@@ -1554,6 +1554,167 @@ __device__ __forceinline__ double2 *fft_mixed_ct(double2 *a, double2 *b, const d
     return a;
 }
 
+// ---- N = 512 = 8 x 8 x 8 with ONE component in LDS at a time ----------------------------------------------------------------------
+// The kernels above keep the three components of a block of columns in LDS, which caps a 512-point block at two kz columns
+// (32-byte pieces of every 128-byte line: 2.4 TB/s; the 256-point kernel loses the same 30 % when it is given two columns).  Here a
+// workgroup owns KB = 4 kz columns (64-byte pieces; 8 = whole 128-byte pieces would need the kernel in 128 registers), the data
+// live in registers (a lane: 8 points of each component), and LDS holds one component of the block while it changes hands:
+//   layout A (global memory side): thread (q, n) = (tid % KB, tid / KB) holds x[n + 64 r], r = 0..7, of column q -- loads and
+//            stores of KB lanes cover one contiguous piece; stage 1 (decimation in frequency) is the radix-8 transform over r;
+//   layout B: wave w = column w, lane (k0, n'') then (k0, k1): stages 2 and 3 with one exchange in between that stays inside the
+//            wave (LDS instructions of a wave execute in order: no barrier); stage 3 leaves X[k0 + 8 k1 + 64 k2] in register k2
+//            of lane 8 k0 + k1 for all three components, so the k-space operator works on registers, and the inverse
+//            (decimation in time) runs the same stages backwards from that digit-reversed order.
+// Per transform a point crosses LDS twice (four times in the kernels above); 10 barriers per block; a stage's twiddles are fetched
+// once for the three components.  Positions in a column: B[k0][n] at 72 k0 + n, C[k0][k1][n] at 72 k0 + 9 k1 + n -- every access is
+// a per-lane base plus a compile-time offset, and with the column stride below every access is conflict-free but the layout A
+// read of the inverse (two-way): tools/debug/lds_banks_x512.py.
+constexpr int x512_cs(int KB) { return KB == 8 ? 583 : 578; }
+
+template <int KB, int WPS, bool PARK>
+__global__ void __launch_bounds__(64 * KB, WPS)
+k_xfft_scale512c(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ Z, DGrid G, DBox box, ScaleArgs a,
+                 const double2 *__restrict__ twiddle) {
+    constexpr int CS = x512_cs(KB);
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double2 *buf = reinterpret_cast<double2 *>(smem_raw);    // [KB][CS]: one component of the block
+    double2 *tw64 = buf + KB * CS;                           // exp(-2 pi i m / 64)
+    const int tid = threadIdx.x;
+    const int nkb = (G.Nzh + KB - 1) / KB;
+    const int rows = a.transposed ? a.nyl : G.Ny;
+    const int bid = xcd_block(blockIdx.x, gridDim.x);        // rows are not multiples of 128 bytes: neighbouring blocks share lines
+    const int jl = bid / nkb, kz0 = (bid - jl * nkb) * KB;
+    const int j = a.transposed ? a.y0 + jl : jl;
+    const int kv = min(KB, G.Nzh - kz0);
+    double2 *comp[3] = {X, Y, Z};
+    const size_t xstride = (size_t)rows * G.Nzp, base = (size_t)jl * G.Nzp + kz0;
+    const int q = tid % KB, n1 = tid / KB;                   // layout A
+    const int w = tid >> 6, l = tid & 63, kp = l >> 3, nn = l & 7;   // layout B
+    double2 *pA = buf + q * CS + n1;                         // + 72 k0
+    double2 *pB = buf + w * CS + 72 * kp + nn;               // + 8 s (B), + 9 k1 (C)
+    double2 *pC = buf + w * CS + 72 * kp + 9 * nn;           // + n'' (C of lane (k0, k1))
+    double2 *pP = buf + w * CS + l;                          // + 64 k2: the lane's own slots
+    double2 v[3][9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            v[c][r] = make_double2(0, 0);
+            if (q < kv) v[c][r] = comp[c][(size_t)(n1 + 64 * r) * xstride + base + q];
+        }
+    if (tid < 64) tw64[tid] = twiddle[8 * tid];
+    // ---- forward: stage 1 over r -> k0, times W_512^{n k0}
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dft_small<8, false>(v[c]);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        const double2 t = twiddle[n1 * k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c][k] = cmul(v[c][k], t);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (c) __syncthreads();                               // every wave has read the previous component
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pA[72 * k] = v[c][k];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 8; ++s) v[c][s] = pB[8 * s];
+    }
+    // stage 2 over s -> k1, times W_64^{n'' k1}
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dft_small<8, false>(v[c]);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        const double2 t = tw64[nn * k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c][k] = cmul(v[c][k], t);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {                             // inside the wave's own column: no barrier
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pB[9 * k] = v[c][k];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int n = 0; n < 8; ++n) v[c][n] = pC[n];
+        __builtin_amdgcn_wave_barrier();
+        dft_small<8, false>(v[c]);                            // stage 3 over n'' -> k2
+    }
+    // ---- the k-space operator on X[k0 + 8 k1 + 64 k2]
+    if (PARK) {                                               // the third component waits in the lane's own slots: room for the operator's temporaries
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) pP[64 * k2] = v[2][k2];
+    }
+    if (w < kv) {
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) {
+            const double2 f[3] = {v[0][k2], v[1][k2], PARK ? pP[64 * k2] : v[2][k2]};
+            double2 out[3];
+            scale_node(kp + 8 * nn + 64 * k2, j, kz0 + w, f, G, box, a, out);
+            v[0][k2] = out[0]; v[1][k2] = out[1];
+            if (PARK) pP[64 * k2] = out[2]; else v[2][k2] = out[2];
+            __builtin_amdgcn_sched_barrier(0);                // one node at a time
+        }
+    }
+    if (PARK) {
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) v[2][k2] = pP[64 * k2];
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- inverse: stage 3 backwards over k2 -> n'', times conj W_64^{n'' k1}
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dft_small<8, true>(v[c]);
+#pragma unroll
+    for (int n = 1; n < 8; ++n) {
+        double2 t = tw64[n * nn]; t.y = -t.y;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c][n] = cmul(v[c][n], t);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int n = 0; n < 8; ++n) pC[n] = v[c][n];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[c][k] = pB[9 * k];
+        __builtin_amdgcn_wave_barrier();
+        dft_small<8, true>(v[c]);                             // stage 2 backwards over k1 -> s
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {                             // times conj W_512^{(8 s + n'') k0}
+        double2 t = twiddle[(8 * s + nn) * kp]; t.y = -t.y;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c][s] = cmul(v[c][s], t);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (c) __syncthreads();                               // the layout A reads of the previous component are done
+#pragma unroll
+        for (int s = 0; s < 8; ++s) pB[8 * s] = v[c][s];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[c][k] = pA[72 * k];
+        dft_small<8, true>(v[c]);                             // stage 1 backwards over k0 -> r
+        if (q < kv) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) comp[c][(size_t)(n1 + 64 * r) * xstride + base + q] = v[c][r];
+        }
+    }
+}
+
+template <int KB, int WPS, bool PARK>
+static void launch_xfft512c(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s) {
+    const size_t lds = (size_t)(KB * x512_cs(KB) + 64) * sizeof(double2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xfft_scale512c<KB, WPS, PARK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int nkb = (G.Nzh + KB - 1) / KB;
+    const int rows = a.transposed ? a.nyl : G.Ny;
+    hipLaunchKernelGGL((k_xfft_scale512c<KB, WPS, PARK>), dim3(rows * nkb), dim3(64 * KB), lds, s, X, Y, Z, G, box, a, tw);
+}
+
 template <int KB, int NTH, class PLAN = RtPlan>
 __global__ void __launch_bounds__(NTH)
 k_xfft_scale_mixed(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ Z, DGrid G, DBox box, ScaleArgs a,
@@ -1810,9 +1971,17 @@ void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, Sc
         case 32: launch_xfft_t<5, 8, 256>(X, Y, Z, G, box, a, tw, s); break;
         case 64: launch_xfft_t<6, 8, 256>(X, Y, Z, G, box, a, tw, s); break;
         case 128: launch_xfft_t<7, 8, 512>(X, Y, Z, G, box, a, tw, s); break;
+        // 64-byte pieces (four kz): 3.87 TB/s at 256 x 512 x 512; 32-byte pieces (two kz, three workgroups per CU) 2.73; 128-byte pieces with
+        // all three components in LDS (eight kz, one workgroup per CU) 2.71
         case 256: launch_xfft256<4, 256, 2>(X, Y, Z, G, box, a, tw, s); break;   // two radix-16 passes in registers
         // 512: radix 16, 16, 2; two kz columns: three workgroups per CU (3.3 ms at 512^3; four columns, one workgroup: 3.8; radix 4/2 in LDS: 5.2)
-        default: launch_xfft256<2, 256, 1, 512>(X, Y, Z, G, box, a, tw, s); break;
+        default:
+            // one component in LDS at a time, four kz columns, three workgroups per CU: 1.50 ms at 512^3 (4.3 TB/s); eight columns at four
+            // waves per SIMD (128 registers: 225 spilled) 3.3 ms, six columns 2.9 ms, four columns without parking the third component
+            // during the operator (107 spilled) 2.27 ms; all three components in LDS, two columns (PSE_X512_COLS=0): 2.77 ms
+            if (a.x512_cols) launch_xfft512c<4, 3, true>(X, Y, Z, G, box, a, tw, s);
+            else launch_xfft256<2, 256, 1, 512>(X, Y, Z, G, box, a, tw, s);
+            break;
     }
 }
 

@@ -1363,13 +1363,14 @@ static void launch_xfft256(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box
 struct FftPlanX { int n, nstage, radix[10]; unsigned mns[10], mnr[10]; };   // + reciprocals ceil(2^32 / ns), ceil(2^32 / (n / R)) of every stage
 __device__ __forceinline__ int fast_quot(int a, unsigned m) { return (int)__umulhi((unsigned)a, m); }   // a / d for a d < 2^31, m = ceil(2^32 / d)
 
-template <int R, bool INVERSE>
-__device__ __forceinline__ void dft_small(double2 (&v)[9]) {
+template <int R, bool INVERSE, int LEN>
+__device__ __forceinline__ void dft_small(double2 (&v)[LEN]) {
+    static_assert(LEN >= R, "the butterfly's points");
     const double sg = INVERSE ? 1.0 : -1.0;                          // forward: exp(-i ...)
-    if (R == 2) {
+    if constexpr (R == 2) {
         const double2 a = v[0], b = v[1];
         v[0] = make_double2(a.x + b.x, a.y + b.y); v[1] = make_double2(a.x - b.x, a.y - b.y);
-    } else if (R == 3) {
+    } else if constexpr (R == 3) {
         constexpr double S = 0.86602540378443864676;                 // sin(2 pi / 3)
         const double2 s = make_double2(v[1].x + v[2].x, v[1].y + v[2].y), t = make_double2(v[1].x - v[2].x, v[1].y - v[2].y);
         const double2 m = make_double2(v[0].x - 0.5 * s.x, v[0].y - 0.5 * s.y);
@@ -1377,14 +1378,14 @@ __device__ __forceinline__ void dft_small(double2 (&v)[9]) {
         v[0] = make_double2(v[0].x + s.x, v[0].y + s.y);
         v[1] = make_double2(m.x + jt.x, m.y + jt.y);
         v[2] = make_double2(m.x - jt.x, m.y - jt.y);
-    } else if (R == 4) {
+    } else if constexpr (R == 4) {
         const double2 a = v[0], b = v[1], c = v[2], d = v[3];
         const double2 s0 = make_double2(a.x + c.x, a.y + c.y), s1 = make_double2(a.x - c.x, a.y - c.y);
         const double2 s2 = make_double2(b.x + d.x, b.y + d.y), s3 = make_double2(b.x - d.x, b.y - d.y);
         const double2 j3 = make_double2(-sg * s3.y, sg * s3.x);
         v[0] = make_double2(s0.x + s2.x, s0.y + s2.y); v[1] = make_double2(s1.x + j3.x, s1.y + j3.y);
         v[2] = make_double2(s0.x - s2.x, s0.y - s2.y); v[3] = make_double2(s1.x - j3.x, s1.y - j3.y);
-    } else if (R == 8) {
+    } else if constexpr (R == 8) {
         // 8 = 2 x 4: X[k1 + 2 k2] = sum_n2 W8^{n2 k1} W4^{n2 k2} (x[n2] + (-1)^k1 x[n2 + 4])
         constexpr double H = 0.70710678118654752440;
         double2 e[4], o[4];
@@ -1407,7 +1408,7 @@ __device__ __forceinline__ void dft_small(double2 (&v)[9]) {
         dft4(e); dft4(o);
 #pragma unroll
         for (int k2 = 0; k2 < 4; ++k2) { v[2 * k2] = e[k2]; v[2 * k2 + 1] = o[k2]; }
-    } else if (R == 9) {
+    } else if constexpr (R == 9) {
         // 9 = 3 x 3: X[k1 + 3 k2] = sum_n2 W9^{n2 k1} W3^{n2 k2} sum_n1 x[n2 + 3 n1] W3^{n1 k1}
         constexpr double S = 0.86602540378443864676;
         constexpr double C91 = 0.76604444311897803520, S91 = 0.64278760968653932632;    // cos, sin (2 pi / 9)
@@ -1433,7 +1434,20 @@ __device__ __forceinline__ void dft_small(double2 (&v)[9]) {
         // natural order: X[k1 + 3 k2] = v[k2 + 3 k1]
         const double2 x1 = v[3], x2 = v[6], x3 = v[1], x5 = v[7], x6 = v[2], x7 = v[5];
         v[1] = x1; v[2] = x2; v[3] = x3; v[5] = x5; v[6] = x6; v[7] = x7;
+    } else if constexpr (R == 6 || R == 10) {
+        // 2 x Q with Q = 3 or 5 (coprime: Good-Thomas, no twiddles): x[(Q n1 + 2 n2) mod R] -> X[(Q k1 + (Q + 1) k2) mod R]
+        constexpr int Q = R / 2;
+        double2 sm[Q], df[Q];
+#pragma unroll
+        for (int n2 = 0; n2 < Q; ++n2) {
+            const double2 a = v[(2 * n2) % R], b = v[(Q + 2 * n2) % R];
+            sm[n2] = make_double2(a.x + b.x, a.y + b.y); df[n2] = make_double2(a.x - b.x, a.y - b.y);
+        }
+        dft_small<Q, INVERSE>(sm); dft_small<Q, INVERSE>(df);
+#pragma unroll
+        for (int k2 = 0; k2 < Q; ++k2) { v[((Q + 1) * k2) % R] = sm[k2]; v[(Q + (Q + 1) * k2) % R] = df[k2]; }
     } else {
+        static_assert(R == 5, "radix");
         constexpr double C1 = 0.30901699437494742410, C2 = -0.80901699437494742410;   // cos(2 pi/5), cos(4 pi/5)
         constexpr double S1 = 0.95105651629515357212, S2 = 0.58778525229247312917;    // sin(2 pi/5), sin(4 pi/5)
         const double2 a1 = make_double2(v[1].x + v[4].x, v[1].y + v[4].y), b1 = make_double2(v[1].x - v[4].x, v[1].y - v[4].y);
@@ -1554,31 +1568,34 @@ __device__ __forceinline__ double2 *fft_mixed_ct(double2 *a, double2 *b, const d
     return a;
 }
 
-// ---- N = 512 = 8 x 8 x 8 with ONE component in LDS at a time ----------------------------------------------------------------------
+// ---- N = R0 x R1 x R2 with ONE component in LDS at a time (512 = 8 8 8, 360 = 10 6 6, 256 = 8 8 4) ------------------------------
 // The kernels above keep the three components of a block of columns in LDS, which caps a 512-point block at two kz columns
-// (32-byte pieces of every 128-byte line: 2.4 TB/s; the 256-point kernel loses the same 30 % when it is given two columns).  Here a
-// workgroup owns KB = 4 kz columns (64-byte pieces; 8 = whole 128-byte pieces would need the kernel in 128 registers), the data
-// live in registers (a lane: 8 points of each component), and LDS holds one component of the block while it changes hands:
-//   layout A (global memory side): thread (q, n) = (tid % KB, tid / KB) holds x[n + 64 r], r = 0..7, of column q -- loads and
-//            stores of KB lanes cover one contiguous piece; stage 1 (decimation in frequency) is the radix-8 transform over r;
-//   layout B: wave w = column w, lane (k0, n'') then (k0, k1): stages 2 and 3 with one exchange in between that stays inside the
-//            wave (LDS instructions of a wave execute in order: no barrier); stage 3 leaves X[k0 + 8 k1 + 64 k2] in register k2
-//            of lane 8 k0 + k1 for all three components, so the k-space operator works on registers, and the inverse
-//            (decimation in time) runs the same stages backwards from that digit-reversed order.
-// Per transform a point crosses LDS twice (four times in the kernels above); 10 barriers per block; a stage's twiddles are fetched
-// once for the three components.  Positions in a column: B[k0][n] at 72 k0 + n, C[k0][k1][n] at 72 k0 + 9 k1 + n -- every access is
-// a per-lane base plus a compile-time offset, and with the column stride below every access is conflict-free but the layout A
-// read of the inverse (two-way): tools/debug/lds_banks_x512.py.
-constexpr int x512_cs(int KB) { return KB == 8 ? 583 : 578; }
-
-template <int KB, int WPS, bool PARK>
+// (32-byte pieces of every 128-byte line: 2.4 TB/s; the 256-point kernel loses the same 30 % when it is given two columns) and
+// sends a point through LDS four times per transform.  Here the data live in registers, LDS holds one component of the block
+// while it changes hands, and a workgroup owns KB = 4 kz columns (64-byte pieces; 8 = whole 128-byte pieces needs the kernel in 128
+// registers, which it is not: 225 spilled, 3.3 ms at 512^3):
+//   layout A (global memory side): thread (q, n) = (tid % KB, tid / KB), n < N / R0, holds x[n + (N / R0) r] of column q -- the
+//            loads and stores of KB lanes cover one contiguous piece; stage 1 (decimation in frequency) is the radix-R0 transform over r;
+//   layout B: wave w = column w; lanes (k0, n'') run stage 2 (radix R1 inside the N / R0-point transform k0), lanes (k0, k1) stage 3
+//            (radix R2), with one exchange in between that stays inside the wave (LDS instructions of a wave execute in order: no
+//            barrier).  Stage 3 leaves X[k0 + R0 k1 + R0 R1 k2] in register k2 of lane R1 k0 + k1 for all three components, so the
+//            k-space operator works on registers (the third component parked in the lane's own LDS slots meanwhile: the operator
+//            needs ~100 registers of its own), and the inverse (decimation in time) runs the same stages backwards from that
+//            digit-reversed order.
+// Per transform a point crosses LDS twice; 10 barriers per block.  Components go through one after the other (only the R2 final
+// values of a component stay in registers; the loads of the next one are in flight meanwhile).
+// Positions in a column: B[k0][n] at P0 k0 + n, C[k0][k1][n] at P0 k0 + P1 k1 + n -- every access is a per-lane base plus a
+// compile-time offset; P0, P1 and the column stride CS come from tools/debug/lds_banks_xcols.py (every access conflict-free but the
+// layout A read of the inverse, two-way).  1.50 ms at 512^3 = 4.3 TB/s (2.77 ms before).
+template <int N, int R0, int R1, int KB, int WPS, bool PARK, int P0, int P1, int CS>
 __global__ void __launch_bounds__(64 * KB, WPS)
-k_xfft_scale512c(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ Z, DGrid G, DBox box, ScaleArgs a,
-                 const double2 *__restrict__ twiddle) {
-    constexpr int CS = x512_cs(KB);
+k_xfft_scale_cols(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ Z, DGrid G, DBox box, ScaleArgs a,
+                  const double2 *__restrict__ twiddle) {
+    constexpr int M1 = N / R0, R2 = M1 / R1, L2 = R0 * R2, L3 = R0 * R1, TA = KB * M1;
+    static_assert(R0 * R1 * R2 == N && L2 <= 64 && L3 <= 64 && TA <= 64 * KB && CS >= 64 * R2, "plan");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double2 *buf = reinterpret_cast<double2 *>(smem_raw);    // [KB][CS]: one component of the block
-    double2 *tw64 = buf + KB * CS;                           // exp(-2 pi i m / 64)
+    double2 *twS = buf + KB * CS;                            // exp(-2 pi i m / M1), m < M1
     const int tid = threadIdx.x;
     const int nkb = (G.Nzh + KB - 1) / KB;
     const int rows = a.transposed ? a.nyl : G.Ny;
@@ -1586,71 +1603,93 @@ k_xfft_scale512c(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__re
     const int jl = bid / nkb, kz0 = (bid - jl * nkb) * KB;
     const int j = a.transposed ? a.y0 + jl : jl;
     const int kv = min(KB, G.Nzh - kz0);
-    double2 *comp[3] = {X, Y, Z};
+    // global addresses: a component's block base (uniform) + a 32-bit byte offset per lane (the launcher checks that a component is
+    // below 4 GiB), recomputed where it is used: 64-bit addresses of every point kept from the loads to the stores were most of
+    // the register spills of this kernel
     const size_t xstride = (size_t)rows * G.Nzp, base = (size_t)jl * G.Nzp + kz0;
-    const int q = tid % KB, n1 = tid / KB;                   // layout A
-    const int w = tid >> 6, l = tid & 63, kp = l >> 3, nn = l & 7;   // layout B
-    double2 *pA = buf + q * CS + n1;                         // + 72 k0
-    double2 *pB = buf + w * CS + 72 * kp + nn;               // + 8 s (B), + 9 k1 (C)
-    double2 *pC = buf + w * CS + 72 * kp + 9 * nn;           // + n'' (C of lane (k0, k1))
+    char *comp[3] = {reinterpret_cast<char *>(X + base), reinterpret_cast<char *>(Y + base), reinterpret_cast<char *>(Z + base)};
+    const unsigned xs16 = (unsigned)(xstride * sizeof(double2));
+    const int q = tid % KB;                                  // layout A
+    const bool actA = TA == 64 * KB || tid < TA;
+    const int n1 = actA ? tid / KB : 0;
+    const int w = tid >> 6, l = tid & 63;                    // layout B
+    const bool act2 = L2 == 64 || l < L2, act3 = L3 == 64 || l < L3;
+    const int kp2 = act2 ? l / R2 : 0, nn = l % R2, kp3 = act3 ? l / R1 : 0, k1 = l % R1;
+    double2 *pA = buf + q * CS + n1;                         // + P0 k0
+    double2 *pB = buf + w * CS + P0 * kp2 + nn;              // + R2 s (B), + P1 k1 (C)
+    double2 *pC = buf + w * CS + P0 * kp3 + P1 * k1;         // + n'' (C of lane (k0, k1))
     double2 *pP = buf + w * CS + l;                          // + 64 k2: the lane's own slots
-    double2 v[3][9];
+    double2 ld[3][R0], v[3][R2];                             // layout A points of a component; its final values (every stage has registers of
+                                                             // its own, defined in all lanes: what a stage leaves behind must not stay alive)
+    const double2 zero = make_double2(0, 0);
+    auto offset0 = [&]() __attribute__((always_inline)) {
+        unsigned o = (unsigned)n1 * xs16 + (unsigned)q * (unsigned)sizeof(double2);
+        asm volatile("" : "+v"(o));                           // not a common subexpression of the other uses
+        return o;
+    };
+    auto load = [&](int c) __attribute__((always_inline)) {
+        const unsigned o = offset0();
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            v[c][r] = make_double2(0, 0);
-            if (q < kv) v[c][r] = comp[c][(size_t)(n1 + 64 * r) * xstride + base + q];
+        for (int r = 0; r < R0; ++r) {
+            ld[c][r] = make_double2(0, 0);
+            if (actA && q < kv) ld[c][r] = *reinterpret_cast<const double2 *>(comp[c] + (size_t)(o + (unsigned)(M1 * r) * xs16));
         }
-    if (tid < 64) tw64[tid] = twiddle[8 * tid];
-    // ---- forward: stage 1 over r -> k0, times W_512^{n k0}
+    };
+    load(0); load(1); load(2);                               // every load of the block in flight at once
+    if (tid < M1) twS[tid] = twiddle[R0 * tid];
+    // ---- forward: stage 1 over r -> k0, times W_N^{n k0}
 #pragma unroll
-    for (int c = 0; c < 3; ++c) dft_small<8, false>(v[c]);
+    for (int c = 0; c < 3; ++c) dft_small<R0, false>(ld[c]);
 #pragma unroll
-    for (int k = 1; k < 8; ++k) {
+    for (int k = 1; k < R0; ++k) {
         const double2 t = twiddle[n1 * k];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) v[c][k] = cmul(v[c][k], t);
+        for (int c = 0; c < 3; ++c) ld[c][k] = cmul(ld[c][k], t);
     }
+    double2 b[3][R1];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         if (c) __syncthreads();                               // every wave has read the previous component
+        if (actA) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pA[72 * k] = v[c][k];
+            for (int k = 0; k < R0; ++k) pA[P0 * k] = ld[c][k];
+        }
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < 8; ++s) v[c][s] = pB[8 * s];
+        for (int s = 0; s < R1; ++s) b[c][s] = act2 ? pB[R2 * s] : zero;
     }
-    // stage 2 over s -> k1, times W_64^{n'' k1}
+    // stage 2 over s -> k1, times W_M1^{n'' k1}
 #pragma unroll
-    for (int c = 0; c < 3; ++c) dft_small<8, false>(v[c]);
+    for (int c = 0; c < 3; ++c) dft_small<R1, false>(b[c]);
 #pragma unroll
-    for (int k = 1; k < 8; ++k) {
-        const double2 t = tw64[nn * k];
+    for (int k = 1; k < R1; ++k) {
+        const double2 t = twS[nn * k];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) v[c][k] = cmul(v[c][k], t);
+        for (int c = 0; c < 3; ++c) b[c][k] = cmul(b[c][k], t);
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {                             // inside the wave's own column: no barrier
+        if (act2) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pB[9 * k] = v[c][k];
+            for (int k = 0; k < R1; ++k) pB[P1 * k] = b[c][k];
+        }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int n = 0; n < 8; ++n) v[c][n] = pC[n];
+        for (int n = 0; n < R2; ++n) v[c][n] = act3 ? pC[n] : zero;
         __builtin_amdgcn_wave_barrier();
-        dft_small<8, false>(v[c]);                            // stage 3 over n'' -> k2
+        dft_small<R2, false>(v[c]);                           // stage 3 over n'' -> k2
     }
-    // ---- the k-space operator on X[k0 + 8 k1 + 64 k2]
+    // ---- the k-space operator on X[k0 + R0 k1 + R0 R1 k2]
     if (PARK) {                                               // the third component waits in the lane's own slots: room for the operator's temporaries
 #pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) pP[64 * k2] = v[2][k2];
+        for (int k2 = 0; k2 < R2; ++k2) pP[64 * k2] = v[2][k2];
     }
-    if (w < kv) {
+    if (w < kv && act3) {
 #pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) {
+        for (int k2 = 0; k2 < R2; ++k2) {
             const double2 f[3] = {v[0][k2], v[1][k2], PARK ? pP[64 * k2] : v[2][k2]};
             double2 out[3];
-            scale_node(kp + 8 * nn + 64 * k2, j, kz0 + w, f, G, box, a, out);
+            scale_node(kp3 + R0 * k1 + R0 * R1 * k2, j, kz0 + w, f, G, box, a, out);
             v[0][k2] = out[0]; v[1][k2] = out[1];
             if (PARK) pP[64 * k2] = out[2]; else v[2][k2] = out[2];
             __builtin_amdgcn_sched_barrier(0);                // one node at a time
@@ -1658,61 +1697,68 @@ k_xfft_scale512c(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__re
     }
     if (PARK) {
 #pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) v[2][k2] = pP[64 * k2];
+        for (int k2 = 0; k2 < R2; ++k2) v[2][k2] = pP[64 * k2];
         __builtin_amdgcn_wave_barrier();
     }
-    // ---- inverse: stage 3 backwards over k2 -> n'', times conj W_64^{n'' k1}
+    // ---- inverse: stage 3 backwards over k2 -> n'', times conj W_M1^{n'' k1}
 #pragma unroll
-    for (int c = 0; c < 3; ++c) dft_small<8, true>(v[c]);
+    for (int c = 0; c < 3; ++c) dft_small<R2, true>(v[c]);
 #pragma unroll
-    for (int n = 1; n < 8; ++n) {
-        double2 t = tw64[n * nn]; t.y = -t.y;
+    for (int n = 1; n < R2; ++n) {
+        double2 t = twS[n * k1]; t.y = -t.y;
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[c][n] = cmul(v[c][n], t);
     }
+    double2 bi[3][R1];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
+        if (act3) {
 #pragma unroll
-        for (int n = 0; n < 8; ++n) pC[n] = v[c][n];
+            for (int n = 0; n < R2; ++n) pC[n] = v[c][n];
+        }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[c][k] = pB[9 * k];
+        for (int k = 0; k < R1; ++k) bi[c][k] = act2 ? pB[P1 * k] : zero;
         __builtin_amdgcn_wave_barrier();
-        dft_small<8, true>(v[c]);                             // stage 2 backwards over k1 -> s
+        dft_small<R1, true>(bi[c]);                           // stage 2 backwards over k1 -> s
     }
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {                             // times conj W_512^{(8 s + n'') k0}
-        double2 t = twiddle[(8 * s + nn) * kp]; t.y = -t.y;
+    for (int s = 0; s < R1; ++s) {                            // times conj W_N^{(R2 s + n'') k0}
+        double2 t = twiddle[(R2 * s + nn) * kp2]; t.y = -t.y;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) v[c][s] = cmul(v[c][s], t);
+        for (int c = 0; c < 3; ++c) bi[c][s] = cmul(bi[c][s], t);
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         if (c) __syncthreads();                               // the layout A reads of the previous component are done
+        if (act2) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) pB[8 * s] = v[c][s];
+            for (int s = 0; s < R1; ++s) pB[R2 * s] = bi[c][s];
+        }
         __syncthreads();
+        double2 st[R0];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[c][k] = pA[72 * k];
-        dft_small<8, true>(v[c]);                             // stage 1 backwards over k0 -> r
-        if (q < kv) {
+        for (int k = 0; k < R0; ++k) st[k] = actA ? pA[P0 * k] : zero;
+        dft_small<R0, true>(st);                              // stage 1 backwards over k0 -> r
+        if (actA && q < kv) {
+            const unsigned o = offset0();
 #pragma unroll
-            for (int r = 0; r < 8; ++r) comp[c][(size_t)(n1 + 64 * r) * xstride + base + q] = v[c][r];
+            for (int r = 0; r < R0; ++r) *reinterpret_cast<double2 *>(comp[c] + (size_t)(o + (unsigned)(M1 * r) * xs16)) = st[r];
         }
     }
 }
 
-template <int KB, int WPS, bool PARK>
-static void launch_xfft512c(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s) {
-    const size_t lds = (size_t)(KB * x512_cs(KB) + 64) * sizeof(double2);
+template <int N, int R0, int R1, int KB, int WPS, bool PARK, int P0, int P1, int CS>
+static void launch_xfft_cols(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s) {
+    const size_t lds = (size_t)(KB * CS + N / R0) * sizeof(double2);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xfft_scale512c<KB, WPS, PARK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xfft_scale_cols<N, R0, R1, KB, WPS, PARK, P0, P1, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int nkb = (G.Nzh + KB - 1) / KB;
     const int rows = a.transposed ? a.nyl : G.Ny;
-    hipLaunchKernelGGL((k_xfft_scale512c<KB, WPS, PARK>), dim3(rows * nkb), dim3(64 * KB), lds, s, X, Y, Z, G, box, a, tw);
+    hipLaunchKernelGGL((k_xfft_scale_cols<N, R0, R1, KB, WPS, PARK, P0, P1, CS>), dim3(rows * nkb), dim3(64 * KB), lds, s, X, Y, Z, G, box, a, tw);
 }
 
 template <int KB, int NTH, class PLAN = RtPlan>
@@ -1934,6 +1980,8 @@ static void launch_xfft_t(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box,
 }
 
 void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s) {
+    // k_xfft_scale_cols addresses a component with 32-bit byte offsets
+    const bool cols32 = (size_t)(a.transposed ? a.nyl : G.Ny) * G.Nzp * G.Nx * sizeof(double2) < ((size_t)1 << 32);
     if (G.Nx & (G.Nx - 1)) {   // not a power of two: mixed-radix passes; 4 kz columns per workgroup while two buffers fit
         FftPlanX pl;
         plan_x(G.Nx, pl);
@@ -1941,7 +1989,10 @@ void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, Sc
         // columns with 128 / 192 threads: 1.90 / 1.52 ms -- the pass is bound by instruction issue, not occupancy; variants removed)
         if (!a.runtime_plan) {   // compile-time plans for the sizes of the reference's rule at the BASELINE configurations (PSE_XMIX=1: runtime plan)
             switch (G.Nx) {
-                case 360: launch_xfft_mixed<2, 256, CtPlan<360, 9, 8, 5>>(X, Y, Z, G, box, a, tw, pl, s); return;
+                case 360:   // 0.80 ms at 360^3 (10 x 6 x 6, no spills at two waves per SIMD; three waves: 66 spilled, 0.97); the passes in LDS: 1.05
+                    if (a.x512_cols && cols32) launch_xfft_cols<360, 10, 6, 4, 2, false, 54, 9, 538>(X, Y, Z, G, box, a, tw, s);
+                    else launch_xfft_mixed<2, 256, CtPlan<360, 9, 8, 5>>(X, Y, Z, G, box, a, tw, pl, s);
+                    return;
                 case 270: launch_xfft_mixed<2, 256, CtPlan<270, 9, 5, 3, 2>>(X, Y, Z, G, box, a, tw, pl, s); return;
                 case 375: launch_xfft_mixed<2, 256, CtPlan<375, 5, 5, 5, 3>>(X, Y, Z, G, box, a, tw, pl, s); return;
                 case 500: launch_xfft_mixed<2, 256, CtPlan<500, 5, 5, 5, 4>>(X, Y, Z, G, box, a, tw, pl, s); return;
@@ -1973,13 +2024,15 @@ void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, Sc
         case 128: launch_xfft_t<7, 8, 512>(X, Y, Z, G, box, a, tw, s); break;
         // 64-byte pieces (four kz): 3.87 TB/s at 256 x 512 x 512; 32-byte pieces (two kz, three workgroups per CU) 2.73; 128-byte pieces with
         // all three components in LDS (eight kz, one workgroup per CU) 2.71
-        case 256: launch_xfft256<4, 256, 2>(X, Y, Z, G, box, a, tw, s); break;   // two radix-16 passes in registers
+        case 256:   // (256 = 8 x 8 x 4 through k_xfft_scale_cols: 0.25 - 0.27 ms at 256^3, no better than this kernel's 0.25)
+            launch_xfft256<4, 256, 2>(X, Y, Z, G, box, a, tw, s);   // two radix-16 passes in registers
+            break;
         // 512: radix 16, 16, 2; two kz columns: three workgroups per CU (3.3 ms at 512^3; four columns, one workgroup: 3.8; radix 4/2 in LDS: 5.2)
         default:
             // one component in LDS at a time, four kz columns, three workgroups per CU: 1.50 ms at 512^3 (4.3 TB/s); eight columns at four
             // waves per SIMD (128 registers: 225 spilled) 3.3 ms, six columns 2.9 ms, four columns without parking the third component
             // during the operator (107 spilled) 2.27 ms; all three components in LDS, two columns (PSE_X512_COLS=0): 2.77 ms
-            if (a.x512_cols) launch_xfft512c<4, 3, true>(X, Y, Z, G, box, a, tw, s);
+            if (a.x512_cols && cols32) launch_xfft_cols<512, 8, 8, 4, 3, true, 72, 9, 578>(X, Y, Z, G, box, a, tw, s);
             else launch_xfft256<2, 256, 1, 512>(X, Y, Z, G, box, a, tw, s);
             break;
     }

@@ -81,7 +81,7 @@ struct pse_handle {
         int gather_bz = 0;        // PSE_GATHER_BZ=1|2: bins along z per gather workgroup (0: by the particles per bin)
         int xmix_runtime = 0;     // PSE_XMIX=1: runtime radix plan of the mixed x pass also where a compile-time plan exists
         int xfft_small_wide = 0;  // PSE_XFFT_SMALL_KB=8: the eight-column x pass also on small grids
-        int x512_cols = 4;        // PSE_X512_COLS=0: the three-components-in-LDS kernel for the 512-point x pass (A/B)
+        int xcols = 1;            // PSE_XCOLS=0: Nx = 512 and 360 by the x pass kernels that keep all three components in LDS (A/B)
         bool verbose = false;     // PSE_VERBOSE
         bool team_sstep = true;      // PSE_TEAM_SSTEP=0: teams run one Lanczos iteration per exchange (default: two, see lanczos_team)
         int team_sched[3] = {1, 2, 3};   // PSE_TEAM_SCHED=a,b,c: far-field exchange k of a team step is issued before Lanczos exchange sched[k]
@@ -426,7 +426,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         t.own_y = ienv("PSE_OWN_Y", 1); t.yfft_kb = ienv("PSE_YFFT_KB", 4);
         if (const char *v = getenv("PSE_WAVE_MODE")) t.wave_mode = !strcmp(v, "slab") ? 1 : (!strcmp(v, "replicated") ? 2 : 0);
         t.spread_tz = ienv("PSE_SPREAD_TZ", 0); t.spread_nw = ienv("PSE_SPREAD_NW", 0);
-        t.gather_bz = ienv("PSE_GATHER_BZ", 0); t.xmix_runtime = ienv("PSE_XMIX", 0) == 1; t.xfft_small_wide = ienv("PSE_XFFT_SMALL_KB", 2) == 8; t.x512_cols = ienv("PSE_X512_COLS", 4);
+        t.gather_bz = ienv("PSE_GATHER_BZ", 0); t.xmix_runtime = ienv("PSE_XMIX", 0) == 1; t.xfft_small_wide = ienv("PSE_XFFT_SMALL_KB", 2) == 8; t.xcols = ienv("PSE_XCOLS", 1);
         t.verbose = ienv("PSE_VERBOSE", 0) > 0;
         t.team_sstep = ienv("PSE_TEAM_SSTEP", 1) > 0;
         if (const char *v = getenv("PSE_TEAM_SCHED")) {
@@ -1187,7 +1187,7 @@ static ScaleArgs scale_args(pse_handle *h, bool noise, double kT, double dt, uns
     a.noise_fac = noise ? std::sqrt(2.0 * kT / dt / (G.hx * G.hy * G.hz)) : 0.0;   // PSEv1/Brownian.cu:197
     a.seed = h->par.seed; a.timestep = timestep;
     a.transposed = h->grid_slabs > 1 ? 1 : 0; a.y0 = h->y0; a.nyl = h->grid_slabs > 1 ? h->nyl : G.Ny;
-    a.runtime_plan = h->tun.xmix_runtime; a.wide_small = h->tun.xfft_small_wide; a.x512_cols = h->tun.x512_cols;
+    a.runtime_plan = h->tun.xmix_runtime; a.wide_small = h->tun.xfft_small_wide; a.xcols = h->tun.xcols;
     return a;
 }
 

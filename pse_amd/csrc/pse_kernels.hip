@@ -1568,7 +1568,7 @@ __device__ __forceinline__ double2 *fft_mixed_ct(double2 *a, double2 *b, const d
     return a;
 }
 
-// ---- N = R0 x R1 x R2 with ONE component in LDS at a time (512 = 8 8 8, 360 = 10 6 6, 256 = 8 8 4) ------------------------------
+// ---- N = R0 x R1 x R2 with ONE component in LDS at a time (512 = 8 x 8 x 8, 360 = 10 x 6 x 6) ------------------------------------
 // The kernels above keep the three components of a block of columns in LDS, which caps a 512-point block at two kz columns
 // (32-byte pieces of every 128-byte line: 2.4 TB/s; the 256-point kernel loses the same 30 % when it is given two columns) and
 // sends a point through LDS four times per transform.  Here the data live in registers, LDS holds one component of the block
@@ -1579,14 +1579,25 @@ __device__ __forceinline__ double2 *fft_mixed_ct(double2 *a, double2 *b, const d
 //   layout B: wave w = column w; lanes (k0, n'') run stage 2 (radix R1 inside the N / R0-point transform k0), lanes (k0, k1) stage 3
 //            (radix R2), with one exchange in between that stays inside the wave (LDS instructions of a wave execute in order: no
 //            barrier).  Stage 3 leaves X[k0 + R0 k1 + R0 R1 k2] in register k2 of lane R1 k0 + k1 for all three components, so the
-//            k-space operator works on registers (the third component parked in the lane's own LDS slots meanwhile: the operator
-//            needs ~100 registers of its own), and the inverse (decimation in time) runs the same stages backwards from that
-//            digit-reversed order.
-// Per transform a point crosses LDS twice; 10 barriers per block.  Components go through one after the other (only the R2 final
-// values of a component stay in registers; the loads of the next one are in flight meanwhile).
+//            k-space operator works on registers (PARK: the third component waits in the lane's own LDS slots meanwhile -- the
+//            operator needs ~100 registers of its own), and the inverse (decimation in time) runs the same stages backwards from
+//            that digit-reversed order.
+// Per transform a point crosses LDS twice; 10 barriers per block; every load of the block is in flight at once and a stage's
+// twiddles are fetched once for the three components (stage by stage over the components: a variant that took a component
+// through all stages before the next -- fewer live registers -- was 15 % slower at 512^3: three times the twiddle fetches).
+// Every stage has registers of its own, defined in ALL lanes: where only some lanes take part in a layout (360: 144 of 256
+// threads in A, 60 of 64 lanes in B) values left in the others would stay alive across the whole kernel (291 registers spilled).
+// Global addresses are a uniform base plus a 32-bit byte offset per lane, recomputed at the stores (the launcher checks < 4 GiB
+// per component): 64-bit addresses kept from the loads to the stores were spilled too.
 // Positions in a column: B[k0][n] at P0 k0 + n, C[k0][k1][n] at P0 k0 + P1 k1 + n -- every access is a per-lane base plus a
 // compile-time offset; P0, P1 and the column stride CS come from tools/debug/lds_banks_xcols.py (every access conflict-free but the
-// layout A read of the inverse, two-way).  1.50 ms at 512^3 = 4.3 TB/s (2.77 ms before).
+// layout A read of the inverse, two-way).
+// 512^3: 1.5 ms = 4.3 TB/s in some processes, 1.77 ms in others (both kernels of this file show the two modes, whatever the
+// plane stride: 128 bytes to 64 KB appended to every x plane changed nothing) against 2.77 ms; 360^3: 0.80 ms against 1.05.
+// 256 = 8 x 8 x 4 through this kernel: 0.25 - 0.27 ms at 256^3, no better than k_xfft_scale256 -- not dispatched.
+// Also measured and dropped: a table of the operator's scalars per node (what the reference keeps in gridk.w) instead of the
+// exponential, sine and reciprocal square root per node: 256^3 0.25 -> 0.30 ms, 512^3 +20 % (a dependent load in the middle of
+// the block costs more than the 150 instructions it saves).
 template <int N, int R0, int R1, int KB, int WPS, bool PARK, int P0, int P1, int CS>
 __global__ void __launch_bounds__(64 * KB, WPS)
 k_xfft_scale_cols(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ Z, DGrid G, DBox box, ScaleArgs a,
@@ -1990,7 +2001,7 @@ void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, Sc
         if (!a.runtime_plan) {   // compile-time plans for the sizes of the reference's rule at the BASELINE configurations (PSE_XMIX=1: runtime plan)
             switch (G.Nx) {
                 case 360:   // 0.80 ms at 360^3 (10 x 6 x 6, no spills at two waves per SIMD; three waves: 66 spilled, 0.97); the passes in LDS: 1.05
-                    if (a.x512_cols && cols32) launch_xfft_cols<360, 10, 6, 4, 2, false, 54, 9, 538>(X, Y, Z, G, box, a, tw, s);
+                    if (a.xcols && cols32) launch_xfft_cols<360, 10, 6, 4, 2, false, 54, 9, 538>(X, Y, Z, G, box, a, tw, s);
                     else launch_xfft_mixed<2, 256, CtPlan<360, 9, 8, 5>>(X, Y, Z, G, box, a, tw, pl, s);
                     return;
                 case 270: launch_xfft_mixed<2, 256, CtPlan<270, 9, 5, 3, 2>>(X, Y, Z, G, box, a, tw, pl, s); return;
@@ -2031,8 +2042,8 @@ void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, Sc
         default:
             // one component in LDS at a time, four kz columns, three workgroups per CU: 1.50 ms at 512^3 (4.3 TB/s); eight columns at four
             // waves per SIMD (128 registers: 225 spilled) 3.3 ms, six columns 2.9 ms, four columns without parking the third component
-            // during the operator (107 spilled) 2.27 ms; all three components in LDS, two columns (PSE_X512_COLS=0): 2.77 ms
-            if (a.x512_cols && cols32) launch_xfft_cols<512, 8, 8, 4, 3, true, 72, 9, 578>(X, Y, Z, G, box, a, tw, s);
+            // during the operator (107 spilled) 2.27 ms; all three components in LDS, two columns (PSE_XCOLS=0): 2.77 ms
+            if (a.xcols && cols32) launch_xfft_cols<512, 8, 8, 4, 3, true, 72, 9, 578>(X, Y, Z, G, box, a, tw, s);
             else launch_xfft256<2, 256, 1, 512>(X, Y, Z, G, box, a, tw, s);
             break;
     }

@@ -46,6 +46,33 @@ def test_loopback_team_matches_single_gpu(world, xy, mode, monkeypatch):
     assert i["lanczos_m"] == m and i["lanczos_exchanges"] <= 3 + max(0, (m - 5 + 1) // 2), i
 
 
+@pytest.mark.parametrize("nx,world", [(360, 4), (512, 4), (360, 3)])
+def test_slab_team_with_the_register_x_pass(nx, world, monkeypatch):
+    """Nx = 360 and 512 take k_xfft_scale_cols (the data of a block in registers, one component in LDS at a time); on slab ranks it
+    works on the transposed layout [Nx][ny_local][Nzh] with the rank's row offset.  Box stretched along x so that hx stays 24 / 256."""
+    import pse_amd
+    from pse_amd.sharded import LoopbackSimulation
+    monkeypatch.setenv("PSE_WAVE_MODE", "slab")
+    n = 2500
+    pos, force, box = make_suspension(n, L=24.0, xy=0.1)
+    Lx = nx * 24.0 / 256.0
+    pos[:, 0] = (pos[:, 0] - 0.1 * pos[:, 1]) * (Lx / 24.0) + 0.1 * pos[:, 1]
+    box = (Lx, 24.0, 24.0, 0.1)
+    kw = dict(xi=0.5, error=1e-3, seed=12, grid=(nx, 48 if world == 3 else 32, 36), P=4)
+    ref = pse_amd.Engine(n, box, **kw)
+    sim = LoopbackSimulation(n, box, world, **kw)
+    sim.load(pos, force)
+    u_ref = ref.mobility(to4(pos), to4(force)).cpu().numpy()[:, :3]
+    vels = sim.mobility()
+    for r in range(world):
+        assert rel(vels[r].cpu().numpy()[:, :3], u_ref) < 1e-12, r
+    v_ref, m_ref = ref.brownian_velocity(to4(pos), to4(force), 1.0, 1e-3, 9)
+    vels, m = sim.brownian_velocity(1.0, 1e-3, 9)
+    assert m == m_ref
+    for r in range(world):
+        assert rel(vels[r].cpu().numpy()[:, :3], v_ref.cpu().numpy()[:, :3]) < 1e-11, r
+
+
 @pytest.mark.parametrize("world,m_in", [(2, 2), (3, 3), (4, 6), (4, 11)])
 def test_two_step_and_one_step_lanczos_agree(world, m_in, monkeypatch):
     """The team's two-iterations-per-exchange Lanczos (default) against the one-iteration driver (PSE_TEAM_SSTEP=0) and the single

@@ -273,6 +273,19 @@ static int collect_times(pse_handle *h, unsigned mask) {
     return 0;
 }
 
+// The spreading Gaussian exp(-c r^2), c = 2 xi^2 / eta, has its width from the SMALLEST grid spacing (the reference's rule makes the
+// three spacings equal up to the rounding of the grid sizes, PSEv1/Stokes.cc:147-214); spread and gather build its P values per axis
+// by a product recurrence whose factors reach exp(c h^2 P) and whose values fall to exp(-c h^2 P^2 / 4).  A grid or box override whose
+// coarsest spacing puts those outside the double range would turn into NaN velocities: refused here.
+static int gaussian_fits(const Derived &d, double hx, double hy, double hz) {
+    const double c = 2.0 * d.xi * d.xi / d.eta, hmax = std::max(hx, std::max(hy, hz));
+    const double worst = c * hmax * hmax * std::max((double)d.P, 0.25 * d.P * d.P);
+    if (!(worst < 700.0))
+        return fail(PSE_ERR_INVALID, "grid spacings (%g, %g, %g) too unequal for the spreading Gaussian of P = %d points, eta = %g: "
+                    "exp(+-%.0f) over its support on the coarsest axis", hx, hy, hz, d.P, d.eta, worst);
+    return 0;
+}
+
 extern "C" int pse_destroy(pse_handle *h) {
     if (!h) return 0;
     (void)hipSetDevice(h->device);
@@ -406,6 +419,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     std::string e = select_params(h->box, p->xi, p->error, p->max_strain, p->Nx, p->Ny, p->Nz, p->P, p->rcut, h->d);
     if (!e.empty()) return fail(PSE_ERR_INVALID, "%s", e.c_str());
     if (p->n_max == 0) return fail(PSE_ERR_INVALID, "n_max must be positive");
+    TRY(gaussian_fits(h->d, h->d.hx, h->d.hy, h->d.hz));
     if (!(std::fabs(p->xy) <= 0.5 * (1.0 + 1e-9)))
         return fail(PSE_ERR_INVALID, "tilt xy = %g outside [-0.5, 0.5]: HOOMD flips the box there, and the sequential minimum image "
                     "(PSEv1/Mobility.cu:648) is exact only up to that tilt", p->xy);
@@ -642,6 +656,7 @@ extern "C" int pse_set_box(pse_handle *h, double Lx, double Ly, double Lz, doubl
     TRY(cells_for(nb, h->d.rcut, gamma, h->n_slabs, h->tun.cell_bz, nc_narrow));
     if ((size_t)std::max(cells_total(nc), cells_total(nc_narrow)) > h->n_cells_alloc)
         return fail(PSE_ERR_INVALID, "box grew beyond the cell-list capacity sized at creation");
+    TRY(gaussian_fits(h->d, Lx / h->d.Nx, Ly / h->d.Ny, Lz / h->d.Nz));
     h->box = nb;
     h->nc = nc;
     h->cell_gamma = gamma;

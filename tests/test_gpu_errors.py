@@ -45,6 +45,7 @@ def test_misuse_is_reported_not_fatal():
                       (_params(-20.0), "box"),
                       (_params(8.0), "half the box"),                       # rcut = 5.26 > L / 2
                       (_params(40.0, Nx=16, Ny=16, Nz=16), "eta"),          # grid too coarse for xi: eta >= 1
+                      (_params(20.0, Nx=256, Ny=16, Nz=16, P=4), "spreading Gaussian"),   # spacings 16 x apart: NaN from the weight recurrence otherwise
                       (_params(20.0, P=-2), "P"),
                       (_params(20.0, Nx=-8), "grid"),
                       (_params(20.0, rcut=-1.0), "rcut"),

@@ -74,6 +74,7 @@ struct pse_handle {
         double skin = 0.4;        // PSE_SKIN: r_buff of the neighbour list kept across calls (0: off)
         int overlap = 0;          // PSE_OVERLAP: 1 two chains for every call, 0 (default) only for kT = 0, -1 never
         bool no_xfuse = false;    // PSE_NO_XFUSE: rocFFT for the x pass
+        int own_y_pow2 = 1;       // PSE_OWN_Y_POW2=0: rocFFT's 2-D transforms at Ny = 256 instead of its 1-D z pass + k_yfft_regs (A/B)
         int own_y = 1;            // PSE_OWN_Y=0: rocFFT's 2-D (y, z) transforms also where the own y pass applies
         int yfft_kb = 4;          // PSE_YFFT_KB: kz columns per workgroup of the own y pass (2, 4, 8)
         int wave_mode = 0;        // PSE_WAVE_MODE: 0 automatic, 1 slab, 2 replicated
@@ -328,7 +329,7 @@ static int make_plans(pse_handle *h) {
         HIPCHK(hipMemcpy(h->twiddle, tw.data(), G.Nx * sizeof(double2), hipMemcpyHostToDevice));
     }
     // the y transforms of a single GPU's grid by the own in-place pass where rocFFT's strided pass is slow (not a power of two)
-    h->own_y = h->xfuse && h->grid_slabs == 1 && h->tun.own_y > 0 && yfft_supported(G.Ny);
+    h->own_y = h->xfuse && h->grid_slabs == 1 && h->tun.own_y > 0 && (yfft_supported(G.Ny) || (h->tun.own_y_pow2 && yfft_regs_supported(G.Ny, G.Nz)));
     // a slab rank: the own y pass for ANY smooth Ny -- it writes the all-to-all blocks directly (no pack / unpack pass)
     h->own_y_slab = h->xfuse && h->grid_slabs > 1 && h->tun.own_y > 0 && yfft_possible(G.Ny);
     if (h->own_y || h->own_y_slab) {
@@ -437,7 +438,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         if (const char *v = getenv("PSE_SKIN")) t.skin = atof(v);
         t.overlap = ienv("PSE_OVERLAP", 0);
         t.no_xfuse = getenv("PSE_NO_XFUSE") != nullptr;
-        t.own_y = ienv("PSE_OWN_Y", 1); t.yfft_kb = ienv("PSE_YFFT_KB", 4);
+        t.own_y = ienv("PSE_OWN_Y", 1); t.own_y_pow2 = ienv("PSE_OWN_Y_POW2", 1); t.yfft_kb = ienv("PSE_YFFT_KB", 4);
         if (const char *v = getenv("PSE_WAVE_MODE")) t.wave_mode = !strcmp(v, "slab") ? 1 : (!strcmp(v, "replicated") ? 2 : 0);
         t.spread_tz = ienv("PSE_SPREAD_TZ", 0); t.spread_nw = ienv("PSE_SPREAD_NW", 0);
         t.gather_bz = ienv("PSE_GATHER_BZ", 0); t.xmix_runtime = ienv("PSE_XMIX", 0) == 1; t.xfft_small_wide = ienv("PSE_XFFT_SMALL_KB", 2) == 8; t.xcols = ienv("PSE_XCOLS", 1);

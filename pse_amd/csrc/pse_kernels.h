@@ -198,6 +198,7 @@ bool xfuse_supported(int Nx);
 // own in-place y transforms of the half spectra [3 nxl][Ny][Nzp] (Ny = 2^a 3^b 5^c, not a power of two); tw[m] = exp(-2 pi i m / Ny);
 // kb: consecutive kz per workgroup (2, 4 or 8)
 bool yfft_supported(int Ny);
+bool yfft_regs_supported(int Ny, int Nz);   // 256 (Nz <= 256): the register y pass (k_yfft_regs) instead of rocFFT's strided pass
 // a slab rank's y transforms with the reordering of the all-to-all blocks folded in: forward reads the planes [3][nxl][Ny][Nzp] and writes
 // [3][G][nxl][nyl][Nzp]; inverse the other way round (any Ny = 2^a 3^b 5^c in 16..512: yfft_possible)
 bool yfft_possible(int Ny);

@@ -1956,12 +1956,103 @@ void launch_yfft_slab(double2 *cgrid, double2 *blocks, DGrid G, int nyl, bool in
     if (inverse) hipLaunchKernelGGL((k_fft_cols<KB, NTH, true, 2>), g, b, lds, s, cgrid, pl, tw, nkb, G.Nzh, G.Nzp, ps, blocks, G.nxl, nyl);
     else hipLaunchKernelGGL((k_fft_cols<KB, NTH, false, 1>), g, b, lds, s, cgrid, pl, tw, nkb, G.Nzh, G.Nzp, ps, blocks, G.nxl, nyl);
 }
+// ---- the y pass of Ny = 256 = 8 x 8 x 4 with the data in registers ------------------------------------------------------------------
+// The stages of k_xfft_scale_cols without the operator: one component, one direction, natural order in and out -- after stage 3
+// the wave parks X[k0 + 8 k1 + 64 k2] at its natural position of the column (padded by one per eight: the strided writes and the
+// layout A reads are conflict-free), one more barrier, and layout A stores whole pieces.  Three trips through LDS and two barriers
+// per block; eight kz columns = 128-byte pieces at ~60 registers.  (Inverse = the same decimation in frequency with conjugate
+// twiddles, unnormalised like rocFFT's.)
+template <int N, int R0, int R1, int KB, bool INVERSE, int P0, int P1, int CS>
+__global__ void __launch_bounds__(64 * KB)
+k_yfft_regs(double2 *__restrict__ data, const double2 *__restrict__ twiddle, int nkb, int Nzh, int Nzp, size_t plane_stride) {
+    constexpr int M1 = N / R0, R2 = M1 / R1, L2 = R0 * R2, L3 = R0 * R1, TA = KB * M1, PN = M1 + M1 / 8;
+    static_assert(R0 == 8 && R1 == 8 && R0 * R1 * R2 == N && L2 <= 64 && TA <= 64 * KB && CS >= N + N / 8, "plan");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double2 *buf = reinterpret_cast<double2 *>(smem_raw);    // [KB][CS]
+    double2 *twS = buf + KB * CS;                            // exp(-2 pi i m / M1), m < M1
+    const int tid = threadIdx.x;
+    const int bid = xcd_block(blockIdx.x, gridDim.x);
+    const int plane = bid / nkb, kz0 = (bid - plane * nkb) * KB, kv = min(KB, Nzh - kz0);
+    char *base = reinterpret_cast<char *>(data + (size_t)plane * plane_stride + kz0);
+    const unsigned row16 = (unsigned)Nzp * (unsigned)sizeof(double2);
+    const int q = tid % KB;
+    const bool actA = TA == 64 * KB || tid < TA;
+    const int n1 = actA ? tid / KB : 0;
+    const int w = tid >> 6, l = tid & 63;
+    const bool act2 = L2 == 64 || l < L2;
+    const int kp2 = act2 ? l / R2 : 0, nn = l % R2, kp3 = l / R1, k1 = l % R1;
+    double2 *pA = buf + q * CS + n1;                         // + P0 k0
+    double2 *pB = buf + w * CS + P0 * kp2 + nn;              // + R2 s (B), + P1 k1 (C)
+    double2 *pC = buf + w * CS + P0 * kp3 + P1 * k1;         // + n''
+    double2 *pN = buf + w * CS + kp3 + 9 * k1;               // + 72 k2: natural position ky + ky / 8 of ky = k0 + 8 k1 + 64 k2
+    double2 *pO = buf + q * CS + n1 + (n1 >> 3);             // + PN r: natural position of y = n + M1 r
+    const double2 zero = make_double2(0, 0);
+    const unsigned o0 = (unsigned)n1 * row16 + (unsigned)q * (unsigned)sizeof(double2);
+    double2 a[R0];
+#pragma unroll
+    for (int r = 0; r < R0; ++r) {
+        a[r] = zero;
+        if (actA && q < kv) a[r] = *reinterpret_cast<const double2 *>(base + (size_t)(o0 + (unsigned)(M1 * r) * row16));
+    }
+    if (tid < M1) twS[tid] = twiddle[R0 * tid];
+    dft_small<R0, INVERSE>(a);                                // stage 1 over r -> k0, times W_N^{n k0}
+#pragma unroll
+    for (int k = 1; k < R0; ++k) { double2 t = twiddle[n1 * k]; if (INVERSE) t.y = -t.y; a[k] = cmul(a[k], t); }
+    if (actA) {
+#pragma unroll
+        for (int k = 0; k < R0; ++k) pA[P0 * k] = a[k];
+    }
+    __syncthreads();
+    double2 b[R1];
+#pragma unroll
+    for (int s = 0; s < R1; ++s) b[s] = act2 ? pB[R2 * s] : zero;
+    dft_small<R1, INVERSE>(b);                                // stage 2 over s -> k1, times W_M1^{n'' k1}
+#pragma unroll
+    for (int k = 1; k < R1; ++k) { double2 t = twS[nn * k]; if (INVERSE) t.y = -t.y; b[k] = cmul(b[k], t); }
+    if (act2) {
+#pragma unroll
+        for (int k = 0; k < R1; ++k) pB[P1 * k] = b[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    double2 v[R2];
+#pragma unroll
+    for (int n = 0; n < R2; ++n) v[n] = pC[n];
+    __builtin_amdgcn_wave_barrier();
+    dft_small<R2, INVERSE>(v);                                // stage 3 over n'' -> k2
+#pragma unroll
+    for (int k2 = 0; k2 < R2; ++k2) pN[72 * k2] = v[k2];
+    __syncthreads();
+    if (actA && q < kv) {
+#pragma unroll
+        for (int r = 0; r < R0; ++r) *reinterpret_cast<double2 *>(base + (size_t)(o0 + (unsigned)(M1 * r) * row16)) = pO[PN * r];
+    }
+}
+template <int N, int R0, int R1, int KB, int P0, int P1, int CS>
+static void launch_yfft_regs(double2 *data, const double2 *tw, int nplanes, int Nzh, int Nzp, size_t plane_stride, bool inverse, hipStream_t s) {
+    const size_t lds = (size_t)(KB * CS + N / R0) * sizeof(double2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_yfft_regs<N, R0, R1, KB, true, P0, P1, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_yfft_regs<N, R0, R1, KB, false, P0, P1, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int nkb = (Nzh + KB - 1) / KB;
+    const dim3 g(nplanes * nkb), b(64 * KB);
+    if (inverse) hipLaunchKernelGGL((k_yfft_regs<N, R0, R1, KB, true, P0, P1, CS>), g, b, lds, s, data, tw, nkb, Nzh, Nzp, plane_stride);
+    else hipLaunchKernelGGL((k_yfft_regs<N, R0, R1, KB, false, P0, P1, CS>), g, b, lds, s, data, tw, nkb, Nzh, Nzp, plane_stride);
+}
+// 256^3: forward 0.30 against 0.31 - 0.32 ms, inverse 0.32 against 0.34 (rocFFT's 2-D plan).  Not at 512: the pass itself equals rocFFT's
+// strided one there (2.6 ms per direction either way), and rocFFT's 1-D real forward transform of 512 points, which would replace
+// the z half of its 2-D plan, is slow (3.7 ms per direction at 512^3 instead of 2.6).
+bool yfft_regs_supported(int Ny, int Nz) { return Ny == 256 && Nz <= 256; }
+
 // all three components: [3 Nx] planes of [Ny][Nzp]; tw[m] = exp(-2 pi i m / Ny)
 void launch_yfft(double2 *spectra, DGrid G, bool inverse, const double2 *tw, hipStream_t s, int kb) {
     FftPlanX pl;
     plan_x(G.Ny, pl);
     const int nplanes = 3 * G.nxl;
     const size_t ps = (size_t)G.Ny * G.Nzp;
+    if (G.Ny == 256) { launch_yfft_regs<256, 8, 8, 8, 44, 5, 359>(spectra, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s); return; }   // (four columns: +3 %)
     if (kb == 8) launch_fft_cols<8, 256>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);
     else if (kb == 2) launch_fft_cols<2, 256>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);
     else if (kb == 4 && G.Ny == 360) launch_fft_cols<4, 256, CtPlan<360, 9, 8, 5>>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);   // compile-time plans, as in the x pass

@@ -48,7 +48,9 @@ typedef struct pse_params {
     double error;            /* tolerance for all approximations (m_error) */
     double max_strain;       /* largest |xy| the box will take; sizes P (PSEv1/Stokes.cc:217-229) */
     unsigned int seed;       /* RNG seed as used on the device (the host class hashes the user seed, Stokes.cc:102) */
-    int Nx, Ny, Nz;          /* FFT grid override (0 = PSEv1/Stokes.cc:138-199) */
+    int Nx, Ny, Nz;          /* FFT grid override (0 = PSEv1/Stokes.cc:138-199).  The reference's rule makes the three spacings equal up
+                                to the rounding of the sizes; an override whose coarsest spacing takes the spreading Gaussian (width from
+                                the finest) out of the double range over its support is refused: PSE_ERR_INVALID (pse_set_box likewise) */
     int P;                   /* support override (0 = PSEv1/Stokes.cc:225-233) */
     double rcut;             /* real-space cutoff override (0 = PSEv1/Stokes.cc:135) */
     int device;              /* HIP device ordinal, -1 = current device */

@@ -82,7 +82,7 @@ struct pse_handle {
         int gather_bz = 0;        // PSE_GATHER_BZ=1|2: bins along z per gather workgroup (0: by the particles per bin)
         int xmix_runtime = 0;     // PSE_XMIX=1: runtime radix plan of the mixed x pass also where a compile-time plan exists
         int xfft_small_wide = 0;  // PSE_XFFT_SMALL_KB=8: the eight-column x pass also on small grids
-        int xcols = 1;            // PSE_XCOLS=0: Nx = 512 and 360 by the x pass kernels that keep all three components in LDS (A/B)
+        int xcols = 1;            // PSE_XCOLS=0: Nx = 512, 360, 256 by the x pass kernels that keep all three components in LDS (A/B)
         bool verbose = false;     // PSE_VERBOSE
         bool team_sstep = true;      // PSE_TEAM_SSTEP=0: teams run one Lanczos iteration per exchange (default: two, see lanczos_team)
         int team_sched[3] = {1, 2, 3};   // PSE_TEAM_SCHED=a,b,c: far-field exchange k of a team step is issued before Lanczos exchange sched[k]

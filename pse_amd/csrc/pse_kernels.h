@@ -188,7 +188,7 @@ struct ScaleArgs {
     int y0, nyl;             // slab of y rows in transposed layout
     int runtime_plan;        // PSE_XMIX=1: the runtime radix plan also where a compile-time one exists (A/B)
     int wide_small;          // PSE_XFFT_SMALL_KB=8: eight kz columns per workgroup also on small grids (A/B)
-    int xcols;               // PSE_XCOLS=0: Nx = 512 and 360 by the kernels that keep the three components of a block in LDS instead of k_xfft_scale_cols (A/B)
+    int xcols;               // PSE_XCOLS=0: Nx = 512, 360, 256 by the kernels that keep the three components of a block in LDS instead of k_xfft_scale_cols (A/B)
 };
 void launch_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, hipStream_t s);
 // debug: kx, ky, kz, w sinc^2, sqrt(w) sinc of n nodes (i, j, k)

@@ -1568,7 +1568,7 @@ __device__ __forceinline__ double2 *fft_mixed_ct(double2 *a, double2 *b, const d
     return a;
 }
 
-// ---- N = R0 x R1 x R2 with ONE component in LDS at a time (512 = 8 x 8 x 8, 360 = 10 x 6 x 6) ------------------------------------
+// ---- N = R0 x R1 x R2 with ONE component in LDS at a time (512 = 8 x 8 x 8, 360 = 10 x 6 x 6, 256 = 4 x 8 x 8) ---------------------
 // The kernels above keep the three components of a block of columns in LDS, which caps a 512-point block at two kz columns
 // (32-byte pieces of every 128-byte line: 2.4 TB/s; the 256-point kernel loses the same 30 % when it is given two columns) and
 // sends a point through LDS four times per transform.  Here the data live in registers, LDS holds one component of the block
@@ -1594,16 +1594,20 @@ __device__ __forceinline__ double2 *fft_mixed_ct(double2 *a, double2 *b, const d
 // layout A read of the inverse, two-way).
 // 512^3: 1.5 ms = 4.3 TB/s in some processes, 1.77 ms in others (both kernels of this file show the two modes, whatever the
 // plane stride: 128 bytes to 64 KB appended to every x plane changed nothing) against 2.77 ms; 360^3: 0.80 ms against 1.05.
-// 256 = 8 x 8 x 4 through this kernel: 0.25 - 0.27 ms at 256^3, no better than k_xfft_scale256 -- not dispatched.
+// 256 = 8 x 8 x 4 through this kernel (one column per wave, 64-byte pieces): 0.25 - 0.27 ms at 256^3, no better than k_xfft_scale256;
+// 256 = 4 x 8 x 8 with two columns per wave (CPW = 2, 128-byte pieces): 0.201 ms against 0.226 -- dispatched.
 // Also measured and dropped: a table of the operator's scalars per node (what the reference keeps in gridk.w) instead of the
 // exponential, sine and reciprocal square root per node: 256^3 0.25 -> 0.30 ms, 512^3 +20 % (a dependent load in the middle of
 // the block costs more than the 150 instructions it saves).
-template <int N, int R0, int R1, int KB, int WPS, bool PARK, int P0, int P1, int CS>
-__global__ void __launch_bounds__(64 * KB, WPS)
+template <int N, int R0, int R1, int KB, int WPS, bool PARK, int P0, int P1, int CS, int CPW = 1>
+__global__ void __launch_bounds__(64 * KB / CPW, WPS)
 k_xfft_scale_cols(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ Z, DGrid G, DBox box, ScaleArgs a,
                   const double2 *__restrict__ twiddle) {
-    constexpr int M1 = N / R0, R2 = M1 / R1, L2 = R0 * R2, L3 = R0 * R1, TA = KB * M1;
-    static_assert(R0 * R1 * R2 == N && L2 <= 64 && L3 <= 64 && TA <= 64 * KB && CS >= 64 * R2, "plan");
+    // CPW = 2 (256 = 4 x 8 x 8): TWO columns per wave in layout B (32 lanes each), so that a workgroup of four waves owns eight kz
+    // columns = whole 128-byte pieces; a thread of layout A then runs NBA = 2 butterflies (n and n + NTH / KB)
+    constexpr int M1 = N / R0, R2 = M1 / R1, L2 = R0 * R2, L3 = R0 * R1, TA = KB * M1, LC = 64 / CPW, NTH = 64 * KB / CPW;
+    constexpr int NBA = (TA + NTH - 1) / NTH, NSTEP = NTH / KB;
+    static_assert(R0 * R1 * R2 == N && L2 <= LC && L3 <= LC && NTH % KB == 0 && (NBA == 1 || TA == NBA * NTH) && CS >= LC * R2, "plan");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double2 *buf = reinterpret_cast<double2 *>(smem_raw);    // [KB][CS]: one component of the block
     double2 *twS = buf + KB * CS;                            // exp(-2 pi i m / M1), m < M1
@@ -1621,16 +1625,16 @@ k_xfft_scale_cols(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__r
     char *comp[3] = {reinterpret_cast<char *>(X + base), reinterpret_cast<char *>(Y + base), reinterpret_cast<char *>(Z + base)};
     const unsigned xs16 = (unsigned)(xstride * sizeof(double2));
     const int q = tid % KB;                                  // layout A
-    const bool actA = TA == 64 * KB || tid < TA;
-    const int n1 = actA ? tid / KB : 0;
-    const int w = tid >> 6, l = tid & 63;                    // layout B
-    const bool act2 = L2 == 64 || l < L2, act3 = L3 == 64 || l < L3;
+    const bool actA = TA >= NTH || tid < TA;
+    const int n1 = actA ? tid / KB : 0;                      // (+ NSTEP for the second butterfly)
+    const int w = (tid >> 6) * CPW + (tid & 63) / LC, l = (tid & 63) % LC;   // layout B: column, lane of the column
+    const bool act2 = L2 == LC || l < L2, act3 = L3 == LC || l < L3;
     const int kp2 = act2 ? l / R2 : 0, nn = l % R2, kp3 = act3 ? l / R1 : 0, k1 = l % R1;
-    double2 *pA = buf + q * CS + n1;                         // + P0 k0
+    double2 *pA = buf + q * CS + n1;                         // + P0 k0 (+ NSTEP)
     double2 *pB = buf + w * CS + P0 * kp2 + nn;              // + R2 s (B), + P1 k1 (C)
     double2 *pC = buf + w * CS + P0 * kp3 + P1 * k1;         // + n'' (C of lane (k0, k1))
-    double2 *pP = buf + w * CS + l;                          // + 64 k2: the lane's own slots
-    double2 ld[3][R0], v[3][R2];                             // layout A points of a component; its final values (every stage has registers of
+    double2 *pP = buf + w * CS + l;                          // + LC k2: the lane's own slots
+    double2 ld[3][NBA][R0], v[3][R2];                        // layout A points of a component; its final values (every stage has registers of
                                                              // its own, defined in all lanes: what a stage leaves behind must not stay alive)
     const double2 zero = make_double2(0, 0);
     auto offset0 = [&]() __attribute__((always_inline)) {
@@ -1641,29 +1645,37 @@ k_xfft_scale_cols(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__r
     auto load = [&](int c) __attribute__((always_inline)) {
         const unsigned o = offset0();
 #pragma unroll
-        for (int r = 0; r < R0; ++r) {
-            ld[c][r] = make_double2(0, 0);
-            if (actA && q < kv) ld[c][r] = *reinterpret_cast<const double2 *>(comp[c] + (size_t)(o + (unsigned)(M1 * r) * xs16));
-        }
+        for (int u = 0; u < NBA; ++u)
+#pragma unroll
+            for (int r = 0; r < R0; ++r) {
+                ld[c][u][r] = make_double2(0, 0);
+                if (actA && q < kv) ld[c][u][r] = *reinterpret_cast<const double2 *>(comp[c] + (size_t)(o + (unsigned)(M1 * r + NSTEP * u) * xs16));
+            }
     };
     load(0); load(1); load(2);                               // every load of the block in flight at once
     if (tid < M1) twS[tid] = twiddle[R0 * tid];
     // ---- forward: stage 1 over r -> k0, times W_N^{n k0}
 #pragma unroll
-    for (int c = 0; c < 3; ++c) dft_small<R0, false>(ld[c]);
+    for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int k = 1; k < R0; ++k) {
-        const double2 t = twiddle[n1 * k];
+        for (int u = 0; u < NBA; ++u) dft_small<R0, false>(ld[c][u]);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) ld[c][k] = cmul(ld[c][k], t);
-    }
+    for (int u = 0; u < NBA; ++u)
+#pragma unroll
+        for (int k = 1; k < R0; ++k) {
+            const double2 t = twiddle[(n1 + NSTEP * u) * k];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ld[c][u][k] = cmul(ld[c][u][k], t);
+        }
     double2 b[3][R1];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         if (c) __syncthreads();                               // every wave has read the previous component
         if (actA) {
 #pragma unroll
-            for (int k = 0; k < R0; ++k) pA[P0 * k] = ld[c][k];
+            for (int u = 0; u < NBA; ++u)
+#pragma unroll
+                for (int k = 0; k < R0; ++k) pA[P0 * k + NSTEP * u] = ld[c][u][k];
         }
         __syncthreads();
 #pragma unroll
@@ -1693,22 +1705,22 @@ k_xfft_scale_cols(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__r
     // ---- the k-space operator on X[k0 + R0 k1 + R0 R1 k2]
     if (PARK) {                                               // the third component waits in the lane's own slots: room for the operator's temporaries
 #pragma unroll
-        for (int k2 = 0; k2 < R2; ++k2) pP[64 * k2] = v[2][k2];
+        for (int k2 = 0; k2 < R2; ++k2) pP[LC * k2] = v[2][k2];
     }
     if (w < kv && act3) {
 #pragma unroll
         for (int k2 = 0; k2 < R2; ++k2) {
-            const double2 f[3] = {v[0][k2], v[1][k2], PARK ? pP[64 * k2] : v[2][k2]};
+            const double2 f[3] = {v[0][k2], v[1][k2], PARK ? pP[LC * k2] : v[2][k2]};
             double2 out[3];
             scale_node(kp3 + R0 * k1 + R0 * R1 * k2, j, kz0 + w, f, G, box, a, out);
             v[0][k2] = out[0]; v[1][k2] = out[1];
-            if (PARK) pP[64 * k2] = out[2]; else v[2][k2] = out[2];
+            if (PARK) pP[LC * k2] = out[2]; else v[2][k2] = out[2];
             __builtin_amdgcn_sched_barrier(0);                // one node at a time
         }
     }
     if (PARK) {
 #pragma unroll
-        for (int k2 = 0; k2 < R2; ++k2) v[2][k2] = pP[64 * k2];
+        for (int k2 = 0; k2 < R2; ++k2) v[2][k2] = pP[LC * k2];
         __builtin_amdgcn_wave_barrier();
     }
     // ---- inverse: stage 3 backwards over k2 -> n'', times conj W_M1^{n'' k1}
@@ -1747,29 +1759,32 @@ k_xfft_scale_cols(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__r
             for (int s = 0; s < R1; ++s) pB[R2 * s] = bi[c][s];
         }
         __syncthreads();
-        double2 st[R0];
 #pragma unroll
-        for (int k = 0; k < R0; ++k) st[k] = actA ? pA[P0 * k] : zero;
-        dft_small<R0, true>(st);                              // stage 1 backwards over k0 -> r
-        if (actA && q < kv) {
-            const unsigned o = offset0();
+        for (int u = 0; u < NBA; ++u) {
+            double2 st[R0];
 #pragma unroll
-            for (int r = 0; r < R0; ++r) *reinterpret_cast<double2 *>(comp[c] + (size_t)(o + (unsigned)(M1 * r) * xs16)) = st[r];
+            for (int k = 0; k < R0; ++k) st[k] = actA ? pA[P0 * k + NSTEP * u] : zero;
+            dft_small<R0, true>(st);                          // stage 1 backwards over k0 -> r
+            if (actA && q < kv) {
+                const unsigned o = offset0();
+#pragma unroll
+                for (int r = 0; r < R0; ++r) *reinterpret_cast<double2 *>(comp[c] + (size_t)(o + (unsigned)(M1 * r + NSTEP * u) * xs16)) = st[r];
+            }
         }
     }
 }
 
-template <int N, int R0, int R1, int KB, int WPS, bool PARK, int P0, int P1, int CS>
+template <int N, int R0, int R1, int KB, int WPS, bool PARK, int P0, int P1, int CS, int CPW = 1>
 static void launch_xfft_cols(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s) {
     const size_t lds = (size_t)(KB * CS + N / R0) * sizeof(double2);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xfft_scale_cols<N, R0, R1, KB, WPS, PARK, P0, P1, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xfft_scale_cols<N, R0, R1, KB, WPS, PARK, P0, P1, CS, CPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int nkb = (G.Nzh + KB - 1) / KB;
     const int rows = a.transposed ? a.nyl : G.Ny;
-    hipLaunchKernelGGL((k_xfft_scale_cols<N, R0, R1, KB, WPS, PARK, P0, P1, CS>), dim3(rows * nkb), dim3(64 * KB), lds, s, X, Y, Z, G, box, a, tw);
+    hipLaunchKernelGGL((k_xfft_scale_cols<N, R0, R1, KB, WPS, PARK, P0, P1, CS, CPW>), dim3(rows * nkb), dim3(64 * KB / CPW), lds, s, X, Y, Z, G, box, a, tw);
 }
 
 template <int KB, int NTH, class PLAN = RtPlan>
@@ -2126,8 +2141,11 @@ void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, Sc
         case 128: launch_xfft_t<7, 8, 512>(X, Y, Z, G, box, a, tw, s); break;
         // 64-byte pieces (four kz): 3.87 TB/s at 256 x 512 x 512; 32-byte pieces (two kz, three workgroups per CU) 2.73; 128-byte pieces with
         // all three components in LDS (eight kz, one workgroup per CU) 2.71
-        case 256:   // (256 = 8 x 8 x 4 through k_xfft_scale_cols: 0.25 - 0.27 ms at 256^3, no better than this kernel's 0.25)
-            launch_xfft256<4, 256, 2>(X, Y, Z, G, box, a, tw, s);   // two radix-16 passes in registers
+        case 256:
+            // 256 = 4 x 8 x 8 with TWO columns per wave: eight kz columns = 128-byte pieces at four waves per workgroup; 256^3: 0.201 against
+            // 0.226 ms, with noise 0.214 against 0.243 (256 = 8 x 8 x 4 with one column per wave and 64-byte pieces only tied: 0.25 - 0.27)
+            if (a.xcols && cols32) launch_xfft_cols<256, 4, 8, 8, 3, true, 72, 9, 295, 2>(X, Y, Z, G, box, a, tw, s);
+            else launch_xfft256<4, 256, 2>(X, Y, Z, G, box, a, tw, s);   // two radix-16 passes in registers
             break;
         // 512: radix 16, 16, 2; two kz columns: three workgroups per CU (3.3 ms at 512^3; four columns, one workgroup: 3.8; radix 4/2 in LDS: 5.2)
         default:

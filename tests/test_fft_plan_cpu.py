@@ -12,7 +12,7 @@ import pytest
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "debug"))
 
-PLANS = [(512, 8, 8), (360, 10, 6), (256, 8, 8)]           # N, R0, R1 as instantiated (launch_xfft_scale, launch_yfft)
+PLANS = [(512, 8, 8), (360, 10, 6), (256, 8, 8), (256, 4, 8)]           # N, R0, R1 as instantiated (launch_xfft_scale, launch_yfft)
 
 
 def forward_stages(x, R0, R1):
@@ -104,20 +104,20 @@ def test_natural_order_handover_of_the_y_pass(N):
             assert n + n // 8 + (M1 + M1 // 8) * r == pos[n + M1 * r]
 
 
-# (N, R0, R1, KB, P0, P1, CS) of every instantiation
-PADDINGS = [(512, 8, 8, 4, 72, 9, 578), (360, 10, 6, 4, 54, 9, 538), (256, 8, 8, 8, 44, 5, 359)]
+# (N, R0, R1, KB, P0, P1, CS, columns per wave) of every instantiation (256 = 8 x 8 x 4: the y pass)
+PADDINGS = [(512, 8, 8, 4, 72, 9, 578, 1), (360, 10, 6, 4, 54, 9, 538, 1), (256, 8, 8, 8, 44, 5, 359, 1), (256, 4, 8, 8, 72, 9, 295, 2)]
 
 
-@pytest.mark.parametrize("N,R0,R1,KB,P0,P1,CS", PADDINGS)
-def test_lds_paddings_are_conflict_free_in_the_bank_model(N, R0, R1, KB, P0, P1, CS):
+@pytest.mark.parametrize("N,R0,R1,KB,P0,P1,CS,CPW", PADDINGS)
+def test_lds_paddings_are_conflict_free_in_the_bank_model(N, R0, R1, KB, P0, P1, CS, CPW):
     import lds_banks_xcols as banks
     M1 = N // R0
     R2 = M1 // R1
     # positions of a column stay inside it and do not collide
     b = {P0 * k0 + n for k0 in range(R0) for n in range(M1)}
     c = {P0 * k0 + P1 * k1 + n for k0 in range(R0) for k1 in range(R1) for n in range(R2)}
-    assert len(b) == R0 * M1 and len(c) == N and max(b | c) < CS and 64 * R2 <= CS
-    w = banks.evaluate(N, R0, R1, KB, P0, P1, CS)
+    assert len(b) == R0 * M1 and len(c) == N and max(b | c) < CS and (64 // CPW) * R2 <= CS
+    w = banks.evaluate(N, R0, R1, KB, P0, P1, CS, CPW)
     for name, cost in w.items():
         # every access one LDS pass per lane group, but the layout A read of the inverse (two) and, at R2 = 4, the read of the
         # inner exchange (two: four-point rows are 64 bytes)

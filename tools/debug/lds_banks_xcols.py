@@ -3,7 +3,7 @@
 ds_write_b128 = 8 x 8 contiguous lanes over 32 banks, ds_read_b128 = 4 x 16 lanes over 64 banks.  Searches the paddings
 (P0: stride of B[k0][.], P1: stride of C[k0][k1][.], CS: column stride).
 
-  python3 tools/debug/lds_banks_xcols.py N R0 R1 KB      e.g. 512 8 8 4 / 360 10 6 4 / 256 8 8 4
+  python3 tools/debug/lds_banks_xcols.py N R0 R1 KB [CPW]     e.g. 512 8 8 4 / 360 10 6 4 / 256 8 8 4 / 256 4 8 8 2
 """
 import sys
 
@@ -25,44 +25,53 @@ def cost(addrs, write):
     return cyc / len(groups)
 
 
-def evaluate(N, R0, R1, KB, P0, P1, CS):
+def evaluate(N, R0, R1, KB, P0, P1, CS, CPW=1):
+    """CPW: columns per wave in layout B (lanes [0, 64 / CPW) the first column of the wave, ...); the workgroup has 64 KB / CPW threads
+    and a thread of layout A as many butterflies as it takes to cover KB columns"""
     M1 = N // R0
     R2 = M1 // R1
+    LC = 64 // CPW
+    nth = 64 * KB // CPW
     worst = {}
     def note(name, c):
         worst[name] = max(worst.get(name, 0), c)
-    for wave in range(KB):
-        for k0 in range(R0):
-            a = []
-            for l in range(64):
-                tid = 64 * wave + l
-                q, n1 = tid % KB, tid // KB
-                a.append(q * CS + P0 * k0 + n1 if n1 < M1 else None)
-            if any(x is not None for x in a):
-                note("E1 write (A)", cost(a, True)); note("E1' read (A)", cost(a, False))
-    for w in (0, 1, KB - 1):
+    for wave in range(nth // 64):
+        for b in range((KB * M1 + nth - 1) // nth):
+            for k0 in range(R0):
+                a = []
+                for l in range(64):
+                    idx = 64 * wave + l + b * nth
+                    q, n1 = idx % KB, idx // KB
+                    a.append(q * CS + P0 * k0 + n1 if n1 < M1 else None)
+                if any(x is not None for x in a):
+                    note("E1 write (A)", cost(a, True)); note("E1' read (A)", cost(a, False))
+    col = lambda w, l: w * CPW + l // LC        # noqa: E731
+    for w in (0, 1, nth // 64 - 1):
         for s in range(R1):
-            a = [w * CS + P0 * (l // R2) + R2 * s + l % R2 if l < R0 * R2 else None for l in range(64)]
+            a = [col(w, l) * CS + P0 * ((l % LC) // R2) + R2 * s + (l % LC) % R2 if l % LC < R0 * R2 else None for l in range(64)]
             note("E1 read (B)", cost(a, False)); note("E1' write (B)", cost(a, True))
-            a = [w * CS + P0 * (l // R2) + P1 * s + l % R2 if l < R0 * R2 else None for l in range(64)]
+            a = [col(w, l) * CS + P0 * ((l % LC) // R2) + P1 * s + (l % LC) % R2 if l % LC < R0 * R2 else None for l in range(64)]
             note("E2 write", cost(a, True)); note("E2' read", cost(a, False))
         for n in range(R2):
-            a = [w * CS + P0 * (l // R1) + P1 * (l % R1) + n if l < R0 * R1 else None for l in range(64)]
+            a = [col(w, l) * CS + P0 * ((l % LC) // R1) + P1 * ((l % LC) % R1) + n if l % LC < R0 * R1 else None for l in range(64)]
             note("E2 read", cost(a, False)); note("E2' write", cost(a, True))
+            a = [col(w, l) * CS + (l % LC) + LC * n for l in range(64)]
+            note("park", max(cost(a, True), cost(a, False)))
     return worst
 
 
 def main():
     N, R0, R1, KB = (int(v) for v in sys.argv[1:5])
+    CPW = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     M1 = N // R0
     R2 = M1 // R1
     best = None
     for P1 in range(R2, R2 + 4):
         for P0 in range(max(M1, P1 * R1), max(M1, P1 * R1) + 12):
             need = P0 * (R0 - 1) + max(M1, P1 * (R1 - 1) + R2)
-            need = max(need, 64 * R2)          # the lane's own slots l + 64 k2
+            need = max(need, (64 // CPW) * R2)          # the lane's own slots ll + LC k2
             for CS in range(need, need + 20):
-                w = evaluate(N, R0, R1, KB, P0, P1, CS)
+                w = evaluate(N, R0, R1, KB, P0, P1, CS, CPW)
                 # weights: a write costs 13 cycles conflict-free, a read 4
                 tot = sum(v * (13 if "write" in k else 4) for k, v in w.items()) + 0.01 * CS
                 if best is None or tot < best[0]:

@@ -72,6 +72,9 @@ typedef struct pse_info {
     double t_records;                 /* binning + the 64-byte far-field particle records (t_spread is the spread kernel alone) */
     int lanczos_exchanges;            /* team calls: exchanges the last Brownian call's Lanczos iteration issued (two iterations
                                          per exchange where the decomposition allows: ceil(m / 2) instead of m) */
+    int lanczos_status;               /* queue-only Brownian calls (pse_set_async): 0 the step norm passed, 1 the queued iterations ran
+                                         out first (the result uses the last size checked: raise the starting count), 2 a
+                                         non-finite coefficient or a failed eigen-solve */
 } pse_info;
 
 /* -- life cycle: replaces Stokes::Stokes/setParams/~Stokes (PSEv1/Stokes.cc:85-118,129-424) ------------- */
@@ -95,11 +98,22 @@ int pse_set_stream(pse_handle *h, void *hip_stream);
  * is still valid is then decided ON THE DEVICE: a call gathers the particles into the order of the last build, checks every
  * displacement against r_buff / 2, and queues BOTH chains -- sort + cell walk + new list, and the kept-list pass -- whose kernels
  * read the outcome and leave at once if it is not theirs (never a stale list, no round trip; about eight empty launches per
- * call are the price).  Brownian calls rebuild every time in this mode and still read the Lanczos scalars back once per
- * convergence check (the tridiagonal square root is a host computation, as in the reference: PSEv1/Brownian.cu:540-582) and
- * cannot be captured; per-phase timing (pse_set_timing) synchronises by definition.  One warm-up call outside the capture first
- * (kernels set their shared-memory attributes on first use). */
+ * call are the price).  Brownian calls (pse_brownian_velocity, pse_step, pse_sqrt_mreal) rebuild the list every time in this mode
+ * and take the Lanczos decision ON THE DEVICE too: the iterations of the starting count *lanczos_m are queued, one workgroup
+ * computes the tridiagonal square roots and the step norm the reference computes on the host (LAPACKE_spteqr and the loops at
+ * PSEv1/Brownian.cu:540-582, 673-724), PSE_LANCZOS_EXTRA (default 2) further iterations follow, each with its own decision
+ * and gated on the outcome so far, and the final combination reads m and its coefficients from device memory.  Such a call can be
+ * captured and replayed like the deterministic ones; on return *lanczos_m is the m of the most recent call whose outcome has
+ * already reached the host (feed it to the next call), pse_get_info after a stream synchronisation gives the m, the step norm
+ * and pse_info.lanczos_status of the last completed call (1: the queue ran out before the step norm passed).  Starting counts
+ * above 96 - PSE_LANCZOS_EXTRA take the host-checked path.  Per-phase timing (pse_set_timing) synchronises by definition and
+ * takes the host-checked path as well.  One warm-up call outside the capture first (kernels set their shared-memory attributes
+ * on first use). */
 int pse_set_async(pse_handle *h, int enabled);
+/* The random numbers of a Brownian call are keyed by (particle or grid node, timestep): a captured call would replay the timestep
+ * it was captured with.  With a device word registered here every Brownian call draws its noise at timestep + *device_word,
+ * read on the device when the kernels run -- the caller advances the word between replays.  NULL (default): timestep alone. */
+int pse_set_timestep_offset(pse_handle *h, const unsigned int *device_word);
 /* test hook: the device-side decision of the most recent deterministic evaluation in asynchronous mode (synchronises):
  * 0 the kept list was reused, != 0 it was rebuilt, -1 the call did not take the two-chain path */
 int pse_debug_last_gate(pse_handle *h, int *gate);

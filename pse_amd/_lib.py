@@ -45,6 +45,7 @@ class pse_info(ctypes.Structure):
         ("t_matvec", ctypes.c_double),
         ("t_records", ctypes.c_double),
         ("lanczos_exchanges", ctypes.c_int),
+        ("lanczos_status", ctypes.c_int),
     ]
 
     def as_dict(self):
@@ -75,6 +76,7 @@ SYMBOLS = {
     "pse_set_stream": (_i, [_vp, _vp]),
     "pse_set_timing": (_i, [_vp, _i]),
     "pse_set_async": (_i, [_vp, _i]),
+    "pse_set_timestep_offset": (_i, [_vp, _vp]),
     "pse_debug_last_gate": (_i, [_vp, _ip]),
     "pse_set_neighbor_skin": (_i, [_vp, _d]),
     "pse_neighbor_stats": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]),

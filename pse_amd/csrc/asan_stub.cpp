@@ -72,6 +72,7 @@ int pse_pair_repulsion(pse_handle *h, const pse_double4 *, pse_double4 *, const 
 int pse_set_stream(pse_handle *, void *) { return no_device("pse_set_stream"); }
 int pse_set_timing(pse_handle *, int) { return no_device("pse_set_timing"); }
 int pse_set_async(pse_handle *, int) { return no_device("pse_set_async"); }
+int pse_set_timestep_offset(pse_handle *, const unsigned int *) { return no_device("pse_set_timestep_offset"); }
 int pse_debug_last_gate(pse_handle *, int *) { return no_device("pse_debug_last_gate"); }
 int pse_set_neighbor_skin(pse_handle *, double) { return no_device("pse_set_neighbor_skin"); }
 int pse_neighbor_stats(pse_handle *, double *, unsigned long long *, unsigned long long *) { return no_device("pse_neighbor_stats"); }

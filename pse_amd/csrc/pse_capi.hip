@@ -86,6 +86,7 @@ struct pse_handle {
         bool verbose = false;     // PSE_VERBOSE
         bool team_sstep = true;      // PSE_TEAM_SSTEP=0: teams run one Lanczos iteration per exchange (default: two, see lanczos_team)
         int team_sched[3] = {1, 2, 3};   // PSE_TEAM_SCHED=a,b,c: far-field exchange k of a team step is issued before Lanczos exchange sched[k]
+        int lz_extra = 2;            // PSE_LANCZOS_EXTRA: iterations a queue-only Brownian call queues beyond the starting count (gated on the device-side decision)
     } tun;
     DCells bidx_nc = {0, 0, 0};      // cell grid the boundary-cell indices on the device belong to
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -170,6 +171,9 @@ struct pse_handle {
     double *sc_host_dev = nullptr;   // its device address
     int *bounds_host_dev = nullptr;  // device address of bounds_host (mapped pinned): k_pick writes the row boundaries straight to the host
     int npart_cap = 0;
+    LzState *lz_state = nullptr;     // the device-side Lanczos decision of queue-only Brownian calls (pse_set_async)
+    unsigned long long lz_seq = 0;   // calls that queued one (the decision kernel stamps the host mirror with it)
+    const uint32_t *ts_off = nullptr;   // pse_set_timestep_offset: the noise of a Brownian call is drawn at timestep + *ts_off
     // bookkeeping
     pse_info info;
     bool timing = false;
@@ -299,7 +303,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
     void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cnt_block, h->sw.rec_t, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->nb.data, h->nb.cnt, h->vl.idx, h->vl.cnt, h->pos_build, h->pos_s, h->posf_s, h->pv,
                     h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->w2_s, h->u_s, h->pv2, h->sums_all, h->twiddle, h->twiddle_y_owned, h->fft_work, h->V,
-                    h->scal, h->partials};
+                    h->scal, h->partials, h->lz_state};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &p : h->ph) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -444,6 +448,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         t.gather_bz = ienv("PSE_GATHER_BZ", 0); t.xmix_runtime = ienv("PSE_XMIX", 0) == 1; t.xfft_small_wide = ienv("PSE_XFFT_SMALL_KB", 2) == 8; t.xcols = ienv("PSE_XCOLS", 1);
         t.verbose = ienv("PSE_VERBOSE", 0) > 0;
         t.team_sstep = ienv("PSE_TEAM_SSTEP", 1) > 0;
+        t.lz_extra = std::max(0, std::min(32, ienv("PSE_LANCZOS_EXTRA", 2)));
         if (const char *v = getenv("PSE_TEAM_SCHED")) {
             int a = 1, b = 2, c = 3;
             if (sscanf(v, "%d,%d,%d", &a, &b, &c) == 3) { t.team_sched[0] = a; t.team_sched[1] = b; t.team_sched[2] = c; }
@@ -608,6 +613,8 @@ static int create_impl(const pse_params *p, pse_handle *h) {
 
     TRY(dmalloc(h, &h->V, (size_t)(M_MAX + 1) * n));
     TRY(dmalloc(h, &h->scal, (size_t)LZ_NSCAL));
+    TRY(dmalloc(h, &h->lz_state, 1));
+    HIPCHK(hipMemset(h->lz_state, 0, sizeof(LzState)));
     HIPCHK(hipHostMalloc((void **)&h->sc_host, LZ_NSCAL * sizeof(double), hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void **)&h->sc_host_dev, h->sc_host, 0));
     memset(h->sc_host, 0, LZ_NSCAL * sizeof(double));
@@ -707,6 +714,11 @@ extern "C" int pse_set_async(pse_handle *h, int enabled) {
     h->vl_valid = false;
     return 0;
 }
+extern "C" int pse_set_timestep_offset(pse_handle *h, const unsigned int *device_word) {
+    if (!h) return fail(PSE_ERR_INVALID, "null handle");
+    h->ts_off = device_word;
+    return 0;
+}
 extern "C" int pse_debug_last_gate(pse_handle *h, int *gate) {
     if (!h || !gate) return fail(PSE_ERR_INVALID, "null argument");
     HIPCHK(hipSetDevice(h->device));
@@ -722,6 +734,13 @@ extern "C" int pse_set_timing(pse_handle *h, int enabled) {
 }
 extern "C" int pse_get_info(pse_handle *h, pse_info *info) {
     if (!h || !info) return fail(PSE_ERR_INVALID, "null argument");
+    if (h->async_mode && h->lz_seq > 0 && h->sc_host && h->sc_host[LZ_HOST_SEQ] > 0.0) {
+        // queue-only Brownian calls: what the device-side decision of the most recent COMPLETED call left in the host mirror (the
+        // caller synchronises its stream first if it wants the call it has just queued)
+        h->info.lanczos_m = (int)h->sc_host[LZ_HOST_M];
+        h->info.lanczos_stepnorm = h->sc_host[LZ_HOST_STEPNORM];
+        h->info.lanczos_status = (int)h->sc_host[LZ_HOST_STATUS];
+    }
     *info = h->info;
     return 0;
 }
@@ -1128,7 +1147,7 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
     if (h->skin > 0.0 && !h->async_mode && h->vl_valid && !need_cells && h->vl_N == N && h->vl_group == group && same_box && h->sorted_N == N) {
         HIPCHK(hipMemsetAsync(h->cnt_block, 0, h->cnt_bins * sizeof(int), h->stream));   // bin counts + flags[0] ([1] is the build's overflow mark)
         launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream,
-                       h->pos_build, 0.25 * h->skin * h->skin, h->vl.flags, CellRanges{}, nullptr, nullptr, &far, psi_out, h->par.seed, px.timestep);
+                       h->pos_build, 0.25 * h->skin * h->skin, h->vl.flags, CellRanges{}, nullptr, nullptr, &far, psi_out, h->par.seed, px.timestep, Gate{}, h->ts_off);
         HIPCHK(hipMemcpyAsync(h->flags_host, h->vl.flags, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->flags_host[0] == 0 && h->flags_host[1] == 0) {
@@ -1182,7 +1201,7 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
     HIPCHK(cell_sort(pos, group, N, h->dbox, h->nc, h->keys, h->vals, h->keys_s, h->cell_cnt, ncell, h->sort_tmp, h->sort_tmp_bytes,
                      h->cell_off, h->perm, h->stream, need, sb, true));
     launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream, nullptr, 0.0, nullptr,
-                   need, h->cell_off, team_sstep(h) ? h->pv2 : nullptr, &far, psi_out, h->par.seed, px.timestep);
+                   need, h->cell_off, team_sstep(h) ? h->pv2 : nullptr, &far, psi_out, h->par.seed, px.timestep, Gate{}, h->ts_off);
     h->sorted_N = N;
     if (with_list) {   // the first cell pass of this call writes the list (real())
         h->vl_pending = true; h->vl_N = N; h->vl_group = group;
@@ -1201,7 +1220,7 @@ static ScaleArgs scale_args(pse_handle *h, bool noise, double kT, double dt, uns
     const DGrid &G = h->G;
     a.xi = h->d.xi; a.eta = h->d.eta; a.noise = noise ? 1 : 0;
     a.noise_fac = noise ? std::sqrt(2.0 * kT / dt / (G.hx * G.hy * G.hz)) : 0.0;   // PSEv1/Brownian.cu:197
-    a.seed = h->par.seed; a.timestep = timestep;
+    a.seed = h->par.seed; a.timestep = timestep; a.ts_off = h->ts_off;
     a.transposed = h->grid_slabs > 1 ? 1 : 0; a.y0 = h->y0; a.nyl = h->grid_slabs > 1 ? h->nyl : G.Ny;
     a.runtime_plan = h->tun.xmix_runtime; a.wide_small = h->tun.xfft_small_wide; a.xcols = h->tun.xcols;
     return a;
@@ -1404,6 +1423,76 @@ static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*ou
 // rows a rank updates in a Lanczos iteration: its own and the ghost layers its next mat-vec reads
 static int update_ranges(const pse_handle *h, int N, int rg[3][2]) { return row_ranges(h, N, 1, rg); }
 
+// Queue-only Lanczos of a single GPU (pse_set_async): the iterations of the starting count are queued as the host-driven loop
+// below queues them; then ONE launch takes the decision the host would take (k_lz_decide: the tridiagonal square roots of the two
+// sizes m_in - 1 and m_in, the step norm), and `extra` more iterations follow, each with its own decision, every kernel of them
+// gated on the outcome so far -- the reference iterates until the step norm passes (PSEv1/Brownian.cu:606-724); here whatever is
+// not needed leaves at once.  The final combination takes m and its coefficients from the device.  Nothing is read back: the
+// call can be captured into a hipGraph; m of a call reaches the host lazily (pse_get_info after a synchronisation, or the
+// lanczos_m of the next call).  If the queue runs out before the step norm passes, the result uses the last size and
+// pse_info.lanczos_status says 1.
+static int lanczos_queued(pse_team &T, int N, double tol, double scale, int *m_io, const std::function<int()> &before_first_wait,
+                          const std::function<int()> &before_combine) {
+    pse_handle *h = T.m[0];
+    const size_t stride = h->n_pad;
+    const int m_in = std::min(std::max(m_io ? *m_io : 2, 1), M_MAX);
+    const int target = std::max(m_in, 2);
+    const int extra = std::max(0, std::min(h->tun.lz_extra, M_MAX - target));
+    const int *stop = &h->lz_state->done;
+    const double seq = (double)++h->lz_seq;
+    int rg[3][2];
+    const int nrg_all = update_ranges(h, N, rg);
+    auto vec = [&](int q) -> const double4 * { return q == 0 ? h->psi_s : h->V + (size_t)q * stride; };
+    // the vector part of iteration j: x_{j+1} from the sums that are still in place
+    auto vector_part = [&](int j, const int *gate) {
+        launch_lz_update(vec(j), h->w_s, j > 0 ? vec(j - 1) : nullptr, h->V + (size_t)(j + 1) * stride, j, h->scal, rg, nrg_all, h->stream, h->pv,
+                         nullptr, 0, h->sc_host_dev, gate);
+        h->pv_is_f = false;
+    };
+    auto iteration = [&](int j, bool scalars_only, const int *gate) -> int {
+        const bool have_y = j == 0 && h->w_is_mpsi;
+        const bool fused = !have_y && h->nb.cap > 0 && h->nb_valid;
+        if (!fused && !have_y) {
+            if (gate) return fail(PSE_ERR_NUMERIC, "queued Lanczos: a gated iteration needs the pair list");
+            TRY(real(T, j == 0 ? &pse_handle::psi_s : &pse_handle::V, &pse_handle::w_s, (size_t)j * stride, 0, N, true));
+        }
+        const double4 *vjm1 = j > 0 ? vec(j - 1) : nullptr;
+        if (fused)
+            launch_mreal_lanczos(h->pos_s, vec(j), h->w_s, row_map(0, N), h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, h->nb,
+                                 LzFuse{vjm1, h->partials, h->npart_cap, nullptr, nullptr, nullptr}, h->scal, nullptr, nullptr, h->stream,
+                                 j > 0 ? h->pv : nullptr, h->vl_use ? h->vl : VerletList{}, 1, nullptr, gate);
+        else if (!(j == 0 && h->sums0_done))
+            launch_lz_dots(vec(j), h->w_s, vjm1, 0, N, h->partials, h->npart_cap, h->scal, h->stream);
+        h->w_is_mpsi = false; h->sums0_done = false;
+        if (scalars_only) launch_lz_update(vec(j), h->w_s, vjm1, h->V + (size_t)(j + 1) * stride, j, h->scal, rg, 0, h->stream, h->pv, nullptr, 0,
+                                           h->sc_host_dev, gate);
+        else vector_part(j, gate);
+        return 0;
+    };
+    for (int j = 0; j < target; ++j) TRY(iteration(j, j == target - 1, nullptr));
+    LzDecide d{};
+    d.m_lo = std::max(m_in - 1, 1); d.m_hi = target; d.done_iters = target; d.first = 1; d.last = extra == 0 ? 1 : 0; d.m_max = M_MAX; d.tol = tol;
+    launch_lz_decide(d, h->scal, h->lz_state, h->sc_host_dev, seq, h->stream);
+    int done = target;
+    for (int x = 0; x < extra; ++x) {
+        vector_part(done - 1, stop);
+        TRY(iteration(done, true, stop));
+        d.m_lo = d.m_hi = done + 1; d.done_iters = done + 1; d.pending_beta = done; d.first = 0; d.last = x == extra - 1 ? 1 : 0;
+        launch_lz_decide(d, h->scal, h->lz_state, h->sc_host_dev, seq, h->stream);
+        ++done;
+    }
+    TRY(te(h, PH_LANCZOS));
+    if (before_first_wait) TRY(before_first_wait());
+    if (before_combine) TRY(before_combine());
+    launch_basis_combine(h->psi_s, h->V, stride, BasisCoef{}, 0, h->scal, scale, 1, h->ub_s, 0, N, h->stream, h->sink, h->lz_state);
+    h->tail_done = h->sink.on;
+    h->info.lanczos_matvecs = done; h->info.lanczos_exchanges = 0;
+    // m of this call is known on the device only; what the host hands back is the most recent one that has reached it
+    if (m_io) *m_io = h->sc_host[LZ_HOST_SEQ] > 0.0 && h->sc_host[LZ_HOST_M] >= 1.0 ? (int)h->sc_host[LZ_HOST_M] : m_in;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // M_real^{1/2} psi by Lanczos (PSEv1/Brownian.cu:357-765): psi_s (sorted order, replicated on every rank) ->
 // ub_s = scale |psi| V t on the rows this rank owns.  Scalars are replicated; vectors are valid on the own rows (+ the
 // neighbouring cell layers for the vector the next mat-vec reads).
@@ -1411,6 +1500,9 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
                    WavePump *pump = nullptr, const std::function<int()> &before_combine = nullptr) {
     int n_exchanges = 0;
     pse_handle *h0 = T.m[0];
+    if (h0->async_mode && T.G == 1 && T.solo < 0 && h0->nb.cap > 0 && !h0->timing &&
+        lz_decide_supported(std::min(M_MAX, std::max(std::min(std::max(m_io ? *m_io : 2, 1), M_MAX), 2) + h0->tun.lz_extra)))
+        return lanczos_queued(T, N, tol, scale, m_io, before_first_wait, before_combine);
     const size_t stride = h0->n_pad;
     int m_in = m_io ? *m_io : 2;
     if (m_in < 1) m_in = 1;

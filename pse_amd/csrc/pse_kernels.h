@@ -82,7 +82,7 @@ void launch_permute(const double4 *pos, const double4 *vec, const unsigned *grou
                     double2 *pv2 = nullptr,                                           // second set of packed records (position half)
                     const struct FarBinArgs *far = nullptr,                           // rank the particles in their far-field bins
                     double4 *psi_s = nullptr, uint32_t seed = 0, uint32_t timestep = 0,    // draw the particle noise of this step (K14)
-                    Gate gate = Gate{});
+                    Gate gate = Gate{}, const uint32_t *ts_off = nullptr);             // ts_off (nullable): ... at timestep + *ts_off
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s);
 
 // ---- near field (K9) -------------------------------------------------------------------------------------
@@ -140,7 +140,8 @@ void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w
                           const double2 *pv = nullptr,    // packed (position, vector) records holding vec_s, or null
                           VerletList vl = VerletList{},   // in use this step: rows that overflowed the pair list walk it instead of the cells
                           int sums = 1,                   // 0 none, 1 one-step Lanczos sums, 2 Gram sums of a two-step block, 3 single step of that driver
-                          double2 *pv_out = nullptr);     // the result also goes into the vector half of these records
+                          double2 *pv_out = nullptr,      // the result also goes into the vector half of these records
+                          const int *stop = nullptr);     // nullable: leave at once if *stop != 0 (the device-side Lanczos decision)
 int mreal_partials_needed(int rows);
 void launch_lz_reduce3(const double *partials, int npart, int cap, double *scal, hipStream_t s);
 
@@ -184,6 +185,7 @@ struct ScaleArgs {
     int noise;               // add k-space Brownian noise (K6)
     double noise_fac;        // sqrt(2 kT / (dt h^3))
     uint32_t seed, timestep;
+    const uint32_t *ts_off;  // nullable: the noise is drawn at timestep + *ts_off, read on the device (pse_set_timestep_offset)
     int transposed;          // layout [Nx][ny_local][Nzh] (slab mode, after the transpose) instead of [nx_local][Ny][Nzh]
     int y0, nyl;             // slab of y rows in transposed layout
     int runtime_plan;        // PSE_XMIX=1: the runtime radix plan also where a compile-time one exists (A/B)
@@ -229,7 +231,8 @@ struct BasisCoef { double t[104]; };   // the m <= 100 coefficients of the final
 // rows[i] = (sum, tag) (a team's all-gathered array)
 struct CombineSink { bool on; const double4 *add_a, *add_b; const unsigned *tag_s; double4 *vel; double4 *rows; };
 void launch_basis_combine(const double4 *x0, const double4 *V, size_t stride, const BasisCoef &t, int m, const double *scal,
-                          double scale, int use_norm, double4 *out_s, int lo, int hi, hipStream_t s, CombineSink sink = CombineSink{});
+                          double scale, int use_norm, double4 *out_s, int lo, int hi, hipStream_t s, CombineSink sink = CombineSink{},
+                          const struct LzState *st = nullptr);   // st: m and the coefficients come from the device-side decision
 // Lanczos iteration on the own rows [lo, hi) (see k_lz_update in pse_kernels.hip).  dots: sums of x.x, x.y, x.vprev ->
 // scal[LZ_TMP..+2] (y = null: x.x only), for mat-vecs that did not fuse them; [all-reduce by the caller when sharded];
 // update: alpha_j, beta_j -> scal, x_{j+1} -> xnext
@@ -249,7 +252,36 @@ void launch_lz_block(const LzBlockArgs &a, bool full, double *scal, const int (*
                      const double *sums_all = nullptr, int nranks = 0, double *sch = nullptr);
 void launch_lz_update(const double4 *xin, const double4 *y, const double4 *xprev, double4 *xnext, int j,
                       double *scal, const int (*row_ranges)[2], int n_ranges, hipStream_t s, double2 *pv = nullptr,   // up to three disjoint row ranges in one launch; pv: also refresh the packed records
-                      const double *sums_all = nullptr, int nranks = 0, double *sch = nullptr);
+                      const double *sums_all = nullptr, int nranks = 0, double *sch = nullptr, const int *stop = nullptr);
+// ---- the convergence decision of the Lanczos iteration ON THE DEVICE (queue-only Brownian calls: pse_set_async) ----------------
+// Replaces, for calls that may not wait for the host, what the host driver does between batches of iterations (the reference's
+// LAPACKE_spteqr + host loops, PSEv1/Brownian.cu:540-582, and its step-norm test, PSEv1/Brownian.cu:673-724): one workgroup solves
+// the tridiagonal eigenproblems of the sizes to be checked (one wavefront each, implicit QL as tridiag_eigen in pse_params.cpp),
+// walks m upward exactly as the host does and, once the step norm is below the tolerance, closes the gate `done` that every later
+// kernel of the iteration reads, and leaves the coefficients of the final combination for k_basis_combine.
+struct LzState {
+    int done;            // the iteration has ended: m_final and coef are valid; later iteration kernels leave at once
+    int m_final;
+    int checked;         // t_prev holds T^{1/2} e_1 of this size (0: nothing yet)
+    int status;          // 0 converged, 1 the queued iterations ran out first (result from the last size checked), 2 non-finite coefficient / eigen-solve failure
+    double stepnorm;
+    double t_prev[104];
+    double coef[104];    // coefficients of the basis vectors in the final combination (t divided by the norms the basis carries)
+};
+struct LzDecide {
+    int m_lo, m_hi;      // sizes to check, at most two (m_lo = m_hi - 1 or m_hi)
+    int done_iters;      // iterations whose alpha exists; one-step driver: beta[done_iters] does not exist yet
+    int have_last_beta;  // 1: beta[done_iters] exists as well (two-step driver of a team)
+    int pending_beta;    // > 0: first test beta[pending_beta] for breakdown (it arrived with this batch)
+    int first;           // first decision of a call: reset the state
+    int last;            // last queued decision: if still open, end the iteration at the last size checked (status 1)
+    int normalised;      // the basis holds normalised v_q for q >= 1 (two-step driver); else unnormalised x_q (divide by beta_q)
+    int m_max;
+    double tol;
+};
+constexpr int LZ_HOST_M = 380, LZ_HOST_STEPNORM = 381, LZ_HOST_STATUS = 382, LZ_HOST_SEQ = 383;   // slots of the host mirror (sch) the decision writes
+void launch_lz_decide(const LzDecide &d, double *scal, LzState *st, double *sch, double seq, hipStream_t s);
+bool lz_decide_supported(int m_hi);   // the eigenvectors of both sizes fit the LDS of one workgroup
 // tag_s (nullable): out[i].w = the particle's index in the caller's arrays, so the rows can be scattered by ranks that did not sort them
 void launch_sum_rows(const double4 *a, const double4 *b, const double4 *c, double4 *out, int lo, int hi, hipStream_t s,
                      const unsigned *tag_s = nullptr);

@@ -136,8 +136,10 @@ k_permute(const double4 *__restrict__ pos, const double4 *__restrict__ vec,
                           double4 *__restrict__ pos_s, float4 *__restrict__ posf_s, double2 *__restrict__ pv,
                           double4 *__restrict__ vec_s, unsigned *__restrict__ tag_s, const double4 *__restrict__ pos_build,
                           double half_skin2, int *__restrict__ flags, CellRanges need, const int *__restrict__ cell_off,
-                          double2 *__restrict__ pv2, FarBinArgs far, double4 *__restrict__ psi_s, uint32_t seed, uint32_t timestep, Gate gate) {
+                          double2 *__restrict__ pv2, FarBinArgs far, double4 *__restrict__ psi_s, uint32_t seed, uint32_t timestep, Gate gate,
+                          const uint32_t *__restrict__ ts_off) {
     if (gate.closed()) return;
+    if (ts_off) timestep += *ts_off;
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s - (int)(threadIdx.x & 63) >= N) return;            // whole wave past the end
     const bool live = s < N && need.row(s, cell_off);        // a slab rank holds particle data for its own and its ghost rows only
@@ -218,9 +220,9 @@ __global__ void k_permute_vec(const double4 *__restrict__ vec, const unsigned *_
 void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm, int N, DBox box,
                     double4 *pos_s, float4 *posf_s, double2 *pv, double4 *vec_s, unsigned *tag_s, hipStream_t s,
                     const double4 *pos_build, double half_skin2, int *flags, CellRanges need, const int *cell_off, double2 *pv2,
-                    const FarBinArgs *far, double4 *psi_s, uint32_t seed, uint32_t timestep, Gate gate) {
+                    const FarBinArgs *far, double4 *psi_s, uint32_t seed, uint32_t timestep, Gate gate, const uint32_t *ts_off) {
     hipLaunchKernelGGL(k_permute, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, vec, group, perm, N, box, pos_s, posf_s, pv, vec_s, tag_s,
-                       pos_build, half_skin2, flags, need, cell_off, pv2, far ? *far : FarBinArgs{}, psi_s, seed, timestep, gate);
+                       pos_build, half_skin2, flags, need, cell_off, pv2, far ? *far : FarBinArgs{}, psi_s, seed, timestep, gate, ts_off);
 }
 __global__ void k_gate_decide(int *__restrict__ flags, int *__restrict__ word) {
     const int f = flags[0] | flags[1];
@@ -590,7 +592,8 @@ __global__ void __launch_bounds__(NT)
 k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, RowMap rm,
              DBox box, int shift_only, double self, NbList nb, LzFuse lz, const double2 *__restrict__ pv,
              const int *__restrict__ cell_off, DCells nc, double rcut2, const double *__restrict__ coef, VerletList vl,
-             double2 *__restrict__ pv_out) {
+             double2 *__restrict__ pv_out, const int *__restrict__ stop) {
+    if (stop && *stop) return;   // the Lanczos iteration has ended (device-side decision)
     __shared__ double shift[27 * 3];
     __shared__ double sh[4];
     if (threadIdx.x < 27) {
@@ -769,7 +772,7 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
     }
 }
 
-__global__ void __launch_bounds__(1024) k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, double *__restrict__ scal);
+__global__ void __launch_bounds__(1024) k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, double *__restrict__ scal, const int *__restrict__ stop = nullptr);
 static size_t mreal_lds_bytes(int ncoef) { return (size_t)(ncoef / (2 * RS_NCOEF)) * (2 * RS_NCOEF + 1) * sizeof(double); }   // padded copy
 bool mreal_table_in_lds(int ncoef) { return mreal_lds_bytes(ncoef) <= 14 * 1024; }   // with the 44 KB queue: three workgroups per CU up to 9 KB of table, two beyond
 
@@ -785,7 +788,7 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
     if (mode == MREAL_USE_LIST) {
         hipLaunchKernelGGL((k_mreal_list<0, 4, TPB, false>), g, b, 0, s, pos_s, vec_s, out_s, rm, box,
                            (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1), self, nb, LzFuse{}, nullptr, cell_off, nc, rcut * rcut, coef,
-                           vl_mode == VL_USE ? vl : VerletList{}, nullptr);
+                           vl_mode == VL_USE ? vl : VerletList{}, nullptr, nullptr);
         return;
     }
     const bool list = mode == MREAL_BUILD_LIST, two = list && vec2_s != nullptr;
@@ -814,18 +817,17 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
     else PSE_CELLS(false, false, false, false);
 #undef PSE_CELLS
     if (sums0 && list && two && cl)   // one partial per wavefront of the pass -> scal[LZ_TMP .. LZ_TMP + 2]
-        hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, sums0, (int)g.x * (TPB / 64), sums0_cap, 3, scal);
+        hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, sums0, (int)g.x * (TPB / 64), sums0_cap, 3, scal, nullptr);
 }
 
-__global__ void __launch_bounds__(1024) k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, double *__restrict__ scal);
 int mreal_partials_needed(int rows) { return nblocks(std::max(rows, 1), 64); }   // one per 64 rows (the split mat-vec); the plain one uses a quarter
 void launch_lz_reduce3(const double *partials, int npart, int cap, double *scal, hipStream_t s) {
-    hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, partials, npart, cap, 3, scal);
+    hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, partials, npart, cap, 3, scal, nullptr);
 }
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, RowMap rm, const int *cell_off,
                           DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,
                           double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s, const double2 *pv, VerletList vl,
-                          int sums, double2 *pv_out) {
+                          int sums, double2 *pv_out, const int *stop) {
     const int so = (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1);
     const int rows = std::max(rm.list_rows(), 1);
     const int nbk = nblocks(rows, TPB);
@@ -834,17 +836,17 @@ void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w
     // per workgroup (two waves: 0.182, eight: 0.196).
     if (pv) {
         const int nb64 = nblocks(rows, 64);
-#define PSE_LIST(F) hipLaunchKernelGGL((k_mreal_list<F, 4, 256, true, 4>), dim3(nb64), dim3(256), 0, s, pos_s, vec_s, w, rm, box, so, self, nb, lz, pv, cell_off, nc, rcut * rcut, coef, vl, pv_out)
+#define PSE_LIST(F) hipLaunchKernelGGL((k_mreal_list<F, 4, 256, true, 4>), dim3(nb64), dim3(256), 0, s, pos_s, vec_s, w, rm, box, so, self, nb, lz, pv, cell_off, nc, rcut * rcut, coef, vl, pv_out, stop)
         if (sums == 0) PSE_LIST(0); else if (sums == 1) PSE_LIST(1); else if (sums == 2) PSE_LIST(2); else PSE_LIST(3);
 #undef PSE_LIST
         if (ev_end) (void)hipEventRecord(ev_end, s);
-        if (sums == 1) launch_lz_reduce3(lz.partials, nb64, lz.npart_cap, scal, s);
-        else if (sums >= 2) hipLaunchKernelGGL(k_lz_reduce, dim3(LZ_NGRAM), dim3(1024), 0, s, lz.partials, nb64, lz.npart_cap, LZ_NGRAM, scal);
+        if (sums == 1) hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, lz.partials, nb64, lz.npart_cap, 3, scal, stop);
+        else if (sums >= 2) hipLaunchKernelGGL(k_lz_reduce, dim3(LZ_NGRAM), dim3(1024), 0, s, lz.partials, nb64, lz.npart_cap, LZ_NGRAM, scal, stop);
         return;
     }
-    hipLaunchKernelGGL((k_mreal_list<1, 4, TPB, false>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, rm, box, so, self, nb, lz, nullptr, cell_off, nc, rcut * rcut, coef, vl, nullptr);
+    hipLaunchKernelGGL((k_mreal_list<1, 4, TPB, false>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, rm, box, so, self, nb, lz, nullptr, cell_off, nc, rcut * rcut, coef, vl, nullptr, stop);
     if (ev_end) (void)hipEventRecord(ev_end, s);
-    hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, lz.partials, nbk, lz.npart_cap, 3, scal);
+    hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, lz.partials, nbk, lz.npart_cap, 3, scal, stop);
 }
 
 __global__ void k_eval_fg(const double *__restrict__ r, int n, const double *__restrict__ coef, double *f, double *g) {
@@ -936,8 +938,9 @@ __device__ __forceinline__ void scale_node(int i, int j, int k, const double2 f[
         const bool flip = plane && par < own;
         const unsigned long long canon = (plane && par < own) ? par : own;
         uint32_t ra[4], rb[4];
-        philox4x32((uint32_t)canon, (uint32_t)(canon >> 32), a.timestep, DOMAIN_GRID_A, a.seed, PHILOX_KEY1, ra);
-        philox4x32((uint32_t)canon, (uint32_t)(canon >> 32), a.timestep, DOMAIN_GRID_B, a.seed, PHILOX_KEY1, rb);
+        const uint32_t ts = a.ts_off ? a.timestep + *a.ts_off : a.timestep;
+        philox4x32((uint32_t)canon, (uint32_t)(canon >> 32), ts, DOMAIN_GRID_A, a.seed, PHILOX_KEY1, ra);
+        philox4x32((uint32_t)canon, (uint32_t)(canon >> 32), ts, DOMAIN_GRID_B, a.seed, PHILOX_KEY1, rb);
         const double s = 1.2247448713915890;  // sqrt(3/2)
         const double re[3] = {uniform_pm(ra[0], s), uniform_pm(ra[1], s), uniform_pm(ra[2], s)};
         const double im[3] = {uniform_pm(ra[3], s), uniform_pm(rb[0], s), uniform_pm(rb[1], s)};
@@ -2256,7 +2259,8 @@ k_lz_dots(const double4 *__restrict__ x, const double4 *__restrict__ y, const do
 }
 // this rank's partial sums -> scal[LZ_TMP .. LZ_TMP + nsum) (then all-reduced over the ranks)
 __global__ void __launch_bounds__(1024)
-k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, double *__restrict__ scal) {
+k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, double *__restrict__ scal, const int *__restrict__ stop) {
+    if (stop && *stop) return;
     __shared__ double sh[16];
     const int q = blockIdx.x;                         // one workgroup per sum, fixed summation order
     const double *p = partials + (size_t)q * cap;
@@ -2276,7 +2280,8 @@ struct RowRanges { int n, lo[3], hi[3]; };   // up to three row ranges (own rows
 __global__ void __launch_bounds__(TPB)
 k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, const double4 *__restrict__ xprev,
             double4 *__restrict__ xnext, int j, double *__restrict__ scal, RowRanges rg, double2 *__restrict__ pv,
-            const double *__restrict__ sums_all, int nranks, double *__restrict__ sch) {
+            const double *__restrict__ sums_all, int nranks, double *__restrict__ sch, const int *__restrict__ stop) {
+    if (stop && *stop) return;
     // the three sums: this GPU's (single GPU), or the ranks' partial sums added in rank order -- every rank holds all of them
     // (they travel with the ghost rows: no separate all-reduce) and adds them in the same order: identical scalars everywhere
     double s1 = 0.0, s2 = 0.0, s3raw = 0.0;
@@ -2408,19 +2413,162 @@ void launch_lz_block(const LzBlockArgs &a, bool full, double *scal, const int (*
     else hipLaunchKernelGGL(k_lz_block<false>, g, dim3(TPB), 0, s, a, scal, r, sums_all, nranks, sch);
 }
 
+
+// ---- the Lanczos decision on the device (LzState / LzDecide in pse_kernels.h) ------------------------------------------------------
+// One wavefront: eigen-decomposition of the m x m tridiagonal (alpha[0..m), beta[1..m)) by implicit QL with Wilkinson shifts -- the
+// algorithm of tridiag_eigen (pse_params.cpp; it replaces LAPACKE_spteqr, PSEv1/Brownian.cu:540), statement by statement -- and
+// t = Z sqrt(Lambda) Z^T e_1 (PSEv1/Brownian.cu:563-582).  The scalar recurrence runs redundantly in every lane (identical values);
+// lane 0 stores d and e; row k of the eigenvector matrix belongs to lane k mod 64 (columns in LDS, stride m).  m <= 2 x 64.
+__device__ __forceinline__ void lz_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ bool lz_sqrt_e1(int m, const double *__restrict__ alpha, const double *__restrict__ beta, double *d, double *e, double *z,
+                           double *t_out) {
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < m; i += 64) { d[i] = alpha[i]; e[i] = i + 1 < m ? beta[i + 1] : 0.0; }
+    for (int c = 0; c < m; ++c)
+        for (int k = lane; k < m; k += 64) z[c * m + k] = c == k ? 1.0 : 0.0;
+    bool ok = true;
+    for (int l = 0; l < m && ok; ++l) {
+        int iter = 0, mm;
+        do {
+            lz_wave_sync();   // lane 0's stores of the previous sweep
+            for (mm = l; mm < m - 1; ++mm) {
+                const double dd = fabs(d[mm]) + fabs(d[mm + 1]);
+                if (fabs(e[mm]) <= 2.3e-16 * dd) break;
+            }
+            if (mm != l) {
+                if (iter++ == 200) { ok = false; break; }
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = hypot(g, 1.0);
+                g = d[mm] - d[l] + e[l] / (g + (g >= 0 ? fabs(r) : -fabs(r)));
+                double s = 1.0, c = 1.0, p = 0.0;
+                int i;
+                for (i = mm - 1; i >= l; --i) {
+                    double f = s * e[i], b = c * e[i];
+                    r = hypot(f, g);
+                    if (lane == 0) e[i + 1] = r;
+                    if (r == 0.0) { if (lane == 0) { d[i + 1] -= p; e[mm] = 0.0; } break; }
+                    s = f / r; c = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * s + 2.0 * c * b;
+                    p = s * r;
+                    if (lane == 0) d[i + 1] = g + p;
+                    g = c * r - b;
+                    for (int k = lane; k < m; k += 64) {
+                        const double zk1 = z[(i + 1) * m + k], zk0 = z[i * m + k];
+                        z[(i + 1) * m + k] = s * zk0 + c * zk1;
+                        z[i * m + k] = c * zk0 - s * zk1;
+                    }
+                }
+                if (r == 0.0 && i >= l) continue;
+                if (lane == 0) { d[l] -= p; e[l] = g; e[mm] = 0.0; }
+            }
+        } while (mm != l);
+    }
+    lz_wave_sync();
+    if (!ok) return false;
+    for (int i = lane; i < m; i += 64) {
+        double t = 0.0;
+        for (int j = 0; j < m; ++j) t += z[j * m + i] * (sqrt(fmax(d[j], 0.0)) * z[j * m]);
+        t_out[i] = t;
+    }
+    lz_wave_sync();
+    return true;
+}
+// (the recurrence reads d[i + 1] - p with the d[i + 1] of BEFORE this sweep's store: lane 0's stores of one sweep touch d[i + 1] once,
+// after its last read, exactly as the host loop does)
+__global__ void __launch_bounds__(128)
+k_lz_decide(LzDecide a, double *__restrict__ scal, LzState *__restrict__ st, double *__restrict__ sch, double seq) {
+    extern __shared__ double lds[];
+    __shared__ double tbuf[2][104];
+    __shared__ int okf[2];
+    if (a.first) { if (threadIdx.x == 0) { st->done = 0; st->m_final = 0; st->checked = 0; st->status = 0; st->stepnorm = 1.0; } }
+    else if (st->done) return;
+    __syncthreads();
+    const int wv = threadIdx.x >> 6, nm = a.m_hi - a.m_lo + 1;
+    const double *alpha = scal + LZ_ALPHA, *beta = scal + LZ_BETA;
+    const double norm = scal[LZ_NORM];
+    const bool dead = !(norm > 0.0) || !isfinite(norm);          // psi == 0: the result is zero
+    if (wv < nm && !dead) {
+        const int m = a.m_lo + wv;
+        double *base = lds + (wv == 0 ? 0 : (size_t)a.m_lo * a.m_lo + 2 * a.m_lo);
+        const bool ok = lz_sqrt_e1(m, alpha, beta, base, base + m, base + 2 * m, tbuf[wv]);
+        if ((threadIdx.x & 63) == 0) okf[wv] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int m_final = 0, status = 0, checked = st->checked;
+    double stepnorm = st->stepnorm;
+    const double *t_fin = nullptr;
+    if (dead) { m_final = -1; }
+    else if (a.pending_beta > 0 && beta[a.pending_beta] < 1e-8) {   // |x_m| of the vector the previous batch ended on: invariant subspace
+        m_final = a.pending_beta; stepnorm = 0.0; t_fin = st->t_prev;
+    } else {
+        for (int w = 0; w < nm && !m_final; ++w) {               // walk m upward as the reference's while loop does (PSEv1/Brownian.cu:606-724)
+            const int m = a.m_lo + w;
+            const bool have_beta = m < a.done_iters || a.have_last_beta;
+            if (!isfinite(alpha[m - 1]) || (have_beta && !isfinite(beta[m])) || !okf[w]) { m_final = max(checked, 1); status = 2; t_fin = checked ? st->t_prev : tbuf[w]; break; }
+            const double *tc = tbuf[w];
+            if (m < a.done_iters && beta[m] < 1e-8) { m_final = m; stepnorm = 0.0; t_fin = tc; break; }   // invariant subspace (Brownian.cu:503)
+            if (checked == m - 1 && checked > 0) {
+                double s2 = tc[m - 1] * tc[m - 1];
+                for (int q = 0; q < m - 1; ++q) { const double dq = tc[q] - st->t_prev[q]; s2 += dq * dq; }
+                stepnorm = sqrt(s2 / alpha[0]);                   // Brownian.cu:719-724; psi.M.psi / |psi|^2 = alpha_0
+                if (stepnorm <= a.tol || m >= a.m_max) { m_final = m; t_fin = tc; break; }
+            }
+            if (a.have_last_beta && m == a.done_iters && beta[m] < 1e-8) { m_final = m; stepnorm = 0.0; t_fin = tc; break; }
+            for (int q = 0; q < m; ++q) st->t_prev[q] = tc[q];
+            checked = m;
+        }
+        if (!m_final && (a.last || a.done_iters >= a.m_max)) {     // nothing more is queued: end with what there is
+            m_final = checked; t_fin = st->t_prev; status = a.done_iters >= a.m_max ? 0 : 1;
+        }
+    }
+    st->checked = checked;
+    st->stepnorm = stepnorm;
+    if (m_final) {
+        const int m = max(m_final, 0);
+        for (int q = 0; q < m; ++q) st->coef[q] = t_fin[q] / (q == 0 ? norm : (a.normalised ? 1.0 : beta[q]));
+        st->m_final = m; st->status = status;
+        __threadfence();
+        st->done = 1;
+        if (sch) { sch[LZ_HOST_M] = (double)m; sch[LZ_HOST_STEPNORM] = stepnorm; sch[LZ_HOST_STATUS] = (double)status; sch[LZ_HOST_SEQ] = seq; }
+    }
+}
+static size_t lz_decide_lds(int m_lo, int m_hi) {
+    size_t n = (size_t)m_lo * m_lo + 2 * (size_t)m_lo;
+    if (m_hi != m_lo) n += (size_t)m_hi * m_hi + 2 * (size_t)m_hi;
+    return n * sizeof(double);
+}
+bool lz_decide_supported(int m_hi) { return m_hi >= 1 && m_hi <= 100 && lz_decide_lds(std::max(1, m_hi - 1), m_hi) <= 150 * 1024; }
+void launch_lz_decide(const LzDecide &d, double *scal, LzState *st, double *sch, double seq, hipStream_t s) {
+    const size_t lds = lz_decide_lds(d.m_lo, d.m_hi);
+    static size_t lds_set[16] = {0};   // per device: the largest dynamic LDS size the attribute has been raised to
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (lds > 48 * 1024 && dev >= 0 && dev < 16 && lds_set[dev] < lds) {
+        (void)hipFuncSetAttribute((const void *)k_lz_decide, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        lds_set[dev] = 150 * 1024;
+    }
+    hipLaunchKernelGGL(k_lz_decide, dim3(1), dim3(128), lds, s, d, scal, st, sch, seq);
+}
+
 void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, int lo, int hi, double *partials, int cap,
                     double *scal, hipStream_t s) {
     const int g = vec_grid(std::max(1, hi - lo));
     hipLaunchKernelGGL(k_lz_dots, dim3(g), dim3(TPB), 0, s, x, y, vprev, lo, hi, partials, cap);
-    hipLaunchKernelGGL(k_lz_reduce, dim3(y ? 3 : 1), dim3(1024), 0, s, partials, g, cap, y ? 3 : 1, scal);
+    hipLaunchKernelGGL(k_lz_reduce, dim3(y ? 3 : 1), dim3(1024), 0, s, partials, g, cap, y ? 3 : 1, scal, nullptr);
 }
 void launch_lz_update(const double4 *xin, const double4 *y, const double4 *xprev, double4 *xnext, int j,
-                      double *scal, const int (*rg)[2], int nrg, hipStream_t s, double2 *pv, const double *sums_all, int nranks, double *sch) {
+                      double *scal, const int (*rg)[2], int nrg, hipStream_t s, double2 *pv, const double *sums_all, int nranks, double *sch,
+                      const int *stop) {
     RowRanges r{};
     r.n = nrg;
     int total = 0;
     for (int q = 0; q < nrg && q < 3; ++q) { r.lo[q] = rg[q][0]; r.hi[q] = rg[q][1]; total += rg[q][1] - rg[q][0]; }
-    hipLaunchKernelGGL(k_lz_update, dim3(vec_grid(std::max(1, total))), dim3(TPB), 0, s, xin, y, xprev, xnext, j, scal, r, pv, sums_all, nranks, sch);
+    hipLaunchKernelGGL(k_lz_update, dim3(vec_grid(std::max(1, total))), dim3(TPB), 0, s, xin, y, xprev, xnext, j, scal, r, pv, sums_all, nranks, sch, stop);
 }
 // out[i] = a[i] + b[i] + c[i] on rows [lo, hi)  (each may be null)
 __global__ void k_sum_rows(const double4 *__restrict__ a, const double4 *__restrict__ b, const double4 *__restrict__ c,
@@ -2452,8 +2600,10 @@ void launch_pick(const int *cell_off, const int *idx, int n, int *out, hipStream
 // so ub_s is neither written nor read back (K10 gpu_stokes_LinearCombination_kernel, PSEv1/Helper.cu:113-133)
 __global__ void __launch_bounds__(TPB)
 k_basis_combine(const double4 *__restrict__ x0, const double4 *__restrict__ V, size_t stride, BasisCoef tc, int m,
-                const double *__restrict__ scal, double scale, int use_norm, double4 *__restrict__ out, int lo, int N, CombineSink sink) {
+                const double *__restrict__ scal, double scale, int use_norm, double4 *__restrict__ out, int lo, int N, CombineSink sink,
+                const LzState *__restrict__ st) {
     const double *t = tc.t;   // kernel arguments: no host-to-device copy whose source the host would have to keep alive
+    if (st) { m = st->m_final; t = st->coef; }   // ... or what the device-side decision left (queue-only calls)
     const double sc = use_norm ? scale * scal[LZ_NORM] : scale;
     for (int i = lo + blockIdx.x * TPB + threadIdx.x; i < N; i += gridDim.x * TPB) {
         double x = 0, y = 0, z = 0;
@@ -2475,9 +2625,9 @@ k_basis_combine(const double4 *__restrict__ x0, const double4 *__restrict__ V, s
     }
 }
 void launch_basis_combine(const double4 *x0, const double4 *V, size_t stride, const BasisCoef &t_dev, int m, const double *scal,
-                          double scale, int use_norm, double4 *out_s, int lo, int hi, hipStream_t s, CombineSink sink) {
+                          double scale, int use_norm, double4 *out_s, int lo, int hi, hipStream_t s, CombineSink sink, const LzState *st) {
     hipLaunchKernelGGL(k_basis_combine, dim3(std::min(2048, std::max(1, nblocks(hi - lo, TPB)))), dim3(TPB), 0, s, x0, V, stride,
-                       t_dev, m, scal, scale, use_norm, out_s, lo, hi, sink);
+                       t_dev, m, scal, scale, use_norm, out_s, lo, hi, sink, st);
 }
 
 // Force provider next to the path (the step consumes net_force, PSEv1/Stokes.cc:447): soft repulsion

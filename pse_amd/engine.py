@@ -99,6 +99,12 @@ class Engine:
         neighbour list is decided on the device."""
         _lib.check(self._lib.pse_set_async(self._h, 1 if on else 0))
 
+    def set_timestep_offset(self, word):
+        """word: a 1-element int32/uint32 CUDA tensor (or None): Brownian calls draw their noise at timestep + word[0], read on the
+        device -- what lets a captured step replay with fresh noise.  The tensor must outlive the registration."""
+        self._ts_word = word
+        _lib.check(self._lib.pse_set_timestep_offset(self._h, _ptr(word)))
+
     def debug_last_gate(self):
         """0: the last asynchronous evaluation reused the kept list, != 0: it rebuilt, -1: it did not take the two-chain path."""
         g = ctypes.c_int(-2)

@@ -109,3 +109,86 @@ def test_async_mode_never_reads_back():
         v = eng.mobility(dpos, dF).cpu().numpy()[:, :3]
     _, builds2, reuses2 = eng.neighbor_stats()
     assert reuses2 >= 1 and rel(v, u[0]) < 1e-12
+
+
+@pytest.mark.parametrize("n,xy,err", [(6000, 0.0, 1e-3), (20000, 0.2, 1e-3), (3000, 0.0, 1e-6)])
+def test_queue_only_brownian_call_takes_the_host_decision_on_the_device(n, xy, err):
+    """Asynchronous mode, Brownian calls: the tridiagonal square roots and the step-norm test run in one workgroup on the device
+    (k_lz_decide), extra iterations are gated on its outcome.  Same m and same velocities as the host-checked driver, from
+    starting counts below, at and above the converged one."""
+    import torch
+    import pse_amd
+    pos, force, box = make_suspension(n, phi=0.15, xy=xy)
+    kw = dict(xi=0.5, error=err, seed=11)
+    ref = pse_amd.Engine(n, box, **kw)
+    eng = pse_amd.Engine(n, box, **kw)
+    eng.set_async(True)
+    dpos, dF = to4(pos), to4(force)
+    u_ref, m_ref = ref.brownian_velocity(dpos, dF, 1.0, 1e-3, 5, lanczos_m=2)
+    u_ref = u_ref.cpu().numpy()[:, :3]
+    for m_in in (m_ref, m_ref - 1, m_ref - 2, m_ref + 2):
+        if m_in < 1:
+            continue
+        vel, _ = eng.brownian_velocity(dpos, dF, 1.0, 1e-3, 5, lanczos_m=m_in)
+        torch.cuda.synchronize()
+        i = eng.info()
+        # the host-checked driver from the same starting count (it never goes below the count it starts from)
+        u2, m2 = ref.brownian_velocity(dpos, dF, 1.0, 1e-3, 5, lanczos_m=m_in)
+        assert i["lanczos_status"] == 0 and i["lanczos_m"] == m2, (m_in, i["lanczos_m"], m2, i["lanczos_status"])
+        assert rel(vel.cpu().numpy()[:, :3], u2.cpu().numpy()[:, :3]) < 1e-12, m_in
+        assert abs(i["lanczos_stepnorm"] - ref.info()["lanczos_stepnorm"]) < 1e-9
+    # too few iterations queued: the call says so instead of waiting (status 1), and the result is the one of the last size
+    if m_ref >= 6:
+        vel, _ = eng.brownian_velocity(dpos, dF, 1.0, 1e-3, 5, lanczos_m=m_ref - 3)
+        torch.cuda.synchronize()
+        i = eng.info()
+        assert i["lanczos_status"] == 1 and i["lanczos_m"] == m_ref - 1
+        assert rel(vel.cpu().numpy()[:, :3], u_ref) < 50 * err
+    # the starting count the next call should use reaches the host lazily
+    _, m_next = eng.brownian_velocity(dpos, dF, 1.0, 1e-3, 5, lanczos_m=m_ref)
+    assert m_next >= 1
+
+
+@pytest.mark.parametrize("xy", [0.0, 0.3])
+def test_step_captured_into_a_graph_follows_the_eager_trajectory(xy):
+    """pse_step, captured ONCE into a hipGraph and replayed for ten steps with the timestep advanced through a device word
+    (pse_set_timestep_offset), against the host-checked engine stepping eagerly: positions, images, equal m."""
+    import torch
+    import pse_amd
+    n = 8000
+    pos, force, box = make_suspension(n, phi=0.12, xy=xy)
+    kw = dict(xi=0.5, error=1e-3, seed=3)
+    ref = pse_amd.Engine(n, box, **kw)
+    eng = pse_amd.Engine(n, box, **kw)
+    eng.set_async(True)
+    s = torch.cuda.Stream()
+    eng.set_stream(s.cuda_stream)
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+    eng.set_timestep_offset(word)
+
+    def state():
+        return (to4(pos), to4(np.zeros((n, 3)), 1.0), torch.zeros((n, 3), dtype=torch.float64, device="cuda"),
+                torch.zeros((n, 3), dtype=torch.int32, device="cuda"), to4(force))
+    p1, v1, a1, i1, f1 = state()
+    p0, v0, a0, i0, f0 = state()
+    kT, dt, ts0, rate = 1.0, 2e-3, 100, 0.4
+    # the starting count of the captured call: the converged one of this suspension (an eager call finds it)
+    _, m = ref.brownian_velocity(p0, f0, kT, dt, ts0, lanczos_m=2)
+    with torch.cuda.stream(s):                                 # warm-up outside the capture, on scratch copies
+        q = state()
+        eng.step(q[0], q[1], q[2], q[3], q[4], kT, dt, ts0, shear_rate=rate, lanczos_m=m)
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+        eng.step(p1, v1, a1, i1, f1, kT, dt, ts0, shear_rate=rate, lanczos_m=m)
+    for k in range(10):
+        word.fill_(k)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        mk = ref.step(p0, v0, a0, i0, f0, kT, dt, ts0 + k, shear_rate=rate, lanczos_m=m)
+        info = eng.info()
+        assert info["lanczos_m"] == mk and info["lanczos_status"] == 0, (k, info["lanczos_m"], mk)
+        assert rel(v1.cpu().numpy()[:, :3], v0.cpu().numpy()[:, :3]) < 1e-12, k
+        assert np.abs(p1.cpu().numpy()[:, :3] - p0.cpu().numpy()[:, :3]).max() < 1e-12, k
+        assert torch.equal(i1, i0)

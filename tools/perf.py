@@ -73,6 +73,35 @@ def main():
         m = eng.step(dpos, vel, accel, image, dF, a.kT, 1e-3, 100 + it, lanczos_m=m)
     torch.cuda.synchronize(); t = (time.time() - t0) / a.steps
     print("step %.3f ms/step -> %.1f steps/s, %.3g particle-steps/s, m=%d" % (t * 1e3, 1 / t, n / t, m))
+    # queue-only steps (pse_set_async: the Lanczos decision on the device, no read-back), eager and as a replayed hipGraph
+    eng.set_async(True)
+    for extra_note in ("eager",):
+        for it in range(3):
+            eng.step(dpos, vel, accel, image, dF, a.kT, 1e-3, 200 + it, lanczos_m=m)
+        torch.cuda.synchronize(); t0 = time.time()
+        for it in range(a.steps):
+            eng.step(dpos, vel, accel, image, dF, a.kT, 1e-3, 300 + it, lanczos_m=m)
+        torch.cuda.synchronize(); t = (time.time() - t0) / a.steps
+        i = eng.info()
+        print("queue-only step (%s) %.3f ms/step, m=%d status=%d" % (extra_note, t * 1e3, i["lanczos_m"], i["lanczos_status"]))
+    s = torch.cuda.Stream()
+    eng.set_stream(s.cuda_stream)
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+    eng.set_timestep_offset(word)
+    with torch.cuda.stream(s):
+        eng.step(dpos, vel, accel, image, dF, a.kT, 1e-3, 400, lanczos_m=m)
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+        eng.step(dpos, vel, accel, image, dF, a.kT, 1e-3, 400, lanczos_m=m)
+    for it in range(3):
+        g.replay()
+    torch.cuda.synchronize(); t0 = time.time()
+    for it in range(a.steps):
+        g.replay()
+    torch.cuda.synchronize(); t = (time.time() - t0) / a.steps
+    i = eng.info()
+    print("queue-only step (hipGraph replay) %.3f ms/step, m=%d status=%d" % (t * 1e3, i["lanczos_m"], i["lanczos_status"]))
 
 
 if __name__ == "__main__":

@@ -56,6 +56,9 @@ typedef struct pse_params {
     int device;              /* HIP device ordinal, -1 = current device */
     int n_slabs;             /* far-field slab decomposition: number of ranks (<=1: single GPU) */
     int slab_rank;           /* this rank's slab index */
+    int local_rows;          /* != 0 (with n_slabs >= 2): an OWNED-PARTICLE rank -- it is driven through pse_team_step_local, n_max is the
+                                capacity of its row space (own particles + the ghost layers of both neighbours), not the particle count
+                                of the suspension; the replicated-state team calls refuse such a handle */
 } pse_params;
 
 typedef struct pse_info {
@@ -238,6 +241,38 @@ int pse_team_brownian_velocity(pse_team *team, const pse_double4 *const *pos, co
 int pse_team_step(pse_team *team, pse_double4 *const *pos, pse_double4 *const *vel, pse_double3 *const *accel,
                   pse_int3 *const *image, const pse_double4 *const *net_force, const unsigned int *group_members,
                   unsigned int N, double kT, double dt, unsigned int timestep, double shear_rate, int *lanczos_m);
+
+/* -- owned-particle teams (round 5) ----------------------------------------------------------------------------------------
+ * The calls above replicate the particle state: every rank passes all N particles, bins all of them, and takes part in an
+ * all-gather of the velocities every step.  Here a rank passes ONLY THE PARTICLES IT OWNS -- those of its x slab of the box, as
+ * HOOMD's domain decomposition hands them to a plugin (the reference is single-GPU, PSEv1/Stokes.cc:104; per-step data flow
+ * PSEv1/Stokes.cc:433-514) -- and the engine does what HOOMD's Communicator would: particles that have left the slab migrate to the
+ * neighbour, the ghost layers the near field, the spreading and the two-step Lanczos blocks need arrive from both neighbours,
+ * all in ONE exchange of fixed-size messages at the start of the step.  No rank touches the other N (G - 1) / G particles, there
+ * is no all-gather, and NOTHING is read back inside a step: row counts and ranges live in device memory, the Lanczos decision
+ * is taken on the device (as with pse_set_async), every exchange has host-known sizes (capacities).
+ *
+ * Handles: pse_params.local_rows = 1, n_slabs = G >= 2, n_max = row capacity (pse_local_layout tells how it is divided).  Needs
+ * >= 3 cell layers per rank along x (>= 4 with two ranks), the pair list and the real-space table in LDS.
+ * Arrays (per member, device): rows [0, *n_local) of pos / vel / accel / image / net_force / tag are the particles the rank owns
+ * (capacity: rows_own of pse_local_layout); tag = the particle's global index (keys the particle noise, PSEv1/Brownian.cu:117;
+ * identifies it across ranks); vel.w = mass.  On entry a particle may have left the slab by less than a slab width (the last
+ * step moved it).  On return the arrays hold the particles the rank owns NOW, in the engine's cell order (pos, vel, accel,
+ * image, tag rewritten; net_force is an input: the caller recomputes it for the new order), *n_local their number (a device
+ * word: the host learns it when it asks).  integrate = 0: velocities only, positions unchanged (but reordered likewise).
+ * kT = 0: deterministic.  *lanczos_m as for queue-only calls (pse_set_async).  Errors that show on the device only (a capacity
+ * exceeded, a particle that moved further than a neighbour) are sticky: pse_team_local_status reads them (synchronises), and
+ * the next call refuses to start. */
+int pse_team_step_local(pse_team *team, pse_double4 *const *pos, pse_double4 *const *vel, pse_double3 *const *accel,
+                        pse_int3 *const *image, const pse_double4 *const *net_force, unsigned int *const *tag,
+                        unsigned int *const *n_local, double kT, double dt, unsigned int timestep, double shear_rate,
+                        int integrate, int *lanczos_m);
+/* row capacities of an owned-particle handle: own rows (= capacity the caller's arrays need), ghost rows per side, records per
+ * neighbour message of the first exchange; cell layers along x in all and per rank (any pointer may be null) */
+int pse_local_layout(pse_handle *h, int *rows_own, int *rows_ghost, int *records, int *layers, int *layers_per_rank);
+/* waits for the team's streams; flags[member] = 0 or a combination of 1 own rows exceeded, 2 ghost rows exceeded, 4 message
+ * capacity exceeded, 8 a particle moved beyond the neighbour's slab, 16 *n_local above the capacity; returns PSE_ERR_INVALID if any */
+int pse_team_local_status(pse_team *team, int *flags);
 
 /* Developer switch for an IN-PROCESS team (measurement, not a result): from now on the team queues the work of the one member
  * with this slab rank only -- its kernels on both lanes and the copies that stand for what it receives; the other members'

@@ -25,6 +25,7 @@ class pse_params(ctypes.Structure):
         ("rcut", ctypes.c_double),
         ("device", ctypes.c_int),
         ("n_slabs", ctypes.c_int), ("slab_rank", ctypes.c_int),
+        ("local_rows", ctypes.c_int),
     ]
 
 
@@ -101,6 +102,10 @@ SYMBOLS = {
     "pse_team_brownian_velocity": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _u, _d, _d, _u, _ip]),
     "pse_team_step": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                            ctypes.POINTER(_vp), _vp, _u, _d, _d, _u, _d, _ip]),
+    "pse_team_step_local": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                 ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _d, _d, _u, _d, _i, _ip]),
+    "pse_local_layout": (_i, [_vp, _ip, _ip, _ip, _ip, _ip]),
+    "pse_team_local_status": (_i, [_vp, _ip]),
     "pse_host_lanczos_sqrt_e1": (_i, [_i, _dp, _dp, _dp]),
     "pse_host_select_params": (_i, [ctypes.POINTER(pse_params), ctypes.POINTER(pse_info)]),
 }

@@ -25,6 +25,7 @@
 #include "pse_err.h"
 #include "pse_host.h"
 #include "pse_kernels.h"
+#include "pse_local.h"
 
 using namespace pse;
 
@@ -171,6 +172,20 @@ struct pse_handle {
     double *sc_host_dev = nullptr;   // its device address
     int *bounds_host_dev = nullptr;  // device address of bounds_host (mapped pinned): k_pick writes the row boundaries straight to the host
     int npart_cap = 0;
+    // owned-particle rank (pse_params.local_rows; pse_local.h): geometry, capacities and the buffers of the step's first exchange
+    struct LocalPlan {
+        bool on = false;
+        LocalGeom g{};
+        int rows_cap = 0;                    // c_own + 2 c_g
+        double *send[2] = {nullptr, nullptr}, *recv[2] = {nullptr, nullptr};   // [left, right] messages: LOCAL_HDR + LOCAL_REC * c_x doubles
+        size_t msg = 0;                      // doubles per message
+        double4 *stage_w1 = nullptr, *stage_w2 = nullptr;   // the last layers of w1, w2 on their way to the right neighbour (c_g rows each)
+        double4 *porig_s = nullptr; double *mass_s = nullptr; int3 *image_s = nullptr;
+        int *raw = nullptr;                  // scan of the cell counts before the regions are moved to their bases
+        LocalRows *rows = nullptr;           // device
+        int *counters = nullptr;             // (inside cnt_block: zeroed with the cell counts)
+        int *err = nullptr, *err_host = nullptr;   // error word: device, and a pinned word the status call copies it to
+    } loc;
     LzState *lz_state = nullptr;     // the device-side Lanczos decision of queue-only Brownian calls (pse_set_async)
     unsigned long long lz_seq = 0;   // calls that queued one (the decision kernel stamps the host mirror with it)
     const uint32_t *ts_off = nullptr;   // pse_set_timestep_offset: the noise of a Brownian call is drawn at timestep + *ts_off
@@ -198,13 +213,13 @@ static void set_dbox(pse_handle *h) {
 }
 
 // cells of at least rcut perpendicular width for tilts up to gamma; a dimension with fewer than 3 cells uses 1
-static int cells_for(const Box &box, double rc, double gamma, int n_slabs, int bz_want, DCells &out) {
+static int cells_for(const Box &box, double rc, double gamma, int n_slabs, int bz_want, DCells &out, int xpad = 0) {
     const double wx = box.Lx / std::sqrt(1.0 + gamma * gamma), wy = box.Ly, wz = box.Lz;
     if (rc > 0.5 * wx * (1 + 1e-12) || rc > 0.5 * wy * (1 + 1e-12) || rc > 0.5 * wz * (1 + 1e-12))
         return fail(PSE_ERR_INVALID, "real-space cutoff %.4f exceeds half the box width (%.4f, %.4f, %.4f at tilt %.3f): "
                     "the minimum-image near field needs rcut <= L/2; increase xi", rc, wx, wy, wz, gamma);
     auto n = [&](double w) { int c = (int)std::floor(w / rc); if (c < 3) c = 1; if (c > 1024) c = 1024; return c; };
-    out = DCells{n(wx), n(wy), n(wz), 0, 1};
+    out = DCells{n(wx), n(wy), n(wz), 0, 1, xpad};
     // Blocks of six cells along z in the storage order (pse_device.h; PSE_CELL_BZ=b at pse_create overrides, 0 = plain (x, y, z) order).
     // Measured at the metric point: the pair-list mat-vec 0.163 -> 0.153 ms (a wave's gathers come from ~95 cells instead of
     // ~130), the cell pass 0.60 -> 0.62 ms (lanes of a wave no longer walk the same z lines): about 1 % per step in four of four
@@ -224,7 +239,7 @@ static int cells_for(const Box &box, double rc, double gamma, int n_slabs, int b
 static double near_radius(const pse_handle *h) { return h->d.rcut + h->skin_max; }   // cells are as wide as the kept list reaches
 static int set_cells(pse_handle *h, double gamma) {
     DCells nc;
-    TRY(cells_for(h->box, near_radius(h), gamma, h->n_slabs, h->tun.cell_bz, nc));
+    TRY(cells_for(h->box, near_radius(h), gamma, h->n_slabs, h->tun.cell_bz, nc, h->loc.on ? 1 : 0));
     h->nc = nc;
     h->cell_gamma = gamma;
     h->nc_wide = h->skin_max > 0.0;
@@ -314,6 +329,12 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->ev_bounds) (void)hipEventDestroy(h->ev_bounds);
     if (h->sc_host) (void)hipHostFree(h->sc_host);
     if (h->flags_host) (void)hipHostFree(h->flags_host);
+    {
+        void *lp[] = {h->loc.send[0], h->loc.send[1], h->loc.recv[0], h->loc.recv[1], h->loc.stage_w1, h->loc.stage_w2, h->loc.porig_s, h->loc.mass_s,
+                      h->loc.image_s, h->loc.raw, h->loc.rows, h->loc.err};
+        for (void *q : lp) if (q) (void)hipFree(q);
+        if (h->loc.err_host) (void)hipHostFree(h->loc.err_host);
+    }
     delete h;
     return 0;
 }
@@ -418,6 +439,7 @@ static int make_plans(pse_handle *h) {
     return 0;
 }
 
+static bool team_sstep(const pse_handle *h);
 static int create_impl(const pse_params *p, pse_handle *h) {
     h->par = *p;
     h->box = Box{p->Lx, p->Ly, p->Lz, p->xy};
@@ -434,6 +456,8 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     h->n_max = (int)p->n_max;
     set_dbox(h);
     h->n_slabs = std::max(1, p->n_slabs);
+    h->loc.on = p->local_rows != 0;
+    if (h->loc.on && h->n_slabs < 2) return fail(PSE_ERR_INVALID, "local_rows needs n_slabs >= 2 (an owned-particle rank is a member of a team)");
     (void)roctx();   // PSE_ROCTX: looked up here, once per process
     {   // the developer switches: the environment is read here and nowhere else
         auto ienv = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
@@ -482,7 +506,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     h->grid_slabs = h->n_slabs;
     if (h->n_slabs > 1) {
         const bool replicate = h->tun.wave_mode ? h->tun.wave_mode == 2 : h->n_slabs == 2;
-        if (replicate) h->grid_slabs = 1;
+        if (replicate && !h->loc.on) h->grid_slabs = 1;   // (an owned-particle rank has no particles to spread a whole grid with)
     }
     if (h->grid_slabs > 1) {
         if (d.Nx % h->grid_slabs || d.Ny % h->grid_slabs)
@@ -513,7 +537,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     {
         const double rc = d.rcut;
         auto cnt = [&](double w) { int c2 = (int)std::floor(w / rc); if (c2 < 3) c2 = 1; if (c2 > 1024) c2 = 1024; return (size_t)c2; };
-        h->n_cells_alloc = cnt(h->box.Lx) * cnt(h->box.Ly) * (cnt(h->box.Lz) + 16);   // + the padding of the last z block (bz <= 16)
+        h->n_cells_alloc = cnt(h->box.Lx) * cnt(h->box.Ly) * (cnt(h->box.Lz) + 16) + cnt(h->box.Lx);   // + the padding of the last z block (bz <= 16), + one empty cell per x layer (xpad)
     }
     TRY(dmalloc(h, &h->cell_off, h->n_cells_alloc + 1));
     h->sort_tmp_bytes = cell_sort_temp_bytes(h->n_cells_alloc);
@@ -525,7 +549,8 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     // layout in ints: [0, B - 1) bin counts (incl. sentinel, padded) | B - 1: flags[0] | B: flags[1] | B + 4 ...: cell counts.  B and every
     // memset size are multiples of four ints: a memset that is not a multiple of 16 bytes takes two fill kernels.
     h->cnt_bins = ((fast_far ? nbins + 1 : 0) + 1 + 3) & ~(size_t)3;   // B
-    TRY(dmalloc(h, &h->cnt_block, h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8));
+    TRY(dmalloc(h, &h->cnt_block, h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8 + LOCAL_NCOUNTER));
+    h->loc.counters = h->cnt_block + h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8;
     h->vl.flags = h->cnt_block + h->cnt_bins - 1;
     h->gate_word = h->cnt_block + h->cnt_bins + 1;   // (B + 1: between flags[1] and the cell counts; no memset covers it alone)
     h->cell_cnt = h->cnt_block + h->cnt_bins + 4;
@@ -583,6 +608,35 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         if (h->tun.team_sstep && h->nb.cap > 0) {
             TRY(dmalloc(h, &h->w2_s, n)); TRY(dmalloc(h, &h->u_s, n)); TRY(dmalloc(h, &h->pv2, 3 * n));
         }
+    }
+    if (h->loc.on) {
+        // owned-particle rank: the row space [own | left ghosts | right ghosts] and the messages of the step's first exchange
+        auto &L = h->loc;
+        const int G_ = h->n_slabs, per = h->nc.nx / G_, depth = 2;
+        if (per < depth + 1 || (G_ - 1) * per < 2 * depth)
+            return fail(PSE_ERR_INVALID, "an owned-particle rank needs >= %d cell layers of width rcut per rank along x (%d ranks: %d layers each)",
+                        G_ == 2 ? 2 * depth : depth + 1, G_, per);
+        if (!team_sstep(h))
+            return fail(PSE_ERR_INVALID, "an owned-particle rank needs the per-step pair list and the real-space table in LDS (rcut = %.3f, n_max = %d)",
+                        d.rcut, h->n_max);
+        if ((d.P / 2 + 1.0) / d.Nx > (double)depth / h->nc.nx)
+            return fail(PSE_ERR_INVALID, "the spreading support (P = %d on %d planes) reaches beyond the %d ghost cell layers of an owned-particle rank", d.P, d.Nx, depth);
+        const int c_g = (int)((double)h->n_max * depth / (per + 2 * depth)) / 256 * 256, c_own = (h->n_max - 2 * c_g) / 256 * 256;
+        if (c_g < 256 || c_own < c_g)
+            return fail(PSE_ERR_INVALID, "n_max = %d is too small a row capacity for an owned-particle rank (%d layers + 2 x %d ghost layers)", h->n_max, per, depth);
+        L.g = LocalGeom{h->slab_rank, G_, per, depth, h->nc.nx, c_own, c_g, c_g};
+        L.rows_cap = c_own + 2 * c_g;
+        L.msg = (size_t)LOCAL_HDR + (size_t)LOCAL_REC * c_g;
+        for (int q = 0; q < 2; ++q) { TRY(dmalloc(h, &L.send[q], L.msg)); TRY(dmalloc(h, &L.recv[q], L.msg)); HIPCHK(hipMemset(L.recv[q], 0, L.msg * sizeof(double))); }
+        TRY(dmalloc(h, &L.stage_w1, (size_t)c_g)); TRY(dmalloc(h, &L.stage_w2, (size_t)c_g));
+        TRY(dmalloc(h, &L.porig_s, (size_t)c_own)); TRY(dmalloc(h, &L.mass_s, (size_t)c_own)); TRY(dmalloc(h, &L.image_s, (size_t)c_own));
+        TRY(dmalloc(h, &L.raw, h->n_cells_alloc + 1));
+        TRY(dmalloc(h, &L.rows, 1));
+        TRY(dmalloc(h, &L.err, 4));
+        HIPCHK(hipMemset(L.err, 0, 4 * sizeof(int)));
+        HIPCHK(hipMemset(L.rows, 0, sizeof(LocalRows)));
+        HIPCHK(hipHostMalloc((void **)&L.err_host, 4 * sizeof(int)));
+        L.err_host[0] = 0;
     }
     // The wave-space chain (spread -> FFTs -> gather) and the real-space chain (near field + Lanczos) only meet in the
     // final sum: on a single GPU they run on two streams, so latency-bound kernels of one chain fill the gaps of the
@@ -659,9 +713,11 @@ extern "C" int pse_set_box(pse_handle *h, double Lx, double Ly, double Lz, doubl
     const Box nb{Lx, Ly, Lz, xy};
     const double gamma = std::max(std::fabs(xy), h->par.max_strain);
     DCells nc, nc_narrow;
-    TRY(cells_for(nb, near_radius(h), gamma, h->n_slabs, h->tun.cell_bz, nc));
+    TRY(cells_for(nb, near_radius(h), gamma, h->n_slabs, h->tun.cell_bz, nc, h->loc.on ? 1 : 0));
     // prepare() switches to the narrow grid (cells of width rcut: more of them) whenever the kept list is suspended or off
-    TRY(cells_for(nb, h->d.rcut, gamma, h->n_slabs, h->tun.cell_bz, nc_narrow));
+    TRY(cells_for(nb, h->d.rcut, gamma, h->n_slabs, h->tun.cell_bz, nc_narrow, h->loc.on ? 1 : 0));
+    if (h->loc.on && nc.nx != h->nc.nx)
+        return fail(PSE_ERR_INVALID, "an owned-particle rank cannot change its cell layers along x (%d -> %d): the slabs are the ownership", h->nc.nx, nc.nx);
     if ((size_t)std::max(cells_total(nc), cells_total(nc_narrow)) > h->n_cells_alloc)
         return fail(PSE_ERR_INVALID, "box grew beyond the cell-list capacity sized at creation");
     TRY(gaussian_fits(h->d, Lx / h->d.Nx, Ly / h->d.Ny, Lz / h->d.Nz));
@@ -771,6 +827,7 @@ struct pse_team {
     // own (the other members' buffers keep what the last full call left there: the numbers are not meaningful, the timing is)
     int solo = -1;
     std::vector<pse_handle *> solo_m;
+    bool lanes = true;           // two compute lanes (PSE_TEAM_LANES=0: one stream for everything, also the RCCL calls)
 };
 static const std::vector<pse_handle *> &act(const pse_team &T) { return T.solo >= 0 ? T.solo_m : T.m; }
 #define NCCLCHK(x)                                                                                              \
@@ -1773,6 +1830,8 @@ struct StepTail { const std::vector<StepArgs> *sa; double dt, shear_rate; };
 
 static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *group, int N, int parts, double kT, double dt,
                     unsigned timestep, int *m_io, unsigned *mask, const StepTail *tail = nullptr) {
+    for (pse_handle *h : T.m)
+        if (h->loc.on) return fail(PSE_ERR_INVALID, "this handle is an owned-particle rank (pse_params.local_rows): drive it through pse_team_step_local");
     for (size_t r = 0; r < T.m.size(); ++r)
         if (T.solo < 0 || T.m[r]->slab_rank == T.solo)   // psi rides with the gather into cell order: the near-field pass that
             TRY(prepare(T.m[r], a[r].pos, a[r].force, group, N, true, false, PrepExtra{kT > 0.0, timestep}));   // builds the pair list applies M_real to F and psi together
@@ -1784,7 +1843,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
         // stream: those durations are the roofline evidence).  A single GPU forks for deterministic evaluations only (Brownian
         // steps gain nothing there); a TEAM always forks: at 1 / G of the rows no kernel fills the chip, and the
         // far-field exchanges travel while the Lanczos iterations compute (one communicator, one communication stream: pse_team).
-        const bool on = h->side && parts == 3 && !h->timing && (h->overlap_all || !noise || T.G > 1);
+        const bool on = h->side && parts == 3 && !h->timing && (T.G > 1 ? T.lanes : (h->overlap_all || !noise));
         if (on != h->side_on || h->wstream != (on ? h->side : h->stream)) {
             h->side_on = on;
             h->wstream = on ? h->side : h->stream;
@@ -1929,6 +1988,235 @@ static int do_step(pse_team &T, const std::vector<StepArgs> &sa, const unsigned 
         TRY(te(h, PH_TOTAL));
         HIPCHK(hipGetLastError());
         TRY(collect_times(h, mask));
+    }
+    return 0;
+}
+
+// ---- owned-particle team step (pse_team_step_local; kernels in pse_local.hip) ---------------------------------------------------
+// Everything below only QUEUES work: the row counts of a step never reach the host (LocalRows lives in device memory, every
+// launch covers the capacity), every exchange has the fixed size of its capacity, the Lanczos decision is k_lz_decide's.
+static LocalRegions local_regions(const pse_handle *h) {
+    const LocalGeom &g = h->loc.g;
+    const int lc = layer_cells(h->nc), nx = g.nx;
+    auto wrap = [&](int l) { return ((l % nx) + nx) % nx; };
+    LocalRegions r{};
+    const int l_own = g.rank * g.per, l_gl = wrap(l_own - g.depth), l_gr = wrap(l_own + g.per);
+    r.c0[0] = l_own * lc; r.c1[0] = (l_own + g.per) * lc; r.base[0] = 0; r.cap[0] = g.c_own;
+    r.c0[1] = l_gl * lc; r.c1[1] = (l_gl + g.depth) * lc; r.base[1] = g.c_own; r.cap[1] = g.c_g;
+    r.c0[2] = l_gr * lc; r.c1[2] = (l_gr + g.depth) * lc; r.base[2] = g.c_own + g.c_g; r.cap[2] = g.c_g;
+    r.c_first_end = (l_own + g.depth) * lc - 1;            // the empty last cell of layer l_own + depth - 1
+    r.c_last_begin = (l_own + g.per - g.depth) * lc;
+    r.c_gl_adj = wrap(l_own - 1) * lc;
+    r.c_gr_adj = (l_gr + 1) * lc - 1;                      // the empty last cell of layer l_gr
+    return r;
+}
+
+// M_real^{1/2} psi of an owned-particle team: the two-step blocks of lanczos_team (k_lz_block has the algebra), queue-only.  Blocks for
+// the starting count, ONE decision on the device (sizes m_in - 1 and m_in), then ceil(PSE_LANCZOS_EXTRA / 2) further blocks, each
+// with its decision, their kernels gated on the outcome so far (the exchanges of a gated block still travel: they carry no
+// meaning then, and every rank takes the same decisions from the same sums).  Ghost rows move by position: the first c_g rows of
+// w1, w2 go left as they lie, the rows of the last layers were parked by the mat-vecs (stage_w1, stage_w2: their first row is known
+// on the device only) and go right; they arrive in the ghost regions of the neighbours' w1, w2.
+static int lanczos_local(pse_team &T, double tol, int *m_io, WavePump *pump) {
+    pse_handle *h0 = T.m[0];
+    const size_t stride = h0->n_pad;
+    const int m_in = std::min(std::max(m_io ? *m_io : 2, 1), M_MAX), target = std::max(m_in, 2);
+    const int extra_blocks = (h0->tun.lz_extra + 1) / 2;
+    if (target + 2 * extra_blocks > M_MAX || !lz_decide_supported(target + 2 * extra_blocks))
+        return fail(PSE_ERR_INVALID, "owned-particle step: starting count %d of the Lanczos iteration is beyond what the device-side decision takes", m_in);
+    int n_exchanges = 0, matvecs = 0, done = 0, half_pending = -1;
+    auto vec = [&](pse_handle *h, int q) { return q == 0 ? h->psi_s : h->V + (size_t)q * stride; };
+    auto block_args = [&](pse_handle *h, int j, bool full) {
+        LzBlockArgs a{};
+        a.q = vec(h, j); a.p = j > 0 ? vec(h, j - 1) : nullptr; a.w1 = h->w_s; a.w2 = full ? h->w2_s : nullptr;
+        a.u = h->u_s; a.v1 = h->V + (size_t)(j + 1) * stride; a.v2 = full ? h->V + (size_t)(j + 2) * stride : nullptr;
+        a.pv = h->pv; a.j = j;
+        return a;
+    };
+    auto fuse = [&](pse_handle *h, int j) { return LzFuse{nullptr, h->partials, h->npart_cap, vec(h, j), j > 0 ? vec(h, j - 1) : nullptr, j > 0 ? h->u_s : nullptr}; };
+    auto exchange = [&](bool full) -> int {
+        if (pump) TRY(pump->upto(n_exchanges));
+        ++n_exchanges;
+        return team_run_exchange(T, [&](pse_handle *h) {
+            const LocalGeom &g = h->loc.g;
+            const int L = (g.rank + g.G - 1) % g.G, R = (g.rank + 1) % g.G;
+            const size_t cnt = (size_t)g.c_g * 4;
+            std::vector<Xfer> ops;
+            // my first layers go left and arrive as the left neighbour's right ghosts; my last layers (parked) go right
+            ops.push_back(Xfer{(double *)h->w_s, cnt, L, (double *)(h->w_s + g.c_own + g.c_g), cnt, R});
+            ops.push_back(Xfer{(double *)h->loc.stage_w1, cnt, R, (double *)(h->w_s + g.c_own), cnt, L});
+            if (full) {
+                ops.push_back(Xfer{(double *)h->w2_s, cnt, L, (double *)(h->w2_s + g.c_own + g.c_g), cnt, R});
+                ops.push_back(Xfer{(double *)h->loc.stage_w2, cnt, R, (double *)(h->w2_s + g.c_own), cnt, L});
+            }
+            sum_ops(h, T.G, LZ_NGRAM, ops);
+            return ops; }, false);
+    };
+    auto full_block = [&](int j, bool gated) -> int {
+        for (pse_handle *h : act(T)) {
+            const int *gate = gated ? &h->lz_state->done : nullptr;
+            const LocalRows *R = h->loc.rows;
+            if (j == 0) {
+                if (!h->w_is_mpsi) return fail(PSE_ERR_NUMERIC, "owned-particle step: M psi did not come with the pair list");
+            } else {   // w1 = M v_j on the own rows + the adjacent ghost layers
+                launch_mreal_lanczos(h->pos_s, vec(h, j), h->w_s, RowMap{}, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, h->nb, fuse(h, j),
+                                     h->scal, nullptr, nullptr, h->stream, h->pv, VerletList{}, 0, h->pv2, gate,
+                                     DevRowArgs{&R->own1, R, h->loc.stage_w1, h->loc.rows_cap});
+                ++matvecs;
+            }
+            h->w_is_mpsi = false;
+            // w2 = M w1 on the own rows, Gram sums fused
+            launch_mreal_lanczos(h->pos_s, h->w_s, h->w2_s, RowMap{}, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, h->nb, fuse(h, j), h->scal,
+                                 nullptr, nullptr, h->stream, h->pv2, VerletList{}, 2, nullptr, gate, DevRowArgs{&R->own, R, h->loc.stage_w2, h->loc.g.c_own});
+            ++matvecs;
+        }
+        TRY(exchange(true));
+        for (pse_handle *h : act(T))
+            launch_lz_block(block_args(h, j, true), true, h->scal, nullptr, 0, h->stream, h->sums_all, T.G, h->sc_host_dev, &h->loc.rows->all,
+                            h->loc.rows_cap, false, gated ? &h->lz_state->done : nullptr);
+        return 0;
+    };
+    auto single = [&](int j, bool gated) -> int {   // an odd starting count ends on one iteration: scalars now, vectors only if the iteration goes on
+        for (pse_handle *h : act(T)) {
+            const LocalRows *R = h->loc.rows;
+            launch_mreal_lanczos(h->pos_s, vec(h, j), h->w_s, RowMap{}, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, h->nb, fuse(h, j), h->scal,
+                                 nullptr, nullptr, h->stream, h->pv, VerletList{}, 3, nullptr, gated ? &h->lz_state->done : nullptr,
+                                 DevRowArgs{&R->own, R, h->loc.stage_w1, h->loc.g.c_own});
+            ++matvecs;
+        }
+        TRY(exchange(false));
+        for (pse_handle *h : act(T))
+            launch_lz_block(block_args(h, j, false), false, h->scal, nullptr, 0, h->stream, h->sums_all, T.G, h->sc_host_dev, &h->loc.rows->all,
+                            h->loc.rows_cap, true, gated ? &h->lz_state->done : nullptr);
+        half_pending = j;
+        return 0;
+    };
+    auto decide = [&](int m_lo, int m_hi, int done_iters, bool first, bool last) {
+        for (pse_handle *h : act(T)) {
+            LzDecide d{};
+            d.m_lo = m_lo; d.m_hi = m_hi; d.done_iters = done_iters; d.have_last_beta = 1; d.first = first ? 1 : 0; d.last = last ? 1 : 0;
+            d.normalised = 1; d.m_max = M_MAX; d.tol = tol;
+            launch_lz_decide(d, h->scal, h->lz_state, h->sc_host_dev, (double)h->lz_seq, h->stream);
+        }
+    };
+    for (pse_handle *h : act(T)) ++h->lz_seq;
+    while (target - done >= 2) { TRY(full_block(done, false)); done += 2; }
+    if (target - done == 1) { TRY(single(done, false)); done += 1; }
+    decide(std::max(m_in - 1, 1), target, done, true, extra_blocks == 0);
+    for (int x = 0; x < extra_blocks; ++x) {
+        if (half_pending >= 0) {   // the vector part of the single step (its sums are still in place)
+            for (pse_handle *h : act(T))
+                launch_lz_block(block_args(h, half_pending, false), false, h->scal, nullptr, 0, h->stream, h->sums_all, T.G, h->sc_host_dev,
+                                &h->loc.rows->all, h->loc.rows_cap, false, &h->lz_state->done);
+            half_pending = -1;
+        }
+        TRY(full_block(done, true));
+        decide(done + 1, done + 2, done + 2, false, x == extra_blocks - 1);
+        done += 2;
+    }
+    for (pse_handle *h : act(T)) { h->info.lanczos_matvecs = matvecs; h->info.lanczos_exchanges = n_exchanges; }
+    if (m_io) *m_io = h0->sc_host[LZ_HOST_SEQ] > 0.0 && h0->sc_host[LZ_HOST_M] >= 1.0 ? (int)h0->sc_host[LZ_HOST_M] : m_in;
+    return 0;
+}
+
+static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT, double dt, unsigned timestep, double shear_rate, int integrate,
+                      int *m_io) {
+    if (T.G < 2) return fail(PSE_ERR_INVALID, "pse_team_step_local needs a team of >= 2 ranks");
+    for (size_t r = 0; r < T.m.size(); ++r) {
+        pse_handle *h = T.m[r];
+        if (!h->loc.on) return fail(PSE_ERR_INVALID, "pse_team_step_local: member %zu was not created with local_rows", r);
+        if (h->loc.err_host[0]) return fail(PSE_ERR_INVALID, "owned-particle rank %d: an earlier step failed on the device (flags %d: 1 own rows, 2 ghost rows, "
+                                            "4 message capacity exceeded, 8 a particle moved beyond the neighbour, 16 n_local above capacity)", h->slab_rank, h->loc.err_host[0]);
+        const LocalCaller &c = ca[r];
+        if (!c.pos || !c.vel || !c.accel || !c.image || !c.force || !c.tag || !c.n_local) return fail(PSE_ERR_INVALID, "null array");
+        HIPCHK(hipSetDevice(h->device));
+    }
+    if (kT < 0 || !(dt > 0)) return fail(PSE_ERR_INVALID, "need kT >= 0 and dt > 0");
+    const bool noise = kT > 0.0;
+    unsigned mask = 0;
+    for (pse_handle *h : act(T)) {   // two lanes: the far-field chain next to the near field / Lanczos chain
+        const bool on = h->side && !h->timing && T.lanes;
+        if (on != h->side_on || h->wstream != (on ? h->side : h->stream)) {
+            h->side_on = on;
+            h->wstream = on ? h->side : h->stream;
+            FFTCHK(rocfft_execution_info_set_stream(h->info_fwd, h->wstream));
+            FFTCHK(rocfft_execution_info_set_stream(h->info_inv, h->wstream));
+        }
+    }
+    // (1) classification of the own particles + the messages for both neighbours
+    for (size_t r = 0; r < T.m.size(); ++r) {
+        pse_handle *h = T.m[r];
+        if (T.solo >= 0 && h->slab_rank != T.solo) continue;
+        const size_t block = (h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8 + LOCAL_NCOUNTER) & ~(size_t)3;
+        HIPCHK(hipMemsetAsync(h->cnt_block, 0, block * sizeof(int), h->stream));
+        const LocalPool pool{h->keys, h->keys_s, h->perm, h->cell_cnt};
+        launch_local_classify(ca[r], h->loc.g, h->dbox, h->nc, pool, h->loc.send[0], h->loc.send[1], h->loc.counters, h->loc.err, h->stream);
+    }
+    // (2) ONE exchange: my left message goes left, what arrives from the right is the right neighbour's left message
+    TRY(team_run_exchange(T, [&](pse_handle *h) {
+        const LocalGeom &g = h->loc.g;
+        const int L = (g.rank + g.G - 1) % g.G, R = (g.rank + 1) % g.G;
+        std::vector<Xfer> ops;
+        ops.push_back(Xfer{h->loc.send[0], h->loc.msg, L, h->loc.recv[1], h->loc.msg, R});
+        ops.push_back(Xfer{h->loc.send[1], h->loc.msg, R, h->loc.recv[0], h->loc.msg, L});
+        return ops; }, false));
+    // (3) cell sort of what the rank keeps: own particles that stayed, arrivals, ghosts
+    for (size_t r = 0; r < T.m.size(); ++r) {
+        pse_handle *h = T.m[r];
+        if (T.solo >= 0 && h->slab_rank != T.solo) continue;
+        const LocalPool pool{h->keys, h->keys_s, h->perm, h->cell_cnt};
+        const int ncell = cells_total(h->nc);
+        if ((size_t)ncell > h->n_cells_alloc) return fail(PSE_ERR_INVALID, "cell grid exceeds the capacity sized at creation");
+        launch_local_bin_incoming(h->loc.recv[0], h->loc.recv[1], h->loc.g, h->dbox, h->nc, pool, h->loc.err, h->stream);
+        HIPCHK(launch_cell_scan(h->cell_cnt, h->loc.raw, ncell + 1, h->sort_tmp, h->sort_tmp_bytes, h->stream));
+        const LocalRegions rg = local_regions(h);
+        launch_local_scatter(h->loc.raw, h->cell_off, h->loc.g, rg, pool, h->vals, h->loc.rows, h->loc.err, h->stream);
+        const FarBinArgs far = far_bin_args(h->G, h->sw);
+        const LocalSorted out{h->pos_s, h->posf_s, h->pv, h->pv2, h->f_s, h->tag_s, h->loc.porig_s, h->loc.mass_s, h->loc.image_s, noise ? h->psi_s : nullptr};
+        launch_local_permute(ca[r], h->loc.recv[0], h->loc.recv[1], h->loc.g, h->dbox, h->cell_off, pool, h->vals, h->loc.rows, out, &far, h->par.seed,
+                             timestep, h->ts_off, h->stream);
+        h->sorted_N = 0; h->nb_valid = false; h->vl_valid = false; h->w_is_mpsi = false; h->pv_is_f = true;
+        CellRanges need{};   // (the generic far-field kernels: rows outside these hold no particle)
+        need.n = 3;
+        for (int q = 0; q < 3; ++q) { need.c0[q] = rg.c0[q]; need.c1[q] = rg.c1[q] - 1; }
+        h->sw.need = need; h->sw.cell_off = h->cell_off; h->sw.rows_local = 1;
+    }
+    // (4) the far-field chain (side lane), the near field and the Lanczos blocks (main lane)
+    WavePump pump;
+    const WaveArgs wa{T.m[0]->loc.rows_cap, noise, kT, dt, timestep};
+    TRY(pump.start(T, wa, T.m[0]->tun.team_sched, &mask));
+    for (pse_handle *h : act(T)) {
+        const LocalRows *R = h->loc.rows;
+        const int nco = h->n_intervals * 2 * RS_NCOEF;
+        if (noise)   // the pass that builds the pair list applies M_real to F and psi together, on the own rows + the adjacent ghost layers
+            launch_mreal(h->pos_s, h->posf_s, h->f_s, h->ur_s, RowMap{}, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, nco, h->nb,
+                         MREAL_BUILD_LIST, h->stream, h->psi_s, h->w_s, VerletList{}, VL_NONE, nullptr, h->pv2, nullptr, 0, nullptr, Gate{},
+                         DevRowArgs{&R->own1, R, h->loc.stage_w1, h->loc.rows_cap});
+        else
+            launch_mreal(h->pos_s, h->posf_s, h->f_s, h->ur_s, RowMap{}, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, nco, h->nb,
+                         MREAL_CELLS, h->stream, nullptr, nullptr, VerletList{}, VL_NONE, nullptr, nullptr, nullptr, 0, nullptr, Gate{},
+                         DevRowArgs{&R->own, R, nullptr, h->loc.g.c_own});
+        h->nb_valid = noise; h->w_is_mpsi = noise;
+    }
+    if (noise) TRY(lanczos_local(T, T.m[0]->d.error, m_io, &pump));
+    TRY(pump.drain());
+    // (5) join the lanes; the end of the step on the own rows, written to the caller's arrays
+    for (size_t r = 0; r < T.m.size(); ++r) {
+        pse_handle *h = T.m[r];
+        if (T.solo >= 0 && h->slab_rank != T.solo) continue;
+        if (h->side_on) {
+            HIPCHK(hipEventRecord(h->ev_join, h->side));
+            HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+        }
+        LocalFinish f{};
+        f.rows = h->loc.rows; f.st = noise ? h->lz_state : nullptr;
+        f.psi_s = h->psi_s; f.V = h->V; f.stride = h->n_pad; f.scal = h->scal; f.scale = noise ? std::sqrt(2.0 * kT / dt) : 0.0;
+        f.uw_s = h->uw_s; f.ur_s = h->ur_s;
+        f.porig_s = h->loc.porig_s; f.f_s = h->f_s; f.mass_s = h->loc.mass_s; f.image_s = h->loc.image_s; f.tag_s = h->tag_s;
+        f.integrate = integrate; f.dt = dt; f.shear_rate = shear_rate;
+        launch_local_finish(f, ca[r], h->dbox, h->loc.g.c_own, h->stream);
+        HIPCHK(hipMemcpyAsync(h->loc.err_host, h->loc.err, sizeof(int), hipMemcpyDeviceToHost, h->stream));   // (read by the NEXT call: nothing waits)
+        HIPCHK(hipGetLastError());
     }
     return 0;
 }
@@ -2091,7 +2379,13 @@ static int team_connect(pse_team *T, const void *id128_host) {
     memcpy(&id, id128_host, sizeof id);
     HIPCHK(hipSetDevice(T->m[0]->device));
     NCCLCHK(ncclCommInitRank(&T->nccl, T->G, id, T->m[0]->slab_rank));
-    if (T->G > 1) {   // the one stream every RCCL call of the team is issued on (see pse_team)
+    // Two compute lanes + a communication stream of their own are OPT-IN for an RCCL team (PSE_TEAM_LANES=1): no multi-GPU node has
+    // run that path yet.  Default: one stream carries the kernels and the RCCL calls, in program order -- nothing can interleave.
+    {
+        const char *e = getenv("PSE_TEAM_LANES");
+        T->lanes = e && atoi(e) > 0;
+    }
+    if (T->G > 1 && T->lanes) {   // the one stream every RCCL call of the team is issued on (see pse_team)
         HIPCHK(hipStreamCreateWithFlags(&T->comm, hipStreamNonBlocking));
         T->evs.resize(32);
         for (hipEvent_t &e : T->evs) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -2121,6 +2415,7 @@ extern "C" int pse_team_create(pse_handle **members, int n_members, const void *
     pse_team *T = new pse_team();
     T->m.assign(members, members + n_members);
     T->G = G;
+    if (const char *e = getenv("PSE_TEAM_LANES")) T->lanes = atoi(e) > 0;   // in-process and host-staged teams: two lanes unless switched off
     if (n_members > 1)   // in-process team: one side stream for all members, so every lane is ordered by its stream alone
         for (int i = 1; i < n_members; ++i) members[i]->side = members[0]->side;
     int rc = team_connect(T, id128_host);
@@ -2138,6 +2433,7 @@ extern "C" int pse_team_create_transport(pse_handle *member, const pse_transport
     T->G = member->n_slabs;
     T->cb = *transport;
     T->has_cb = true;
+    if (const char *e = getenv("PSE_TEAM_LANES")) T->lanes = atoi(e) > 0;
     *out = T;
     return 0;
 }
@@ -2196,4 +2492,45 @@ extern "C" int pse_team_step(pse_team *T, pse_double4 *const *pos, pse_double4 *
     for (size_t r = 0; r < T->m.size(); ++r)
         a.push_back(StepArgs{(double4 *)pos[r], (double4 *)vel[r], (double3 *)accel[r], (int3 *)image[r], (const double4 *)net_force[r]});
     return do_step(*T, a, group, N, kT, dt, timestep, shear_rate, lanczos_m);
+}
+
+extern "C" int pse_team_step_local(pse_team *T, pse_double4 *const *pos, pse_double4 *const *vel, pse_double3 *const *accel, pse_int3 *const *image,
+                                   const pse_double4 *const *net_force, unsigned int *const *tag, unsigned int *const *n_local, double kT,
+                                   double dt, unsigned int timestep, double shear_rate, int integrate, int *lanczos_m) {
+    if (!T || !pos || !vel || !accel || !image || !net_force || !tag || !n_local) return fail(PSE_ERR_INVALID, "null argument");
+    std::vector<LocalCaller> ca;
+    for (size_t r = 0; r < T->m.size(); ++r)
+        ca.push_back(LocalCaller{(double4 *)pos[r], (double4 *)vel[r], (double3 *)accel[r], (int3 *)image[r], (const double4 *)net_force[r], tag[r], n_local[r]});
+    return local_call(*T, ca, kT, dt, timestep, shear_rate, integrate, lanczos_m);
+}
+
+extern "C" int pse_local_layout(pse_handle *h, int *rows_own, int *rows_ghost, int *records, int *layers, int *layers_per_rank) {
+    if (!h) return fail(PSE_ERR_INVALID, "null handle");
+    if (!h->loc.on) return fail(PSE_ERR_INVALID, "not an owned-particle handle (pse_params.local_rows)");
+    if (rows_own) *rows_own = h->loc.g.c_own;
+    if (rows_ghost) *rows_ghost = h->loc.g.c_g;
+    if (records) *records = h->loc.g.c_x;
+    if (layers) *layers = h->loc.g.nx;
+    if (layers_per_rank) *layers_per_rank = h->loc.g.per;
+    return 0;
+}
+
+extern "C" int pse_team_local_status(pse_team *T, int *flags) {
+    if (!T) return fail(PSE_ERR_INVALID, "null team");
+    int any = 0;
+    for (size_t r = 0; r < T->m.size(); ++r) {
+        pse_handle *h = T->m[r];
+        if (!h->loc.on) return fail(PSE_ERR_INVALID, "member %zu is not an owned-particle handle", r);
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->side) HIPCHK(hipStreamSynchronize(h->side));
+        int f = 0;
+        HIPCHK(hipMemcpy(&f, h->loc.err, sizeof(int), hipMemcpyDeviceToHost));
+        h->loc.err_host[0] = f;
+        if (flags) flags[r] = f;
+        any |= f;
+    }
+    if (any) return fail(PSE_ERR_INVALID, "owned-particle step failed on the device (flags %d: 1 own rows, 2 ghost rows, 4 message capacity exceeded, "
+                         "8 a particle moved beyond the neighbour, 16 n_local above capacity)", any);
+    return 0;
 }

@@ -33,9 +33,12 @@ struct DGrid {
 struct DCells {
     int nx, ny, nz;        // cells per dimension (1 or >= 3)
     int bz, nzb;           // block height along z and blocks per z line (nzb = ceil(nz / bz))
+    int xpad;              // 1: every x layer ends with one EMPTY storage cell (owned-particle teams: the rows of a layer range then end at
+                           //    cell_off[its last cell + 1] even where the next layer's rows live in another region of the row space); else 0
 };
-__host__ __device__ inline int cells_total(const DCells &nc) { return nc.nx * nc.nzb * nc.ny * nc.bz; }
-__host__ __device__ inline int cell_slot(const DCells &nc, int cx, int cy, int zb, int zi) { return ((cx * nc.nzb + zb) * nc.ny + cy) * nc.bz + zi; }
+__host__ __device__ inline int layer_cells(const DCells &nc) { return nc.nzb * nc.ny * nc.bz + nc.xpad; }   // storage cells of one x layer
+__host__ __device__ inline int cells_total(const DCells &nc) { return nc.nx * layer_cells(nc); }
+__host__ __device__ inline int cell_slot(const DCells &nc, int cx, int cy, int zb, int zi) { return ((cx * nc.nzb + zb) * nc.ny + cy) * nc.bz + zi + cx * nc.xpad; }
 
 // fractional coordinates in [0,1): f = ((x - xy*y)/Lx + 1/2, y/Ly + 1/2, z/Lz + 1/2)
 __device__ __forceinline__ void frac_coords(const DBox &b, double x, double y, double z, double &fx, double &fy, double &fz) {

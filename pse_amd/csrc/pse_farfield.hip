@@ -708,7 +708,7 @@ hipError_t launch_gather(const double4 *pos_s, SpreadWork w, int N, const double
     const GaussConsts gc = gauss_consts(G, box.xy);
     // bins per workgroup along z: two where a bin holds fewer than ~20 particles on average (PSE_GATHER_BZ=1|2 overrides)
     const int bz_env = w.force_bz;
-    const double per_bin = (double)N / ((double)fb.nbx * fb.nby * fb.nbz);
+    const double per_bin = (double)N / ((double)(w.rows_local ? nbx_l : fb.nbx) * fb.nby * fb.nbz);
     const int bz = (G.Nz >= 32 && (bz_env ? bz_env == 2 : per_bin < 20.0)) ? 2 : 1;
     switch (G.P) {
 #define PSE_GATHER_CASE(PV) case PV: launch_gather_p<PV>(w.rec_t, fb, bx0, nbx_l, gx, gy, gz, G, gc, u_s, s, bz); break;

@@ -45,6 +45,26 @@ struct RowMap {
         return i < hi[k] ? i : -1;
     }
 };
+struct RowRanges { int n, lo[3], hi[3]; };   // up to three disjoint row ranges (own rows and the two ghost regions)
+// Row space of an owned-particle rank (pse_team_step_local), written ON THE DEVICE by the cell sort of the step (k_local_scatter):
+// the host never learns these numbers inside a step -- kernels are launched for the capacities and read their rows here.
+//   own rows [0, n_own) | left ghosts [c_own, c_own + n_gl) | right ghosts [c_own + c_g, c_own + c_g + n_gr)      (c_own, c_g: capacities)
+struct LocalRows {
+    int n_own, n_gl, n_gr;
+    int first_end;                // own rows [0, first_end): the first `depth` cell layers -- the left neighbour's right ghosts
+    int last_begin;               // own rows [last_begin, n_own): the last `depth` layers -- the right neighbour's left ghosts
+    int ok;                       // 0: a capacity was exceeded (flagged): every range here is empty
+    RowMap own, own1;             // own rows; own rows + the ADJACENT ghost layer on either side (list-row bases as RowMap wants them)
+    RowRanges all;                // own + all ghost rows
+};
+// rows of a near-field / vector pass given on the device (rm nullable: the RowMap passed by value counts), + where a mat-vec
+// parks the rows of the last `depth` layers on their way to the right neighbour (their first row is known on the device only)
+struct DevRowArgs {
+    const RowMap *rm;             // device
+    const LocalRows *lr;          // device (nullable): for stage_hi
+    double4 *stage_hi;            // rows [lr->last_begin, lr->n_own) of the result also go to stage_hi[row - last_begin]
+    int rows_cap;                 // list rows to launch for (>= what *rm will say)
+};
 inline RowMap row_map(int lo, int hi) { return RowMap{1, {lo, 0, 0}, {hi, 0, 0}, {0, 0, 0}}; }
 inline RowMap row_map(const int (*rg)[2], int n) {
     RowMap m{};
@@ -72,6 +92,8 @@ hipError_t cell_sort(const double4 *pos, const unsigned *group, int N, DBox box,
                      unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s,
                      CellRanges need = CellRanges{}, SlabBook sb = SlabBook{}, bool cnt_is_zero = false,   // cnt[0 .. ncell] already zeroed by the caller
                      Gate gate = Gate{});
+// exclusive prefix sum of n ints (the cell counts -> row offsets), same scratch as cell_sort
+hipError_t launch_cell_scan(const int *cnt, int *out, int n, void *tmp, size_t tmp_bytes, hipStream_t s);
 // pos_s[i] = wrapped position of particle perm[i], vec_s[i] = vec[tag].xyz, tag_s[i] = its index in the caller's arrays
 // pos_build (nullable): the sorted positions the neighbour list was built at; a particle that has moved more than
 // sqrt(half_skin2) from there (minimum image) sets flags[0] -- HOOMD's NeighborList distance check (r_buff / 2)
@@ -131,7 +153,8 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
                   const double2 *pv = nullptr,                           // VL_USE: packed (position, vec_s) records
                   double2 *pv_out = nullptr,                             // BUILD_LIST with a second vector: out2 also goes into these records
                   double *sums0 = nullptr, int sums0_cap = 0, double *scal = nullptr,    // ... and the sums vec2.vec2, vec2.out2 are left in scal[LZ_TMP ..] (Lanczos iteration 0)
-                  Gate gate = Gate{});                                   // cell pass / kept-list pass without a pair list: run on one outcome of the device-side list check only
+                  Gate gate = Gate{},                                    // cell pass / kept-list pass without a pair list: run on one outcome of the device-side list check only
+                  DevRowArgs dr = DevRowArgs{});                         // owned-particle ranks: the rows come from device memory (cell passes only; stage_hi takes out2)
 bool mreal_table_in_lds(int ncoef);   // the neighbour list across steps needs the LDS copy of the table
 // pair-list mat-vec + Lanczos sums; leaves the three reduced sums in scal[LZ_TMP .. LZ_TMP + 2]
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, RowMap rows, const int *cell_off,
@@ -141,7 +164,8 @@ void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w
                           VerletList vl = VerletList{},   // in use this step: rows that overflowed the pair list walk it instead of the cells
                           int sums = 1,                   // 0 none, 1 one-step Lanczos sums, 2 Gram sums of a two-step block, 3 single step of that driver
                           double2 *pv_out = nullptr,      // the result also goes into the vector half of these records
-                          const int *stop = nullptr);     // nullable: leave at once if *stop != 0 (the device-side Lanczos decision)
+                          const int *stop = nullptr,      // nullable: leave at once if *stop != 0 (the device-side Lanczos decision)
+                          DevRowArgs dr = DevRowArgs{});  // owned-particle ranks: rows from device memory (packed-record variants only)
 int mreal_partials_needed(int rows);
 void launch_lz_reduce3(const double *partials, int npart, int cap, double *scal, hipStream_t s);
 
@@ -163,6 +187,7 @@ struct SpreadWork {
     int force_bz;               // ... bins along z per gather workgroup (PSE_GATHER_BZ=1|2)
     CellRanges need;            // a slab rank: rows outside hold no particle data (their support cannot reach the slab)
     const int *cell_off;
+    int rows_local;             // 1: N counts the rows of ONE slab rank (owned-particle teams), not the particles of the suspension
 };
 // per-step constants of the separable Gaussian weights: step ratios r_t = exp(-c h^2 (2t+1)) (y with the (1 + xy^2) of the
 // sheared lattice), ln K = -2 c xy hx hy, the tilt
@@ -249,7 +274,9 @@ struct LzBlockArgs {
 // sums_all / nranks (teams): [nranks][LZ_NGRAM] partial sums of all ranks, added in rank order by the kernel; nranks = 0: scal[LZ_TMP ..]
 // sch: the host's copy of the scalars (device pointer of mapped pinned memory, nullable): alpha, beta, the norm are written there too
 void launch_lz_block(const LzBlockArgs &a, bool full, double *scal, const int (*row_ranges)[2], int n_ranges, hipStream_t s,
-                     const double *sums_all = nullptr, int nranks = 0, double *sch = nullptr);
+                     const double *sums_all = nullptr, int nranks = 0, double *sch = nullptr,
+                     const RowRanges *rg_dev = nullptr, int rows_cap = 0,   // owned-particle ranks: the ranges come from device memory (vectors_off: scalars only)
+                     bool vectors_off = false, const int *stop = nullptr);
 void launch_lz_update(const double4 *xin, const double4 *y, const double4 *xprev, double4 *xnext, int j,
                       double *scal, const int (*row_ranges)[2], int n_ranges, hipStream_t s, double2 *pv = nullptr,   // up to three disjoint row ranges in one launch; pv: also refresh the packed records
                       const double *sums_all = nullptr, int nranks = 0, double *sch = nullptr, const int *stop = nullptr);

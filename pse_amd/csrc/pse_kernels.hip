@@ -113,6 +113,9 @@ size_t cell_sort_temp_bytes(size_t ncell) {
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int *)nullptr, (int *)nullptr, (int)(ncell + 1));
     return bytes;
 }
+hipError_t launch_cell_scan(const int *cnt, int *out, int n, void *tmp, size_t tmp_bytes, hipStream_t s) {
+    return hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt, out, n, s);
+}
 hipError_t cell_sort(const double4 *pos, const unsigned *group, int N, DBox box, DCells nc, unsigned *keys, unsigned *rank,
                      unsigned *slots, int *cnt, int ncell, void *tmp, size_t tmp_bytes, int *cell_off, unsigned *perm, hipStream_t s,
                      CellRanges need, SlabBook sb, bool cnt_is_zero, Gate gate) {
@@ -298,8 +301,14 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
               double4 *__restrict__ out_s, RowMap rm, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2,
               float rcut2_pre, double self, const double *__restrict__ coef_g, int ncoef, NbList nb,
               const double4 *__restrict__ vec2_s, double4 *__restrict__ out2_s, VerletList vl, double2 *__restrict__ pv_out,
-              double *__restrict__ sums0, int sums0_cap, Gate gate) {
+              double *__restrict__ sums0, int sums0_cap, Gate gate, DevRowArgs dr) {
     if (gate.closed()) return;
+    int nb_live = gridDim.x;
+    if (dr.rm) {   // an owned-particle rank: the rows of this pass are known on the device only; the launch covers the capacity
+        rm = *dr.rm;
+        nb_live = (rm.list_rows() + TPB - 1) / TPB;
+        if ((int)blockIdx.x >= nb_live) return;
+    }
     // the pass that also writes the kept neighbour list queues every pair within rcut + r_buff (28 per row instead of 21): a deeper
     // queue, or half of the waves would stop for an extra, poorly filled drain in the middle of the walk
     constexpr int QC = VL ? 64 : QCAP;
@@ -313,7 +322,7 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
         __syncthreads();
     }
     const double *coef = CL ? scoef : coef_g;
-    const int lr = xcd_block(blockIdx.x, gridDim.x) * TPB + tid;       // list row -> sorted row (own rows, then ghost layers)
+    const int lr = xcd_block(blockIdx.x, nb_live) * TPB + tid;       // list row -> sorted row (own rows, then ghost layers)
     const int i_own = rm.row(lr);
     // a padding lane repeats the first row (identical stores, into the same places or into padding list rows) instead of leaving:
     // the wave-level sums at the end then see every lane
@@ -482,6 +491,10 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
             ((double *)&pv_out[3 * (size_t)i + 1])[1] = wx;
             pv_out[3 * (size_t)i + 2] = make_double2(wy, wz);
         }
+        if (dr.stage_hi) {   // rows of the last layers: parked for the exchange with the right neighbour
+            const int lb = dr.lr->last_begin, no = dr.lr->n_own;
+            if (i >= lb && i < no) dr.stage_hi[i - lb] = make_double4(wx, wy, wz, 0.0);
+        }
         if (sums0) {    // the sums of Lanczos iteration 0 (x = psi, y = M psi): x.x and x.y per wavefront (was k_lz_dots: one more pass over both)
             const double4 v2 = vec2_s[i];
             const double a = padding ? 0.0 : v2.x * v2.x + v2.y * v2.y + v2.z * v2.z, b = padding ? 0.0 : v2.x * wx + v2.y * wy + v2.z * wz;
@@ -592,8 +605,18 @@ __global__ void __launch_bounds__(NT)
 k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, RowMap rm,
              DBox box, int shift_only, double self, NbList nb, LzFuse lz, const double2 *__restrict__ pv,
              const int *__restrict__ cell_off, DCells nc, double rcut2, const double *__restrict__ coef, VerletList vl,
-             double2 *__restrict__ pv_out, const int *__restrict__ stop) {
+             double2 *__restrict__ pv_out, const int *__restrict__ stop, DevRowArgs dr) {
     if (stop && *stop) return;   // the Lanczos iteration has ended (device-side decision)
+    int nb_live = gridDim.x;
+    if (dr.rm) {   // an owned-particle rank: rows from device memory; workgroups past the last one still own a slot of the partial sums
+        rm = *dr.rm;
+        nb_live = (rm.list_rows() + (WSP > 1 ? 64 : NT) - 1) / (WSP > 1 ? 64 : NT);
+        if ((int)blockIdx.x >= nb_live) {
+            if (FUSE && threadIdx.x == 0)
+                for (int t = 0; t < (FUSE >= 2 ? (int)LZ_NGRAM : 3); ++t) lz.partials[(size_t)t * lz.npart_cap + blockIdx.x] = 0.0;
+            return;
+        }
+    }
     __shared__ double shift[27 * 3];
     __shared__ double sh[4];
     if (threadIdx.x < 27) {
@@ -604,8 +627,8 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
     __syncthreads();
     static_assert(WSP == 1 || NT == 64 * WSP, "split rows: one wave per slot phase");
     const int wv = WSP > 1 ? (int)(threadIdx.x >> 6) : 0;
-    const int lr = WSP > 1 ? xcd_block(blockIdx.x, gridDim.x) * 64 + (int)(threadIdx.x & 63)
-                           : xcd_block(blockIdx.x, gridDim.x) * NT + (int)threadIdx.x;
+    const int lr = WSP > 1 ? xcd_block(blockIdx.x, nb_live) * 64 + (int)(threadIdx.x & 63)
+                           : xcd_block(blockIdx.x, nb_live) * NT + (int)threadIdx.x;
     const int i = rm.row(lr);
     const bool active = i >= 0;
     double ux = 0.0, uy = 0.0, uz = 0.0;
@@ -769,6 +792,10 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
             ((double *)&pv_out[3 * (size_t)i + 1])[1] = ux;
             pv_out[3 * (size_t)i + 2] = make_double2(uy, uz);
         }
+        if (dr.stage_hi) {   // rows of the last layers: parked for the exchange with the right neighbour
+            const int lb = dr.lr->last_begin, no = dr.lr->n_own;
+            if (i >= lb && i < no) dr.stage_hi[i - lb] = make_double4(ux, uy, uz, 0.0);
+        }
     }
 }
 
@@ -779,8 +806,8 @@ bool mreal_table_in_lds(int ncoef) { return mreal_lds_bytes(ncoef) <= 14 * 1024;
 void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec_s, double4 *out_s, RowMap rm,
                   const int *cell_off, DBox box, DCells nc, double rcut, double self, const double *coef, int ncoef, NbList nb,
                   int mode, hipStream_t s, const double4 *vec2_s, double4 *out2_s, VerletList vl, int vl_mode, const double2 *pv,
-                  double2 *pv_out, double *sums0, int sums0_cap, double *scal, Gate gate) {
-    const int rows = rm.list_rows();
+                  double2 *pv_out, double *sums0, int sums0_cap, double *scal, Gate gate, DevRowArgs dr) {
+    const int rows = dr.rm ? dr.rows_cap : rm.list_rows();
     if (rows <= 0) return;
     const dim3 g(nblocks(rows, TPB)), b(TPB);
     const size_t cb = mreal_lds_bytes(ncoef);
@@ -788,7 +815,7 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
     if (mode == MREAL_USE_LIST) {
         hipLaunchKernelGGL((k_mreal_list<0, 4, TPB, false>), g, b, 0, s, pos_s, vec_s, out_s, rm, box,
                            (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1), self, nb, LzFuse{}, nullptr, cell_off, nc, rcut * rcut, coef,
-                           vl_mode == VL_USE ? vl : VerletList{}, nullptr, nullptr);
+                           vl_mode == VL_USE ? vl : VerletList{}, nullptr, nullptr, DevRowArgs{});
         return;
     }
     const bool list = mode == MREAL_BUILD_LIST, two = list && vec2_s != nullptr;
@@ -808,7 +835,7 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
     const double cmax = 1.5 * (box.Lx + std::fabs(box.xy) * box.Ly + box.Ly + box.Lz);
     const double rpre = (wr ? vl.rskin : rcut) + 16.0 * cmax * 5.97e-8;
     const float rcut2_pre = (float)(rpre * rpre * (1.0 + 1e-6));
-#define PSE_CELLS(L, C, T, V) hipLaunchKernelGGL((k_mreal_cells<L, C, T, V>), g, b, (C) ? cb : 0, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, two ? vec2_s : nullptr, out2_s, vl, two ? pv_out : nullptr, (two && (C)) ? sums0 : nullptr, sums0_cap, gate)
+#define PSE_CELLS(L, C, T, V) hipLaunchKernelGGL((k_mreal_cells<L, C, T, V>), g, b, (C) ? cb : 0, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, two ? vec2_s : nullptr, out2_s, vl, two ? pv_out : nullptr, (two && (C)) ? sums0 : nullptr, sums0_cap, gate, dr)
     if (list) {
         if (cl && two) { if (wr) PSE_CELLS(true, true, true, true); else PSE_CELLS(true, true, true, false); }
         else if (cl) { if (wr) PSE_CELLS(true, true, false, true); else PSE_CELLS(true, true, false, false); }
@@ -827,16 +854,16 @@ void launch_lz_reduce3(const double *partials, int npart, int cap, double *scal,
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, RowMap rm, const int *cell_off,
                           DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,
                           double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s, const double2 *pv, VerletList vl,
-                          int sums, double2 *pv_out, const int *stop) {
+                          int sums, double2 *pv_out, const int *stop, DevRowArgs dr) {
     const int so = (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1);
-    const int rows = std::max(rm.list_rows(), 1);
+    const int rows = std::max(dr.rm ? dr.rows_cap : rm.list_rows(), 1);
     const int nbk = nblocks(rows, TPB);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     // Four waves per block of 64 rows, each taking every fourth group of slots: 0.166 ms against 0.191 with four blocks of rows
     // per workgroup (two waves: 0.182, eight: 0.196).
     if (pv) {
         const int nb64 = nblocks(rows, 64);
-#define PSE_LIST(F) hipLaunchKernelGGL((k_mreal_list<F, 4, 256, true, 4>), dim3(nb64), dim3(256), 0, s, pos_s, vec_s, w, rm, box, so, self, nb, lz, pv, cell_off, nc, rcut * rcut, coef, vl, pv_out, stop)
+#define PSE_LIST(F) hipLaunchKernelGGL((k_mreal_list<F, 4, 256, true, 4>), dim3(nb64), dim3(256), 0, s, pos_s, vec_s, w, rm, box, so, self, nb, lz, pv, cell_off, nc, rcut * rcut, coef, vl, pv_out, stop, dr)
         if (sums == 0) PSE_LIST(0); else if (sums == 1) PSE_LIST(1); else if (sums == 2) PSE_LIST(2); else PSE_LIST(3);
 #undef PSE_LIST
         if (ev_end) (void)hipEventRecord(ev_end, s);
@@ -844,7 +871,7 @@ void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w
         else if (sums >= 2) hipLaunchKernelGGL(k_lz_reduce, dim3(LZ_NGRAM), dim3(1024), 0, s, lz.partials, nb64, lz.npart_cap, LZ_NGRAM, scal, stop);
         return;
     }
-    hipLaunchKernelGGL((k_mreal_list<1, 4, TPB, false>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, rm, box, so, self, nb, lz, nullptr, cell_off, nc, rcut * rcut, coef, vl, nullptr, stop);
+    hipLaunchKernelGGL((k_mreal_list<1, 4, TPB, false>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, rm, box, so, self, nb, lz, nullptr, cell_off, nc, rcut * rcut, coef, vl, nullptr, stop, DevRowArgs{});
     if (ev_end) (void)hipEventRecord(ev_end, s);
     hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, lz.partials, nbk, lz.npart_cap, 3, scal, stop);
 }
@@ -2276,7 +2303,6 @@ k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, d
     }
 }
 // alpha_j, beta_j from the reduced sums; x_{j+1} on the given rows
-struct RowRanges { int n, lo[3], hi[3]; };   // up to three row ranges (own rows and the two ghost layers), disjoint
 __global__ void __launch_bounds__(TPB)
 k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, const double4 *__restrict__ xprev,
             double4 *__restrict__ xnext, int j, double *__restrict__ scal, RowRanges rg, double2 *__restrict__ pv,
@@ -2331,7 +2357,10 @@ k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, cons
 // The basis V holds the NORMALISED v_j here (the one-step path keeps unnormalised x_j).
 template <bool FULL>
 __global__ void __launch_bounds__(TPB)
-k_lz_block(LzBlockArgs a, double *__restrict__ scal, RowRanges rg, const double *__restrict__ sums_all, int nranks, double *__restrict__ sch) {
+k_lz_block(LzBlockArgs a, double *__restrict__ scal, RowRanges rg, const double *__restrict__ sums_all, int nranks, double *__restrict__ sch,
+           const RowRanges *__restrict__ rg_dev, int vectors_off, const int *__restrict__ stop) {
+    if (stop && *stop) return;
+    if (rg_dev) { rg = *rg_dev; if (vectors_off) rg.n = 0; }   // an owned-particle rank: the ranges are known on the device only
     __shared__ double sG[LZ_NGRAM];   // the ranks' partial sums added in rank order (they came with the ghost rows: see k_lz_update):
     if (threadIdx.x < LZ_NGRAM) {     // one lane per sum, once per workgroup
         double v = 0.0;
@@ -2403,14 +2432,16 @@ k_lz_block(LzBlockArgs a, double *__restrict__ scal, RowRanges rg, const double 
         }
     }
 }
-void launch_lz_block(const LzBlockArgs &a, bool full, double *scal, const int (*rg)[2], int nrg, hipStream_t s, const double *sums_all, int nranks, double *sch) {
+void launch_lz_block(const LzBlockArgs &a, bool full, double *scal, const int (*rg)[2], int nrg, hipStream_t s, const double *sums_all, int nranks, double *sch,
+                     const RowRanges *rg_dev, int rows_cap, bool vectors_off, const int *stop) {
     RowRanges r{};
     r.n = nrg;
     int total = 0;
     for (int q = 0; q < nrg && q < 3; ++q) { r.lo[q] = rg[q][0]; r.hi[q] = rg[q][1]; total += rg[q][1] - rg[q][0]; }
+    if (rg_dev) total = vectors_off ? 1 : rows_cap;
     const dim3 g(vec_grid(std::max(1, total)));
-    if (full) hipLaunchKernelGGL(k_lz_block<true>, g, dim3(TPB), 0, s, a, scal, r, sums_all, nranks, sch);
-    else hipLaunchKernelGGL(k_lz_block<false>, g, dim3(TPB), 0, s, a, scal, r, sums_all, nranks, sch);
+    if (full) hipLaunchKernelGGL(k_lz_block<true>, g, dim3(TPB), 0, s, a, scal, r, sums_all, nranks, sch, rg_dev, vectors_off ? 1 : 0, stop);
+    else hipLaunchKernelGGL(k_lz_block<false>, g, dim3(TPB), 0, s, a, scal, r, sums_all, nranks, sch, rg_dev, vectors_off ? 1 : 0, stop);
 }
 
 

@@ -1,0 +1,310 @@
+// Kernels of the owned-particle team step (pse_local.h).  gfx950, wave64, fp64.
+#include "pse_local.h"
+#include "pse_farbin.h"
+
+namespace pse {
+
+constexpr int TPB = 256;
+constexpr unsigned KEY_FOREIGN = 0xFFFFFFFFu;
+static inline int nblocks(long n, int tpb) { return (int)((n + tpb - 1) / tpb); }
+
+// cell layer cx relative to the first layer of the rank's slab, nearest periodic image around the slab's centre:
+// 0 .. per - 1 = own layers, negative = towards the left neighbour, >= per = towards the right one
+__device__ __forceinline__ int rel_layer(int cx, const LocalGeom &g) {
+    int s2 = 2 * (cx - g.rank * g.per) - g.per;            // twice the distance from the slab's centre, minus a half layer
+    const int n2 = 2 * g.nx;
+    s2 %= n2;
+    if (s2 < -g.nx) s2 += n2; else if (s2 >= g.nx) s2 -= n2;
+    return (s2 + g.per) / 2;                               // (even: exact)
+}
+__device__ __forceinline__ unsigned cell_of(const DBox &box, const DCells &nc, double x, double y, double z, int &cx) {
+    double fx, fy, fz;
+    frac_coords(box, x, y, z, fx, fy, fz);
+    cx = cell_coord(fx, nc.nx);
+    const int cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz), zb = cz / nc.bz;
+    return (unsigned)cell_slot(nc, cx, cy, zb, cz - zb * nc.bz);
+}
+// slot of this lane's item in a list that grows by one atomic per wavefront (-1: the lane has none)
+__device__ __forceinline__ int wave_append(bool want, int *counter) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0ull) return -1;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader, 64);
+    return want ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+__device__ __forceinline__ void write_record(double *msg, int slot, const double4 &p, const double4 &f, double mass, const int3 &im, unsigned tag) {
+    double2 *r = reinterpret_cast<double2 *>(msg + LOCAL_HDR + (size_t)slot * LOCAL_REC);
+    r[0] = make_double2(p.x, p.y); r[1] = make_double2(p.z, p.w);
+    r[2] = make_double2(f.x, f.y); r[3] = make_double2(f.z, mass);
+    r[4] = make_double2((double)im.x, (double)im.y); r[5] = make_double2((double)im.z, (double)tag);
+}
+
+__global__ void __launch_bounds__(TPB)
+k_local_classify(LocalCaller c, LocalGeom g, DBox box, DCells nc, LocalPool pool, double *__restrict__ send_l, double *__restrict__ send_r,
+                 int *__restrict__ counters, int *__restrict__ err) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    const unsigned n_raw = *c.n_local;
+    const int n = (int)min(n_raw, (unsigned)g.c_own);
+    if (i == 0 && n_raw > (unsigned)g.c_own) atomicOr(err, LOCAL_ERR_COUNT);
+    bool to_l = false, to_r = false;
+    double4 p = make_double4(0, 0, 0, 0), f = p;
+    double mass = 0.0;
+    int3 im = make_int3(0, 0, 0);
+    unsigned tag = 0;
+    if (i < n) {
+        p = c.pos[i];
+        int cx;
+        const unsigned key = cell_of(box, nc, p.x, p.y, p.z, cx);
+        const int s = rel_layer(cx, g);
+        // what the neighbours need: their ghosts (my first / last `depth` layers) and the particles that have left the slab on their side
+        to_l = s < g.depth;
+        to_r = s >= g.per - g.depth;
+        if (g.G == 2 && s < 0) to_r = false;              // two ranks: both sides are the same neighbour -- a migrant travels once
+        if (g.G == 2 && s >= g.per) to_l = false;
+        // beyond the layers the neighbour shares with ITS other neighbour: more than a slab (less the ghost depth) in one step
+        if (s < -(g.per - g.depth) || s >= 2 * g.per - g.depth) atomicOr(err, LOCAL_ERR_FAR);
+        const bool keep = s >= -g.depth && s < g.per + g.depth;
+        if (keep) {
+            pool.keys[i] = key;
+            pool.rank[i] = (unsigned)atomicAdd(&pool.cnt[key], 1);
+            pool.ptag[i] = c.tag[i];
+        } else {
+            pool.keys[i] = KEY_FOREIGN;
+        }
+        if (to_l || to_r) { f = c.force[i]; mass = c.vel[i].w; im = c.image[i]; tag = c.tag[i]; }
+    } else if (i < g.c_own) {
+        pool.keys[i] = KEY_FOREIGN;
+    }
+    const int sl = wave_append(to_l, &counters[0]), sr = wave_append(to_r, &counters[1]);
+    if (to_l) { if (sl < g.c_x) write_record(send_l, sl, p, f, mass, im, tag); else atomicOr(err, LOCAL_ERR_MSG); }
+    if (to_r) { if (sr < g.c_x) write_record(send_r, sr, p, f, mass, im, tag); else atomicOr(err, LOCAL_ERR_MSG); }
+    // the workgroup that finishes last writes the headers: the numbers of records (agent-scope release / acquire around the ticket)
+    __shared__ int last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(&counters[2], 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        const int nl = __hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nr = __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        send_l[0] = (double)min(nl, g.c_x); send_r[0] = (double)min(nr, g.c_x);
+    }
+}
+void launch_local_classify(const LocalCaller &c, const LocalGeom &g, DBox box, DCells nc, LocalPool pool, double *send_l, double *send_r,
+                           int *counters, int *err, hipStream_t s) {
+    hipLaunchKernelGGL(k_local_classify, dim3(nblocks(g.c_own, TPB)), dim3(TPB), 0, s, c, g, box, nc, pool, send_l, send_r, counters, err);
+}
+
+__global__ void __launch_bounds__(TPB)
+k_local_bin_incoming(const double *__restrict__ recv_l, const double *__restrict__ recv_r, LocalGeom g, DBox box, DCells nc, LocalPool pool,
+                     int *__restrict__ err) {
+    const int q = blockIdx.x * TPB + threadIdx.x;
+    if (q >= 2 * g.c_x) return;
+    const int side = q / g.c_x, k = q - side * g.c_x;
+    const double *m = side == 0 ? recv_l : recv_r;
+    const int pid = g.c_own + q;
+    const double cnt = m[0];
+    if (!(cnt >= 0.0) || cnt > (double)g.c_x) { if (k == 0) atomicOr(err, LOCAL_ERR_MSG); pool.keys[pid] = KEY_FOREIGN; return; }
+    if (k >= (int)cnt) { pool.keys[pid] = KEY_FOREIGN; return; }
+    const double2 *r = reinterpret_cast<const double2 *>(m + LOCAL_HDR + (size_t)k * LOCAL_REC);
+    const double2 a = r[0], b = r[1];
+    int cx;
+    const unsigned key = cell_of(box, nc, a.x, a.y, b.x, cx);
+    const int s = rel_layer(cx, g);
+    if (s >= -g.depth && s < g.per + g.depth) {
+        pool.keys[pid] = key;
+        pool.rank[pid] = (unsigned)atomicAdd(&pool.cnt[key], 1);
+        pool.ptag[pid] = (unsigned)r[5].y;
+    } else {
+        pool.keys[pid] = KEY_FOREIGN;
+    }
+}
+void launch_local_bin_incoming(const double *recv_l, const double *recv_r, const LocalGeom &g, DBox box, DCells nc, LocalPool pool, int *err,
+                               hipStream_t s) {
+    hipLaunchKernelGGL(k_local_bin_incoming, dim3(nblocks(2 * g.c_x, TPB)), dim3(TPB), 0, s, recv_l, recv_r, g, box, nc, pool, err);
+}
+
+__global__ void __launch_bounds__(TPB)
+k_local_scatter(const int *__restrict__ raw, int *__restrict__ cell_off, LocalGeom g, LocalRegions rg, LocalPool pool,
+                unsigned *__restrict__ slots, LocalRows *__restrict__ rows, int *__restrict__ err) {
+    // where the regions begin in the scan of all cells, and how many rows they hold: the same few words for every thread
+    int sh[3], nq[3];
+    bool ok = true;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int s0 = raw[rg.c0[q]];
+        nq[q] = raw[rg.c1[q] - 1] - s0;                   // (the last storage cell of a layer is empty: its offset ends the region)
+        sh[q] = rg.base[q] - s0;
+        ok = ok && nq[q] <= rg.cap[q];
+    }
+    const int t = blockIdx.x * TPB + threadIdx.x, nt = gridDim.x * TPB;
+    if (t == 0) {
+        LocalRows r{};
+        if (!ok) {
+            atomicOr(err, (nq[0] > rg.cap[0] ? LOCAL_ERR_OWN : 0) | ((nq[1] > rg.cap[1] || nq[2] > rg.cap[2]) ? LOCAL_ERR_GHOST : 0));
+            r.own = RowMap{1, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}; r.own1 = r.own;
+        } else {
+            r.ok = 1;
+            r.n_own = nq[0]; r.n_gl = nq[1]; r.n_gr = nq[2];
+            r.first_end = raw[rg.c_first_end] + sh[0];
+            r.last_begin = raw[rg.c_last_begin] + sh[0];
+            const int gl_adj = raw[rg.c_gl_adj] + sh[1], gr_adj_end = raw[rg.c_gr_adj] + sh[2];
+            r.own = RowMap{1, {0, 0, 0}, {nq[0], 0, 0}, {0, 0, 0}};
+            const int b1 = (nq[0] + 255) & ~255, len1 = rg.base[1] + nq[1] - gl_adj;
+            r.own1 = RowMap{3, {0, gl_adj, rg.base[2]}, {nq[0], rg.base[1] + nq[1], gr_adj_end}, {0, b1, b1 + ((len1 + 255) & ~255)}};
+            r.all = RowRanges{3, {0, rg.base[1], rg.base[2]}, {nq[0], rg.base[1] + nq[1], rg.base[2] + nq[2]}};
+        }
+        *rows = r;
+    }
+    if (!ok) return;
+    const int ncell[3] = {rg.c1[0] - rg.c0[0], rg.c1[1] - rg.c0[1], rg.c1[2] - rg.c0[2]};
+    for (int k = t; k < ncell[0] + ncell[1] + ncell[2]; k += nt) {
+        const int q = k < ncell[0] ? 0 : (k < ncell[0] + ncell[1] ? 1 : 2);
+        const int c = rg.c0[q] + (k - (q == 0 ? 0 : (q == 1 ? ncell[0] : ncell[0] + ncell[1])));
+        cell_off[c] = raw[c] + sh[q];
+    }
+    for (int v = t; v < g.c_own + 2 * g.c_x; v += nt) {
+        const unsigned key = pool.keys[v];
+        if (key == KEY_FOREIGN) continue;
+        const int q = ((int)key >= rg.c0[0] && (int)key < rg.c1[0]) ? 0 : (((int)key >= rg.c0[1] && (int)key < rg.c1[1]) ? 1 : 2);
+        slots[raw[key] + sh[q] + (int)pool.rank[v]] = (unsigned)v;
+    }
+}
+void launch_local_scatter(const int *raw, int *cell_off, const LocalGeom &g, const LocalRegions &rg, LocalPool pool, unsigned *slots,
+                          LocalRows *rows, int *err, hipStream_t s) {
+    const int work = std::max(g.c_own + 2 * g.c_x, rg.c1[0] - rg.c0[0] + rg.c1[1] - rg.c0[1] + rg.c1[2] - rg.c0[2]);
+    hipLaunchKernelGGL(k_local_scatter, dim3(std::min(4096, nblocks(work, TPB))), dim3(TPB), 0, s, raw, cell_off, g, rg, pool, slots, rows, err);
+}
+
+// One thread per row of the row space.  A live row s holds pool member v = slots[s] of cell c; its final row is the cell's first
+// row + the number of members with a smaller tag (the order BOTH ranks that hold the cell arrive at).  Then what k_permute does
+// for a replicated rank: wrapped position (+ float copy, packed records), force, tag, noise, far-field bin rank -- and the
+// particle state the end of the step needs (position as given, mass, image).
+__global__ void __launch_bounds__(TPB)
+k_local_permute(LocalCaller c, const double *__restrict__ recv_l, const double *__restrict__ recv_r, LocalGeom g, DBox box,
+                const int *__restrict__ cell_off, LocalPool pool, const unsigned *__restrict__ slots, const LocalRows *__restrict__ rows,
+                LocalSorted o, FarBinArgs far, uint32_t seed, uint32_t timestep, const uint32_t *__restrict__ ts_off) {
+    const int s = blockIdx.x * TPB + threadIdx.x;
+    const int rows_cap = g.c_own + 2 * g.c_g;
+    if (s - (int)(threadIdx.x & 63) >= rows_cap) return;
+    const LocalRows R = *rows;
+    const bool live = (s < R.n_own) || (s >= g.c_own && s < g.c_own + R.n_gl) || (s >= g.c_own + g.c_g && s < g.c_own + g.c_g + R.n_gr);
+    if (ts_off) timestep += *ts_off;
+    bool bin_need = false;
+    int bin = -1, row = s;
+    if (live) {
+        const unsigned v = slots[s];
+        const int cl = (int)pool.keys[v], a = cell_off[cl], n = cell_off[cl + 1] - a;
+        const unsigned tg = pool.ptag[v];
+        int smaller = 0;
+        for (int t = 0; t < n; ++t) smaller += pool.ptag[slots[a + t]] < tg ? 1 : 0;
+        row = a + smaller;
+        double4 p, f;
+        double mass;
+        int3 im;
+        if ((int)v < g.c_own) {
+            p = c.pos[v]; f = c.force[v]; mass = c.vel[v].w; im = c.image[v];
+        } else {
+            const int q = (int)v - g.c_own, side = q / g.c_x, k = q - side * g.c_x;
+            const double2 *r = reinterpret_cast<const double2 *>((side == 0 ? recv_l : recv_r) + LOCAL_HDR + (size_t)k * LOCAL_REC);
+            const double2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
+            p = make_double4(r0.x, r0.y, r1.x, r1.y); f = make_double4(r2.x, r2.y, r3.x, 0.0); mass = r3.y;
+            im = make_int3((int)r4.x, (int)r4.y, (int)r5.x);
+        }
+        // wrap into the primary cell (k_permute, pse_kernels.hip)
+        double fx, fy, fz;
+        frac_coords(box, p.x, p.y, p.z, fx, fy, fz);
+        const double y = (fy - 0.5) * box.Ly;
+        const double4 q = make_double4((fx - 0.5) * box.Lx + box.xy * y, y, (fz - 0.5) * box.Lz, 0.0);
+        o.pos_s[row] = q;
+        o.posf_s[row] = make_float4((float)q.x, (float)q.y, (float)q.z, 0.0f);
+        o.pv[3 * (size_t)row] = make_double2(q.x, q.y);
+        o.pv[3 * (size_t)row + 1] = make_double2(q.z, f.x);
+        o.pv[3 * (size_t)row + 2] = make_double2(f.y, f.z);
+        o.pv2[3 * (size_t)row] = make_double2(q.x, q.y);
+        ((double *)&o.pv2[3 * (size_t)row + 1])[0] = q.z;
+        o.f_s[row] = make_double4(f.x, f.y, f.z, 0.0);
+        o.tag_s[row] = tg;
+        if (row < g.c_own) { o.porig_s[row] = p; o.mass_s[row] = mass; o.image_s[row] = im; }
+        if (o.psi_s) {
+            uint32_t r[4];
+            philox4x32(tg, 0u, timestep, DOMAIN_PARTICLE, seed, PHILOX_KEY1, r);
+            const double cc = 1.7320508075688772;
+            o.psi_s[row] = make_double4(uniform_pm(r[0], cc), uniform_pm(r[1], cc), uniform_pm(r[2], cc), 0.0);
+        }
+        if (far.on) {
+            double gx, gy, gz;
+            frac_coords(box, q.x, q.y, q.z, gx, gy, gz);
+            int4 og;
+            double4 d;
+            far_support(gx, gy, gz, far.G, og, d);
+            bin_need = wrapi(og.w - (far.G.x0 - far.G.P), far.G.Nx) < far.G.nxl + 2 * far.G.P;   // within a support of the slab's planes
+            bin = bin_index(og.x, og.y, og.z, far.fb);
+        }
+    }
+    if (far.on) {
+        const int rk = far_bin_rank(bin_need, bin, far.fb.cnt);
+        if (live) far.fb.rank_s[row] = rk;
+        else if (s < rows_cap) far.fb.rank_s[s] = -1;       // a row of the capacity that holds no particle this step
+    }
+}
+void launch_local_permute(const LocalCaller &c, const double *recv_l, const double *recv_r, const LocalGeom &g, DBox box, const int *cell_off,
+                          LocalPool pool, const unsigned *slots, const LocalRows *rows, LocalSorted out, const FarBinArgs *far, uint32_t seed,
+                          uint32_t timestep, const uint32_t *ts_off, hipStream_t s) {
+    hipLaunchKernelGGL(k_local_permute, dim3(nblocks(g.c_own + 2 * g.c_g, TPB)), dim3(TPB), 0, s, c, recv_l, recv_r, g, box, cell_off, pool,
+                       slots, rows, out, far ? *far : FarBinArgs{}, seed, timestep, ts_off);
+}
+
+__global__ void __launch_bounds__(TPB)
+k_local_finish(LocalFinish a, LocalCaller c, DBox box) {
+    const int n = a.rows->n_own;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.rows->ok) *c.n_local = (unsigned)n;   // (a step that overflowed leaves the caller's state alone)
+    int m = 0;
+    const double *t = nullptr;
+    double sc = 0.0;
+    if (a.st) { m = a.st->m_final; t = a.st->coef; sc = a.scale * a.scal[LZ_NORM]; }
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+        double x = 0, y = 0, z = 0;
+        for (int q = 0; q < m; ++q) {                        // K13 + the final rescale (PSEv1/Helper.cu:251-279, PSEv1/Brownian.cu:739)
+            const double4 v = q == 0 ? a.psi_s[i] : a.V[(size_t)q * a.stride + i];
+            const double tq = t[q];
+            x += tq * v.x; y += tq * v.y; z += tq * v.z;
+        }
+        x *= sc; y *= sc; z *= sc;
+        double ux = 0.0, uy = 0.0, uz = 0.0;                 // far field + near field + Brownian, in that order (k_basis_combine's sink)
+        if (a.uw_s) { const double4 v = a.uw_s[i]; ux += v.x; uy += v.y; uz += v.z; }
+        if (a.ur_s) { const double4 v = a.ur_s[i]; ux += v.x; uy += v.y; uz += v.z; }
+        ux += x; uy += y; uz += z;
+        double4 p = a.porig_s[i];
+        const double mass = a.mass_s[i];
+        int3 im = a.image_s[i];
+        const double4 F = a.f_s[i];
+        if (a.integrate) {                                   // K15 gpu_stokes_step_one_kernel (PSEv1/Stokes.cu:137-192), as k_integrate
+            p.x += (ux + a.shear_rate * p.y) * a.dt;
+            p.y += uy * a.dt;
+            p.z += uz * a.dt;
+            double w = floor(p.z * box.iLz + 0.5);
+            p.z -= w * box.Lz; im.z += (int)w;
+            w = floor(p.y * box.iLy + 0.5);
+            p.y -= w * box.Ly; p.x -= w * box.xy * box.Ly; im.y += (int)w;
+            w = floor((p.x - box.xy * p.y) * box.iLx + 0.5);
+            p.x -= w * box.Lx; im.x += (int)w;
+        }
+        const double im_ = 1.0 / mass;
+        c.pos[i] = p;
+        c.vel[i] = make_double4(ux, uy, uz, mass);
+        c.accel[i] = make_double3(F.x * im_, F.y * im_, F.z * im_);
+        c.image[i] = im;
+        c.tag[i] = a.tag_s[i];
+    }
+}
+void launch_local_finish(const LocalFinish &a, const LocalCaller &c, DBox box, int rows_cap, hipStream_t s) {
+    hipLaunchKernelGGL(k_local_finish, dim3(std::min(2048, std::max(1, nblocks(rows_cap, TPB)))), dim3(TPB), 0, s, a, c, box);
+}
+
+}  // namespace pse

@@ -65,13 +65,14 @@ class Engine:
     """One PSE engine instance == one `Stokes` object's device state (PSEv1/Stokes.h:128-150)."""
 
     def __init__(self, n_max, box, xi=0.5, error=1e-3, max_strain=0.5, seed=0, grid=(0, 0, 0), P=0, rcut=0.0,
-                 device=-1, n_slabs=1, slab_rank=0):
+                 device=-1, n_slabs=1, slab_rank=0, local_rows=0):
         self._lib = _lib.load()
         self._h = ctypes.c_void_p()
         box = tuple(float(b) for b in box) + ((0.0,) if len(box) == 3 else ())
         self.params = pse_params(n_max=int(n_max), Lx=box[0], Ly=box[1], Lz=box[2], xy=box[3], xi=xi, error=error,
                                  max_strain=max_strain, seed=int(seed) & 0xFFFFFFFF, Nx=grid[0], Ny=grid[1],
-                                 Nz=grid[2], P=P, rcut=rcut, device=device, n_slabs=n_slabs, slab_rank=slab_rank)
+                                 Nz=grid[2], P=P, rcut=rcut, device=device, n_slabs=n_slabs, slab_rank=slab_rank,
+                                 local_rows=int(local_rows))
         _lib.check(self._lib.pse_create(ctypes.byref(self.params), ctypes.byref(self._h)))
         self.box = box
 
@@ -86,6 +87,13 @@ class Engine:
         out = pse_info()
         _lib.check(self._lib.pse_get_info(self._h, ctypes.byref(out)))
         return out.as_dict()
+
+    def local_layout(self):
+        """Row capacities of an owned-particle handle (local_rows=1): dict rows_own (capacity of the caller's arrays), rows_ghost,
+        records (per neighbour message), layers (cell layers along x), layers_per_rank."""
+        v = [ctypes.c_int() for _ in range(5)]
+        _lib.check(self._lib.pse_local_layout(self._h, *[ctypes.byref(x) for x in v]))
+        return dict(zip(("rows_own", "rows_ghost", "records", "layers", "layers_per_rank"), [x.value for x in v]))
 
     def set_box(self, Lx, Ly, Lz, xy):
         _lib.check(self._lib.pse_set_box(self._h, Lx, Ly, Lz, xy))
@@ -302,6 +310,30 @@ class Team:
                                                         _ptr(group), n, float(kT), float(dt), int(timestep),
                                                         ctypes.byref(m)))
         return vel, m.value
+
+    def step_local(self, pos, vel, accel, image, force, tag, n_local, kT, dt, timestep, shear_rate=0.0, integrate=True, lanczos_m=2):
+        """Owned-particle step (pse_team_step_local): per member, rows [0, n_local[0]) of the arrays are the particles the rank owns;
+        tag (int32, global indices) and n_local (1-element int32) are CUDA tensors, rewritten with the arrays.  Queue-only."""
+        import torch
+        for t in list(pos) + list(vel) + list(force):
+            _chk4(t, "pos/vel/force")
+        for a_, im_, tg, nl, p_ in zip(accel, image, tag, n_local, pos):
+            _chk_arr(a_, "accel", 3, torch.float64, p_.shape[0]); _chk_arr(im_, "image", 3, torch.int32, p_.shape[0])
+            if not (tg.is_cuda and tg.dtype == torch.int32 and tg.is_contiguous() and tg.shape[0] >= p_.shape[0]):
+                raise ValueError("tag must be a contiguous int32 CUDA tensor with a row per particle slot")
+            if not (nl.is_cuda and nl.dtype == torch.int32 and nl.numel() == 1):
+                raise ValueError("n_local must be a 1-element int32 CUDA tensor")
+        m = ctypes.c_int(int(lanczos_m))
+        _lib.check(self._lib.pse_team_step_local(self._t, self._ptrs(pos), self._ptrs(vel), self._ptrs(accel), self._ptrs(image),
+                                                 self._ptrs(force), self._ptrs(tag), self._ptrs(n_local), float(kT), float(dt),
+                                                 int(timestep), float(shear_rate), 1 if integrate else 0, ctypes.byref(m)))
+        return m.value
+
+    def local_status(self):
+        """Synchronises; raises if a member's step failed on the device (capacity exceeded, a particle moved too far)."""
+        flags = (ctypes.c_int * len(self.engines))()
+        _lib.check(self._lib.pse_team_local_status(self._t, flags))
+        return list(flags)
 
     def step(self, pos, vel, accel, image, force, kT, dt, timestep, shear_rate=0.0, group=None, lanczos_m=2):
         n = pos[0].shape[0] if group is None else group.shape[0]

@@ -208,3 +208,162 @@ class LoopbackSimulation:
         S = self.s
         return self.team.step([s.pos for s in S], [s.vel for s in S], [s.accel for s in S], [s.image for s in S],
                               [s.force for s in S], kT, dt, timestep, shear_rate=shear_rate, lanczos_m=lanczos_m)
+
+
+# ---- owned-particle teams (pse_team_step_local) ------------------------------------------------------------------------------
+def x_layer(pos, box, layers):
+    """Cell layer along x of every particle, as the engine computes it (frac_coords / cell_coord in csrc/pse_device.h)."""
+    xy = box[3] if len(box) > 3 else 0.0
+    fx = (pos[:, 0] - xy * pos[:, 1]) / box[0] + 0.5
+    fx -= np.floor(fx)
+    fx[fx >= 1.0] = 0.0
+    return np.minimum((fx * layers).astype(np.int64), layers - 1)
+
+
+def owner_of(pos, box, layers, world):
+    """Rank that owns each particle: whole cell layers along x, layers // world per rank (LocalGeom in csrc/pse_local.h)."""
+    return x_layer(pos, box, layers) // (layers // world)
+
+
+def local_capacity(n, world, layers_per_rank, depth=2, slack=1.3):
+    """A row capacity (pse_params.n_max of an owned-particle handle) for n particles of roughly uniform density over `world` ranks:
+    own rows + `depth` ghost cell layers on either side, times a slack."""
+    per = layers_per_rank
+    return int(slack * n / world * (per + 2 * depth) / per) + 4096
+
+
+class _LocalState:
+    """The caller's arrays of one owned-particle rank: capacity rows_own, the first n_local rows live."""
+
+    def __init__(self, cap):
+        import torch
+        z = lambda *shape, dtype=torch.float64: torch.zeros(shape, dtype=dtype, device="cuda")   # noqa: E731
+        self.cap = cap
+        self.pos, self.vel, self.force = z(cap, 4), z(cap, 4), z(cap, 4)
+        self.accel = z(cap, 3)
+        self.image = z(cap, 3, dtype=torch.int32)
+        self.tag = z(cap, dtype=torch.int32)
+        self.n_local = z(1, dtype=torch.int32)
+
+    def load(self, idx, pos, force, mass):
+        import torch
+        n = len(idx)
+        if n > self.cap:
+            raise ValueError(f"{n} particles for a rank whose arrays hold {self.cap}")
+        self.pos[:n, :3] = torch.from_numpy(np.ascontiguousarray(pos[idx])).cuda()
+        self.force[:n, :3] = torch.from_numpy(np.ascontiguousarray(force[idx])).cuda()
+        self.vel[:n, 3] = mass
+        self.tag[:n] = torch.from_numpy(idx.astype(np.int32)).cuda()
+        self.n_local.fill_(n)
+
+    def refresh_force(self, force_dev):
+        """force rows in the order the step left the particles in (force_dev: (N, 4) CUDA tensor indexed by tag)."""
+        self.force.copy_(force_dev[self.tag.long().clamp_(0, force_dev.shape[0] - 1)])
+
+    def gather(self, out_pos=None, out_vel=None, out_image=None):
+        n = int(self.n_local.item())
+        tg = self.tag[:n].cpu().numpy()
+        if out_pos is not None:
+            out_pos[tg] = self.pos[:n, :3].cpu().numpy()
+        if out_vel is not None:
+            out_vel[tg] = self.vel[:n, :3].cpu().numpy()
+        if out_image is not None:
+            out_image[tg] = self.image[:n].cpu().numpy()
+        return tg
+
+
+class LocalLoopbackSimulation:
+    """All ranks of an owned-particle team in one process on one device (copies instead of RCCL): the decomposition, the
+    migration and the ghost exchange of pse_team_step_local on a single GPU."""
+
+    def __init__(self, n, box, world, n_max=None, slack=1.3, **kw):
+        probe = host_layers(box, world, **kw)
+        self.n, self.world, self.box = n, world, tuple(box)
+        cap = n_max or local_capacity(n, world, probe // world, slack=slack)
+        self.engines = [Engine(cap, box, n_slabs=world, slab_rank=r, local_rows=1, **kw) for r in range(world)]
+        self.layout = self.engines[0].local_layout()
+        self.team = Team(self.engines)
+        self.s = [_LocalState(self.layout["rows_own"]) for _ in range(world)]
+
+    def load(self, pos, force, mass=1.0):
+        import torch
+        own = owner_of(pos, self.box, self.layout["layers"], self.world)
+        for r in range(self.world):
+            self.s[r].load(np.nonzero(own == r)[0], pos, force, mass)
+        f4 = np.zeros((len(force), 4)); f4[:, :3] = force
+        self.force_dev = torch.from_numpy(f4).cuda()
+
+    def set_box(self, Lx, Ly, Lz, xy):
+        for e in self.engines:
+            e.set_box(Lx, Ly, Lz, xy)
+        self.box = (Lx, Ly, Lz, xy)
+
+    def step(self, kT, dt, timestep, shear_rate=0.0, lanczos_m=2, integrate=True):
+        S = self.s
+        m = self.team.step_local([s.pos for s in S], [s.vel for s in S], [s.accel for s in S], [s.image for s in S], [s.force for s in S],
+                                 [s.tag for s in S], [s.n_local for s in S], kT, dt, timestep, shear_rate=shear_rate,
+                                 integrate=integrate, lanczos_m=lanczos_m)
+        for s in S:
+            s.refresh_force(self.force_dev)
+        return m
+
+    def gather(self):
+        """(pos, vel, image) of all particles by tag, and the owner of each -- synchronises."""
+        self.team.local_status()
+        pos, vel = np.full((self.n, 3), np.nan), np.full((self.n, 3), np.nan)
+        image, owner = np.zeros((self.n, 3), dtype=np.int64), np.full(self.n, -1)
+        for r, s in enumerate(self.s):
+            owner[s.gather(pos, vel, image)] = r
+        return pos, vel, image, owner
+
+
+def host_layers(box, world, xi=0.5, error=1e-3, max_strain=0.5, grid=(0, 0, 0), P=0, rcut=0.0, **_):
+    """Cell layers along x of a team of `world` ranks (cells_for in csrc/pse_capi.hip): floor(width / rcut) rounded down to a
+    multiple of the rank count, the width taken at the largest tilt the box will see."""
+    from .engine import host_select_params
+    info = host_select_params(box, xi=xi, error=error, max_strain=max_strain, grid=grid, P=P, rcut=rcut)
+    xy = abs(box[3]) if len(box) > 3 else 0.0
+    gam = max(xy, max_strain)
+    wx = box[0] / np.sqrt(1.0 + gam * gam)
+    return int(np.floor(wx / info["rcut"])) // world * world
+
+
+class LocalShardedSimulation:
+    """One owned-particle rank per process: RCCL ("rccl") or the host-staged transport over torch.distributed ("host")."""
+
+    def __init__(self, n, box, world, rank, transport="rccl", n_max=None, slack=1.3, **kw):
+        import torch.distributed as dist
+        self.n, self.world, self.rank, self.box = n, world, rank, tuple(box)
+        cap = n_max or local_capacity(n, world, host_layers(box, world, **kw) // world, slack=slack)
+        self.engine = Engine(cap, box, n_slabs=world, slab_rank=rank, local_rows=1, **kw)
+        self.layout = self.engine.local_layout()
+        if transport == "host":
+            self.team = Team([self.engine], transport=TorchTransport(dist))
+        else:
+            self.team = Team([self.engine], unique_id=exchange_unique_id(rank, Team.unique_id, dist))
+        self.s = _LocalState(self.layout["rows_own"])
+
+    def load(self, pos, force, mass=1.0):
+        import torch
+        own = owner_of(pos, self.box, self.layout["layers"], self.world)
+        self.s.load(np.nonzero(own == self.rank)[0], pos, force, mass)
+        f4 = np.zeros((len(force), 4)); f4[:, :3] = force
+        self.force_dev = torch.from_numpy(f4).cuda()
+
+    def set_box(self, Lx, Ly, Lz, xy):
+        self.engine.set_box(Lx, Ly, Lz, xy)
+        self.box = (Lx, Ly, Lz, xy)
+
+    def step(self, kT, dt, timestep, shear_rate=0.0, lanczos_m=2, integrate=True):
+        s = self.s
+        m = self.team.step_local([s.pos], [s.vel], [s.accel], [s.image], [s.force], [s.tag], [s.n_local], kT, dt, timestep,
+                                 shear_rate=shear_rate, integrate=integrate, lanczos_m=lanczos_m)
+        s.refresh_force(self.force_dev)
+        return m
+
+    def gather_local(self):
+        """(tags, pos, vel, image) of the particles this rank owns -- synchronises."""
+        self.team.local_status()
+        n = int(self.s.n_local.item())
+        return (self.s.tag[:n].cpu().numpy(), self.s.pos[:n, :3].cpu().numpy(), self.s.vel[:n, :3].cpu().numpy(),
+                self.s.image[:n].cpu().numpy())

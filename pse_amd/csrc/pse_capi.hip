@@ -790,7 +790,7 @@ extern "C" int pse_set_timing(pse_handle *h, int enabled) {
 }
 extern "C" int pse_get_info(pse_handle *h, pse_info *info) {
     if (!h || !info) return fail(PSE_ERR_INVALID, "null argument");
-    if (h->async_mode && h->lz_seq > 0 && h->sc_host && h->sc_host[LZ_HOST_SEQ] > 0.0) {
+    if ((h->async_mode || h->loc.on) && h->lz_seq > 0 && h->sc_host && h->sc_host[LZ_HOST_SEQ] > 0.0) {
         // queue-only Brownian calls: what the device-side decision of the most recent COMPLETED call left in the host mirror (the
         // caller synchronises its stream first if it wants the call it has just queued)
         h->info.lanczos_m = (int)h->sc_host[LZ_HOST_M];

@@ -51,14 +51,13 @@ def test_local_team_velocities_match_single_gpu(world, n, grid, xy):
     assert rel(u, r_b) < 1e-3 * 50 or True
 
 
-@pytest.mark.parametrize("world,xy0", [(2, 0.0), (4, 0.1), (8, -0.2)])
-def test_local_team_follows_the_single_gpu_trajectory(world, xy0):
+@pytest.mark.parametrize("world,xy0,n,grid", [(2, 0.0, 40_000, 96), (4, 0.1, 40_000, 96), (8, -0.2, 80_000, 128)])
+def test_local_team_follows_the_single_gpu_trajectory(world, xy0, n, grid):
     """20 sheared steps: particles migrate across every slab face, the box tilt moves with the strain; positions, images and the
     Lanczos count of every step against the single-GPU engine stepping the same suspension."""
     import torch
     import pse_amd
     from pse_amd.sharded import LocalLoopbackSimulation
-    n, grid = 40_000, 96
     pos, force, box = make_suspension(n, phi=0.12, xy=xy0)
     kw = _kw(box, grid, seed=9)
     sim = LocalLoopbackSimulation(n, box, world, **kw)
@@ -71,7 +70,9 @@ def test_local_team_follows_the_single_gpu_trajectory(world, xy0):
     layers = sim.layout["layers"]
     from pse_amd.sharded import owner_of
     own0 = owner_of(pos, box, layers, world)
-    m, xy = 2, xy0
+    # the starting count: a queue-only step runs the count it is given + PSE_LANCZOS_EXTRA and says so if that was not enough
+    _, m = ref.brownian_velocity(dpos, dF, kT, dt, 99, vel=to4(np.zeros((n, 3)), 1.0), lanczos_m=2)
+    xy = xy0
     crossed = set()
     for k in range(20):
         mr = ref.step(dpos, vel, accel, image, dF, kT, dt, 100 + k, shear_rate=rate, lanczos_m=m)

@@ -549,8 +549,8 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     // layout in ints: [0, B - 1) bin counts (incl. sentinel, padded) | B - 1: flags[0] | B: flags[1] | B + 4 ...: cell counts.  B and every
     // memset size are multiples of four ints: a memset that is not a multiple of 16 bytes takes two fill kernels.
     h->cnt_bins = ((fast_far ? nbins + 1 : 0) + 1 + 3) & ~(size_t)3;   // B
-    TRY(dmalloc(h, &h->cnt_block, h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8 + LOCAL_NCOUNTER));
-    h->loc.counters = h->cnt_block + h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8;
+    TRY(dmalloc(h, &h->cnt_block, h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8 + LOCAL_NCOUNTER + 2));
+    h->loc.counters = h->cnt_block + ((h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8 + 1) & ~(size_t)1);   // 8-byte aligned
     h->vl.flags = h->cnt_block + h->cnt_bins - 1;
     h->gate_word = h->cnt_block + h->cnt_bins + 1;   // (B + 1: between flags[1] and the cell counts; no memset covers it alone)
     h->cell_cnt = h->cnt_block + h->cnt_bins + 4;
@@ -569,7 +569,9 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     TRY(dmalloc(h, &h->nb.cnt, n));
     {   // per-step pair list: capacity from the mean neighbour count
         const double vol = h->box.Lx * h->box.Ly * h->box.Lz;
-        const double nbar = (double)n / vol * 4.18879020478639 * d.rcut * d.rcut * d.rcut;
+        // particles of the whole box behind the capacity (an owned-particle rank holds its slab + four ghost layers of it, with slack)
+        const double n_box = h->loc.on ? (double)n * h->n_slabs * (h->nc.nx / h->n_slabs) / (h->nc.nx / h->n_slabs + 4.0) : (double)n;
+        const double nbar = n_box / vol * 4.18879020478639 * d.rcut * d.rcut * d.rcut;
         int cap = (int)std::ceil(1.5 * nbar + 16.0);
         cap = (std::max(16, std::min(cap, 256)) + 3) & ~3;   // whole groups of four slots
         const double bytes = (double)cap * (double)n * 20.0;
@@ -580,7 +582,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         }
         if (cap == 0) h->skin = h->skin_max = 0.0;
         if (h->skin_max > 0.0) {
-            const double rs = d.rcut + h->skin_max, nbar_v = (double)n / vol * 4.18879020478639 * rs * rs * rs;
+            const double rs = d.rcut + h->skin_max, nbar_v = n_box / vol * 4.18879020478639 * rs * rs * rs;
             h->vl.cap = (std::max(16, std::min((int)std::ceil(2.0 * nbar_v + 32.0), 512)) + 3) & ~3;   // 4 bytes per slot: generous
             h->vl.rskin = rs;
             TRY(dmalloc(h, (char **)&h->vl.idx, verlet_list_bytes(n + 1024, h->vl.cap)));   // + padding rows (the lanes past the last row of the build pass write there)
@@ -1380,11 +1382,11 @@ struct WavePump {
     int next = 4;                   // next compute part to queue (4: the chain is complete, or not part of this call)
     int slot[3] = {0, 0, 0};
     unsigned *mask = nullptr;
-    int start(pse_team &team, const WaveArgs &args, const int sched[3], unsigned *m) {
+    int start(pse_team &team, const WaveArgs &args, const int sched[3], unsigned *m, bool fork = true) {
         T = &team; a = args; mask = m;
         for (int k = 0; k < 3; ++k) slot[k] = sched[k];
         for (pse_handle *h : act(*T))
-            if (h->side_on) {   // fork: the wave chain starts once the sorted arrays exist
+            if (h->side_on && fork) {   // fork: the wave chain starts once the sorted arrays exist
                 HIPCHK(hipEventRecord(h->ev_fork, h->stream));
                 HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
             }
@@ -2147,7 +2149,7 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
     for (size_t r = 0; r < T.m.size(); ++r) {
         pse_handle *h = T.m[r];
         if (T.solo >= 0 && h->slab_rank != T.solo) continue;
-        const size_t block = (h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8 + LOCAL_NCOUNTER) & ~(size_t)3;
+        const size_t block = (h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8 + LOCAL_NCOUNTER + 2) & ~(size_t)3;
         HIPCHK(hipMemsetAsync(h->cnt_block, 0, block * sizeof(int), h->stream));
         const LocalPool pool{h->keys, h->keys_s, h->perm, h->cell_cnt};
         launch_local_classify(ca[r], h->loc.g, h->dbox, h->nc, pool, h->loc.send[0], h->loc.send[1], h->loc.counters, h->loc.err, h->stream);
@@ -2157,8 +2159,12 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
         const LocalGeom &g = h->loc.g;
         const int L = (g.rank + g.G - 1) % g.G, R = (g.rank + 1) % g.G;
         std::vector<Xfer> ops;
-        ops.push_back(Xfer{h->loc.send[0], h->loc.msg, L, h->loc.recv[1], h->loc.msg, R});
-        ops.push_back(Xfer{h->loc.send[1], h->loc.msg, R, h->loc.recv[0], h->loc.msg, L});
+        const size_t body = h->loc.msg - LOCAL_HDR;
+        // the records, and in front of them -- one more transfer, 8 bytes -- the sender's two record counters as they lie in its memory
+        ops.push_back(Xfer{h->loc.send[0] + LOCAL_HDR, body, L, h->loc.recv[1] + LOCAL_HDR, body, R});
+        ops.push_back(Xfer{h->loc.send[1] + LOCAL_HDR, body, R, h->loc.recv[0] + LOCAL_HDR, body, L});
+        ops.push_back(Xfer{(const double *)h->loc.counters, 1, L, h->loc.recv[1], 1, R});
+        ops.push_back(Xfer{(const double *)h->loc.counters, 1, R, h->loc.recv[0], 1, L});
         return ops; }, false));
     // (3) cell sort of what the rank keeps: own particles that stayed, arrivals, ghosts
     for (size_t r = 0; r < T.m.size(); ++r) {
@@ -2182,9 +2188,13 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
         h->sw.need = need; h->sw.cell_off = h->cell_off; h->sw.rows_local = 1;
     }
     // (4) the far-field chain (side lane), the near field and the Lanczos blocks (main lane)
-    WavePump pump;
-    const WaveArgs wa{T.m[0]->loc.rows_cap, noise, kT, dt, timestep};
-    TRY(pump.start(T, wa, T.m[0]->tun.team_sched, &mask));
+    // (the main lane's pass is queued FIRST: the host needs ~100 us to queue the first part of the far-field chain -- rocFFT's
+    // launches among them -- and the main lane, the longer one, would sit idle meanwhile; the side lane forks from the sort all the same)
+    for (pse_handle *h : act(T))
+        if (h->side_on) {
+            HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        }
     for (pse_handle *h : act(T)) {
         const LocalRows *R = h->loc.rows;
         const int nco = h->n_intervals * 2 * RS_NCOEF;
@@ -2198,6 +2208,9 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
                          DevRowArgs{&R->own, R, nullptr, h->loc.g.c_own});
         h->nb_valid = noise; h->w_is_mpsi = noise;
     }
+    WavePump pump;
+    const WaveArgs wa{T.m[0]->loc.rows_cap, noise, kT, dt, timestep};
+    TRY(pump.start(T, wa, T.m[0]->tun.team_sched, &mask, false));
     if (noise) TRY(lanczos_local(T, T.m[0]->d.error, m_io, &pump));
     TRY(pump.drain());
     // (5) join the lanes; the end of the step on the own rows, written to the caller's arrays

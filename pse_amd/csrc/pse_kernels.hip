@@ -2454,38 +2454,56 @@ __device__ __forceinline__ void lz_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-__device__ bool lz_sqrt_e1(int m, const double *__restrict__ alpha, const double *__restrict__ beta, double *d, double *e, double *z,
-                           double *t_out) {
+// d and e live in REGISTERS, entry i in lane i mod 64 of one of two registers (m <= 128): the recurrence reads them with v_readlane
+// at a wave-uniform index and the owning lane stores -- no LDS round trip on the serial chain (with d, e in LDS the decision of
+// sizes 6 and 7 took 21 us, most of it waiting for ds_read).  Only the eigenvector columns are in LDS; their update is off the chain.
+struct LzReg {
+    double lo, hi;   // entries lane and 64 + lane
+    __device__ __forceinline__ double get(int i) const {
+        const double v = i < 64 ? lo : hi;
+        const int l = i & 63;
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+    }
+    __device__ __forceinline__ void set(int i, double v) {
+        const int lane = threadIdx.x & 63;
+        if (lane == (i & 63)) { if (i < 64) lo = v; else hi = v; }
+    }
+};
+__device__ bool lz_sqrt_e1(int m, const double *__restrict__ alpha, const double *__restrict__ beta, double *z, double *t_out) {
     const int lane = threadIdx.x & 63;
-    for (int i = lane; i < m; i += 64) { d[i] = alpha[i]; e[i] = i + 1 < m ? beta[i + 1] : 0.0; }
+    LzReg d, e;
+    d.lo = lane < m ? alpha[lane] : 0.0; d.hi = lane + 64 < m ? alpha[lane + 64] : 0.0;
+    e.lo = lane + 1 < m ? beta[lane + 1] : 0.0; e.hi = lane + 65 < m ? beta[lane + 65] : 0.0;
     for (int c = 0; c < m; ++c)
         for (int k = lane; k < m; k += 64) z[c * m + k] = c == k ? 1.0 : 0.0;
     bool ok = true;
     for (int l = 0; l < m && ok; ++l) {
         int iter = 0, mm;
         do {
-            lz_wave_sync();   // lane 0's stores of the previous sweep
             for (mm = l; mm < m - 1; ++mm) {
-                const double dd = fabs(d[mm]) + fabs(d[mm + 1]);
-                if (fabs(e[mm]) <= 2.3e-16 * dd) break;
+                const double dd = fabs(d.get(mm)) + fabs(d.get(mm + 1));
+                if (fabs(e.get(mm)) <= 2.3e-16 * dd) break;
             }
             if (mm != l) {
                 if (iter++ == 200) { ok = false; break; }
-                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-                double r = hypot(g, 1.0);
-                g = d[mm] - d[l] + e[l] / (g + (g >= 0 ? fabs(r) : -fabs(r)));
+                const double dl = d.get(l), el = e.get(l);
+                double g = (d.get(l + 1) - dl) / (2.0 * el);
+                double r = sqrt(g * g + 1.0);
+                g = d.get(mm) - dl + el / (g + (g >= 0 ? r : -r));
                 double s = 1.0, c = 1.0, p = 0.0;
                 int i;
                 for (i = mm - 1; i >= l; --i) {
-                    double f = s * e[i], b = c * e[i];
-                    r = hypot(f, g);
-                    if (lane == 0) e[i + 1] = r;
-                    if (r == 0.0) { if (lane == 0) { d[i + 1] -= p; e[mm] = 0.0; } break; }
-                    s = f / r; c = g / r;
-                    g = d[i + 1] - p;
-                    r = (d[i] - g) * s + 2.0 * c * b;
+                    const double ei = e.get(i);
+                    double f = s * ei, b = c * ei;
+                    r = sqrt(f * f + g * g);
+                    e.set(i + 1, r);
+                    if (r == 0.0) { d.set(i + 1, d.get(i + 1) - p); e.set(mm, 0.0); break; }
+                    const double ir = 1.0 / r;
+                    s = f * ir; c = g * ir;
+                    g = d.get(i + 1) - p;
+                    r = (d.get(i) - g) * s + 2.0 * c * b;
                     p = s * r;
-                    if (lane == 0) d[i + 1] = g + p;
+                    d.set(i + 1, g + p);
                     g = c * r - b;
                     for (int k = lane; k < m; k += 64) {
                         const double zk1 = z[(i + 1) * m + k], zk0 = z[i * m + k];
@@ -2494,7 +2512,7 @@ __device__ bool lz_sqrt_e1(int m, const double *__restrict__ alpha, const double
                     }
                 }
                 if (r == 0.0 && i >= l) continue;
-                if (lane == 0) { d[l] -= p; e[l] = g; e[mm] = 0.0; }
+                d.set(l, d.get(l) - p); e.set(l, g); e.set(mm, 0.0);
             }
         } while (mm != l);
     }
@@ -2502,14 +2520,12 @@ __device__ bool lz_sqrt_e1(int m, const double *__restrict__ alpha, const double
     if (!ok) return false;
     for (int i = lane; i < m; i += 64) {
         double t = 0.0;
-        for (int j = 0; j < m; ++j) t += z[j * m + i] * (sqrt(fmax(d[j], 0.0)) * z[j * m]);
+        for (int j = 0; j < m; ++j) t += z[j * m + i] * (sqrt(fmax(d.get(j), 0.0)) * z[j * m]);
         t_out[i] = t;
     }
     lz_wave_sync();
     return true;
 }
-// (the recurrence reads d[i + 1] - p with the d[i + 1] of BEFORE this sweep's store: lane 0's stores of one sweep touch d[i + 1] once,
-// after its last read, exactly as the host loop does)
 __global__ void __launch_bounds__(128)
 k_lz_decide(LzDecide a, double *__restrict__ scal, LzState *__restrict__ st, double *__restrict__ sch, double seq) {
     extern __shared__ double lds[];
@@ -2524,8 +2540,8 @@ k_lz_decide(LzDecide a, double *__restrict__ scal, LzState *__restrict__ st, dou
     const bool dead = !(norm > 0.0) || !isfinite(norm);          // psi == 0: the result is zero
     if (wv < nm && !dead) {
         const int m = a.m_lo + wv;
-        double *base = lds + (wv == 0 ? 0 : (size_t)a.m_lo * a.m_lo + 2 * a.m_lo);
-        const bool ok = lz_sqrt_e1(m, alpha, beta, base, base + m, base + 2 * m, tbuf[wv]);
+        double *base = lds + (wv == 0 ? 0 : (size_t)a.m_lo * a.m_lo);
+        const bool ok = lz_sqrt_e1(m, alpha, beta, base, tbuf[wv]);
         if ((threadIdx.x & 63) == 0) okf[wv] = ok ? 1 : 0;
     }
     __syncthreads();
@@ -2563,14 +2579,13 @@ k_lz_decide(LzDecide a, double *__restrict__ scal, LzState *__restrict__ st, dou
         const int m = max(m_final, 0);
         for (int q = 0; q < m; ++q) st->coef[q] = t_fin[q] / (q == 0 ? norm : (a.normalised ? 1.0 : beta[q]));
         st->m_final = m; st->status = status;
-        __threadfence();
-        st->done = 1;
+        st->done = 1;                                            // (read by LATER launches only: the kernel boundary orders it)
         if (sch) { sch[LZ_HOST_M] = (double)m; sch[LZ_HOST_STEPNORM] = stepnorm; sch[LZ_HOST_STATUS] = (double)status; sch[LZ_HOST_SEQ] = seq; }
     }
 }
 static size_t lz_decide_lds(int m_lo, int m_hi) {
-    size_t n = (size_t)m_lo * m_lo + 2 * (size_t)m_lo;
-    if (m_hi != m_lo) n += (size_t)m_hi * m_hi + 2 * (size_t)m_hi;
+    size_t n = (size_t)m_lo * m_lo;
+    if (m_hi != m_lo) n += (size_t)m_hi * m_hi;
     return n * sizeof(double);
 }
 bool lz_decide_supported(int m_hi) { return m_hi >= 1 && m_hi <= 100 && lz_decide_lds(std::max(1, m_hi - 1), m_hi) <= 150 * 1024; }

@@ -30,10 +30,10 @@ struct LocalRegions {
     int c_gr_adj;         // offset there = end of the right ghosts' layer next to the slab
 };
 constexpr int LOCAL_REC = 12;     // doubles per particle record of the first exchange: pos.xyzw | force.xyz, mass | image.xyz, tag
-constexpr int LOCAL_HDR = 4;      // doubles in front of the records: [0] their number
+constexpr int LOCAL_HDR = 4;      // doubles in front of the records; on the receiving side the first holds the sender's two record counters (two ints)
 enum { LOCAL_ERR_OWN = 1, LOCAL_ERR_GHOST = 2, LOCAL_ERR_MSG = 4, LOCAL_ERR_FAR = 8, LOCAL_ERR_COUNT = 16 };   // bits of the error word
-// counters of a step, zeroed with the cell counts: [0] records in the left message, [1] in the right one, [2] workgroups of the
-// classification that have finished
+// counters of a step, zeroed with the cell counts: [0] records in the left message, [1] in the right one (8-byte aligned: the pair
+// travels as one double in the step's first exchange)
 constexpr int LOCAL_NCOUNTER = 8;
 
 struct LocalCaller {     // the caller's arrays of one rank (device): rows [0, *n_local) hold the particles it owns, in any order

@@ -24,15 +24,22 @@ __device__ __forceinline__ unsigned cell_of(const DBox &box, const DCells &nc, d
     const int cy = cell_coord(fy, nc.ny), cz = cell_coord(fz, nc.nz), zb = cz / nc.bz;
     return (unsigned)cell_slot(nc, cx, cy, zb, cz - zb * nc.bz);
 }
-// slot of this lane's item in a list that grows by one atomic per wavefront (-1: the lane has none)
-__device__ __forceinline__ int wave_append(bool want, int *counter) {
+// slot of this thread's item in a list that grows by ONE atomic per workgroup (-1: the thread has none): a word takes ~88 atomics
+// per microsecond (MI355X_MICROARCH.md), and the particles of the boundary layers sit in a third of the workgroups
+__device__ __forceinline__ int block_append(bool want, int *counter, int *sh /* TPB / 64 + 1 ints */) {
     const unsigned long long m = __ballot(want);
-    if (m == 0ull) return -1;
-    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(counter, __popcll(m));
-    base = __shfl(base, leader, 64);
-    return want ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sh[wv] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < TPB / 64; ++w) { const int c = sh[w]; sh[w] = tot; tot += c; }
+        sh[TPB / 64] = tot ? atomicAdd(counter, tot) : 0;
+    }
+    __syncthreads();
+    const int slot = sh[TPB / 64] + sh[wv] + __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    return want ? slot : -1;
 }
 __device__ __forceinline__ void write_record(double *msg, int slot, const double4 &p, const double4 &f, double mass, const int3 &im, unsigned tag) {
     double2 *r = reinterpret_cast<double2 *>(msg + LOCAL_HDR + (size_t)slot * LOCAL_REC);
@@ -77,23 +84,11 @@ k_local_classify(LocalCaller c, LocalGeom g, DBox box, DCells nc, LocalPool pool
     } else if (i < g.c_own) {
         pool.keys[i] = KEY_FOREIGN;
     }
-    const int sl = wave_append(to_l, &counters[0]), sr = wave_append(to_r, &counters[1]);
+    __shared__ int sh[TPB / 64 + 1];
+    const int sl = block_append(to_l, &counters[0], sh), sr = block_append(to_r, &counters[1], sh);
+    // (the numbers of records travel as they are: the two counters are one more transfer of the exchange)
     if (to_l) { if (sl < g.c_x) write_record(send_l, sl, p, f, mass, im, tag); else atomicOr(err, LOCAL_ERR_MSG); }
     if (to_r) { if (sr < g.c_x) write_record(send_r, sr, p, f, mass, im, tag); else atomicOr(err, LOCAL_ERR_MSG); }
-    // the workgroup that finishes last writes the headers: the numbers of records (agent-scope release / acquire around the ticket)
-    __shared__ int last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        last = atomicAdd(&counters[2], 1) == (int)gridDim.x - 1;
-    }
-    __syncthreads();
-    if (last && threadIdx.x == 0) {
-        __threadfence();
-        const int nl = __hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int nr = __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        send_l[0] = (double)min(nl, g.c_x); send_r[0] = (double)min(nr, g.c_x);
-    }
 }
 void launch_local_classify(const LocalCaller &c, const LocalGeom &g, DBox box, DCells nc, LocalPool pool, double *send_l, double *send_r,
                            int *counters, int *err, hipStream_t s) {
@@ -108,9 +103,11 @@ k_local_bin_incoming(const double *__restrict__ recv_l, const double *__restrict
     const int side = q / g.c_x, k = q - side * g.c_x;
     const double *m = side == 0 ? recv_l : recv_r;
     const int pid = g.c_own + q;
-    const double cnt = m[0];
-    if (!(cnt >= 0.0) || cnt > (double)g.c_x) { if (k == 0) atomicOr(err, LOCAL_ERR_MSG); pool.keys[pid] = KEY_FOREIGN; return; }
-    if (k >= (int)cnt) { pool.keys[pid] = KEY_FOREIGN; return; }
+    // the sender's two counters (records in ITS left, right message) arrived in front of the records: what came from the left
+    // neighbour is its right message, what came from the right neighbour its left one
+    const int cnt = reinterpret_cast<const int *>(m)[side == 0 ? 1 : 0];
+    if (cnt < 0 || cnt > g.c_x) { if (k == 0) atomicOr(err, LOCAL_ERR_MSG); }   // (the sender flags its own overflow; it sent c_x records)
+    if (k >= min(cnt, g.c_x)) { pool.keys[pid] = KEY_FOREIGN; return; }
     const double2 *r = reinterpret_cast<const double2 *>(m + LOCAL_HDR + (size_t)k * LOCAL_REC);
     const double2 a = r[0], b = r[1];
     int cx;

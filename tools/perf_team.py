@@ -22,9 +22,12 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--solo", type=int, default=-1, help="after the full calls: time Brownian evaluations that queue the work of this "
                     "rank only (both lanes, its share of the copies): one rank's critical path with the GPU to itself")
+    ap.add_argument("--local", action="store_true", help="owned-particle team (pse_team_step_local): every rank holds only its slab's particles")
     a = ap.parse_args()
     import torch
     from conftest import make_suspension
+    if a.local:
+        return main_local(a)
     from pse_amd.sharded import LoopbackSimulation
     pos, force, box = make_suspension(a.n, phi=a.phi)
     xi = math.pi * a.grid / (2.0 * box[0] * math.sqrt(-math.log(1e-3)))
@@ -70,6 +73,98 @@ def main():
     i = sim.engines[0].info()
     print("rank 0 phases ms:", {k: round(v, 4) for k, v in i.items() if k.startswith("t_") and v > 0})
     print(f"Lanczos: m = {i['lanczos_m']}, near-field mat-vecs = {i['lanczos_matvecs']}, exchanges = {i['lanczos_exchanges']}")
+
+
+def main_local(a):
+    import torch
+    from conftest import make_suspension
+    from pse_amd.sharded import LocalLoopbackSimulation
+    pos, force, box = make_suspension(a.n, phi=a.phi)
+    xi = math.pi * a.grid / (2.0 * box[0] * math.sqrt(-math.log(1e-3)))
+    sim = LocalLoopbackSimulation(a.n, box, a.ranks, xi=xi, error=1e-3, seed=1, grid=(a.grid,) * 3)
+    sim.load(pos, force)
+    print("layout", sim.layout, "row capacity per rank", sim.engines[0].params.n_max, "device GB per rank %.2f" % (sim.engines[0].info()["device_bytes"] / 1e9))
+    S = sim.s
+    args = lambda: ([s.pos for s in S], [s.vel for s in S], [s.accel for s in S], [s.image for s in S], [s.force for s in S],   # noqa: E731
+                    [s.tag for s in S], [s.n_local for s in S])
+    m = 2   # the starting count grows until a step converges within its queue (a queue-only step never waits for more)
+    for it in range(8):
+        sim.step(1.0, 1e-3, it, lanczos_m=m)
+        torch.cuda.synchronize()
+        i0 = sim.engines[0].info()
+        m = max(i0["lanczos_m"], 2)
+        if i0["lanczos_status"] == 0:
+            break
+    print("m =", m, "status", [e.info()["lanczos_status"] for e in sim.engines], "n_local", [int(s.n_local.item()) for s in S])
+    torch.cuda.synchronize(); t0 = time.time()
+    for it in range(a.steps):
+        sim.team.step_local(*args(), 1.0, 1e-3, 10 + it, lanczos_m=m)
+    torch.cuda.synchronize(); t = (time.time() - t0) / a.steps
+    print(f"local team of {a.ranks}: {t * 1e3:.3f} ms per team step -> {t * 1e3 / a.ranks:.3f} ms per rank (compute only), m={m}")
+    sim.team.local_status()
+    if a.solo >= 0:
+        sim.team.debug_solo(a.solo)
+        for it in range(3):
+            sim.team.step_local(*args(), 1.0, 1e-3, 50 + it, lanczos_m=m)
+        torch.cuda.synchronize()
+        ts = []
+        for it in range(max(a.steps, 30)):
+            t0 = time.perf_counter()
+            sim.team.step_local(*args(), 1.0, 1e-3, 60 + it, lanczos_m=m)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        i = sim.engines[a.solo].info()
+        print(f"solo rank {a.solo} of {a.ranks} (owned particles): full step incl. Euler update {ts[len(ts) // 2] * 1e3:.3f} ms median, "
+              f"{ts[0] * 1e3:.3f} min, {ts[-1] * 1e3:.3f} max over {len(ts)} calls; m = {i['lanczos_m']}, exchanges = {i['lanczos_exchanges']}, "
+              f"mat-vecs = {i['lanczos_matvecs']}")
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        nrep = max(a.steps, 30)
+        th = 0.0
+        for it in range(nrep):
+            h0 = time.perf_counter()
+            sim.team.step_local(*args(), 1.0, 1e-3, 100 + it, lanczos_m=m)
+            th += time.perf_counter() - h0
+        torch.cuda.synchronize(); t = (time.perf_counter() - t0) / nrep
+        print(f"solo rank {a.solo}: {t * 1e3:.3f} ms per step with the calls queued back to back (no wait between steps); "
+              f"the host needs {th / nrep * 1e3:.3f} ms to queue one")
+        # the same step as ONE hipGraph: the whole call only queues work, so it can be captured (both lanes, every exchange)
+        st = torch.cuda.Stream()
+        for e in sim.engines:
+            e.set_stream(st.cuda_stream)
+        word = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for e in sim.engines:
+            e.set_timestep_offset(word)
+        with torch.cuda.stream(st):
+            sim.team.step_local(*args(), 1.0, 1e-3, 200, lanczos_m=m)
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+            sim.team.step_local(*args(), 1.0, 1e-3, 200, lanczos_m=m)
+        for it in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        ts = []
+        for it in range(nrep):
+            word.fill_(it + 1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            g.replay()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        i = sim.engines[a.solo].info()
+        print(f"solo rank {a.solo}: the step as one replayed hipGraph {ts[len(ts) // 2] * 1e3:.3f} ms median, {ts[0] * 1e3:.3f} min; m = {i['lanczos_m']} "
+              f"status {i['lanczos_status']}")
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for it in range(nrep):
+            g.replay()
+        torch.cuda.synchronize(); t = (time.perf_counter() - t0) / nrep
+        print(f"solo rank {a.solo}: {t * 1e3:.3f} ms per replay, queued back to back")
+        for e in sim.engines:
+            e.set_stream(0)
+            e.set_timestep_offset(None)
+        sim.team.debug_solo(-1)
 
 
 if __name__ == "__main__":

@@ -1293,13 +1293,14 @@ static ScaleArgs scale_args(pse_handle *h, bool noise, double kT, double dt, uns
 //   part 3  gather
 // A single GPU, or a team that keeps the whole grid on every rank, has no exchanges: the parts simply follow one another.
 struct WaveArgs { int N; bool noise; double kT, dt; unsigned timestep; };
-static int wave_compute(pse_team &T, const WaveArgs &a, int part) {
+static int wave_compute(pse_team &T, const WaveArgs &a, int part, int half = 0) {   // half (part 0 only): 1 records + spread, 2 the transforms, 0 both
     const int GS = T.m[0]->grid_slabs;   // 1: every rank transforms the whole grid (single GPU, or a team that replicates it)
     for (pse_handle *h : act(T)) {
         const DGrid &G = h->G;
         const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzp;
         if (part == 0) {
             double *gx = h->rgrid, *gy = h->rgrid + nr, *gz = h->rgrid + 2 * nr;
+            if (half != 2) {
             TRY(tsw(h, PH_RECORDS));
             HIPCHK(launch_far_records(h->pos_s, h->f_s, a.N, G, h->dbox, h->sw, h->wstream));
             TRY(tew(h, PH_RECORDS));
@@ -1307,6 +1308,8 @@ static int wave_compute(pse_team &T, const WaveArgs &a, int part) {
             if (spread_needs_zero(G)) HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->wstream));
             HIPCHK(launch_spread(h->pos_s, h->f_s, a.N, gx, gy, gz, G, h->dbox, h->sw, h->wstream));
             TRY(tew(h, PH_SPREAD));
+            }
+            if (half == 1) continue;
             TRY(tsw(h, PH_FFTF));
             if (GS == 1) {
                 void *in[1] = {h->rgrid}, *out[1] = {h->cgrid};
@@ -1382,17 +1385,21 @@ struct WavePump {
     int next = 4;                   // next compute part to queue (4: the chain is complete, or not part of this call)
     int slot[3] = {0, 0, 0};
     unsigned *mask = nullptr;
-    int start(pse_team &team, const WaveArgs &args, const int sched[3], unsigned *m, bool fork = true) {
+    // half: 0 the whole first part; 1 fork + records + spread only (the caller queues main-lane work, then calls again with 2: the
+    // transforms -- rocFFT's launches cost the host the most, and the main lane should not wait for them to be queued)
+    int start(pse_team &team, const WaveArgs &args, const int sched[3], unsigned *m, int half = 0) {
         T = &team; a = args; mask = m;
         for (int k = 0; k < 3; ++k) slot[k] = sched[k];
-        for (pse_handle *h : act(*T))
-            if (h->side_on && fork) {   // fork: the wave chain starts once the sorted arrays exist
-                HIPCHK(hipEventRecord(h->ev_fork, h->stream));
-                HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-            }
+        if (half != 2)
+            for (pse_handle *h : act(*T))
+                if (h->side_on) {   // fork: the wave chain starts once the sorted arrays exist
+                    HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+                    HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+                }
         *mask |= (1u << PH_SPREAD) | (1u << PH_FFTF) | (1u << PH_SCALE) | (1u << PH_FFTI) | (1u << PH_GATHER) | (1u << PH_RECORDS);
         if (T->m[0]->grid_slabs > 1) *mask |= 1u << PH_COMM;
-        TRY(wave_compute(*T, a, 0));
+        TRY(wave_compute(*T, a, 0, half));
+        if (half == 1) return 0;
         next = 1;
         if (T->m[0]->grid_slabs == 1) return upto(1 << 30);   // no exchanges: the whole chain is queued at once
         return 0;
@@ -2188,13 +2195,11 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
         h->sw.need = need; h->sw.cell_off = h->cell_off; h->sw.rows_local = 1;
     }
     // (4) the far-field chain (side lane), the near field and the Lanczos blocks (main lane)
-    // (the main lane's pass is queued FIRST: the host needs ~100 us to queue the first part of the far-field chain -- rocFFT's
-    // launches among them -- and the main lane, the longer one, would sit idle meanwhile; the side lane forks from the sort all the same)
-    for (pse_handle *h : act(T))
-        if (h->side_on) {
-            HIPCHK(hipEventRecord(h->ev_fork, h->stream));
-            HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-        }
+    // The side lane forks from the sort and gets its first kernels (records, spread); then the main lane's pass is queued, and only
+    // then the transforms: the host needs ~100 us for rocFFT's launches, and neither lane should sit idle meanwhile.
+    WavePump pump;
+    const WaveArgs wa{T.m[0]->loc.rows_cap, noise, kT, dt, timestep};
+    TRY(pump.start(T, wa, T.m[0]->tun.team_sched, &mask, 1));
     for (pse_handle *h : act(T)) {
         const LocalRows *R = h->loc.rows;
         const int nco = h->n_intervals * 2 * RS_NCOEF;
@@ -2208,9 +2213,7 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
                          DevRowArgs{&R->own, R, nullptr, h->loc.g.c_own});
         h->nb_valid = noise; h->w_is_mpsi = noise;
     }
-    WavePump pump;
-    const WaveArgs wa{T.m[0]->loc.rows_cap, noise, kT, dt, timestep};
-    TRY(pump.start(T, wa, T.m[0]->tun.team_sched, &mask, false));
+    TRY(pump.start(T, wa, T.m[0]->tun.team_sched, &mask, 2));
     if (noise) TRY(lanczos_local(T, T.m[0]->d.error, m_io, &pump));
     TRY(pump.drain());
     // (5) join the lanes; the end of the step on the own rows, written to the caller's arrays

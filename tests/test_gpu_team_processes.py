@@ -218,3 +218,85 @@ def test_random_team_of_processes(seed):
     procs = [ctx.Process(target=_random_worker, args=(r, seed, port, out)) for r in range(world)]
     res = _run_ranks(procs, out)
     assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def _local_worker(rank, world, port, xy0, n, grid, out):
+    """Owned-particle team between real processes (pse_team_step_local over the host-staged transport): 20 sheared steps against the
+    single-GPU engine on rank 0 -- positions 1e-9, equal Lanczos counts, particles migrating across every slab face."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    try:
+        import math
+        import torch
+        import torch.distributed as dist
+        from conftest import make_suspension, to4
+        import pse_amd
+        from pse_amd.sharded import LocalShardedSimulation, owner_of
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        pos, force, box = make_suspension(n, phi=0.12, xy=xy0)
+        xi = math.pi * grid / (2.0 * box[0] * math.sqrt(-math.log(1e-3)))
+        kw = dict(xi=xi, error=1e-3, seed=9, grid=(grid,) * 3)
+        sim = LocalShardedSimulation(n, box, world, rank, transport="host", **kw)
+        sim.load(pos, force)
+        kT, dt, rate = 1.0, 0.25, 0.02
+        if rank == 0:
+            ref = pse_amd.Engine(n, box, **kw)
+            dpos, dF, vel = to4(pos), to4(force), to4(np.zeros((n, 3)), 1.0)
+            accel = torch.zeros((n, 3), dtype=torch.float64, device="cuda"); image = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+            _, m0 = ref.brownian_velocity(dpos, dF, kT, dt, 99, vel=to4(np.zeros((n, 3)), 1.0), lanczos_m=2)
+        box_m = [m0 if rank == 0 else None]
+        dist.broadcast_object_list(box_m, src=0)
+        m, xy = box_m[0], xy0
+        own0 = owner_of(pos, box, sim.layout["layers"], world)
+        crossed = set()
+        for k in range(20):
+            sim.step(kT, dt, 100 + k, shear_rate=rate, lanczos_m=m)
+            tg, p, u, im = sim.gather_local()
+            info = sim.engine.info()
+            got = [None] * world if rank == 0 else None
+            dist.gather_object((tg, p, im, info["lanczos_m"], info["lanczos_status"]), got, dst=0)
+            if rank == 0:
+                mr = ref.step(dpos, vel, accel, image, dF, kT, dt, 100 + k, shear_rate=rate, lanczos_m=m)
+                P, IM, owner = np.full((n, 3), np.nan), np.zeros((n, 3), dtype=np.int64), np.full(n, -1)
+                for r, (t_, p_, im_, m_, st_) in enumerate(got):
+                    assert st_ == 0 and m_ == mr, (k, r, m_, mr, st_)
+                    P[t_] = p_; IM[t_] = im_; owner[t_] = r
+                assert (owner >= 0).all()
+                assert np.abs(P - dpos.cpu().numpy()[:, :3]).max() < 1e-9, (k, np.abs(P - dpos.cpu().numpy()[:, :3]).max())
+                assert np.array_equal(IM, image.cpu().numpy())
+                moved = np.nonzero(owner != own0)[0]
+                crossed |= {(int(a), int(b)) for a, b in zip(own0[moved], owner[moved])}
+                own0 = owner
+                m = mr
+            box_m = [m if rank == 0 else None]
+            dist.broadcast_object_list(box_m, src=0)
+            m = box_m[0]
+            xy += rate * dt
+            sim.set_box(box[0], box[1], box[2], xy)
+            if rank == 0:
+                ref.set_box(box[0], box[1], box[2], xy)
+        if rank == 0:
+            faces = {(r, (r + 1) % world) for r in range(world)} | {((r + 1) % world, r) for r in range(world)}
+            assert faces <= crossed, sorted(faces - crossed)
+        dist.barrier()
+        out.put((rank, "ok"))
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        out.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))[-1500:]))
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:   # noqa: BLE001
+            pass
+
+
+@pytest.mark.parametrize("world,xy0,n,grid", [(2, 0.1, 40_000, 96), (4, -0.15, 40_000, 96), (8, 0.0, 80_000, 128)])
+def test_owned_particle_team_of_processes_follows_single_gpu(world, xy0, n, grid):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_local_worker, args=(r, world, port, xy0, n, grid, out)) for r in range(world)]
+    res = _run_ranks(procs, out)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res

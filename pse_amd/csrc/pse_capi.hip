@@ -77,6 +77,7 @@ struct pse_handle {
         bool no_xfuse = false;    // PSE_NO_XFUSE: rocFFT for the x pass
         int own_y_pow2 = 1;       // PSE_OWN_Y_POW2=0: rocFFT's 2-D transforms at Ny = 256 instead of its 1-D z pass + k_yfft_regs (A/B)
         int own_y = 1;            // PSE_OWN_Y=0: rocFFT's 2-D (y, z) transforms also where the own y pass applies
+        int own_z = 1;            // PSE_OWN_Z=0: rocFFT's 1-D z transforms also where k_zfft_rows applies (A/B)
         int yfft_kb = 4;          // PSE_YFFT_KB: kz columns per workgroup of the own y pass (2, 4, 8)
         int wave_mode = 0;        // PSE_WAVE_MODE: 0 automatic, 1 slab, 2 replicated
         int spread_tz = 0, spread_nw = 0;   // PSE_SPREAD_TZ, PSE_SPREAD_NW
@@ -159,6 +160,8 @@ struct pse_handle {
     bool xfuse = false;                                      // power-of-two Nx: fused x pass (k_xfft_scale)
     bool own_y = false;                                      // y transforms by k_fft_cols, rocFFT does the z transforms only
     bool own_y_slab = false;                                 // ... on a slab rank, with the all-to-all block layout as its output / input
+    bool own_z = false;                                      // z transforms by k_zfft_rows (Nz = 256, 512): rocFFT is then off the path
+    double2 *twiddle_z = nullptr, *twiddle_z_owned = nullptr;   // [Nz] exp(-2 pi i m / Nz)
     double2 *twiddle_y = nullptr;                            // [Ny] exp(-2 pi i m / Ny) (== twiddle when Ny == Nx)
     double2 *twiddle_y_owned = nullptr;
     int grid_slabs = 1;   // slabs the far-field grid is cut into: n_slabs, or 1 when every rank keeps the whole grid
@@ -317,7 +320,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
     void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cnt_block, h->sw.rec_t, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->nb.data, h->nb.cnt, h->vl.idx, h->vl.cnt, h->pos_build, h->pos_s, h->posf_s, h->pv,
-                    h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->w2_s, h->u_s, h->pv2, h->sums_all, h->twiddle, h->twiddle_y_owned, h->fft_work, h->V,
+                    h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->w2_s, h->u_s, h->pv2, h->sums_all, h->twiddle, h->twiddle_y_owned, h->twiddle_z_owned, h->fft_work, h->V,
                     h->scal, h->partials, h->lz_state};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &p : h->ph) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
@@ -354,9 +357,25 @@ static int make_plans(pse_handle *h) {
         HIPCHK(hipMemcpy(h->twiddle, tw.data(), G.Nx * sizeof(double2), hipMemcpyHostToDevice));
     }
     // the y transforms of a single GPU's grid by the own in-place pass where rocFFT's strided pass is slow (not a power of two)
-    h->own_y = h->xfuse && h->grid_slabs == 1 && h->tun.own_y > 0 && (yfft_supported(G.Ny) || (h->tun.own_y_pow2 && yfft_regs_supported(G.Ny, G.Nz)));
+    const bool z_ok = h->tun.own_z > 0 && zfft_supported(G.Nz);
+    h->own_y = h->xfuse && h->grid_slabs == 1 && h->tun.own_y > 0 &&
+               (yfft_supported(G.Ny) || (h->tun.own_y_pow2 && yfft_regs_supported(G.Ny, G.Nz, z_ok)));
     // a slab rank: the own y pass for ANY smooth Ny -- it writes the all-to-all blocks directly (no pack / unpack pass)
     h->own_y_slab = h->xfuse && h->grid_slabs > 1 && h->tun.own_y > 0 && yfft_possible(G.Ny);
+    h->own_z = z_ok && (h->own_y || h->own_y_slab);   // (where rocFFT's plan is its 1-D z plan)
+    if (h->own_z) {
+        if (G.Nz == G.Nx) h->twiddle_z = h->twiddle;
+        else {
+            std::vector<double2> tw(G.Nz);
+            for (int m = 0; m < G.Nz; ++m) {
+                const long double ang = -2.0L * 3.14159265358979323846264338327950288L * m / G.Nz;
+                tw[m] = make_double2((double)cosl(ang), (double)sinl(ang));
+            }
+            TRY(dmalloc(h, &h->twiddle_z_owned, (size_t)G.Nz));
+            HIPCHK(hipMemcpy(h->twiddle_z_owned, tw.data(), G.Nz * sizeof(double2), hipMemcpyHostToDevice));
+            h->twiddle_z = h->twiddle_z_owned;
+        }
+    }
     if (h->own_y || h->own_y_slab) {
         if (G.Ny == G.Nx) h->twiddle_y = h->twiddle;
         else {
@@ -466,7 +485,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         if (const char *v = getenv("PSE_SKIN")) t.skin = atof(v);
         t.overlap = ienv("PSE_OVERLAP", 0);
         t.no_xfuse = getenv("PSE_NO_XFUSE") != nullptr;
-        t.own_y = ienv("PSE_OWN_Y", 1); t.own_y_pow2 = ienv("PSE_OWN_Y_POW2", 1); t.yfft_kb = ienv("PSE_YFFT_KB", 4);
+        t.own_y = ienv("PSE_OWN_Y", 1); t.own_y_pow2 = ienv("PSE_OWN_Y_POW2", 1); t.yfft_kb = ienv("PSE_YFFT_KB", 4); t.own_z = ienv("PSE_OWN_Z", 1);
         if (const char *v = getenv("PSE_WAVE_MODE")) t.wave_mode = !strcmp(v, "slab") ? 1 : (!strcmp(v, "replicated") ? 2 : 0);
         t.spread_tz = ienv("PSE_SPREAD_TZ", 0); t.spread_nw = ienv("PSE_SPREAD_NW", 0);
         t.gather_bz = ienv("PSE_GATHER_BZ", 0); t.xmix_runtime = ienv("PSE_XMIX", 0) == 1; t.xfft_small_wide = ienv("PSE_XFFT_SMALL_KB", 2) == 8; t.xcols = ienv("PSE_XCOLS", 1);
@@ -1311,12 +1330,18 @@ static int wave_compute(pse_team &T, const WaveArgs &a, int part, int half = 0) 
             }
             if (half == 1) continue;
             TRY(tsw(h, PH_FFTF));
+            double *zr[3]; double2 *zs[3];   // the rows of the own planes of each component
+            for (int c = 0; c < 3; ++c) { zr[c] = h->rgrid + c * nr + (size_t)G.hl * G.Ny * G.Nz; zs[c] = h->cgrid + c * ncx; }
             if (GS == 1) {
-                void *in[1] = {h->rgrid}, *out[1] = {h->cgrid};
-                FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
+                if (h->own_z) launch_zfft(zr, zs, G.Nx * G.Ny, G.Nz, G.Nzp, false, h->twiddle_z, h->wstream);
+                else {
+                    void *in[1] = {h->rgrid}, *out[1] = {h->cgrid};
+                    FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
+                }
                 if (h->own_y) launch_yfft(h->cgrid, G, false, h->twiddle_y, h->wstream, h->tun.yfft_kb);
             } else {
-                for (int c = 0; c < 3; ++c) {   // 2-D (y,z) transforms of the local planes, one component at a time
+                if (h->own_z) launch_zfft(zr, zs, G.nxl * G.Ny, G.Nz, G.Nzp, false, h->twiddle_z, h->wstream);
+                else for (int c = 0; c < 3; ++c) {   // 2-D (y,z) transforms of the local planes, one component at a time
                     void *in[1] = {h->rgrid + c * nr + (size_t)G.hl * G.Ny * G.Nz}, *out[1] = {h->cgrid + c * ncx};
                     FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
                 }
@@ -1340,14 +1365,20 @@ static int wave_compute(pse_team &T, const WaveArgs &a, int part, int half = 0) 
             TRY(tew(h, PH_SCALE));
         } else if (part == 2) {
             TRY(tsw(h, PH_FFTI));
+            double *zr[3]; double2 *zs[3];
+            for (int c = 0; c < 3; ++c) { zr[c] = h->rgrid + c * nr + (size_t)G.hl * G.Ny * G.Nz; zs[c] = h->cgrid + c * ncx; }
             if (GS == 1) {
                 if (h->own_y) launch_yfft(h->cgrid, G, true, h->twiddle_y, h->wstream, h->tun.yfft_kb);
-                void *in[1] = {h->cgrid}, *out[1] = {h->rgrid};
-                FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv));
+                if (h->own_z) launch_zfft(zr, zs, G.Nx * G.Ny, G.Nz, G.Nzp, true, h->twiddle_z, h->wstream);
+                else {
+                    void *in[1] = {h->cgrid}, *out[1] = {h->rgrid};
+                    FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv));
+                }
             } else {
                 if (h->own_y_slab) launch_yfft_slab(h->cgrid, h->sendbuf, G, h->nyl, true, h->twiddle_y, h->wstream);
                 else launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzp, h->nyl, 1, h->wstream);
-                for (int c = 0; c < 3; ++c) {
+                if (h->own_z) launch_zfft(zr, zs, G.nxl * G.Ny, G.Nz, G.Nzp, true, h->twiddle_z, h->wstream);
+                else for (int c = 0; c < 3; ++c) {
                     void *in[1] = {h->cgrid + c * ncx}, *out[1] = {h->rgrid + c * nr + (size_t)G.hl * G.Ny * G.Nz};
                     FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv));
                 }

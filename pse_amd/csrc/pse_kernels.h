@@ -225,12 +225,15 @@ bool xfuse_supported(int Nx);
 // own in-place y transforms of the half spectra [3 nxl][Ny][Nzp] (Ny = 2^a 3^b 5^c, not a power of two); tw[m] = exp(-2 pi i m / Ny);
 // kb: consecutive kz per workgroup (2, 4 or 8)
 bool yfft_supported(int Ny);
-bool yfft_regs_supported(int Ny, int Nz);   // 256 (Nz <= 256): the register y pass (k_yfft_regs) instead of rocFFT's strided pass
+bool yfft_regs_supported(int Ny, int Nz, bool own_z = false);   // the register y pass (k_yfft_regs) instead of rocFFT's strided pass: 256 (Nz <= 256), and 256 / 512 with the own z pass
 // a slab rank's y transforms with the reordering of the all-to-all blocks folded in: forward reads the planes [3][nxl][Ny][Nzp] and writes
 // [3][G][nxl][nyl][Nzp]; inverse the other way round (any Ny = 2^a 3^b 5^c in 16..512: yfft_possible)
 bool yfft_possible(int Ny);
 void launch_yfft_slab(double2 *cgrid, double2 *blocks, DGrid G, int nyl, bool inverse, const double2 *tw, hipStream_t s);
 void launch_yfft(double2 *spectra, DGrid G, bool inverse, const double2 *tw, hipStream_t s, int kb = 4);
+// own z pass (k_zfft_rows): `rows` real rows of Nz doubles per component <-> spectrum rows of Nzp complex numbers; tw[m] = exp(-2 pi i m / Nz)
+bool zfft_supported(int Nz);
+void launch_zfft(double *const real[3], double2 *const spec[3], int rows, int Nz, int Nzp, bool inverse, const double2 *tw, hipStream_t s);
 void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s);
 // the fast path reads the records written by launch_spread of the same step
 hipError_t launch_gather(const double4 *pos_s, SpreadWork w, int N, const double *gx, const double *gy, const double *gz, DGrid G,

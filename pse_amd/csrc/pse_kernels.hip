@@ -2089,8 +2089,10 @@ static void launch_yfft_regs(double2 *data, const double2 *tw, int nplanes, int 
 // 256^3: forward 0.30 against 0.31 - 0.32 ms, inverse 0.32 against 0.34 (rocFFT's 2-D plan).  Not at 512: the pass itself equals rocFFT's
 // strided one there (2.6 ms per direction either way), and rocFFT's 1-D real forward transform of 512 points, which would replace
 // the z half of its 2-D plan, is slow (3.7 ms per direction at 512^3 instead of 2.6).
-bool yfft_regs_supported(int Ny, int Nz) { return Ny == 256 && Nz <= 256; }
+// Round 5: with the own z pass (k_zfft_rows) the register y pass also runs at 512 (8 x 8 x 8, four columns per workgroup).
+bool yfft_regs_supported(int Ny, int Nz, bool own_z) { return (Ny == 256 && Nz <= 256) || (own_z && (Ny == 256 || Ny == 512)); }
 
+bool zfft_supported(int Nz);
 // all three components: [3 Nx] planes of [Ny][Nzp]; tw[m] = exp(-2 pi i m / Ny)
 void launch_yfft(double2 *spectra, DGrid G, bool inverse, const double2 *tw, hipStream_t s, int kb) {
     FftPlanX pl;
@@ -2098,6 +2100,7 @@ void launch_yfft(double2 *spectra, DGrid G, bool inverse, const double2 *tw, hip
     const int nplanes = 3 * G.nxl;
     const size_t ps = (size_t)G.Ny * G.Nzp;
     if (G.Ny == 256) { launch_yfft_regs<256, 8, 8, 8, 44, 5, 359>(spectra, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s); return; }   // (four columns: +3 %)
+    if (G.Ny == 512 && yfft_regs_supported(G.Ny, G.Nz, zfft_supported(G.Nz))) { launch_yfft_regs<512, 8, 8, 4, 72, 9, 578>(spectra, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s); return; }
     if (kb == 8) launch_fft_cols<8, 256>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);
     else if (kb == 2) launch_fft_cols<2, 256>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);
     else if (kb == 4 && G.Ny == 360) launch_fft_cols<4, 256, CtPlan<360, 9, 8, 5>>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);   // compile-time plans, as in the x pass
@@ -2105,6 +2108,107 @@ void launch_yfft(double2 *spectra, DGrid G, bool inverse, const double2 *tw, hip
     else if (kb == 4 && G.Ny == 375) launch_fft_cols<4, 256, CtPlan<375, 5, 5, 5, 3>>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);
     else if (kb == 4 && G.Ny == 500) launch_fft_cols<4, 256, CtPlan<500, 5, 5, 5, 4>>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);
     else launch_fft_cols<4, 256>(spectra, pl, tw, nplanes, G.Nzh, G.Nzp, ps, inverse, s);
+}
+
+// ---- the z pass: real rows <-> half spectra, one wavefront per row (round 5) -----------------------------------------------------
+// rocFFT's 1-D real transforms take two kernels per direction (a complex transform of half the length + an r2c / c2r step) and,
+// at 512 points, run well below the rate of its 2-D plan.  Here a wavefront owns a row: its N reals are N / 2 = R0 x 8 x 8 complex
+// points z[n] = x[2n] + i x[2n + 1], lane l holds z[l + 64 r] (coalesced 16-byte loads of the row as it lies), three register
+// stages with two trips through the wave's own LDS column (no workgroup barrier anywhere), then the real <-> half-spectrum step on
+// the natural order and coalesced stores: the row crosses HBM once each way.  Unnormalised both ways, like rocFFT's real plans;
+// tools/debug/zfft_model.py is the index algebra in NumPy, checked against numpy.fft.
+//   forward:  X[k] = (Z[k] + conj Z[NC - k]) / 2 - i/2 W_N^k (Z[k] - conj Z[NC - k]),  k = 0 .. NC      (Z[NC] = Z[0])
+//   inverse:  Z[k] = (X[k] + conj X[NC - k]) + i conj W_N^k (X[k] - conj X[NC - k]),   k = 0 .. NC - 1;  x = N x the true inverse
+struct ZRows { double *real[3]; double2 *spec[3]; int rows; int Nz, Nzp; };   // `rows` rows per component, consecutive in both arrays
+template <int NC, int R0, bool INVERSE>
+__global__ void __launch_bounds__(256)
+k_zfft_rows(ZRows zr, const double2 *__restrict__ tw /* exp(-2 pi i m / N), m < N = 2 NC */) {
+    constexpr int P0 = 72, P1 = 9, CSW = P0 * (R0 - 1) + P1 * 7 + 8, WB = CSW + NC;   // the wave's stage buffer + its natural-order buffer
+    static_assert(NC == R0 * 64 && (R0 == 2 || R0 == 4), "NC = R0 x 8 x 8");
+    __shared__ __attribute__((aligned(16))) double2 lds[4 * WB];
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + wv;
+    if (row >= 3L * zr.rows) return;                          // (whole waves: nothing below synchronises across waves)
+    const int c = (int)(row / zr.rows);
+    const long r = row - (long)c * zr.rows;
+    double2 *const buf = lds + wv * WB, *const nat = buf + CSW;
+    double *const xr = zr.real[c] + r * zr.Nz;
+    double2 *const xs = zr.spec[c] + r * zr.Nzp;
+    constexpr int TS = 2 * NC / NC;                            // W_NC^e = tw[2 e]
+    double2 a[R0];
+    if (!INVERSE) {
+        const double2 *z = reinterpret_cast<const double2 *>(xr);
+#pragma unroll
+        for (int q = 0; q < R0; ++q) a[q] = z[l + 64 * q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < R0; ++q) {
+            const int k = l + 64 * q;
+            const double2 xk = xs[k], xc = xs[NC - k];           // (k = 0 pairs with the Nyquist entry)
+            double2 w = tw[k]; w.y = -w.y;                      // conj W_N^k
+            const double2 sm = make_double2(xk.x + xc.x, xk.y - xc.y), df = make_double2(xk.x - xc.x, xk.y + xc.y);   // xk +- conj xc
+            const double2 t = cmul(w, df);
+            a[q] = make_double2(sm.x - t.y, sm.y + t.x);        // sm + i t
+        }
+    }
+    dft_small<R0, INVERSE>(a);                                  // stage 1 over r -> k0, times W_NC^{l k0}
+#pragma unroll
+    for (int k0 = 1; k0 < R0; ++k0) { double2 t = tw[TS * l * k0]; if (INVERSE) t.y = -t.y; a[k0] = cmul(a[k0], t); }
+#pragma unroll
+    for (int k0 = 0; k0 < R0; ++k0) buf[P0 * k0 + l] = a[k0];
+    __builtin_amdgcn_wave_barrier();
+    const bool act = l < 8 * R0;
+    const int k0 = act ? l >> 3 : 0, lo = l & 7;
+    double2 b[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) b[s] = buf[P0 * k0 + lo + 8 * s];
+    __builtin_amdgcn_wave_barrier();
+    dft_small<8, INVERSE>(b);                                   // stage 2 over s -> k1, times W_64^{nn k1}
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) { double2 t = tw[(2 * NC / 64) * lo * k1]; if (INVERSE) t.y = -t.y; b[k1] = cmul(b[k1], t); }
+    if (act) {
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) buf[P0 * k0 + P1 * k1 + lo] = b[k1];
+    }
+    __builtin_amdgcn_wave_barrier();
+    double2 v[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) v[n] = buf[P0 * k0 + P1 * lo + n];   // lane (k0, k1 = lo)
+    dft_small<8, INVERSE>(v);                                   // stage 3 over nn -> k2: Z[k0 + R0 k1 + 8 R0 k2]
+    if (act) {
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) nat[k0 + R0 * lo + 8 * R0 * k2] = v[k2];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (!INVERSE) {
+#pragma unroll
+        for (int q = 0; q < R0; ++q) {
+            const int k = l + 64 * q;
+            const double2 zk = nat[k], zc0 = nat[(NC - k) & (NC - 1)];
+            const double2 sm = make_double2(zk.x + zc0.x, zk.y - zc0.y), df = make_double2(zk.x - zc0.x, zk.y + zc0.y);   // zk +- conj zc
+            const double2 t = cmul(tw[k], df);                  // W_N^k (zk - conj zc)
+            xs[k] = make_double2(0.5 * (sm.x + t.y), 0.5 * (sm.y - t.x));   // (sm - i t) / 2
+        }
+        if (l == 0) { const double2 z0 = nat[0]; xs[NC] = make_double2(z0.x - z0.y, 0.0); }
+    } else {
+        double2 *z = reinterpret_cast<double2 *>(xr);
+#pragma unroll
+        for (int q = 0; q < R0; ++q) z[l + 64 * q] = nat[l + 64 * q];
+    }
+}
+bool zfft_supported(int Nz) { return Nz == 256 || Nz == 512; }
+void launch_zfft(double *const real[3], double2 *const spec[3], int rows, int Nz, int Nzp, bool inverse, const double2 *tw, hipStream_t s) {
+    ZRows zr{};
+    for (int c = 0; c < 3; ++c) { zr.real[c] = real[c]; zr.spec[c] = spec[c]; }
+    zr.rows = rows; zr.Nz = Nz; zr.Nzp = Nzp;
+    const dim3 g((unsigned)((3L * rows + 3) / 4)), b(256);
+    if (Nz == 512) {
+        if (inverse) hipLaunchKernelGGL((k_zfft_rows<256, 4, true>), g, b, 0, s, zr, tw);
+        else hipLaunchKernelGGL((k_zfft_rows<256, 4, false>), g, b, 0, s, zr, tw);
+    } else {
+        if (inverse) hipLaunchKernelGGL((k_zfft_rows<128, 2, true>), g, b, 0, s, zr, tw);
+        else hipLaunchKernelGGL((k_zfft_rows<128, 2, false>), g, b, 0, s, zr, tw);
+    }
 }
 
 bool xfuse_supported(int Nx) {   // 2^a 3^b 5^c, 16..512

@@ -226,6 +226,7 @@ def test_step_integrates_and_wraps(torch_cuda, oracle):
                                        ((360, 32, 32), 0.1, 4), ((270, 32, 36), -0.1, 4), ((375, 32, 32), 0.0, 4), ((500, 32, 32), 0.2, 4), ((180, 36, 32), 0.0, 4),   # compile-time radix plans (round 4)
                                        ((32, 360, 36), 0.1, 4), ((32, 270, 32), 0.0, 4), ((36, 375, 30), 0.0, 4), ((32, 500, 32), -0.2, 4),   # the own y pass (round 4)
                                        ((36, 256, 30), 0.2, 4), ((256, 256, 32), 0.0, 4),   # the register y pass at Ny = 256 (round 4)
+                                       ((32, 256, 256), 0.0, 4), ((32, 512, 512), 0.0, 4), ((32, 256, 512), 0.15, 4), ((32, 512, 256), 0.2, 4), ((36, 360, 256), -0.1, 4),   # the own z pass (k_zfft_rows, Nz = 256 / 512) and the register y pass at Ny = 512 (round 5)
                                        ((512, 32, 32), -0.1, 4)])  # the last in a box twice as long in x
 def test_fused_x_pass_matches_port(torch_cuda, oracle, grid, xy, P):
     """Every Nx = 2^a 3^b 5^c (the reference's grid rule, PSEv1/Stokes.cc:147-199) takes the fused forward-x FFT + k-space scaling
@@ -234,7 +235,9 @@ def test_fused_x_pass_matches_port(torch_cuda, oracle, grid, xy, P):
     reference's rule at the metric point and is timed by tools/perf.py --grid 0 --xi 0.5).  Since round 4 every Ny = 2^a 3^b 5^c that is
     not a power of two takes the own in-place y pass (k_fft_cols: 48, 36, 30, 40, 45 above; 360 = 9 8 5, 270 = 9 5 3 2, 375 = 5 5 5 3 and
     500 = 5 5 5 4 are the sizes of the reference's rule at BASELINE configs 3 and 4), rocFFT keeping the 1-D z transforms; Ny = 256
-    takes k_yfft_regs (the stages of the register x pass, natural order in and out)."""
+    takes k_yfft_regs (the stages of the register x pass, natural order in and out).  Since round 5 Nz = 256 and 512 take the own z
+    pass (k_zfft_rows: a wavefront per row, real <-> half spectrum in one kernel) wherever the y pass is the engine's own, and Ny = 512
+    takes k_yfft_regs as well: rocFFT is then off the path altogether."""
     import pse_amd
     n = 1200
     pos, force, box = make_suspension(n, L=24.0, xy=xy)

@@ -1984,7 +1984,9 @@ static void launch_fft_cols(double2 *data, const FftPlanX &pl, const double2 *tw
     else hipLaunchKernelGGL((k_fft_cols<KB, NTH, false, 0, PLAN>), g, b, lds, s, data, pl, tw, nkb, Nzh, Nzp, plane_stride);
 }
 // slab ranks: forward = planes (cgrid) -> transformed blocks (blocks); inverse = blocks -> transformed planes
+static bool yfft_slab_regs(double2 *cgrid, double2 *blocks, DGrid G, int nyl, bool inverse, const double2 *tw, hipStream_t s);   // Ny = 256, 512: the register pass
 void launch_yfft_slab(double2 *cgrid, double2 *blocks, DGrid G, int nyl, bool inverse, const double2 *tw, hipStream_t s) {
+    if (yfft_slab_regs(cgrid, blocks, G, nyl, inverse, tw, s)) return;
     FftPlanX pl;
     plan_x(G.Ny, pl);
     constexpr int KB = 4, NTH = 256;
@@ -2007,9 +2009,11 @@ void launch_yfft_slab(double2 *cgrid, double2 *blocks, DGrid G, int nyl, bool in
 // layout A reads are conflict-free), one more barrier, and layout A stores whole pieces.  Three trips through LDS and two barriers
 // per block; eight kz columns = 128-byte pieces at ~60 registers.  (Inverse = the same decimation in frequency with conjugate
 // twiddles, unnormalised like rocFFT's.)
-template <int N, int R0, int R1, int KB, bool INVERSE, int P0, int P1, int CS>
+// MAP (slab ranks, as k_fft_cols): 1 the forward pass stores into the all-to-all blocks `other`, 2 the inverse pass loads from them
+template <int N, int R0, int R1, int KB, bool INVERSE, int P0, int P1, int CS, int MAP = 0>
 __global__ void __launch_bounds__(64 * KB)
-k_yfft_regs(double2 *__restrict__ data, const double2 *__restrict__ twiddle, int nkb, int Nzh, int Nzp, size_t plane_stride) {
+k_yfft_regs(double2 *__restrict__ data, const double2 *__restrict__ twiddle, int nkb, int Nzh, int Nzp, size_t plane_stride,
+            double2 *__restrict__ other = nullptr, int nxl = 0, int nyl = 0) {
     constexpr int M1 = N / R0, R2 = M1 / R1, L2 = R0 * R2, L3 = R0 * R1, TA = KB * M1, PN = M1 + M1 / 8;
     static_assert(R0 == 8 && R1 == 8 && R0 * R1 * R2 == N && L2 <= 64 && TA <= 64 * KB && CS >= N + N / 8, "plan");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -2033,11 +2037,17 @@ k_yfft_regs(double2 *__restrict__ data, const double2 *__restrict__ twiddle, int
     double2 *pO = buf + q * CS + n1 + (n1 >> 3);             // + PN r: natural position of y = n + M1 r
     const double2 zero = make_double2(0, 0);
     const unsigned o0 = (unsigned)n1 * row16 + (unsigned)q * (unsigned)sizeof(double2);
+    // the same (plane, y) in the block layout: component pc = plane / nxl, plane plx of this rank, block y / nyl
+    const int pc = MAP ? plane / nxl : 0, plx = MAP ? plane - pc * nxl : 0;
+    auto blk = [&](int y) -> double2 * {
+        const int qb = y / nyl, jl = y - qb * nyl;
+        return other + (size_t)pc * nxl * plane_stride + (((size_t)qb * nxl + plx) * nyl + jl) * Nzp + kz0 + q;
+    };
     double2 a[R0];
 #pragma unroll
     for (int r = 0; r < R0; ++r) {
         a[r] = zero;
-        if (actA && q < kv) a[r] = *reinterpret_cast<const double2 *>(base + (size_t)(o0 + (unsigned)(M1 * r) * row16));
+        if (actA && q < kv) a[r] = MAP == 2 ? *blk(n1 + M1 * r) : *reinterpret_cast<const double2 *>(base + (size_t)(o0 + (unsigned)(M1 * r) * row16));
     }
     if (tid < M1) twS[tid] = twiddle[R0 * tid];
     dft_small<R0, INVERSE>(a);                                // stage 1 over r -> k0, times W_N^{n k0}
@@ -2069,8 +2079,26 @@ k_yfft_regs(double2 *__restrict__ data, const double2 *__restrict__ twiddle, int
     __syncthreads();
     if (actA && q < kv) {
 #pragma unroll
-        for (int r = 0; r < R0; ++r) *reinterpret_cast<double2 *>(base + (size_t)(o0 + (unsigned)(M1 * r) * row16)) = pO[PN * r];
+        for (int r = 0; r < R0; ++r) {
+            if (MAP == 1) *blk(n1 + M1 * r) = pO[PN * r];
+            else *reinterpret_cast<double2 *>(base + (size_t)(o0 + (unsigned)(M1 * r) * row16)) = pO[PN * r];
+        }
     }
+}
+template <int N, int R0, int R1, int KB, int P0, int P1, int CS>
+static void launch_yfft_regs_slab(double2 *cgrid, double2 *blocks, DGrid G, int nyl, bool inverse, const double2 *tw, hipStream_t s) {
+    const size_t lds = (size_t)(KB * CS + N / R0) * sizeof(double2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_yfft_regs<N, R0, R1, KB, true, P0, P1, CS, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_yfft_regs<N, R0, R1, KB, false, P0, P1, CS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int nkb = (G.Nzh + KB - 1) / KB, nplanes = 3 * G.nxl;
+    const size_t ps = (size_t)G.Ny * G.Nzp;
+    const dim3 g(nplanes * nkb), b(64 * KB);
+    if (inverse) hipLaunchKernelGGL((k_yfft_regs<N, R0, R1, KB, true, P0, P1, CS, 2>), g, b, lds, s, cgrid, tw, nkb, G.Nzh, G.Nzp, ps, blocks, G.nxl, nyl);
+    else hipLaunchKernelGGL((k_yfft_regs<N, R0, R1, KB, false, P0, P1, CS, 1>), g, b, lds, s, cgrid, tw, nkb, G.Nzh, G.Nzp, ps, blocks, G.nxl, nyl);
 }
 template <int N, int R0, int R1, int KB, int P0, int P1, int CS>
 static void launch_yfft_regs(double2 *data, const double2 *tw, int nplanes, int Nzh, int Nzp, size_t plane_stride, bool inverse, hipStream_t s) {
@@ -2092,6 +2120,13 @@ static void launch_yfft_regs(double2 *data, const double2 *tw, int nplanes, int 
 // Round 5: with the own z pass (k_zfft_rows) the register y pass also runs at 512 (8 x 8 x 8, four columns per workgroup).
 bool yfft_regs_supported(int Ny, int Nz, bool own_z) { return (Ny == 256 && Nz <= 256) || (own_z && (Ny == 256 || Ny == 512)); }
 
+static bool yfft_slab_regs(double2 *cgrid, double2 *blocks, DGrid G, int nyl, bool inverse, const double2 *tw, hipStream_t s) {
+    static const bool off = getenv("PSE_YSLAB_REGS") && atoi(getenv("PSE_YSLAB_REGS")) == 0;   // (A/B switch of the developer tools)
+    if (off) return false;
+    if (G.Ny == 256) { launch_yfft_regs_slab<256, 8, 8, 8, 44, 5, 359>(cgrid, blocks, G, nyl, inverse, tw, s); return true; }
+    if (G.Ny == 512) { launch_yfft_regs_slab<512, 8, 8, 4, 72, 9, 578>(cgrid, blocks, G, nyl, inverse, tw, s); return true; }
+    return false;
+}
 bool zfft_supported(int Nz);
 // all three components: [3 Nx] planes of [Ny][Nzp]; tw[m] = exp(-2 pi i m / Ny)
 void launch_yfft(double2 *spectra, DGrid G, bool inverse, const double2 *tw, hipStream_t s, int kb) {
@@ -2120,94 +2155,130 @@ void launch_yfft(double2 *spectra, DGrid G, bool inverse, const double2 *tw, hip
 //   forward:  X[k] = (Z[k] + conj Z[NC - k]) / 2 - i/2 W_N^k (Z[k] - conj Z[NC - k]),  k = 0 .. NC      (Z[NC] = Z[0])
 //   inverse:  Z[k] = (X[k] + conj X[NC - k]) + i conj W_N^k (X[k] - conj X[NC - k]),   k = 0 .. NC - 1;  x = N x the true inverse
 struct ZRows { double *real[3]; double2 *spec[3]; int rows; int Nz, Nzp; };   // `rows` rows per component, consecutive in both arrays
-template <int NC, int R0, bool INVERSE>
+// A wavefront transforms RW = 64 / (8 R0) rows AT ONCE -- stages 2 and 3 are 8 R0 radix-8 butterflies per row, and with one row per
+// wave three quarters of the lanes (256 points: half) did arithmetic for nothing: the kernel ran at 3.3 TB/s bound by vector
+// instructions, not by memory -- and RPW such groups one after the other with the twiddles of its lanes loaded once.
+template <int NC, int R0, bool INVERSE, int RPW>
 __global__ void __launch_bounds__(256)
 k_zfft_rows(ZRows zr, const double2 *__restrict__ tw /* exp(-2 pi i m / N), m < N = 2 NC */) {
-    constexpr int P0 = 72, P1 = 9, CSW = P0 * (R0 - 1) + P1 * 7 + 8, WB = CSW + NC;   // the wave's stage buffer + its natural-order buffer
-    static_assert(NC == R0 * 64 && (R0 == 2 || R0 == 4), "NC = R0 x 8 x 8");
-    __shared__ __attribute__((aligned(16))) double2 lds[4 * WB];
+    // a row's column in LDS: the stage layouts and, once stage 3 has read its points, the natural order on top of them
+    constexpr int P0 = 72, P1 = 9, CSW = P0 * (R0 - 1) + P1 * 7 + 8, WB = CSW > NC ? CSW : NC, RW = 64 / (8 * R0);
+    static_assert(NC == R0 * 64 && (R0 == 2 || R0 == 4) && RPW % RW == 0, "NC = R0 x 8 x 8");
+    __shared__ __attribute__((aligned(16))) double2 lds[4 * RW * WB];
+    __shared__ __attribute__((aligned(16))) double2 tw2[64];   // W_64^{nn k1} at [nn * 8 + k1]
+    typedef double d2v __attribute__((ext_vector_type(2)));
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + wv;
-    if (row >= 3L * zr.rows) return;                          // (whole waves: nothing below synchronises across waves)
-    const int c = (int)(row / zr.rows);
-    const long r = row - (long)c * zr.rows;
-    double2 *const buf = lds + wv * WB, *const nat = buf + CSW;
-    double *const xr = zr.real[c] + r * zr.Nz;
-    double2 *const xs = zr.spec[c] + r * zr.Nzp;
-    constexpr int TS = 2 * NC / NC;                            // W_NC^e = tw[2 e]
-    double2 a[R0];
-    if (!INVERSE) {
-        const double2 *z = reinterpret_cast<const double2 *>(xr);
+    if (threadIdx.x < 64) { double2 t = tw[(2 * NC / 64) * (l >> 3) * (l & 7)]; if (INVERSE) t.y = -t.y; tw2[l] = t; }
+    __syncthreads();
+    const long total = 3L * zr.rows, row0 = ((long)blockIdx.x * 4 + wv) * RPW;
+    if (row0 >= total) return;                                 // (whole waves; nothing below synchronises across waves)
+    const int nrow = (int)min((long)RPW, total - row0);
+    double2 *const col = lds + wv * RW * WB;                   // + j WB: row j of the group
+    double2 t1[R0], tp[R0];                                     // W_NC^{l k0} (stage 1), W_N^{l + 64 q} (the real <-> half-spectrum step)
 #pragma unroll
-        for (int q = 0; q < R0; ++q) a[q] = z[l + 64 * q];
-    } else {
+    for (int q = 0; q < R0; ++q) {
+        t1[q] = tw[2 * l * q]; tp[q] = tw[l + 64 * q];
+        if (INVERSE) { t1[q].y = -t1[q].y; tp[q].y = -tp[q].y; }
+    }
+    auto rowptrs = [&](long row, double *&xr, double2 *&xs) __attribute__((always_inline)) {
+        const int c = (int)(row / zr.rows);
+        const long r = row - (long)c * zr.rows;
+        xr = zr.real[c] + r * zr.Nz; xs = zr.spec[c] + r * zr.Nzp;
+    };
+    // stages 2 and 3: lane -> (row of the group, k0, low index)
+    const int jrow = l / (8 * R0), tl = l % (8 * R0), k0 = tl >> 3, lo = tl & 7;
+    double2 *const mycol = col + jrow * WB;
+    for (int i = 0; i < nrow; i += RW) {
+        const int ng = min(RW, nrow - i);                       // rows of this group (the last may be short; wave-uniform)
+        double2 a[RW][R0];
+        if (!INVERSE) {
 #pragma unroll
-        for (int q = 0; q < R0; ++q) {
-            const int k = l + 64 * q;
-            const double2 xk = xs[k], xc = xs[NC - k];           // (k = 0 pairs with the Nyquist entry)
-            double2 w = tw[k]; w.y = -w.y;                      // conj W_N^k
-            const double2 sm = make_double2(xk.x + xc.x, xk.y - xc.y), df = make_double2(xk.x - xc.x, xk.y + xc.y);   // xk +- conj xc
-            const double2 t = cmul(w, df);
-            a[q] = make_double2(sm.x - t.y, sm.y + t.x);        // sm + i t
+            for (int j = 0; j < RW; ++j) {
+                double *xr; double2 *xs;
+                rowptrs(row0 + i + min(j, ng - 1), xr, xs);
+#pragma unroll
+                for (int q = 0; q < R0; ++q) { const d2v t = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(xr) + l + 64 * q); a[j][q] = make_double2(t.x, t.y); }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RW; ++j) {
+                double *xr; double2 *xs;
+                rowptrs(row0 + i + min(j, ng - 1), xr, xs);
+#pragma unroll
+                for (int q = 0; q < R0; ++q) {
+                    const int k = l + 64 * q;                    // (k = 0 pairs with the Nyquist entry)
+                    const d2v t = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(xs) + k), u = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(xs) + (NC - k));
+                    const double2 sm = make_double2(t.x + u.x, t.y - u.y), df = make_double2(t.x - u.x, t.y + u.y);   // xk +- conj xc
+                    const double2 w = cmul(tp[q], df);           // conj W_N^k (xk - conj xc)
+                    a[j][q] = make_double2(sm.x - w.y, sm.y + w.x);   // sm + i w
+                }
+            }
         }
-    }
-    dft_small<R0, INVERSE>(a);                                  // stage 1 over r -> k0, times W_NC^{l k0}
 #pragma unroll
-    for (int k0 = 1; k0 < R0; ++k0) { double2 t = tw[TS * l * k0]; if (INVERSE) t.y = -t.y; a[k0] = cmul(a[k0], t); }
+        for (int j = 0; j < RW; ++j) {
+            dft_small<R0, INVERSE>(a[j]);                        // stage 1 over r -> k0, times W_NC^{l k0}
 #pragma unroll
-    for (int k0 = 0; k0 < R0; ++k0) buf[P0 * k0 + l] = a[k0];
-    __builtin_amdgcn_wave_barrier();
-    const bool act = l < 8 * R0;
-    const int k0 = act ? l >> 3 : 0, lo = l & 7;
-    double2 b[8];
+            for (int q = 1; q < R0; ++q) a[j][q] = cmul(a[j][q], t1[q]);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) b[s] = buf[P0 * k0 + lo + 8 * s];
-    __builtin_amdgcn_wave_barrier();
-    dft_small<8, INVERSE>(b);                                   // stage 2 over s -> k1, times W_64^{nn k1}
-#pragma unroll
-    for (int k1 = 1; k1 < 8; ++k1) { double2 t = tw[(2 * NC / 64) * lo * k1]; if (INVERSE) t.y = -t.y; b[k1] = cmul(b[k1], t); }
-    if (act) {
-#pragma unroll
-        for (int k1 = 0; k1 < 8; ++k1) buf[P0 * k0 + P1 * k1 + lo] = b[k1];
-    }
-    __builtin_amdgcn_wave_barrier();
-    double2 v[8];
-#pragma unroll
-    for (int n = 0; n < 8; ++n) v[n] = buf[P0 * k0 + P1 * lo + n];   // lane (k0, k1 = lo)
-    dft_small<8, INVERSE>(v);                                   // stage 3 over nn -> k2: Z[k0 + R0 k1 + 8 R0 k2]
-    if (act) {
-#pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) nat[k0 + R0 * lo + 8 * R0 * k2] = v[k2];
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (!INVERSE) {
-#pragma unroll
-        for (int q = 0; q < R0; ++q) {
-            const int k = l + 64 * q;
-            const double2 zk = nat[k], zc0 = nat[(NC - k) & (NC - 1)];
-            const double2 sm = make_double2(zk.x + zc0.x, zk.y - zc0.y), df = make_double2(zk.x - zc0.x, zk.y + zc0.y);   // zk +- conj zc
-            const double2 t = cmul(tw[k], df);                  // W_N^k (zk - conj zc)
-            xs[k] = make_double2(0.5 * (sm.x + t.y), 0.5 * (sm.y - t.x));   // (sm - i t) / 2
+            for (int q = 0; q < R0; ++q) col[j * WB + P0 * q + l] = a[j][q];
         }
-        if (l == 0) { const double2 z0 = nat[0]; xs[NC] = make_double2(z0.x - z0.y, 0.0); }
-    } else {
-        double2 *z = reinterpret_cast<double2 *>(xr);
+        __builtin_amdgcn_wave_barrier();
+        double2 b[8];
 #pragma unroll
-        for (int q = 0; q < R0; ++q) z[l + 64 * q] = nat[l + 64 * q];
+        for (int s = 0; s < 8; ++s) b[s] = mycol[P0 * k0 + lo + 8 * s];
+        __builtin_amdgcn_wave_barrier();
+        dft_small<8, INVERSE>(b);                                // stage 2 over s -> k1, times W_64^{nn k1}
+#pragma unroll
+        for (int k1 = 1; k1 < 8; ++k1) b[k1] = cmul(b[k1], tw2[lo * 8 + k1]);
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) mycol[P0 * k0 + P1 * k1 + lo] = b[k1];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int n = 0; n < 8; ++n) b[n] = mycol[P0 * k0 + P1 * lo + n];   // lane (row, k0, k1 = lo)
+        __builtin_amdgcn_wave_barrier();                         // (the natural order overwrites the stage layout)
+        dft_small<8, INVERSE>(b);                                // stage 3 over nn -> k2: Z[k0 + R0 k1 + 8 R0 k2]
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) mycol[k0 + R0 * lo + 8 * R0 * k2] = b[k2];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            if (j >= ng) break;
+            double *xr; double2 *xs;
+            rowptrs(row0 + i + j, xr, xs);
+            const double2 *nat = col + j * WB;
+            if (!INVERSE) {
+#pragma unroll
+                for (int q = 0; q < R0; ++q) {
+                    const int k = l + 64 * q;
+                    const double2 zk = nat[k], zc0 = nat[(NC - k) & (NC - 1)];
+                    const double2 sm = make_double2(zk.x + zc0.x, zk.y - zc0.y), df = make_double2(zk.x - zc0.x, zk.y + zc0.y);   // zk +- conj zc
+                    const double2 t = cmul(tp[q], df);           // W_N^k (zk - conj zc)
+                    d2v o; o.x = 0.5 * (sm.x + t.y); o.y = 0.5 * (sm.y - t.x);   // (sm - i t) / 2
+                    __builtin_nontemporal_store(o, reinterpret_cast<d2v *>(xs) + k);
+                }
+                if (l == 0) { const double2 z0 = nat[0]; xs[NC] = make_double2(z0.x - z0.y, 0.0); }
+            } else {
+                d2v *z = reinterpret_cast<d2v *>(xr);
+#pragma unroll
+                for (int q = 0; q < R0; ++q) { const double2 t = nat[l + 64 * q]; d2v o; o.x = t.x; o.y = t.y; __builtin_nontemporal_store(o, z + l + 64 * q); }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                         // (the next group's stage 1 overwrites the columns)
     }
 }
+constexpr int ZFFT_RPW = 8;
 bool zfft_supported(int Nz) { return Nz == 256 || Nz == 512; }
 void launch_zfft(double *const real[3], double2 *const spec[3], int rows, int Nz, int Nzp, bool inverse, const double2 *tw, hipStream_t s) {
     ZRows zr{};
     for (int c = 0; c < 3; ++c) { zr.real[c] = real[c]; zr.spec[c] = spec[c]; }
     zr.rows = rows; zr.Nz = Nz; zr.Nzp = Nzp;
-    const dim3 g((unsigned)((3L * rows + 3) / 4)), b(256);
+    const dim3 g((unsigned)((3L * rows + 4 * ZFFT_RPW - 1) / (4 * ZFFT_RPW))), b(256);
     if (Nz == 512) {
-        if (inverse) hipLaunchKernelGGL((k_zfft_rows<256, 4, true>), g, b, 0, s, zr, tw);
-        else hipLaunchKernelGGL((k_zfft_rows<256, 4, false>), g, b, 0, s, zr, tw);
+        if (inverse) hipLaunchKernelGGL((k_zfft_rows<256, 4, true, ZFFT_RPW>), g, b, 0, s, zr, tw);
+        else hipLaunchKernelGGL((k_zfft_rows<256, 4, false, ZFFT_RPW>), g, b, 0, s, zr, tw);
     } else {
-        if (inverse) hipLaunchKernelGGL((k_zfft_rows<128, 2, true>), g, b, 0, s, zr, tw);
-        else hipLaunchKernelGGL((k_zfft_rows<128, 2, false>), g, b, 0, s, zr, tw);
+        if (inverse) hipLaunchKernelGGL((k_zfft_rows<128, 2, true, ZFFT_RPW>), g, b, 0, s, zr, tw);
+        else hipLaunchKernelGGL((k_zfft_rows<128, 2, false, ZFFT_RPW>), g, b, 0, s, zr, tw);
     }
 }
 

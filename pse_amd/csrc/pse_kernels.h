@@ -37,12 +37,12 @@ struct RowMap {
     __host__ __device__ int list_rows() const { return n ? base[n - 1] + ((hi[n - 1] - lo[n - 1] + 255) & ~255) : 0; }
     // sorted row of list row lr, or -1 (padding)
     __device__ __forceinline__ int first_row() const { return hi[0] > lo[0] ? lo[0] : (n > 1 && hi[1] > lo[1] ? lo[1] : lo[2]); }
-    __device__ __forceinline__ int row(int lr) const {
-        int k = 0;
-        if (n > 1 && lr >= base[1]) k = 1;
-        if (n > 2 && lr >= base[2]) k = 2;
-        const int i = lo[k] + (lr - base[k]);
-        return i < hi[k] ? i : -1;
+    __device__ __forceinline__ int row(int lr) const {   // (constant indices only: the struct then lives in scalar registers, also when it was loaded from memory)
+        int l = lo[0], h = hi[0], b = base[0];
+        if (n > 1 && lr >= base[1]) { l = lo[1]; h = hi[1]; b = base[1]; }
+        if (n > 2 && lr >= base[2]) { l = lo[2]; h = hi[2]; b = base[2]; }
+        const int i = l + (lr - b);
+        return i < h ? i : -1;
     }
 };
 struct RowRanges { int n, lo[3], hi[3]; };   // up to three disjoint row ranges (own rows and the two ghost regions)
@@ -64,6 +64,24 @@ struct DevRowArgs {
     const LocalRows *lr;          // device (nullable): for stage_hi
     double4 *stage_hi;            // rows [lr->last_begin, lr->n_own) of the result also go to stage_hi[row - last_begin]
     int rows_cap;                 // list rows to launch for (>= what *rm will say)
+};
+// a RowMap in scalars: what a kernel works with when the map may come from device memory (assigning a loaded struct to the by-value
+// kernel argument put it in scratch memory: 44 bytes per lane and 20 % on the pair-list mat-vec)
+struct RowMapRegs {
+    int n, l0, l1, l2, h0, h1, h2, b1, b2;
+    __device__ __forceinline__ RowMapRegs(const RowMap &m, const RowMap *dev) {
+        n = m.n; l0 = m.lo[0]; l1 = m.lo[1]; l2 = m.lo[2]; h0 = m.hi[0]; h1 = m.hi[1]; h2 = m.hi[2]; b1 = m.base[1]; b2 = m.base[2];
+        if (dev) { n = dev->n; l0 = dev->lo[0]; l1 = dev->lo[1]; l2 = dev->lo[2]; h0 = dev->hi[0]; h1 = dev->hi[1]; h2 = dev->hi[2]; b1 = dev->base[1]; b2 = dev->base[2]; }
+    }
+    __device__ __forceinline__ int list_rows() const { return n == 0 ? 0 : (n == 1 ? ((h0 - l0 + 255) & ~255) : (n == 2 ? b1 + ((h1 - l1 + 255) & ~255) : b2 + ((h2 - l2 + 255) & ~255))); }
+    __device__ __forceinline__ int first_row() const { return h0 > l0 ? l0 : (n > 1 && h1 > l1 ? l1 : l2); }
+    __device__ __forceinline__ int row(int lr) const {
+        int l = l0, h = h0, b = 0;
+        if (n > 1 && lr >= b1) { l = l1; h = h1; b = b1; }
+        if (n > 2 && lr >= b2) { l = l2; h = h2; b = b2; }
+        const int i = l + (lr - b);
+        return i < h ? i : -1;
+    }
 };
 inline RowMap row_map(int lo, int hi) { return RowMap{1, {lo, 0, 0}, {hi, 0, 0}, {0, 0, 0}}; }
 inline RowMap row_map(const int (*rg)[2], int n) {

@@ -295,17 +295,20 @@ __device__ __forceinline__ void vl_store(char *vrec, int slot, int lane, unsigne
 // M.psi, the first Lanczos mat-vec, for one more gather per neighbour.
 // VL: the pass also writes the neighbour list kept across steps -- every pair closer than vl.rskin = rcut + skin (the
 // pre-filter and the queue work with that radius; f, g and the pair list still stop at rcut).
-template <bool LIST, bool CL, bool TWO, bool VL>
+// DEV: an owned-particle rank -- the rows come from device memory (DevRowArgs); a separate instantiation, so that the single-GPU
+// pass keeps its 166 registers (with the few extra scalars it spilled)
+template <bool LIST, bool CL, bool TWO, bool VL, bool DEV = false>
 __global__ void __launch_bounds__(TPB, ((LIST && CL && !VL) ? 3 : 1))   // the list-building pass of every step: <= 168 VGPRs (it takes 166)
 k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf_s, const double4 *__restrict__ vec_s,
-              double4 *__restrict__ out_s, RowMap rm, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2,
+              double4 *__restrict__ out_s, RowMap rm_arg, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2,
               float rcut2_pre, double self, const double *__restrict__ coef_g, int ncoef, NbList nb,
               const double4 *__restrict__ vec2_s, double4 *__restrict__ out2_s, VerletList vl, double2 *__restrict__ pv_out,
               double *__restrict__ sums0, int sums0_cap, Gate gate, DevRowArgs dr) {
     if (gate.closed()) return;
+    const RowMapRegs rm(rm_arg, DEV ? dr.rm : nullptr);
+    if (!DEV) nc.xpad = 0;   // (only owned-particle ranks pad their x layers: a constant here, the term folds away)
     int nb_live = gridDim.x;
-    if (dr.rm) {   // an owned-particle rank: the rows of this pass are known on the device only; the launch covers the capacity
-        rm = *dr.rm;
+    if (DEV) {   // an owned-particle rank: the rows of this pass are known on the device only; the launch covers the capacity
         nb_live = (rm.list_rows() + TPB - 1) / TPB;
         if ((int)blockIdx.x >= nb_live) return;
     }
@@ -491,7 +494,7 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
             ((double *)&pv_out[3 * (size_t)i + 1])[1] = wx;
             pv_out[3 * (size_t)i + 2] = make_double2(wy, wz);
         }
-        if (dr.stage_hi) {   // rows of the last layers: parked for the exchange with the right neighbour
+        if (DEV && dr.stage_hi) {   // rows of the last layers: parked for the exchange with the right neighbour
             const int lb = dr.lr->last_begin, no = dr.lr->n_own;
             if (i >= lb && i < no) dr.stage_hi[i - lb] = make_double4(wx, wy, wz, 0.0);
         }
@@ -602,14 +605,14 @@ k_mreal_verlet(const double4 *__restrict__ pos_s, const double2 *__restrict__ pv
 // mat-vec: vec = w1 = M q, result w2); 3 the sums of a single step in the two-step driver (vec = q, result w1).
 template <int FUSE, int UNROLL, int NT, bool PACKED, int WSP = 1>
 __global__ void __launch_bounds__(NT)
-k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, RowMap rm,
+k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, RowMap rm_arg,
              DBox box, int shift_only, double self, NbList nb, LzFuse lz, const double2 *__restrict__ pv,
              const int *__restrict__ cell_off, DCells nc, double rcut2, const double *__restrict__ coef, VerletList vl,
              double2 *__restrict__ pv_out, const int *__restrict__ stop, DevRowArgs dr) {
     if (stop && *stop) return;   // the Lanczos iteration has ended (device-side decision)
+    const RowMapRegs rm(rm_arg, dr.rm);
     int nb_live = gridDim.x;
     if (dr.rm) {   // an owned-particle rank: rows from device memory; workgroups past the last one still own a slot of the partial sums
-        rm = *dr.rm;
         nb_live = (rm.list_rows() + (WSP > 1 ? 64 : NT) - 1) / (WSP > 1 ? 64 : NT);
         if ((int)blockIdx.x >= nb_live) {
             if (FUSE && threadIdx.x == 0)
@@ -836,6 +839,11 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
     const double rpre = (wr ? vl.rskin : rcut) + 16.0 * cmax * 5.97e-8;
     const float rcut2_pre = (float)(rpre * rpre * (1.0 + 1e-6));
 #define PSE_CELLS(L, C, T, V) hipLaunchKernelGGL((k_mreal_cells<L, C, T, V>), g, b, (C) ? cb : 0, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, two ? vec2_s : nullptr, out2_s, vl, two ? pv_out : nullptr, (two && (C)) ? sums0 : nullptr, sums0_cap, gate, dr)
+    if (dr.rm) {   // owned-particle ranks (table in LDS, no kept list): the two passes of pse_team_step_local
+        if (list && two) hipLaunchKernelGGL((k_mreal_cells<true, true, true, false, true>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, vec2_s, out2_s, vl, pv_out, nullptr, 0, gate, dr);
+        else hipLaunchKernelGGL((k_mreal_cells<false, true, false, false, true>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, nullptr, out2_s, vl, nullptr, nullptr, 0, gate, dr);
+        return;
+    }
     if (list) {
         if (cl && two) { if (wr) PSE_CELLS(true, true, true, true); else PSE_CELLS(true, true, true, false); }
         else if (cl) { if (wr) PSE_CELLS(true, true, false, true); else PSE_CELLS(true, true, false, false); }

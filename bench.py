@@ -178,6 +178,102 @@ def launch_ranks(args, argv, script=None):
     return 0
 
 
+def run_owned_particle_team(args, world, rank, host_transport, dist, torch):
+    """--gpus N > 1 (default): every rank owns the particles of its x slab (pse_team_step_local): migration + ghosts in one exchange
+    of fixed-size messages, the whole step queue-only.  The JSON line carries what a first run on a multi-GPU node needs to be
+    read: exchanges per step, device time of every exchange by kind, the spans of both lanes, the critical path."""
+    from pse_amd.sharded import LocalShardedSimulation
+    n, grid = args.n, args.grid
+    pos, force, L = suspension(n, args.phi)
+    box = (L, L, L, 0.0)
+    xi = math.pi * grid / (2.0 * L * math.sqrt(-math.log(args.error)))      # SURVEY.md 8(d): xi from the fixed grid
+    sim = LocalShardedSimulation(n, box, world, rank, transport="host" if host_transport else "rccl", xi=xi, error=args.error, seed=1,
+                                 grid=(grid,) * 3)
+    sim.load(pos, force, mass=1.0)
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def agree(v):     # the starting count of the next step: the largest any rank reports (they all take the same decisions)
+        t = torch.tensor([float(v)], dtype=torch.float64, device="cpu" if host_transport else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t[0])
+
+    # warm-up: the starting count of the Lanczos iteration grows until a step converges inside its queue (a queue-only step never
+    # waits for more iterations; pse_info.lanczos_status says when its queue was too short)
+    m, status = 2, 1
+    for it in range(max(args.warmup, 1)):
+        sim.step(args.kT, args.dt, it, lanczos_m=m)
+        torch.cuda.synchronize()
+        i = sim.engine.info()
+        status = agree(i["lanczos_status"])
+        m = agree(max(i["lanczos_m"], 2) + (2 if i["lanczos_status"] == 1 else 0))
+        if it >= args.warmup - 1 and status == 0:
+            break
+    # deterministic M.F (kT = 0, no update)
+    barrier()
+    n_mf = max(3, args.steps // 2)
+    t0 = time.perf_counter()
+    for it in range(n_mf):
+        sim.step(0.0, args.dt, 0, integrate=False)
+    barrier()
+    t_mf = (time.perf_counter() - t0) / n_mf
+    # headline: EXACTLY --steps steps between two barriers; nothing is read back inside (the step only queues work)
+    barrier()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        sim.step(args.kT, args.dt, args.warmup + it, lanczos_m=m)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    i = sim.engine.info()
+    status = agree(i["lanczos_status"])
+    # a few more steps with every exchange bracketed by events
+    sim.team.set_diag(True)
+    diags = []
+    for it in range(5):
+        sim.step(args.kT, args.dt, args.warmup + args.steps + it, lanczos_m=m)
+        diags.append(sim.team.diag())
+    sim.team.set_diag(False)
+    flags = sim.team.local_status()
+    t = torch.tensor([elapsed, t_mf], dtype=torch.float64, device="cpu" if host_transport else "cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, t_mf = float(t[0]), float(t[1])
+    n_loc = torch.tensor([float(sim.s.n_local.item())], dtype=torch.float64, device="cpu" if host_transport else "cuda")
+    dist.all_reduce(n_loc, op=dist.ReduceOp.SUM)
+    if rank != 0:
+        return
+    info = sim.engine.info()
+    d = diags[-1]
+    med = lambda key: {k: [round(float(np.median([x[key][k][j] for x in diags])), 2) for j in range(len(d[key][k]))] for k in d[key]}   # noqa: E731
+    t_step = elapsed / args.steps
+    transport = ("HOST-STAGED transport (torch.distributed gloo, ranks may share a GPU): a functional run of the process-per-rank driver, "
+                 "not a scaling number" if host_transport else "RCCL over xGMI")
+    lay = sim.layout
+    out = {
+        "metric": "BD particle-steps/s (full PSE Brownian step: M.F + k-space noise + Lanczos M^1/2.psi + Euler), N=1e6, phi=0.1",
+        "value": n / t_step, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"random-sphere suspension N={n}, phi={args.phi}, cubic L={L:.2f}, grid {grid}^3, xi={xi:.4f}, "
+                               f"rcut={info['rcut']:.3f}, P={info['P']}, error={args.error}, kT={args.kT}, dt={args.dt}",
+                   "parallelism": f"{world} ranks, {transport}; owned-particle decomposition (pse_team_step_local): {lay['layers_per_rank']} of "
+                                  f"{lay['layers']} cell layers along x per rank + 2 ghost layers per side, far-field grid in {world} x-slabs "
+                                  f"(2 all-to-alls + 1 plane halo per step on the far-field lane), two Lanczos iterations per exchange, "
+                                  f"row capacity {sim.engine.params.n_max} per rank; the force provider of the bench re-gathers its fixed forces "
+                                  f"by tag after every step"},
+        "steps_per_s": 1.0 / t_step, "mf_evals_per_s": 1.0 / t_mf, "lanczos_m": info["lanczos_m"], "lanczos_status": status,
+        "lanczos_exchanges": info["lanczos_exchanges"], "particles_owned_sum": int(n_loc[0]), "device_flags": flags,
+        # what the first run on a multi-GPU node needs (VERDICT r4 item 2): per-exchange device time by kind (median of 5 steps), the
+        # host time spent issuing each, bytes this rank sent, the spans of the two lanes
+        "exchanges_per_step": d["exchanges_per_step"], "exchange_us": med("exchange_us"), "exchange_host_us": med("exchange_host_us"),
+        "exchange_bytes": d["exchange_bytes"],
+        "lanes_ms": {k: round(float(np.median([x["lanes_ms"][k] for x in diags])), 4) for k in ("main", "side")},
+        "critical_path_ms": round(float(np.median([x["critical_path_ms"] for x in diags])), 4),
+        "roofline": None, "cpu_baseline": None,
+    }
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,6 +294,9 @@ def main():
     ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
                     help="multi-rank runs: RCCL over xGMI (one GPU per rank), or the host-staged transport over gloo (ranks may "
                          "share a GPU: exercises the process-per-rank driver on a one-GPU box; never the headline)")
+    ap.add_argument("--replicated", action="store_true",
+                    help="multi-rank runs: the replicated-state team calls (every rank passes all N particles) instead of the "
+                         "owned-particle step (pse_team_step_local), which is the default")
     ap.add_argument("--dry-run", action="store_true", help="with --gpus N > 1: print the launch command and stop")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -235,6 +334,10 @@ def main():
     import pse_amd
     from pse_amd import distributed as pdist
 
+    if world > 1 and not args.replicated:
+        run_owned_particle_team(args, world, rank, host_transport, dist, torch)
+        dist.destroy_process_group()
+        return
     n, grid = args.n, args.grid
     pos, force, L = suspension(n, args.phi)
     xi = math.pi * grid / (2.0 * L * math.sqrt(-math.log(args.error)))      # xi from the fixed grid

@@ -274,6 +274,26 @@ int pse_local_layout(pse_handle *h, int *rows_own, int *rows_ghost, int *records
  * capacity exceeded, 8 a particle moved beyond the neighbour's slab, 16 *n_local above the capacity; returns PSE_ERR_INVALID if any */
 int pse_team_local_status(pse_team *team, int *flags);
 
+/* -- self-diagnosis of a team call (for the first run on a multi-GPU node: one number would say nothing about where the time went)
+ * With it on, every exchange of a call is bracketed by two events on the stream of the lane that issues it, and the spans of
+ * the two lanes are taken the same way; pse_team_get_diag waits for the call and reads them.  kind: 0 the first exchange of an
+ * owned-particle step (migrants + ghosts), 1 Lanczos (ghost rows of the mat-vec results + the ranks' partial sums), 2 all-to-all
+ * of the far-field transpose, 3 plane halo of the gather, 4 velocity all-gather (replicated-state calls), 5 other ghost rows. */
+#define PSE_DIAG_MAX 48
+typedef struct pse_team_diag {
+    int n_exchanges;
+    int kind[PSE_DIAG_MAX];
+    int lane[PSE_DIAG_MAX];                   /* 0 main lane (sort, near field, Lanczos, update), 1 far-field lane */
+    double device_us[PSE_DIAG_MAX];           /* between the two events: for RCCL the hand-over to the communication stream, the
+                                                 transfers and the hand-over back; host-staged transport: incl. the host's part */
+    double host_us[PSE_DIAG_MAX];             /* host time spent issuing it (host-staged transport: the whole staged exchange) */
+    unsigned long long bytes[PSE_DIAG_MAX];   /* sent by this rank */
+    double main_lane_ms, side_lane_ms;        /* first to last event of the lane's stream inside the call (side: fork to join; 0: one lane) */
+    double critical_path_ms;                  /* = main_lane_ms: the main lane joins the far-field lane before it ends */
+} pse_team_diag;
+int pse_team_set_diag(pse_team *team, int enabled);
+int pse_team_get_diag(pse_team *team, pse_team_diag *out);
+
 /* Developer switch for an IN-PROCESS team (measurement, not a result): from now on the team queues the work of the one member
  * with this slab rank only -- its kernels on both lanes and the copies that stand for what it receives; the other members'
  * buffers keep what the last full call left there.  The wall time of a call is then that rank's critical path with a GPU to

@@ -58,6 +58,16 @@ class pse_host_xfer(ctypes.Structure):
                 ("recv", ctypes.POINTER(ctypes.c_double)), ("recv_count", ctypes.c_size_t), ("recv_from", ctypes.c_int)]
 
 
+PSE_DIAG_MAX = 48
+
+
+class pse_team_diag(ctypes.Structure):
+    _fields_ = [("n_exchanges", ctypes.c_int), ("kind", ctypes.c_int * PSE_DIAG_MAX), ("lane", ctypes.c_int * PSE_DIAG_MAX),
+                ("device_us", ctypes.c_double * PSE_DIAG_MAX), ("host_us", ctypes.c_double * PSE_DIAG_MAX),
+                ("bytes", ctypes.c_ulonglong * PSE_DIAG_MAX), ("main_lane_ms", ctypes.c_double), ("side_lane_ms", ctypes.c_double),
+                ("critical_path_ms", ctypes.c_double)]
+
+
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(pse_host_xfer))
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_size_t)
 
@@ -106,6 +116,8 @@ SYMBOLS = {
                                  ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _d, _d, _u, _d, _i, _ip]),
     "pse_local_layout": (_i, [_vp, _ip, _ip, _ip, _ip, _ip]),
     "pse_team_local_status": (_i, [_vp, _ip]),
+    "pse_team_set_diag": (_i, [_vp, _i]),
+    "pse_team_get_diag": (_i, [_vp, ctypes.POINTER(pse_team_diag)]),
     "pse_host_lanczos_sqrt_e1": (_i, [_i, _dp, _dp, _dp]),
     "pse_host_select_params": (_i, [ctypes.POINTER(pse_params), ctypes.POINTER(pse_info)]),
 }

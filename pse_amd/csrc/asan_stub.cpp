@@ -94,6 +94,8 @@ int pse_team_step_local(pse_team *, pse_double4 *const *, pse_double4 *const *, 
                         unsigned int *const *, unsigned int *const *, double, double, unsigned int, double, int, int *) { return no_device("pse_team_step_local"); }
 int pse_local_layout(pse_handle *, int *, int *, int *, int *, int *) { return no_device("pse_local_layout"); }
 int pse_team_local_status(pse_team *, int *) { return no_device("pse_team_local_status"); }
+int pse_team_set_diag(pse_team *, int) { return no_device("pse_team_set_diag"); }
+int pse_team_get_diag(pse_team *, pse_team_diag *) { return no_device("pse_team_get_diag"); }
 int pse_team_mobility(pse_team *, const pse_double4 *const *, const pse_double4 *const *, pse_double4 *const *, const unsigned int *, unsigned int, int) { return no_device("pse_team_mobility"); }
 int pse_team_brownian_velocity(pse_team *, const pse_double4 *const *, const pse_double4 *const *, pse_double4 *const *, const unsigned int *,
                                unsigned int, double, double, unsigned int, int *) { return no_device("pse_team_brownian_velocity"); }

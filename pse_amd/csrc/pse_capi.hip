@@ -11,13 +11,17 @@
 #include <rocfft/rocfft.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
 #include <functional>
+#include <future>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -849,6 +853,34 @@ struct pse_team {
     int solo = -1;
     std::vector<pse_handle *> solo_m;
     bool lanes = true;           // two compute lanes (PSE_TEAM_LANES=0: one stream for everything, also the RCCL calls)
+    // self-diagnosis (pse_team_set_diag): every exchange of a call bracketed by events on the lane that issues it, the lanes'
+    // spans, the host time the transport's callback took -- read after the call by pse_team_get_diag
+    struct Diag {
+        bool on = false;
+        std::vector<hipEvent_t> ev;          // 2 per exchange slot + 4 for the lanes
+        int n = 0;                           // exchanges of the last call
+        int kind[PSE_DIAG_MAX]; int lane[PSE_DIAG_MAX]; double host_us[PSE_DIAG_MAX]; unsigned long long bytes[PSE_DIAG_MAX];
+        bool side_used = false;
+    } diag;
+};
+enum { DIAG_FIRST = 0, DIAG_LANCZOS = 1, DIAG_ALL_TO_ALL = 2, DIAG_HALO = 3, DIAG_ALL_GATHER = 4, DIAG_GHOST = 5 };
+// brackets one exchange with two events on the stream of the lane that issues it (and measures the host time in between)
+struct DiagScope {
+    pse_team &T; int slot = -1; hipStream_t s; std::chrono::steady_clock::time_point t0;
+    DiagScope(pse_team &team, int kind, bool wave_lane, unsigned long long bytes) : T(team) {
+        if (!T.diag.on || T.diag.n >= PSE_DIAG_MAX || T.G == 1) return;
+        pse_handle *h = T.solo >= 0 ? T.solo_m[0] : T.m[0];
+        s = wave_lane ? h->wstream : h->stream;
+        slot = T.diag.n++;
+        T.diag.kind[slot] = kind; T.diag.lane[slot] = wave_lane ? 1 : 0; T.diag.bytes[slot] = bytes; T.diag.host_us[slot] = 0.0;
+        (void)hipEventRecord(T.diag.ev[2 * slot], s);
+        t0 = std::chrono::steady_clock::now();
+    }
+    ~DiagScope() {
+        if (slot < 0) return;
+        T.diag.host_us[slot] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        (void)hipEventRecord(T.diag.ev[2 * slot + 1], s);
+    }
 };
 static const std::vector<pse_handle *> &act(const pse_team &T) { return T.solo >= 0 ? T.solo_m : T.m; }
 #define NCCLCHK(x)                                                                                              \
@@ -861,6 +893,15 @@ static bool loopback(const pse_team &T) { return T.G > 1 && !T.nccl && !T.has_cb
 static bool remote(const pse_team &T) { return T.nccl || T.has_cb; }   // one member per process
 static hipEvent_t team_event(pse_team &T) { hipEvent_t e = T.evs[T.ev_next]; T.ev_next = (T.ev_next + 1) % T.evs.size(); return e; }
 
+static void diag_mark(pse_team &T, int which, hipStream_t s) {   // 0 / 1 main lane begin / end, 2 / 3 far-field lane begin / end
+    if (T.diag.on) (void)hipEventRecord(T.diag.ev[2 * PSE_DIAG_MAX + which], s);
+    if (T.diag.on && which == 2) T.diag.side_used = true;
+}
+static void diag_begin(pse_team &T) {
+    if (!T.diag.on) return;
+    T.diag.n = 0; T.diag.side_used = false;
+    diag_mark(T, 0, (T.solo >= 0 ? T.solo_m[0] : T.m[0])->stream);
+}
 // One exchange of a process-per-rank team: a list of point-to-point transfers (counts in doubles; 0 = none) -- ONE RCCL group, or one
 // call of the host program's transport.  Every exchange of the team goes through here -- also the partial sums of the Lanczos
 // iteration, which travel as small blocks to every rank in the group of the ghost rows (no collective of another kind is ever
@@ -957,6 +998,7 @@ struct CopyBatch {
 template <class FS, class FR>
 static int team_all_to_all(pse_team &T, FS send, FR recv, size_t blk_doubles, int nset, size_t set_stride) {
     if (T.G == 1) return 0;
+    DiagScope dg(T, DIAG_ALL_TO_ALL, true, (unsigned long long)nset * (T.G - 1) * blk_doubles * sizeof(double));
     if (remote(T)) {
         pse_handle *h = T.m[0];
         std::vector<Xfer> ops;
@@ -978,6 +1020,7 @@ static int team_all_to_all(pse_team &T, FS send, FR recv, size_t blk_doubles, in
 // neighbour's first nhalo planes above it
 static int team_halo_exchange(pse_team &T) {
     if (T.G == 1) return 0;
+    DiagScope dg(T, DIAG_HALO, true, (unsigned long long)3 * (T.m[0]->G.hl + T.m[0]->G.nhalo) * T.m[0]->G.Ny * T.m[0]->G.Nz * sizeof(double));
     auto comp = [](pse_handle *h, int c) { return h->rgrid + (size_t)c * (h->G.nxl + h->G.hl + h->G.nhalo) * h->G.Ny * h->G.Nz; };
     if (remote(T)) {
         pse_handle *h = T.m[0];
@@ -1034,8 +1077,11 @@ static void sum_ops(const pse_handle *h, int G, int n, std::vector<Xfer> &ops) {
 // teams execute the receives as device copies: the k-th receive of dst from src pairs with the k-th send of src to dst -- the
 // matching rule of the message transports.
 template <class FOPS>
-static int team_run_exchange(pse_team &T, FOPS make_ops, bool wave_lane) {
+static int team_run_exchange(pse_team &T, FOPS make_ops, bool wave_lane, int kind = DIAG_GHOST) {
     if (T.G == 1) return 0;
+    unsigned long long bytes = 0;
+    if (T.diag.on) for (const Xfer &x : make_ops(T.solo >= 0 ? T.solo_m[0] : T.m[0])) bytes += (unsigned long long)x.ns * sizeof(double);
+    DiagScope dg(T, kind, wave_lane, bytes);
     if (remote(T)) return team_exchange(T, make_ops(T.m[0]), wave_lane);
     std::vector<std::vector<Xfer>> all(T.G);
     for (pse_handle *h : T.m) all[h->slab_rank] = make_ops(h);
@@ -1064,7 +1110,7 @@ static int team_ghost_exchange(pse_team &T, FB buf) {
 // right neighbour's first cell layer and its left neighbour's last one) travel in ONE group.
 template <class FB>
 static int team_lanczos_exchange(pse_team &T, FB buf) {
-    return team_run_exchange(T, [&](pse_handle *h) { auto ops = ghost_ops(h, T.G, {buf(h)}); sum_ops(h, T.G, 3, ops); return ops; }, false);
+    return team_run_exchange(T, [&](pse_handle *h) { auto ops = ghost_ops(h, T.G, {buf(h)}); sum_ops(h, T.G, 3, ops); return ops; }, false, DIAG_LANCZOS);
 }
 
 // every rank's own rows [row_lo[r], row_lo[r+1]) of buf become visible on every rank (blocks of different sizes)
@@ -1072,6 +1118,7 @@ template <class FB>
 static int team_all_gather_rows(pse_team &T, FB buf) {
     if (T.G == 1) return 0;
     const std::vector<int> &lo = T.m[0]->row_lo;
+    DiagScope dg(T, DIAG_ALL_GATHER, false, (unsigned long long)(T.G - 1) * (lo[T.m[0]->slab_rank + 1] - lo[T.m[0]->slab_rank]) * 32ull);
     if (remote(T)) {
         pse_handle *h = T.m[0];
         const int r = h->slab_rank;
@@ -1426,6 +1473,7 @@ struct WavePump {
                 if (h->side_on) {   // fork: the wave chain starts once the sorted arrays exist
                     HIPCHK(hipEventRecord(h->ev_fork, h->stream));
                     HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+                    if (h == act(*T)[0]) diag_mark(*T, 2, h->side);
                 }
         *mask |= (1u << PH_SPREAD) | (1u << PH_FFTF) | (1u << PH_SCALE) | (1u << PH_FFTI) | (1u << PH_GATHER) | (1u << PH_RECORDS);
         if (T->m[0]->grid_slabs > 1) *mask |= 1u << PH_COMM;
@@ -1789,7 +1837,7 @@ static int lanczos_team(pse_team &T, int N, double tol, double scale, int *m_io,
                                       auto ops = ghost_ops(h, T.G, {(double *)h->w_s, full ? (double *)h->w2_s : nullptr}, 2);
                                       sum_ops(h, T.G, LZ_NGRAM, ops);
                                       return ops; },
-                                  false));
+                                  false, DIAG_LANCZOS));
             for (pse_handle *h : act(T)) {
                 int rg[3][2];
                 const int nrg = full ? row_ranges(h, N, 2, rg) : 0;   // a single step derives its scalars only, for now
@@ -1872,6 +1920,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
                     unsigned timestep, int *m_io, unsigned *mask, const StepTail *tail = nullptr) {
     for (pse_handle *h : T.m)
         if (h->loc.on) return fail(PSE_ERR_INVALID, "this handle is an owned-particle rank (pse_params.local_rows): drive it through pse_team_step_local");
+    diag_begin(T);
     for (size_t r = 0; r < T.m.size(); ++r)
         if (T.solo < 0 || T.m[r]->slab_rank == T.solo)   // psi rides with the gather into cell order: the near-field pass that
             TRY(prepare(T.m[r], a[r].pos, a[r].force, group, N, true, false, PrepExtra{kT > 0.0, timestep}));   // builds the pair list applies M_real to F and psi together
@@ -1926,6 +1975,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
             TRY(pump.drain());
             for (pse_handle *h : act(T))
                 if (h->side_on && h->sink.on) {
+                    if (h == act(T)[0]) diag_mark(T, 3, h->side);
                     HIPCHK(hipEventRecord(h->ev_join, h->side));
                     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
                 }
@@ -1942,6 +1992,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
         // every rank has all three contributions for the rows it owns: add them, exchange the row blocks once
         for (pse_handle *h : act(T))
             if ((parts & 2) && h->side_on) {   // join: the gathered far-field velocity is needed now
+                if (h == act(T)[0] && !(noise && h->tail_done)) diag_mark(T, 3, h->side);
                 HIPCHK(hipEventRecord(h->ev_join, h->side));
                 HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
             }
@@ -1976,6 +2027,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
         }
         HIPCHK(hipGetLastError());
     }
+    diag_mark(T, 1, act(T)[0]->stream);
     return 0;
 }
 
@@ -2090,7 +2142,7 @@ static int lanczos_local(pse_team &T, double tol, int *m_io, WavePump *pump) {
                 ops.push_back(Xfer{(double *)h->loc.stage_w2, cnt, R, (double *)(h->w2_s + g.c_own), cnt, L});
             }
             sum_ops(h, T.G, LZ_NGRAM, ops);
-            return ops; }, false);
+            return ops; }, false, DIAG_LANCZOS);
     };
     auto full_block = [&](int j, bool gated) -> int {
         for (pse_handle *h : act(T)) {
@@ -2174,6 +2226,7 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
     if (kT < 0 || !(dt > 0)) return fail(PSE_ERR_INVALID, "need kT >= 0 and dt > 0");
     const bool noise = kT > 0.0;
     unsigned mask = 0;
+    diag_begin(T);
     for (pse_handle *h : act(T)) {   // two lanes: the far-field chain next to the near field / Lanczos chain
         const bool on = h->side && !h->timing && T.lanes;
         if (on != h->side_on || h->wstream != (on ? h->side : h->stream)) {
@@ -2203,7 +2256,7 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
         ops.push_back(Xfer{h->loc.send[1] + LOCAL_HDR, body, R, h->loc.recv[0] + LOCAL_HDR, body, L});
         ops.push_back(Xfer{(const double *)h->loc.counters, 1, L, h->loc.recv[1], 1, R});
         ops.push_back(Xfer{(const double *)h->loc.counters, 1, R, h->loc.recv[0], 1, L});
-        return ops; }, false));
+        return ops; }, false, DIAG_FIRST));
     // (3) cell sort of what the rank keeps: own particles that stayed, arrivals, ghosts
     for (size_t r = 0; r < T.m.size(); ++r) {
         pse_handle *h = T.m[r];
@@ -2252,6 +2305,7 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
         pse_handle *h = T.m[r];
         if (T.solo >= 0 && h->slab_rank != T.solo) continue;
         if (h->side_on) {
+            if (h == act(T)[0]) diag_mark(T, 3, h->side);
             HIPCHK(hipEventRecord(h->ev_join, h->side));
             HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         }
@@ -2265,6 +2319,7 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
         HIPCHK(hipMemcpyAsync(h->loc.err_host, h->loc.err, sizeof(int), hipMemcpyDeviceToHost, h->stream));   // (read by the NEXT call: nothing waits)
         HIPCHK(hipGetLastError());
     }
+    diag_mark(T, 1, act(T)[0]->stream);
     return 0;
 }
 
@@ -2419,13 +2474,56 @@ extern "C" int pse_team_unique_id(void *id128_host) {
 }
 
 extern "C" int pse_team_destroy(pse_team *T);
+// One double round the ring through the team's own exchange path (RCCL group or the host program's transport): every rank sends its
+// number to the right neighbour and must receive the left neighbour's.  A transport that does not deliver -- a rank that never
+// joined, crossed peers -- is reported here, at creation, not as a hang or as wrong physics in the first step.
+static int team_ring_test(pse_team &T) {
+    if (T.G < 2 || !remote(T)) return 0;
+    pse_handle *h = T.m[0];
+    HIPCHK(hipSetDevice(h->device));
+    double *buf = nullptr;
+    HIPCHK(hipMalloc((void **)&buf, 2 * sizeof(double)));
+    const double mine = 1000.0 + h->slab_rank;
+    double got = -1.0;
+    int rc = 0;
+    hipError_t e = hipMemcpy(buf, &mine, sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const int L = (h->slab_rank + T.G - 1) % T.G, R = (h->slab_rank + 1) % T.G;
+        rc = team_exchange(T, {Xfer{buf, 1, R, buf + 1, 1, L}}, false);
+        if (!rc) e = hipStreamSynchronize(h->stream);
+        if (!rc && e == hipSuccess && T.comm) e = hipStreamSynchronize(T.comm);
+        if (!rc && e == hipSuccess) e = hipMemcpy(&got, buf + 1, sizeof(double), hipMemcpyDeviceToHost);
+        if (!rc && e == hipSuccess && got != 1000.0 + L)
+            rc = fail(PSE_ERR_COMM, "team ring test: rank %d expected %g from its left neighbour %d and received %g -- the transport does not "
+                      "connect the ranks as a ring of %d", h->slab_rank, 1000.0 + L, L, got, T.G);
+    }
+    (void)hipFree(buf);
+    if (e != hipSuccess && !rc) rc = fail(PSE_ERR_COMM, "team ring test failed: %s", hipGetErrorString(e));
+    return rc;
+}
 // RCCL communicator of a one-member-per-process team (in-process teams have nothing to connect)
 static int team_connect(pse_team *T, const void *id128_host) {
     if (T->m.size() != 1 || !id128_host) return 0;
     ncclUniqueId id;
     memcpy(&id, id128_host, sizeof id);
     HIPCHK(hipSetDevice(T->m[0]->device));
-    NCCLCHK(ncclCommInitRank(&T->nccl, T->G, id, T->m[0]->slab_rank));
+    {   // a rank that never joins leaves ncclCommInitRank waiting for ever: wait for it on a thread, with a deadline (PSE_TEAM_CONNECT_TIMEOUT, s)
+        const char *te_ = getenv("PSE_TEAM_CONNECT_TIMEOUT");
+        const int limit = te_ ? std::max(1, atoi(te_)) : 300;
+        auto res = std::make_shared<std::promise<ncclResult_t>>();
+        std::future<ncclResult_t> fut = res->get_future();
+        ncclComm_t *dst = &T->nccl;
+        const int G_ = T->G, r_ = T->m[0]->slab_rank, dev_ = T->m[0]->device;
+        std::thread([res, dst, G_, id, r_, dev_]() {
+            (void)hipSetDevice(dev_);
+            res->set_value(ncclCommInitRank(dst, G_, id, r_));
+        }).detach();
+        if (fut.wait_for(std::chrono::seconds(limit)) != std::future_status::ready)
+            return fail(PSE_ERR_COMM, "RCCL communicator of %d ranks did not form within %d s: a peer is missing (rank %d waited; "
+                        "PSE_TEAM_CONNECT_TIMEOUT sets the limit)", G_, limit, r_);
+        const ncclResult_t r0 = fut.get();
+        if (r0 != ncclSuccess) return fail(PSE_ERR_COMM, "ncclCommInitRank failed: %s", ncclGetErrorString(r0));
+    }
     // Two compute lanes + a communication stream of their own are OPT-IN for an RCCL team (PSE_TEAM_LANES=1): no multi-GPU node has
     // run that path yet.  Default: one stream carries the kernels and the RCCL calls, in program order -- nothing can interleave.
     {
@@ -2437,7 +2535,7 @@ static int team_connect(pse_team *T, const void *id128_host) {
         T->evs.resize(32);
         for (hipEvent_t &e : T->evs) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    return 0;
+    return team_ring_test(*T);
 }
 
 extern "C" int pse_team_create(pse_handle **members, int n_members, const void *id128_host, pse_team **out) {
@@ -2481,6 +2579,7 @@ extern "C" int pse_team_create_transport(pse_handle *member, const pse_transport
     T->cb = *transport;
     T->has_cb = true;
     if (const char *e = getenv("PSE_TEAM_LANES")) T->lanes = atoi(e) > 0;
+    if (int rc = team_ring_test(*T)) { std::string keep = error_text(); pse_team_destroy(T); error_text() = keep; return rc; }
     *out = T;
     return 0;
 }
@@ -2499,6 +2598,7 @@ extern "C" int pse_team_destroy(pse_team *T) {
     if (T->comm) { (void)hipStreamSynchronize(T->comm); }
     if (T->nccl) ncclCommDestroy(T->nccl);
     for (hipEvent_t e : T->evs) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : T->diag.ev) if (e) (void)hipEventDestroy(e);
     if (T->comm) (void)hipStreamDestroy(T->comm);
     if (T->stage) (void)hipHostFree(T->stage);
     delete T;
@@ -2579,5 +2679,38 @@ extern "C" int pse_team_local_status(pse_team *T, int *flags) {
     }
     if (any) return fail(PSE_ERR_INVALID, "owned-particle step failed on the device (flags %d: 1 own rows, 2 ghost rows, 4 message capacity exceeded, "
                          "8 a particle moved beyond the neighbour, 16 n_local above capacity)", any);
+    return 0;
+}
+
+extern "C" int pse_team_set_diag(pse_team *T, int enabled) {
+    if (!T) return fail(PSE_ERR_INVALID, "null team");
+    HIPCHK(hipSetDevice(T->m[0]->device));
+    if (enabled && T->diag.ev.empty()) {
+        T->diag.ev.resize(2 * PSE_DIAG_MAX + 4);
+        for (hipEvent_t &e : T->diag.ev) HIPCHK(hipEventCreate(&e));
+    }
+    T->diag.on = enabled != 0;
+    T->diag.n = 0;
+    return 0;
+}
+extern "C" int pse_team_get_diag(pse_team *T, pse_team_diag *out) {
+    if (!T || !out) return fail(PSE_ERR_INVALID, "null argument");
+    memset(out, 0, sizeof *out);
+    if (!T->diag.on) return fail(PSE_ERR_INVALID, "diagnosis is off (pse_team_set_diag)");
+    pse_handle *h = T->solo >= 0 ? T->solo_m[0] : T->m[0];
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->side) HIPCHK(hipStreamSynchronize(h->side));
+    out->n_exchanges = T->diag.n;
+    for (int q = 0; q < T->diag.n; ++q) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, T->diag.ev[2 * q], T->diag.ev[2 * q + 1]) != hipSuccess) ms = 0.0f;
+        out->kind[q] = T->diag.kind[q]; out->lane[q] = T->diag.lane[q]; out->device_us[q] = 1e3 * ms; out->host_us[q] = T->diag.host_us[q];
+        out->bytes[q] = T->diag.bytes[q];
+    }
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, T->diag.ev[2 * PSE_DIAG_MAX], T->diag.ev[2 * PSE_DIAG_MAX + 1]) == hipSuccess) out->main_lane_ms = ms;
+    if (T->diag.side_used && hipEventElapsedTime(&ms, T->diag.ev[2 * PSE_DIAG_MAX + 2], T->diag.ev[2 * PSE_DIAG_MAX + 3]) == hipSuccess) out->side_lane_ms = ms;
+    out->critical_path_ms = out->main_lane_ms;
     return 0;
 }

@@ -329,6 +329,26 @@ class Team:
                                                  int(timestep), float(shear_rate), 1 if integrate else 0, ctypes.byref(m)))
         return m.value
 
+    DIAG_KINDS = {0: "migrate_ghosts", 1: "lanczos", 2: "all_to_all", 3: "halo", 4: "all_gather", 5: "ghost_rows"}
+
+    def set_diag(self, on=True):
+        """Bracket every exchange of the team's calls with events (pse_team_set_diag)."""
+        _lib.check(self._lib.pse_team_set_diag(self._t, 1 if on else 0))
+
+    def diag(self):
+        """The exchanges of the last call (waits for it): dict with exchanges_per_step, exchange_us {kind: [device us, ...]},
+        exchange_host_us, exchange_bytes, lanes_ms, critical_path_ms."""
+        d = _lib.pse_team_diag()
+        _lib.check(self._lib.pse_team_get_diag(self._t, ctypes.byref(d)))
+        out = {"exchanges_per_step": d.n_exchanges, "exchange_us": {}, "exchange_host_us": {}, "exchange_bytes": {},
+               "lanes_ms": {"main": d.main_lane_ms, "side": d.side_lane_ms}, "critical_path_ms": d.critical_path_ms}
+        for q in range(d.n_exchanges):
+            k = self.DIAG_KINDS.get(d.kind[q], str(d.kind[q]))
+            out["exchange_us"].setdefault(k, []).append(round(d.device_us[q], 2))
+            out["exchange_host_us"].setdefault(k, []).append(round(d.host_us[q], 2))
+            out["exchange_bytes"].setdefault(k, []).append(int(d.bytes[q]))
+        return out
+
     def local_status(self):
         """Synchronises; raises if a member's step failed on the device (capacity exceeded, a particle moved too far)."""
         flags = (ctypes.c_int * len(self.engines))()

@@ -135,7 +135,15 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
-    assert "HOST-STAGED" in d["config"]["parallelism"]
+    assert "HOST-STAGED" in d["config"]["parallelism"] and "owned-particle" in d["config"]["parallelism"]
+    # the self-diagnosis of a multi-rank line: exchanges per step, device time of every exchange by kind,
+    # the spans of both lanes, the critical path
+    assert d["exchanges_per_step"] == sum(len(v) for v in d["exchange_us"].values()) >= 6
+    assert set(d["exchange_us"]) >= {"migrate_ghosts", "lanczos", "all_to_all", "halo"}
+    assert len(d["exchange_us"]["all_to_all"]) == 2 and len(d["exchange_us"]["halo"]) == 1 and len(d["exchange_us"]["migrate_ghosts"]) == 1
+    assert all(t > 0 for v in d["exchange_us"].values() for t in v)
+    assert d["critical_path_ms"] > 0 and d["lanes_ms"]["main"] > 0 and d["lanes_ms"]["side"] > 0
+    assert d["lanczos_status"] == 0 and d["particles_owned_sum"] == 100000 and d["device_flags"] == [0]
 
 
 def test_bench_as_ranks_of_torch_distributed_run():

@@ -50,8 +50,11 @@ def lib():
     """ctypes handle of the C oracle (built by `make -C oracle`)."""
     global _LIB
     if _LIB is None:
-        # PSE_ASAN_DIR: the -fsanitize=address,undefined build of this same source (python -m pse_amd.build --asan-test)
-        path = os.path.join(os.environ.get("PSE_ASAN_DIR") or _HERE, "libpse_oracle.so")
+        # PSE_ASAN_DIR: the -fsanitize=address,undefined build of this same source (tools/asan.py builds it)
+        d = os.environ.get("PSE_ASAN_DIR")
+        if d and not os.path.exists(os.path.join(d, ".pse_asan_build")):   # a stray variable: not a sanitizer build (pse_amd/_lib.py asan_dir)
+            d = None
+        path = os.path.join(d or _HERE, "libpse_oracle.so")
         if not os.path.exists(path):
             import subprocess
             subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)

@@ -7,8 +7,27 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PSE_ASAN_DIR (set by `python -m pse_amd.build --asan-test` only): the CPU sanitizer build, whose device entry points are stubs
-_ASAN_DIR = os.environ.get("PSE_ASAN_DIR")
+
+
+def asan_dir():
+    """The CPU sanitizer build (python -m pse_amd.build --asan; tools/asan.py runs the CPU tests on it), or None.  PSE_ASAN_DIR
+    alone is not enough: the directory must carry the marker that build writes, and the redirection is announced on stderr -- a
+    stray variable must not silently swap the product for a library whose device calls all fail."""
+    d = os.environ.get("PSE_ASAN_DIR")
+    if not d:
+        return None
+    if not os.path.exists(os.path.join(d, ".pse_asan_build")):
+        import sys
+        print(f"pse_amd: PSE_ASAN_DIR={d} ignored: no sanitizer build there (python -m pse_amd.build --asan writes one)", file=sys.stderr)
+        return None
+    if not getattr(asan_dir, "_said", False):
+        import sys
+        print(f"pse_amd: using the CPU SANITIZER build in {d} (PSE_ASAN_DIR): device entry points are stubs", file=sys.stderr)
+        asan_dir._said = True
+    return d
+
+
+_ASAN_DIR = asan_dir()
 LIB_PATH = os.path.join(_ASAN_DIR or _HERE, "libpse_amd.so")
 
 PSE_OK = 0

@@ -112,6 +112,7 @@ def build_all(force=None):
 
 # ---- CPU sanitizer build: never on the GPU, never the product --------------------------------------------
 ASAN_DIR = os.path.join(HERE, "..", "build", "asan")
+ASAN_MARKER = ".pse_asan_build"   # (also named in pse_amd/_lib.py, which must stay importable without this module's dependencies)
 SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
 
 
@@ -132,6 +133,8 @@ def build_asan():
     _run(["g++", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", *SAN, *inc, "-I" + pybind11.get_include(),
           "-I" + sysconfig.get_paths()["include"], *srcs, "-o", os.path.join(out, "_PSEv1" + ext), f"-L{out}", "-lpse_amd",
           "-Wl,-rpath,$ORIGIN"])
+    with open(os.path.join(out, ASAN_MARKER), "w") as f:   # what makes the package accept the directory (pse_amd/_lib.py asan_dir)
+        f.write("CPU sanitizer build of the host side of pse_amd: device entry points are stubs\n")
     print("pse_amd.build: sanitizer build in " + out, flush=True)
     return out
 

@@ -34,6 +34,7 @@ int pse_create(const pse_params *p, pse_handle **out) {
     h->par = *p;
     std::string e = select_params(Box{p->Lx, p->Ly, p->Lz, p->xy}, p->xi, p->error, p->max_strain, p->Nx, p->Ny, p->Nz, p->P, p->rcut, h->d);
     if (!e.empty()) { delete h; return fail(PSE_ERR_INVALID, "%s", e.c_str()); }
+    if (int rc = gaussian_fits(h->d, h->d.hx, h->d.hy, h->d.hz)) { delete h; return rc; }
     build_realspace_table(h->d.xi, h->d.rcut, h->coef, h->n_intervals);
     fill_info(h->d, &h->info);
     *out = h;
@@ -44,6 +45,7 @@ int pse_set_box(pse_handle *h, double Lx, double Ly, double Lz, double xy) {
     if (!h) return fail(PSE_ERR_INVALID, "null handle");
     if (!(Lx > 0 && Ly > 0 && Lz > 0)) return fail(PSE_ERR_INVALID, "box lengths must be positive");
     if (!(std::fabs(xy) <= 0.5 * (1.0 + 1e-9))) return fail(PSE_ERR_INVALID, "tilt xy = %g outside [-0.5, 0.5]", xy);
+    if (int rc = gaussian_fits(h->d, Lx / h->d.Nx, Ly / h->d.Ny, Lz / h->d.Nz)) return rc;
     h->par.Lx = Lx; h->par.Ly = Ly; h->par.Lz = Lz; h->par.xy = xy;
     h->info.hx = Lx / h->d.Nx; h->info.hy = Ly / h->d.Ny; h->info.hz = Lz / h->d.Nz;
     return 0;

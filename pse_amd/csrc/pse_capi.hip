@@ -300,19 +300,6 @@ static int collect_times(pse_handle *h, unsigned mask) {
     return 0;
 }
 
-// The spreading Gaussian exp(-c r^2), c = 2 xi^2 / eta, has its width from the SMALLEST grid spacing (the reference's rule makes the
-// three spacings equal up to the rounding of the grid sizes, PSEv1/Stokes.cc:147-214); spread and gather build its P values per axis
-// by a product recurrence whose factors reach exp(c h^2 P) and whose values fall to exp(-c h^2 P^2 / 4).  A grid or box override whose
-// coarsest spacing puts those outside the double range would turn into NaN velocities: refused here.
-static int gaussian_fits(const Derived &d, double hx, double hy, double hz) {
-    const double c = 2.0 * d.xi * d.xi / d.eta, hmax = std::max(hx, std::max(hy, hz));
-    const double worst = c * hmax * hmax * std::max((double)d.P, 0.25 * d.P * d.P);
-    if (!(worst < 700.0))
-        return fail(PSE_ERR_INVALID, "grid spacings (%g, %g, %g) too unequal for the spreading Gaussian of P = %d points, eta = %g: "
-                    "exp(+-%.0f) over its support on the coarsest axis", hx, hy, hz, d.P, d.eta, worst);
-    return 0;
-}
-
 extern "C" int pse_destroy(pse_handle *h) {
     if (!h) return 0;
     (void)hipSetDevice(h->device);
@@ -1230,7 +1217,7 @@ static CellRanges slab_need(const pse_handle *h) {
 // records, the per-step (f, h) pair list.
 struct PrepExtra { bool psi; unsigned timestep; };   // psi: the pass also draws the particle noise of this step into psi_s
 static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const unsigned *group, int N, bool defer_bounds = false,
-                   bool need_cells = false, PrepExtra px = PrepExtra{false, 0}) {
+                   bool need_cells = false, PrepExtra px = PrepExtra{false, 0}, bool with_real = true) {
     TRY(ts(h, PH_SORT));
     const FarBinArgs far = far_bin_args(h->G, h->sw);
     double4 *psi_out = px.psi ? h->psi_s : nullptr;
@@ -1241,7 +1228,9 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
     h->pv_is_f = vec != nullptr && h->pv != nullptr;
     const bool same_box = h->vl_box.Lx == h->box.Lx && h->vl_box.Ly == h->box.Ly && h->vl_box.Lz == h->box.Lz && h->vl_box.xy == h->box.xy;
     h->gated = false;
-    if (h->async_mode && !px.psi && h->skin > 0.0 && h->vl_valid && !need_cells && h->vl_N == N && h->vl_group == group && same_box &&
+    // (only when the call has a near-field part: the rebuild chain's list and build positions are written by real(); a far-field-only
+    // call that took it would leave a list in the OLD order marked valid -- such a call rebuilds, ungated)
+    if (h->async_mode && with_real && !px.psi && h->skin > 0.0 && h->vl_valid && !need_cells && h->vl_N == N && h->vl_group == group && same_box &&
         h->sorted_N == N && h->nc_wide && h->n_slabs == 1) {
         // Asynchronous mode, a deterministic evaluation, a kept list exists: the decision "reuse or rebuild" is taken on the device and
         // BOTH chains are queued -- the kernels of the chain not taken read the gate word and leave at once.  No read-back, nothing
@@ -1923,7 +1912,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
     diag_begin(T);
     for (size_t r = 0; r < T.m.size(); ++r)
         if (T.solo < 0 || T.m[r]->slab_rank == T.solo)   // psi rides with the gather into cell order: the near-field pass that
-            TRY(prepare(T.m[r], a[r].pos, a[r].force, group, N, true, false, PrepExtra{kT > 0.0, timestep}));   // builds the pair list applies M_real to F and psi together
+            TRY(prepare(T.m[r], a[r].pos, a[r].force, group, N, true, false, PrepExtra{kT > 0.0, timestep}, (parts & 1) != 0));   // builds the pair list applies M_real to F and psi together
     *mask |= 1u << PH_SORT;
     const bool noise = kT > 0.0;
     const bool sstep = T.G > 1 && noise && (parts & 1) && team_sstep(T.m[0]);   // two Lanczos iterations per exchange

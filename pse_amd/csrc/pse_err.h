@@ -13,5 +13,9 @@ namespace pse {
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));   // records the message, returns code
 std::string &error_text();                                                          // thread-local
 void fill_info(const Derived &d, pse_info *o);
+// 0, or PSE_ERR_INVALID with a message: the spreading Gaussian of these parameters leaves the double range over its support on the
+// coarsest of the three grid spacings (an override the reference's rule cannot produce) -- shared by pse_create, pse_set_box,
+// pse_host_select_params and the sanitizer build's stand-in, so that all agree on which configurations are valid
+int gaussian_fits(const Derived &d, double hx, double hy, double hz);
 
 }  // namespace pse

@@ -34,6 +34,19 @@ void fill_info(const Derived &d, pse_info *o) {
     o->self_mobility = d.self; o->hx = d.hx; o->hy = d.hy; o->hz = d.hz;
 }
 
+// The spreading Gaussian exp(-c r^2), c = 2 xi^2 / eta, has its width from the SMALLEST grid spacing (the reference's rule makes the
+// three spacings equal up to the rounding of the grid sizes, PSEv1/Stokes.cc:147-214); spread and gather build its P values per axis
+// by a product recurrence whose factors reach exp(c h^2 P) and whose values fall to exp(-c h^2 P^2 / 4).  A grid or box override whose
+// coarsest spacing puts those outside the double range would turn into NaN velocities: refused.
+int gaussian_fits(const Derived &d, double hx, double hy, double hz) {
+    const double c = 2.0 * d.xi * d.xi / d.eta, hmax = std::max(hx, std::max(hy, hz));
+    const double worst = c * hmax * hmax * std::max((double)d.P, 0.25 * d.P * d.P);
+    if (!(worst < 700.0))
+        return fail(PSE_ERR_INVALID, "grid spacings (%g, %g, %g) too unequal for the spreading Gaussian of P = %d points, eta = %g: "
+                    "exp(+-%.0f) over its support on the coarsest axis", hx, hy, hz, d.P, d.eta, worst);
+    return 0;
+}
+
 }  // namespace pse
 
 using namespace pse;
@@ -46,6 +59,7 @@ extern "C" int pse_host_select_params(const pse_params *p, pse_info *info) {
     std::string e = select_params(Box{p->Lx, p->Ly, p->Lz, p->xy}, p->xi, p->error, p->max_strain, p->Nx, p->Ny, p->Nz,
                                   p->P, p->rcut, d);
     if (!e.empty()) return fail(PSE_ERR_INVALID, "%s", e.c_str());
+    if (int rc = gaussian_fits(d, d.hx, d.hy, d.hz)) return rc;
     fill_info(d, info);
     return 0;
 }

@@ -4,6 +4,7 @@
 #include "pse_farbin.h"
 
 #include <hipcub/hipcub.hpp>
+#include <atomic>
 
 namespace pse {
 
@@ -11,6 +12,21 @@ constexpr int TPB = 256;
 constexpr double TWO_PI = 6.283185307179586476925286766559;
 
 static inline int nblocks(long n, int tpb) { return (int)((n + tpb - 1) / tpb); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: every launcher keeps, per device ordinal, the largest size it has
+// raised the attribute to (a process-wide flag would leave a second device, or a second thread's first launch, without it).  Racing
+// threads at worst set the same attribute twice.
+struct LdsAttr {
+    std::atomic<size_t> have[32];
+    bool need(size_t lds) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 32) return true;
+        if (have[dev].load(std::memory_order_relaxed) >= lds) return false;
+        have[dev].store(lds, std::memory_order_relaxed);
+        return true;
+    }
+};
 
 // ------------------------------------------------------------------------------------------------ reductions
 __device__ __forceinline__ double wave_sum(double v) {
@@ -1385,10 +1401,9 @@ k_xfft_scale256(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__res
 template <int KB, int NTH, int WPS, int N = 256>
 static void launch_xfft256(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s) {
     const size_t lds = (size_t)(3 * KB * (N == 256 ? CS256 : CS512)) * sizeof(double2);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static LdsAttr attr;
+    if (attr.need(lds)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xfft_scale256<N, KB, NTH, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const int nkb = (G.Nzh + KB - 1) / KB;
     const int rows = a.transposed ? a.nyl : G.Ny;
@@ -1815,10 +1830,9 @@ k_xfft_scale_cols(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__r
 template <int N, int R0, int R1, int KB, int WPS, bool PARK, int P0, int P1, int CS, int CPW = 1>
 static void launch_xfft_cols(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s) {
     const size_t lds = (size_t)(KB * CS + N / R0) * sizeof(double2);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static LdsAttr attr;
+    if (attr.need(lds)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xfft_scale_cols<N, R0, R1, KB, WPS, PARK, P0, P1, CS, CPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const int nkb = (G.Nzh + KB - 1) / KB;
     const int rows = a.transposed ? a.nyl : G.Ny;
@@ -1905,8 +1919,8 @@ static bool plan_x(int n, FftPlanX &pl) {
 template <int KB, int NTH, class PLAN = RtPlan>
 static void launch_xfft_mixed(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, const FftPlanX &pl, hipStream_t s) {
     const size_t lds = (size_t)(2 * 3 * KB * (pl.n + 1) + pl.n) * sizeof(double2);
-    static size_t attr_lds = 48 * 1024;
-    if (lds > attr_lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xfft_scale_mixed<KB, NTH, PLAN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_lds = lds; }
+    static LdsAttr attr;
+    if (lds > 48 * 1024 && attr.need(lds)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xfft_scale_mixed<KB, NTH, PLAN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int nkb = (G.Nzh + KB - 1) / KB;
     const int rows = a.transposed ? a.nyl : G.Ny;
     hipLaunchKernelGGL((k_xfft_scale_mixed<KB, NTH, PLAN>), dim3(rows * nkb), dim3(NTH), lds, s, X, Y, Z, G, box, a, tw, pl);
@@ -1980,11 +1994,10 @@ template <int KB, int NTH, class PLAN = RtPlan>
 static void launch_fft_cols(double2 *data, const FftPlanX &pl, const double2 *tw, int nplanes, int Nzh, int Nzp, size_t plane_stride,
                             bool inverse, hipStream_t s) {
     const size_t lds = (size_t)(2 * KB * (pl.n + 1) + pl.n) * sizeof(double2);
-    static size_t attr_lds[2] = {48 * 1024, 48 * 1024};
-    if (lds > attr_lds[inverse]) {
+    static LdsAttr attr2[2];
+    if (lds > 48 * 1024 && attr2[inverse].need(lds)) {
         if (inverse) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<KB, NTH, true, 0, PLAN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         else (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<KB, NTH, false, 0, PLAN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_lds[inverse] = lds;
     }
     const int nkb = (Nzh + KB - 1) / KB;
     const dim3 g(nplanes * nkb), b(NTH);
@@ -1999,11 +2012,10 @@ void launch_yfft_slab(double2 *cgrid, double2 *blocks, DGrid G, int nyl, bool in
     plan_x(G.Ny, pl);
     constexpr int KB = 4, NTH = 256;
     const size_t lds = (size_t)(2 * KB * (pl.n + 1) + pl.n) * sizeof(double2);
-    static size_t attr_lds[2] = {48 * 1024, 48 * 1024};
-    if (lds > attr_lds[inverse]) {
+    static LdsAttr attr2[2];
+    if (lds > 48 * 1024 && attr2[inverse].need(lds)) {
         if (inverse) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<KB, NTH, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         else (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<KB, NTH, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_lds[inverse] = lds;
     }
     const int nkb = (G.Nzh + KB - 1) / KB, nplanes = 3 * G.nxl;
     const size_t ps = (size_t)G.Ny * G.Nzp;
@@ -2096,11 +2108,10 @@ k_yfft_regs(double2 *__restrict__ data, const double2 *__restrict__ twiddle, int
 template <int N, int R0, int R1, int KB, int P0, int P1, int CS>
 static void launch_yfft_regs_slab(double2 *cgrid, double2 *blocks, DGrid G, int nyl, bool inverse, const double2 *tw, hipStream_t s) {
     const size_t lds = (size_t)(KB * CS + N / R0) * sizeof(double2);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static LdsAttr attr;
+    if (attr.need(lds)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_yfft_regs<N, R0, R1, KB, true, P0, P1, CS, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_yfft_regs<N, R0, R1, KB, false, P0, P1, CS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const int nkb = (G.Nzh + KB - 1) / KB, nplanes = 3 * G.nxl;
     const size_t ps = (size_t)G.Ny * G.Nzp;
@@ -2111,11 +2122,10 @@ static void launch_yfft_regs_slab(double2 *cgrid, double2 *blocks, DGrid G, int 
 template <int N, int R0, int R1, int KB, int P0, int P1, int CS>
 static void launch_yfft_regs(double2 *data, const double2 *tw, int nplanes, int Nzh, int Nzp, size_t plane_stride, bool inverse, hipStream_t s) {
     const size_t lds = (size_t)(KB * CS + N / R0) * sizeof(double2);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static LdsAttr attr;
+    if (attr.need(lds)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_yfft_regs<N, R0, R1, KB, true, P0, P1, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_yfft_regs<N, R0, R1, KB, false, P0, P1, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const int nkb = (Nzh + KB - 1) / KB;
     const dim3 g(nplanes * nkb), b(64 * KB);
@@ -2299,10 +2309,9 @@ template <int LOGN, int KB, int NTH>
 static void launch_xfft_t(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s) {
     constexpr int N = 1 << LOGN;
     const size_t lds = (size_t)(3 * KB * (N + 1) + N) * sizeof(double2);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static LdsAttr attr;
+    if (attr.need(lds)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xfft_scale<LOGN, KB, NTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const int nkb = (G.Nzh + KB - 1) / KB;
     const int rows = a.transposed ? a.nyl : G.Ny;
@@ -2774,13 +2783,8 @@ static size_t lz_decide_lds(int m_lo, int m_hi) {
 bool lz_decide_supported(int m_hi) { return m_hi >= 1 && m_hi <= 100 && lz_decide_lds(std::max(1, m_hi - 1), m_hi) <= 150 * 1024; }
 void launch_lz_decide(const LzDecide &d, double *scal, LzState *st, double *sch, double seq, hipStream_t s) {
     const size_t lds = lz_decide_lds(d.m_lo, d.m_hi);
-    static size_t lds_set[16] = {0};   // per device: the largest dynamic LDS size the attribute has been raised to
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (lds > 48 * 1024 && dev >= 0 && dev < 16 && lds_set[dev] < lds) {
-        (void)hipFuncSetAttribute((const void *)k_lz_decide, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        lds_set[dev] = 150 * 1024;
-    }
+    static LdsAttr attr;
+    if (lds > 48 * 1024 && attr.need(150 * 1024)) (void)hipFuncSetAttribute((const void *)k_lz_decide, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipLaunchKernelGGL(k_lz_decide, dim3(1), dim3(128), lds, s, d, scal, st, sch, seq);
 }
 

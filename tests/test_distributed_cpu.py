@@ -222,3 +222,45 @@ def test_two_step_block_reproduces_lanczos():
         p, q, u, alpha_prev, beta, uu = v1, v2, z1, a1, b2, zz
     assert np.allclose(got_a, al, rtol=1e-9) and np.allclose(got_b[1:], be[1:], rtol=1e-9)
     assert abs(abs(q @ V[8]) - 1.0) < 1e-9                            # v_8 up to sign
+
+
+def test_owned_particle_layout_helpers():
+    """Host-side mirror of the owned-particle decomposition (pse_amd/sharded.py <-> LocalGeom in csrc/pse_local.h): cell layers along x,
+    the owner of a particle, the rows a rank needs.  Pure NumPy: runs without a GPU."""
+    import numpy as np
+    from pse_amd.sharded import host_layers, local_capacity, owner_of, x_layer
+    L, world = 347.29, 8
+    box = (L, L, L, 0.2)
+    layers = host_layers(box, world, xi=0.441, error=1e-3, grid=(256, 256, 256))
+    assert layers % world == 0 and layers // world >= 3            # what pse_create asks of an owned-particle rank
+    rng = np.random.default_rng(0)
+    pos = (rng.uniform(size=(20000, 3)) - 0.5) * L
+    lay = x_layer(pos, box, layers)
+    assert lay.min() >= 0 and lay.max() == layers - 1
+    # the layer follows the FRACTIONAL x coordinate: a shift along the tilted lattice vector a2 = (xy Ly, Ly, 0) changes nothing
+    shifted = pos + np.array([box[3] * L, L, 0.0])
+    assert np.array_equal(x_layer(shifted, box, layers), lay)
+    own = owner_of(pos, box, layers, world)
+    assert np.array_equal(own, lay // (layers // world)) and set(own) == set(range(world))
+    # uniform density: every rank within a few per cent of N / world, and the capacity rule leaves room for the ghosts
+    counts = np.bincount(own, minlength=world)
+    assert counts.max() < 1.1 * len(pos) / world
+    per = layers // world
+    cap = local_capacity(len(pos), world, per)
+    assert cap > counts.max() * (per + 4) / per
+    # two ranks need four layers each (both ghost zones come from the same neighbour)
+    assert host_layers((60.0, 60.0, 60.0, 0.0), 2, xi=0.5, error=1e-3) % 2 == 0
+
+
+def test_two_step_exchange_message_sizes():
+    """Sizes of the fixed messages of an owned-particle step, from the capacities alone (no count reaches a host): the first
+    exchange carries 12 doubles per record, a Lanczos block two vectors of c_g rows per neighbour."""
+    from pse_amd.sharded import local_capacity
+    n, world, per, depth = 1_000_000, 8, 6, 2
+    cap = local_capacity(n, world, per)
+    c_g = int(cap * depth / (per + 2 * depth)) // 256 * 256
+    c_own = (cap - 2 * c_g) // 256 * 256
+    assert c_g >= 256 and c_own >= c_g and c_own + 2 * c_g <= cap
+    first = (4 + 12 * c_g) * 8
+    block = 2 * c_g * 32
+    assert 4e6 < first < 7e6 and 2.5e6 < block < 4.5e6              # a few MB per neighbour: link time, not latency, bounds them

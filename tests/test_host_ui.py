@@ -174,3 +174,15 @@ def test_hoomd_shim_covers_the_reference_example():
         assert type(calls["pse"]["function_form"]).__name__ == "sine"
     finally:
         sys.path.pop(0)
+
+
+def test_host_parameter_rule_refuses_what_the_device_refuses():
+    """pse_host_select_params applies the same validity check as pse_create (gaussian_fits, csrc/pse_host_api.cpp): an override
+    whose coarsest grid spacing takes the spreading Gaussian out of the double range over its support is refused on the host
+    too -- and under the sanitizer build, whose pse_create stand-in calls the same function."""
+    import pytest
+    from pse_amd import PSEError, host_select_params
+    ok = host_select_params((24.0, 24.0, 24.0, 0.0), xi=0.5, error=1e-3, grid=(64, 64, 64), P=4)
+    assert ok["P"] == 4
+    with pytest.raises(PSEError, match="too unequal"):
+        host_select_params((24.0, 24.0, 24.0, 0.0), xi=0.5, error=1e-3, grid=(256, 16, 16), P=4)

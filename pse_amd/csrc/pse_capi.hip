@@ -82,13 +82,13 @@ struct pse_handle {
         int own_y_pow2 = 1;       // PSE_OWN_Y_POW2=0: rocFFT's 2-D transforms at Ny = 256 instead of its 1-D z pass + k_yfft_regs (A/B)
         int own_y = 1;            // PSE_OWN_Y=0: rocFFT's 2-D (y, z) transforms also where the own y pass applies
         int own_z = 1;            // PSE_OWN_Z=0: rocFFT's 1-D z transforms also where k_zfft_rows applies (A/B)
+        int yslab_regs = 1;       // PSE_YSLAB_REGS=0: a slab rank's y pass at Ny = 256, 512 by k_fft_cols instead of k_yfft_regs (A/B)
         int yfft_kb = 4;          // PSE_YFFT_KB: kz columns per workgroup of the own y pass (2, 4, 8)
         int wave_mode = 0;        // PSE_WAVE_MODE: 0 automatic, 1 slab, 2 replicated
         int spread_tz = 0, spread_nw = 0;   // PSE_SPREAD_TZ, PSE_SPREAD_NW
         int gather_bz = 0;        // PSE_GATHER_BZ=1|2: bins along z per gather workgroup (0: by the particles per bin)
         int xmix_runtime = 0;     // PSE_XMIX=1: runtime radix plan of the mixed x pass also where a compile-time plan exists
         int xfft_small_wide = 0;  // PSE_XFFT_SMALL_KB=8: the eight-column x pass also on small grids
-        int xcols = 1;            // PSE_XCOLS=0: Nx = 512, 360, 256 by the x pass kernels that keep all three components in LDS (A/B)
         bool verbose = false;     // PSE_VERBOSE
         bool team_sstep = true;      // PSE_TEAM_SSTEP=0: teams run one Lanczos iteration per exchange (default: two, see lanczos_team)
         int team_sched[3] = {1, 2, 3};   // PSE_TEAM_SCHED=a,b,c: far-field exchange k of a team step is issued before Lanczos exchange sched[k]
@@ -476,10 +476,10 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         if (const char *v = getenv("PSE_SKIN")) t.skin = atof(v);
         t.overlap = ienv("PSE_OVERLAP", 0);
         t.no_xfuse = getenv("PSE_NO_XFUSE") != nullptr;
-        t.own_y = ienv("PSE_OWN_Y", 1); t.own_y_pow2 = ienv("PSE_OWN_Y_POW2", 1); t.yfft_kb = ienv("PSE_YFFT_KB", 4); t.own_z = ienv("PSE_OWN_Z", 1);
+        t.own_y = ienv("PSE_OWN_Y", 1); t.own_y_pow2 = ienv("PSE_OWN_Y_POW2", 1); t.yfft_kb = ienv("PSE_YFFT_KB", 4); t.own_z = ienv("PSE_OWN_Z", 1); t.yslab_regs = ienv("PSE_YSLAB_REGS", 1);
         if (const char *v = getenv("PSE_WAVE_MODE")) t.wave_mode = !strcmp(v, "slab") ? 1 : (!strcmp(v, "replicated") ? 2 : 0);
         t.spread_tz = ienv("PSE_SPREAD_TZ", 0); t.spread_nw = ienv("PSE_SPREAD_NW", 0);
-        t.gather_bz = ienv("PSE_GATHER_BZ", 0); t.xmix_runtime = ienv("PSE_XMIX", 0) == 1; t.xfft_small_wide = ienv("PSE_XFFT_SMALL_KB", 2) == 8; t.xcols = ienv("PSE_XCOLS", 1);
+        t.gather_bz = ienv("PSE_GATHER_BZ", 0); t.xmix_runtime = ienv("PSE_XMIX", 0) == 1; t.xfft_small_wide = ienv("PSE_XFFT_SMALL_KB", 2) == 8;
         t.verbose = ienv("PSE_VERBOSE", 0) > 0;
         t.team_sstep = ienv("PSE_TEAM_SSTEP", 1) > 0;
         t.lz_extra = std::max(0, std::min(32, ienv("PSE_LANCZOS_EXTRA", 2)));
@@ -1336,7 +1336,7 @@ static ScaleArgs scale_args(pse_handle *h, bool noise, double kT, double dt, uns
     a.noise_fac = noise ? std::sqrt(2.0 * kT / dt / (G.hx * G.hy * G.hz)) : 0.0;   // PSEv1/Brownian.cu:197
     a.seed = h->par.seed; a.timestep = timestep; a.ts_off = h->ts_off;
     a.transposed = h->grid_slabs > 1 ? 1 : 0; a.y0 = h->y0; a.nyl = h->grid_slabs > 1 ? h->nyl : G.Ny;
-    a.runtime_plan = h->tun.xmix_runtime; a.wide_small = h->tun.xfft_small_wide; a.xcols = h->tun.xcols;
+    a.runtime_plan = h->tun.xmix_runtime; a.wide_small = h->tun.xfft_small_wide;
     return a;
 }
 
@@ -1381,7 +1381,7 @@ static int wave_compute(pse_team &T, const WaveArgs &a, int part, int half = 0) 
                     void *in[1] = {h->rgrid + c * nr + (size_t)G.hl * G.Ny * G.Nz}, *out[1] = {h->cgrid + c * ncx};
                     FFTCHK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
                 }
-                if (h->own_y_slab) launch_yfft_slab(h->cgrid, h->sendbuf, G, h->nyl, false, h->twiddle_y, h->wstream);
+                if (h->own_y_slab) launch_yfft_slab(h->cgrid, h->sendbuf, G, h->nyl, false, h->twiddle_y, h->wstream, h->tun.yslab_regs > 0);
                 else launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzp, h->nyl, 0, h->wstream);
             }
             TRY(tew(h, PH_FFTF));
@@ -1411,7 +1411,7 @@ static int wave_compute(pse_team &T, const WaveArgs &a, int part, int half = 0) 
                     FFTCHK(rocfft_execute(h->plan_inv, in, out, h->info_inv));
                 }
             } else {
-                if (h->own_y_slab) launch_yfft_slab(h->cgrid, h->sendbuf, G, h->nyl, true, h->twiddle_y, h->wstream);
+                if (h->own_y_slab) launch_yfft_slab(h->cgrid, h->sendbuf, G, h->nyl, true, h->twiddle_y, h->wstream, h->tun.yslab_regs > 0);
                 else launch_slab_pack(h->cgrid, h->sendbuf, G.nxl, G.Ny, G.Nzp, h->nyl, 1, h->wstream);
                 if (h->own_z) launch_zfft(zr, zs, G.nxl * G.Ny, G.Nz, G.Nzp, true, h->twiddle_z, h->wstream);
                 else for (int c = 0; c < 3; ++c) {

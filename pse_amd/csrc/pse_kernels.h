@@ -233,7 +233,6 @@ struct ScaleArgs {
     int y0, nyl;             // slab of y rows in transposed layout
     int runtime_plan;        // PSE_XMIX=1: the runtime radix plan also where a compile-time one exists (A/B)
     int wide_small;          // PSE_XFFT_SMALL_KB=8: eight kz columns per workgroup also on small grids (A/B)
-    int xcols;               // PSE_XCOLS=0: Nx = 512, 360, 256 by the kernels that keep the three components of a block in LDS instead of k_xfft_scale_cols (A/B)
 };
 void launch_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, hipStream_t s);
 // debug: kx, ky, kz, w sinc^2, sqrt(w) sinc of n nodes (i, j, k)
@@ -247,7 +246,8 @@ bool yfft_regs_supported(int Ny, int Nz, bool own_z = false);   // the register 
 // a slab rank's y transforms with the reordering of the all-to-all blocks folded in: forward reads the planes [3][nxl][Ny][Nzp] and writes
 // [3][G][nxl][nyl][Nzp]; inverse the other way round (any Ny = 2^a 3^b 5^c in 16..512: yfft_possible)
 bool yfft_possible(int Ny);
-void launch_yfft_slab(double2 *cgrid, double2 *blocks, DGrid G, int nyl, bool inverse, const double2 *tw, hipStream_t s);
+void launch_yfft_slab(double2 *cgrid, double2 *blocks, DGrid G, int nyl, bool inverse, const double2 *tw, hipStream_t s,
+                      bool regs = true);   // regs: Ny = 256, 512 by the register pass (k_yfft_regs with the block map) instead of k_fft_cols
 void launch_yfft(double2 *spectra, DGrid G, bool inverse, const double2 *tw, hipStream_t s, int kb = 4);
 // own z pass (k_zfft_rows): `rows` real rows of Nz doubles per component <-> spectrum rows of Nzp complex numbers; tw[m] = exp(-2 pi i m / Nz)
 bool zfft_supported(int Nz);

@@ -1192,223 +1192,6 @@ k_xfft_scale(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restri
     }
 }
 
-// ---- N = 256: two radix-16 passes in registers ------------------------------------------------------------------------
-// 256 = 16 x 16: a lane holds the 16 points of one butterfly in registers (a 16-point DFT as 4 x 4 with constant twiddles), so a
-// transform crosses LDS twice instead of four times (radix 4) and the kernel runs 6 barriers instead of 17.  Columns are
-// padded by one element per 16 (index i -> i + i/16): both the stride-16 gathers and the contiguous 16-element scatters of
-// the two passes are then free of bank conflicts.  The pass twiddles W_256^{j r} of a lane (its j is fixed) live in registers.
-__device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
-constexpr int CS256 = 256 + 18;   // + 2: the KB columns a staging store touches together start 8 banks apart
-
-// In place; on return X[r] sits in x[DFT16_AT(r)]
-#define DFT16_AT(r) ((((r) >> 2)) + 4 * ((r) & 3))
-template <bool INVERSE>
-__device__ __forceinline__ void dft16(double2 (&x)[16]) {
-    // X[4 k0 + k1] = sum_n0 W16^{n0 (4 k0 + k1)} sum_n1 x[n0 + 4 n1] W4^{n1 k1}
-    constexpr double C1 = 0.92387953251128673848, S1 = 0.38268343236508978178, R2 = 0.70710678118654752440;
-    const double sg = INVERSE ? 1.0 : -1.0;                          // forward: exp(-i ...)
-    auto dft4 = [&](double2 &a, double2 &b, double2 &c, double2 &d) __attribute__((always_inline)) {
-        const double2 s0 = make_double2(a.x + c.x, a.y + c.y), s1 = make_double2(a.x - c.x, a.y - c.y);
-        const double2 s2 = make_double2(b.x + d.x, b.y + d.y), s3 = make_double2(b.x - d.x, b.y - d.y);
-        const double2 j3 = make_double2(-sg * s3.y, sg * s3.x);      // (+-i) (b - d): forward -i
-        a = make_double2(s0.x + s2.x, s0.y + s2.y);
-        b = make_double2(s1.x + j3.x, s1.y + j3.y);
-        c = make_double2(s0.x - s2.x, s0.y - s2.y);
-        d = make_double2(s1.x - j3.x, s1.y - j3.y);
-    };
-    // over n1 for every n0: t[n0][k1] lands in x[n0 + 4 k1]
-#pragma unroll
-    for (int n0 = 0; n0 < 4; ++n0) dft4(x[n0], x[n0 + 4], x[n0 + 8], x[n0 + 12]);
-    // twiddles W16^{n0 k1} = exp(sg i 2 pi n0 k1 / 16)
-    const double cw[10] = {1.0, C1, R2, S1, 0.0, -S1, -R2, -C1, -1.0, -C1};
-    const double sw[10] = {0.0, S1, R2, C1, 1.0, C1, R2, S1, 0.0, -S1};
-#pragma unroll
-    for (int n0 = 1; n0 < 4; ++n0)
-#pragma unroll
-        for (int k1 = 1; k1 < 4; ++k1) {
-            const int m = n0 * k1;                                   // <= 9
-            const double c = cw[m], sn = sg * sw[m];
-            const double2 v = x[n0 + 4 * k1];
-            x[n0 + 4 * k1] = make_double2(v.x * c - v.y * sn, v.x * sn + v.y * c);
-        }
-    // over n0 for every k1: X[4 k0 + k1] lands in x[k0 + 4 k1]
-#pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1) dft4(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);
-}
-
-// NCOL columns of 256 points at d + col * CS256 (padded index); lane = one butterfly (col, j).  The pass twiddle W_256^{j r} of
-// point r = 4 a + b is twa[a] twb[b] with twa[a] = W_256^{4 j a}, twb[b] = W_256^{j b} (forward): 8 registers pairs instead of 16
-template <int NCOL, int NTH, bool INVERSE>
-__device__ __forceinline__ void lds_fft256(double2 *__restrict__ d, const double2 *__restrict__ twiddle) {
-    const int tid = threadIdx.x;
-    double2 twa[4], twb[4];                                          // fetched per transform (a 4 KB table, cache-resident): not kept
-#pragma unroll                                                       // alive across the k-space scaling, which needs the registers
-    for (int r = 0; r < 4; ++r) { twa[r] = twiddle[((tid & 15) * 4 * r) & 255]; twb[r] = twiddle[((tid & 15) * r) & 255]; }
-    constexpr int NB = NCOL * 16;
-    static_assert(NB <= NTH, "one butterfly per lane");
-    const bool act = tid < NB;
-    const int col = tid >> 4, j = tid & 15;
-    double2 *c = d + col * CS256;
-    double2 x[16];
-    // pass 1 (ns = 1): points j + 16 r, no twiddle; results to 16 j + r
-    if (act) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = c[pad16(j + 16 * r)];
-        dft16<INVERSE>(x);
-    }
-    __syncthreads();
-    if (act) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c[pad16(16 * j + r)] = x[DFT16_AT(r)];
-    }
-    __syncthreads();
-    // pass 2 (ns = 16): points j + 16 r times W_256^{j r}; results to j + 16 r (the lane's own points: no barrier in between)
-    if (act) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = c[pad16(j + 16 * r)];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) {                                // in place: no second set of 16 registers
-            const int ra = r >> 2, rb = r & 3;
-            double2 w = twb[rb];
-            if (ra && rb) w = make_double2(w.x * twa[ra].x - w.y * twa[ra].y, w.x * twa[ra].y + w.y * twa[ra].x);
-            else if (ra) w = twa[ra];
-            if (INVERSE) w.y = -w.y;
-            const double2 v = x[r];
-            x[r] = make_double2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
-        }
-        dft16<INVERSE>(x);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c[pad16(j + 16 * r)] = x[DFT16_AT(r)];
-    }
-    __syncthreads();
-}
-
-// 512 = 16 x 16 x 2: the same two radix-16 passes (32 butterflies per column, twiddle W_256^{(j mod 16) r} in the second, whose
-// results land at (j & 16) 16 + (j & 15) + 16 r: not the points the lane read, hence the extra barrier) and a radix-2 pass
-// with W_512^j in place.  tw[m] = exp(-2 pi i m / 512).
-constexpr int CS512 = 512 + 32 + 2;
-template <int NCOL, int NTH, bool INVERSE>
-__device__ __forceinline__ void lds_fft512(double2 *__restrict__ d, const double2 *__restrict__ twiddle) {
-    const int tid = threadIdx.x;
-    constexpr int NB = NCOL * 32;
-    static_assert(NB <= NTH, "one radix-16 butterfly per lane");
-    const bool act = tid < NB;
-    const int col = tid >> 5, j = tid & 31, k = j & 15;
-    double2 twa[4], twb[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { twa[r] = twiddle[(8 * k * r) & 511]; twb[r] = twiddle[(2 * k * r) & 511]; }
-    double2 *c = d + col * CS512;
-    double2 x[16];
-    if (act) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = c[pad16(j + 32 * r)];
-        dft16<INVERSE>(x);
-    }
-    __syncthreads();
-    if (act) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c[pad16(16 * j + r)] = x[DFT16_AT(r)];
-    }
-    __syncthreads();
-    if (act) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = c[pad16(j + 32 * r)];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) {
-            const int ra = r >> 2, rb = r & 3;
-            double2 w = twb[rb];
-            if (ra && rb) w = make_double2(w.x * twa[ra].x - w.y * twa[ra].y, w.x * twa[ra].y + w.y * twa[ra].x);
-            else if (ra) w = twa[ra];
-            if (INVERSE) w.y = -w.y;
-            const double2 v = x[r];
-            x[r] = make_double2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
-        }
-        dft16<INVERSE>(x);
-    }
-    __syncthreads();
-    if (act) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c[pad16((j & 16) * 16 + k + 16 * r)] = x[DFT16_AT(r)];
-    }
-    __syncthreads();
-    for (int e = tid; e < NCOL * 256; e += NTH) {
-        double2 *c2 = d + (e >> 8) * CS512;
-        const int j2 = e & 255;
-        double2 w = twiddle[j2];
-        if (INVERSE) w.y = -w.y;
-        const double2 a = c2[pad16(j2)], b0 = c2[pad16(j2 + 256)];
-        const double2 b = make_double2(b0.x * w.x - b0.y * w.y, b0.x * w.y + b0.y * w.x);
-        c2[pad16(j2)] = make_double2(a.x + b.x, a.y + b.y);
-        c2[pad16(j2 + 256)] = make_double2(a.x - b.x, a.y - b.y);
-    }
-    __syncthreads();
-}
-
-template <int N, int KB, int NTH, int WPS>
-__global__ void __launch_bounds__(NTH, WPS)
-k_xfft_scale256(double2 *__restrict__ X, double2 *__restrict__ Y, double2 *__restrict__ Z, DGrid G, DBox box, ScaleArgs a,
-                const double2 *__restrict__ twiddle) {
-    static_assert(N == 256 || N == 512, "two radix-16 passes (+ one radix-2 pass)");
-    constexpr int NCOL = 3 * KB, CS = N == 256 ? CS256 : CS512;   // the column stride of this N
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double2 *d = reinterpret_cast<double2 *>(smem_raw);      // [3][KB][CS]
-    const int tid = threadIdx.x;
-    const int nkb = (G.Nzh + KB - 1) / KB;
-    const int rows = a.transposed ? a.nyl : G.Ny;
-    // neighbouring kz blocks of a row share 128-byte lines (a block's pieces are 64 or 32 bytes): keep them on one XCD, so the
-    // second one finds the line in that XCD's L2 (round-robin placement fetched every line from memory twice)
-    const int bid = xcd_block(blockIdx.x, gridDim.x);
-    const int jl = bid / nkb, k0 = (bid - jl * nkb) * KB;
-    const int j = a.transposed ? a.y0 + jl : jl;
-    const int kv = min(KB, G.Nzh - k0);
-    double2 *comp[3] = {X, Y, Z};
-    const size_t xstride = (size_t)rows * G.Nzp, base = (size_t)jl * G.Nzp + k0;
-    {   // every load of a lane in flight before the first is parked in LDS
-        constexpr int PER = (3 * N * KB + NTH - 1) / NTH;
-        double2 v[PER];
-#pragma unroll
-        for (int it = 0; it < PER; ++it) {                    // KB consecutive kz are contiguous in memory
-            const int e = tid + it * NTH, c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
-            v[it] = make_double2(0, 0);
-            if (e < 3 * N * KB && q < kv) v[it] = comp[c][(size_t)x * xstride + base + q];
-        }
-#pragma unroll
-        for (int it = 0; it < PER; ++it) {
-            const int e = tid + it * NTH, c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
-            if (e < 3 * N * KB) d[(c * KB + q) * CS + pad16(x)] = v[it];
-        }
-    }
-    __syncthreads();
-    if constexpr (N == 256) lds_fft256<NCOL, NTH, false>(d, twiddle); else lds_fft512<NCOL, NTH, false>(d, twiddle);
-    for (int e = tid; e < N * KB; e += NTH) {
-        const int x = e / KB, q = e - x * KB;
-        if (q < kv) {
-            const int px = pad16(x);
-            const double2 f[3] = {d[q * CS + px], d[(KB + q) * CS + px], d[(2 * KB + q) * CS + px]};
-            double2 out[3];
-            scale_node(x, j, k0 + q, f, G, box, a, out);
-            d[q * CS + px] = out[0]; d[(KB + q) * CS + px] = out[1]; d[(2 * KB + q) * CS + px] = out[2];
-        }
-    }
-    __syncthreads();
-    if constexpr (N == 256) lds_fft256<NCOL, NTH, true>(d, twiddle); else lds_fft512<NCOL, NTH, true>(d, twiddle);
-    for (int e = tid; e < 3 * N * KB; e += NTH) {
-        const int c = e / (N * KB), r = e - c * (N * KB), x = r / KB, q = r - x * KB;
-        if (q < kv) comp[c][(size_t)x * xstride + base + q] = d[(c * KB + q) * CS + pad16(x)];
-    }
-}
-
-template <int KB, int NTH, int WPS, int N = 256>
-static void launch_xfft256(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s) {
-    const size_t lds = (size_t)(3 * KB * (N == 256 ? CS256 : CS512)) * sizeof(double2);
-    static LdsAttr attr;
-    if (attr.need(lds)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xfft_scale256<N, KB, NTH, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
-    const int nkb = (G.Nzh + KB - 1) / KB;
-    const int rows = a.transposed ? a.nyl : G.Ny;
-    hipLaunchKernelGGL((k_xfft_scale256<N, KB, NTH, WPS>), dim3(rows * nkb), dim3(NTH), lds, s, X, Y, Z, G, box, a, tw);
-}
 
 // ---- any Nx = 2^a 3^b 5^c (the grids the reference's rule produces, PSEv1/Stokes.cc:147-199) ---------------------------------
 // Mixed-radix Stockham passes (radix 5, 4, 3, 2) between two LDS buffers: a butterfly reads its R points from one buffer and
@@ -2006,8 +1789,8 @@ static void launch_fft_cols(double2 *data, const FftPlanX &pl, const double2 *tw
 }
 // slab ranks: forward = planes (cgrid) -> transformed blocks (blocks); inverse = blocks -> transformed planes
 static bool yfft_slab_regs(double2 *cgrid, double2 *blocks, DGrid G, int nyl, bool inverse, const double2 *tw, hipStream_t s);   // Ny = 256, 512: the register pass
-void launch_yfft_slab(double2 *cgrid, double2 *blocks, DGrid G, int nyl, bool inverse, const double2 *tw, hipStream_t s) {
-    if (yfft_slab_regs(cgrid, blocks, G, nyl, inverse, tw, s)) return;
+void launch_yfft_slab(double2 *cgrid, double2 *blocks, DGrid G, int nyl, bool inverse, const double2 *tw, hipStream_t s, bool regs) {
+    if (regs && yfft_slab_regs(cgrid, blocks, G, nyl, inverse, tw, s)) return;
     FftPlanX pl;
     plan_x(G.Ny, pl);
     constexpr int KB = 4, NTH = 256;
@@ -2139,8 +1922,6 @@ static void launch_yfft_regs(double2 *data, const double2 *tw, int nplanes, int 
 bool yfft_regs_supported(int Ny, int Nz, bool own_z) { return (Ny == 256 && Nz <= 256) || (own_z && (Ny == 256 || Ny == 512)); }
 
 static bool yfft_slab_regs(double2 *cgrid, double2 *blocks, DGrid G, int nyl, bool inverse, const double2 *tw, hipStream_t s) {
-    static const bool off = getenv("PSE_YSLAB_REGS") && atoi(getenv("PSE_YSLAB_REGS")) == 0;   // (A/B switch of the developer tools)
-    if (off) return false;
     if (G.Ny == 256) { launch_yfft_regs_slab<256, 8, 8, 8, 44, 5, 359>(cgrid, blocks, G, nyl, inverse, tw, s); return true; }
     if (G.Ny == 512) { launch_yfft_regs_slab<512, 8, 8, 4, 72, 9, 578>(cgrid, blocks, G, nyl, inverse, tw, s); return true; }
     return false;
@@ -2319,8 +2100,7 @@ static void launch_xfft_t(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box,
 }
 
 void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, ScaleArgs a, const double2 *tw, hipStream_t s) {
-    // k_xfft_scale_cols addresses a component with 32-bit byte offsets
-    const bool cols32 = (size_t)(a.transposed ? a.nyl : G.Ny) * G.Nzp * G.Nx * sizeof(double2) < ((size_t)1 << 32);
+    // (k_xfft_scale_cols addresses a component with 32-bit byte offsets: 512 x 512 x 264 complex numbers, the largest grid, are 1.1 GB)
     if (G.Nx & (G.Nx - 1)) {   // not a power of two: mixed-radix passes; 4 kz columns per workgroup while two buffers fit
         FftPlanX pl;
         plan_x(G.Nx, pl);
@@ -2329,8 +2109,7 @@ void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, Sc
         if (!a.runtime_plan) {   // compile-time plans for the sizes of the reference's rule at the BASELINE configurations (PSE_XMIX=1: runtime plan)
             switch (G.Nx) {
                 case 360:   // 0.80 ms at 360^3 (10 x 6 x 6, no spills at two waves per SIMD; three waves: 66 spilled, 0.97); the passes in LDS: 1.05
-                    if (a.xcols && cols32) launch_xfft_cols<360, 10, 6, 4, 2, false, 54, 9, 538>(X, Y, Z, G, box, a, tw, s);
-                    else launch_xfft_mixed<2, 256, CtPlan<360, 9, 8, 5>>(X, Y, Z, G, box, a, tw, pl, s);
+                    launch_xfft_cols<360, 10, 6, 4, 2, false, 54, 9, 538>(X, Y, Z, G, box, a, tw, s);
                     return;
                 case 270: launch_xfft_mixed<2, 256, CtPlan<270, 9, 5, 3, 2>>(X, Y, Z, G, box, a, tw, pl, s); return;
                 case 375: launch_xfft_mixed<2, 256, CtPlan<375, 5, 5, 5, 3>>(X, Y, Z, G, box, a, tw, pl, s); return;
@@ -2366,16 +2145,14 @@ void launch_xfft_scale(double2 *X, double2 *Y, double2 *Z, DGrid G, DBox box, Sc
         case 256:
             // 256 = 4 x 8 x 8 with TWO columns per wave: eight kz columns = 128-byte pieces at four waves per workgroup; 256^3: 0.201 against
             // 0.226 ms, with noise 0.214 against 0.243 (256 = 8 x 8 x 4 with one column per wave and 64-byte pieces only tied: 0.25 - 0.27)
-            if (a.xcols && cols32) launch_xfft_cols<256, 4, 8, 8, 3, true, 72, 9, 295, 2>(X, Y, Z, G, box, a, tw, s);
-            else launch_xfft256<4, 256, 2>(X, Y, Z, G, box, a, tw, s);   // two radix-16 passes in registers
+            launch_xfft_cols<256, 4, 8, 8, 3, true, 72, 9, 295, 2>(X, Y, Z, G, box, a, tw, s);
             break;
         // 512: radix 16, 16, 2; two kz columns: three workgroups per CU (3.3 ms at 512^3; four columns, one workgroup: 3.8; radix 4/2 in LDS: 5.2)
         default:
             // one component in LDS at a time, four kz columns, three workgroups per CU: 1.50 ms at 512^3 (4.3 TB/s); eight columns at four
             // waves per SIMD (128 registers: 225 spilled) 3.3 ms, six columns 2.9 ms, four columns without parking the third component
-            // during the operator (107 spilled) 2.27 ms; all three components in LDS, two columns (PSE_XCOLS=0): 2.77 ms
-            if (a.xcols && cols32) launch_xfft_cols<512, 8, 8, 4, 3, true, 72, 9, 578>(X, Y, Z, G, box, a, tw, s);
-            else launch_xfft256<2, 256, 1, 512>(X, Y, Z, G, box, a, tw, s);
+            // during the operator (107 spilled) 2.27 ms; all three components in LDS, two columns (k_xfft_scale256, removed in round 5): 2.77 ms
+            launch_xfft_cols<512, 8, 8, 4, 3, true, 72, 9, 578>(X, Y, Z, G, box, a, tw, s);
             break;
     }
 }

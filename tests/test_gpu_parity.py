@@ -229,8 +229,21 @@ def test_step_integrates_and_wraps(torch_cuda, oracle):
                                        ((32, 256, 256), 0.0, 4), ((32, 512, 512), 0.0, 4), ((32, 256, 512), 0.15, 4), ((32, 512, 256), 0.2, 4), ((36, 360, 256), -0.1, 4),   # the own z pass (k_zfft_rows, Nz = 256 / 512) and the register y pass at Ny = 512 (round 5)
                                        ((512, 32, 32), -0.1, 4)])  # the last in a box twice as long in x
 def test_fused_x_pass_matches_port(torch_cuda, oracle, grid, xy, P):
+    _check_far_field_passes(oracle, grid, xy, P)
+
+
+# the sizes at which the developer switches select other kernels (tests/test_gpu_switches.py runs these under every switch): the
+# register x passes (256, 360, 512), a runtime-plan size, the own y pass (360: k_fft_cols; 256, 512: k_yfft_regs), the own z pass
+@pytest.mark.parametrize("grid,xy,P", [((256, 32, 32), 0.2, 4), ((360, 32, 32), 0.1, 4), ((512, 32, 32), -0.1, 4), ((240, 32, 32), 0.15, 4),
+                                       ((64, 48, 40), 0.3, 0), ((32, 360, 36), 0.1, 4), ((36, 256, 30), 0.2, 4), ((32, 512, 256), 0.2, 4),
+                                       ((32, 256, 512), 0.15, 4)])
+def test_far_field_passes_at_the_switch_sizes(torch_cuda, oracle, grid, xy, P):
+    _check_far_field_passes(oracle, grid, xy, P)
+
+
+def _check_far_field_passes(oracle, grid, xy, P):
     """Every Nx = 2^a 3^b 5^c (the reference's grid rule, PSEv1/Stokes.cc:147-199) takes the fused forward-x FFT + k-space scaling
-    (+ noise) + inverse-x FFT kernel: radix 4/2 in LDS for powers of two, two radix-16 passes in registers at 256 (+ a radix-2 pass at 512), mixed
+    (+ noise) + inverse-x FFT kernel: radix 4/2 in LDS for powers of two up to 128, the register pass k_xfft_scale_cols at 256, 360 and 512, mixed
     radix 9/8/5/4/3/2 otherwise (60 = 5 4 3, 45 = 9 5, 36 = 9 4, 90 = 9 5 2, 120 = 8 5 3, 50 = 5 5 2; 240 = 8 5 3 2 and 225 = 9 5 5 are grids above 200 (two kz columns per workgroup); 360 = 9 8 5 is the grid of the
     reference's rule at the metric point and is timed by tools/perf.py --grid 0 --xi 0.5).  Since round 4 every Ny = 2^a 3^b 5^c that is
     not a power of two takes the own in-place y pass (k_fft_cols: 48, 36, 30, 40, 45 above; 360 = 9 8 5, 270 = 9 5 3 2, 375 = 5 5 5 3 and

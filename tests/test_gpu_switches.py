@@ -1,0 +1,53 @@
+"""Every developer switch the README names runs the parity cases of the code it selects, in a child process with the switch set
+(the environment is read once per handle, in pse_create): no kernel family lives in the library without a test.
+The cases are the ones of tests/test_gpu_parity.py, tests/test_gpu_slabs.py and tests/test_gpu_local.py that exercise the sizes
+the switch matters at."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+X = "far_field_passes_at_the_switch_sizes"
+CASES = [
+    # (environment, files, -k expression)
+    ({"PSE_OWN_Y": "0"}, ["test_gpu_parity.py"], X),                       # rocFFT's 2-D (y, z) plans everywhere
+    ({"PSE_OWN_Y_POW2": "0"}, ["test_gpu_parity.py"], X),                  # ... at Ny = 256 / 512 only
+    ({"PSE_OWN_Z": "0"}, ["test_gpu_parity.py"], X),                       # rocFFT's 1-D z transforms under the own y pass
+    ({"PSE_XMIX": "1"}, ["test_gpu_parity.py"], X),                        # runtime radix plans where compile-time ones exist
+    ({"PSE_NO_XFUSE": "1"}, ["test_gpu_parity.py"], X + " or wave_matches_port"),   # rocFFT 3-D + k_scale
+    ({"PSE_XFFT_SMALL_KB": "8"}, ["test_gpu_parity.py"], X),               # eight-column x pass on small grids
+    ({"PSE_YFFT_KB": "2"}, ["test_gpu_parity.py"], X),
+    ({"PSE_YFFT_KB": "8"}, ["test_gpu_parity.py"], X),
+    ({"PSE_OVERLAP": "1"}, ["test_gpu_parity.py"], "brownian_velocity_matches_port or step_integrates or wave_matches_port"),
+    ({"PSE_OVERLAP": "-1"}, ["test_gpu_parity.py"], "brownian_velocity_matches_port or total_mobility"),
+    ({"PSE_GATHER_BZ": "1"}, ["test_gpu_parity.py"], "wave_matches_port or both_halves"),
+    ({"PSE_GATHER_BZ": "2"}, ["test_gpu_parity.py"], "wave_matches_port or both_halves"),
+    ({"PSE_SPREAD_TZ": "8"}, ["test_gpu_parity.py"], "wave_matches_port or both_halves"),
+    ({"PSE_SPREAD_TZ": "16"}, ["test_gpu_parity.py"], "wave_matches_port or both_halves"),
+    ({"PSE_SPREAD_NW": "1"}, ["test_gpu_parity.py"], "wave_matches_port"),
+    ({"PSE_SPREAD_NW": "4"}, ["test_gpu_parity.py"], "wave_matches_port"),
+    ({"PSE_SIDE_PRIORITY": "low"}, ["test_gpu_parity.py"], "total_mobility or wave_matches_port"),
+    ({"PSE_SKIN": "0"}, ["test_gpu_parity.py", "test_gpu_nlist.py"], "mreal_matches_oracle or brownian_velocity_matches_port or step_integrates"),
+    ({"PSE_LANCZOS_EXTRA": "0"}, ["test_gpu_async.py"], "captured"),       # no gated iterations queued: the starting count must suffice
+    ({"PSE_LANCZOS_EXTRA": "4"}, ["test_gpu_async.py", "test_gpu_local.py"], "captured or velocities_match"),
+    ({"PSE_TEAM_SSTEP": "0"}, ["test_gpu_slabs.py"], "clustered or particle_group or follows_tilt"),  # one Lanczos iteration per exchange (replicated-state teams)
+    ({"PSE_TEAM_LANES": "0"}, ["test_gpu_slabs.py", "test_gpu_local.py"], "team_of_eight or clustered or velocities_match"),   # one stream for everything
+    ({"PSE_TEAM_SCHED": "0,0,0"}, ["test_gpu_slabs.py"], "team_of_eight or clustered"),
+    ({"PSE_WAVE_MODE": "replicated"}, ["test_gpu_slabs.py"], "team_of_eight or clustered"),
+    ({"PSE_WAVE_MODE": "slab"}, ["test_gpu_slabs.py"], "keeps_replicas or clustered"),
+    ({"PSE_YSLAB_REGS": "0"}, ["test_gpu_local.py"], "velocities_match"),   # a slab rank's y pass by k_fft_cols also at Ny = 256
+]
+
+
+@pytest.mark.parametrize("env,files,expr", CASES, ids=[",".join(f"{k}={v}" for k, v in c[0].items()) for c in CASES])
+def test_switch(env, files, expr):
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", *[os.path.join(ROOT, "tests", f) for f in files], "-k", expr],
+                       env=e, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    tail = r.stdout[-3000:]
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "no tests ran" not in tail, tail      # the expression selected something

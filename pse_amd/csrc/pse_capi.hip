@@ -2215,6 +2215,13 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
     if (kT < 0 || !(dt > 0)) return fail(PSE_ERR_INVALID, "need kT >= 0 and dt > 0");
     const bool noise = kT > 0.0;
     unsigned mask = 0;
+    static const bool dbg = getenv("PSE_DEBUG_SYNC") != nullptr;   // developer aid: wait and report after every stage
+    auto stage = [&](const char *what) -> int {
+        if (!dbg) return 0;
+        hipError_t e = hipDeviceSynchronize();
+        fprintf(stderr, "pse local_call: %s: %s\n", what, hipGetErrorString(e));
+        return e == hipSuccess ? 0 : fail(PSE_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+    };
     diag_begin(T);
     for (pse_handle *h : act(T)) {   // two lanes: the far-field chain next to the near field / Lanczos chain
         const bool on = h->side && !h->timing && T.lanes;
@@ -2234,6 +2241,7 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
         const LocalPool pool{h->keys, h->keys_s, h->perm, h->cell_cnt};
         launch_local_classify(ca[r], h->loc.g, h->dbox, h->nc, pool, h->loc.send[0], h->loc.send[1], h->loc.counters, h->loc.err, h->stream);
     }
+    TRY(stage("classify"));
     // (2) ONE exchange: my left message goes left, what arrives from the right is the right neighbour's left message
     TRY(team_run_exchange(T, [&](pse_handle *h) {
         const LocalGeom &g = h->loc.g;
@@ -2246,6 +2254,7 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
         ops.push_back(Xfer{(const double *)h->loc.counters, 1, L, h->loc.recv[1], 1, R});
         ops.push_back(Xfer{(const double *)h->loc.counters, 1, R, h->loc.recv[0], 1, L});
         return ops; }, false, DIAG_FIRST));
+    TRY(stage("first exchange"));
     // (3) cell sort of what the rank keeps: own particles that stayed, arrivals, ghosts
     for (size_t r = 0; r < T.m.size(); ++r) {
         pse_handle *h = T.m[r];
@@ -2268,11 +2277,13 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
         h->sw.need = need; h->sw.cell_off = h->cell_off; h->sw.rows_local = 1;
     }
     // (4) the far-field chain (side lane), the near field and the Lanczos blocks (main lane)
+    TRY(stage("sort + permute"));
     // The side lane forks from the sort and gets its first kernels (records, spread); then the main lane's pass is queued, and only
     // then the transforms: the host needs ~100 us for rocFFT's launches, and neither lane should sit idle meanwhile.
     WavePump pump;
     const WaveArgs wa{T.m[0]->loc.rows_cap, noise, kT, dt, timestep};
     TRY(pump.start(T, wa, T.m[0]->tun.team_sched, &mask, 1));
+    TRY(stage("records + spread"));
     for (pse_handle *h : act(T)) {
         const LocalRows *R = h->loc.rows;
         const int nco = h->n_intervals * 2 * RS_NCOEF;
@@ -2286,9 +2297,13 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
                          DevRowArgs{&R->own, R, nullptr, h->loc.g.c_own});
         h->nb_valid = noise; h->w_is_mpsi = noise;
     }
+    TRY(stage("near field"));
     TRY(pump.start(T, wa, T.m[0]->tun.team_sched, &mask, 2));
+    TRY(stage("forward transforms"));
     if (noise) TRY(lanczos_local(T, T.m[0]->d.error, m_io, &pump));
+    TRY(stage("lanczos"));
     TRY(pump.drain());
+    TRY(stage("far field"));
     // (5) join the lanes; the end of the step on the own rows, written to the caller's arrays
     for (size_t r = 0; r < T.m.size(); ++r) {
         pse_handle *h = T.m[r];

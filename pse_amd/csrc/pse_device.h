@@ -63,6 +63,7 @@ __device__ __forceinline__ void min_image(const DBox &b, double &dx, double &dy,
 
 __device__ __forceinline__ int cell_coord(double f, int n) {
     int c = (int)(f * n);
+    c = c < 0 ? 0 : c;            // (a NaN coordinate converts to INT_MIN: garbage in must not become an address out of bounds)
     return c >= n ? n - 1 : c;
 }
 

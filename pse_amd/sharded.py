@@ -256,6 +256,13 @@ class _LocalState:
         self.tag[:n] = torch.from_numpy(idx.astype(np.int32)).cuda()
         self.n_local.fill_(n)
 
+    def snapshot(self):
+        return [t.clone() for t in (self.pos, self.vel, self.force, self.accel, self.image, self.tag, self.n_local)]
+
+    def restore(self, snap):
+        for t, c in zip((self.pos, self.vel, self.force, self.accel, self.image, self.tag, self.n_local), snap):
+            t.copy_(c)
+
     def refresh_force(self, force_dev):
         """force rows in the order the step left the particles in (force_dev: (N, 4) CUDA tensor indexed by tag)."""
         self.force.copy_(force_dev[self.tag.long().clamp_(0, force_dev.shape[0] - 1)])

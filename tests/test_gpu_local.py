@@ -91,3 +91,53 @@ def test_local_team_follows_the_single_gpu_trajectory(world, xy0, n, grid):
         own0 = owner
     faces = {(r, (r + 1) % world) for r in range(world)} | {((r + 1) % world, r) for r in range(world)}
     assert faces <= crossed, sorted(faces - crossed)
+
+
+@pytest.mark.parametrize("lanes", ["1", "0"])
+def test_local_team_step_captured_into_a_graph(lanes, monkeypatch):
+    """The owned-particle step only queues work: ONE hipGraph holds the step of a whole in-process team (both lanes of every rank,
+    every exchange) and replays it with the timestep advanced through a device word -- against the same team stepping eagerly.
+    lanes = 0: everything on one stream (what an RCCL team runs by default)."""
+    import torch
+    from pse_amd.sharded import LocalLoopbackSimulation
+    monkeypatch.setenv("PSE_TEAM_LANES", lanes)
+    n, grid, world = 40_000, 96, 4
+    pos, force, box = make_suspension(n, phi=0.12, xy=0.1)
+    kw = _kw(box, grid, seed=4)
+    sims = [LocalLoopbackSimulation(n, box, world, **kw) for _ in range(2)]
+    for s in sims:
+        s.load(pos, force)
+    eager, cap = sims
+    kT, dt, m = 1.0, 0.05, 8
+    st = torch.cuda.Stream()
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for e in cap.engines:
+        e.set_stream(st.cuda_stream)
+        e.set_timestep_offset(word)
+    S = cap.s
+    args = lambda: ([s.pos for s in S], [s.vel for s in S], [s.accel for s in S], [s.image for s in S], [s.force for s in S],   # noqa: E731
+                    [s.tag for s in S], [s.n_local for s in S])
+    # step 0 eagerly on both (also the warm-up of the captured team), then capture step "1 + word" and replay it for word = 0 .. 5
+    eager.step(kT, dt, 0, lanczos_m=m)
+    with torch.cuda.stream(st):
+        cap.team.step_local(*args(), kT, dt, 0, lanczos_m=m)
+    st.synchronize()
+    for s in S:
+        s.refresh_force(cap.force_dev)
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+        cap.team.step_local(*args(), kT, dt, 1, lanczos_m=m)
+    # (the capture does not execute: the state is still the one after step 0)
+    for k in range(6):
+        word.fill_(k)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        for s in S:
+            s.refresh_force(cap.force_dev)
+        eager.step(kT, dt, 1 + k, lanczos_m=m)
+        pe, ue, ie, oe = eager.gather()
+        pc, uc, ic, oc = cap.gather()
+        assert [e.info()["lanczos_m"] for e in cap.engines] == [e.info()["lanczos_m"] for e in eager.engines], k
+        assert np.abs(pc - pe).max() < 1e-12 and np.array_equal(ic, ie) and np.array_equal(oc, oe), (k, np.abs(pc - pe).max())

@@ -6,12 +6,15 @@
 export TMPDIR=/tmp
 PYREAL=$(python3 -c 'import os,sys; print(os.path.realpath(sys.executable))')
 T=${1:-r05x}
-O=gpurun_out/$T; rm -rf $O; mkdir -p $O
+ONLY=${2:-all}     # "team": the team measurements only (the configurations take most of the time)
+O=gpurun_out/$T; mkdir -p $O
+if [ "$ONLY" = all ]; then
 {
 for a in "--n 1000 --phi 0.05 --grid 64 --only-mf --steps 200" "--n 65536 --grid 64 --only-mf --steps 200" "--n 1048576 --phi 0.2 --grid 256 --steps 10" "--n 1048576 --phi 0.1 --grid 256 --xy 0.3 --steps 10" "--n 4194304 --phi 0.3 --grid 512 --steps 5" "--grid 0 --xi 0.5 --steps 5"; do
   echo "== tools/perf.py $a"; timeout 600 python3 tools/perf.py $a 2>&1 | grep -E "create|phases|M.F |^step|queue-only"
 done
 } > $O/configs.txt
+fi
 {
 echo "# one rank's critical path with the GPU to itself (pse_team_debug_solo), eight ranks, zero-latency links (device copies)"
 echo "== owned-particle step (pse_team_step_local), metric point N = 1e6, 256^3"
@@ -21,7 +24,7 @@ timeout 600 python3 tools/perf_team.py --local --ranks 8 --solo 3 --n 4194304 --
 echo "== owned-particle step, four ranks, metric point"
 timeout 600 python3 tools/perf_team.py --local --ranks 4 --solo 1 2>&1 | grep -E "local team|solo rank 1 of|back to back"
 echo "== one lane (PSE_TEAM_LANES=0: what an RCCL team runs by default), metric point"
-PSE_TEAM_LANES=0 timeout 600 python3 tools/perf_team.py --local --ranks 8 --solo 3 2>&1 | grep -E "solo rank 3 of|back to back"
+PSE_TEAM_LANES=0 timeout 600 python3 tools/perf_team.py --local --ranks 8 --solo 3 2>&1 | grep -E "solo rank 3"
 echo "== replicated-state step (pse_team_step; Brownian evaluation without the Euler update, as in round 4), metric point"
 timeout 600 python3 tools/perf_team.py --ranks 8 --solo 3 2>&1 | grep -E "team of|solo"
 echo "== replicated-state step, config 4"

@@ -2176,7 +2176,9 @@ static int lanczos_local(pse_team &T, double tol, int *m_io, WavePump *pump) {
         for (pse_handle *h : act(T)) {
             LzDecide d{};
             d.m_lo = m_lo; d.m_hi = m_hi; d.done_iters = done_iters; d.have_last_beta = 1; d.first = first ? 1 : 0; d.last = last ? 1 : 0;
-            d.normalised = 1; d.m_max = M_MAX; d.tol = tol;
+            // (pse_team_debug_solo: the other ranks' sums are stale, the step norm means nothing -- the decision is made to pass at the
+            // starting count, as it does in the steady state of a time-stepping loop, so the gated block is timed as what it then is)
+            d.normalised = 1; d.m_max = M_MAX; d.tol = T.solo >= 0 ? 1e300 : tol;
             launch_lz_decide(d, h->scal, h->lz_state, h->sc_host_dev, (double)h->lz_seq, h->stream);
         }
     };

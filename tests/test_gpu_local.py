@@ -141,3 +141,88 @@ def test_local_team_step_captured_into_a_graph(lanes, monkeypatch):
         pc, uc, ic, oc = cap.gather()
         assert [e.info()["lanczos_m"] for e in cap.engines] == [e.info()["lanczos_m"] for e in eager.engines], k
         assert np.abs(pc - pe).max() < 1e-12 and np.array_equal(ic, ie) and np.array_equal(oc, oe), (k, np.abs(pc - pe).max())
+
+
+def test_local_team_reports_what_only_the_device_can_see():
+    """Nothing is read back inside an owned-particle step, so what only the device can see -- a capacity that was exceeded, a
+    particle that outran its neighbour -- is a sticky flag: pse_team_local_status reads it, the next call refuses to start, and a
+    step that overflowed leaves the caller's particle count alone."""
+    import torch
+    import pse_amd
+    from pse_amd import PSEError
+    from pse_amd.sharded import LocalLoopbackSimulation, host_layers, local_capacity
+    n, grid, world = 24_000, 64, 4
+    pos, force, box = make_suspension(n, phi=0.1)
+    kw = _kw(box, grid)
+    # (a) a particle handed to the wrong rank, two slabs away from where it lies: flag 8
+    sim = LocalLoopbackSimulation(n, box, world, **kw)
+    sim.load(pos, force)
+    s0 = sim.s[0]
+    k = int(s0.n_local.item())
+    far = np.array([box[0] * (2.5 / world - 0.5), 0.0, 0.0])          # the middle of rank 2's slab
+    s0.pos[k, :3] = torch.tensor(far, dtype=torch.float64, device="cuda"); s0.vel[k, 3] = 1.0; s0.tag[k] = n - 1
+    s0.n_local.fill_(k + 1)
+    sim.step(0.0, 1e-3, 0, integrate=False)
+    with pytest.raises(PSEError, match="flags 8"):
+        sim.team.local_status()
+    with pytest.raises(PSEError, match="earlier step failed"):
+        sim.step(0.0, 1e-3, 1, integrate=False)
+    # (b) a row capacity with 4 % room, and a whole cell layer of rank 1's particles moving into rank 0's slab in one step: rank 0's
+    # own rows overflow (flag 1); the step leaves every rank's particle count alone
+    from pse_amd.sharded import owner_of, x_layer
+    layers = host_layers(box, world, **kw)
+    per = layers // world
+    counts = np.bincount(owner_of(pos, box, layers, world), minlength=world)
+    tight = LocalLoopbackSimulation(n, box, world, n_max=int(1.04 * counts.max() * (per + 4) / per) + 512, **kw)
+    assert tight.layout["rows_own"] >= counts.max()
+    moved = pos.copy()
+    sel = x_layer(pos, box, layers) == per                             # rank 1's first layer
+    moved[sel, 0] -= box[0] / layers                                   # ... one layer to the left: rank 0's last layer
+    own = owner_of(pos, box, layers, world)                            # (owners as they were BEFORE the move)
+    for r in range(world):
+        tight.s[r].load(np.nonzero(own == r)[0], moved, force, 1.0)
+    assert counts[0] + sel.sum() > tight.layout["rows_own"]
+    before = [int(s.n_local.item()) for s in tight.s]
+    tight.team.step_local([s.pos for s in tight.s], [s.vel for s in tight.s], [s.accel for s in tight.s], [s.image for s in tight.s],
+                          [s.force for s in tight.s], [s.tag for s in tight.s], [s.n_local for s in tight.s], 0.0, 1e-3, 0, integrate=False)
+    with pytest.raises(PSEError, match="owned-particle step failed"):
+        tight.team.local_status()
+    assert [int(s.n_local.item()) for s in tight.s] == before
+    # (c) *n_local above what the arrays hold: flag 16
+    sim2 = LocalLoopbackSimulation(n, box, world, **kw)
+    sim2.load(pos, force)
+    sim2.s[1].n_local.fill_(sim2.layout["rows_own"] + 5)
+    sim2.step(0.0, 1e-3, 0, integrate=False)
+    with pytest.raises(PSEError):
+        sim2.team.local_status()
+
+
+def test_local_and_replicated_entry_points_refuse_each_others_handles():
+    import pse_amd
+    from pse_amd import PSEError
+    from pse_amd.engine import Team
+    from pse_amd.sharded import LocalLoopbackSimulation, LoopbackSimulation
+    n, grid, world = 24_000, 64, 2
+    pos, force, box = make_suspension(n, phi=0.1)
+    kw = _kw(box, grid)
+    loc = LocalLoopbackSimulation(n, box, world, **kw)
+    loc.load(pos, force)
+    full = [to4(pos) for _ in range(world)]
+    with pytest.raises(PSEError, match="owned-particle rank"):
+        loc.team.mobility(full, [to4(force) for _ in range(world)], [to4(np.zeros((n, 3))) for _ in range(world)])
+    rep = LoopbackSimulation(n, box, world, **kw)
+    rep.load(pos, force)
+    S = loc.s
+    with pytest.raises(PSEError, match="local_rows"):
+        rep.team.step_local([s.pos for s in S], [s.vel for s in S], [s.accel for s in S], [s.image for s in S], [s.force for s in S],
+                            [s.tag for s in S], [s.n_local for s in S], 0.0, 1e-3, 0)
+    # too few cell layers per rank: refused at creation with the reason
+    with pytest.raises(PSEError, match="cell layers"):
+        pse_amd.Engine(4096, box, n_slabs=8, slab_rank=0, local_rows=1, **kw)
+    # a team measures itself: every exchange of a call by kind, the lanes' spans
+    loc.team.set_diag(True)
+    loc.step(1.0, 1e-3, 3, lanczos_m=8)
+    d = loc.team.diag()
+    assert d["exchanges_per_step"] == sum(len(v) for v in d["exchange_us"].values())
+    assert len(d["exchange_us"]["migrate_ghosts"]) == 1 and len(d["exchange_us"]["all_to_all"]) == 2 and len(d["exchange_us"]["halo"]) == 1
+    assert len(d["exchange_us"]["lanczos"]) == 5 and d["critical_path_ms"] > 0 and d["lanes_ms"]["side"] > 0

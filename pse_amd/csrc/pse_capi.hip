@@ -1541,7 +1541,7 @@ static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*ou
         launch_mreal(h->pos_s, h->posf_s, v, h->*out + out_off, rank_rows(h, N, mode == MREAL_BUILD_LIST ? depth : 0), h->cell_off, h->dbox,
                      h->nc, h->d.rcut, h->d.self, h->coef, h->n_intervals * 2 * RS_NCOEF, h->nb, mode, h->stream,
                      psi ? h->psi_s : nullptr, h->w_s, h->vl, vlm,
-                     vlm == VL_USE && v == h->f_s && h->pv_is_f ? h->pv : nullptr,
+                     v == h->f_s && h->pv_is_f && (vlm == VL_USE || mode != MREAL_USE_LIST) ? h->pv : nullptr,   // packed (position, F) records
                      psi && depth > 0 ? h->pv2 : nullptr,    // two-step Lanczos: the next mat-vec gathers w = M psi from the second records
                      psi && h->n_slabs == 1 ? h->partials : nullptr, h->npart_cap, h->scal);   // single GPU: + the sums of Lanczos iteration 0
         h->sums0_done = psi && h->n_slabs == 1 && vlm != VL_USE && mreal_table_in_lds(h->n_intervals * 2 * RS_NCOEF);
@@ -2291,11 +2291,11 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
         const int nco = h->n_intervals * 2 * RS_NCOEF;
         if (noise)   // the pass that builds the pair list applies M_real to F and psi together, on the own rows + the adjacent ghost layers
             launch_mreal(h->pos_s, h->posf_s, h->f_s, h->ur_s, RowMap{}, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, nco, h->nb,
-                         MREAL_BUILD_LIST, h->stream, h->psi_s, h->w_s, VerletList{}, VL_NONE, nullptr, h->pv2, nullptr, 0, nullptr, Gate{},
+                         MREAL_BUILD_LIST, h->stream, h->psi_s, h->w_s, VerletList{}, VL_NONE, h->pv, h->pv2, nullptr, 0, nullptr, Gate{},
                          DevRowArgs{&R->own1, R, h->loc.stage_w1, h->loc.rows_cap});
         else
             launch_mreal(h->pos_s, h->posf_s, h->f_s, h->ur_s, RowMap{}, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, nco, h->nb,
-                         MREAL_CELLS, h->stream, nullptr, nullptr, VerletList{}, VL_NONE, nullptr, nullptr, nullptr, 0, nullptr, Gate{},
+                         MREAL_CELLS, h->stream, nullptr, nullptr, VerletList{}, VL_NONE, h->pv, nullptr, nullptr, 0, nullptr, Gate{},
                          DevRowArgs{&R->own, R, nullptr, h->loc.g.c_own});
         h->nb_valid = noise; h->w_is_mpsi = noise;
     }

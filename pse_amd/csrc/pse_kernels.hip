@@ -313,13 +313,15 @@ __device__ __forceinline__ void vl_store(char *vrec, int slot, int lane, unsigne
 // pre-filter and the queue work with that radius; f, g and the pair list still stop at rcut).
 // DEV: an owned-particle rank -- the rows come from device memory (DevRowArgs); a separate instantiation, so that the single-GPU
 // pass keeps its 166 registers (with the few extra scalars it spilled)
-template <bool LIST, bool CL, bool TWO, bool VL, bool DEV = false>
+// PK: the drain reads a neighbour's position AND vector from the packed 48-byte record pv[j] (three 16-byte gathers from one or two
+// lines instead of four from two arrays): the pass is bound by the drain's round trips through the texture addresser, not by its scan.
+template <bool LIST, bool CL, bool TWO, bool VL, bool DEV = false, bool PK = false>
 __global__ void __launch_bounds__(TPB, ((LIST && CL && !VL) ? 3 : 1))   // the list-building pass of every step: <= 168 VGPRs (it takes 166)
 k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf_s, const double4 *__restrict__ vec_s,
               double4 *__restrict__ out_s, RowMap rm_arg, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2,
               float rcut2_pre, double self, const double *__restrict__ coef_g, int ncoef, NbList nb,
               const double4 *__restrict__ vec2_s, double4 *__restrict__ out2_s, VerletList vl, double2 *__restrict__ pv_out,
-              double *__restrict__ sums0, int sums0_cap, Gate gate, DevRowArgs dr) {
+              double *__restrict__ sums0, int sums0_cap, Gate gate, DevRowArgs dr, const double2 *__restrict__ pvin) {
     if (gate.closed()) return;
     const RowMapRegs rm(rm_arg, DEV ? dr.rm : nullptr);
     if (!DEV) nc.xpad = 0;   // (only owned-particle ranks pad their x layers: a constant here, the term folds away)
@@ -379,7 +381,14 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
                 j[u] = (int)(e[u] & JMASK);
             }
 #pragma unroll
-            for (int u = 0; u < DU; ++u) { p[u] = pos_s[j[u]]; F[u] = vec_s[j[u]]; if (TWO) G[u] = vec2_s[j[u]]; }
+            for (int u = 0; u < DU; ++u) {
+                if (PK) {
+                    const double2 *r = pvin + 3 * (size_t)j[u];
+                    const double2 a = r[0], b = r[1], c = r[2];
+                    p[u] = make_double4(a.x, a.y, b.x, 0.0); F[u] = make_double4(b.y, c.x, c.y, 0.0);
+                } else { p[u] = pos_s[j[u]]; F[u] = vec_s[j[u]]; }
+                if (TWO) G[u] = vec2_s[j[u]];
+            }
 #pragma unroll
             for (int u = 0; u < DU; ++u) {
                 double sx, sy, sz;
@@ -854,18 +863,21 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
     const double cmax = 1.5 * (box.Lx + std::fabs(box.xy) * box.Ly + box.Ly + box.Lz);
     const double rpre = (wr ? vl.rskin : rcut) + 16.0 * cmax * 5.97e-8;
     const float rcut2_pre = (float)(rpre * rpre * (1.0 + 1e-6));
-#define PSE_CELLS(L, C, T, V) hipLaunchKernelGGL((k_mreal_cells<L, C, T, V>), g, b, (C) ? cb : 0, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, two ? vec2_s : nullptr, out2_s, vl, two ? pv_out : nullptr, (two && (C)) ? sums0 : nullptr, sums0_cap, gate, dr)
-    if (dr.rm) {   // owned-particle ranks (table in LDS, no kept list): the two passes of pse_team_step_local
-        if (list && two) hipLaunchKernelGGL((k_mreal_cells<true, true, true, false, true>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, vec2_s, out2_s, vl, pv_out, nullptr, 0, gate, dr);
-        else hipLaunchKernelGGL((k_mreal_cells<false, true, false, false, true>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, nullptr, out2_s, vl, nullptr, nullptr, 0, gate, dr);
+#define PSE_CELLS(L, C, T, V) hipLaunchKernelGGL((k_mreal_cells<L, C, T, V>), g, b, (C) ? cb : 0, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, two ? vec2_s : nullptr, out2_s, vl, two ? pv_out : nullptr, (two && (C)) ? sums0 : nullptr, sums0_cap, gate, dr, nullptr)
+#define PSE_CELLS_PK(L, T, D) hipLaunchKernelGGL((k_mreal_cells<L, true, T, false, D, true>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, two ? vec2_s : nullptr, out2_s, vl, two ? pv_out : nullptr, (two && !(D)) ? sums0 : nullptr, sums0_cap, gate, dr, pv)
+    if (dr.rm) {   // owned-particle ranks (table in LDS, no kept list, packed records): the two passes of pse_team_step_local
+        if (list && two) PSE_CELLS_PK(true, true, true); else PSE_CELLS_PK(false, false, true);
         return;
     }
-    if (list) {
+    if (pv && cl && !wr && vl_mode != VL_USE && (two || !list)) {   // the hot passes of a single GPU: packed (position, vector) records
+        if (list) PSE_CELLS_PK(true, true, false); else PSE_CELLS_PK(false, false, false);
+    } else if (list) {
         if (cl && two) { if (wr) PSE_CELLS(true, true, true, true); else PSE_CELLS(true, true, true, false); }
         else if (cl) { if (wr) PSE_CELLS(true, true, false, true); else PSE_CELLS(true, true, false, false); }
         else PSE_CELLS(true, false, false, false);
     } else if (cl) { if (wr) PSE_CELLS(false, true, false, true); else PSE_CELLS(false, true, false, false); }
     else PSE_CELLS(false, false, false, false);
+#undef PSE_CELLS_PK
 #undef PSE_CELLS
     if (sums0 && list && two && cl)   // one partial per wavefront of the pass -> scal[LZ_TMP .. LZ_TMP + 2]
         hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, sums0, (int)g.x * (TPB / 64), sums0_cap, 3, scal, nullptr);

@@ -840,6 +840,7 @@ struct pse_team {
     int solo = -1;
     std::vector<pse_handle *> solo_m;
     bool lanes = true;           // two compute lanes (PSE_TEAM_LANES=0: one stream for everything, also the RCCL calls)
+    bool debug_sync = getenv("PSE_DEBUG_SYNC") != nullptr;   // (read once, when the team is created)
     // self-diagnosis (pse_team_set_diag): every exchange of a call bracketed by events on the lane that issues it, the lanes'
     // spans, the host time the transport's callback took -- read after the call by pse_team_get_diag
     struct Diag {
@@ -2217,9 +2218,8 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
     if (kT < 0 || !(dt > 0)) return fail(PSE_ERR_INVALID, "need kT >= 0 and dt > 0");
     const bool noise = kT > 0.0;
     unsigned mask = 0;
-    static const bool dbg = getenv("PSE_DEBUG_SYNC") != nullptr;   // developer aid: wait and report after every stage
-    auto stage = [&](const char *what) -> int {
-        if (!dbg) return 0;
+    auto stage = [&](const char *what) -> int {   // developer aid (PSE_DEBUG_SYNC, read when the team was created): wait and report after every stage
+        if (!T.debug_sync) return 0;
         hipError_t e = hipDeviceSynchronize();
         fprintf(stderr, "pse local_call: %s: %s\n", what, hipGetErrorString(e));
         return e == hipSuccess ? 0 : fail(PSE_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));

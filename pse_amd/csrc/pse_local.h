@@ -29,7 +29,7 @@ struct LocalRegions {
     int c_gl_adj;         // offset there = begin of the left ghosts' layer next to the slab
     int c_gr_adj;         // offset there = end of the right ghosts' layer next to the slab
 };
-constexpr int LOCAL_REC = 12;     // doubles per particle record of the first exchange: pos.xyzw | force.xyz, mass | image.xyz, tag
+constexpr int LOCAL_REC = 10;     // doubles per particle record of the first exchange: pos.xyzw | force.xyz, mass | (image.xyz, tag) as four 32-bit words
 constexpr int LOCAL_HDR = 4;      // doubles in front of the records; on the receiving side the first holds the sender's two record counters (two ints)
 enum { LOCAL_ERR_OWN = 1, LOCAL_ERR_GHOST = 2, LOCAL_ERR_MSG = 4, LOCAL_ERR_FAR = 8, LOCAL_ERR_COUNT = 16 };   // bits of the error word
 // counters of a step, zeroed with the cell counts: [0] records in the left message, [1] in the right one (8-byte aligned: the pair

@@ -45,7 +45,8 @@ __device__ __forceinline__ void write_record(double *msg, int slot, const double
     double2 *r = reinterpret_cast<double2 *>(msg + LOCAL_HDR + (size_t)slot * LOCAL_REC);
     r[0] = make_double2(p.x, p.y); r[1] = make_double2(p.z, p.w);
     r[2] = make_double2(f.x, f.y); r[3] = make_double2(f.z, mass);
-    r[4] = make_double2((double)im.x, (double)im.y); r[5] = make_double2((double)im.z, (double)tag);
+    const int4 w = make_int4(im.x, im.y, im.z, (int)tag);      // bit patterns: the transports move bytes
+    r[4] = *reinterpret_cast<const double2 *>(&w);
 }
 
 __global__ void __launch_bounds__(TPB)
@@ -116,7 +117,8 @@ k_local_bin_incoming(const double *__restrict__ recv_l, const double *__restrict
     if (s >= -g.depth && s < g.per + g.depth) {
         pool.keys[pid] = key;
         pool.rank[pid] = (unsigned)atomicAdd(&pool.cnt[key], 1);
-        pool.ptag[pid] = (unsigned)r[5].y;
+        const double2 w2 = r[4];
+        pool.ptag[pid] = (unsigned)reinterpret_cast<const int4 *>(&w2)->w;
     } else {
         pool.keys[pid] = KEY_FOREIGN;
     }
@@ -209,9 +211,10 @@ k_local_permute(LocalCaller c, const double *__restrict__ recv_l, const double *
         } else {
             const int q = (int)v - g.c_own, side = q / g.c_x, k = q - side * g.c_x;
             const double2 *r = reinterpret_cast<const double2 *>((side == 0 ? recv_l : recv_r) + LOCAL_HDR + (size_t)k * LOCAL_REC);
-            const double2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
+            const double2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
             p = make_double4(r0.x, r0.y, r1.x, r1.y); f = make_double4(r2.x, r2.y, r3.x, 0.0); mass = r3.y;
-            im = make_int3((int)r4.x, (int)r4.y, (int)r5.x);
+            const int4 w = *reinterpret_cast<const int4 *>(&r4);
+            im = make_int3(w.x, w.y, w.z);
         }
         // wrap into the primary cell (k_permute, pse_kernels.hip)
         double fx, fy, fz;

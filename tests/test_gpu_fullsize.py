@@ -292,3 +292,38 @@ def test_fullsize_far_field_accuracy(oracle, n, phi, grid, xy):
         assert np.abs(got - want).max() < 1e-12 * np.abs(want).max(), lo
     del eng, g
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("n,phi,grid", [(1_000_000, 0.1, 256), (4_194_304, 0.3, 512)])
+def test_owned_particle_team_of_eight_at_full_size(n, phi, grid):
+    """The owned-particle step (pse_team_step_local) at the metric point and at BASELINE config 4, eight ranks in this process: two
+    Brownian steps against the single-GPU engine (positions 1e-9, equal Lanczos counts), every particle owned by exactly one rank
+    afterwards, no device-side flag."""
+    import torch
+    import pse_amd
+    from pse_amd.sharded import LocalLoopbackSimulation
+    pos, force, box = make_suspension(n, phi=phi)
+    xi = math.pi * grid / (2.0 * box[0] * math.sqrt(-math.log(1e-3)))
+    kw = dict(xi=xi, error=1e-3, seed=11, grid=(grid,) * 3)
+    ref = pse_amd.Engine(n, box, **kw)
+    dpos, dF, vel = to4(pos), to4(force), to4(np.zeros((n, 3)), 1.0)
+    accel = torch.zeros((n, 3), dtype=torch.float64, device="cuda"); image = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+    kT, dt = 1.0, 1e-3
+    _, m = ref.brownian_velocity(dpos, dF, kT, dt, 0, vel=to4(np.zeros((n, 3)), 1.0), lanczos_m=2)
+    ms = [ref.step(dpos, vel, accel, image, dF, kT, dt, 1 + k, lanczos_m=m) for k in range(2)]
+    p_ref, im_ref = dpos.cpu().numpy()[:, :3].copy(), image.cpu().numpy().copy()
+    del ref, dpos, dF, vel, accel, image
+    torch.cuda.empty_cache()
+    sim = LocalLoopbackSimulation(n, box, 8, **kw)
+    sim.load(pos, force)
+    for k in range(2):
+        sim.step(kT, dt, 1 + k, lanczos_m=m)
+        torch.cuda.synchronize()
+        infos = [e.info() for e in sim.engines]
+        assert all(i["lanczos_status"] == 0 and i["lanczos_m"] == ms[k] for i in infos), (k, ms[k], [i["lanczos_m"] for i in infos])
+    p, u, im, owner = sim.gather()
+    assert (owner >= 0).all()
+    assert sum(int(s.n_local.item()) for s in sim.s) == n
+    assert np.abs(p - p_ref).max() < 1e-9 and np.array_equal(im, im_ref)
+    del sim
+    torch.cuda.empty_cache()

@@ -43,11 +43,30 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("env,files,expr", CASES, ids=[",".join(f"{k}={v}" for k, v in c[0].items()) for c in CASES])
-def test_switch(env, files, expr):
+def _run_case(case):
+    env, files, expr = case
     e = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", *[os.path.join(ROOT, "tests", f) for f in files], "-k", expr],
                        env=e, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    tail = r.stdout[-3000:]
-    assert r.returncode == 0, tail
+    return r.returncode, r.stdout[-3000:]
+
+
+_results = {}
+
+
+def _result(idx):
+    """The child runs are independent of one another (each has its own process and handles): the first test that asks starts them
+    all, four at a time, and every test reads its own outcome -- most of a child's time is interpreter and library start-up."""
+    if not _results:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            for i, out in enumerate(pool.map(_run_case, CASES)):
+                _results[i] = out
+    return _results[idx]
+
+
+@pytest.mark.parametrize("idx", range(len(CASES)), ids=[",".join(f"{k}={v}" for k, v in c[0].items()) for c in CASES])
+def test_switch(idx):
+    rc, tail = _result(idx)
+    assert rc == 0, tail
     assert " passed" in tail and "no tests ran" not in tail, tail      # the expression selected something

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--solo", type=int, default=-1, help="after the full calls: time Brownian evaluations that queue the work of this "
                     "rank only (both lanes, its share of the copies): one rank's critical path with the GPU to itself")
     ap.add_argument("--local", action="store_true", help="owned-particle team (pse_team_step_local): every rank holds only its slab's particles")
+    ap.add_argument("--m", type=int, default=0, help="--local: starting count of the Lanczos iteration (default: found by warm-up steps)")
     a = ap.parse_args()
     import torch
     from conftest import make_suspension
@@ -87,8 +88,8 @@ def main_local(a):
     S = sim.s
     args = lambda: ([s.pos for s in S], [s.vel for s in S], [s.accel for s in S], [s.image for s in S], [s.force for s in S],   # noqa: E731
                     [s.tag for s in S], [s.n_local for s in S])
-    m = 2   # the starting count grows until a step converges within its queue (a queue-only step never waits for more)
-    for it in range(8):
+    m = a.m or 2   # the starting count grows until a step converges within its queue (a queue-only step never waits for more)
+    for it in range(0 if a.m else 8):
         sim.step(1.0, 1e-3, it, lanczos_m=m)
         torch.cuda.synchronize()
         i0 = sim.engines[0].info()

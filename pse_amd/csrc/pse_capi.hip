@@ -661,11 +661,15 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     // PSE_OVERLAP=1 forks them too, -1 never forks).  With pse_set_timing on, everything runs on one stream: per-kernel
     // durations -- the roofline evidence -- are then those of the kernel alone.
     if (h->tun.overlap >= 0) {
-        {   // PSE_SIDE_PRIORITY=low|high: the far-field lane at the lowest / highest stream priority (default: the default priority)
+        {   // PSE_SIDE_PRIORITY=low|high|default: the far-field lane at the lowest / highest / the default stream priority.  Default: the
+            // default priority -- but LOW on an owned-particle rank, whose near field + Lanczos chain is the longer lane by ~100 us at
+            // eight ranks: its mat-vecs then lose less to the transforms that run next to them (solo rank, metric point 0.724 -> 0.701 ms,
+            // BASELINE config 4 2.72 -> 2.69)
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo: numerically largest = lowest priority
             const char *pr = getenv("PSE_SIDE_PRIORITY");
-            if (pr && (!strcmp(pr, "low") || !strcmp(pr, "high")))
+            if (!pr || !*pr) pr = h->loc.on ? "low" : "default";
+            if (!strcmp(pr, "low") || !strcmp(pr, "high"))
                 HIPCHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, !strcmp(pr, "low") ? lo : hi));
             else
                 HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
@@ -1349,14 +1353,13 @@ static ScaleArgs scale_args(pse_handle *h, bool noise, double kT, double dt, uns
 //   part 3  gather
 // A single GPU, or a team that keeps the whole grid on every rank, has no exchanges: the parts simply follow one another.
 struct WaveArgs { int N; bool noise; double kT, dt; unsigned timestep; };
-static int wave_compute(pse_team &T, const WaveArgs &a, int part, int half = 0) {   // half (part 0 only): 1 records + spread, 2 the transforms, 0 both
+static int wave_compute(pse_team &T, const WaveArgs &a, int part) {
     const int GS = T.m[0]->grid_slabs;   // 1: every rank transforms the whole grid (single GPU, or a team that replicates it)
     for (pse_handle *h : act(T)) {
         const DGrid &G = h->G;
         const size_t nr = (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, ncx = (size_t)G.nxl * G.Ny * G.Nzp;
         if (part == 0) {
             double *gx = h->rgrid, *gy = h->rgrid + nr, *gz = h->rgrid + 2 * nr;
-            if (half != 2) {
             TRY(tsw(h, PH_RECORDS));
             HIPCHK(launch_far_records(h->pos_s, h->f_s, a.N, G, h->dbox, h->sw, h->wstream));
             TRY(tew(h, PH_RECORDS));
@@ -1364,8 +1367,6 @@ static int wave_compute(pse_team &T, const WaveArgs &a, int part, int half = 0) 
             if (spread_needs_zero(G)) HIPCHK(hipMemsetAsync(h->rgrid, 0, 3 * nr * sizeof(double), h->wstream));
             HIPCHK(launch_spread(h->pos_s, h->f_s, a.N, gx, gy, gz, G, h->dbox, h->sw, h->wstream));
             TRY(tew(h, PH_SPREAD));
-            }
-            if (half == 1) continue;
             TRY(tsw(h, PH_FFTF));
             double *zr[3]; double2 *zs[3];   // the rows of the own planes of each component
             for (int c = 0; c < 3; ++c) { zr[c] = h->rgrid + c * nr + (size_t)G.hl * G.Ny * G.Nz; zs[c] = h->cgrid + c * ncx; }
@@ -1453,22 +1454,25 @@ struct WavePump {
     int next = 4;                   // next compute part to queue (4: the chain is complete, or not part of this call)
     int slot[3] = {0, 0, 0};
     unsigned *mask = nullptr;
-    // half: 0 the whole first part; 1 fork + records + spread only (the caller queues main-lane work, then calls again with 2: the
-    // transforms -- rocFFT's launches cost the host the most, and the main lane should not wait for them to be queued)
-    int start(pse_team &team, const WaveArgs &args, const int sched[3], unsigned *m, int half = 0) {
+    bool forked = false;
+    // the side lane may start from here (the sorted arrays exist); what the caller queues on the main lane afterwards runs NEXT to the chain
+    int fork(pse_team &team) {
+        for (pse_handle *h : act(team))
+            if (h->side_on) {
+                HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+                HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+                if (h == act(team)[0]) diag_mark(team, 2, h->side);
+            }
+        forked = true;
+        return 0;
+    }
+    int start(pse_team &team, const WaveArgs &args, const int sched[3], unsigned *m) {
         T = &team; a = args; mask = m;
         for (int k = 0; k < 3; ++k) slot[k] = sched[k];
-        if (half != 2)
-            for (pse_handle *h : act(*T))
-                if (h->side_on) {   // fork: the wave chain starts once the sorted arrays exist
-                    HIPCHK(hipEventRecord(h->ev_fork, h->stream));
-                    HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-                    if (h == act(*T)[0]) diag_mark(*T, 2, h->side);
-                }
+        if (!forked) TRY(fork(team));
         *mask |= (1u << PH_SPREAD) | (1u << PH_FFTF) | (1u << PH_SCALE) | (1u << PH_FFTI) | (1u << PH_GATHER) | (1u << PH_RECORDS);
         if (T->m[0]->grid_slabs > 1) *mask |= 1u << PH_COMM;
-        TRY(wave_compute(*T, a, 0, half));
-        if (half == 1) return 0;
+        TRY(wave_compute(*T, a, 0));
         next = 1;
         if (T->m[0]->grid_slabs == 1) return upto(1 << 30);   // no exchanges: the whole chain is queued at once
         return 0;
@@ -1936,7 +1940,11 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
     // With noise on one stream the wave chain is queued BEHIND the Lanczos iterations: the host has to read their scalars
     // back before it can finish the Brownian part, and meanwhile the GPU works through the far field instead of idling.
     const bool wave_behind = noise && (parts & 2) && (parts & 1) && !T.m[0]->side_on;
-    if ((parts & 2) && !wave_behind) TRY(wave_start());
+    // Two lanes and noise: the near field + Lanczos chain is the longer lane, so its first pass is queued BEFORE the far-field chain
+    // (which forks here and follows at once); a deterministic evaluation has the far field as its longer lane and keeps it first.
+    const bool near_first = noise && parts == 3 && T.m[0]->side_on;
+    if (near_first) TRY(pump.fork(T));
+    if ((parts & 2) && !wave_behind && !near_first) TRY(wave_start());
     // the slab row boundaries are needed from here on (a host round trip); the first part of the far-field chain is queued
     for (pse_handle *h : act(T)) TRY(slab_bounds_wait(h, N));
     if (parts & 1) {
@@ -1945,6 +1953,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
         for (pse_handle *h : act(T)) TRY(te(h, PH_REAL));
         *mask |= 1u << PH_REAL;
     }
+    if (near_first) TRY(wave_start());
     if (noise) {
         for (pse_handle *h : act(T)) TRY(ts(h, PH_LANCZOS));   // closed inside the Lanczos driver, after the first batch of iterations
         for (pse_handle *h : act(T)) h->matvec_timed = false;
@@ -2280,12 +2289,12 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
     }
     // (4) the far-field chain (side lane), the near field and the Lanczos blocks (main lane)
     TRY(stage("sort + permute"));
-    // The side lane forks from the sort and gets its first kernels (records, spread); then the main lane's pass is queued, and only
-    // then the transforms: the host needs ~100 us for rocFFT's launches, and neither lane should sit idle meanwhile.
+    // The side lane forks from the sort, but the main lane's pass is queued FIRST: the near field + Lanczos chain is the longer of the
+    // two (the far-field lane ends ~250 us earlier at eight ranks), and a dispatch that reaches the device behind the spread waits
+    // for the spread's workgroups to leave the CUs.
     WavePump pump;
     const WaveArgs wa{T.m[0]->loc.rows_cap, noise, kT, dt, timestep};
-    TRY(pump.start(T, wa, T.m[0]->tun.team_sched, &mask, 1));
-    TRY(stage("records + spread"));
+    TRY(pump.fork(T));
     for (pse_handle *h : act(T)) {
         const LocalRows *R = h->loc.rows;
         const int nco = h->n_intervals * 2 * RS_NCOEF;
@@ -2300,8 +2309,8 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
         h->nb_valid = noise; h->w_is_mpsi = noise;
     }
     TRY(stage("near field"));
-    TRY(pump.start(T, wa, T.m[0]->tun.team_sched, &mask, 2));
-    TRY(stage("forward transforms"));
+    TRY(pump.start(T, wa, T.m[0]->tun.team_sched, &mask));
+    TRY(stage("records + spread + forward transforms"));
     if (noise) TRY(lanczos_local(T, T.m[0]->d.error, m_io, &pump));
     TRY(stage("lanczos"));
     TRY(pump.drain());

@@ -2,19 +2,21 @@
 """Timeline of ONE rank's Brownian evaluation from a rocprofv3 kernel trace of `tools/perf_team.py --solo R` (developer tool):
 every dispatch between the last two k_cell_keys launches with its queue, start, duration and the idle time of its queue before
 it, then per queue: busy time, idle time between its first and last dispatch; and how long two queues were busy at once.
-  python3 tools/timeline_solo.py <dir with *_kernel_trace.csv> [marker kernel, default k_cell_keys]"""
+  python3 tools/timeline_solo.py <dir with *_kernel_trace.csv> [marker kernel, default k_cell_keys] [index of the step's marker, default -2]"""
 import csv
 import glob
 import sys
 
-f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
+import os
+f = max(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True), key=os.path.getmtime)   # (merged run directories accumulate: the newest)
 marker = sys.argv[2] if len(sys.argv) > 2 else 'k_cell_keys'
 rows = [r for r in csv.DictReader(open(f))]
 for r in rows:
     r['s'] = int(r['Start_Timestamp']); r['e'] = int(r['End_Timestamp'])
 rows.sort(key=lambda r: r['s'])
 marks = [i for i, r in enumerate(rows) if marker in r['Kernel_Name']]
-a, b = marks[-2], marks[-1]
+k = int(sys.argv[3]) if len(sys.argv) > 3 else -2
+a, b = marks[k], marks[k + 1]
 # the call starts with the memset in front of the marker kernel
 while a > 0 and rows[a - 1]['s'] > rows[a]['s'] - 20000 and 'fillBuffer' in rows[a - 1]['Kernel_Name']:
     a -= 1

@@ -31,7 +31,9 @@ echo "== replicated-state step, config 4"
 timeout 600 python3 tools/perf_team.py --ranks 8 --solo 3 --n 4194304 --phi 0.3 --grid 512 --steps 3 2>&1 | grep -E "team of|solo"
 } > $O/team8_solo_times.txt 2>&1
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- $PYREAL tools/perf_team.py --local --ranks 8 --steps 5 --solo 3 > $O/trace.log 2>&1
-python3 tools/timeline_solo.py $O/trace k_local_classify > $O/team8_local_timeline.txt 2>&1
+{ echo "# one EAGER solo step of rank 3 of 8 (owned-particle step, metric point) under rocprofv3 --kernel-trace: tools/timeline_solo.py <trace> k_local_classify -50"
+  echo "# (the last steps of the run are replayed hipGraphs, whose nodes the runtime launches branch by branch: not this timeline)"
+  python3 tools/timeline_solo.py $O/trace k_local_classify -50; } > $O/team8_local_timeline.txt 2>&1
 PSE_TEAM_LANES=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- $PYREAL tools/perf_team.py --local --ranks 8 --steps 5 --solo 3 > $O/stats1.log 2>&1
 python3 - $O <<'PY' > $O/team8_local_kernel_stats.txt
 import csv,glob,sys

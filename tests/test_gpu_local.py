@@ -51,6 +51,52 @@ def test_local_team_velocities_match_single_gpu(world, n, grid, xy):
     assert rel(u, r_b) < 1e-3 * 50 or True
 
 
+def test_local_team_with_empty_ranks():
+    """All particles in the slabs of ranks 0 and 1 of four: rank 2 owns nothing and sees no ghosts on its right, rank 3 owns nothing
+    and holds only ghosts (rank 0's first layers, through the periodic face).  Every launch of a step covers capacities, so empty
+    row ranges, empty messages and zero partial sums must all pass through: M.F, Brownian velocities, and steps that let particles
+    diffuse into the empty slabs, against the single-GPU engine."""
+    import pse_amd
+    from pse_amd.sharded import LocalLoopbackSimulation, host_layers, owner_of
+    world, grid, xy = 4, 64, 0.2
+    pos, force, box = make_suspension(30_000, phi=0.1, xy=xy)
+    kw = _kw(box, grid)
+    keep = owner_of(pos, box, host_layers(box, world, **kw), world) < 2
+    pos, force = np.ascontiguousarray(pos[keep]), np.ascontiguousarray(force[keep])
+    n = len(pos)
+    sim = LocalLoopbackSimulation(n, box, world, n_max=3 * n, **kw)     # (row capacity of a rank: own rows + ghosts; half of all particles live on one rank)
+    sim.load(pos, force)
+    counts = [int(s.n_local.item()) for s in sim.s]
+    assert counts[2] == 0 and counts[3] == 0 and counts[0] > 0 and counts[1] > 0, counts
+    ref = pse_amd.Engine(n, box, **kw)
+    dpos, dF = to4(pos), to4(force)
+    sim.step(0.0, 1e-3, 0, integrate=False)
+    p, u, im, owner = sim.gather()
+    assert (owner >= 0).all() and sim.team.local_status() == [0] * world
+    r_mf = ref.mobility(dpos, dF).cpu().numpy()[:, :3]
+    assert rel(u, r_mf) < 1e-11, rel(u, r_mf)
+    vel = to4(np.zeros((n, 3)), 1.0)
+    _, mr = ref.brownian_velocity(dpos, dF, 1.0, 1e-3, 7, vel=vel, lanczos_m=2)
+    sim.step(1.0, 1e-3, 7, integrate=False, lanczos_m=mr)
+    p, u, im, owner = sim.gather()
+    assert all(e.info()["lanczos_status"] == 0 and e.info()["lanczos_m"] == mr for e in sim.engines)
+    assert rel(u, vel.cpu().numpy()[:, :3]) < 1e-9
+    # large steps: the cloud spreads into the empty slabs (first arrivals of ranks 2 and 3 are migrants, not initial particles)
+    import torch
+    accel = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+    image = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+    kT, dt, m = 1.0, 0.25, mr
+    for k in range(6):
+        m_ref = ref.step(dpos, vel, accel, image, dF, kT, dt, 100 + k, lanczos_m=m)
+        m_loc = sim.step(kT, dt, 100 + k, lanczos_m=m)
+        assert sim.team.local_status() == [0] * world
+        m = m_ref
+    p, u, im, owner = sim.gather()
+    counts = [int(s.n_local.item()) for s in sim.s]
+    assert counts[2] > 0 and counts[3] > 0 and sum(counts) == n, counts
+    assert np.abs(p - dpos.cpu().numpy()[:, :3]).max() < 1e-8 and (im == image.cpu().numpy()).all()
+
+
 @pytest.mark.parametrize("world,xy0,n,grid", [(2, 0.0, 40_000, 96), (4, 0.1, 40_000, 96), (8, -0.2, 80_000, 128)])
 def test_local_team_follows_the_single_gpu_trajectory(world, xy0, n, grid):
     """20 sheared steps: particles migrate across every slab face, the box tilt moves with the strain; positions, images and the

@@ -51,6 +51,37 @@ def test_local_team_velocities_match_single_gpu(world, n, grid, xy):
     assert rel(u, r_b) < 1e-3 * 50 or True
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_local_team_with_a_dense_cluster_on_a_slab_face(world):
+    """400 particles inside a ball of radius 5 at the origin -- on the face between two slabs: their rows (own rows on one side, ghost
+    rows on the other) hold several times the capacity of the pair list, so the list-building pass marks them and every mat-vec
+    of the step walks the cells for them, with the padded x layers and the device-side row ranges of an owned-particle rank."""
+    import pse_amd
+    from pse_amd.sharded import LocalLoopbackSimulation
+    n0, grid = 24_000, 64
+    pos, force, box = make_suspension(n0, phi=0.1, xy=0.15)
+    rng = np.random.default_rng(3)
+    d = rng.normal(size=(400, 3)); d *= (5.0 * rng.uniform(size=(400, 1)) ** (1 / 3)) / np.linalg.norm(d, axis=1, keepdims=True)
+    pos = np.vstack([pos, d]); force = np.vstack([force, rng.normal(size=(400, 3))])
+    n = len(pos)
+    kw = _kw(box, grid)
+    sim = LocalLoopbackSimulation(n, box, world, **kw)
+    sim.load(pos, force)
+    ref = pse_amd.Engine(n, box, **kw)
+    dpos, dF = to4(pos), to4(force)
+    sim.step(0.0, 1e-3, 0, integrate=False)
+    p, u, im, owner = sim.gather()
+    assert len(set(owner[n0:])) >= 2, "the cluster should straddle a slab face"
+    r_mf = ref.mobility(dpos, dF).cpu().numpy()[:, :3]
+    assert rel(u, r_mf) < 1e-11, rel(u, r_mf)
+    vel = to4(np.zeros((n, 3)), 1.0)
+    _, mr = ref.brownian_velocity(dpos, dF, 1.0, 1e-3, 7, vel=vel, lanczos_m=2)
+    sim.step(1.0, 1e-3, 7, integrate=False, lanczos_m=mr)
+    p, u, im, owner = sim.gather()
+    assert all(e.info()["lanczos_status"] == 0 and e.info()["lanczos_m"] == mr for e in sim.engines), (mr, [e.info()["lanczos_m"] for e in sim.engines])
+    assert rel(u, vel.cpu().numpy()[:, :3]) < 1e-9, rel(u, vel.cpu().numpy()[:, :3])
+
+
 def test_local_team_with_empty_ranks():
     """All particles in the slabs of ranks 0 and 1 of four: rank 2 owns nothing and sees no ghosts on its right, rank 3 owns nothing
     and holds only ghosts (rank 0's first layers, through the periodic face).  Every launch of a step covers capacities, so empty

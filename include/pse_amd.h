@@ -262,7 +262,12 @@ int pse_team_step(pse_team *team, pse_double4 *const *pos, pse_double4 *const *v
  * word: the host learns it when it asks).  integrate = 0: velocities only, positions unchanged (but reordered likewise).
  * kT = 0: deterministic.  *lanczos_m as for queue-only calls (pse_set_async).  Errors that show on the device only (a capacity
  * exceeded, a particle that moved further than a neighbour) are sticky: pse_team_local_status reads them (synchronises), and
- * the next call refuses to start. */
+ * the next call refuses to start.
+ * Shear: the slabs are slabs of the FRACTIONAL x coordinate, so between two calls of pse_set_box that follow the strain
+ * continuously an affinely advected particle keeps its slab.  A Lees-Edwards FLIP of the tilt (xy + 0.5 -> - 0.5,
+ * PSEv1/VariantShearFunction.cc:34-43) re-maps the fractional x of every particle by its fractional y: the owner of the particle
+ * data redistributes them before the next call (what HOOMD's domain decomposition does at a flip; the Python mirror:
+ * pse_amd.sharded.*.redistribute) -- a step cannot follow it (flag 8). */
 int pse_team_step_local(pse_team *team, pse_double4 *const *pos, pse_double4 *const *vel, pse_double3 *const *accel,
                         pse_int3 *const *image, const pse_double4 *const *net_force, unsigned int *const *tag,
                         unsigned int *const *n_local, double kT, double dt, unsigned int timestep, double shear_rate,

@@ -225,6 +225,14 @@ def owner_of(pos, box, layers, world):
     return x_layer(pos, box, layers) // (layers // world)
 
 
+def tilt_flipped(old_box, new_box):
+    """True when a box change is a Lees-Edwards flip (xy + 0.5 -> - 0.5: the lattice vector b becomes b -+ a).  A flip re-maps the
+    fractional x of a particle by its fractional y: EVERY particle may change slab at once, which the migration inside
+    pse_team_step_local (one neighbour per step) cannot follow -- the owner of the particle data redistributes, as HOOMD's domain
+    decomposition does.  (Between flips the slabs are co-moving with the shear: an affinely advected particle keeps its slab.)"""
+    return abs((new_box[3] if len(new_box) > 3 else 0.0) - (old_box[3] if len(old_box) > 3 else 0.0)) > 0.25
+
+
 def local_capacity(n, world, layers_per_rank, depth=2, slack=1.3):
     """A row capacity (pse_params.n_max of an owned-particle handle) for n particles of roughly uniform density over `world` ranks:
     own rows + `depth` ghost cell layers on either side, times a slack."""
@@ -254,6 +262,24 @@ class _LocalState:
         self.force[:n, :3] = torch.from_numpy(np.ascontiguousarray(force[idx])).cuda()
         self.vel[:n, 3] = mass
         self.tag[:n] = torch.from_numpy(idx.astype(np.int32)).cuda()
+        self.n_local.fill_(n)
+
+    def state(self):
+        """(tag, pos, image, mass) of the live rows, as NumPy arrays -- synchronises."""
+        n = int(self.n_local.item())
+        return (self.tag[:n].cpu().numpy(), self.pos[:n].cpu().numpy(), self.image[:n].cpu().numpy(), self.vel[:n, 3].cpu().numpy())
+
+    def load_state(self, tag, pos4, image, mass):
+        """Replace the live rows (a redistribution: the particles this rank owns now)."""
+        import torch
+        n = len(tag)
+        if n > self.cap:
+            raise ValueError(f"{n} particles for a rank whose arrays hold {self.cap}")
+        self.pos[:n] = torch.from_numpy(np.ascontiguousarray(pos4)).cuda()
+        self.image[:n] = torch.from_numpy(np.ascontiguousarray(image.astype(np.int32))).cuda()
+        self.vel[:n] = 0.0
+        self.vel[:n, 3] = torch.from_numpy(np.ascontiguousarray(mass)).cuda()
+        self.tag[:n] = torch.from_numpy(np.ascontiguousarray(tag.astype(np.int32))).cuda()
         self.n_local.fill_(n)
 
     def snapshot(self):
@@ -301,9 +327,23 @@ class LocalLoopbackSimulation:
         self.force_dev = torch.from_numpy(f4).cuda()
 
     def set_box(self, Lx, Ly, Lz, xy):
+        flip = tilt_flipped(self.box, (Lx, Ly, Lz, xy))
         for e in self.engines:
             e.set_box(Lx, Ly, Lz, xy)
         self.box = (Lx, Ly, Lz, xy)
+        if flip:
+            self.redistribute()
+
+    def redistribute(self):
+        """Every particle to the rank that owns it under the CURRENT box (after a tilt flip; see tilt_flipped) -- synchronises."""
+        self.team.local_status()
+        parts = [s.state() for s in self.s]
+        tag, pos4, image, mass = (np.concatenate([p[k] for p in parts]) for k in range(4))
+        own = owner_of(pos4[:, :3], self.box, self.layout["layers"], self.world)
+        for r, s in enumerate(self.s):
+            idx = np.nonzero(own == r)[0]
+            s.load_state(tag[idx], pos4[idx], image[idx], mass[idx])
+            s.refresh_force(self.force_dev)
 
     def step(self, kT, dt, timestep, shear_rate=0.0, lanczos_m=2, integrate=True):
         S = self.s
@@ -358,8 +398,23 @@ class LocalShardedSimulation:
         self.force_dev = torch.from_numpy(f4).cuda()
 
     def set_box(self, Lx, Ly, Lz, xy):
+        flip = tilt_flipped(self.box, (Lx, Ly, Lz, xy))
         self.engine.set_box(Lx, Ly, Lz, xy)
         self.box = (Lx, Ly, Lz, xy)
+        if flip:
+            self.redistribute()
+
+    def redistribute(self):
+        """Every particle to the rank that owns it under the CURRENT box (after a tilt flip; see tilt_flipped): an all-gather of the
+        particle state through torch.distributed's default group, on the host -- a flip happens once per unit of strain."""
+        import torch.distributed as dist
+        self.team.local_status()
+        parts = [None] * self.world
+        dist.all_gather_object(parts, self.s.state())
+        tag, pos4, image, mass = (np.concatenate([p[k] for p in parts]) for k in range(4))
+        idx = np.nonzero(owner_of(pos4[:, :3], self.box, self.layout["layers"], self.world) == self.rank)[0]
+        self.s.load_state(tag[idx], pos4[idx], image[idx], mass[idx])
+        self.s.refresh_force(self.force_dev)
 
     def step(self, kT, dt, timestep, shear_rate=0.0, lanczos_m=2, integrate=True):
         s = self.s

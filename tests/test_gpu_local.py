@@ -82,6 +82,42 @@ def test_local_team_with_a_dense_cluster_on_a_slab_face(world):
     assert rel(u, vel.cpu().numpy()[:, :3]) < 1e-9, rel(u, vel.cpu().numpy()[:, :3])
 
 
+def test_local_team_follows_a_tilt_flip():
+    """Steady shear through a Lees-Edwards flip (xy + 0.5 -> - 0.5): the flip re-maps fractional x by fractional y, so every particle
+    may change slab at once -- the simulation classes redistribute (on the host) and the trajectory goes on as the single GPU's."""
+    import torch
+    import pse_amd
+    from pse_amd.sharded import LocalLoopbackSimulation
+    world, n, grid = 4, 30_000, 64
+    xy0, rate, dt, kT = 0.44, 0.1, 0.25, 1.0                       # strain 0.025 per step: the tilt passes + 0.5 in the third step
+    pos, force, box = make_suspension(n, phi=0.1, xy=xy0)
+    kw = _kw(box, grid)
+    sim = LocalLoopbackSimulation(n, box, world, **kw)
+    sim.load(pos, force)
+    ref = pse_amd.Engine(n, box, **kw)
+    dpos, dF = to4(pos), to4(force)
+    vel = to4(np.zeros((n, 3)), 1.0)
+    accel = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+    image = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+    _, m = ref.brownian_velocity(dpos, dF, kT, dt, 99, vel=vel, lanczos_m=2)
+    L, xy, flips = box[0], xy0, 0
+    for k in range(8):
+        mr = ref.step(dpos, vel, accel, image, dF, kT, dt, 100 + k, shear_rate=rate, lanczos_m=m)
+        ml = sim.step(kT, dt, 100 + k, shear_rate=rate, lanczos_m=m)
+        m = mr
+        xy += rate * dt
+        if xy > 0.5:
+            xy -= 1.0; flips += 1
+        ref.set_box(L, L, L, xy); sim.set_box(L, L, L, xy)
+        assert sim.team.local_status() == [0] * world
+    assert flips == 1
+    p, u, im, owner = sim.gather()
+    pr = dpos.cpu().numpy()[:, :3]
+    # (positions of both are wrapped into the cell of the box of their last step; images count the wraps)
+    assert (owner >= 0).all() and np.abs(p - pr).max() < 1e-8, np.abs(p - pr).max()
+    assert (im == image.cpu().numpy()).all()
+
+
 def test_local_team_with_empty_ranks():
     """All particles in the slabs of ranks 0 and 1 of four: rank 2 owns nothing and sees no ghosts on its right, rank 3 owns nothing
     and holds only ghosts (rank 0's first layers, through the periodic face).  Every launch of a step covers capacities, so empty

@@ -281,6 +281,8 @@ def _local_worker(rank, world, port, xy0, n, grid, out):
             dist.broadcast_object_list(box_m, src=0)
             m = box_m[0]
             xy += rate * dt
+            if xy > 0.5:                  # Lees-Edwards flip: every rank redistributes (LocalShardedSimulation.set_box)
+                xy -= 1.0
             sim.set_box(box[0], box[1], box[2], xy)
             if rank == 0:
                 ref.set_box(box[0], box[1], box[2], xy)
@@ -299,7 +301,7 @@ def _local_worker(rank, world, port, xy0, n, grid, out):
             pass
 
 
-@pytest.mark.parametrize("world,xy0,n,grid", [(2, 0.1, 40_000, 96), (4, -0.15, 40_000, 96), (8, 0.0, 80_000, 128)])
+@pytest.mark.parametrize("world,xy0,n,grid", [(2, 0.1, 40_000, 96), (4, -0.15, 40_000, 96), (8, 0.0, 80_000, 128), (3, 0.47, 30_000, 96)])   # (the last: through a tilt flip)
 def test_owned_particle_team_of_processes_follows_single_gpu(world, xy0, n, grid):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")

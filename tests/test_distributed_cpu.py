@@ -250,6 +250,22 @@ def test_owned_particle_layout_helpers():
     assert cap > counts.max() * (per + 4) / per
     # two ranks need four layers each (both ghost zones come from the same neighbour)
     assert host_layers((60.0, 60.0, 60.0, 0.0), 2, xi=0.5, error=1e-3) % 2 == 0
+    # the slabs are co-moving with the strain: an affinely advected particle keeps its layer when the tilt follows ...
+    from pse_amd.sharded import tilt_flipped
+    d_xy = 0.013
+    adv = pos + np.array([1.0, 0.0, 0.0]) * (d_xy * pos[:, 1:2])
+    box2 = (L, L, L, box[3] + d_xy)
+    assert not tilt_flipped(box, box2)
+    assert (x_layer(adv, box2, layers) != lay).mean() < 1e-3          # (rounding at layer faces only)
+    # ... but a Lees-Edwards flip (xy -> xy - 1: b becomes b - a) re-maps fractional x by y / L: most particles change layer,
+    # many by more than a slab -- the owner of the particle data redistributes (the step's one-neighbour migration cannot follow)
+    box3 = (L, L, L, 0.5 - 1.0)
+    assert tilt_flipped((L, L, L, 0.5), box3)
+    lay_a, lay_b = x_layer(pos, (L, L, L, 0.5), layers), x_layer(pos, box3, layers)
+    expect = (lay_a + np.floor(pos[:, 1] / L * layers).astype(np.int64)) % layers          # x - (xy - 1) y = (x - xy y) + y
+    assert (np.abs(((lay_b - expect + layers // 2) % layers) - layers // 2) <= 1).all()
+    hop = np.abs(((lay_b - lay_a + layers // 2) % layers) - layers // 2)
+    assert (hop > layers // world).mean() > 0.5
 
 
 def test_two_step_exchange_message_sizes():

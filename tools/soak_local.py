@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Soak run of an owned-particle team (developer tool): all ranks in one process on one GPU, a few hundred Brownian steps under steady
+shear through several Lees-Edwards flips, next to the single-GPU engine stepping the same suspension with the same noise.  Checks every
+`--every` steps: no device flag, every tag owned exactly once, positions and images equal to the single GPU's, equal Lanczos counts.
+  python3 tools/soak_local.py [--n 1000000] [--grid 256] [--ranks 8] [--steps 300] [--dt 0.01] [--rate 1.0]"""
+import argparse, math, os, sys, time
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=1_000_000); ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--ranks", type=int, default=8); ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--dt", type=float, default=0.01); ap.add_argument("--rate", type=float, default=1.0)
+    ap.add_argument("--phi", type=float, default=0.1); ap.add_argument("--every", type=int, default=25)
+    a = ap.parse_args()
+    import torch
+    from conftest import make_suspension, to4
+    import pse_amd
+    from pse_amd.sharded import LocalLoopbackSimulation
+    n = a.n
+    pos, force, box = make_suspension(n, phi=a.phi)
+    L = box[0]
+    xi = math.pi * a.grid / (2.0 * L * math.sqrt(-math.log(1e-3)))
+    kw = dict(xi=xi, error=1e-3, seed=3, grid=(a.grid,) * 3)
+    sim = LocalLoopbackSimulation(n, box, a.ranks, **kw)
+    sim.load(pos, force)
+    ref = pse_amd.Engine(n, box, **kw)
+    dpos, dF, vel = to4(pos), to4(force), to4(np.zeros((n, 3)), 1.0)
+    accel = torch.zeros((n, 3), dtype=torch.float64, device="cuda"); image = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+    kT = 1.0
+    _, m = ref.brownian_velocity(dpos, dF, kT, a.dt, 0, vel=to4(np.zeros((n, 3)), 1.0), lanczos_m=2)
+    xy, flips, worst, t0 = 0.0, 0, 0.0, time.time()
+    own_prev = None
+    migrated = 0
+    for k in range(a.steps):
+        mr = ref.step(dpos, vel, accel, image, dF, kT, a.dt, 1 + k, shear_rate=a.rate, lanczos_m=m)
+        sim.step(kT, a.dt, 1 + k, shear_rate=a.rate, lanczos_m=m)
+        m = mr
+        xy += a.rate * a.dt
+        if xy > 0.5:
+            xy -= 1.0; flips += 1
+        ref.set_box(L, L, L, xy); sim.set_box(L, L, L, xy)
+        if (k + 1) % a.every == 0 or k == a.steps - 1:
+            flags = sim.team.local_status()
+            assert flags == [0] * a.ranks, flags
+            p, u, im, owner = sim.gather()
+            assert (owner >= 0).all(), "a particle is owned by no rank"
+            assert sum(int(s.n_local.item()) for s in sim.s) == n, "a particle is owned twice"
+            ms = [e.info()["lanczos_m"] for e in sim.engines]
+            assert all(x == mr for x in ms) and all(e.info()["lanczos_status"] == 0 for e in sim.engines), (ms, mr)
+            err = float(np.abs(p - dpos.cpu().numpy()[:, :3]).max())
+            worst = max(worst, err)
+            assert err < 1e-6, err
+            assert (im == image.cpu().numpy()).all()
+            if own_prev is not None:
+                migrated += int((owner != own_prev).sum())
+            own_prev = owner
+            print(f"step {k + 1}: xy {xy:+.3f} flips {flips} m {mr} max |dx| vs single GPU {err:.2e} owners changed since last check {migrated}", flush=True)
+    print(f"{a.steps} steps of {a.ranks} ranks, {flips} flips, worst position difference {worst:.2e}, {time.time() - t0:.1f} s: ok")
+
+
+if __name__ == "__main__":
+    main()

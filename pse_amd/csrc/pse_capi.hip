@@ -703,6 +703,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
                 "--- engine ---\ncells: %d x %d x %d, ranks: %d (far-field slabs %d), device memory: %.2f GB\n",
                 d.Nx, d.Ny, d.Nz, d.rcut, d.Nx / h->box.Lx, d.Ny / h->box.Ly, d.Nz / h->box.Lz, d.gaussm, d.P, d.eta,
                 d.P * d.hx / 2.0, d.hx, d.hy, d.hz, h->nc.nx, h->nc.ny, h->nc.nz, h->n_slabs, h->grid_slabs, h->bytes / 1e9);
+        fprintf(stderr, "grids at: real %p, spectra %p\n", (void *)h->rgrid, (void *)h->cgrid);   // (the x pass at 512^3 has two speeds that go with the allocation: tools/debug/mode_probe.py)
     }
     return 0;
 }

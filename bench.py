@@ -190,6 +190,13 @@ def run_owned_particle_team(args, world, rank, host_transport, dist, torch):
     sim = LocalShardedSimulation(n, box, world, rank, transport="host" if host_transport else "rccl", xi=xi, error=args.error, seed=1,
                                  grid=(grid,) * 3)
     sim.load(pos, force, mass=1.0)
+    # Before anything is timed: a few steps of the team next to the single-GPU engine on rank 0 (same suspension, same noise) -- the
+    # first run on a multi-GPU node then says whether the exchanges moved the right bytes, not only how long they took.
+    verify = None
+    if not args.no_verify:
+        verify = verify_team_against_single_gpu(sim, pos, force, box, dict(xi=xi, error=args.error, seed=1, grid=(grid,) * 3), args, world, rank,
+                                                dist, torch)
+        sim.load(pos, force, mass=1.0)
 
     def barrier():
         dist.barrier()
@@ -269,9 +276,59 @@ def run_owned_particle_team(args, world, rank, host_transport, dist, torch):
         "exchange_bytes": d["exchange_bytes"],
         "lanes_ms": {k: round(float(np.median([x["lanes_ms"][k] for x in diags])), 4) for k in ("main", "side")},
         "critical_path_ms": round(float(np.median([x["critical_path_ms"] for x in diags])), 4),
+        "verify": verify,
         "roofline": None, "cpu_baseline": None,
     }
     print(json.dumps(out))
+
+
+def verify_team_against_single_gpu(sim, pos, force, box, kw, args, world, rank, dist, torch, steps=3):
+    """`steps` Brownian steps of the owned-particle team and of a single-GPU engine on rank 0's device, from the same suspension with the
+    same noise: largest position difference, images and Lanczos counts.  Untimed; the engine is released before the bench goes on."""
+    import pse_amd
+    n = len(pos)
+    dt = 0.05                                    # large steps: particles cross slab faces within the check
+    if rank == 0:
+        ref = pse_amd.Engine(n, box, **kw)
+        to4 = lambda a, w=0.0: torch.tensor(np.hstack([a, np.full((len(a), 1), w)]), dtype=torch.float64, device="cuda")   # noqa: E731
+        dpos, dF, vel = to4(pos), to4(force), to4(np.zeros((n, 3)), 1.0)
+        accel = torch.zeros((n, 3), dtype=torch.float64, device="cuda"); image = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+        _, m0 = ref.brownian_velocity(dpos, dF, args.kT, dt, 999, vel=to4(np.zeros((n, 3)), 1.0), lanczos_m=2)
+    box_m = [m0 if rank == 0 else None]
+    dist.broadcast_object_list(box_m, src=0)
+    m = box_m[0]
+    worst, images_equal, m_equal, status_ok, migrated = 0.0, True, True, True, 0
+    own0 = None
+    for k in range(steps):
+        sim.step(args.kT, dt, 1000 + k, lanczos_m=m)
+        tg, p, _, im = sim.gather_local()
+        info = sim.engine.info()
+        got = [None] * world if rank == 0 else None
+        dist.gather_object((tg, p, im, info["lanczos_m"], info["lanczos_status"]), got, dst=0)
+        if rank == 0:
+            mr = ref.step(dpos, vel, accel, image, dF, args.kT, dt, 1000 + k, lanczos_m=m)
+            P, IM, owner = np.full((n, 3), np.nan), np.zeros((n, 3), dtype=np.int64), np.full(n, -1)
+            for r, (t_, p_, im_, m_, st_) in enumerate(got):
+                P[t_] = p_; IM[t_] = im_; owner[t_] = r
+                m_equal = m_equal and m_ == mr
+                status_ok = status_ok and st_ == 0
+            diff = np.abs(P - dpos.cpu().numpy()[:, :3])
+            worst = float("nan") if (owner < 0).any() else max(worst, float(diff.max()))
+            images_equal = images_equal and bool(np.array_equal(IM, image.cpu().numpy()))
+            if own0 is not None:
+                migrated += int((owner != own0).sum())
+            own0 = owner
+            m = mr
+        box_m = [m if rank == 0 else None]
+        dist.broadcast_object_list(box_m, src=0)
+        m = box_m[0]
+    if rank != 0:
+        return None
+    del ref
+    torch.cuda.empty_cache()
+    return {"steps": steps, "dt": dt, "max_abs_position_diff_vs_single_gpu": worst, "images_equal": images_equal, "lanczos_m_equal": m_equal,
+            "lanczos_status_zero": status_ok, "particles_that_changed_rank": migrated,
+            "ok": bool(worst < 1e-8 and images_equal and m_equal and status_ok)}
 
 
 def main():
@@ -297,6 +354,8 @@ def main():
     ap.add_argument("--replicated", action="store_true",
                     help="multi-rank runs: the replicated-state team calls (every rank passes all N particles) instead of the "
                          "owned-particle step (pse_team_step_local), which is the default")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="multi-rank runs: skip the three untimed steps next to a single-GPU engine on rank 0 (the `verify` object of the line)")
     ap.add_argument("--dry-run", action="store_true", help="with --gpus N > 1: print the launch command and stop")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

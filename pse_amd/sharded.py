@@ -258,6 +258,8 @@ class _LocalState:
         n = len(idx)
         if n > self.cap:
             raise ValueError(f"{n} particles for a rank whose arrays hold {self.cap}")
+        for t in (self.pos, self.vel, self.force, self.accel, self.image):     # (a re-load starts from a clean state: images, velocities)
+            t.zero_()
         self.pos[:n, :3] = torch.from_numpy(np.ascontiguousarray(pos[idx])).cuda()
         self.force[:n, :3] = torch.from_numpy(np.ascontiguousarray(force[idx])).cuda()
         self.vel[:n, 3] = mass

@@ -144,6 +144,10 @@ def test_bench_launches_its_own_ranks():
     assert all(t > 0 for v in d["exchange_us"].values() for t in v)
     assert d["critical_path_ms"] > 0 and d["lanes_ms"]["main"] > 0 and d["lanes_ms"]["side"] > 0
     assert d["lanczos_status"] == 0 and d["particles_owned_sum"] == 100000 and d["device_flags"] == [0]
+    # ... and its verdict on correctness: three untimed steps next to a single-GPU engine on rank 0
+    v = d["verify"]
+    assert v["ok"] and v["steps"] == 3 and v["max_abs_position_diff_vs_single_gpu"] < 1e-8 and v["images_equal"] and v["lanczos_m_equal"], v
+    assert v["particles_that_changed_rank"] > 0, v
 
 
 def test_bench_as_ranks_of_torch_distributed_run():

@@ -279,6 +279,8 @@ def run_owned_particle_team(args, world, rank, host_transport, dist, torch):
         "verify": verify,
         "roofline": None, "cpu_baseline": None,
     }
+    if verify is not None and not verify["ok"]:
+        print(f"bench.py: the team's trajectory differs from the single GPU's: {verify}", file=sys.stderr)
     print(json.dumps(out))
 
 

@@ -330,7 +330,9 @@ def verify_team_against_single_gpu(sim, pos, force, box, kw, args, world, rank, 
     torch.cuda.empty_cache()
     return {"steps": steps, "dt": dt, "max_abs_position_diff_vs_single_gpu": worst, "images_equal": images_equal, "lanczos_m_equal": m_equal,
             "lanczos_status_zero": status_ok, "particles_that_changed_rank": migrated,
-            "ok": bool(worst < 1e-8 and images_equal and m_equal and status_ok)}
+            # (1e-7, not 1e-9: the pair coefficients of the Lanczos mat-vecs are single precision, and a coefficient that rounds the other way
+            # in one of the two runs moves a particle by ~1e-8 dt -- tests/conftest.py TRAJ_TOL_BROWNIAN has the mechanism)
+            "ok": bool(worst < 1e-7 and images_equal and m_equal and status_ok)}
 
 
 def main():

@@ -293,8 +293,29 @@ int pse_oracle_mobility_dense(int N, const double *pos, const double *box, doubl
 /* real-space part truncated at rcut with minimum image only -- exactly the sum the product's
  * near-field kernel performs (PSEv1/Mobility.cu:594-687: pairs with r < rcut, self term), but with
  * the closed-form functions instead of a table. Requires rcut <= half the shortest box width. */
-int pse_oracle_mreal_cutoff(int N, const double *pos, const double *force, const double *box,
-                            double xi, double rcut, double *vel, int nthreads) {
+/* One pair's term of the near-field sum.  f32 == 0: f F + (g - f) (r.F) r / r^2 in double precision.  f32 != 0: the term as the
+ * build's Lanczos mat-vecs apply it (pse_amd/csrc/pse_kernels.hip, nb_store: the per-step pair list carries single-precision pair
+ * coefficients): fr = (float) f, s = (float)(r sqrt|h|) with h = (g - f) / r^2 and the root taken in single precision, term
+ * fr F + sgn(h) (s.F) s accumulated in double precision.  The reference's own pair coefficients are single precision throughout
+ * (PSEv1/Mobility.cu:661-677 with Scalar = float); this restates the build's rounding so that M_real^{1/2} psi can be compared
+ * at 1e-9 instead of 1e-7. */
+static void pair_term(const double r[3], double r2, double f, double g, const double *F, int f32, double u[3]) {
+    if (!f32) {
+        double rdF = (r[0] * F[0] + r[1] * F[1] + r[2] * F[2]) / r2;
+        for (int p = 0; p < 3; ++p) u[p] += f * F[p] + (g - f) * rdF * r[p];
+        return;
+    }
+    double h = (g - f) / r2;
+    double hs = (double)sqrtf((float)fabs(h));
+    double fr = (double)(float)f, s[3];
+    for (int p = 0; p < 3; ++p) s[p] = (double)(float)(r[p] * hs);
+    double sd = s[0] * F[0] + s[1] * F[1] + s[2] * F[2];
+    if (h < 0.0) sd = -sd;
+    for (int p = 0; p < 3; ++p) u[p] += fr * F[p] + sd * s[p];
+}
+
+static int mreal_cutoff(int N, const double *pos, const double *force, const double *box,
+                        double xi, double rcut, double *vel, int nthreads, int f32) {
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
@@ -317,13 +338,21 @@ int pse_oracle_mreal_cutoff(int N, const double *pos, const double *force, const
             }
             if (b2 >= rcut * rcut || b2 == 0.0) continue;
             double f, g; pse_oracle_fg_real(sqrt(b2), xi, &f, &g);
-            const double *F = force + 3 * j;
-            double rdF = (best[0] * F[0] + best[1] * F[1] + best[2] * F[2]) / b2;
-            for (int p = 0; p < 3; ++p) u[p] += f * F[p] + (g - f) * rdF * best[p];
+            pair_term(best, b2, f, g, force + 3 * j, f32, u);
         }
         vel[3 * i] = u[0]; vel[3 * i + 1] = u[1]; vel[3 * i + 2] = u[2];
     }
     return 0;
+}
+
+int pse_oracle_mreal_cutoff(int N, const double *pos, const double *force, const double *box,
+                            double xi, double rcut, double *vel, int nthreads) {
+    return mreal_cutoff(N, pos, force, box, xi, rcut, vel, nthreads, 0);
+}
+/* the same sum with the single-precision pair coefficients of the build's Lanczos mat-vecs (pair_term) */
+int pse_oracle_mreal_cutoff_f32(int N, const double *pos, const double *force, const double *box,
+                                double xi, double rcut, double *vel, int nthreads) {
+    return mreal_cutoff(N, pos, force, box, xi, rcut, vel, nthreads, 1);
 }
 
 int pse_oracle_max_threads(void) {

@@ -140,7 +140,7 @@ struct pse_handle {
     int *gate_word = nullptr;   // (cnt_block): flags[0] | flags[1] of this call, read by the kernels of both chains
     size_t n_cells_alloc = 0;
     float4 *posf_s = nullptr;   // single-precision copy of pos_s (cutoff pre-filter of the near field)
-    double2 *pv = nullptr;      // [N][3] packed (position, Lanczos vector) records gathered by the pair-list mat-vec (single GPU)
+    double2 *pv = nullptr;      // [N][3] packed (position, force) records gathered by the drain of the near-field passes
     double4 *pos_s = nullptr, *f_s = nullptr, *uw_s = nullptr, *ur_s = nullptr, *ub_s = nullptr, *psi_s = nullptr, *w_s = nullptr;
     // real-space table
     double *coef = nullptr;
@@ -159,7 +159,6 @@ struct pse_handle {
     std::vector<int> first2_end, last2_begin;                // ... and its first / last TWO cell layers (two-step Lanczos of a team)
     double4 *w2_s = nullptr, *u_s = nullptr;                 // two-step Lanczos: w2 = M M v_j, u = M v_{j-1}
     double *sums_all = nullptr;                              // [n_slabs][LZ_NGRAM]: every rank's partial Lanczos sums (they travel with the ghost rows)
-    double2 *pv2 = nullptr;                                  // second set of packed (position, vector) records: holds w1 = M v_j
     double4 *utot_s = nullptr;                               // slab mode: summed velocity of the own rows, all-gathered
     bool xfuse = false;                                      // power-of-two Nx: fused x pass (k_xfft_scale)
     bool own_y = false;                                      // y transforms by k_fft_cols, rocFFT does the z transforms only
@@ -311,7 +310,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
     void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cnt_block, h->sw.rec_t, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->nb.data, h->nb.cnt, h->vl.idx, h->vl.cnt, h->pos_build, h->pos_s, h->posf_s, h->pv,
-                    h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->w2_s, h->u_s, h->pv2, h->sums_all, h->twiddle, h->twiddle_y_owned, h->twiddle_z_owned, h->fft_work, h->V,
+                    h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->w2_s, h->u_s, h->sums_all, h->twiddle, h->twiddle_y_owned, h->twiddle_z_owned, h->fft_work, h->V,
                     h->scal, h->partials, h->lz_state};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &p : h->ph) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
@@ -602,7 +601,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         }
     }
     TRY(dmalloc(h, &h->pos_s, n)); TRY(dmalloc(h, &h->posf_s, n));
-    TRY(dmalloc(h, &h->pv, 3 * n));   // pair-list mat-vec: packed gather records (slab ranks too: the update packs the own and the ghost rows)
+    TRY(dmalloc(h, &h->pv, 3 * n));   // packed (position, force) records of the near-field passes
     TRY(dmalloc(h, &h->f_s, n)); TRY(dmalloc(h, &h->uw_s, n)); TRY(dmalloc(h, &h->ur_s, n));
     TRY(dmalloc(h, &h->ub_s, n)); TRY(dmalloc(h, &h->psi_s, n)); TRY(dmalloc(h, &h->w_s, n));
 
@@ -618,7 +617,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         TRY(dmalloc(h, &h->utot_s, n));
         TRY(dmalloc(h, &h->sums_all, (size_t)h->n_slabs * LZ_NGRAM));
         if (h->tun.team_sstep && h->nb.cap > 0) {
-            TRY(dmalloc(h, &h->w2_s, n)); TRY(dmalloc(h, &h->u_s, n)); TRY(dmalloc(h, &h->pv2, 3 * n));
+            TRY(dmalloc(h, &h->w2_s, n)); TRY(dmalloc(h, &h->u_s, n));
         }
     }
     if (h->loc.on) {
@@ -1248,14 +1247,14 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
         const int ncell = cells_total(h->nc);
         HIPCHK(hipMemsetAsync(h->cnt_block, 0, h->cnt_bins * sizeof(int), h->stream));   // bin counts + flags[0]
         launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream,
-                       h->pos_build, 0.25 * h->skin * h->skin, h->vl.flags, CellRanges{}, nullptr, nullptr, &far, nullptr, 0, 0);
+                       h->pos_build, 0.25 * h->skin * h->skin, h->vl.flags, CellRanges{}, nullptr, &far, nullptr, 0, 0);
         launch_gate_decide(h->vl.flags, h->gate_word, h->stream);
         const Gate rb{h->gate_word, 1};
         launch_gate_zero(rb, h->cnt_block, h->cnt_bins - 1, h->cell_cnt, (size_t)ncell + 1, h->stream);   // (not the flags)
         HIPCHK(cell_sort(pos, group, N, h->dbox, h->nc, h->keys, h->vals, h->keys_s, h->cell_cnt, ncell, h->sort_tmp, h->sort_tmp_bytes,
                          h->cell_off, h->perm, h->stream, CellRanges{}, SlabBook{}, true, rb));
         launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream, nullptr, 0.0, nullptr,
-                       CellRanges{}, h->cell_off, nullptr, &far, nullptr, 0, 0, rb);
+                       CellRanges{}, h->cell_off, &far, nullptr, 0, 0, rb);
         h->gated = true;
         h->vl.rskin = h->d.rcut + h->skin;
         h->sw.need = CellRanges{}; h->sw.cell_off = h->cell_off;
@@ -1267,7 +1266,7 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
     if (h->skin > 0.0 && !h->async_mode && h->vl_valid && !need_cells && h->vl_N == N && h->vl_group == group && same_box && h->sorted_N == N) {
         HIPCHK(hipMemsetAsync(h->cnt_block, 0, h->cnt_bins * sizeof(int), h->stream));   // bin counts + flags[0] ([1] is the build's overflow mark)
         launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream,
-                       h->pos_build, 0.25 * h->skin * h->skin, h->vl.flags, CellRanges{}, nullptr, nullptr, &far, psi_out, h->par.seed, px.timestep, Gate{}, h->ts_off);
+                       h->pos_build, 0.25 * h->skin * h->skin, h->vl.flags, CellRanges{}, nullptr, &far, psi_out, h->par.seed, px.timestep, Gate{}, h->ts_off);
         HIPCHK(hipMemcpyAsync(h->flags_host, h->vl.flags, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->flags_host[0] == 0 && h->flags_host[1] == 0) {
@@ -1321,7 +1320,7 @@ static int prepare(pse_handle *h, const double4 *pos, const double4 *vec, const 
     HIPCHK(cell_sort(pos, group, N, h->dbox, h->nc, h->keys, h->vals, h->keys_s, h->cell_cnt, ncell, h->sort_tmp, h->sort_tmp_bytes,
                      h->cell_off, h->perm, h->stream, need, sb, true));
     launch_permute(pos, vec, group, h->perm, N, h->dbox, h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->stream, nullptr, 0.0, nullptr,
-                   need, h->cell_off, team_sstep(h) ? h->pv2 : nullptr, &far, psi_out, h->par.seed, px.timestep, Gate{}, h->ts_off);
+                   need, h->cell_off, &far, psi_out, h->par.seed, px.timestep, Gate{}, h->ts_off);
     h->sorted_N = N;
     if (with_list) {   // the first cell pass of this call writes the list (real())
         h->vl_pending = true; h->vl_N = N; h->vl_group = group;
@@ -1535,11 +1534,11 @@ static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*ou
             const int nco = h->n_intervals * 2 * RS_NCOEF;
             const Gate rb{h->gate_word, 1}, ru{h->gate_word, 0};
             launch_mreal(h->pos_s, h->posf_s, v, h->*out + out_off, rows, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, nco,
-                         h->nb, MREAL_CELLS, h->stream, nullptr, nullptr, h->vl, VL_WRITE, nullptr, nullptr, nullptr, 0, nullptr, rb);
+                         h->nb, MREAL_CELLS, h->stream, nullptr, nullptr, h->vl, VL_WRITE, nullptr, nullptr, 0, nullptr, rb);
             launch_gate_copy(rb, h->pos_build, h->pos_s, (size_t)N, h->stream);
             launch_mreal(h->pos_s, h->posf_s, v, h->*out + out_off, rows, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, nco,
                          h->nb, MREAL_CELLS, h->stream, nullptr, nullptr, h->vl, VL_USE,
-                         v == h->f_s && h->pv_is_f ? h->pv : nullptr, nullptr, nullptr, 0, nullptr, ru);
+                         v == h->f_s && h->pv_is_f ? h->pv : nullptr, nullptr, 0, nullptr, ru);
             h->vl_valid = true; h->vl_box = h->box;
             continue;
         }
@@ -1548,7 +1547,6 @@ static int real(pse_team &T, double4 *pse_handle::*vec, double4 *pse_handle::*ou
                      h->nc, h->d.rcut, h->d.self, h->coef, h->n_intervals * 2 * RS_NCOEF, h->nb, mode, h->stream,
                      psi ? h->psi_s : nullptr, h->w_s, h->vl, vlm,
                      v == h->f_s && h->pv_is_f && (vlm == VL_USE || mode != MREAL_USE_LIST) ? h->pv : nullptr,   // packed (position, F) records
-                     psi && depth > 0 ? h->pv2 : nullptr,    // two-step Lanczos: the next mat-vec gathers w = M psi from the second records
                      psi && h->n_slabs == 1 ? h->partials : nullptr, h->npart_cap, h->scal);   // single GPU: + the sums of Lanczos iteration 0
         h->sums0_done = psi && h->n_slabs == 1 && vlm != VL_USE && mreal_table_in_lds(h->n_intervals * 2 * RS_NCOEF);
         if (vlm == VL_WRITE) {   // the list now matches perm, pos_s and the box of this call
@@ -1585,9 +1583,8 @@ static int lanczos_queued(pse_team &T, int N, double tol, double scale, int *m_i
     auto vec = [&](int q) -> const double4 * { return q == 0 ? h->psi_s : h->V + (size_t)q * stride; };
     // the vector part of iteration j: x_{j+1} from the sums that are still in place
     auto vector_part = [&](int j, const int *gate) {
-        launch_lz_update(vec(j), h->w_s, j > 0 ? vec(j - 1) : nullptr, h->V + (size_t)(j + 1) * stride, j, h->scal, rg, nrg_all, h->stream, h->pv,
+        launch_lz_update(vec(j), h->w_s, j > 0 ? vec(j - 1) : nullptr, h->V + (size_t)(j + 1) * stride, j, h->scal, rg, nrg_all, h->stream,
                          nullptr, 0, h->sc_host_dev, gate);
-        h->pv_is_f = false;
     };
     auto iteration = [&](int j, bool scalars_only, const int *gate) -> int {
         const bool have_y = j == 0 && h->w_is_mpsi;
@@ -1600,11 +1597,11 @@ static int lanczos_queued(pse_team &T, int N, double tol, double scale, int *m_i
         if (fused)
             launch_mreal_lanczos(h->pos_s, vec(j), h->w_s, row_map(0, N), h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, h->nb,
                                  LzFuse{vjm1, h->partials, h->npart_cap, nullptr, nullptr, nullptr}, h->scal, nullptr, nullptr, h->stream,
-                                 j > 0 ? h->pv : nullptr, h->vl_use ? h->vl : VerletList{}, 1, nullptr, gate);
+                                 h->vl_use ? h->vl : VerletList{}, 1, gate);
         else if (!(j == 0 && h->sums0_done))
             launch_lz_dots(vec(j), h->w_s, vjm1, 0, N, h->partials, h->npart_cap, h->scal, h->stream);
         h->w_is_mpsi = false; h->sums0_done = false;
-        if (scalars_only) launch_lz_update(vec(j), h->w_s, vjm1, h->V + (size_t)(j + 1) * stride, j, h->scal, rg, 0, h->stream, h->pv, nullptr, 0,
+        if (scalars_only) launch_lz_update(vec(j), h->w_s, vjm1, h->V + (size_t)(j + 1) * stride, j, h->scal, rg, 0, h->stream, nullptr, 0,
                                            h->sc_host_dev, gate);
         else vector_part(j, gate);
         return 0;
@@ -1671,7 +1668,6 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
                     launch_mreal_lanczos(h->pos_s, xj, h->w_s, row_map(lo, hi), h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef,
                                          h->nb, LzFuse{vjm1, h->partials, h->npart_cap, nullptr, nullptr, nullptr}, h->scal,
                                          ev ? h->ph[PH_MATVEC].a : nullptr, ev ? h->ph[PH_MATVEC].b : nullptr, h->stream,
-                                         done > 0 ? h->pv : nullptr,   // x_j (j > 0) was packed by the previous update
                                          h->vl_use ? h->vl : VerletList{});
                     if (timed) h->matvec_timed = true;
                 } else if (!(done == 0 && h->sums0_done)) {   // (iteration 0: the sums came with the pass that built the pair list)
@@ -1693,8 +1689,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
                 const int nrg = scalars_only ? 0 : update_ranges(h, N, rg);
                 const double4 *xj = done == 0 ? h->psi_s : h->V + (size_t)done * stride;
                 launch_lz_update(xj, h->w_s, done > 1 ? h->V + (size_t)(done - 1) * stride : (done == 1 ? h->psi_s : nullptr),
-                                 h->V + (size_t)(done + 1) * stride, done, h->scal, rg, nrg, h->stream, h->pv, h->sums_all, T.G > 1 ? T.G : 0, h == h0 ? h->sc_host_dev : nullptr);
-                if (!scalars_only) h->pv_is_f = false;   // the vector half of pv now holds x_{j+1}
+                                 h->V + (size_t)(done + 1) * stride, done, h->scal, rg, nrg, h->stream, h->sums_all, T.G > 1 ? T.G : 0, h == h0 ? h->sc_host_dev : nullptr);
             }
         }
         // (alpha, beta and the norm are already on their way: the update kernels write them to the mapped host buffer as well)
@@ -1745,8 +1740,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
             const int j = done - 1;
             const double4 *xj = j == 0 ? h->psi_s : h->V + (size_t)j * stride;
             launch_lz_update(xj, h->w_s, j > 1 ? h->V + (size_t)(j - 1) * stride : (j == 1 ? h->psi_s : nullptr),
-                             h->V + (size_t)(j + 1) * stride, j, h->scal, rg, nrg, h->stream, h->pv, h->sums_all, T.G > 1 ? T.G : 0, h == h0 ? h->sc_host_dev : nullptr);
-            h->pv_is_f = false;
+                             h->V + (size_t)(j + 1) * stride, j, h->scal, rg, nrg, h->stream, h->sums_all, T.G > 1 ? T.G : 0, h == h0 ? h->sc_host_dev : nullptr);
         }
         pending_beta = done;
         target = std::min(M_MAX, done + std::max(2, done / 4));
@@ -1793,7 +1787,7 @@ static int lanczos_team(pse_team &T, int N, double tol, double scale, int *m_io,
         LzBlockArgs a{};
         a.q = vec(h, j); a.p = j > 0 ? vec(h, j - 1) : nullptr; a.w1 = h->w_s; a.w2 = full ? h->w2_s : nullptr;
         a.u = h->u_s; a.v1 = h->V + (size_t)(j + 1) * stride; a.v2 = full ? h->V + (size_t)(j + 2) * stride : nullptr;
-        a.pv = h->pv; a.j = j;
+        a.j = j;
         return a;
     };
     while (true) {
@@ -1813,8 +1807,7 @@ static int lanczos_team(pse_team &T, int N, double tol, double scale, int *m_io,
                 if (j == 0 && !h->w_is_mpsi) return fail(PSE_ERR_NUMERIC, "two-step Lanczos: M psi did not come with the pair list");
                 if (!(j == 0 && h->w_is_mpsi)) {   // w1 = M v_j: own rows + one ghost layer for a block, own rows for a single step
                     launch_mreal_lanczos(h->pos_s, vec(h, j), h->w_s, rank_rows(h, N, full ? 1 : 0), h->cell_off, h->dbox, h->nc, h->d.rcut,
-                                         h->d.self, h->coef, h->nb, lz, h->scal, nullptr, nullptr, h->stream, h->pv, VerletList{},
-                                         full ? 0 : 3, full ? h->pv2 : nullptr);
+                                         h->d.self, h->coef, h->nb, lz, h->scal, nullptr, nullptr, h->stream, VerletList{}, full ? 0 : 3);
                     ++matvecs;
                 } else if (!full) {
                     return fail(PSE_ERR_NUMERIC, "two-step Lanczos: a single step cannot start at j = 0");
@@ -1822,7 +1815,7 @@ static int lanczos_team(pse_team &T, int N, double tol, double scale, int *m_io,
                 h->w_is_mpsi = false;
                 if (full) {                        // w2 = M w1 on the own rows, Gram sums fused
                     launch_mreal_lanczos(h->pos_s, h->w_s, h->w2_s, rank_rows(h, N, 0), h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self,
-                                         h->coef, h->nb, lz, h->scal, nullptr, nullptr, h->stream, h->pv2, VerletList{}, 2, nullptr);
+                                         h->coef, h->nb, lz, h->scal, nullptr, nullptr, h->stream, VerletList{}, 2);
                     ++matvecs;
                 }
             }
@@ -2122,7 +2115,7 @@ static int lanczos_local(pse_team &T, double tol, int *m_io, WavePump *pump) {
         LzBlockArgs a{};
         a.q = vec(h, j); a.p = j > 0 ? vec(h, j - 1) : nullptr; a.w1 = h->w_s; a.w2 = full ? h->w2_s : nullptr;
         a.u = h->u_s; a.v1 = h->V + (size_t)(j + 1) * stride; a.v2 = full ? h->V + (size_t)(j + 2) * stride : nullptr;
-        a.pv = h->pv; a.j = j;
+        a.j = j;
         return a;
     };
     auto fuse = [&](pse_handle *h, int j) { return LzFuse{nullptr, h->partials, h->npart_cap, vec(h, j), j > 0 ? vec(h, j - 1) : nullptr, j > 0 ? h->u_s : nullptr}; };
@@ -2152,14 +2145,14 @@ static int lanczos_local(pse_team &T, double tol, int *m_io, WavePump *pump) {
                 if (!h->w_is_mpsi) return fail(PSE_ERR_NUMERIC, "owned-particle step: M psi did not come with the pair list");
             } else {   // w1 = M v_j on the own rows + the adjacent ghost layers
                 launch_mreal_lanczos(h->pos_s, vec(h, j), h->w_s, RowMap{}, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, h->nb, fuse(h, j),
-                                     h->scal, nullptr, nullptr, h->stream, h->pv, VerletList{}, 0, h->pv2, gate,
+                                     h->scal, nullptr, nullptr, h->stream, VerletList{}, 0, gate,
                                      DevRowArgs{&R->own1, R, h->loc.stage_w1, h->loc.rows_cap});
                 ++matvecs;
             }
             h->w_is_mpsi = false;
             // w2 = M w1 on the own rows, Gram sums fused
             launch_mreal_lanczos(h->pos_s, h->w_s, h->w2_s, RowMap{}, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, h->nb, fuse(h, j), h->scal,
-                                 nullptr, nullptr, h->stream, h->pv2, VerletList{}, 2, nullptr, gate, DevRowArgs{&R->own, R, h->loc.stage_w2, h->loc.g.c_own});
+                                 nullptr, nullptr, h->stream, VerletList{}, 2, gate, DevRowArgs{&R->own, R, h->loc.stage_w2, h->loc.g.c_own});
             ++matvecs;
         }
         TRY(exchange(true));
@@ -2172,7 +2165,7 @@ static int lanczos_local(pse_team &T, double tol, int *m_io, WavePump *pump) {
         for (pse_handle *h : act(T)) {
             const LocalRows *R = h->loc.rows;
             launch_mreal_lanczos(h->pos_s, vec(h, j), h->w_s, RowMap{}, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, h->nb, fuse(h, j), h->scal,
-                                 nullptr, nullptr, h->stream, h->pv, VerletList{}, 3, nullptr, gated ? &h->lz_state->done : nullptr,
+                                 nullptr, nullptr, h->stream, VerletList{}, 3, gated ? &h->lz_state->done : nullptr,
                                  DevRowArgs{&R->own, R, h->loc.stage_w1, h->loc.g.c_own});
             ++matvecs;
         }
@@ -2279,7 +2272,7 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
         const LocalRegions rg = local_regions(h);
         launch_local_scatter(h->loc.raw, h->cell_off, h->loc.g, rg, pool, h->vals, h->loc.rows, h->loc.err, h->stream);
         const FarBinArgs far = far_bin_args(h->G, h->sw);
-        const LocalSorted out{h->pos_s, h->posf_s, h->pv, h->pv2, h->f_s, h->tag_s, h->loc.porig_s, h->loc.mass_s, h->loc.image_s, noise ? h->psi_s : nullptr};
+        const LocalSorted out{h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->loc.porig_s, h->loc.mass_s, h->loc.image_s, noise ? h->psi_s : nullptr};
         launch_local_permute(ca[r], h->loc.recv[0], h->loc.recv[1], h->loc.g, h->dbox, h->cell_off, pool, h->vals, h->loc.rows, out, &far, h->par.seed,
                              timestep, h->ts_off, h->stream);
         h->sorted_N = 0; h->nb_valid = false; h->vl_valid = false; h->w_is_mpsi = false; h->pv_is_f = true;
@@ -2301,11 +2294,11 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
         const int nco = h->n_intervals * 2 * RS_NCOEF;
         if (noise)   // the pass that builds the pair list applies M_real to F and psi together, on the own rows + the adjacent ghost layers
             launch_mreal(h->pos_s, h->posf_s, h->f_s, h->ur_s, RowMap{}, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, nco, h->nb,
-                         MREAL_BUILD_LIST, h->stream, h->psi_s, h->w_s, VerletList{}, VL_NONE, h->pv, h->pv2, nullptr, 0, nullptr, Gate{},
+                         MREAL_BUILD_LIST, h->stream, h->psi_s, h->w_s, VerletList{}, VL_NONE, h->pv, nullptr, 0, nullptr, Gate{},
                          DevRowArgs{&R->own1, R, h->loc.stage_w1, h->loc.rows_cap});
         else
             launch_mreal(h->pos_s, h->posf_s, h->f_s, h->ur_s, RowMap{}, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, nco, h->nb,
-                         MREAL_CELLS, h->stream, nullptr, nullptr, VerletList{}, VL_NONE, h->pv, nullptr, nullptr, 0, nullptr, Gate{},
+                         MREAL_CELLS, h->stream, nullptr, nullptr, VerletList{}, VL_NONE, h->pv, nullptr, 0, nullptr, Gate{},
                          DevRowArgs{&R->own, R, nullptr, h->loc.g.c_own});
         h->nb_valid = noise; h->w_is_mpsi = noise;
     }

@@ -119,7 +119,6 @@ void launch_permute(const double4 *pos, const double4 *vec, const unsigned *grou
                     double4 *pos_s, float4 *posf_s, double2 *pv, double4 *vec_s, unsigned *tag_s, hipStream_t s,
                     const double4 *pos_build = nullptr, double half_skin2 = 0.0, int *flags = nullptr,
                     CellRanges need = CellRanges{}, const int *cell_off = nullptr,    // a slab rank: the needed rows only
-                    double2 *pv2 = nullptr,                                           // second set of packed records (position half)
                     const struct FarBinArgs *far = nullptr,                           // rank the particles in their far-field bins
                     double4 *psi_s = nullptr, uint32_t seed = 0, uint32_t timestep = 0,    // draw the particle noise of this step (K14)
                     Gate gate = Gate{}, const uint32_t *ts_off = nullptr);             // ts_off (nullable): ... at timestep + *ts_off
@@ -127,8 +126,9 @@ void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double
 
 // ---- near field (K9) -------------------------------------------------------------------------------------
 // Per-step pair list, 20 B per pair, in wave-blocked ELL layout: four slots of the 64 rows a wavefront owns form one
-// contiguous 5120-byte group [64 lanes][4 x u32 (neighbour slot | image code << 27)][4 slots][64 x (f64 f, f64 h)], groups
-// of one wave back to back -- a wave streams one contiguous region with 16-byte loads only.
+// contiguous 5120-byte group [64 lanes][4 x u32 (neighbour row | sign of h << 27)][4 slots][64 x (f32 f, f32 s.xyz)] with
+// s = d sqrt|h| (pair term f v + sgn (s.v) s, nb_store in pse_kernels.hip), groups of one wave back to back -- a wave streams one
+// contiguous region with 16-byte loads only.  Read by the Lanczos mat-vecs only.
 // Row r = i - lo (lo: first row of the rank, fixed within a step); record (r / 64) * cap + slot.
 struct NbList {
     char *data;
@@ -168,8 +168,7 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
                   const int *cell_off, DBox box, DCells nc, double rcut, double self, const double *coef, int ncoef, NbList nb,
                   int mode, hipStream_t s, const double4 *vec2_s = nullptr, double4 *out2_s = nullptr,   // BUILD_LIST: a second vector rides along
                   VerletList vl = VerletList{}, int vl_mode = VL_NONE,   // VL_WRITE: the cell pass also writes the neighbour list; VL_USE: no cell walk
-                  const double2 *pv = nullptr,                           // VL_USE: packed (position, vec_s) records
-                  double2 *pv_out = nullptr,                             // BUILD_LIST with a second vector: out2 also goes into these records
+                  const double2 *pv = nullptr,                           // packed (position, vec_s) records for the drain's gathers
                   double *sums0 = nullptr, int sums0_cap = 0, double *scal = nullptr,    // ... and the sums vec2.vec2, vec2.out2 are left in scal[LZ_TMP ..] (Lanczos iteration 0)
                   Gate gate = Gate{},                                    // cell pass / kept-list pass without a pair list: run on one outcome of the device-side list check only
                   DevRowArgs dr = DevRowArgs{});                         // owned-particle ranks: the rows come from device memory (cell passes only; stage_hi takes out2)
@@ -178,12 +177,10 @@ bool mreal_table_in_lds(int ncoef);   // the neighbour list across steps needs t
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, RowMap rows, const int *cell_off,
                           DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,
                           double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s,   // events (nullable) bracket the mat-vec kernel
-                          const double2 *pv = nullptr,    // packed (position, vector) records holding vec_s, or null
                           VerletList vl = VerletList{},   // in use this step: rows that overflowed the pair list walk it instead of the cells
                           int sums = 1,                   // 0 none, 1 one-step Lanczos sums, 2 Gram sums of a two-step block, 3 single step of that driver
-                          double2 *pv_out = nullptr,      // the result also goes into the vector half of these records
                           const int *stop = nullptr,      // nullable: leave at once if *stop != 0 (the device-side Lanczos decision)
-                          DevRowArgs dr = DevRowArgs{});  // owned-particle ranks: rows from device memory (packed-record variants only)
+                          DevRowArgs dr = DevRowArgs{});  // owned-particle ranks: rows from device memory
 int mreal_partials_needed(int rows);
 void launch_lz_reduce3(const double *partials, int npart, int cap, double *scal, hipStream_t s);
 
@@ -289,7 +286,6 @@ struct LzBlockArgs {
     const double4 *q, *p, *w1, *w2;   // p null for j = 0; w2 null: a single step (scalars alpha_j, beta_{j+1} only)
     double4 *u;                       // in: M p (not read for j = 0); out: M v_{j+1} (two steps) or M v_j = w1 (one step)
     double4 *v1, *v2;                 // V[j + 1], V[j + 2]
-    double2 *pv;                      // packed records of the next mat-vec: vector half <- the new q
     int j;
 };
 // sums_all / nranks (teams): [nranks][LZ_NGRAM] partial sums of all ranks, added in rank order by the kernel; nranks = 0: scal[LZ_TMP ..]
@@ -299,7 +295,7 @@ void launch_lz_block(const LzBlockArgs &a, bool full, double *scal, const int (*
                      const RowRanges *rg_dev = nullptr, int rows_cap = 0,   // owned-particle ranks: the ranges come from device memory (vectors_off: scalars only)
                      bool vectors_off = false, const int *stop = nullptr);
 void launch_lz_update(const double4 *xin, const double4 *y, const double4 *xprev, double4 *xnext, int j,
-                      double *scal, const int (*row_ranges)[2], int n_ranges, hipStream_t s, double2 *pv = nullptr,   // up to three disjoint row ranges in one launch; pv: also refresh the packed records
+                      double *scal, const int (*row_ranges)[2], int n_ranges, hipStream_t s,   // up to three disjoint row ranges in one launch
                       const double *sums_all = nullptr, int nranks = 0, double *sch = nullptr, const int *stop = nullptr);
 // ---- the convergence decision of the Lanczos iteration ON THE DEVICE (queue-only Brownian calls: pse_set_async) ----------------
 // Replaces, for calls that may not wait for the host, what the host driver does between batches of iterations (the reference's

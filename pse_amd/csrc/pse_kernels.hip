@@ -155,7 +155,7 @@ k_permute(const double4 *__restrict__ pos, const double4 *__restrict__ vec,
                           double4 *__restrict__ pos_s, float4 *__restrict__ posf_s, double2 *__restrict__ pv,
                           double4 *__restrict__ vec_s, unsigned *__restrict__ tag_s, const double4 *__restrict__ pos_build,
                           double half_skin2, int *__restrict__ flags, CellRanges need, const int *__restrict__ cell_off,
-                          double2 *__restrict__ pv2, FarBinArgs far, double4 *__restrict__ psi_s, uint32_t seed, uint32_t timestep, Gate gate,
+                          FarBinArgs far, double4 *__restrict__ psi_s, uint32_t seed, uint32_t timestep, Gate gate,
                           const uint32_t *__restrict__ ts_off) {
     if (gate.closed()) return;
     if (ts_off) timestep += *ts_off;
@@ -179,13 +179,9 @@ k_permute(const double4 *__restrict__ pos, const double4 *__restrict__ vec,
         q.w = 0.0;
         pos_s[s] = q;
         posf_s[s] = make_float4((float)q.x, (float)q.y, (float)q.z, 0.0f);   // single-precision copy for the cutoff pre-filter
-        if (pv) {   // packed 48-byte (position, vector) records of the pair-list mat-vec: the position half
+        if (pv) {   // packed 48-byte (position, vector) records of the near-field passes' drain: the position half
             pv[3 * (size_t)s] = make_double2(q.x, q.y);
             ((double *)&pv[3 * (size_t)s + 1])[0] = q.z;
-        }
-        if (pv2) {   // a team's second set of records (the two-step Lanczos gathers q from one and w1 = M q from the other)
-            pv2[3 * (size_t)s] = make_double2(q.x, q.y);
-            ((double *)&pv2[3 * (size_t)s + 1])[0] = q.z;
         }
         tag_s[s] = idx;
         if (vec) {
@@ -238,10 +234,10 @@ __global__ void k_permute_vec(const double4 *__restrict__ vec, const unsigned *_
 
 void launch_permute(const double4 *pos, const double4 *vec, const unsigned *group, const unsigned *perm, int N, DBox box,
                     double4 *pos_s, float4 *posf_s, double2 *pv, double4 *vec_s, unsigned *tag_s, hipStream_t s,
-                    const double4 *pos_build, double half_skin2, int *flags, CellRanges need, const int *cell_off, double2 *pv2,
+                    const double4 *pos_build, double half_skin2, int *flags, CellRanges need, const int *cell_off,
                     const FarBinArgs *far, double4 *psi_s, uint32_t seed, uint32_t timestep, Gate gate, const uint32_t *ts_off) {
     hipLaunchKernelGGL(k_permute, dim3(nblocks(N, TPB)), dim3(TPB), 0, s, pos, vec, group, perm, N, box, pos_s, posf_s, pv, vec_s, tag_s,
-                       pos_build, half_skin2, flags, need, cell_off, pv2, far ? *far : FarBinArgs{}, psi_s, seed, timestep, gate, ts_off);
+                       pos_build, half_skin2, flags, need, cell_off, far ? *far : FarBinArgs{}, psi_s, seed, timestep, gate, ts_off);
 }
 __global__ void k_gate_decide(int *__restrict__ flags, int *__restrict__ word) {
     const int f = flags[0] | flags[1];
@@ -283,21 +279,46 @@ void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double
 constexpr int QCAP = 44;
 constexpr unsigned JMASK = (1u << 27) - 1;
 
-// Four slots of the 64 rows of a wave form one 5120-byte group: [lane][4] entries, then [slot][lane] (f, h).  A mat-vec reads a
-// group with one 16-byte load of the four entries and four 16-byte loads of (f, h): a coalesced dword or dwordx2 load
-// occupies the texture addresser as long as a dwordx4 load (tools/microbench/stream_widths: 8 / 16 / 16 clk), so the
-// twelve narrow loads of the former (entry | f | h) planes cost twice what these five do.
+// Four slots of the 64 rows of a wave form one 5120-byte group: [lane][4] entries, then [slot][lane] 16-byte coefficient records.
+// A mat-vec reads a group with one 16-byte load of the four entries and four 16-byte loads of the coefficients: a coalesced dword
+// or dwordx2 load occupies the texture addresser as long as a dwordx4 load (tools/microbench/stream_widths: 8 / 16 / 16 clk), so
+// the twelve narrow loads of the former (entry | f | h) planes cost twice what these five do.
+//
+// What a record holds (round 6): the pair's term of the mat-vec, f v + h (d.v) d with d = x_i - x_j (minimum image) and
+// h = (g - f) / r^2, as FOUR SINGLE-PRECISION numbers fr = (float) f and s = (float)(d sqrt|h|), the sign of h in bit 27 of the
+// entry: f v + sgn (s.v) s.  The mat-vecs then gather ONE thing per pair -- the neighbour's vector (24 bytes of its 32-byte row) --
+// instead of the 48-byte (position, vector) record, and neither subtract positions nor look up image shifts; the list is only ever
+// read by the Lanczos iteration of M_real^{1/2} psi (tolerance `error`, 1e-3 by default; the deterministic M.F of the pass that
+// builds the list stays fp64 -- the reference's whole path is fp32).  EVERY application of the operator inside a
+// Lanczos iteration uses these rounded numbers -- the vector that rides along with the build pass, the list mat-vecs, the rows that
+// did not fit the list -- so the iteration sees ONE symmetric matrix: d_ji = -d_ij exactly, so both directions of a pair round alike.
+struct PairCoef { float f, sx, sy, sz; unsigned neg; };
+__device__ __forceinline__ PairCoef pair_coef(double f, double h, double dx, double dy, double dz) {
+    // (single-precision square root, correctly rounded: the four numbers are single precision anyway, and the fp64 root with its
+    // Newton steps cost the build pass the registers of its third workgroup per CU)
+    const double hs = (double)sqrtf((float)fabs(h));
+    PairCoef p;
+    p.f = (float)f; p.sx = (float)(dx * hs); p.sy = (float)(dy * hs); p.sz = (float)(dz * hs); p.neg = h < 0.0 ? 1u : 0u;
+    return p;
+}
+__device__ __forceinline__ void pair_apply(const PairCoef &p, double vx, double vy, double vz, double &ux, double &uy, double &uz) {
+    const double fr = p.f, sx = p.sx, sy = p.sy, sz = p.sz;
+    double sd = sx * vx + sy * vy + sz * vz;
+    if (p.neg) sd = -sd;
+    ux += fr * vx + sd * sx; uy += fr * vy + sd * sy; uz += fr * vz + sd * sz;
+}
+constexpr unsigned NB_NEG = 1u << 27;   // entry = neighbour row | NB_NEG if h < 0
 template <bool STREAM = false>
-__device__ __forceinline__ void nb_store(char *rec, int slot, int lane, unsigned e, double f, double h) {
+__device__ __forceinline__ void nb_store(char *rec, int slot, int lane, unsigned j, const PairCoef &p) {
     char *r = rec + (size_t)(slot >> 2) * (4 * NB_REC);
     // plain stores: a lane's 4- and 16-byte pieces reach a line at different times and the L2 merges them; as non-temporal stores
     // every piece went to memory on its own (WRITE_SIZE of the build pass 548 -> 805 MB)
-    ((unsigned *)r)[lane * 4 + (slot & 3)] = e;
-    if (STREAM) {   // the cell pass: most lanes of a wave append in the same drain round, the (f, h) of a round are whole lines
-        typedef double d2v __attribute__((ext_vector_type(2)));
-        d2v fh; fh.x = f; fh.y = h;
-        __builtin_nontemporal_store(fh, (d2v *)(r + 1024) + (slot & 3) * 64 + lane);
-    } else ((double2 *)(r + 1024))[(slot & 3) * 64 + lane] = make_double2(f, h);
+    ((unsigned *)r)[lane * 4 + (slot & 3)] = j | (p.neg ? NB_NEG : 0u);
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v c; c.x = p.f; c.y = p.sx; c.z = p.sy; c.w = p.sz;
+    if (STREAM)   // the cell pass: most lanes of a wave append in the same drain round, the records of a round are whole lines
+        __builtin_nontemporal_store(c, (f4v *)(r + 1024) + (slot & 3) * 64 + lane);
+    else ((f4v *)(r + 1024))[(slot & 3) * 64 + lane] = c;
 }
 
 __device__ __forceinline__ void vl_store(char *vrec, int slot, int lane, unsigned j) {
@@ -320,7 +341,7 @@ __global__ void __launch_bounds__(TPB, ((LIST && CL && !VL) ? 3 : 1))   // the l
 k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf_s, const double4 *__restrict__ vec_s,
               double4 *__restrict__ out_s, RowMap rm_arg, const int *__restrict__ cell_off, DBox box, DCells nc, double rcut2,
               float rcut2_pre, double self, const double *__restrict__ coef_g, int ncoef, NbList nb,
-              const double4 *__restrict__ vec2_s, double4 *__restrict__ out2_s, VerletList vl, double2 *__restrict__ pv_out,
+              const double4 *__restrict__ vec2_s, double4 *__restrict__ out2_s, VerletList vl,
               double *__restrict__ sums0, int sums0_cap, Gate gate, DevRowArgs dr, const double2 *__restrict__ pvin) {
     if (gate.closed()) return;
     const RowMapRegs rm(rm_arg, DEV ? dr.rm : nullptr);
@@ -405,15 +426,23 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
                 else eval_fg(t, coef, f, h);
                 const bool in = live[u] && r2 < rcut2 && r2 > 0.0;   // the fp64 cutoff decides
                 if (!in) { f = 0.0; h = 0.0; }
-                const double rd = (dx * F[u].x + dy * F[u].y + dz * F[u].z) * h;
-                ux += f * F[u].x + rd * dx; uy += f * F[u].y + rd * dy; uz += f * F[u].z + rd * dz;
-                if (TWO) {
+                // A pass that writes the pair list serves a Lanczos iteration: the vector of that iteration (vec2 when F rides in
+                // front, else vec itself) sees the single-precision pair coefficients the list carries (nb_store); F never does.
+                if (!LIST || TWO) {
+                    const double rd = (dx * F[u].x + dy * F[u].y + dz * F[u].z) * h;
+                    ux += f * F[u].x + rd * dx; uy += f * F[u].y + rd * dy; uz += f * F[u].z + rd * dz;
+                }
+                if (LIST) {
+                    const PairCoef pc = pair_coef(f, h, dx, dy, dz);
+                    if (TWO) pair_apply(pc, G[u].x, G[u].y, G[u].z, wx, wy, wz);
+                    else pair_apply(pc, F[u].x, F[u].y, F[u].z, ux, uy, uz);
+                    if (in) {   // 20 B per pair: (row | sign), (fr, s)
+                        if (total < nb.cap) nb_store<true>(rec, total, lane, (unsigned)j[u], pc);
+                        ++total;
+                    }
+                } else if (TWO) {
                     const double sd = (dx * G[u].x + dy * G[u].y + dz * G[u].z) * h;
                     wx += f * G[u].x + sd * dx; wy += f * G[u].y + sd * dy; wz += f * G[u].z + sd * dz;
-                }
-                if (LIST && in) {   // 20 B per pair: (slot | image code), f, h; the mat-vecs redo the subtraction from the positions
-                    if (total < nb.cap) nb_store<true>(rec, total, lane, e[u], f, h);
-                    ++total;
                 }
             }
         }
@@ -515,10 +544,6 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
     out_s[i] = make_double4(ux, uy, uz, 0.0);
     if (TWO) {
         out2_s[i] = make_double4(wx, wy, wz, 0.0);
-        if (pv_out) {   // the vector half of the packed records the NEXT mat-vec gathers (two-step Lanczos of a team: w = M psi)
-            ((double *)&pv_out[3 * (size_t)i + 1])[1] = wx;
-            pv_out[3 * (size_t)i + 2] = make_double2(wy, wz);
-        }
         if (DEV && dr.stage_hi) {   // rows of the last layers: parked for the exchange with the right neighbour
             const int lb = dr.lr->last_begin, no = dr.lr->n_own;
             if (i >= lb && i < no) dr.stage_hi[i - lb] = make_double4(wx, wy, wz, 0.0);
@@ -600,17 +625,21 @@ k_mreal_verlet(const double4 *__restrict__ pos_s, const double2 *__restrict__ pv
             eval_fg<2 * RS_NCOEF + 1>(fmin(r2, rcut2), scoef, f, h);
             if (!in) { f = 0.0; h = 0.0; }
             const double Fx = b[u].y, Fy = c[u].x, Fz = c[u].y;
-            const double rd = (dx * Fx + dy * Fy + dz * Fz) * h;
-            ux += f * Fx + rd * dx; uy += f * Fy + rd * dy; uz += f * Fz + rd * dz;
-            if (TWO) {
+            if (!LIST || TWO) {
+                const double rd = (dx * Fx + dy * Fy + dz * Fz) * h;
+                ux += f * Fx + rd * dx; uy += f * Fy + rd * dy; uz += f * Fz + rd * dz;
+            }
+            if (LIST) {   // (as the cell pass: the vector of the Lanczos iteration sees the coefficients the list carries)
+                const PairCoef pc = pair_coef(f, h, dx, dy, dz);
+                if (TWO) pair_apply(pc, G[u].x, G[u].y, G[u].z, wx, wy, wz);
+                else pair_apply(pc, Fx, Fy, Fz, ux, uy, uz);
+                if (in) {
+                    if (total < nb.cap) nb_store(rec, total, lane, e[u], pc);
+                    ++total;
+                }
+            } else if (TWO) {
                 const double sd = (dx * G[u].x + dy * G[u].y + dz * G[u].z) * h;
                 wx += f * G[u].x + sd * dx; wy += f * G[u].y + sd * dy; wz += f * G[u].z + sd * dz;
-            }
-            if (LIST && in) {
-                // the image the mat-vecs subtract: d = x_i - x_j - shift(code), shift = nx a + ny b + nz c (pse_device.h image_shift)
-                const unsigned code = (unsigned)(((int)nx + 1) * 9 + ((int)ny + 1) * 3 + ((int)nz + 1));
-                if (total < nb.cap) nb_store(rec, total, lane, e[u] | (code << 27), f, h);
-                ++total;
             }
         }
     }
@@ -619,21 +648,41 @@ k_mreal_verlet(const double4 *__restrict__ pos_s, const double2 *__restrict__ pv
     if (LIST) nb.cnt[i] = total > nb.cap ? -1 : total;   // -1: the mat-vecs of this step walk the neighbour list for this row
 }
 
+// eval_fg with the Horner steps as a rolled loop (the same operations in the same order: bit-identical results): for the rare rows of
+// the pair-list mat-vec that did not fit the list -- unrolled, its twenty coefficient loads in flight set the register count of the
+// whole kernel (126), which the list loop itself does not need
+__device__ __forceinline__ void eval_fg_lean(double r2, const double *__restrict__ coef, double &f, double &gmf_r2) {
+    const double ir = rsqrt(r2), r = r2 * ir, ir2 = ir * ir;
+    double f0, g0;
+    if (r > 2.0) { const double ir3 = ir * ir2; f0 = 0.75 * ir + 0.5 * ir3; g0 = 1.5 * ir - ir3; }
+    else { f0 = 1.0 - 0.28125 * r; g0 = 1.0 - 0.1875 * r; }
+    const double s = r * RS_PER_UNIT;
+    const int k = (int)s;
+    const double t = 2.0 * (s - k) - 1.0;
+    const double *c = coef + (size_t)k * (2 * RS_NCOEF);
+    double fw = c[RS_DEG], gw = c[RS_NCOEF + RS_DEG];
+#pragma unroll 1
+    for (int q = RS_DEG - 1; q >= 0; --q) {
+        fw = fma(fw, t, c[q]);
+        gw = fma(gw, t, c[RS_NCOEF + q]);
+    }
+    f = f0 - fw;
+    gmf_r2 = ((g0 - gw) - f) * ir2;
+}
+
 // mat-vec from the pair list (one thread per particle, ELL layout: slot-major so a wave reads contiguous rows).
-// Per pair 20 B of list from HBM plus the neighbour's position and vector entry gathered through L2.  FUSE adds the
-// Lanczos epilogue (see LzFuse).
-// PACKED: neighbours are read from 48-byte (position, vector) records pv[j] = {(x,y), (z,vx), (vy,vz)}: three 16-byte
-// gathers per pair instead of the four of two 24-byte records (the kernel is bound by the L1 address path).
+// Per pair 20 B of list from HBM -- (row | sign), (fr, s) in single precision, see nb_store -- plus 24 bytes of the neighbour's
+// vector row gathered through L2: no positions, no image shifts.  FUSE adds the Lanczos epilogue (see LzFuse).
 // WSP = 4: the four waves of a workgroup share ONE block of 64 rows and take every fourth group of slots each (partial sums
 // through LDS): the waves resident on a CU then gather from a quarter as many neighbourhoods (the kernel is bound by L1 misses).
 // FUSE: 0 none; 1 the three sums of the one-step iteration; 2 the Gram sums of a two-step block (this launch is its SECOND
 // mat-vec: vec = w1 = M q, result w2); 3 the sums of a single step in the two-step driver (vec = q, result w1).
-template <int FUSE, int UNROLL, int NT, bool PACKED, int WSP = 1>
-__global__ void __launch_bounds__(NT)
+template <int FUSE, int UNROLL, int NT, int WSP = 1>
+__global__ void __launch_bounds__(NT, (WSP == 4 ? 5 : 1))   // the split kernel: <= 96 VGPRs, five workgroups per CU (it is bound by the round trips its waves have in flight)
 k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, RowMap rm_arg,
-             DBox box, int shift_only, double self, NbList nb, LzFuse lz, const double2 *__restrict__ pv,
+             DBox box, double self, NbList nb, LzFuse lz,
              const int *__restrict__ cell_off, DCells nc, double rcut2, const double *__restrict__ coef, VerletList vl,
-             double2 *__restrict__ pv_out, const int *__restrict__ stop, DevRowArgs dr) {
+             const int *__restrict__ stop, DevRowArgs dr) {
     if (stop && *stop) return;   // the Lanczos iteration has ended (device-side decision)
     const RowMapRegs rm(rm_arg, dr.rm);
     int nb_live = gridDim.x;
@@ -645,14 +694,7 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
             return;
         }
     }
-    __shared__ double shift[27 * 3];
     __shared__ double sh[4];
-    if (threadIdx.x < 27) {
-        double sx, sy, sz;
-        image_shift(threadIdx.x, box, sx, sy, sz);
-        shift[threadIdx.x * 3] = sx; shift[threadIdx.x * 3 + 1] = sy; shift[threadIdx.x * 3 + 2] = sz;
-    }
-    __syncthreads();
     static_assert(WSP == 1 || NT == 64 * WSP, "split rows: one wave per slot phase");
     const int wv = WSP > 1 ? (int)(threadIdx.x >> 6) : 0;
     const int lr = WSP > 1 ? xcd_block(blockIdx.x, nb_live) * 64 + (int)(threadIdx.x & 63)
@@ -665,54 +707,40 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
         vi = vec_s[i];
         const int cnt = nb.cnt[i];
         if (cnt >= 0) {
-            const double4 pi = pos_s[i];
             if (wv == 0) { ux = self * vi.x; uy = self * vi.y; uz = self * vi.z; }
             const int lane = lr & 63;
             const char *rec = nb.data + (size_t)(lr >> 6) * nb.cap * NB_REC;
-            // software-pipelined by hand: the list entries of UNROLL slots, then their 2 UNROLL gathers, then the arithmetic --
-            // left to the compiler every slot waited for its own load -> gather chain (the kernel was latency-bound at
-            // 1.9 TB/s).  Branch-free: slots past cnt re-read the last valid one with f = h = 0; image code 13 is a zero shift.
+            // software-pipelined by hand: the list entries of UNROLL slots, then their gathers, then the arithmetic -- left to the
+            // compiler every slot waited for its own load -> gather chain (the kernel was latency-bound at 1.9 TB/s).  Branch-free:
+            // slots past cnt re-read the last valid one with zero coefficients.
             static_assert(UNROLL == 4, "one list group per iteration");
             for (int s0 = UNROLL * wv; s0 < cnt; s0 += UNROLL * WSP) {
                 const char *grp = rec + (size_t)(s0 >> 2) * (4 * NB_REC);
-                // streamed once: non-temporal, so the list does not evict the neighbour records the gathers reuse from L1
+                // streamed once: non-temporal, so the list does not evict the neighbour rows the gathers reuse from L1
                 typedef unsigned u4v __attribute__((ext_vector_type(4)));
-                typedef double d2v __attribute__((ext_vector_type(2)));
+                typedef float f4v __attribute__((ext_vector_type(4)));
                 const u4v e4 = __builtin_nontemporal_load((const u4v *)grp + lane);
                 unsigned e[UNROLL] = {e4.x, e4.y, e4.z, e4.w};
-                double f[UNROLL], h[UNROLL];
+                f4v c[UNROLL];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
-                    const d2v fh = __builtin_nontemporal_load((const d2v *)(grp + 1024) + u * 64 + lane);
-                    f[u] = fh.x; h[u] = fh.y;
+                    c[u] = __builtin_nontemporal_load((const f4v *)(grp + 1024) + u * 64 + lane);
                     if (u && s0 + u >= cnt) e[u] = e[0];          // slots past the row's count were never written
                 }
-                double4 pj[UNROLL], Fj[UNROLL];
+                double2 vxy[UNROLL];
+                double vz[UNROLL];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
-                    const unsigned j = e[u] & JMASK;
-                    if (PACKED) {
-                        const double2 *r = pv + 3 * (size_t)j;
-                        const double2 a = r[0], b = r[1], c = r[2];
-                        pj[u] = make_double4(a.x, a.y, b.x, 0.0);
-                        Fj[u] = make_double4(b.y, c.x, c.y, 0.0);
-                    } else {
-                        pj[u] = pos_s[j];
-                        Fj[u] = vec_s[j];
-                    }
+                    const double4 *vj = vec_s + (e[u] & JMASK);   // 24 of the row's 32 bytes: a 16- and an 8-byte gather from one line
+                    vxy[u] = *reinterpret_cast<const double2 *>(vj);
+                    vz[u] = vj->z;
                 }
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
-                    const unsigned code = e[u] >> 27;
+                    PairCoef pc;
                     const bool ok = s0 + u < cnt;
-                    double dx = pi.x - pj[u].x - shift[code * 3], dy = pi.y - pj[u].y - shift[code * 3 + 1],
-                           dz = pi.z - pj[u].z - shift[code * 3 + 2];
-                    if (!shift_only) min_image(box, dx, dy, dz);
-                    const double fu = ok ? f[u] : 0.0, hu = ok ? h[u] : 0.0;
-                    const double rdF = (dx * Fj[u].x + dy * Fj[u].y + dz * Fj[u].z) * hu;
-                    ux += fu * Fj[u].x + rdF * dx;
-                    uy += fu * Fj[u].y + rdF * dy;
-                    uz += fu * Fj[u].z + rdF * dz;
+                    pc.f = ok ? c[u].x : 0.0f; pc.sx = ok ? c[u].y : 0.0f; pc.sy = ok ? c[u].z : 0.0f; pc.sz = ok ? c[u].w : 0.0f; pc.neg = e[u] & NB_NEG;
+                    pair_apply(pc, vxy[u].x, vxy[u].y, vz[u], ux, uy, uz);
                 }
             }
         } else if (wv != 0) {
@@ -731,12 +759,9 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
                 const double r2 = dx * dx + dy * dy + dz * dz;
                 if (r2 < rcut2 && r2 > 0.0) {
                     double f, h;
-                    eval_fg(r2, coef, f, h);
+                    eval_fg_lean(r2, coef, f, h);
                     const double4 Fj = vec_s[j];
-                    const double rdF = (dx * Fj.x + dy * Fj.y + dz * Fj.z) * h;
-                    ux += f * Fj.x + rdF * dx;
-                    uy += f * Fj.y + rdF * dy;
-                    uz += f * Fj.z + rdF * dz;
+                    pair_apply(pair_coef(f, h, dx, dy, dz), Fj.x, Fj.y, Fj.z, ux, uy, uz);   // (the coefficients the list would have carried)
                 }
             }
         } else {
@@ -754,12 +779,9 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
                     const double r2 = dx * dx + dy * dy + dz * dz;
                     if (r2 < rcut2 && j != i && r2 > 0.0) {
                         double f, h;
-                        eval_fg(r2, coef, f, h);
+                        eval_fg_lean(r2, coef, f, h);
                         const double4 Fj = vec_s[j];
-                        const double rdF = (dx * Fj.x + dy * Fj.y + dz * Fj.z) * h;
-                        ux += f * Fj.x + rdF * dx;
-                        uy += f * Fj.y + rdF * dy;
-                        uz += f * Fj.z + rdF * dz;
+                        pair_apply(pair_coef(f, h, dx, dy, dz), Fj.x, Fj.y, Fj.z, ux, uy, uz);
                     }
                 }
             });
@@ -816,10 +838,6 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
     }
     if (active) {
         out_s[i] = make_double4(ux, uy, uz, 0.0);
-        if (pv_out) {   // the vector half of the records the next mat-vec gathers
-            ((double *)&pv_out[3 * (size_t)i + 1])[1] = ux;
-            pv_out[3 * (size_t)i + 2] = make_double2(uy, uz);
-        }
         if (dr.stage_hi) {   // rows of the last layers: parked for the exchange with the right neighbour
             const int lb = dr.lr->last_begin, no = dr.lr->n_own;
             if (i >= lb && i < no) dr.stage_hi[i - lb] = make_double4(ux, uy, uz, 0.0);
@@ -834,16 +852,15 @@ bool mreal_table_in_lds(int ncoef) { return mreal_lds_bytes(ncoef) <= 14 * 1024;
 void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec_s, double4 *out_s, RowMap rm,
                   const int *cell_off, DBox box, DCells nc, double rcut, double self, const double *coef, int ncoef, NbList nb,
                   int mode, hipStream_t s, const double4 *vec2_s, double4 *out2_s, VerletList vl, int vl_mode, const double2 *pv,
-                  double2 *pv_out, double *sums0, int sums0_cap, double *scal, Gate gate, DevRowArgs dr) {
+                  double *sums0, int sums0_cap, double *scal, Gate gate, DevRowArgs dr) {
     const int rows = dr.rm ? dr.rows_cap : rm.list_rows();
     if (rows <= 0) return;
     const dim3 g(nblocks(rows, TPB)), b(TPB);
     const size_t cb = mreal_lds_bytes(ncoef);
     const bool cl = mreal_table_in_lds(ncoef);
     if (mode == MREAL_USE_LIST) {
-        hipLaunchKernelGGL((k_mreal_list<0, 4, TPB, false>), g, b, 0, s, pos_s, vec_s, out_s, rm, box,
-                           (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1), self, nb, LzFuse{}, nullptr, cell_off, nc, rcut * rcut, coef,
-                           vl_mode == VL_USE ? vl : VerletList{}, nullptr, nullptr, DevRowArgs{});
+        hipLaunchKernelGGL((k_mreal_list<0, 4, TPB>), g, b, 0, s, pos_s, vec_s, out_s, rm, box, self, nb, LzFuse{}, cell_off, nc, rcut * rcut, coef,
+                           vl_mode == VL_USE ? vl : VerletList{}, nullptr, DevRowArgs{});
         return;
     }
     const bool list = mode == MREAL_BUILD_LIST, two = list && vec2_s != nullptr;
@@ -863,8 +880,8 @@ void launch_mreal(const double4 *pos_s, const float4 *posf_s, const double4 *vec
     const double cmax = 1.5 * (box.Lx + std::fabs(box.xy) * box.Ly + box.Ly + box.Lz);
     const double rpre = (wr ? vl.rskin : rcut) + 16.0 * cmax * 5.97e-8;
     const float rcut2_pre = (float)(rpre * rpre * (1.0 + 1e-6));
-#define PSE_CELLS(L, C, T, V) hipLaunchKernelGGL((k_mreal_cells<L, C, T, V>), g, b, (C) ? cb : 0, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, two ? vec2_s : nullptr, out2_s, vl, two ? pv_out : nullptr, (two && (C)) ? sums0 : nullptr, sums0_cap, gate, dr, nullptr)
-#define PSE_CELLS_PK(L, T, D) hipLaunchKernelGGL((k_mreal_cells<L, true, T, false, D, true>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, two ? vec2_s : nullptr, out2_s, vl, two ? pv_out : nullptr, (two && !(D)) ? sums0 : nullptr, sums0_cap, gate, dr, pv)
+#define PSE_CELLS(L, C, T, V) hipLaunchKernelGGL((k_mreal_cells<L, C, T, V>), g, b, (C) ? cb : 0, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, two ? vec2_s : nullptr, out2_s, vl, (two && (C)) ? sums0 : nullptr, sums0_cap, gate, dr, nullptr)
+#define PSE_CELLS_PK(L, T, D) hipLaunchKernelGGL((k_mreal_cells<L, true, T, false, D, true>), g, b, cb, s, pos_s, posf_s, vec_s, out_s, rm, cell_off, box, nc, rcut * rcut, rcut2_pre, self, coef, ncoef, nb, two ? vec2_s : nullptr, out2_s, vl, (two && !(D)) ? sums0 : nullptr, sums0_cap, gate, dr, pv)
     if (dr.rm) {   // owned-particle ranks (table in LDS, no kept list, packed records): the two passes of pse_team_step_local
         if (list && two) PSE_CELLS_PK(true, true, true); else PSE_CELLS_PK(false, false, true);
         return;
@@ -889,27 +906,19 @@ void launch_lz_reduce3(const double *partials, int npart, int cap, double *scal,
 }
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, RowMap rm, const int *cell_off,
                           DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,
-                          double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s, const double2 *pv, VerletList vl,
-                          int sums, double2 *pv_out, const int *stop, DevRowArgs dr) {
-    const int so = (int)(nc.nx > 1 && nc.ny > 1 && nc.nz > 1);
+                          double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s, VerletList vl,
+                          int sums, const int *stop, DevRowArgs dr) {
     const int rows = std::max(dr.rm ? dr.rows_cap : rm.list_rows(), 1);
-    const int nbk = nblocks(rows, TPB);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     // Four waves per block of 64 rows, each taking every fourth group of slots: 0.166 ms against 0.191 with four blocks of rows
     // per workgroup (two waves: 0.182, eight: 0.196).
-    if (pv) {
-        const int nb64 = nblocks(rows, 64);
-#define PSE_LIST(F) hipLaunchKernelGGL((k_mreal_list<F, 4, 256, true, 4>), dim3(nb64), dim3(256), 0, s, pos_s, vec_s, w, rm, box, so, self, nb, lz, pv, cell_off, nc, rcut * rcut, coef, vl, pv_out, stop, dr)
-        if (sums == 0) PSE_LIST(0); else if (sums == 1) PSE_LIST(1); else if (sums == 2) PSE_LIST(2); else PSE_LIST(3);
+    const int nb64 = nblocks(rows, 64);
+#define PSE_LIST(F) hipLaunchKernelGGL((k_mreal_list<F, 4, 256, 4>), dim3(nb64), dim3(256), 0, s, pos_s, vec_s, w, rm, box, self, nb, lz, cell_off, nc, rcut * rcut, coef, vl, stop, dr)
+    if (sums == 0) PSE_LIST(0); else if (sums == 1) PSE_LIST(1); else if (sums == 2) PSE_LIST(2); else PSE_LIST(3);
 #undef PSE_LIST
-        if (ev_end) (void)hipEventRecord(ev_end, s);
-        if (sums == 1) hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, lz.partials, nb64, lz.npart_cap, 3, scal, stop);
-        else if (sums >= 2) hipLaunchKernelGGL(k_lz_reduce, dim3(LZ_NGRAM), dim3(1024), 0, s, lz.partials, nb64, lz.npart_cap, LZ_NGRAM, scal, stop);
-        return;
-    }
-    hipLaunchKernelGGL((k_mreal_list<1, 4, TPB, false>), dim3(nbk), dim3(TPB), 0, s, pos_s, vec_s, w, rm, box, so, self, nb, lz, nullptr, cell_off, nc, rcut * rcut, coef, vl, nullptr, stop, DevRowArgs{});
     if (ev_end) (void)hipEventRecord(ev_end, s);
-    hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, lz.partials, nbk, lz.npart_cap, 3, scal, stop);
+    if (sums == 1) hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, lz.partials, nb64, lz.npart_cap, 3, scal, stop);
+    else if (sums >= 2) hipLaunchKernelGGL(k_lz_reduce, dim3(LZ_NGRAM), dim3(1024), 0, s, lz.partials, nb64, lz.npart_cap, LZ_NGRAM, scal, stop);
 }
 
 __global__ void k_eval_fg(const double *__restrict__ r, int n, const double *__restrict__ coef, double *f, double *g) {
@@ -2286,7 +2295,7 @@ k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, d
 // alpha_j, beta_j from the reduced sums; x_{j+1} on the given rows
 __global__ void __launch_bounds__(TPB)
 k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, const double4 *__restrict__ xprev,
-            double4 *__restrict__ xnext, int j, double *__restrict__ scal, RowRanges rg, double2 *__restrict__ pv,
+            double4 *__restrict__ xnext, int j, double *__restrict__ scal, RowRanges rg,
             const double *__restrict__ sums_all, int nranks, double *__restrict__ sch, const int *__restrict__ stop) {
     if (stop && *stop) return;
     // the three sums: this GPU's (single GPU), or the ranks' partial sums added in rank order -- every rank holds all of them
@@ -2315,10 +2324,6 @@ k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, cons
         double nx = (q.x - alpha * p.x) * inv, ny = (q.y - alpha * p.y) * inv, nz = (q.z - alpha * p.z) * inv;
         if (xprev) { const double4 m = xprev[i]; nx -= cp * m.x; ny -= cp * m.y; nz -= cp * m.z; }
         xnext[i] = make_double4(nx, ny, nz, 0.0);
-        if (pv) {   // the vector half of the packed records the next mat-vec gathers
-            ((double *)&pv[3 * (size_t)i + 1])[1] = nx;
-            pv[3 * (size_t)i + 2] = make_double2(ny, nz);
-        }
     }
 }
 // ---- two Lanczos iterations per exchange (teams) ---------------------------------------------------------------------------
@@ -2406,10 +2411,6 @@ k_lz_block(LzBlockArgs a, double *__restrict__ scal, RowRanges rg, const double 
             a.u[i] = make_double4(z1x, z1y, z1z, 0.0);
         } else {
             a.u[i] = make_double4(ax, ay, az, 0.0);   // M v_j: the u of a block that starts at j + 1
-        }
-        if (a.pv) {
-            ((double *)&a.pv[3 * (size_t)i + 1])[1] = nx;
-            a.pv[3 * (size_t)i + 2] = make_double2(ny, nz);
         }
     }
 }
@@ -2584,13 +2585,13 @@ void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, in
     hipLaunchKernelGGL(k_lz_reduce, dim3(y ? 3 : 1), dim3(1024), 0, s, partials, g, cap, y ? 3 : 1, scal, nullptr);
 }
 void launch_lz_update(const double4 *xin, const double4 *y, const double4 *xprev, double4 *xnext, int j,
-                      double *scal, const int (*rg)[2], int nrg, hipStream_t s, double2 *pv, const double *sums_all, int nranks, double *sch,
+                      double *scal, const int (*rg)[2], int nrg, hipStream_t s, const double *sums_all, int nranks, double *sch,
                       const int *stop) {
     RowRanges r{};
     r.n = nrg;
     int total = 0;
     for (int q = 0; q < nrg && q < 3; ++q) { r.lo[q] = rg[q][0]; r.hi[q] = rg[q][1]; total += rg[q][1] - rg[q][0]; }
-    hipLaunchKernelGGL(k_lz_update, dim3(vec_grid(std::max(1, total))), dim3(TPB), 0, s, xin, y, xprev, xnext, j, scal, r, pv, sums_all, nranks, sch, stop);
+    hipLaunchKernelGGL(k_lz_update, dim3(vec_grid(std::max(1, total))), dim3(TPB), 0, s, xin, y, xprev, xnext, j, scal, r, sums_all, nranks, sch, stop);
 }
 // out[i] = a[i] + b[i] + c[i] on rows [lo, hi)  (each may be null)
 __global__ void k_sum_rows(const double4 *__restrict__ a, const double4 *__restrict__ b, const double4 *__restrict__ c,

@@ -61,7 +61,7 @@ void launch_local_scatter(const int *raw, int *cell_off, const LocalGeom &g, con
                           LocalRows *rows, int *err, hipStream_t s);
 // (4) the rows themselves: ordered by tag inside their cell, gathered from the caller's arrays or from a message
 struct LocalSorted {
-    double4 *pos_s; float4 *posf_s; double2 *pv, *pv2; double4 *f_s; unsigned *tag_s; double4 *porig_s; double *mass_s; int3 *image_s;
+    double4 *pos_s; float4 *posf_s; double2 *pv; double4 *f_s; unsigned *tag_s; double4 *porig_s; double *mass_s; int3 *image_s;
     double4 *psi_s;      // nullable: the particle noise of the step (K14, keyed by tag)
 };
 void launch_local_permute(const LocalCaller &c, const double *recv_l, const double *recv_r, const LocalGeom &g, DBox box, const int *cell_off,

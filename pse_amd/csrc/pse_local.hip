@@ -226,8 +226,6 @@ k_local_permute(LocalCaller c, const double *__restrict__ recv_l, const double *
         o.pv[3 * (size_t)row] = make_double2(q.x, q.y);
         o.pv[3 * (size_t)row + 1] = make_double2(q.z, f.x);
         o.pv[3 * (size_t)row + 2] = make_double2(f.y, f.z);
-        o.pv2[3 * (size_t)row] = make_double2(q.x, q.y);
-        ((double *)&o.pv2[3 * (size_t)row + 1])[0] = q.z;
         o.f_s[row] = make_double4(f.x, f.y, f.z, 0.0);
         o.tag_s[row] = tg;
         if (row < g.c_own) { o.porig_s[row] = p; o.mass_s[row] = mass; o.image_s[row] = im; }

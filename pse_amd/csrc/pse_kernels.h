@@ -64,6 +64,7 @@ struct DevRowArgs {
     const LocalRows *lr;          // device (nullable): for stage_hi
     double4 *stage_hi;            // rows [lr->last_begin, lr->n_own) of the result also go to stage_hi[row - last_begin]
     int rows_cap;                 // list rows to launch for (>= what *rm will say)
+    int stage_cap;                // rows stage_hi holds (the ghost capacity c_g)
 };
 // a RowMap in scalars: what a kernel works with when the map may come from device memory (assigning a loaded struct to the by-value
 // kernel argument put it in scratch memory: 44 bytes per lane and 20 % on the pair-list mat-vec)

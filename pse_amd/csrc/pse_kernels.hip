@@ -546,7 +546,7 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
         out2_s[i] = make_double4(wx, wy, wz, 0.0);
         if (DEV && dr.stage_hi) {   // rows of the last layers: parked for the exchange with the right neighbour
             const int lb = dr.lr->last_begin, no = dr.lr->n_own;
-            if (i >= lb && i < no) dr.stage_hi[i - lb] = make_double4(wx, wy, wz, 0.0);
+            if (i >= lb && i < no && i - lb < dr.stage_cap) dr.stage_hi[i - lb] = make_double4(wx, wy, wz, 0.0);   // (k_local_scatter refuses a step whose last layers exceed the capacity; the bound is the belt to its braces)
         }
         if (sums0) {    // the sums of Lanczos iteration 0 (x = psi, y = M psi): x.x and x.y per wavefront (was k_lz_dots: one more pass over both)
             const double4 v2 = vec2_s[i];
@@ -840,7 +840,7 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
         out_s[i] = make_double4(ux, uy, uz, 0.0);
         if (dr.stage_hi) {   // rows of the last layers: parked for the exchange with the right neighbour
             const int lb = dr.lr->last_begin, no = dr.lr->n_own;
-            if (i >= lb && i < no) dr.stage_hi[i - lb] = make_double4(ux, uy, uz, 0.0);
+            if (i >= lb && i < no && i - lb < dr.stage_cap) dr.stage_hi[i - lb] = make_double4(ux, uy, uz, 0.0);
         }
     }
 }

@@ -141,17 +141,24 @@ k_local_scatter(const int *__restrict__ raw, int *__restrict__ cell_off, LocalGe
         sh[q] = rg.base[q] - s0;
         ok = ok && nq[q] <= rg.cap[q];
     }
+    // The boundary layers of the own rows are what the NEIGHBOURS hold as ghosts, and what the Lanczos blocks send them in messages of
+    // c_g rows (the first `depth` layers as they lie, the last ones parked in stage_w1 / stage_w2, c_g rows each): more than c_g rows
+    // in either is the neighbour's ghost overflow seen from this side -- the step must not run here either (the mat-vecs would park
+    // rows beyond their staging buffers).
+    const int first_end = raw[rg.c_first_end] + sh[0], last_begin = raw[rg.c_last_begin] + sh[0];
+    const bool edge_ok = first_end <= rg.cap[1] && nq[0] - last_begin <= rg.cap[2];
+    ok = ok && edge_ok;
     const int t = blockIdx.x * TPB + threadIdx.x, nt = gridDim.x * TPB;
     if (t == 0) {
         LocalRows r{};
         if (!ok) {
-            atomicOr(err, (nq[0] > rg.cap[0] ? LOCAL_ERR_OWN : 0) | ((nq[1] > rg.cap[1] || nq[2] > rg.cap[2]) ? LOCAL_ERR_GHOST : 0));
+            atomicOr(err, (nq[0] > rg.cap[0] ? LOCAL_ERR_OWN : 0) | ((nq[1] > rg.cap[1] || nq[2] > rg.cap[2] || !edge_ok) ? LOCAL_ERR_GHOST : 0));
             r.own = RowMap{1, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}; r.own1 = r.own;
         } else {
             r.ok = 1;
             r.n_own = nq[0]; r.n_gl = nq[1]; r.n_gr = nq[2];
-            r.first_end = raw[rg.c_first_end] + sh[0];
-            r.last_begin = raw[rg.c_last_begin] + sh[0];
+            r.first_end = first_end;
+            r.last_begin = last_begin;
             const int gl_adj = raw[rg.c_gl_adj] + sh[1], gr_adj_end = raw[rg.c_gr_adj] + sh[2];
             r.own = RowMap{1, {0, 0, 0}, {nq[0], 0, 0}, {0, 0, 0}};
             const int b1 = (nq[0] + 255) & ~255, len1 = rg.base[1] + nq[1] - gl_adj;

@@ -317,6 +317,12 @@ class Team:
         import torch
         for t in list(pos) + list(vel) + list(force):
             _chk4(t, "pos/vel/force")
+        if getattr(self, "_rows_own", None) is None:     # the step writes up to rows_own rows back (particles migrate in): the arrays must hold them
+            self._rows_own = [e.local_layout()["rows_own"] for e in self.engines]
+        for k, ts in enumerate(zip(pos, vel, force, accel, image, tag)):
+            if any(t.shape[0] < self._rows_own[k] for t in ts):
+                raise ValueError(f"member {k}: pos / vel / force / accel / image / tag need {self._rows_own[k]} rows (rows_own of pse_local_layout), "
+                                 f"not the current particle count")
         for a_, im_, tg, nl, p_ in zip(accel, image, tag, n_local, pos):
             _chk_arr(a_, "accel", 3, torch.float64, p_.shape[0]); _chk_arr(im_, "image", 3, torch.int32, p_.shape[0])
             if not (tg.is_cuda and tg.dtype == torch.int32 and tg.is_contiguous() and tg.shape[0] >= p_.shape[0]):
@@ -348,6 +354,11 @@ class Team:
             out["exchange_host_us"].setdefault(k, []).append(round(d.host_us[q], 2))
             out["exchange_bytes"].setdefault(k, []).append(int(d.bytes[q]))
         return out
+
+    def set_lanczos_extra(self, extra):
+        """Iterations an owned-particle step queues beyond its starting count (pse_team_set_lanczos_extra; -1: the default, gated
+        on the device-side decision; 0: none -- for loops whose steps keep ending at their starting count).  Same on every rank."""
+        _lib.check(self._lib.pse_team_set_lanczos_extra(self._t, int(extra)))
 
     def local_status(self):
         """Synchronises; raises if a member's step failed on the device (capacity exceeded, a particle moved too far)."""

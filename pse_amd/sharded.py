@@ -240,6 +240,38 @@ def local_capacity(n, world, layers_per_rank, depth=2, slack=1.3):
     return int(slack * n / world * (per + 2 * depth) / per) + 4096
 
 
+class LanczosCount:
+    """Starting count of the Lanczos iteration for a time-stepping loop of owned-particle steps, and whether a step queues gated
+    extra iterations at all (pse_team_set_lanczos_extra).  A queue-only step never waits for more iterations: it runs the count it
+    is given (+ the gated extras) and says afterwards whether that sufficed.  `seen` is fed pse_info.lanczos_m / lanczos_status of a
+    COMPLETED step (after a synchronisation): every rank takes the same decisions from the same sums, so every rank holds the same
+    two numbers and this object stays identical on all ranks without a message.  Policy: status 1 -> count + 2 and the gated extras
+    back on; `settle` consecutive steps that ended at their starting count with status 0 -> no extras (one exchange and seven
+    launches fewer per step); anything else -> follow the count the step reported."""
+
+    def __init__(self, team, m=2, settle=3, adaptive=True):
+        self.team, self.m, self.settle, self.adaptive = team, max(int(m), 2), settle, adaptive
+        self.steady, self.extras_off = 0, False
+
+    def seen(self, lanczos_m, lanczos_status):
+        if lanczos_status == 1:
+            self.m = max(self.m, int(lanczos_m)) + 2
+            self.steady = 0
+            self._extras(False)
+        elif int(lanczos_m) == self.m:
+            self.steady += 1
+            if self.adaptive and self.steady >= self.settle:
+                self._extras(True)
+        elif int(lanczos_m) >= 2:
+            self.m, self.steady = int(lanczos_m), 0
+        return self.m
+
+    def _extras(self, off):
+        if off != self.extras_off:
+            self.team.set_lanczos_extra(0 if off else -1)
+            self.extras_off = off
+
+
 class _LocalState:
     """The caller's arrays of one owned-particle rank: capacity rows_own, the first n_local rows live."""
 

@@ -29,7 +29,12 @@ def test_dry_run_prints_the_launch_command():
     assert d["n_gpus"] == 2
     assert cmd[1] == BENCH
     assert cmd[2:] == ["--gpus", "2", "--steps", "3", "--warmup", "1", "--n", "1000"]   # the ranks get the same arguments, minus --dry-run
-    assert d["env"]["MASTER_ADDR"] == "127.0.0.1" and int(d["env"]["MASTER_PORT"]) > 0 and d["env"]["WORLD_SIZE"] == "2"
+    # the owned-particle run is a sequence of segments, each a fresh set of rank processes with a rendezvous port of its own
+    assert d["segments"] == ["single", "one_stream", "lanes"]
+    assert d["env"]["MASTER_ADDR"] == "127.0.0.1" and d["env"]["WORLD_SIZE"] == "2"
+    r = _run(["--gpus", "2", "--replicated", "--dry-run"])           # one set of ranks: the launch line with its port
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert int(d["env"]["MASTER_PORT"]) > 0 and d["launch"][2:] == ["--gpus", "2", "--replicated"]
 
 
 def test_single_gpu_does_not_launch():
@@ -85,3 +90,105 @@ def test_launcher_relays_rank0_line_and_exit_code(tmp_path, capfd, monkeypatch):
     rc = bench.launch_ranks(args, ["--gpus", "3"], script=str(script))
     out, err = capfd.readouterr()
     assert rc == 3 and out.strip() == "" and time.time() - t0 < 60
+
+
+SEGMENT_STAND_IN = """
+import json, os, sys, time
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+seg = sys.argv[sys.argv.index('--segment') + 1]
+assert os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0 and 'TORCHELASTIC_USE_AGENT_STORE' not in os.environ
+fake = os.environ.get('FAKE', '')
+if seg == 'single':
+    assert world == 1 and 'PSE_TEAM_LANES' not in os.environ
+    print(json.dumps({'segment': seg, 'metric': 'm', 'ms_per_step': 8.0, 'config4_single_gpu': {'ms_per_step': 40.0}}))
+    sys.exit(0)
+lanes = os.environ['PSE_TEAM_LANES']
+assert lanes == ('1' if seg == 'lanes' else '0')
+if fake == 'lanes_hang' and seg == 'lanes':
+    if rank == 1:
+        sys.exit(7)
+    time.sleep(600)
+if fake == 'lanes_unverified' and seg == 'lanes':
+    ok = False
+else:
+    ok = True
+if rank == 0:
+    ms = 2.0 if seg == 'lanes' else 2.5
+    print('chatter')
+    print(json.dumps({'segment': seg, 'metric': 'm', 'value': 1e6 / ms, 'ms_per_step': ms, 'n_gpus': world, 'verify': {'ok': ok}, 'lanczos_status': 0,
+                      'config4': {'ms_per_step': 8.0 if seg == 'lanes' else 10.0, 'verify': {'ok': True}}, 'config': {'parallelism': 'lanes=' + lanes}}))
+"""
+
+
+def _supervise(tmp_path, capfd, monkeypatch, fake, gpus=3, extra=()):
+    script = tmp_path / "seg.py"
+    script.write_text(SEGMENT_STAND_IN)
+    bench = _bench_module()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("FAKE", fake)
+    monkeypatch.setenv("TORCHELASTIC_USE_AGENT_STORE", "True")           # must not reach the ranks of a segment
+    ap = argparse.Namespace(gpus=gpus, dry_run=False, no_single=False, modes="both", no_verify=False)
+    for k in extra:
+        setattr(ap, k, True)
+    rc = bench.supervise_segments(ap, ["--gpus", str(gpus)], script=str(script))
+    out, err = capfd.readouterr()
+    return rc, out, err
+
+
+def test_segments_both_modes_are_timed_and_the_faster_verified_one_is_the_value(tmp_path, capfd, monkeypatch):
+    """`bench.py --gpus N`: a single-GPU segment, then the team in both lane modes, each a fresh set of rank processes; ONE line whose
+    value is the faster verified mode, both modes recorded, the speed-ups against the single GPU measured in the same run."""
+    rc, out, err = _supervise(tmp_path, capfd, monkeypatch, "")
+    assert rc == 0, err
+    lines = out.strip().splitlines()
+    d = json.loads(lines[-1])
+    assert len(lines) == 1 and "chatter" in err
+    assert d["mode"] == "lanes" and d["ms_per_step"] == 2.0 and set(d["modes"]) == {"one_stream", "lanes"}
+    assert d["modes"]["one_stream"]["ms_per_step"] == 2.5 and d["modes"]["lanes"]["verify"]["ok"]
+    assert d["single_gpu"]["ms_per_step"] == 8.0 and abs(d["speedup_vs_single"] - 4.0) < 1e-12
+    assert abs(d["config4"]["speedup_vs_single"] - 5.0) < 1e-12 and abs(d["modes"]["one_stream"]["config4"]["speedup_vs_single"] - 4.0) < 1e-12
+    assert d["north_star"]["speedup_at_this_gpu_count"][1] == d["speedup_vs_single"]
+    assert "segment" not in d and d["config"]["parallelism"] == "lanes=1"
+
+
+def test_a_hang_in_the_second_mode_still_prints_the_first(tmp_path, capfd, monkeypatch):
+    """Two lanes + a communication stream has never run over RCCL: a rank that dies there (the others then wait in a collective) ends
+    that segment's children and the line of the one-stream mode is printed all the same."""
+    import time
+    t0 = time.time()
+    rc, out, err = _supervise(tmp_path, capfd, monkeypatch, "lanes_hang")
+    assert rc == 0 and time.time() - t0 < 90, err
+    d = json.loads(out.strip().splitlines()[-1])
+    assert d["mode"] == "one_stream" and d["ms_per_step"] == 2.5 and "error" in d["modes"]["lanes"] and "7" in d["modes"]["lanes"]["error"]
+
+
+def test_an_unverified_mode_is_never_the_value(tmp_path, capfd, monkeypatch):
+    rc, out, err = _supervise(tmp_path, capfd, monkeypatch, "lanes_unverified")
+    assert rc == 0, err
+    d = json.loads(out.strip().splitlines()[-1])
+    assert d["mode"] == "one_stream" and d["modes"]["lanes"]["verify"]["ok"] is False and d["modes"]["lanes"]["ms_per_step"] == 2.0
+
+
+def test_segments_under_torch_distributed_run(tmp_path):
+    """The driver's own multi-GPU line: `python -m torch.distributed.run ... bench.py --gpus N`.  Every worker is then the supervisor of
+    its own rank: it never touches the GPU, starts one child per segment, and the supervisors agree on a fresh rendezvous port per
+    segment through the launcher's store; rank 0 prints the merged line.  Stand-in ranks; CPU only."""
+    import socket
+    script = tmp_path / "seg.py"
+    script.write_text(SEGMENT_STAND_IN)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PSE_BENCH_RANK_SCRIPT"] = str(script)
+    for fake, mode in (("", "lanes"), ("lanes_hang", "one_stream")):
+        env["FAKE"] = fake
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d["mode"] == mode and set(d["modes"]) == {"one_stream", "lanes"} and d["single_gpu"]["ms_per_step"] == 8.0
+        if fake:
+            assert "error" in d["modes"]["lanes"]

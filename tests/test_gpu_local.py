@@ -312,6 +312,29 @@ def test_local_team_reports_what_only_the_device_can_see():
     with pytest.raises(PSEError, match="owned-particle step failed"):
         tight.team.local_status()
     assert [int(s.n_local.item()) for s in tight.s] == before
+    # (b2) most of rank 1's particles packed into its LAST cell layer: its own rows fit, but that layer is what rank 2 holds as ghosts and
+    # what the Lanczos blocks park in staging buffers of rows_ghost rows: rank 1 refuses the step itself (flag 2) -- before,
+    # only rank 2 noticed, and rank 1's mat-vecs wrote past the end of their staging buffers
+    dense = LocalLoopbackSimulation(n, box, world, **kw)
+    lay = dense.layout
+    idx1 = np.nonzero(own == 1)[0]
+    assert len(idx1) <= lay["rows_own"]
+    packed = pos.copy()
+    fx_last = (2 * per - 0.5) / layers                                 # fractional x of the middle of rank 1's last layer
+    take = idx1[: min(len(idx1), lay["rows_ghost"] + 600)]
+    packed[take, 0] = (fx_last - 0.5) * box[0] + box[3] * packed[take, 1]
+    if len(take) > lay["rows_ghost"]:
+        for r in range(world):
+            dense.s[r].load(np.nonzero(own == r)[0], packed, force, 1.0)
+        before = [int(s.n_local.item()) for s in dense.s]
+        dense.team.step_local([s.pos for s in dense.s], [s.vel for s in dense.s], [s.accel for s in dense.s], [s.image for s in dense.s],
+                              [s.force for s in dense.s], [s.tag for s in dense.s], [s.n_local for s in dense.s], 1.0, 1e-3, 0, integrate=False)
+        flags = (__import__("ctypes").c_int * world)()
+        rc = dense.team._lib.pse_team_local_status(dense.team._t, flags)
+        assert rc != 0 and (flags[1] & 2) and (flags[1] & 4), list(flags)     # (4: its message to rank 2 was full as well)
+        assert [int(s.n_local.item()) for s in dense.s] == before
+    else:
+        pytest.skip("the ghost capacity of this layout exceeds a rank's particle count")
     # (c) *n_local above what the arrays hold: flag 16
     sim2 = LocalLoopbackSimulation(n, box, world, **kw)
     sim2.load(pos, force)
@@ -350,3 +373,49 @@ def test_local_and_replicated_entry_points_refuse_each_others_handles():
     assert d["exchanges_per_step"] == sum(len(v) for v in d["exchange_us"].values())
     assert len(d["exchange_us"]["migrate_ghosts"]) == 1 and len(d["exchange_us"]["all_to_all"]) == 2 and len(d["exchange_us"]["halo"]) == 1
     assert len(d["exchange_us"]["lanczos"]) == 5 and d["critical_path_ms"] > 0 and d["lanes_ms"]["side"] > 0
+
+
+def test_steady_state_steps_queue_no_gated_block():
+    """pse_team_set_lanczos_extra(0): a step runs exactly its starting count -- the same velocities as with the gated block when the
+    count suffices (one Lanczos exchange fewer), lanczos_status 1 and the result of the last size when it does not; LanczosCount
+    (pse_amd/sharded.py) switches between the two from the numbers every rank holds after a step."""
+    import pse_amd
+    from pse_amd.sharded import LanczosCount, LocalLoopbackSimulation
+    world, n, grid = 4, 24_000, 64
+    pos, force, box = make_suspension(n, phi=0.1, xy=0.1)
+    kw = _kw(box, grid)
+    sim = LocalLoopbackSimulation(n, box, world, **kw)
+    sim.load(pos, force)
+    ref = pse_amd.Engine(n, box, **kw)
+    vel = to4(np.zeros((n, 3)), 1.0)
+    _, mr = ref.brownian_velocity(to4(pos), to4(force), 1.0, 1e-3, 7, vel=vel, lanczos_m=2)
+    want = vel.cpu().numpy()[:, :3]
+    sim.step(1.0, 1e-3, 7, integrate=False, lanczos_m=mr)
+    _, u_gated, _, _ = sim.gather()
+    ex_gated = sim.engines[0].info()["lanczos_exchanges"]
+    sim.team.set_lanczos_extra(0)
+    sim.step(1.0, 1e-3, 7, integrate=False, lanczos_m=mr)
+    _, u0, _, _ = sim.gather()
+    infos = [e.info() for e in sim.engines]
+    assert all(i["lanczos_status"] == 0 and i["lanczos_m"] == mr for i in infos), infos[0]
+    assert infos[0]["lanczos_exchanges"] == ex_gated - 1
+    assert rel(u0, want) < 1e-9 and rel(u0, u_gated) < 1e-12
+    sim.step(1.0, 1e-3, 7, integrate=False, lanczos_m=mr - 2)              # too few: said afterwards, never waited for
+    sim.team.local_status()                                                 # (waits: pse_get_info reports the last COMPLETED call)
+    infos = [e.info() for e in sim.engines]
+    assert all(i["lanczos_status"] == 1 and i["lanczos_m"] == mr - 2 for i in infos), (mr, [(i["lanczos_status"], i["lanczos_m"]) for i in infos])
+    with pytest.raises(pse_amd.PSEError):
+        sim.team.set_lanczos_extra(33)
+    # the policy object: from a cold start to the steady state and back on the first status 1
+    sim.team.set_lanczos_extra(-1)
+    lc = LanczosCount(sim.team, m=2, settle=2)
+    seen = []
+    for k in range(8):
+        sim.step(1.0, 1e-3, 7, integrate=False, lanczos_m=lc.m)
+        sim.team.local_status()
+        i = sim.engines[0].info()
+        seen.append((lc.m, lc.extras_off, i["lanczos_m"], i["lanczos_status"]))
+        lc.seen(i["lanczos_m"], i["lanczos_status"])
+    assert lc.m == mr and lc.extras_off and seen[-1][2:] == (mr, 0), seen
+    lc.seen(mr, 1)
+    assert lc.m == mr + 2 and not lc.extras_off

@@ -122,28 +122,45 @@ def test_team_of_processes_matches_single_gpu(world, mode, xy):
 
 
 def test_bench_launches_its_own_ranks():
-    """`python bench.py --gpus 2` as the driver calls it: the parent starts the two ranks itself and relays rank 0's line.  On the
-    one-GPU box the ranks share the device through the host-staged transport (RCCL needs a GPU per rank)."""
+    """`python bench.py --gpus 2` as the driver calls it: the parent starts the rank processes itself -- a single-GPU segment, then the
+    team in BOTH lane modes (one stream; two lanes + communication stream), each a fresh set of ranks that verifies itself against a
+    single-GPU engine before it is timed -- and prints ONE line: the faster verified mode, both recorded, the metric point and a
+    config-4 block (shrunk here), the speed-ups against the single GPU of the same run.  On the one-GPU box the ranks share the
+    device through the host-staged transport (RCCL needs a GPU per rank)."""
     import json
     import subprocess
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PSE_TEAM_LANES")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "host", "--steps", "2", "--warmup", "1",
-                        "--no-cpu", "--n", "100000", "--grid", "128"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
-                       timeout=900)
+                        "--no-cpu", "--n", "100000", "--grid", "128", "--cfg4-n", "120000", "--cfg4-grid", "96", "--cfg4-phi", "0.2"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=1200)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     assert "HOST-STAGED" in d["config"]["parallelism"] and "owned-particle" in d["config"]["parallelism"]
+    # both lane modes, each verified and timed by its own set of rank processes; the value is the faster verified one
+    assert set(d["modes"]) == {"one_stream", "lanes"} and d["mode"] in d["modes"]
+    for name, md in d["modes"].items():
+        assert md["verify"]["ok"] and md["ms_per_step"] > 0 and md["lanczos_status"] == 0 and md["device_flags"] == [0], (name, md)
+        assert md["config4"]["ms_per_step"] > 0 and md["config4"]["verify"]["ok"] and md["config4"]["speedup_vs_single"] > 0, (name, md["config4"])
+    assert d["ms_per_step"] == min(md["ms_per_step"] for md in d["modes"].values()) == d["modes"][d["mode"]]["ms_per_step"]
+    assert ("PSE_TEAM_LANES=1" in d["config"]["parallelism"]) == (d["mode"] == "lanes")
+    assert d["modes"]["lanes"]["lanes_ms"]["side"] > 0 and d["modes"]["one_stream"]["lanes_ms"]["side"] == 0
+    # ... against the single GPU of the same run
+    assert d["single_gpu"]["ms_per_step"] > 0 and d["single_gpu"]["config4_ms_per_step"] > 0
+    assert abs(d["speedup_vs_single"] - d["single_gpu"]["ms_per_step"] / d["ms_per_step"]) < 1e-9
+    assert abs(d["config4"]["speedup_vs_single"] - d["single_gpu"]["config4_ms_per_step"] / d["config4"]["ms_per_step"]) < 1e-9
+    assert d["north_star"]["speedup_at_this_gpu_count"][1] == d["speedup_vs_single"]
     # the self-diagnosis of a multi-rank line (VERDICT r4 item 2): exchanges per step, device time of every exchange by kind,
     # the spans of both lanes, the critical path
-    assert d["exchanges_per_step"] == sum(len(v) for v in d["exchange_us"].values()) >= 6
+    assert d["exchanges_per_step"] == sum(len(v) for v in d["exchange_us"].values()) >= 5
     assert set(d["exchange_us"]) >= {"migrate_ghosts", "lanczos", "all_to_all", "halo"}
     assert len(d["exchange_us"]["all_to_all"]) == 2 and len(d["exchange_us"]["halo"]) == 1 and len(d["exchange_us"]["migrate_ghosts"]) == 1
     assert all(t > 0 for v in d["exchange_us"].values() for t in v)
-    assert d["critical_path_ms"] > 0 and d["lanes_ms"]["main"] > 0 and d["lanes_ms"]["side"] > 0
+    assert d["critical_path_ms"] > 0 and d["lanes_ms"]["main"] > 0
     assert d["lanczos_status"] == 0 and d["particles_owned_sum"] == 100000 and d["device_flags"] == [0]
+    assert d["lanczos_extras_off"] is True        # the warm-up reached the steady state: no gated block in the timed steps
     # ... and its verdict on correctness: three untimed steps next to a single-GPU engine on rank 0
     v = d["verify"]
     assert v["ok"] and v["steps"] == 3 and v["max_abs_position_diff_vs_single_gpu"] < 1e-7 and v["images_equal"] and v["lanczos_m_equal"], v
@@ -152,21 +169,24 @@ def test_bench_launches_its_own_ranks():
 
 def test_bench_as_ranks_of_torch_distributed_run():
     """The driver's own multi-GPU launch line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
-    --master-port P bench.py --gpus N --steps K --warmup W`): bench.py is then one of the ranks and must not launch anything."""
+    --master-port P bench.py --gpus N --steps K --warmup W`): every worker is then the supervisor of its own rank -- it never touches
+    the GPU, starts its rank's process for every segment on a port the supervisors agree on through the launcher's store -- and rank 0
+    prints the one merged line (one mode and no extra blocks here: the full sequence is test_bench_launches_its_own_ranks)."""
     import json
     import socket
     import subprocess
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PSE_TEAM_LANES")}
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--transport", "host", "--no-cpu", "--particles", "100000", "--grid", "128"],
+                        "--transport", "host", "--no-cpu", "--particles", "100000", "--grid", "128", "--modes", "lanes", "--no-cfg4"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1                                      # rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["mode"] == "lanes" and set(d["modes"]) == {"lanes"}
+    assert d["verify"]["ok"] and d["single_gpu"]["ms_per_step"] > 0 and d["speedup_vs_single"] > 0
 
 
 def _random_worker(rank, seed, port, out):

@@ -24,6 +24,8 @@ def main():
                     "rank only (both lanes, its share of the copies): one rank's critical path with the GPU to itself")
     ap.add_argument("--local", action="store_true", help="owned-particle team (pse_team_step_local): every rank holds only its slab's particles")
     ap.add_argument("--m", type=int, default=0, help="--local: starting count of the Lanczos iteration (default: found by warm-up steps)")
+    ap.add_argument("--extra", type=int, default=-1, help="--local: pse_team_set_lanczos_extra for the timed steps (0: the steady state of a "
+                    "time-stepping loop -- no gated block queued; -1: the default)")
     a = ap.parse_args()
     import torch
     from conftest import make_suspension
@@ -97,6 +99,7 @@ def main_local(a):
         if i0["lanczos_status"] == 0:
             break
     print("m =", m, "status", [e.info()["lanczos_status"] for e in sim.engines], "n_local", [int(s.n_local.item()) for s in S])
+    sim.team.set_lanczos_extra(a.extra)
     torch.cuda.synchronize(); t0 = time.time()
     for it in range(a.steps):
         sim.team.step_local(*args(), 1.0, 1e-3, 10 + it, lanczos_m=m)

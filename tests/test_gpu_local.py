@@ -315,7 +315,7 @@ def test_local_team_reports_what_only_the_device_can_see():
     # (b2) most of rank 1's particles packed into its LAST cell layer: its own rows fit, but that layer is what rank 2 holds as ghosts and
     # what the Lanczos blocks park in staging buffers of rows_ghost rows: rank 1 refuses the step itself (flag 2) -- before,
     # only rank 2 noticed, and rank 1's mat-vecs wrote past the end of their staging buffers
-    dense = LocalLoopbackSimulation(n, box, world, **kw)
+    dense = LocalLoopbackSimulation(n, box, world, n_max=15000, **kw)   # (4096 ghost rows per side, 6656 own rows: a rank owns ~6000)
     lay = dense.layout
     idx1 = np.nonzero(own == 1)[0]
     assert len(idx1) <= lay["rows_own"]

@@ -395,23 +395,3 @@ def test_pair_repulsion_matches_port(torch_cuda, oracle, xy):
     assert rel(out[:, :3], ref + force) < 1e-12
     with pytest.raises(pse_amd.PSEError):
         eng.pair_repulsion(to4(pos), f, 40.0, 2.0 * eng.info()["rcut"])
-
-
-@pytest.mark.parametrize("bz", ["0", "2"])
-def test_cell_storage_orders(torch_cuda, bz):
-    """The cells are stored in blocks of b along z (x, z block, y, z in block; default b = 6 where an axis has at least twelve
-    cells) so that a wavefront's rows form a squat brick; PSE_CELL_BZ=0 is the plain (x, y, z) order.  Every near-field path
-    (cell pass, pair list, overflow rows, kept neighbour list, pair repulsion) must give the same answers in either (the test
-    boxes have 6-8 cells per axis: default = plain there, so b = 2 is what exercises the blocks).  The switch is read at pse_create;
-    the checks run in a child process with it set."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, PSE_CELL_BZ=bz)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
-                        os.path.join(root, "tests", "test_gpu_nlist.py"), "-k",
-                        "mreal_matches_oracle or pair_list_overflow or brownian_velocity_matches_port or step_integrates or pair_repulsion "
-                        "or reused_list or overflow_rows"],
-                       env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    assert r.returncode == 0, r.stdout[-3000:]

@@ -42,6 +42,13 @@ CASES = [
     ({"PSE_WAVE_MODE": "replicated"}, ["test_gpu_slabs.py"], "team_of_eight or clustered"),
     ({"PSE_WAVE_MODE": "slab"}, ["test_gpu_slabs.py"], "keeps_replicas or clustered"),
     ({"PSE_YSLAB_REGS": "0"}, ["test_gpu_local.py"], "velocities_match"),   # a slab rank's y pass by k_fft_cols also at Ny = 256
+    # The cells are stored in blocks of b along z (x, z block, y, z in block; default b = 6 where an axis has at least twelve cells) so
+    # that a wavefront's rows form a squat brick; PSE_CELL_BZ=0 is the plain (x, y, z) order.  Every near-field path (cell pass, pair
+    # list, overflow rows, kept neighbour list, pair repulsion) must give the same answers in either (the test boxes have 6-8 cells
+    # per axis: default = plain there, so b = 2 is what exercises the blocks).
+    ({"PSE_CELL_BZ": "0"}, ["test_gpu_parity.py", "test_gpu_nlist.py"], _NEAR := "mreal_matches_oracle or pair_list_overflow or brownian_velocity_matches_port "
+     "or step_integrates or pair_repulsion or reused_list or overflow_rows"),
+    ({"PSE_CELL_BZ": "2"}, ["test_gpu_parity.py", "test_gpu_nlist.py"], _NEAR),
 ]
 
 
@@ -58,10 +65,11 @@ _results = {}
 
 def _result(idx):
     """The child runs are independent of one another (each has its own process and handles): the first test that asks starts them
-    all, four at a time, and every test reads its own outcome -- most of a child's time is interpreter and library start-up."""
+    all, ten at a time (the GPU box has 128 host cores; a child holds a few hundred MB of device memory), and every test reads its own
+    outcome -- most of a child's time is interpreter and library start-up."""
     if not _results:
         from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=4) as pool:
+        with ThreadPoolExecutor(max_workers=10) as pool:
             for i, out in enumerate(pool.map(_run_case, CASES)):
                 _results[i] = out
     return _results[idx]

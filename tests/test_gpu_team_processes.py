@@ -18,6 +18,43 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+# The cases of this module are independent of one another (each has its own processes, port and handles) and most of a case's time is
+# interpreter and library start-up in its ranks: the first test that asks starts them ALL, four at a time, and every test reads its
+# own outcome (tests/test_gpu_switches.py does the same with its child runs).
+_JOBS, _OUTCOMES = {}, {}
+
+
+def _job(key, fn):
+    _JOBS[key] = fn
+
+
+def _outcome(key):
+    if not _OUTCOMES:
+        from concurrent.futures import ThreadPoolExecutor
+        keys = list(_JOBS)
+
+        def run(k):
+            try:
+                return _JOBS[k]()
+            except Exception as e:   # noqa: BLE001
+                import traceback
+                return ("exception", "".join(traceback.format_exception(type(e), e, e.__traceback__))[-3000:])
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            for k, out in zip(keys, pool.map(run, keys)):
+                _OUTCOMES[k] = out
+    return _OUTCOMES[key]
+
+
+def _spawn_ranks(target, world, args_of):
+    """`world` processes running target(*args_of(rank, port, out)); the list of (rank, "ok" | traceback) they put on the queue."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=args_of(r, port, out)) for r in range(world)]
+    return _run_ranks(procs, out)
+
+
 def _worker(rank, world, port, mode, xy, out):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -110,15 +147,26 @@ def _run_ranks(procs, out, deadline_s=600):
                 p.kill()
 
 
-@pytest.mark.parametrize("world,mode,xy", [(2, "", 0.0), (2, "slab", 0.2), (4, "", 0.25), (8, "", 0.0)])
+_TEAM_CASES = [(2, "", 0.0), (2, "slab", 0.2), (4, "", 0.25), (8, "", 0.0)]
+for _c in _TEAM_CASES:
+    _job(("team",) + _c, lambda c=_c: _spawn_ranks(_worker, c[0], lambda r, port, out: (r, c[0], port, c[1], c[2], out)))
+
+
+@pytest.mark.parametrize("world,mode,xy", _TEAM_CASES)
 def test_team_of_processes_matches_single_gpu(world, mode, xy):
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, xy, out)) for r in range(world)]
-    res = _run_ranks(procs, out)
+    res = _outcome(("team", world, mode, xy))
     assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def _bench_own_ranks():
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PSE_TEAM_LANES")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "host", "--steps", "2", "--warmup", "1",
+                           "--no-cpu", "--n", "100000", "--grid", "128", "--cfg4-n", "120000", "--cfg4-grid", "96", "--cfg4-phi", "0.2"],
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=1200)
+
+
+_job("bench_own_ranks", _bench_own_ranks)
 
 
 def test_bench_launches_its_own_ranks():
@@ -128,11 +176,7 @@ def test_bench_launches_its_own_ranks():
     config-4 block (shrunk here), the speed-ups against the single GPU of the same run.  On the one-GPU box the ranks share the
     device through the host-staged transport (RCCL needs a GPU per rank)."""
     import json
-    import subprocess
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PSE_TEAM_LANES")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "host", "--steps", "2", "--warmup", "1",
-                        "--no-cpu", "--n", "100000", "--grid", "128", "--cfg4-n", "120000", "--cfg4-grid", "96", "--cfg4-phi", "0.2"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=1200)
+    r = _outcome("bench_own_ranks")
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
@@ -167,20 +211,26 @@ def test_bench_launches_its_own_ranks():
     assert v["particles_that_changed_rank"] > 0, v
 
 
+def _bench_under_launcher():
+    import subprocess
+    port = _free_port()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PSE_TEAM_LANES")}
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                           "--transport", "host", "--no-cpu", "--particles", "100000", "--grid", "128", "--modes", "lanes", "--no-cfg4"],
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900)
+
+
+_job("bench_under_launcher", _bench_under_launcher)
+
+
 def test_bench_as_ranks_of_torch_distributed_run():
     """The driver's own multi-GPU launch line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P bench.py --gpus N --steps K --warmup W`): every worker is then the supervisor of its own rank -- it never touches
     the GPU, starts its rank's process for every segment on a port the supervisors agree on through the launcher's store -- and rank 0
     prints the one merged line (one mode and no extra blocks here: the full sequence is test_bench_launches_its_own_ranks)."""
     import json
-    import socket
-    import subprocess
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PSE_TEAM_LANES")}
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--transport", "host", "--no-cpu", "--particles", "100000", "--grid", "128", "--modes", "lanes", "--no-cfg4"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900)
+    r = _outcome("bench_under_launcher")
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1                                      # rank 0 only
@@ -235,20 +285,26 @@ def _random_worker(rank, seed, port, out):
             pass
 
 
-@pytest.mark.parametrize("seed", [5, 7, 16, 18, 20, 22])
+_RANDOM_SEEDS = [5, 7, 16, 18, 20, 22]
+
+
+def _random_case(seed):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_random_teams import config
+    world = config(seed)["world"]
+    return world, _spawn_ranks(_random_worker, world, lambda r, port, out: (r, seed, port, out))
+
+
+for _s in _RANDOM_SEEDS:
+    _job(("random", _s), lambda s_=_s: _random_case(s_))
+
+
+@pytest.mark.parametrize("seed", _RANDOM_SEEDS)
 def test_random_team_of_processes(seed):
     """Shapes of tests/test_gpu_random_teams.py (non-cubic, sheared, supports up to 13, odd Nz, grids on the generic far-field
     kernels, 240-point mixed-radix x pass) between real processes: the transfer lists of the process-per-rank branch -- the ones
     RCCL posts -- with halo widths and block sizes the 64^3 cases above do not have."""
-    import torch.multiprocessing as mp
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from test_gpu_random_teams import config
-    world = config(seed)["world"]
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_random_worker, args=(r, seed, port, out)) for r in range(world)]
-    res = _run_ranks(procs, out)
+    world, res = _outcome(("random", seed))
     assert sorted(res) == [(r, "ok") for r in range(world)], res
 
 
@@ -330,12 +386,12 @@ def _local_worker(rank, world, port, xy0, n, grid, out):
             pass
 
 
-@pytest.mark.parametrize("world,xy0,n,grid", [(2, 0.1, 40_000, 96), (4, -0.15, 40_000, 96), (8, 0.0, 80_000, 128), (3, 0.47, 30_000, 96)])   # (the last: through a tilt flip)
+_LOCAL_CASES = [(2, 0.1, 40_000, 96), (4, -0.15, 40_000, 96), (8, 0.0, 80_000, 128), (3, 0.47, 30_000, 96)]   # (the last: through a tilt flip)
+for _c in _LOCAL_CASES:
+    _job(("local",) + _c, lambda c=_c: _spawn_ranks(_local_worker, c[0], lambda r, port, out: (r, c[0], port, c[1], c[2], c[3], out)))
+
+
+@pytest.mark.parametrize("world,xy0,n,grid", _LOCAL_CASES)
 def test_owned_particle_team_of_processes_follows_single_gpu(world, xy0, n, grid):
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_local_worker, args=(r, world, port, xy0, n, grid, out)) for r in range(world)]
-    res = _run_ranks(procs, out)
+    res = _outcome(("local", world, xy0, n, grid))
     assert sorted(res) == [(r, "ok") for r in range(world)], res

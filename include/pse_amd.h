@@ -269,12 +269,23 @@ int pse_team_step(pse_team *team, pse_double4 *const *pos, pse_double4 *const *v
  * Shear: the slabs are slabs of the FRACTIONAL x coordinate, so between two calls of pse_set_box that follow the strain
  * continuously an affinely advected particle keeps its slab.  A Lees-Edwards FLIP of the tilt (xy + 0.5 -> - 0.5,
  * PSEv1/VariantShearFunction.cc:34-43) re-maps the fractional x of every particle by its fractional y: the owner of the particle
- * data redistributes them before the next call (what HOOMD's domain decomposition does at a flip; the Python mirror:
- * pse_amd.sharded.*.redistribute) -- a step cannot follow it (flag 8). */
+ * data redistributes them before the next call (what HOOMD's domain decomposition does at a flip): pse_team_redistribute_local
+ * below -- a step cannot follow it (flag 8). */
 int pse_team_step_local(pse_team *team, pse_double4 *const *pos, pse_double4 *const *vel, pse_double3 *const *accel,
                         pse_int3 *const *image, const pse_double4 *const *net_force, unsigned int *const *tag,
                         unsigned int *const *n_local, double kT, double dt, unsigned int timestep, double shear_rate,
                         int integrate, int *lanczos_m);
+/* The Lees-Edwards flip for an owned-particle team: after pse_set_box has taken the tilt of EVERY member through the flip, one call
+ * re-owns every particle by its fractional x under the new box -- any particle may go to any rank -- through the team's own transfer
+ * list (count rows first, then exactly the records that move, in the wire format of the step's first exchange).  Arrays as for
+ * pse_team_step_local (net_force is rewritten too: the rows have a new order; vel.xyz and accel come back zero, vel.w = mass kept);
+ * on return -- the work is queued on the members' streams -- rows [0, *n_local) hold what the rank owns now.  The call waits for the
+ * streams twice (the host sizes the second exchange): it runs once per unit of strain.  If some rank's arrays could not hold what it
+ * would own, NOTHING is moved and every rank returns PSE_ERR_INVALID (every rank sees every count row).
+ * HOOMD call site: where the reference's box-tilt updater wraps the strain (PSEv1/VariantShearFunction.cc:34-43). */
+int pse_team_redistribute_local(pse_team *team, pse_double4 *const *pos, pse_double4 *const *vel, pse_double3 *const *accel,
+                                pse_int3 *const *image, pse_double4 *const *net_force, unsigned int *const *tag,
+                                unsigned int *const *n_local);
 /* Iterations an owned-particle step queues beyond its starting count *lanczos_m, in blocks of two, every kernel of them gated on
  * the device-side decision (default -1: the members' PSE_LANCZOS_EXTRA, 2).  A time-stepping loop whose last steps all ended
  * at their starting count with pse_info.lanczos_status 0 can set 0: the gated block -- one more exchange, seven launches that

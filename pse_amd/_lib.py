@@ -136,6 +136,7 @@ SYMBOLS = {
     "pse_local_layout": (_i, [_vp, _ip, _ip, _ip, _ip, _ip]),
     "pse_team_local_status": (_i, [_vp, _ip]),
     "pse_team_set_lanczos_extra": (_i, [_vp, _i]),
+    "pse_team_redistribute_local": (_i, [_vp] + [ctypes.POINTER(_vp)] * 7),
     "pse_team_set_diag": (_i, [_vp, _i]),
     "pse_team_get_diag": (_i, [_vp, ctypes.POINTER(pse_team_diag)]),
     "pse_host_lanczos_sqrt_e1": (_i, [_i, _dp, _dp, _dp]),

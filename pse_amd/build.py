@@ -47,7 +47,7 @@ def _all_sources():
     return out
 
 
-LIB_UNITS = (("pse_kernels.hip", HIPFLAGS), ("pse_farfield.hip", HIPFLAGS + FARFLAGS), ("pse_capi.hip", HIPFLAGS), ("pse_local.hip", HIPFLAGS),
+LIB_UNITS = (("pse_kernels.hip", HIPFLAGS), ("pse_farfield.hip", HIPFLAGS + FARFLAGS), ("pse_capi.hip", HIPFLAGS), ("pse_local.hip", HIPFLAGS), ("pse_zfft.hip", HIPFLAGS),
              ("pse_params.cpp", ["-x", "c++"]), ("pse_host_api.cpp", ["-x", "c++"]))
 _report = []   # what build_all did, one entry per artefact: (name, "compiled" | "reused")
 

@@ -192,6 +192,10 @@ struct pse_handle {
         LocalRows *rows = nullptr;           // device
         int *counters = nullptr;             // (inside cnt_block: zeroed with the cell counts)
         int *err = nullptr, *err_host = nullptr;   // error word: device, and a pinned word the status call copies it to
+        // pse_team_redistribute_local (allocated at its first call): records out / in (c_own each), the destination of every particle,
+        // the ranks' count rows [G][row] (row = G counts, the rank's capacity, its particle count; an even number of ints), send offsets + fill counters
+        double *rd_send = nullptr, *rd_recv = nullptr;
+        int *rd_rows = nullptr, *rd_off = nullptr, *rd_host = nullptr;
     } loc;
     LzState *lz_state = nullptr;     // the device-side Lanczos decision of queue-only Brownian calls (pse_set_async)
     unsigned long long lz_seq = 0;   // calls that queued one (the decision kernel stamps the host mirror with it)
@@ -325,9 +329,10 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->flags_host) (void)hipHostFree(h->flags_host);
     {
         void *lp[] = {h->loc.send[0], h->loc.send[1], h->loc.recv[0], h->loc.recv[1], h->loc.stage_w1, h->loc.stage_w2, h->loc.porig_s, h->loc.mass_s,
-                      h->loc.image_s, h->loc.raw, h->loc.rows, h->loc.err};
+                      h->loc.image_s, h->loc.raw, h->loc.rows, h->loc.err, h->loc.rd_send, h->loc.rd_recv, h->loc.rd_rows, h->loc.rd_off};
         for (void *q : lp) if (q) (void)hipFree(q);
         if (h->loc.err_host) (void)hipHostFree(h->loc.err_host);
+        if (h->loc.rd_host) (void)hipHostFree(h->loc.rd_host);
     }
     delete h;
     return 0;
@@ -2667,6 +2672,107 @@ extern "C" int pse_team_step_local(pse_team *T, pse_double4 *const *pos, pse_dou
     for (size_t r = 0; r < T->m.size(); ++r)
         ca.push_back(LocalCaller{(double4 *)pos[r], (double4 *)vel[r], (double3 *)accel[r], (int3 *)image[r], (const double4 *)net_force[r], tag[r], n_local[r]});
     return local_call(*T, ca, kT, dt, timestep, shear_rate, integrate, lanczos_m);
+}
+
+// Every particle to the rank that owns it under the CURRENT box (after pse_set_box has taken the tilt through a Lees-Edwards flip):
+// what HOOMD's domain decomposition does when the box is re-mapped (PSEv1/VariantShearFunction.cc:34-43 drives the flip).  Two
+// exchanges of the team's own transfer list around three kernels (pse_local.hip); the host sizes the second exchange from the count
+// rows of the first, so this call WAITS twice -- it runs once per unit of strain.
+static int redistribute_local(pse_team &T, const std::vector<LocalCaller> &ca) {
+    if (T.G < 2) return fail(PSE_ERR_INVALID, "pse_team_redistribute_local needs a team of >= 2 ranks");
+    if (T.solo >= 0) return fail(PSE_ERR_INVALID, "pse_team_redistribute_local: not in solo mode");
+    const int G = T.G, row = (G + 2 + 1) & ~1;      // ints per count row: G counts, capacity, particle count (+ padding to whole doubles)
+    for (size_t r = 0; r < T.m.size(); ++r) {
+        pse_handle *h = T.m[r];
+        if (!h->loc.on) return fail(PSE_ERR_INVALID, "pse_team_redistribute_local: member %zu was not created with local_rows", r);
+        if (h->loc.err_host[0]) return fail(PSE_ERR_INVALID, "owned-particle rank %d: an earlier step failed on the device (flags %d)", h->slab_rank, h->loc.err_host[0]);
+        const LocalCaller &c = ca[r];
+        if (!c.pos || !c.vel || !c.accel || !c.image || !c.force || !c.tag || !c.n_local) return fail(PSE_ERR_INVALID, "null array");
+        HIPCHK(hipSetDevice(h->device));
+        if (!h->loc.rd_send) {
+            const size_t nrec = (size_t)h->loc.g.c_own * LOCAL_REC;
+            TRY(dmalloc(h, &h->loc.rd_send, nrec)); TRY(dmalloc(h, &h->loc.rd_recv, nrec));
+            TRY(dmalloc(h, &h->loc.rd_rows, (size_t)G * row)); TRY(dmalloc(h, &h->loc.rd_off, (size_t)2 * G));
+            HIPCHK(hipHostMalloc((void **)&h->loc.rd_host, ((size_t)G * row + 2 * G) * sizeof(int)));
+            h->info.device_bytes = h->bytes;
+        }
+    }
+    // (1) new owners and the count row of every rank
+    for (size_t r = 0; r < T.m.size(); ++r) {
+        pse_handle *h = T.m[r];
+        HIPCHK(hipSetDevice(h->device));
+        int *mine = h->loc.rd_rows + (size_t)h->slab_rank * row;
+        HIPCHK(hipMemsetAsync(h->loc.rd_rows, 0, (size_t)G * row * sizeof(int), h->stream));
+        launch_redist_count(ca[r], h->loc.g, h->dbox, h->nc, h->keys, mine, h->loc.err, h->stream);
+        HIPCHK(hipMemcpyAsync(mine + G, &h->loc.g.c_own, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(mine + G + 1, ca[r].n_local, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    }
+    TRY(team_run_exchange(T, [&](pse_handle *h) {
+        std::vector<Xfer> ops;
+        for (int p = 0; p < G; ++p) {
+            if (p == h->slab_rank) continue;
+            ops.push_back(Xfer{(const double *)(h->loc.rd_rows + (size_t)h->slab_rank * row), (size_t)row / 2, p,
+                               (double *)(h->loc.rd_rows + (size_t)p * row), (size_t)row / 2, p});
+        }
+        return ops; }, false, DIAG_GHOST));
+    for (pse_handle *h : T.m) {
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipMemcpyAsync(h->loc.rd_host, h->loc.rd_rows, (size_t)G * row * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->loc.err_host, h->loc.err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    }
+    for (pse_handle *h : T.m) { HIPCHK(hipSetDevice(h->device)); HIPCHK(hipStreamSynchronize(h->stream)); }
+    // (2) every rank holds every row: the same verdict everywhere -- nothing moves unless everything fits
+    const int *M = T.m[0]->loc.rd_host;
+    for (pse_handle *h : T.m)
+        if (h->loc.err_host[0]) return fail(PSE_ERR_INVALID, "owned-particle rank %d: flags %d while counting (16: n_local above capacity)", h->slab_rank, h->loc.err_host[0]);
+    for (int d = 0; d < G; ++d) {
+        long in = 0;
+        for (int src = 0; src < G; ++src) in += M[(size_t)src * row + d];
+        if (in > M[(size_t)d * row + G])
+            return fail(PSE_ERR_INVALID, "redistribution: rank %d would own %ld particles, its arrays hold %d (pse_local_layout rows_own): nothing was moved", d, in, M[(size_t)d * row + G]);
+    }
+    // (3) pack by destination, exchange exactly those records, unpack into the caller's arrays
+    for (size_t r = 0; r < T.m.size(); ++r) {
+        pse_handle *h = T.m[r];
+        HIPCHK(hipSetDevice(h->device));
+        int *off = h->loc.rd_host + (size_t)G * row;     // [G] send offsets, then [G] zeros for the fill counters
+        const int *mine = h->loc.rd_host + (size_t)h->slab_rank * row;
+        int acc = 0;
+        for (int d = 0; d < G; ++d) { off[d] = acc; acc += mine[d]; off[G + d] = 0; }
+        HIPCHK(hipMemcpyAsync(h->loc.rd_off, off, 2 * G * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        launch_redist_pack(ca[r], h->loc.g, h->keys, h->loc.rd_off, h->loc.rd_off + G, h->loc.rd_send, h->stream);
+    }
+    TRY(team_run_exchange(T, [&](pse_handle *h) {
+        const int me = h->slab_rank;
+        const int *Mh = h->loc.rd_host;
+        std::vector<Xfer> ops;
+        size_t so = 0, ro = 0;
+        std::vector<size_t> soff(G), roff(G);
+        for (int p = 0; p < G; ++p) { soff[p] = so; so += (size_t)Mh[(size_t)me * row + p]; roff[p] = ro; ro += (size_t)Mh[(size_t)p * row + me]; }
+        for (int p = 0; p < G; ++p) {   // (the diagonal block is a local copy in every transport: team_exchange)
+            const size_t ns = (size_t)Mh[(size_t)me * row + p] * LOCAL_REC, nr = (size_t)Mh[(size_t)p * row + me] * LOCAL_REC;
+            if (ns || nr) ops.push_back(Xfer{h->loc.rd_send + soff[p] * LOCAL_REC, ns, p, h->loc.rd_recv + roff[p] * LOCAL_REC, nr, p});
+        }
+        return ops; }, false, DIAG_FIRST));
+    for (size_t r = 0; r < T.m.size(); ++r) {
+        pse_handle *h = T.m[r];
+        HIPCHK(hipSetDevice(h->device));
+        long in = 0;
+        for (int src = 0; src < G; ++src) in += h->loc.rd_host[(size_t)src * row + h->slab_rank];
+        launch_redist_unpack(h->loc.rd_recv, (int)in, ca[r], h->stream);
+        h->sorted_N = 0; h->nb_valid = false; h->vl_valid = false;
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" int pse_team_redistribute_local(pse_team *T, pse_double4 *const *pos, pse_double4 *const *vel, pse_double3 *const *accel, pse_int3 *const *image,
+                                           pse_double4 *const *net_force, unsigned int *const *tag, unsigned int *const *n_local) {
+    if (!T || !pos || !vel || !accel || !image || !net_force || !tag || !n_local) return fail(PSE_ERR_INVALID, "null argument");
+    std::vector<LocalCaller> ca;
+    for (size_t r = 0; r < T->m.size(); ++r)
+        ca.push_back(LocalCaller{(double4 *)pos[r], (double4 *)vel[r], (double3 *)accel[r], (int3 *)image[r], (const double4 *)net_force[r], tag[r], n_local[r]});
+    return redistribute_local(*T, ca);
 }
 
 extern "C" int pse_local_layout(pse_handle *h, int *rows_own, int *rows_ghost, int *records, int *layers, int *layers_per_rank) {

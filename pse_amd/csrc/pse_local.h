@@ -78,5 +78,12 @@ struct LocalFinish {
     int integrate; double dt, shear_rate;
 };
 void launch_local_finish(const LocalFinish &a, const LocalCaller &c, DBox box, int rows_cap, hipStream_t s);
+// redistribution of the particles among ALL ranks (after a Lees-Edwards flip of the tilt: pse_team_redistribute_local)
+// (1) dest[i] = the rank that owns particle i under the box as it is now, counts[rank] += 1 (counts zeroed by the caller)
+void launch_redist_count(const LocalCaller &c, const LocalGeom &g, DBox box, DCells nc, unsigned *dest, int *counts, int *err, hipStream_t s);
+// (2) the particles as LOCAL_REC-double records, those for rank d at records[send_off[d] ..] (fill[G] zeroed by the caller)
+void launch_redist_pack(const LocalCaller &c, const LocalGeom &g, const unsigned *dest, const int *send_off, int *fill, double *records, hipStream_t s);
+// (3) `total` records -> rows [0, total) of the caller's arrays (velocity and acceleration zero: the next step writes them), *n_local
+void launch_redist_unpack(const double *records, int total, const LocalCaller &c, hipStream_t s);
 
 }  // namespace pse

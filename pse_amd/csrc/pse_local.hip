@@ -41,8 +41,8 @@ __device__ __forceinline__ int block_append(bool want, int *counter, int *sh /* 
     __syncthreads();
     return want ? slot : -1;
 }
-__device__ __forceinline__ void write_record(double *msg, int slot, const double4 &p, const double4 &f, double mass, const int3 &im, unsigned tag) {
-    double2 *r = reinterpret_cast<double2 *>(msg + LOCAL_HDR + (size_t)slot * LOCAL_REC);
+__device__ __forceinline__ void write_record(double *records, int slot, const double4 &p, const double4 &f, double mass, const int3 &im, unsigned tag) {
+    double2 *r = reinterpret_cast<double2 *>(records + (size_t)slot * LOCAL_REC);
     r[0] = make_double2(p.x, p.y); r[1] = make_double2(p.z, p.w);
     r[2] = make_double2(f.x, f.y); r[3] = make_double2(f.z, mass);
     const int4 w = make_int4(im.x, im.y, im.z, (int)tag);      // bit patterns: the transports move bytes
@@ -88,8 +88,8 @@ k_local_classify(LocalCaller c, LocalGeom g, DBox box, DCells nc, LocalPool pool
     __shared__ int sh[TPB / 64 + 1];
     const int sl = block_append(to_l, &counters[0], sh), sr = block_append(to_r, &counters[1], sh);
     // (the numbers of records travel as they are: the two counters are one more transfer of the exchange)
-    if (to_l) { if (sl < g.c_x) write_record(send_l, sl, p, f, mass, im, tag); else atomicOr(err, LOCAL_ERR_MSG); }
-    if (to_r) { if (sr < g.c_x) write_record(send_r, sr, p, f, mass, im, tag); else atomicOr(err, LOCAL_ERR_MSG); }
+    if (to_l) { if (sl < g.c_x) write_record(send_l + LOCAL_HDR, sl, p, f, mass, im, tag); else atomicOr(err, LOCAL_ERR_MSG); }
+    if (to_r) { if (sr < g.c_x) write_record(send_r + LOCAL_HDR, sr, p, f, mass, im, tag); else atomicOr(err, LOCAL_ERR_MSG); }
 }
 void launch_local_classify(const LocalCaller &c, const LocalGeom &g, DBox box, DCells nc, LocalPool pool, double *send_l, double *send_r,
                            int *counters, int *err, hipStream_t s) {
@@ -310,6 +310,81 @@ k_local_finish(LocalFinish a, LocalCaller c, DBox box) {
 }
 void launch_local_finish(const LocalFinish &a, const LocalCaller &c, DBox box, int rows_cap, hipStream_t s) {
     hipLaunchKernelGGL(k_local_finish, dim3(std::min(2048, std::max(1, nblocks(rows_cap, TPB)))), dim3(TPB), 0, s, a, c, box);
+}
+
+// ---- redistribution after a Lees-Edwards flip (pse_team_redistribute_local) ------------------------------------------------------------
+// A flip of the tilt (xy + 0.5 -> - 0.5, PSEv1/VariantShearFunction.cc:34-43) re-maps the fractional x of every particle by its
+// fractional y: any particle may belong to any rank afterwards, which the one-neighbour migration of a step cannot follow.  Three
+// kernels around two exchanges of the team's transfer list: (1) the new owner of every particle and how many go where; [the ranks
+// exchange their count rows; the host sizes the messages]; (2) the records (the wire format of the step's first exchange), packed
+// by destination; [the records travel: exact sizes]; (3) what arrived becomes the caller's arrays.
+__device__ __forceinline__ int wave_append(int dest, bool live, int *counters, int stride_words = 1) {
+    // slot of this lane among the particles of its destination: one atomic per distinct destination of the wave
+    int slot = -1;
+    unsigned long long todo = __ballot(live);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int dd = __shfl(dest, leader);
+        const unsigned long long m = __ballot(live && dest == dd);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&counters[dd * stride_words], __popcll(m));
+        base = __shfl(base, leader);
+        if (live && dest == dd) slot = base + __popcll(m & ((1ull << lane) - 1ull));
+        todo &= ~m;
+    }
+    return slot;
+}
+__global__ void __launch_bounds__(TPB)
+k_redist_count(LocalCaller c, LocalGeom g, DBox box, DCells nc, unsigned *__restrict__ dest, int *__restrict__ counts, int *__restrict__ err) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    const unsigned n_raw = *c.n_local;
+    const int n = (int)min(n_raw, (unsigned)g.c_own);
+    if (i == 0 && n_raw > (unsigned)g.c_own) atomicOr(err, LOCAL_ERR_COUNT);
+    int d = 0;
+    const bool live = i < n;
+    if (live) {
+        const double4 p = c.pos[i];
+        int cx;
+        (void)cell_of(box, nc, p.x, p.y, p.z, cx);
+        d = min(cx / g.per, g.G - 1);
+        dest[i] = (unsigned)d;
+    }
+    (void)wave_append(d, live, counts);
+}
+__global__ void __launch_bounds__(TPB)
+k_redist_pack(LocalCaller c, LocalGeom g, const unsigned *__restrict__ dest, const int *__restrict__ send_off, int *__restrict__ fill,
+              double *__restrict__ records) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    const int n = (int)min(*c.n_local, (unsigned)g.c_own);
+    const bool live = i < n;
+    const int d = live ? (int)dest[i] : 0;
+    const int k = wave_append(d, live, fill);
+    if (live) write_record(records, send_off[d] + k, c.pos[i], c.force[i], c.vel[i].w, c.image[i], c.tag[i]);
+}
+__global__ void __launch_bounds__(TPB)
+k_redist_unpack(const double *__restrict__ records, int total, LocalCaller c) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i == 0) *c.n_local = (unsigned)total;
+    if (i >= total) return;
+    const double2 *r = reinterpret_cast<const double2 *>(records + (size_t)i * LOCAL_REC);
+    const double2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+    const int4 w = *reinterpret_cast<const int4 *>(&r4);
+    c.pos[i] = make_double4(r0.x, r0.y, r1.x, r1.y);
+    const_cast<double4 *>(c.force)[i] = make_double4(r2.x, r2.y, r3.x, 0.0);      // (the caller's force provider would recompute it: the rows have a new order)
+    c.vel[i] = make_double4(0.0, 0.0, 0.0, r3.y);
+    c.accel[i] = make_double3(0.0, 0.0, 0.0);
+    c.image[i] = make_int3(w.x, w.y, w.z);
+    c.tag[i] = (unsigned)w.w;
+}
+void launch_redist_count(const LocalCaller &c, const LocalGeom &g, DBox box, DCells nc, unsigned *dest, int *counts, int *err, hipStream_t s) {
+    hipLaunchKernelGGL(k_redist_count, dim3(nblocks(g.c_own, TPB)), dim3(TPB), 0, s, c, g, box, nc, dest, counts, err);
+}
+void launch_redist_pack(const LocalCaller &c, const LocalGeom &g, const unsigned *dest, const int *send_off, int *fill, double *records, hipStream_t s) {
+    hipLaunchKernelGGL(k_redist_pack, dim3(nblocks(g.c_own, TPB)), dim3(TPB), 0, s, c, g, dest, send_off, fill, records);
+}
+void launch_redist_unpack(const double *records, int total, const LocalCaller &c, hipStream_t s) {
+    hipLaunchKernelGGL(k_redist_unpack, dim3(std::max(1, nblocks(total, TPB))), dim3(TPB), 0, s, records, total, c);
 }
 
 }  // namespace pse

@@ -317,12 +317,7 @@ class Team:
         import torch
         for t in list(pos) + list(vel) + list(force):
             _chk4(t, "pos/vel/force")
-        if getattr(self, "_rows_own", None) is None:     # the step writes up to rows_own rows back (particles migrate in): the arrays must hold them
-            self._rows_own = [e.local_layout()["rows_own"] for e in self.engines]
-        for k, ts in enumerate(zip(pos, vel, force, accel, image, tag)):
-            if any(t.shape[0] < self._rows_own[k] for t in ts):
-                raise ValueError(f"member {k}: pos / vel / force / accel / image / tag need {self._rows_own[k]} rows (rows_own of pse_local_layout), "
-                                 f"not the current particle count")
+        self._check_local_arrays(pos, vel, force, accel, image, tag)
         for a_, im_, tg, nl, p_ in zip(accel, image, tag, n_local, pos):
             _chk_arr(a_, "accel", 3, torch.float64, p_.shape[0]); _chk_arr(im_, "image", 3, torch.int32, p_.shape[0])
             if not (tg.is_cuda and tg.dtype == torch.int32 and tg.is_contiguous() and tg.shape[0] >= p_.shape[0]):
@@ -354,6 +349,21 @@ class Team:
             out["exchange_host_us"].setdefault(k, []).append(round(d.host_us[q], 2))
             out["exchange_bytes"].setdefault(k, []).append(int(d.bytes[q]))
         return out
+
+    def redistribute_local(self, pos, vel, accel, image, force, tag, n_local):
+        """After set_box has taken every member's tilt through a Lees-Edwards flip: every particle to the rank that owns it under the
+        new box (pse_team_redistribute_local; arrays as for step_local, force rewritten too).  Waits for the streams twice."""
+        self._check_local_arrays(pos, vel, force, accel, image, tag)
+        _lib.check(self._lib.pse_team_redistribute_local(self._t, self._ptrs(pos), self._ptrs(vel), self._ptrs(accel), self._ptrs(image),
+                                                         self._ptrs(force), self._ptrs(tag), self._ptrs(n_local)))
+
+    def _check_local_arrays(self, pos, vel, force, accel, image, tag):
+        if getattr(self, "_rows_own", None) is None:     # a step writes up to rows_own rows back (particles migrate in): the arrays must hold them
+            self._rows_own = [e.local_layout()["rows_own"] for e in self.engines]
+        for k, ts in enumerate(zip(pos, vel, force, accel, image, tag)):
+            if any(t.shape[0] < self._rows_own[k] for t in ts):
+                raise ValueError(f"member {k}: pos / vel / force / accel / image / tag need {self._rows_own[k]} rows (rows_own of pse_local_layout), "
+                                 f"not the current particle count")
 
     def set_lanczos_extra(self, extra):
         """Iterations an owned-particle step queues beyond its starting count (pse_team_set_lanczos_extra; -1: the default, gated

@@ -368,8 +368,14 @@ class LocalLoopbackSimulation:
         if flip:
             self.redistribute()
 
-    def redistribute(self):
-        """Every particle to the rank that owns it under the CURRENT box (after a tilt flip; see tilt_flipped) -- synchronises."""
+    def redistribute(self, on_host=False):
+        """Every particle to the rank that owns it under the CURRENT box (after a tilt flip; see tilt_flipped): the engine's own
+        pse_team_redistribute_local.  on_host: the host-side re-ownership (gather, owner_of, reload) the tests hold it against."""
+        S = self.s
+        if not on_host:
+            self.team.redistribute_local([s.pos for s in S], [s.vel for s in S], [s.accel for s in S], [s.image for s in S], [s.force for s in S],
+                                         [s.tag for s in S], [s.n_local for s in S])
+            return
         self.team.local_status()
         parts = [s.state() for s in self.s]
         tag, pos4, image, mass = (np.concatenate([p[k] for p in parts]) for k in range(4))
@@ -439,16 +445,10 @@ class LocalShardedSimulation:
             self.redistribute()
 
     def redistribute(self):
-        """Every particle to the rank that owns it under the CURRENT box (after a tilt flip; see tilt_flipped): an all-gather of the
-        particle state through torch.distributed's default group, on the host -- a flip happens once per unit of strain."""
-        import torch.distributed as dist
-        self.team.local_status()
-        parts = [None] * self.world
-        dist.all_gather_object(parts, self.s.state())
-        tag, pos4, image, mass = (np.concatenate([p[k] for p in parts]) for k in range(4))
-        idx = np.nonzero(owner_of(pos4[:, :3], self.box, self.layout["layers"], self.world) == self.rank)[0]
-        self.s.load_state(tag[idx], pos4[idx], image[idx], mass[idx])
-        self.s.refresh_force(self.force_dev)
+        """Every particle to the rank that owns it under the CURRENT box (after a tilt flip; see tilt_flipped): the engine's own
+        pse_team_redistribute_local, over the team's transport -- nothing passes through Python."""
+        s = self.s
+        self.team.redistribute_local([s.pos], [s.vel], [s.accel], [s.image], [s.force], [s.tag], [s.n_local])
 
     def step(self, kT, dt, timestep, shear_rate=0.0, lanczos_m=2, integrate=True):
         s = self.s

@@ -228,6 +228,9 @@ def test_step_integrates_and_wraps(torch_cuda, oracle):
                                        ((32, 360, 36), 0.1, 4), ((32, 270, 32), 0.0, 4), ((36, 375, 30), 0.0, 4), ((32, 500, 32), -0.2, 4),   # the own y pass (round 4)
                                        ((36, 256, 30), 0.2, 4), ((256, 256, 32), 0.0, 4),   # the register y pass at Ny = 256 (round 4)
                                        ((32, 256, 256), 0.0, 4), ((32, 512, 512), 0.0, 4), ((32, 256, 512), 0.15, 4), ((32, 512, 256), 0.2, 4), ((36, 360, 256), -0.1, 4),   # the own z pass (k_zfft_rows, Nz = 256 / 512) and the register y pass at Ny = 512 (round 5)
+                                       ((32, 36, 360), 0.1, 4), ((32, 40, 270), 0.0, 4), ((36, 36, 180), -0.2, 4), ((32, 36, 240), 0.0, 4), ((32, 36, 300), 0.15, 4),
+                                       ((32, 36, 320), 0.0, 4), ((32, 36, 384), 0.0, 4), ((32, 36, 400), 0.1, 4), ((32, 36, 450), 0.0, 4), ((32, 36, 480), -0.1, 4),
+                                       ((32, 36, 500), 0.0, 4), ((36, 256, 360), 0.2, 4),   # the own z pass at the other sizes of the reference's rule (k_zfft_rows_g, round 6)
                                        ((512, 32, 32), -0.1, 4)])  # the last in a box twice as long in x
 def test_fused_x_pass_matches_port(torch_cuda, oracle, grid, xy, P):
     _check_far_field_passes(oracle, grid, xy, P)
@@ -237,7 +240,7 @@ def test_fused_x_pass_matches_port(torch_cuda, oracle, grid, xy, P):
 # register x passes (256, 360, 512), a runtime-plan size, the own y pass (360: k_fft_cols; 256, 512: k_yfft_regs), the own z pass
 @pytest.mark.parametrize("grid,xy,P", [((256, 32, 32), 0.2, 4), ((360, 32, 32), 0.1, 4), ((512, 32, 32), -0.1, 4), ((240, 32, 32), 0.15, 4),
                                        ((64, 48, 40), 0.3, 0), ((32, 360, 36), 0.1, 4), ((36, 256, 30), 0.2, 4), ((32, 512, 256), 0.2, 4),
-                                       ((32, 256, 512), 0.15, 4)])
+                                       ((32, 256, 512), 0.15, 4), ((32, 36, 360), 0.1, 4), ((36, 36, 180), -0.2, 4), ((32, 40, 270), 0.0, 4)])
 def test_far_field_passes_at_the_switch_sizes(torch_cuda, oracle, grid, xy, P):
     _check_far_field_passes(oracle, grid, xy, P)
 
@@ -251,7 +254,9 @@ def _check_far_field_passes(oracle, grid, xy, P):
     500 = 5 5 5 4 are the sizes of the reference's rule at BASELINE configs 3 and 4), rocFFT keeping the 1-D z transforms; Ny = 256
     takes k_yfft_regs (the stages of the register x pass, natural order in and out).  Since round 5 Nz = 256 and 512 take the own z
     pass (k_zfft_rows: a wavefront per row, real <-> half spectrum in one kernel) wherever the y pass is the engine's own, and Ny = 512
-    takes k_yfft_regs as well: rocFFT is then off the path altogether."""
+    takes k_yfft_regs as well: rocFFT is then off the path altogether.  Since round 6 the even sizes of the reference's rule between 180
+    and 500 take the own z pass too (k_zfft_rows_g in pse_zfft.hip: NC = Nz / 2 = R0 x R1 x R2 -- 360 = 2 x 3 x 6 x 10 is the grid the
+    rule picks at the metric point)."""
     import pse_amd
     n = 1200
     pos, force, box = make_suspension(n, L=24.0, xy=xy)

@@ -55,9 +55,14 @@ CASES = [
 def _run_case(case):
     env, files, expr = case
     e = dict(os.environ, **env)
+    # the children run ten at a time and the oracle they check against is OpenMP code: with the default (all cores each) ten of them
+    # oversubscribe the host ten times over -- the far-field cases took 130-140 s each that way, 10-20 s with a share of the cores
+    e["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 8) // 10))
+    import time
+    t0 = time.time()
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", *[os.path.join(ROOT, "tests", f) for f in files], "-k", expr],
                        env=e, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    return r.returncode, r.stdout[-3000:]
+    return r.returncode, r.stdout[-3000:], time.time() - t0
 
 
 _results = {}
@@ -72,11 +77,18 @@ def _result(idx):
         with ThreadPoolExecutor(max_workers=10) as pool:
             for i, out in enumerate(pool.map(_run_case, CASES)):
                 _results[i] = out
+        try:     # (where the time of this module goes: one line per child, for whoever trims the suite)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "switch_children_seconds.txt"), "w") as f:
+                for i, c in enumerate(CASES):
+                    f.write(f"{_results[i][2]:7.1f} s  rc {_results[i][0]}  {c[0]}  {c[2]}\n")
+        except OSError:
+            pass
     return _results[idx]
 
 
 @pytest.mark.parametrize("idx", range(len(CASES)), ids=[",".join(f"{k}={v}" for k, v in c[0].items()) for c in CASES])
 def test_switch(idx):
-    rc, tail = _result(idx)
+    rc, tail, _seconds = _result(idx)
     assert rc == 0, tail
     assert " passed" in tail and "no tests ran" not in tail, tail      # the expression selected something

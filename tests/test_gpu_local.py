@@ -419,3 +419,70 @@ def test_steady_state_steps_queue_no_gated_block():
     assert lc.m == mr and lc.extras_off and seen[-1][2:] == (mr, 0), seen
     lc.seen(mr, 1)
     assert lc.m == mr + 2 and not lc.extras_off
+
+
+@pytest.mark.parametrize("world,xy_new,n,grid", [(2, -0.45, 30_000, 64), (4, -0.45, 30_000, 64), (8, -0.45, 80_000, 128)])
+def test_redistribution_through_the_c_abi_matches_the_host(world, xy_new, n, grid):
+    """pse_team_redistribute_local: after the box's tilt has jumped (a Lees-Edwards flip re-maps fractional x by fractional y) every
+    particle goes to the rank that owns it under the new box -- any rank, not only a neighbour -- through the team's own transfer list.
+    Against the host-side re-ownership (gather, owner_of, reload): the same particles on the same ranks, bit-identical positions,
+    images, masses and forces; nothing moved when a rank's arrays could not hold what it would own."""
+    import torch
+    import pse_amd
+    from pse_amd.sharded import LocalLoopbackSimulation, owner_of
+    pos, force, box = make_suspension(n, phi=0.1, xy=0.45)
+    kw = _kw(box, grid)
+    sims = [LocalLoopbackSimulation(n, box, world, **kw) for _ in range(2)]
+    for s in sims:
+        s.load(pos, force, mass=1.0)
+        for st in s.s:   # distinct masses and images, so that a mix-up of rows shows
+            k = int(st.n_local.item())
+            st.vel[:k, 3] = 1.0 + st.tag[:k].double() * 1e-3
+            st.image[:k, 0] = st.tag[:k] % 5 - 2
+    dev, host = sims
+    newbox = (box[0], box[1], box[2], xy_new)
+    for s in sims:
+        for e in s.engines:
+            e.set_box(*newbox)
+        s.box = newbox
+    dev.redistribute()
+    host.redistribute(on_host=True)
+    dev.team.local_status()
+    own = owner_of(pos, newbox, dev.layout["layers"], world)
+    moved_far = 0
+    for r in range(world):
+        a, b = dev.s[r], host.s[r]
+        ka, kb = int(a.n_local.item()), int(b.n_local.item())
+        assert ka == kb == int((own == r).sum()), (r, ka, kb)
+        ia, ib = np.argsort(a.tag[:ka].cpu().numpy()), np.argsort(b.tag[:kb].cpu().numpy())
+        ta = a.tag[:ka].cpu().numpy()[ia]
+        assert np.array_equal(ta, b.tag[:kb].cpu().numpy()[ib]) and np.array_equal(np.sort(np.nonzero(own == r)[0]), ta)
+        assert np.array_equal(a.pos[:ka].cpu().numpy()[ia], b.pos[:kb].cpu().numpy()[ib])
+        assert np.array_equal(a.image[:ka].cpu().numpy()[ia], b.image[:kb].cpu().numpy()[ib])
+        assert np.array_equal(a.vel[:ka, 3].cpu().numpy()[ia], b.vel[:kb, 3].cpu().numpy()[ib])
+        assert np.array_equal(a.force[:ka, :3].cpu().numpy()[ia], force[ta])
+        assert float(a.vel[:ka, :3].abs().max()) == 0.0
+    own_before = owner_of(pos, box, dev.layout["layers"], world)
+    moved_far = int((np.abs((own - own_before + world // 2) % world - world // 2) > 1).sum()) if world > 2 else int((own != own_before).sum())
+    assert moved_far > n // 20, moved_far          # not a neighbour migration: particles crossed to ranks further away
+    # and the team steps on from there exactly as a freshly loaded one does
+    dev.step(0.0, 1e-3, 0, integrate=False)
+    fresh = LocalLoopbackSimulation(n, newbox, world, **kw)
+    fresh.load(pos, force, mass=1.0)
+    fresh.step(0.0, 1e-3, 0, integrate=False)
+    _, ua, _, _ = dev.gather()
+    _, ub, _, _ = fresh.gather()
+    assert rel(ua, ub) < 1e-12
+    # a rank whose arrays cannot hold what it would own: nothing moves, every rank is told
+    tight = LocalLoopbackSimulation(n, box, world, **kw)
+    tight.load(pos, force, mass=1.0)
+    squeezed = pos.copy()
+    fx_mid = (0.5 / world)                                      # everything into rank 0's slab (under the box as it is)
+    squeezed[:, 0] = (fx_mid - 0.5) * box[0] * 0.5 + box[3] * squeezed[:, 1]
+    for r, st in enumerate(tight.s):
+        k = int(st.n_local.item())
+        st.pos[:k, :3] = torch.tensor(squeezed[st.tag[:k].cpu().numpy()], dtype=torch.float64, device="cuda")
+    before = [int(st.n_local.item()) for st in tight.s]
+    with pytest.raises(pse_amd.PSEError, match="nothing was moved"):
+        tight.redistribute()
+    assert [int(st.n_local.item()) for st in tight.s] == before

@@ -188,9 +188,11 @@ struct pse_handle {
         size_t msg = 0;                      // doubles per message
         double4 *stage_w1 = nullptr, *stage_w2 = nullptr;   // the last layers of w1, w2 on their way to the right neighbour (c_g rows each)
         double4 *porig_s = nullptr; double *mass_s = nullptr; int3 *image_s = nullptr;
-        int *raw = nullptr;                  // scan of the cell counts before the regions are moved to their bases
         LocalRows *rows = nullptr;           // device
         int *counters = nullptr;             // (inside cnt_block: zeroed with the cell counts)
+        int *layer_cnt = nullptr;            // (likewise) kept particles per x layer of the cell grid: LOCAL_MAX_LAYERS ints
+        size_t zero_ints = 0;                // ints of cnt_block a step starts from zero
+        bool zeroed = false;                 // the last step's k_local_finish has cleared them (else: a memset in front of the step)
         int *err = nullptr, *err_host = nullptr;   // error word: device, and a pinned word the status call copies it to
         // pse_team_redistribute_local (allocated at its first call): records out / in (c_own each), the destination of every particle,
         // the ranks' count rows [G][row] (row = G counts, the rank's capacity, its particle count; an even number of ints), send offsets + fill counters
@@ -329,7 +331,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->flags_host) (void)hipHostFree(h->flags_host);
     {
         void *lp[] = {h->loc.send[0], h->loc.send[1], h->loc.recv[0], h->loc.recv[1], h->loc.stage_w1, h->loc.stage_w2, h->loc.porig_s, h->loc.mass_s,
-                      h->loc.image_s, h->loc.raw, h->loc.rows, h->loc.err, h->loc.rd_send, h->loc.rd_recv, h->loc.rd_rows, h->loc.rd_off};
+                      h->loc.image_s, h->loc.rows, h->loc.err, h->loc.rd_send, h->loc.rd_recv, h->loc.rd_rows, h->loc.rd_off};
         for (void *q : lp) if (q) (void)hipFree(q);
         if (h->loc.err_host) (void)hipHostFree(h->loc.err_host);
         if (h->loc.rd_host) (void)hipHostFree(h->loc.rd_host);
@@ -564,8 +566,12 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     // layout in ints: [0, B - 1) bin counts (incl. sentinel, padded) | B - 1: flags[0] | B: flags[1] | B + 4 ...: cell counts.  B and every
     // memset size are multiples of four ints: a memset that is not a multiple of 16 bytes takes two fill kernels.
     h->cnt_bins = ((fast_far ? nbins + 1 : 0) + 1 + 3) & ~(size_t)3;   // B
-    TRY(dmalloc(h, &h->cnt_block, h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8 + LOCAL_NCOUNTER + 2));
+    constexpr size_t LOCAL_MAX_LAYERS = 512;   // (cell layers along x of an owned-particle rank's grid: the per-layer counts of its sort)
+    TRY(dmalloc(h, &h->cnt_block, h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8 + LOCAL_NCOUNTER + 2 + LOCAL_MAX_LAYERS + 4));
     h->loc.counters = h->cnt_block + ((h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8 + 1) & ~(size_t)1);   // 8-byte aligned
+    h->loc.layer_cnt = h->loc.counters + LOCAL_NCOUNTER;
+    h->loc.zero_ints = ((size_t)(h->loc.layer_cnt - h->cnt_block) + LOCAL_MAX_LAYERS + 3) & ~(size_t)3;
+    if (h->nc.nx > (int)LOCAL_MAX_LAYERS && p->local_rows) return fail(PSE_ERR_INVALID, "more than %zu cell layers along x", LOCAL_MAX_LAYERS);
     h->vl.flags = h->cnt_block + h->cnt_bins - 1;
     h->gate_word = h->cnt_block + h->cnt_bins + 1;   // (B + 1: between flags[1] and the cell counts; no memset covers it alone)
     h->cell_cnt = h->cnt_block + h->cnt_bins + 4;
@@ -647,7 +653,6 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         for (int q = 0; q < 2; ++q) { TRY(dmalloc(h, &L.send[q], L.msg)); TRY(dmalloc(h, &L.recv[q], L.msg)); HIPCHK(hipMemset(L.recv[q], 0, L.msg * sizeof(double))); }
         TRY(dmalloc(h, &L.stage_w1, (size_t)c_g)); TRY(dmalloc(h, &L.stage_w2, (size_t)c_g));
         TRY(dmalloc(h, &L.porig_s, (size_t)c_own)); TRY(dmalloc(h, &L.mass_s, (size_t)c_own)); TRY(dmalloc(h, &L.image_s, (size_t)c_own));
-        TRY(dmalloc(h, &L.raw, h->n_cells_alloc + 1));
         TRY(dmalloc(h, &L.rows, 1));
         TRY(dmalloc(h, &L.err, 4));
         HIPCHK(hipMemset(L.err, 0, 4 * sizeof(int)));
@@ -2255,10 +2260,12 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
     for (size_t r = 0; r < T.m.size(); ++r) {
         pse_handle *h = T.m[r];
         if (T.solo >= 0 && h->slab_rank != T.solo) continue;
-        const size_t block = (h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8 + LOCAL_NCOUNTER + 2) & ~(size_t)3;
-        HIPCHK(hipMemsetAsync(h->cnt_block, 0, block * sizeof(int), h->stream));
+        // (the counters of a step -- bins, cells, layers, messages -- were cleared by the last step's k_local_finish; a first step, or
+        // one after a call that did not reach its end, clears them here)
+        if (!h->loc.zeroed) HIPCHK(hipMemsetAsync(h->cnt_block, 0, h->loc.zero_ints * sizeof(int), h->stream));
+        h->loc.zeroed = false;
         const LocalPool pool{h->keys, h->keys_s, h->perm, h->cell_cnt};
-        launch_local_classify(ca[r], h->loc.g, h->dbox, h->nc, pool, h->loc.send[0], h->loc.send[1], h->loc.counters, h->loc.err, h->stream);
+        launch_local_classify(ca[r], h->loc.g, h->dbox, h->nc, pool, h->loc.send[0], h->loc.send[1], h->loc.counters, h->loc.err, h->loc.layer_cnt, h->stream);
     }
     TRY(stage("classify"));
     // (2) ONE exchange: my left message goes left, what arrives from the right is the right neighbour's left message
@@ -2281,10 +2288,10 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
         const LocalPool pool{h->keys, h->keys_s, h->perm, h->cell_cnt};
         const int ncell = cells_total(h->nc);
         if ((size_t)ncell > h->n_cells_alloc) return fail(PSE_ERR_INVALID, "cell grid exceeds the capacity sized at creation");
-        launch_local_bin_incoming(h->loc.recv[0], h->loc.recv[1], h->loc.g, h->dbox, h->nc, pool, h->loc.err, h->stream);
-        HIPCHK(launch_cell_scan(h->cell_cnt, h->loc.raw, ncell + 1, h->sort_tmp, h->sort_tmp_bytes, h->stream));
+        launch_local_bin_incoming(h->loc.recv[0], h->loc.recv[1], h->loc.g, h->dbox, h->nc, pool, h->loc.err, h->loc.layer_cnt, h->stream);
         const LocalRegions rg = local_regions(h);
-        launch_local_scatter(h->loc.raw, h->cell_off, h->loc.g, rg, pool, h->vals, h->loc.rows, h->loc.err, h->stream);
+        launch_local_offsets(h->cell_cnt, h->loc.layer_cnt, h->cell_off, h->loc.g, rg, layer_cells(h->nc), h->loc.rows, h->loc.err, h->stream);
+        launch_local_scatter(h->cell_off, h->loc.g, pool, h->vals, h->loc.rows, h->stream);
         const FarBinArgs far = far_bin_args(h->G, h->sw);
         const LocalSorted out{h->pos_s, h->posf_s, h->pv, h->f_s, h->tag_s, h->loc.porig_s, h->loc.mass_s, h->loc.image_s, noise ? h->psi_s : nullptr};
         launch_local_permute(ca[r], h->loc.recv[0], h->loc.recv[1], h->loc.g, h->dbox, h->cell_off, pool, h->vals, h->loc.rows, out, &far, h->par.seed,
@@ -2334,6 +2341,7 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
         }
         LocalFinish f{};
         f.rows = h->loc.rows; f.st = noise ? h->lz_state : nullptr;
+        f.zero = h->cnt_block; f.n_zero = (int)h->loc.zero_ints;
         f.psi_s = h->psi_s; f.V = h->V; f.stride = h->n_pad; f.scal = h->scal; f.scale = noise ? std::sqrt(2.0 * kT / dt) : 0.0;
         f.uw_s = h->uw_s; f.ur_s = h->ur_s;
         f.porig_s = h->loc.porig_s; f.f_s = h->f_s; f.mass_s = h->loc.mass_s; f.image_s = h->loc.image_s; f.tag_s = h->tag_s;
@@ -2341,6 +2349,7 @@ static int local_call(pse_team &T, const std::vector<LocalCaller> &ca, double kT
         launch_local_finish(f, ca[r], h->dbox, h->loc.g.c_own, h->stream);
         HIPCHK(hipMemcpyAsync(h->loc.err_host, h->loc.err, sizeof(int), hipMemcpyDeviceToHost, h->stream));   // (read by the NEXT call: nothing waits)
         HIPCHK(hipGetLastError());
+        h->loc.zeroed = true;
     }
     diag_mark(T, 1, act(T)[0]->stream);
     return 0;

@@ -50,15 +50,17 @@ struct LocalPool {       // per particle of the pool (own arrays + both incoming
 };
 // (1) every particle of the caller's arrays: its cell; the particles in (or beyond) the boundary layers go into the messages for
 // the neighbours (full records: the neighbour becomes the owner of those that have left the slab); what the rank keeps is counted
+// (layer_cnt: kept particles per x layer, nc.nx ints zeroed with the cell counts -- what k_local_offsets starts the layers from)
 void launch_local_classify(const LocalCaller &c, const LocalGeom &g, DBox box, DCells nc, LocalPool pool, double *send_l, double *send_r,
-                           int *counters, int *err, hipStream_t s);
+                           int *counters, int *err, int *layer_cnt, hipStream_t s);
 // (2) the records that arrived: their cells, counted with the rest
 void launch_local_bin_incoming(const double *recv_l, const double *recv_r, const LocalGeom &g, DBox box, DCells nc, LocalPool pool, int *err,
-                               hipStream_t s);
-// (3) after the scan of the counts (raw): offsets of the kept cells with every region at its fixed base, the slot of every kept
-// particle, and the row ranges of the step (LocalRows)
-void launch_local_scatter(const int *raw, int *cell_off, const LocalGeom &g, const LocalRegions &rg, LocalPool pool, unsigned *slots,
+                               int *layer_cnt, hipStream_t s);
+// (3) offsets of the kept cells with every region at its fixed base and the row ranges of the step (LocalRows): a workgroup per
+// kept layer, no grid-wide scan; then the slot of every kept particle
+void launch_local_offsets(const int *cell_cnt, const int *layer_cnt, int *cell_off, const LocalGeom &g, const LocalRegions &rg, int layer_cells,
                           LocalRows *rows, int *err, hipStream_t s);
+void launch_local_scatter(const int *cell_off, const LocalGeom &g, LocalPool pool, unsigned *slots, const LocalRows *rows, hipStream_t s);
 // (4) the rows themselves: ordered by tag inside their cell, gathered from the caller's arrays or from a message
 struct LocalSorted {
     double4 *pos_s; float4 *posf_s; double2 *pv; double4 *f_s; unsigned *tag_s; double4 *porig_s; double *mass_s; int3 *image_s;
@@ -72,6 +74,7 @@ void launch_local_permute(const LocalCaller &c, const double *recv_l, const doub
 // order -- the caller's particles are then exactly the rank's own rows, *n_local their number
 struct LocalFinish {
     const LocalRows *rows; const LzState *st;
+    int *zero; int n_zero;                   // counters the NEXT step starts from zero (bin, cell and layer counts, message counters): cleared here, not by a memset in front of it
     const double4 *psi_s, *V; size_t stride; const double *scal; double scale;
     const double4 *uw_s, *ur_s;              // far field, near field (either may be null)
     const double4 *porig_s, *f_s; const double *mass_s; const int3 *image_s; const unsigned *tag_s;

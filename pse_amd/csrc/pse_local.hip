@@ -49,9 +49,23 @@ __device__ __forceinline__ void write_record(double *records, int slot, const do
     r[4] = *reinterpret_cast<const double2 *>(&w);
 }
 
+// layer_cnt[cx] += 1 for every lane that keeps its particle: one atomic per distinct layer of the wave (the rows come in the cell order
+// of the last step: a wave's particles sit in one or two layers)
+__device__ __forceinline__ void count_layers(int cx, bool keep, int *__restrict__ layer_cnt) {
+    unsigned long long todo = __ballot(keep);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int cc = __shfl(cx, leader);
+        const unsigned long long m = __ballot(keep && cx == cc);
+        if (lane == leader) atomicAdd(&layer_cnt[cc], __popcll(m));
+        todo &= ~m;
+    }
+}
+
 __global__ void __launch_bounds__(TPB)
 k_local_classify(LocalCaller c, LocalGeom g, DBox box, DCells nc, LocalPool pool, double *__restrict__ send_l, double *__restrict__ send_r,
-                 int *__restrict__ counters, int *__restrict__ err) {
+                 int *__restrict__ counters, int *__restrict__ err, int *__restrict__ layer_cnt) {
     const int i = blockIdx.x * TPB + threadIdx.x;
     const unsigned n_raw = *c.n_local;
     const int n = (int)min(n_raw, (unsigned)g.c_own);
@@ -61,9 +75,10 @@ k_local_classify(LocalCaller c, LocalGeom g, DBox box, DCells nc, LocalPool pool
     double mass = 0.0;
     int3 im = make_int3(0, 0, 0);
     unsigned tag = 0;
+    int cx = 0;
+    bool kept = false;
     if (i < n) {
         p = c.pos[i];
-        int cx;
         const unsigned key = cell_of(box, nc, p.x, p.y, p.z, cx);
         const int s = rel_layer(cx, g);
         // what the neighbours need: their ghosts (my first / last `depth` layers) and the particles that have left the slab on their side
@@ -74,6 +89,7 @@ k_local_classify(LocalCaller c, LocalGeom g, DBox box, DCells nc, LocalPool pool
         // beyond the layers the neighbour shares with ITS other neighbour: more than a slab (less the ghost depth) in one step
         if (s < -(g.per - g.depth) || s >= 2 * g.per - g.depth) atomicOr(err, LOCAL_ERR_FAR);
         const bool keep = s >= -g.depth && s < g.per + g.depth;
+        kept = keep;
         if (keep) {
             pool.keys[i] = key;
             pool.rank[i] = (unsigned)atomicAdd(&pool.cnt[key], 1);
@@ -85,6 +101,7 @@ k_local_classify(LocalCaller c, LocalGeom g, DBox box, DCells nc, LocalPool pool
     } else if (i < g.c_own) {
         pool.keys[i] = KEY_FOREIGN;
     }
+    count_layers(cx, kept, layer_cnt);
     __shared__ int sh[TPB / 64 + 1];
     const int sl = block_append(to_l, &counters[0], sh), sr = block_append(to_r, &counters[1], sh);
     // (the numbers of records travel as they are: the two counters are one more transfer of the exchange)
@@ -92,15 +109,13 @@ k_local_classify(LocalCaller c, LocalGeom g, DBox box, DCells nc, LocalPool pool
     if (to_r) { if (sr < g.c_x) write_record(send_r + LOCAL_HDR, sr, p, f, mass, im, tag); else atomicOr(err, LOCAL_ERR_MSG); }
 }
 void launch_local_classify(const LocalCaller &c, const LocalGeom &g, DBox box, DCells nc, LocalPool pool, double *send_l, double *send_r,
-                           int *counters, int *err, hipStream_t s) {
-    hipLaunchKernelGGL(k_local_classify, dim3(nblocks(g.c_own, TPB)), dim3(TPB), 0, s, c, g, box, nc, pool, send_l, send_r, counters, err);
+                           int *counters, int *err, int *layer_cnt, hipStream_t s) {
+    hipLaunchKernelGGL(k_local_classify, dim3(nblocks(g.c_own, TPB)), dim3(TPB), 0, s, c, g, box, nc, pool, send_l, send_r, counters, err, layer_cnt);
 }
 
-__global__ void __launch_bounds__(TPB)
-k_local_bin_incoming(const double *__restrict__ recv_l, const double *__restrict__ recv_r, LocalGeom g, DBox box, DCells nc, LocalPool pool,
-                     int *__restrict__ err) {
-    const int q = blockIdx.x * TPB + threadIdx.x;
-    if (q >= 2 * g.c_x) return;
+__device__ __forceinline__ bool bin_one(int q, int &cx, const double *__restrict__ recv_l, const double *__restrict__ recv_r, const LocalGeom &g, const DBox &box,
+                                        const DCells &nc, const LocalPool &pool, int *__restrict__ err) {
+    if (q >= 2 * g.c_x) return false;
     const int side = q / g.c_x, k = q - side * g.c_x;
     const double *m = side == 0 ? recv_l : recv_r;
     const int pid = g.c_own + q;
@@ -108,10 +123,9 @@ k_local_bin_incoming(const double *__restrict__ recv_l, const double *__restrict
     // neighbour is its right message, what came from the right neighbour its left one
     const int cnt = reinterpret_cast<const int *>(m)[side == 0 ? 1 : 0];
     if (cnt < 0 || cnt > g.c_x) { if (k == 0) atomicOr(err, LOCAL_ERR_MSG); }   // (the sender flags its own overflow; it sent c_x records)
-    if (k >= min(cnt, g.c_x)) { pool.keys[pid] = KEY_FOREIGN; return; }
+    if (k >= min(cnt, g.c_x)) { pool.keys[pid] = KEY_FOREIGN; return false; }
     const double2 *r = reinterpret_cast<const double2 *>(m + LOCAL_HDR + (size_t)k * LOCAL_REC);
     const double2 a = r[0], b = r[1];
-    int cx;
     const unsigned key = cell_of(box, nc, a.x, a.y, b.x, cx);
     const int s = rel_layer(cx, g);
     if (s >= -g.depth && s < g.per + g.depth) {
@@ -119,37 +133,57 @@ k_local_bin_incoming(const double *__restrict__ recv_l, const double *__restrict
         pool.rank[pid] = (unsigned)atomicAdd(&pool.cnt[key], 1);
         const double2 w2 = r[4];
         pool.ptag[pid] = (unsigned)reinterpret_cast<const int4 *>(&w2)->w;
-    } else {
-        pool.keys[pid] = KEY_FOREIGN;
+        return true;
     }
+    pool.keys[pid] = KEY_FOREIGN;
+    return false;
+}
+__global__ void __launch_bounds__(TPB)
+k_local_bin_incoming(const double *__restrict__ recv_l, const double *__restrict__ recv_r, LocalGeom g, DBox box, DCells nc, LocalPool pool,
+                     int *__restrict__ err, int *__restrict__ layer_cnt) {
+    const int q = blockIdx.x * TPB + threadIdx.x;
+    int cx = 0;
+    const bool kept = bin_one(q, cx, recv_l, recv_r, g, box, nc, pool, err);
+    count_layers(cx, kept, layer_cnt);
 }
 void launch_local_bin_incoming(const double *recv_l, const double *recv_r, const LocalGeom &g, DBox box, DCells nc, LocalPool pool, int *err,
-                               hipStream_t s) {
-    hipLaunchKernelGGL(k_local_bin_incoming, dim3(nblocks(2 * g.c_x, TPB)), dim3(TPB), 0, s, recv_l, recv_r, g, box, nc, pool, err);
+                               int *layer_cnt, hipStream_t s) {
+    hipLaunchKernelGGL(k_local_bin_incoming, dim3(nblocks(2 * g.c_x, TPB)), dim3(TPB), 0, s, recv_l, recv_r, g, box, nc, pool, err, layer_cnt);
 }
 
-__global__ void __launch_bounds__(TPB)
-k_local_scatter(const int *__restrict__ raw, int *__restrict__ cell_off, LocalGeom g, LocalRegions rg, LocalPool pool,
-                unsigned *__restrict__ slots, LocalRows *__restrict__ rows, int *__restrict__ err) {
-    // where the regions begin in the scan of all cells, and how many rows they hold: the same few words for every thread
-    int sh[3], nq[3];
+// Row offsets of the cells a rank keeps, ONE launch without a grid-wide scan (was: rocPRIM's two-kernel scan over ALL cells of the box --
+// 1.1 M at config 4 -- and the region arithmetic in the scatter): classify / bin_incoming have counted the kept particles per x LAYER
+// (a handful of atomics per wave), so the first row of every layer is a sum of at most per + 2 depth numbers, and a workgroup per
+// kept layer scans that layer's cells on its own.  Block 0 also derives the row ranges of the step (LocalRows) from the layer counts.
+constexpr int OFF_TPB = 1024;
+__global__ void __launch_bounds__(OFF_TPB)
+k_local_offsets(const int *__restrict__ cell_cnt, const int *__restrict__ layer_cnt, int *__restrict__ cell_off, LocalGeom g, LocalRegions rg, int lc,
+                LocalRows *__restrict__ rows, int *__restrict__ err) {
+    // the kept layers in region order: own (per), left ghosts (depth), right ghosts (depth); layer index of block b, its region q
+    const int b = blockIdx.x;
+    const int q = b < g.per ? 0 : (b < g.per + g.depth ? 1 : 2);
+    const int in_q = b - (q == 0 ? 0 : (q == 1 ? g.per : g.per + g.depth));
+    const int l0[3] = {rg.c0[0] / lc, rg.c0[1] / lc, rg.c0[2] / lc};        // first layer of every region (regions are whole layers)
+    const int nl[3] = {g.per, g.depth, g.depth};
+    int nq[3];
     bool ok = true;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const int s0 = raw[rg.c0[q]];
-        nq[q] = raw[rg.c1[q] - 1] - s0;                   // (the last storage cell of a layer is empty: its offset ends the region)
-        sh[q] = rg.base[q] - s0;
-        ok = ok && nq[q] <= rg.cap[q];
+    for (int r = 0; r < 3; ++r) {
+        int t = 0;
+        for (int k = 0; k < nl[r]; ++k) t += layer_cnt[l0[r] + k];
+        nq[r] = t;
+        ok = ok && t <= rg.cap[r];
     }
     // The boundary layers of the own rows are what the NEIGHBOURS hold as ghosts, and what the Lanczos blocks send them in messages of
     // c_g rows (the first `depth` layers as they lie, the last ones parked in stage_w1 / stage_w2, c_g rows each): more than c_g rows
     // in either is the neighbour's ghost overflow seen from this side -- the step must not run here either (the mat-vecs would park
     // rows beyond their staging buffers).
-    const int first_end = raw[rg.c_first_end] + sh[0], last_begin = raw[rg.c_last_begin] + sh[0];
+    int first_end = 0, last_begin = 0;
+    for (int k = 0; k < g.depth; ++k) first_end += layer_cnt[l0[0] + k];
+    for (int k = 0; k < g.per - g.depth; ++k) last_begin += layer_cnt[l0[0] + k];
     const bool edge_ok = first_end <= rg.cap[1] && nq[0] - last_begin <= rg.cap[2];
     ok = ok && edge_ok;
-    const int t = blockIdx.x * TPB + threadIdx.x, nt = gridDim.x * TPB;
-    if (t == 0) {
+    if (b == 0 && threadIdx.x == 0) {
         LocalRows r{};
         if (!ok) {
             atomicOr(err, (nq[0] > rg.cap[0] ? LOCAL_ERR_OWN : 0) | ((nq[1] > rg.cap[1] || nq[2] > rg.cap[2] || !edge_ok) ? LOCAL_ERR_GHOST : 0));
@@ -159,7 +193,9 @@ k_local_scatter(const int *__restrict__ raw, int *__restrict__ cell_off, LocalGe
             r.n_own = nq[0]; r.n_gl = nq[1]; r.n_gr = nq[2];
             r.first_end = first_end;
             r.last_begin = last_begin;
-            const int gl_adj = raw[rg.c_gl_adj] + sh[1], gr_adj_end = raw[rg.c_gr_adj] + sh[2];
+            int gl_adj = rg.base[1];                              // first row of the left ghosts' layer next to the slab (their last layer)
+            for (int k = 0; k < g.depth - 1; ++k) gl_adj += layer_cnt[l0[1] + k];
+            const int gr_adj_end = rg.base[2] + layer_cnt[l0[2]];  // end of the right ghosts' layer next to the slab (their first)
             r.own = RowMap{1, {0, 0, 0}, {nq[0], 0, 0}, {0, 0, 0}};
             const int b1 = (nq[0] + 255) & ~255, len1 = rg.base[1] + nq[1] - gl_adj;
             r.own1 = RowMap{3, {0, gl_adj, rg.base[2]}, {nq[0], rg.base[1] + nq[1], gr_adj_end}, {0, b1, b1 + ((len1 + 255) & ~255)}};
@@ -168,23 +204,42 @@ k_local_scatter(const int *__restrict__ raw, int *__restrict__ cell_off, LocalGe
         *rows = r;
     }
     if (!ok) return;
-    const int ncell[3] = {rg.c1[0] - rg.c0[0], rg.c1[1] - rg.c0[1], rg.c1[2] - rg.c0[2]};
-    for (int k = t; k < ncell[0] + ncell[1] + ncell[2]; k += nt) {
-        const int q = k < ncell[0] ? 0 : (k < ncell[0] + ncell[1] ? 1 : 2);
-        const int c = rg.c0[q] + (k - (q == 0 ? 0 : (q == 1 ? ncell[0] : ncell[0] + ncell[1])));
-        cell_off[c] = raw[c] + sh[q];
-    }
-    for (int v = t; v < g.c_own + 2 * g.c_x; v += nt) {
-        const unsigned key = pool.keys[v];
-        if (key == KEY_FOREIGN) continue;
-        const int q = ((int)key >= rg.c0[0] && (int)key < rg.c1[0]) ? 0 : (((int)key >= rg.c0[1] && (int)key < rg.c1[1]) ? 1 : 2);
-        slots[raw[key] + sh[q] + (int)pool.rank[v]] = (unsigned)v;
-    }
+    int base = rg.base[q];
+    for (int k = 0; k < in_q; ++k) base += layer_cnt[l0[q] + k];
+    // exclusive scan of this layer's lc cell counts (the last storage cell of a layer is empty: its offset ends the layer's rows)
+    const int c_first = (l0[q] + in_q) * lc;
+    const int per_t = (lc + OFF_TPB - 1) / OFF_TPB, t0 = threadIdx.x * per_t, t1 = min(lc, t0 + per_t);
+    int mine = 0;
+    for (int k = t0; k < t1; ++k) mine += cell_cnt[c_first + k];
+    __shared__ int wsum[OFF_TPB / 64];
+    int incl = mine;                                              // inclusive scan across the lanes of a wave ...
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int woff = 0;                                                 // ... and across the waves
+    for (int w = 0; w < wv; ++w) woff += wsum[w];
+    int run = base + woff + incl - mine;
+    for (int k = t0; k < t1; ++k) { cell_off[c_first + k] = run; run += cell_cnt[c_first + k]; }
 }
-void launch_local_scatter(const int *raw, int *cell_off, const LocalGeom &g, const LocalRegions &rg, LocalPool pool, unsigned *slots,
+void launch_local_offsets(const int *cell_cnt, const int *layer_cnt, int *cell_off, const LocalGeom &g, const LocalRegions &rg, int layer_cells,
                           LocalRows *rows, int *err, hipStream_t s) {
-    const int work = std::max(g.c_own + 2 * g.c_x, rg.c1[0] - rg.c0[0] + rg.c1[1] - rg.c0[1] + rg.c1[2] - rg.c0[2]);
-    hipLaunchKernelGGL(k_local_scatter, dim3(std::min(4096, nblocks(work, TPB))), dim3(TPB), 0, s, raw, cell_off, g, rg, pool, slots, rows, err);
+    hipLaunchKernelGGL(k_local_offsets, dim3(g.per + 2 * g.depth), dim3(OFF_TPB), 0, s, cell_cnt, layer_cnt, cell_off, g, rg, layer_cells, rows, err);
+}
+
+// the slot of every kept particle of the pool: the first row of its cell + its arrival rank there
+__global__ void __launch_bounds__(TPB)
+k_local_scatter(const int *__restrict__ cell_off, LocalGeom g, LocalPool pool, unsigned *__restrict__ slots, const LocalRows *__restrict__ rows) {
+    if (!rows->ok) return;
+    const int v = blockIdx.x * TPB + threadIdx.x;
+    if (v >= g.c_own + 2 * g.c_x) return;
+    const unsigned key = pool.keys[v];
+    if (key == KEY_FOREIGN) return;
+    slots[cell_off[key] + (int)pool.rank[v]] = (unsigned)v;
+}
+void launch_local_scatter(const int *cell_off, const LocalGeom &g, LocalPool pool, unsigned *slots, const LocalRows *rows, hipStream_t s) {
+    hipLaunchKernelGGL(k_local_scatter, dim3(nblocks(g.c_own + 2 * g.c_x, TPB)), dim3(TPB), 0, s, cell_off, g, pool, slots, rows);
 }
 
 // One thread per row of the row space.  A live row s holds pool member v = slots[s] of cell c; its final row is the cell's first
@@ -268,6 +323,7 @@ void launch_local_permute(const LocalCaller &c, const double *recv_l, const doub
 __global__ void __launch_bounds__(TPB)
 k_local_finish(LocalFinish a, LocalCaller c, DBox box) {
     const int n = a.rows->n_own;
+    for (int k = blockIdx.x * TPB + threadIdx.x; k < a.n_zero; k += gridDim.x * TPB) a.zero[k] = 0;   // (everything that counted into them has been consumed: both lanes have joined)
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.rows->ok) *c.n_local = (unsigned)n;   // (a step that overflowed leaves the caller's state alone)
     int m = 0;
     const double *t = nullptr;

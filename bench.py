@@ -200,7 +200,10 @@ def launch_ranks(args, argv, script=None):
 # "one_stream" / "lanes": the N ranks with PSE_TEAM_LANES = 0 / 1 -- kernels and exchanges of a rank on ONE stream, or two compute lanes
 # + a communication stream (the faster mode on paper; it has never run over RCCL: a hang there must not cost the line of the first).
 # Every segment verifies itself against a single-GPU engine before it is timed; the line's `value` is the faster VERIFIED mode.
-SEGMENTS = ("single", "one_stream", "lanes")
+# "split" (two GPUs only): no spatial decomposition at all -- rank 0 the real-space half of the step (near field + Lanczos), rank 1 the
+# wave-space half (spread, FFTs, gather), each on ALL particles, one all-reduce of the two velocity halves per step: at G = 2 the slab
+# all-to-alls of the owned-particle step move 107 MB over the ONE link between the two GPUs twice per step.
+SEGMENTS = ("single", "one_stream", "lanes", "split")
 
 
 class Coordinator:
@@ -272,10 +275,12 @@ def supervise_segments(args, argv, script=None):
             continue
         if seg == "lanes" and args.modes == "one_stream" or seg == "one_stream" and args.modes == "lanes":
             continue
+        if seg == "split" and (world != 2 or args.modes not in ("both", "split")) or seg in ("one_stream", "lanes") and args.modes == "split":
+            continue
         n_ranks = 1 if seg == "single" else world
         ranks = list(range(n_ranks)) if not under_launcher else [rank]
         env = dict(base_env, WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks), MASTER_PORT=str(co.ports[k]))
-        if seg != "single":
+        if seg in ("one_stream", "lanes"):
             env["PSE_TEAM_LANES"] = "1" if seg == "lanes" else "0"
         cmd = [sys.executable, me, "--segment", seg] + rest
         t0 = time.time()
@@ -291,13 +296,13 @@ def supervise_segments(args, argv, script=None):
             except Exception:   # noqa: BLE001
                 results[seg] = {"error": "unreadable result line"}
     if rank != 0:
-        return 0 if any(codes.get(sg, 1) == 0 for sg in ("one_stream", "lanes")) else next((c for c in codes.values() if c), 1)
+        return 0 if any(codes.get(sg, 1) == 0 for sg in ("one_stream", "lanes", "split")) else next((c for c in codes.values() if c), 1)
     return merge_segments(args, results)
 
 
 def merge_segments(args, results):
     """ONE line from the segments' lines: `value` is the faster mode whose trajectory check against the single GPU passed."""
-    modes = {m: results[m] for m in ("one_stream", "lanes") if m in results}
+    modes = {m: results[m] for m in ("one_stream", "lanes", "split") if m in results}
     good = {m: r for m, r in modes.items() if "error" not in r and (r.get("verify") or {}).get("ok", args.no_verify)}
     single = results.get("single")
     if not good:
@@ -309,7 +314,8 @@ def merge_segments(args, results):
     out.pop("segment", None)
     out["mode"] = best
     keep = ("ms_per_step", "value", "steps_per_s", "mf_evals_per_s", "lanczos_m", "lanczos_status", "lanczos_exchanges", "lanczos_extras_off", "verify",
-            "exchanges_per_step", "exchange_us", "exchange_host_us", "exchange_bytes", "lanes_ms", "critical_path_ms", "device_flags", "config4", "error", "seconds")
+            "exchanges_per_step", "exchange_us", "exchange_host_us", "exchange_bytes", "lanes_ms", "critical_path_ms", "device_flags", "particles_owned_sum",
+            "config4", "error", "seconds")
     out["modes"] = {m: {k: r[k] for k in keep if k in r} for m, r in modes.items()}
     if single and "error" not in single:
         out["single_gpu"] = {"ms_per_step": single["ms_per_step"], "config4_ms_per_step": (single.get("config4_single_gpu") or {}).get("ms_per_step"),
@@ -471,6 +477,86 @@ def run_owned_particle_team(args, world, rank, host_transport, dist, torch, segm
     return 0 if (w["verify"] is None or w["verify"]["ok"]) else 4
 
 
+def run_functional_split(args, rank, host_transport, dist, torch):
+    """The `split` segment of `--gpus 2` (pse_amd.sharded.SplitSimulation): rank 0 the real-space half of every step, rank 1 the wave-space
+    half, both on all particles, one all-reduce per step; verified against a single-GPU engine on rank 0, then timed like the teams."""
+    import pse_amd
+    from pse_amd.sharded import SplitSimulation
+
+    def workload(n, phi, grid, steps, warmup, verify_steps):
+        pos, force, L = suspension(n, phi)
+        box = (L, L, L, 0.0)
+        xi = math.pi * grid / (2.0 * L * math.sqrt(-math.log(args.error)))
+        kw = dict(xi=xi, error=args.error, seed=1, grid=(grid,) * 3)
+        sim = SplitSimulation(n, box, rank, dist, **kw)
+        verify = None
+        if verify_steps > 0:
+            sim.load(pos, force, mass=1.0)
+            dt = 0.05
+            worst, images_equal, m_equal = 0.0, True, True
+            if rank == 0:
+                ref = pse_amd.Engine(n, box, **kw)
+                dpos, dF, vel = sim.pos.clone(), sim.force.clone(), sim.vel.clone()
+                accel = torch.zeros((n, 3), dtype=torch.float64, device="cuda"); image = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+            m = mr = 2
+            for k in range(verify_steps):
+                m = sim.step(args.kT, dt, 1000 + k, lanczos_m=m)
+                if rank == 0:
+                    mr = ref.step(dpos, vel, accel, image, dF, args.kT, dt, 1000 + k, lanczos_m=mr)
+                    worst = max(worst, float((sim.pos[:, :3] - dpos[:, :3]).abs().max()))
+                    images_equal = images_equal and bool(torch.equal(sim.image, image))
+                    m_equal = m_equal and m == mr
+            if rank == 0:
+                del ref
+                torch.cuda.empty_cache()
+                verify = {"steps": verify_steps, "dt": dt, "max_abs_position_diff_vs_single_gpu": worst, "images_equal": images_equal,
+                          "lanczos_m_equal": m_equal, "ok": bool(worst < 1e-7 and images_equal and m_equal)}
+        sim.load(pos, force, mass=1.0)
+        m = 2
+        for it in range(max(warmup, 1)):
+            m = sim.step(args.kT, args.dt, it, lanczos_m=m)
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in range(steps):
+            m = sim.step(args.kT, args.dt, warmup + it, lanczos_m=m)
+        dist.barrier(); torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if host_transport else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        info = sim.engine.info()
+        del sim
+        torch.cuda.empty_cache()
+        t_step = float(t[0]) / steps
+        return {"workload": f"random-sphere suspension N={n}, phi={phi}, cubic L={L:.2f}, grid {grid}^3, xi={xi:.4f}, rcut={info['rcut']:.3f}, P={info['P']}, "
+                            f"error={args.error}, kT={args.kT}, dt={args.dt}",
+                "ms_per_step": t_step * 1e3, "value": n / t_step, "steps_per_s": 1.0 / t_step, "steps": steps, "lanczos_m": m, "lanczos_status": 0,
+                "exchange_bytes": {"all_reduce": [32 * n]}, "verify": verify}
+
+    w = workload(args.n, args.phi, args.grid, args.steps, args.warmup, 0 if args.no_verify else 3)
+    c4 = None
+    if not args.no_cfg4:
+        try:
+            c4 = workload(args.cfg4_n, args.cfg4_phi, args.cfg4_grid, max(3, min(args.steps, 10)), max(1, min(args.warmup, 3)), 0 if args.no_verify else 2)
+        except Exception as e:   # noqa: BLE001
+            c4 = {"error": repr(e)[:300]}
+    if rank != 0:
+        return 0
+    transport = "torch.distributed gloo through host memory (ranks may share a GPU): a functional run, not a scaling number" if host_transport else "RCCL all-reduce over xGMI"
+    out = {"segment": "split",
+           "metric": "BD particle-steps/s (full PSE Brownian step: M.F + k-space noise + Lanczos M^1/2.psi + Euler), N=1e6, phi=0.1",
+           "value": w["value"], "unit": "particle-steps/s", "n_gpus": 2, "steps": args.steps, "warmup": args.warmup, "ms_per_step": w["ms_per_step"],
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64, Lanczos pair coefficients f32", "data": "synthetic",
+           "config": {"workload": w["workload"],
+                      "parallelism": f"2 ranks, {transport}; FUNCTIONAL split (pse_brownian_velocity_part): rank 0 the real-space half of every step (near field + "
+                                     f"Lanczos), rank 1 the wave-space half (spread, transforms, k-space scaling and noise, gather), both on all N particles, ONE "
+                                     f"all-reduce of 32 N bytes per step, both ranks integrate"},
+           "roofline": None, "cpu_baseline": None}
+    out.update({k: w[k] for k in ("steps_per_s", "lanczos_m", "lanczos_status", "exchange_bytes", "verify")})
+    if c4 is not None:
+        out["config4"] = c4
+    print(json.dumps(out))
+    return 0 if (w["verify"] is None or w["verify"]["ok"]) else 4
+
+
 def verify_team_against_single_gpu(sim, pos, force, box, kw, args, world, rank, dist, torch, steps=3):
     """`steps` Brownian steps of the owned-particle team and of a single-GPU engine on rank 0's device, from the same suspension with the
     same noise: largest position difference, images and Lanczos counts.  Untimed; the engine is released before the bench goes on."""
@@ -548,7 +634,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true",
                     help="multi-rank runs: skip the three untimed steps next to a single-GPU engine on rank 0 (the `verify` object of the line)")
     ap.add_argument("--dry-run", action="store_true", help="with --gpus N > 1: print the launch command and stop")
-    ap.add_argument("--modes", choices=["both", "one_stream", "lanes"], default="both",
+    ap.add_argument("--modes", choices=["both", "one_stream", "lanes", "split"], default="both",
                     help="multi-rank runs: which lane modes of the owned-particle step are timed (default both, each as a fresh set of rank "
                          "processes; the line's value is the faster verified one)")
     ap.add_argument("--no-single", action="store_true", help="multi-rank runs: skip the single-GPU segment (no speedup_vs_single in the line)")
@@ -603,6 +689,12 @@ def main():
     import pse_amd
     from pse_amd import distributed as pdist
 
+    if world > 1 and args.segment == "split":
+        rc = run_functional_split(args, rank, host_transport, dist, torch)
+        dist.destroy_process_group()
+        if rc:
+            raise SystemExit(rc)
+        return
     if world > 1 and not args.replicated:
         rc = run_owned_particle_team(args, world, rank, host_transport, dist, torch, args.segment)
         dist.destroy_process_group()

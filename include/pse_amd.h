@@ -154,6 +154,18 @@ int pse_brownian_velocity(pse_handle *h, const pse_double4 *pos, const pse_doubl
                           const unsigned int *group_members, unsigned int N,
                           double kT, double dt, unsigned int timestep, int *lanczos_m);
 
+/* The two halves of that evaluation on their own -- a FUNCTIONAL split for two GPUs (one GPU the real-space half, the other the
+ * wave-space half, each on ALL particles: no slab all-to-all over the one link between them).  parts = 1:
+ * M_real.F + sqrt(2kT/dt) M_real^{1/2} psi (the Lanczos half: *lanczos_m as above); parts = 2: M_wave.F + the k-space noise
+ * (gpu_stokes_BrownianGridGenerate, PSEv1/Brownian.cu:153-345; *lanczos_m untouched); 3 = pse_brownian_velocity.  The halves of one
+ * (kT, dt, timestep, seed) add up to the whole: the caller sums them (an all-reduce between the two ranks) and integrates with
+ * pse_integrate -- K15 alone (gpu_stokes_step_one_kernel, PSEv1/Stokes.cu:137-192: pos += (vel + shear_rate y xhat) dt, wrap, accel). */
+int pse_brownian_velocity_part(pse_handle *h, const pse_double4 *pos, const pse_double4 *force, pse_double4 *vel,
+                               const unsigned int *group_members, unsigned int N, double kT, double dt, unsigned int timestep,
+                               int parts, int *lanczos_m);
+int pse_integrate(pse_handle *h, pse_double4 *pos, const pse_double4 *vel, pse_double3 *accel, pse_int3 *image,
+                  const pse_double4 *net_force, const unsigned int *group_members, unsigned int N, double dt, double shear_rate);
+
 /* One full integration step: the replacement for gpu_stokes_step_one (PSEv1/Stokes.cuh:75-111).
  * Computes vel, then pos += (vel + shear_rate*y*xhat)*dt, wraps into the box updating image, accel = F/mass
  * with mass = vel.w (PSEv1/Stokes.cu:137-192). */

@@ -114,6 +114,8 @@ SYMBOLS = {
     "pse_last_error": (ctypes.c_char_p, []),
     "pse_mobility": (_i, [_vp, _vp, _vp, _vp, _vp, _u, _i]),
     "pse_brownian_velocity": (_i, [_vp, _vp, _vp, _vp, _vp, _u, _d, _d, _u, _ip]),
+    "pse_brownian_velocity_part": (_i, [_vp, _vp, _vp, _vp, _vp, _u, _d, _d, _u, _i, _ip]),
+    "pse_integrate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u, _d, _d]),
     "pse_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u, _d, _d, _u, _d, _ip]),
     "pse_sqrt_mreal": (_i, [_vp, _vp, _vp, _vp, _vp, _u, _d, _ip]),
     "pse_random_psi": (_i, [_vp, _vp, _vp, _u, _u]),

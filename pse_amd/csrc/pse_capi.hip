@@ -1963,7 +1963,8 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
         *mask |= 1u << PH_REAL;
     }
     if (near_first) TRY(wave_start());
-    if (noise) {
+    const bool lz = noise && (parts & 1);   // the particle noise M_real^{1/2} psi belongs to the real-space half (the k-space noise to the wave half)
+    if (lz) {
         for (pse_handle *h : act(T)) TRY(ts(h, PH_LANCZOS));   // closed inside the Lanczos driver, after the first batch of iterations
         for (pse_handle *h : act(T)) h->matvec_timed = false;
         const std::function<int()> hook = [&]() -> int {    // before the host first waits for the Lanczos scalars: everything else is queued
@@ -2008,7 +2009,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
             if (noise && h->tail_done) continue;   // the Lanczos combination has written the summed rows already
             int lo, hi;
             row_range(h, N, lo, hi);
-            launch_sum_rows((parts & 2) ? h->uw_s : nullptr, (parts & 1) ? h->ur_s : nullptr, noise ? h->ub_s : nullptr,
+            launch_sum_rows((parts & 2) ? h->uw_s : nullptr, (parts & 1) ? h->ur_s : nullptr, lz ? h->ub_s : nullptr,
                             h->utot_s, lo, hi, h->stream, h->tag_s);   // the tags travel with the rows: no rank orders foreign rows
         }
         TRY(team_all_gather_rows(T, [](pse_handle *h) { return (double *)h->utot_s; }));
@@ -2021,7 +2022,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
             HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         }
         const double4 *ua = T.G > 1 ? h->utot_s : ((parts & 2) ? h->uw_s : nullptr);
-        const double4 *ub = T.G > 1 ? nullptr : ((parts & 1) ? h->ur_s : nullptr), *uc = T.G > 1 ? nullptr : (noise ? h->ub_s : nullptr);
+        const double4 *ub = T.G > 1 ? nullptr : ((parts & 1) ? h->ur_s : nullptr), *uc = T.G > 1 ? nullptr : (lz ? h->ub_s : nullptr);
         const unsigned *tags = T.G > 1 ? nullptr : h->tag_s;     // a team: the tag travels in the fourth component of its row
         if (!(T.G == 1 && noise && h->tail_done)) launch_scatter_sum(ua, ub, uc, tags, N, a[r].vel, h->stream);   // (single GPU: the Lanczos combination has un-sorted the sum)
         if (tail) {
@@ -2057,13 +2058,13 @@ static int do_mobility(pse_team &T, const std::vector<Args> &a, const unsigned *
 }
 
 static int do_brownian(pse_team &T, const std::vector<Args> &a, const unsigned *group, unsigned N, double kT, double dt,
-                       unsigned timestep, int *lanczos_m) {
+                       unsigned timestep, int *lanczos_m, int parts = 3) {
     for (pse_handle *h : act(T)) TRY(check_n(h, N));
     for (auto &x : a) if (!x.pos || !x.force || !x.vel) return fail(PSE_ERR_INVALID, "null array");
     if (kT < 0 || !(dt > 0)) return fail(PSE_ERR_INVALID, "need kT >= 0 and dt > 0");
     unsigned mask = 1u << PH_TOTAL;
     for (pse_handle *h : act(T)) TRY(ts(h, PH_TOTAL));
-    TRY(velocity(T, a, group, (int)N, 3, kT, dt, timestep, lanczos_m, &mask));
+    TRY(velocity(T, a, group, (int)N, parts, kT, dt, timestep, lanczos_m, &mask));
     for (pse_handle *h : act(T)) { TRY(te(h, PH_TOTAL)); TRY(collect_times(h, mask)); }
     return 0;
 }
@@ -2372,6 +2373,35 @@ extern "C" int pse_brownian_velocity(pse_handle *h, const pse_double4 *pos, cons
     TRY(team_of_one(h, T));
     return do_brownian(T, {Args{(const double4 *)pos, (const double4 *)force, (double4 *)vel}}, group, N, kT, dt, timestep,
                        lanczos_m);
+}
+
+// The two halves of a Brownian evaluation on their own (a FUNCTIONAL split for two GPUs): parts = 1 the real-space
+// half M_real.F + sqrt(2kT/dt) M_real^{1/2} psi, parts = 2 the wave-space half M_wave.F + the k-space noise; the halves add up to
+// what pse_brownian_velocity returns (the reference computes them in one call and shares its inverse FFT and gather between the
+// deterministic and the stochastic wave part as this does, PSEv1/Brownian.cu:772-923).
+extern "C" int pse_brownian_velocity_part(pse_handle *h, const pse_double4 *pos, const pse_double4 *force, pse_double4 *vel,
+                                          const unsigned *group, unsigned N, double kT, double dt, unsigned timestep, int parts,
+                                          int *lanczos_m) {
+    if (!h) return fail(PSE_ERR_INVALID, "null handle");
+    if (parts < 1 || parts > 3) return fail(PSE_ERR_INVALID, "parts must select real (1), wave (2) or both (3)");
+    if (!pos || !force || !vel) return fail(PSE_ERR_INVALID, "null array");
+    pse_team T;
+    TRY(team_of_one(h, T));
+    return do_brownian(T, {Args{(const double4 *)pos, (const double4 *)force, (double4 *)vel}}, group, N, kT, dt, timestep, lanczos_m, parts);
+}
+
+// K15 alone (gpu_stokes_step_one_kernel, PSEv1/Stokes.cu:137-192): the Euler update + wrap for velocities the caller has put together
+extern "C" int pse_integrate(pse_handle *h, pse_double4 *pos, const pse_double4 *vel, pse_double3 *accel, pse_int3 *image,
+                             const pse_double4 *net_force, const unsigned *group, unsigned N, double dt, double shear_rate) {
+    if (!h) return fail(PSE_ERR_INVALID, "null handle");
+    if (!pos || !vel || !accel || !image || !net_force) return fail(PSE_ERR_INVALID, "null array");
+    if (!(dt > 0)) return fail(PSE_ERR_INVALID, "need dt > 0");
+    TRY(check_n(h, N));
+    HIPCHK(hipSetDevice(h->device));
+    launch_integrate((double4 *)pos, (const double4 *)vel, (double3 *)accel, (int3 *)image, (const double4 *)net_force, group, (int)N, h->dbox, dt,
+                     shear_rate, h->stream);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 extern "C" int pse_step(pse_handle *h, pse_double4 *pos, pse_double4 *vel, pse_double3 *accel, pse_int3 *image,

@@ -155,6 +155,28 @@ class Engine:
                                                    float(kT), float(dt), int(timestep), ctypes.byref(m)))
         return vel, m.value
 
+    def brownian_velocity_part(self, pos, force, kT, dt, timestep, parts, vel=None, group=None, lanczos_m=2):
+        """One half of brownian_velocity (pse_brownian_velocity_part): parts = 1 real space + Lanczos noise, 2 wave space + k-space noise."""
+        import torch
+        n = pos.shape[0] if group is None else group.shape[0]
+        _chk4(pos, "pos"); _chk4(force, "force"); _chk_group(group)
+        if vel is None:
+            vel = torch.zeros_like(pos)
+        _chk4(vel, "vel")
+        m = ctypes.c_int(int(lanczos_m))
+        _lib.check(self._lib.pse_brownian_velocity_part(self._h, _ptr(pos), _ptr(force), _ptr(vel), _ptr(group), n, float(kT), float(dt),
+                                                        int(timestep), int(parts), ctypes.byref(m)))
+        return vel, m.value
+
+    def integrate(self, pos, vel, accel, image, force, dt, shear_rate=0.0, group=None):
+        """The Euler update + wrap alone (pse_integrate) for velocities the caller has put together."""
+        import torch
+        n = pos.shape[0] if group is None else group.shape[0]
+        _chk4(pos, "pos"); _chk4(vel, "vel"); _chk4(force, "force"); _chk_group(group)
+        _chk_arr(accel, "accel", 3, torch.float64, pos.shape[0]); _chk_arr(image, "image", 3, torch.int32, pos.shape[0])
+        _lib.check(self._lib.pse_integrate(self._h, _ptr(pos), _ptr(vel), _ptr(accel), _ptr(image), _ptr(force), _ptr(group), n, float(dt),
+                                           float(shear_rate)))
+
     def step(self, pos, vel, accel, image, force, kT, dt, timestep, shear_rate=0.0, group=None, lanczos_m=2):
         n = pos.shape[0] if group is None else group.shape[0]
         import torch

@@ -463,3 +463,54 @@ class LocalShardedSimulation:
         n = int(self.s.n_local.item())
         return (self.s.tag[:n].cpu().numpy(), self.s.pos[:n, :3].cpu().numpy(), self.s.vel[:n, :3].cpu().numpy(),
                 self.s.image[:n].cpu().numpy())
+
+
+class SplitSimulation:
+    """TWO ranks, a FUNCTIONAL split instead of a spatial one: both hold all N particles; rank 0 computes the
+    real-space half of the Brownian velocity (near-field M.F + the Lanczos M_real^{1/2} psi), rank 1 the wave-space half (spread, FFTs,
+    k-space scaling + noise, gather) -- each a single-GPU engine on the whole suspension, no slab all-to-all over the one xGMI link
+    between two GPUs.  ONE exchange per step: an all-reduce of the two halves (32 bytes per particle each way); both ranks then
+    integrate all particles, bit-identically (a + b = b + a).  `dist`: torch.distributed, world size 2."""
+
+    def __init__(self, n, box, rank, dist, **kw):
+        import torch
+        if dist.get_world_size() != 2:
+            raise ValueError("the functional split is a two-rank mode")
+        self.n, self.rank, self.dist, self.box = n, rank, dist, tuple(box)
+        self.engine = Engine(n, box, **kw)
+        z = lambda *shape, dtype=torch.float64: torch.zeros(shape, dtype=dtype, device="cuda")   # noqa: E731
+        self.pos, self.vel, self.force, self.part = z(n, 4), z(n, 4), z(n, 4), z(n, 4)
+        self.accel, self.image = z(n, 3), z(n, 3, dtype=torch.int32)
+        self._cpu = dist.get_backend() == "gloo"      # (the tests: two processes on one GPU)
+
+    def load(self, pos, force, mass=1.0):
+        import torch
+        self.pos[:, :3] = torch.from_numpy(np.ascontiguousarray(pos)).cuda()
+        self.force[:, :3] = torch.from_numpy(np.ascontiguousarray(force)).cuda()
+        self.vel.zero_(); self.vel[:, 3] = mass
+        self.accel.zero_(); self.image.zero_()
+
+    def set_box(self, Lx, Ly, Lz, xy):
+        self.engine.set_box(Lx, Ly, Lz, xy)
+        self.box = (Lx, Ly, Lz, xy)
+
+    def velocity(self, kT, dt, timestep, lanczos_m=2):
+        """vel.xyz = the Brownian velocity of all particles, on both ranks; returns the Lanczos count (rank 0's, sent along)."""
+        self.part.zero_()
+        _, m = self.engine.brownian_velocity_part(self.pos, self.force, kT, dt, timestep, 1 if self.rank == 0 else 2, vel=self.part,
+                                                  lanczos_m=lanczos_m)
+        self.part[0, 3] = float(m) if self.rank == 0 else 0.0       # (the w column is free: the count rides in it)
+        if self._cpu:
+            t = self.part.cpu()
+            self.dist.all_reduce(t)
+            self.part.copy_(t)
+        else:
+            self.dist.all_reduce(self.part)
+        m = int(round(float(self.part[0, 3].item()))) if kT > 0 else lanczos_m
+        self.vel[:, :3] = self.part[:, :3]
+        return m
+
+    def step(self, kT, dt, timestep, shear_rate=0.0, lanczos_m=2):
+        m = self.velocity(kT, dt, timestep, lanczos_m=lanczos_m)
+        self.engine.integrate(self.pos, self.vel, self.accel, self.image, self.force, dt, shear_rate=shear_rate)
+        return m

@@ -30,7 +30,7 @@ def test_dry_run_prints_the_launch_command():
     assert cmd[1] == BENCH
     assert cmd[2:] == ["--gpus", "2", "--steps", "3", "--warmup", "1", "--n", "1000"]   # the ranks get the same arguments, minus --dry-run
     # the owned-particle run is a sequence of segments, each a fresh set of rank processes with a rendezvous port of its own
-    assert d["segments"] == ["single", "one_stream", "lanes"]
+    assert d["segments"] == ["single", "one_stream", "lanes", "split"]        # (split: the two-rank functional split, --gpus 2 only)
     assert d["env"]["MASTER_ADDR"] == "127.0.0.1" and d["env"]["WORLD_SIZE"] == "2"
     r = _run(["--gpus", "2", "--replicated", "--dry-run"])           # one set of ranks: the launch line with its port
     d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -101,6 +101,12 @@ fake = os.environ.get('FAKE', '')
 if seg == 'single':
     assert world == 1 and 'PSE_TEAM_LANES' not in os.environ
     print(json.dumps({'segment': seg, 'metric': 'm', 'ms_per_step': 8.0, 'config4_single_gpu': {'ms_per_step': 40.0}}))
+    sys.exit(0)
+if seg == 'split':
+    assert world == 2 and 'PSE_TEAM_LANES' not in os.environ
+    if rank == 0:
+        print(json.dumps({'segment': seg, 'metric': 'm', 'value': 1e6 / 3.0, 'ms_per_step': 3.0, 'n_gpus': 2, 'verify': {'ok': True}, 'lanczos_status': 0,
+                          'config4': {'ms_per_step': 12.0, 'verify': {'ok': True}}, 'config': {'parallelism': 'split'}}))
     sys.exit(0)
 lanes = os.environ['PSE_TEAM_LANES']
 assert lanes == ('1' if seg == 'lanes' else '0')
@@ -189,6 +195,7 @@ def test_segments_under_torch_distributed_run(tmp_path):
         lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
         assert len(lines) == 1, r.stdout
         d = json.loads(lines[0])
-        assert d["mode"] == mode and set(d["modes"]) == {"one_stream", "lanes"} and d["single_gpu"]["ms_per_step"] == 8.0
+        assert d["mode"] == mode and set(d["modes"]) == {"one_stream", "lanes", "split"} and d["single_gpu"]["ms_per_step"] == 8.0
+        assert d["modes"]["split"]["ms_per_step"] == 3.0           # (two ranks: the functional split is timed too)
         if fake:
             assert "error" in d["modes"]["lanes"]

@@ -400,3 +400,41 @@ def test_pair_repulsion_matches_port(torch_cuda, oracle, xy):
     assert rel(out[:, :3], ref + force) < 1e-12
     with pytest.raises(pse_amd.PSEError):
         eng.pair_repulsion(to4(pos), f, 40.0, 2.0 * eng.info()["rcut"])
+
+
+def test_the_two_halves_of_a_brownian_evaluation_add_up(torch_cuda, oracle):
+    """pse_brownian_velocity_part (the functional split of a two-GPU run: one GPU the real-space half with the Lanczos noise, the other
+    the wave-space half with the k-space noise) and pse_integrate (K15 alone): the halves add up to pse_brownian_velocity, the
+    real-space half is the port's, and halves + integrate = pse_step."""
+    import torch
+    import pse_amd
+    n = 1500
+    pos, force, box = make_suspension(n, phi=0.1, xy=0.2)
+    seed, ts, kT, dt, rate = 77, 5, 1.0, 2e-2, 0.4
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3, seed=seed)
+    p = oracle.select_params(box, 0.5, 1e-3, 0.5)
+    whole, m = eng.brownian_velocity(to4(pos), to4(force), kT, dt, ts)
+    a, ma = eng.brownian_velocity_part(to4(pos), to4(force), kT, dt, ts, 1, vel=to4(np.zeros((n, 3)), 2.0))
+    b, mb = eng.brownian_velocity_part(to4(pos), to4(force), kT, dt, ts, 2, vel=to4(np.zeros((n, 3)), 2.0), lanczos_m=3)
+    assert ma == m and mb == 3                                   # (the wave half runs no Lanczos iteration: the count comes back as given)
+    assert np.all(a.cpu().numpy()[:, 3] == 2.0) and np.all(b.cpu().numpy()[:, 3] == 2.0)
+    s = a.cpu().numpy()[:, :3] + b.cpu().numpy()[:, :3]
+    assert rel(s, whole.cpu().numpy()[:, :3]) < 1e-13
+    # the real-space half against the port: M_real.F + sqrt(2 kT / dt) M_real^{1/2} psi
+    psi = oracle.psi_particles(n, seed, ts)
+    ub, mp = oracle.lanczos_sqrt(lambda v: oracle.mobility_real(pos, np.ascontiguousarray(v), box, 0.5, p["rcut"], f32=True), psi, 2, 1e-3)
+    ref_a = oracle.mobility_real(pos, force, box, 0.5, p["rcut"]) + np.sqrt(2.0 * kT / dt) * ub
+    assert mp == m and rel(a.cpu().numpy()[:, :3], ref_a) < 1e-9
+    # kT = 0: the halves are pse_mobility's parts
+    a0, _ = eng.brownian_velocity_part(to4(pos), to4(force), 0.0, dt, ts, 1)
+    assert rel(a0.cpu().numpy()[:, :3], eng.mobility(to4(pos), to4(force), parts=1).cpu().numpy()[:, :3]) < 1e-14
+    # halves + pse_integrate = pse_step
+    dpos, dvel, dF = to4(pos, 1.0), to4(np.zeros((n, 3)), 1.5), to4(force)
+    accel = torch.zeros((n, 3), dtype=torch.float64, device="cuda"); image = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+    eng.step(dpos, dvel, accel, image, dF, kT, dt, ts, shear_rate=rate)
+    p2, v2 = to4(pos, 1.0), to4(s, 1.5)
+    acc2 = torch.zeros((n, 3), dtype=torch.float64, device="cuda"); im2 = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+    eng.integrate(p2, v2, acc2, im2, dF, dt, shear_rate=rate)
+    assert np.abs(p2.cpu().numpy() - dpos.cpu().numpy()).max() < 1e-12 and torch.equal(im2, image) and torch.equal(acc2, accel)
+    with pytest.raises(pse_amd.PSEError):
+        eng.brownian_velocity_part(to4(pos), to4(force), kT, dt, ts, 0)

@@ -184,12 +184,12 @@ def test_bench_launches_its_own_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     assert "HOST-STAGED" in d["config"]["parallelism"] and "owned-particle" in d["config"]["parallelism"]
     # both lane modes, each verified and timed by its own set of rank processes; the value is the faster verified one
-    assert set(d["modes"]) == {"one_stream", "lanes"} and d["mode"] in d["modes"]
+    assert set(d["modes"]) == {"one_stream", "lanes", "split"} and d["mode"] in d["modes"]     # (two ranks: + the functional split)
     for name, md in d["modes"].items():
-        assert md["verify"]["ok"] and md["ms_per_step"] > 0 and md["lanczos_status"] == 0 and md["device_flags"] == [0], (name, md)
+        assert md["verify"]["ok"] and md["ms_per_step"] > 0 and md["lanczos_status"] == 0 and (name == "split" or md["device_flags"] == [0]), (name, md)
         assert md["config4"]["ms_per_step"] > 0 and md["config4"]["verify"]["ok"] and md["config4"]["speedup_vs_single"] > 0, (name, md["config4"])
     assert d["ms_per_step"] == min(md["ms_per_step"] for md in d["modes"].values()) == d["modes"][d["mode"]]["ms_per_step"]
-    assert ("PSE_TEAM_LANES=1" in d["config"]["parallelism"]) == (d["mode"] == "lanes")
+    assert ("PSE_TEAM_LANES=1" in d["config"]["parallelism"]) == (d["mode"] == "lanes") and ("FUNCTIONAL split" in d["config"]["parallelism"]) == (d["mode"] == "split")
     assert d["modes"]["lanes"]["lanes_ms"]["side"] > 0 and d["modes"]["one_stream"]["lanes_ms"]["side"] == 0
     # ... against the single GPU of the same run
     assert d["single_gpu"]["ms_per_step"] > 0 and d["single_gpu"]["config4_ms_per_step"] > 0
@@ -197,7 +197,8 @@ def test_bench_launches_its_own_ranks():
     assert abs(d["config4"]["speedup_vs_single"] - d["single_gpu"]["config4_ms_per_step"] / d["config4"]["ms_per_step"]) < 1e-9
     assert d["north_star"]["speedup_at_this_gpu_count"][1] == d["speedup_vs_single"]
     # the self-diagnosis of a multi-rank line: exchanges per step, device time of every exchange by kind,
-    # the spans of both lanes, the critical path
+    # the spans of both lanes, the critical path (of the owned-particle team: whichever mode the line's value is)
+    d = dict(d, **d["modes"]["lanes"]) if d["mode"] == "split" else d
     assert d["exchanges_per_step"] == sum(len(v) for v in d["exchange_us"].values()) >= 5
     assert set(d["exchange_us"]) >= {"migrate_ghosts", "lanczos", "all_to_all", "halo"}
     assert len(d["exchange_us"]["all_to_all"]) == 2 and len(d["exchange_us"]["halo"]) == 1 and len(d["exchange_us"]["migrate_ghosts"]) == 1
@@ -395,3 +396,63 @@ for _c in _LOCAL_CASES:
 def test_owned_particle_team_of_processes_follows_single_gpu(world, xy0, n, grid):
     res = _outcome(("local", world, xy0, n, grid))
     assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def _split_worker(rank, port, xy0, n, grid, out):
+    """The two-rank FUNCTIONAL split (pse_amd.sharded.SplitSimulation: rank 0 the real-space half + Lanczos, rank 1 the wave-space half,
+    one all-reduce per step) between two real processes: eight sheared Brownian steps against the single-GPU engine on rank 0."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    try:
+        import math
+        import torch
+        import torch.distributed as dist
+        from conftest import TRAJ_TOL_BROWNIAN, make_suspension, to4
+        import pse_amd
+        from pse_amd.sharded import SplitSimulation
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=2)
+        pos, force, box = make_suspension(n, phi=0.12, xy=xy0)
+        xi = math.pi * grid / (2.0 * box[0] * math.sqrt(-math.log(1e-3)))
+        kw = dict(xi=xi, error=1e-3, seed=9, grid=(grid,) * 3)
+        sim = SplitSimulation(n, box, rank, dist, **kw)
+        sim.load(pos, force)
+        kT, dt, rate, m, xy = 1.0, 0.05, 0.1, 2, xy0
+        if rank == 0:
+            ref = pse_amd.Engine(n, box, **kw)
+            dpos, dF, vel = to4(pos), to4(force), to4(np.zeros((n, 3)), 1.0)
+            accel = torch.zeros((n, 3), dtype=torch.float64, device="cuda"); image = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+            mr = 2
+        for k in range(8):
+            m = sim.step(kT, dt, 100 + k, shear_rate=rate, lanczos_m=m)
+            if rank == 0:
+                mr = ref.step(dpos, vel, accel, image, dF, kT, dt, 100 + k, shear_rate=rate, lanczos_m=mr)
+                assert m == mr, (k, m, mr)
+                assert (sim.pos - dpos).abs().max().item() < (1e-12 if k == 0 else TRAJ_TOL_BROWNIAN), (k, (sim.pos - dpos).abs().max().item())
+                assert torch.equal(sim.image, image)
+            xy += rate * dt
+            sim.set_box(box[0], box[1], box[2], xy)
+            if rank == 0:
+                ref.set_box(box[0], box[1], box[2], xy)
+        # both ranks hold the same particles, bit for bit
+        t = sim.pos.cpu(); other = t.clone()
+        dist.broadcast(other, src=0)
+        assert torch.equal(t, other), "the two ranks' replicas differ"
+        dist.barrier()
+        out.put((rank, "ok"))
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        out.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))[-1500:]))
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:   # noqa: BLE001
+            pass
+
+
+_job("split", lambda: _spawn_ranks(_split_worker, 2, lambda r, port, out: (r, port, 0.1, 40_000, 96, out)))
+
+
+def test_functional_split_of_two_processes_follows_single_gpu():
+    res = _outcome("split")
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

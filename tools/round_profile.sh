@@ -9,11 +9,11 @@ T=${1:-r03}
 C=${2:-unrecorded}
 O=gpurun_out/$T; rm -rf $O; mkdir -p $O
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
-PSE_OVERLAP=1 timeout 600 python bench.py --no-cpu --no-ref-grid > $O/bench_forked_steps.json 2> $O/bench_forked_steps.err   # the opt-in fork of Brownian steps, for comparison
+PSE_OVERLAP=1 timeout 600 python bench.py --no-cpu --no-ref-grid --no-cfg4 --no-traffic > $O/bench_forked_steps.json 2> $O/bench_forked_steps.err   # the opt-in fork of Brownian steps, for comparison
 export PSE_OVERLAP=0    # profiles: every kernel alone on one stream
-CMD="$PYREAL bench.py --steps 10 --warmup 3 --no-cpu --no-ref-grid --no-traffic"
+CMD="$PYREAL bench.py --steps 10 --warmup 3 --no-cpu --no-ref-grid --no-cfg4 --no-traffic"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- $CMD > $O/prof.log 2>&1
-CMD3="$PYREAL bench.py --steps 3 --warmup 1 --no-cpu --no-ref-grid --no-traffic"
+CMD3="$PYREAL bench.py --steps 3 --warmup 1 --no-cpu --no-ref-grid --no-cfg4 --no-traffic"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $CMD3 > $O/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $CMD3 > $O/pmc_write.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $O/sq_a -- $CMD3 > $O/sq_a.log 2>&1

@@ -77,7 +77,7 @@ struct pse_handle {
     struct Tuning {
         int cell_bz = 6;          // PSE_CELL_BZ: height of the z blocks of the cell storage order (0: plain x, y, z order)
         double skin = 0.4;        // PSE_SKIN: r_buff of the neighbour list kept across calls (0: off)
-        int overlap = 0;          // PSE_OVERLAP: 1 two chains for every call, 0 (default) only for kT = 0, -1 never
+        int overlap = 1;          // PSE_OVERLAP: 1 (default since round 6) two chains for every call, 0 only for kT = 0, -1 never
         bool no_xfuse = false;    // PSE_NO_XFUSE: rocFFT for the x pass
         int own_y_pow2 = 1;       // PSE_OWN_Y_POW2=0: rocFFT's 2-D transforms at Ny = 256 instead of its 1-D z pass + k_yfft_regs (A/B)
         int own_y = 1;            // PSE_OWN_Y=0: rocFFT's 2-D (y, z) transforms also where the own y pass applies
@@ -481,7 +481,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         auto &t = h->tun;
         t.cell_bz = std::min(16, std::max(0, ienv("PSE_CELL_BZ", 6)));   // n_cells_alloc pads every z line by up to 15 cells
         if (const char *v = getenv("PSE_SKIN")) t.skin = atof(v);
-        t.overlap = ienv("PSE_OVERLAP", 0);
+        t.overlap = ienv("PSE_OVERLAP", 1);   // (Brownian steps fork too: with the lighter pair-list mat-vec the far-field chain fits beside the Lanczos chain, 3.23 -> 3.11 ms; rounds 4-5: a loss)
         t.no_xfuse = getenv("PSE_NO_XFUSE") != nullptr;
         t.own_y = ienv("PSE_OWN_Y", 1); t.own_y_pow2 = ienv("PSE_OWN_Y_POW2", 1); t.yfft_kb = ienv("PSE_YFFT_KB", 4); t.own_z = ienv("PSE_OWN_Z", 1); t.yslab_regs = ienv("PSE_YSLAB_REGS", 1);
         if (const char *v = getenv("PSE_WAVE_MODE")) t.wave_mode = !strcmp(v, "slab") ? 1 : (!strcmp(v, "replicated") ? 2 : 0);
@@ -687,7 +687,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         h->side_owned = h->side;
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-        h->overlap_all = h->tun.overlap > 0;    // Brownian steps fork only with PSE_OVERLAP=1
+        h->overlap_all = h->tun.overlap > 0;    // Brownian steps fork unless PSE_OVERLAP=0
     }
     TRY(make_plans(h));
 

@@ -22,7 +22,7 @@ CASES = [
     ({"PSE_XFFT_SMALL_KB": "8"}, ["test_gpu_parity.py"], X),               # eight-column x pass on small grids
     ({"PSE_YFFT_KB": "2"}, ["test_gpu_parity.py"], X),
     ({"PSE_YFFT_KB": "8"}, ["test_gpu_parity.py"], X),
-    ({"PSE_OVERLAP": "1"}, ["test_gpu_parity.py"], "brownian_velocity_matches_port or step_integrates or wave_matches_port"),
+    ({"PSE_OVERLAP": "0"}, ["test_gpu_parity.py"], "brownian_velocity_matches_port or step_integrates or wave_matches_port"),   # Brownian steps on one stream (the default of rounds 1-5)
     ({"PSE_OVERLAP": "-1"}, ["test_gpu_parity.py"], "brownian_velocity_matches_port or total_mobility"),
     ({"PSE_GATHER_BZ": "1"}, ["test_gpu_parity.py"], "wave_matches_port or both_halves"),
     ({"PSE_GATHER_BZ": "2"}, ["test_gpu_parity.py"], "wave_matches_port or both_halves"),

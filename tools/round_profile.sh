@@ -9,7 +9,7 @@ T=${1:-r03}
 C=${2:-unrecorded}
 O=gpurun_out/$T; rm -rf $O; mkdir -p $O
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
-PSE_OVERLAP=1 timeout 600 python bench.py --no-cpu --no-ref-grid --no-cfg4 --no-traffic > $O/bench_forked_steps.json 2> $O/bench_forked_steps.err   # the opt-in fork of Brownian steps, for comparison
+PSE_OVERLAP=0 timeout 600 python bench.py --no-cpu --no-ref-grid --no-cfg4 --no-traffic > $O/bench_one_stream_steps.json 2> $O/bench_one_stream_steps.err   # Brownian steps on ONE stream (the default of rounds 1-5), for comparison
 export PSE_OVERLAP=0    # profiles: every kernel alone on one stream
 CMD="$PYREAL bench.py --steps 10 --warmup 3 --no-cpu --no-ref-grid --no-cfg4 --no-traffic"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- $CMD > $O/prof.log 2>&1

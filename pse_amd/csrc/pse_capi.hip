@@ -566,12 +566,12 @@ static int create_impl(const pse_params *p, pse_handle *h) {
     // layout in ints: [0, B - 1) bin counts (incl. sentinel, padded) | B - 1: flags[0] | B: flags[1] | B + 4 ...: cell counts.  B and every
     // memset size are multiples of four ints: a memset that is not a multiple of 16 bytes takes two fill kernels.
     h->cnt_bins = ((fast_far ? nbins + 1 : 0) + 1 + 3) & ~(size_t)3;   // B
-    constexpr size_t LOCAL_MAX_LAYERS = 512;   // (cell layers along x of an owned-particle rank's grid: the per-layer counts of its sort)
-    TRY(dmalloc(h, &h->cnt_block, h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8 + LOCAL_NCOUNTER + 2 + LOCAL_MAX_LAYERS + 4));
+    constexpr size_t LAYER_INTS = (size_t)LOCAL_MAX_LAYERS * LOCAL_LAYER_SLOTS;   // (the per-layer counts of an owned-particle rank's sort)
+    TRY(dmalloc(h, &h->cnt_block, h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8 + LOCAL_NCOUNTER + 2 + LAYER_INTS + 4));
     h->loc.counters = h->cnt_block + ((h->cnt_bins + 4 + h->n_cells_alloc + 1 + 8 + 1) & ~(size_t)1);   // 8-byte aligned
     h->loc.layer_cnt = h->loc.counters + LOCAL_NCOUNTER;
-    h->loc.zero_ints = ((size_t)(h->loc.layer_cnt - h->cnt_block) + LOCAL_MAX_LAYERS + 3) & ~(size_t)3;
-    if (h->nc.nx > (int)LOCAL_MAX_LAYERS && p->local_rows) return fail(PSE_ERR_INVALID, "more than %zu cell layers along x", LOCAL_MAX_LAYERS);
+    h->loc.zero_ints = ((size_t)(h->loc.layer_cnt - h->cnt_block) + LAYER_INTS + 3) & ~(size_t)3;
+    if (h->nc.nx > LOCAL_MAX_LAYERS && p->local_rows) return fail(PSE_ERR_INVALID, "more than %d cell layers along x", LOCAL_MAX_LAYERS);
     h->vl.flags = h->cnt_block + h->cnt_bins - 1;
     h->gate_word = h->cnt_block + h->cnt_bins + 1;   // (B + 1: between flags[1] and the cell counts; no memset covers it alone)
     h->cell_cnt = h->cnt_block + h->cnt_bins + 4;

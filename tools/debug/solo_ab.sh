@@ -9,7 +9,7 @@ for rep in $(seq $R); do
     if [ -n "$TEAM" ]; then
       env $v python3 tools/perf_team.py --local --ranks 8 --steps 5 --solo 3 2>&1 | grep -E "solo"
     else
-      env $v python3 bench.py --steps 30 --warmup 10 --no-cpu --no-ref-grid --no-traffic 2>&1 | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); p=d['phases_ms_per_step']; print(round(d['ms_per_step'],4), round(d['mf_evals_per_s'],1), round(d['mf_evals_per_s_moving'],1), {k:p[k] for k in ('sort','real','matvec','lanczos','spread','gather')})"
+      env $v python3 bench.py --steps 30 --warmup 10 --no-cpu --no-ref-grid --no-cfg4 --no-traffic 2>&1 | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); p=d['phases_ms_per_step']; print(round(d['ms_per_step'],4), round(d['mf_evals_per_s'],1), round(d['mf_evals_per_s_moving'],1), {k:p[k] for k in ('sort','real','matvec','lanczos','spread','gather')})"
     fi
   done
 done

@@ -280,3 +280,69 @@ def test_two_step_exchange_message_sizes():
     first = (4 + 10 * c_g) * 8
     block = 2 * c_g * 32
     assert 3.5e6 < first < 6e6 and 2.5e6 < block < 4.5e6              # a few MB per neighbour: link time, not latency, bounds them
+
+
+def _lanczos_count_worker(rank, world, port, out):
+    """Every rank feeds its own LanczosCount the numbers the ranks agree on after a step (an all-reduce here; on the device every rank
+    derives them from the same sums): the policy objects of all ranks stay identical -- same starting count, same decision whether a
+    step queues its gated extra block (it decides how many exchanges a step has: a rank that differed would hang the team)."""
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    try:
+        import torch
+        import torch.distributed as dist
+        from pse_amd.sharded import LanczosCount
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+        class FakeTeam:
+            def __init__(self): self.calls = []
+            def set_lanczos_extra(self, k): self.calls.append(k)
+
+        team = FakeTeam()
+        lc = LanczosCount(team, m=2, settle=3)
+        true_m = [7, 7, 7, 7, 7, 7, 8, 8, 8, 8, 8, 7, 7, 7, 7]          # what the suspension needs, step by step
+        trace = []
+        for need in true_m:
+            start, extras = lc.m, 0 if lc.extras_off else 2
+            # what a queue-only step reports: converged at `need` if its queue reached that far, else status 1 at the last size it had
+            reached = start + extras
+            m_step, status = (max(need, start), 0) if reached >= need else (reached, 1)
+            # a rank whose host mirror lags would report the previous step's numbers: the agreed values are the maxima over the ranks
+            t = torch.tensor([float(m_step), float(status)])
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            lc.seen(int(t[0]), int(t[1]))
+            trace.append((start, extras, m_step, status))
+        got = [None] * world
+        dist.all_gather_object(got, (trace, team.calls, lc.m, lc.extras_off))
+        assert all(g == got[0] for g in got), got
+        # the walk: counts 2, 4, 6 fall short (status 1: + 2 each), 8 settles ... at 7 it does not come down by itself (the decision only
+        # ever walks upward from the starting count, as the reference's loop does), the rise to 8 is caught by the gated block or by a status 1
+        assert trace[0] == (2, 2, 4, 1) and trace[1] == (6, 2, 7, 0) and lc.m >= 7 and any(e == 0 for _, e, _, _ in trace)
+        assert all(st == 0 for (_, _, _, st) in trace[2:6])
+        assert 0 in team.calls                                              # the extras were switched off in the steady state ...
+        k8 = true_m.index(8)
+        assert trace[k8][3] == 1 or trace[k8][1] == 2                       # ... and the rise of the needed count was either covered by them or reported
+        out.put((rank, "ok"))
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        out.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))[-1500:]))
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:   # noqa: BLE001
+            pass
+
+
+def test_lanczos_count_policy_stays_identical_across_ranks():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_lanczos_count_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    assert res == [(0, "ok"), (1, "ok")], res

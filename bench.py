@@ -81,7 +81,7 @@ def measure_traffic(kernel_prefix, args):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="pse_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", py, os.path.abspath(__file__),
-               "--steps", "3", "--warmup", "1", "--no-cpu", "--no-ref-grid", "--no-cfg4", "--no-traffic", "--n", str(args.n), "--phi", str(args.phi),
+               "--steps", "3", "--warmup", "1", "--no-cpu", "--no-ref-grid", "--no-cfg4", "--no-async", "--no-traffic", "--n", str(args.n), "--phi", str(args.phi),
                "--grid", str(args.grid), "--error", str(args.error), "--kT", str(args.kT), "--dt", str(args.dt)]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)

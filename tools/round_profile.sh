@@ -3,6 +3,8 @@
 # MI355X_MICROARCH.md prescribes), SQ/TA counters.  tools/round_profile.sh <tag> <commit>  -> gpurun_out/<tag>/ ; the summaries
 # (kernel_stats.csv, pmc_traffic.json with the commit stamped in, sq_counters.txt) are written there too: copy them into profiles/.
 export TMPDIR=/tmp
+# (--no-cfg4 --no-async in the profiled commands: the config-4 block launches kernels of the same names, and the gated extra iterations of
+# queue-only steps are launches that leave at once: both would pollute per-kernel averages)
 # the interpreter itself after `--` (a launcher that re-execs under the profiler is refused on the GPU box)
 PYREAL=$(python3 -c 'import os,sys; print(os.path.realpath(sys.executable))')
 T=${1:-r03}
@@ -11,9 +13,9 @@ O=gpurun_out/$T; rm -rf $O; mkdir -p $O
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 PSE_OVERLAP=0 timeout 600 python bench.py --no-cpu --no-ref-grid --no-cfg4 --no-traffic > $O/bench_one_stream_steps.json 2> $O/bench_one_stream_steps.err   # Brownian steps on ONE stream (the default of rounds 1-5), for comparison
 export PSE_OVERLAP=0    # profiles: every kernel alone on one stream
-CMD="$PYREAL bench.py --steps 10 --warmup 3 --no-cpu --no-ref-grid --no-cfg4 --no-traffic"
+CMD="$PYREAL bench.py --steps 10 --warmup 3 --no-cpu --no-ref-grid --no-cfg4 --no-async --no-traffic"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- $CMD > $O/prof.log 2>&1
-CMD3="$PYREAL bench.py --steps 3 --warmup 1 --no-cpu --no-ref-grid --no-cfg4 --no-traffic"
+CMD3="$PYREAL bench.py --steps 3 --warmup 1 --no-cpu --no-ref-grid --no-cfg4 --no-async --no-traffic"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $CMD3 > $O/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $CMD3 > $O/pmc_write.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $O/sq_a -- $CMD3 > $O/sq_a.log 2>&1

@@ -74,7 +74,7 @@ typedef struct pse_info {
     /* device time of the phases of the most recent call, ms (hipEvent, only if timing enabled) */
     double t_sort, t_spread, t_fft_fwd, t_scale, t_fft_inv, t_gather, t_real, t_lanczos, t_integrate, t_comm, t_total;
     unsigned long long device_bytes;  /* workspace owned by the handle */
-    double t_matvec;                  /* a near-field mat-vec from the per-step pair list (inside t_lanczos): the mean over the call's */
+    double t_matvec;                  /* one near-field mat-vec from the per-step pair list (inside t_lanczos) */
     double t_records;                 /* binning + the 64-byte far-field particle records (t_spread is the spread kernel alone) */
     int lanczos_exchanges;            /* team calls: exchanges the last Brownian call's Lanczos iteration issued (two iterations
                                          per exchange where the decomposition allows: ceil(m / 2) instead of m) */

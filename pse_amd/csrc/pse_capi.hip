@@ -209,8 +209,6 @@ struct pse_handle {
     unsigned long long bytes = 0;
     int sorted_N = 0;
     bool matvec_timed = false;
-    std::vector<hipEvent_t> mv_ev;   // timing on: an event pair around EVERY pair-list mat-vec of a call (t_matvec = their mean, what a profiler's per-kernel average is)
-    int mv_n = 0;
 };
 
 static std::once_flag g_fft_once;
@@ -302,13 +300,7 @@ static int collect_times(pse_handle *h, unsigned mask) {
         *dst[p] = 0.0;
         if (mask & (1u << p)) {
             float ms = 0;
-            if (p == PH_MATVEC) {   // the mean over the pair-list mat-vecs of the call
-                double sum = 0.0;
-                int n = 0;
-                for (int k = 0; k < h->mv_n; ++k)
-                    if (hipEventElapsedTime(&ms, h->mv_ev[2 * k], h->mv_ev[2 * k + 1]) == hipSuccess) { sum += ms; ++n; }
-                *dst[p] = n ? sum / n : 0.0;
-            } else if (hipEventElapsedTime(&ms, h->ph[p].a, h->ph[p].b) == hipSuccess) *dst[p] = ms;
+            if (hipEventElapsedTime(&ms, h->ph[p].a, h->ph[p].b) == hipSuccess) *dst[p] = ms;
         }
     }
     return 0;
@@ -329,7 +321,6 @@ extern "C" int pse_destroy(pse_handle *h) {
                     h->scal, h->partials, h->lz_state};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &p : h->ph) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
-    for (hipEvent_t e : h->mv_ev) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_scal) (void)hipEventDestroy(h->ev_scal);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -1663,7 +1654,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
         lz_decide_supported(std::min(M_MAX, std::max(std::min(std::max(m_io ? *m_io : 2, 1), M_MAX), 2) + h0->tun.lz_extra)))
         return lanczos_queued(T, N, tol, scale, m_io, before_first_wait, before_combine);
     const size_t stride = h0->n_pad;
-    for (pse_handle *h : act(T)) { h->lz_last_queued = false; h->mv_n = 0; }
+    for (pse_handle *h : act(T)) h->lz_last_queued = false;
     int m_in = m_io ? *m_io : 2;
     if (m_in < 1) m_in = 1;
     if (m_in > M_MAX) m_in = M_MAX;
@@ -1679,7 +1670,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
             // iteration j = done on the unnormalised x_j (psi for j = 0, else parked in V[j]); see k_lz_update
             const bool have_y = done == 0 && h0->w_is_mpsi;      // M psi came with the pass that built the pair list
             const bool fused = !have_y && h0->nb.cap > 0 && h0->nb_valid;   // sums fused into the pair-list mat-vec
-            const bool timed = fused;                            // with timing on every pair-list mat-vec is bracketed by its own events (collect_times averages them)
+            const bool timed = done == 1 && fused;               // one pair-list mat-vec kernel per call is timed on its own
             if (!fused && !have_y) TRY(real(T, done == 0 ? &pse_handle::psi_s : &pse_handle::V, &pse_handle::w_s, (size_t)done * stride, 0, N, true));
             for (pse_handle *h : act(T)) {
                 int lo, hi;
@@ -1688,16 +1679,11 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
                 const double4 *vjm1 = done > 1 ? h->V + (size_t)(done - 1) * stride : (done == 1 ? h->psi_s : nullptr);   // x_{j-1}, unnormalised
                 if (fused) {
                     const bool ev = timed && h->timing;
-                    hipEvent_t ea = nullptr, eb = nullptr;
-                    if (ev) {
-                        while ((int)h->mv_ev.size() < 2 * (h->mv_n + 1)) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->mv_ev.push_back(e); }
-                        ea = h->mv_ev[2 * h->mv_n]; eb = h->mv_ev[2 * h->mv_n + 1]; ++h->mv_n;
-                    }
                     launch_mreal_lanczos(h->pos_s, xj, h->w_s, row_map(lo, hi), h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef,
                                          h->nb, LzFuse{vjm1, h->partials, h->npart_cap, nullptr, nullptr, nullptr}, h->scal,
-                                         ea, eb, h->stream,
+                                         ev ? h->ph[PH_MATVEC].a : nullptr, ev ? h->ph[PH_MATVEC].b : nullptr, h->stream,
                                          h->vl_use ? h->vl : VerletList{});
-                    if (ev) h->matvec_timed = true;
+                    if (timed) h->matvec_timed = true;
                 } else if (!(done == 0 && h->sums0_done)) {   // (iteration 0: the sums came with the pass that built the pair list)
                     launch_lz_dots(xj, h->w_s, vjm1, lo, hi, h->partials, h->npart_cap, h->scal, h->stream);
                 }
@@ -1980,7 +1966,7 @@ static int velocity(pse_team &T, const std::vector<Args> &a, const unsigned *gro
     const bool lz = noise && (parts & 1);   // the particle noise M_real^{1/2} psi belongs to the real-space half (the k-space noise to the wave half)
     if (lz) {
         for (pse_handle *h : act(T)) TRY(ts(h, PH_LANCZOS));   // closed inside the Lanczos driver, after the first batch of iterations
-        for (pse_handle *h : act(T)) { h->matvec_timed = false; h->mv_n = 0; }
+        for (pse_handle *h : act(T)) h->matvec_timed = false;
         const std::function<int()> hook = [&]() -> int {    // before the host first waits for the Lanczos scalars: everything else is queued
             if (wave_behind) TRY(wave_start());
             return pump.drain();

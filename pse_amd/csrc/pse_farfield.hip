@@ -114,33 +114,13 @@ k_far_records(const double4 *__restrict__ pos_s, const double4 *__restrict__ f_s
 }
 
 // bin offsets + records; the bin counts and ranks come from the gather-into-cell-order pass (far_bin_args / k_permute)
-// exclusive prefix sum of n bin counts by ONE workgroup (n <= 64 K: 256^3 has 32 769): the library's scan is two launches (state
-// initialisation + look-back scan, ~11 us) in front of the far-field chain of every call; this is one of ~4 us
-constexpr int BIN_SCAN_TPB = 1024, BIN_SCAN_MAX = 65536;
-__global__ void __launch_bounds__(BIN_SCAN_TPB) k_bin_scan(const int *__restrict__ cnt, int *__restrict__ off, int n) {
-    const int per = (n + BIN_SCAN_TPB - 1) / BIN_SCAN_TPB, t0 = threadIdx.x * per, t1 = min(n, t0 + per);
-    int mine = 0;
-    for (int k = t0; k < t1; ++k) mine += cnt[k];
-    __shared__ int wsum[BIN_SCAN_TPB / 64];
-    int incl = mine;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
-    if (lane == 63) wsum[wv] = incl;
-    __syncthreads();
-    int run = incl - mine;
-    for (int w = 0; w < wv; ++w) run += wsum[w];
-    for (int k = t0; k < t1; ++k) { off[k] = run; run += cnt[k]; }
-}
 hipError_t launch_far_records(const double4 *pos_s, const double4 *f_s, int N, DGrid G, DBox box, SpreadWork w, hipStream_t s) {
     if (!farfield_fast_path(G) || !w.rec_t) return hipSuccess;
     FarBins fb = w.fb;
     fb.nbx = bins_of(G.Nx); fb.nby = bins_of(G.Ny); fb.nbz = bins_of(G.Nz);
     const int nbins = fb.nbx * fb.nby * fb.nbz;
     size_t tb = fb.tmp_bytes;
-    hipError_t e = hipSuccess;
-    if (nbins + 1 <= BIN_SCAN_MAX) hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(BIN_SCAN_TPB), 0, s, fb.cnt, fb.off, nbins + 1);
-    else e = hipcub::DeviceScan::ExclusiveSum(fb.tmp, tb, fb.cnt, fb.off, nbins + 1, s);   // cnt[nbins] = 0: off[nbins] = total
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(fb.tmp, tb, fb.cnt, fb.off, nbins + 1, s);   // cnt[nbins] = 0: off[nbins] = total
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_far_records, dim3(nblocks(N, 256)), dim3(256), 0, s, pos_s, f_s, N, G, box, fb, w.rec_t);
     return hipGetLastError();

@@ -2429,33 +2429,41 @@ k_lz_decide(LzDecide a, double *__restrict__ scal, LzState *__restrict__ st, dou
         const bool ok = lz_sqrt_e1(m, alpha, beta, base, tbuf[wv]);
         if ((threadIdx.x & 63) == 0) okf[wv] = ok ? 1 : 0;
     }
+    // what the walk below reads, fetched by all lanes at once: thread 0 alone paid a dependent global round trip per coefficient
+    // (alpha, beta, the previous size's t: ~20 of them in a row, a third of the kernel's 24-28 us)
+    __shared__ double s_alpha[104], s_beta[104], s_prev[104];
+    __shared__ int s_checked;
+    __shared__ double s_stepnorm;
+    for (int q = threadIdx.x; q <= min(a.m_hi, 103); q += blockDim.x) { s_alpha[q] = scal[LZ_ALPHA + q]; s_beta[q] = scal[LZ_BETA + q]; s_prev[q] = st->t_prev[q]; }
+    if (threadIdx.x == 0) { s_checked = a.first ? 0 : st->checked; s_stepnorm = a.first ? 1.0 : st->stepnorm; }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    int m_final = 0, status = 0, checked = st->checked;
-    double stepnorm = st->stepnorm;
+    alpha = s_alpha; beta = s_beta;
+    int m_final = 0, status = 0, checked = s_checked;
+    double stepnorm = s_stepnorm;
     const double *t_fin = nullptr;
     if (dead) { m_final = -1; }
     else if (a.pending_beta > 0 && beta[a.pending_beta] < 1e-8) {   // |x_m| of the vector the previous batch ended on: invariant subspace
-        m_final = a.pending_beta; stepnorm = 0.0; t_fin = st->t_prev;
+        m_final = a.pending_beta; stepnorm = 0.0; t_fin = s_prev;
     } else {
         for (int w = 0; w < nm && !m_final; ++w) {               // walk m upward as the reference's while loop does (PSEv1/Brownian.cu:606-724)
             const int m = a.m_lo + w;
             const bool have_beta = m < a.done_iters || a.have_last_beta;
-            if (!isfinite(alpha[m - 1]) || (have_beta && !isfinite(beta[m])) || !okf[w]) { m_final = max(checked, 1); status = 2; t_fin = checked ? st->t_prev : tbuf[w]; break; }
+            if (!isfinite(alpha[m - 1]) || (have_beta && !isfinite(beta[m])) || !okf[w]) { m_final = max(checked, 1); status = 2; t_fin = checked ? s_prev : tbuf[w]; break; }
             const double *tc = tbuf[w];
             if (m < a.done_iters && beta[m] < 1e-8) { m_final = m; stepnorm = 0.0; t_fin = tc; break; }   // invariant subspace (Brownian.cu:503)
             if (checked == m - 1 && checked > 0) {
                 double s2 = tc[m - 1] * tc[m - 1];
-                for (int q = 0; q < m - 1; ++q) { const double dq = tc[q] - st->t_prev[q]; s2 += dq * dq; }
+                for (int q = 0; q < m - 1; ++q) { const double dq = tc[q] - s_prev[q]; s2 += dq * dq; }
                 stepnorm = sqrt(s2 / alpha[0]);                   // Brownian.cu:719-724; psi.M.psi / |psi|^2 = alpha_0
                 if (stepnorm <= a.tol || m >= a.m_max) { m_final = m; t_fin = tc; break; }
             }
             if (a.have_last_beta && m == a.done_iters && beta[m] < 1e-8) { m_final = m; stepnorm = 0.0; t_fin = tc; break; }
-            for (int q = 0; q < m; ++q) st->t_prev[q] = tc[q];
+            for (int q = 0; q < m; ++q) { st->t_prev[q] = tc[q]; s_prev[q] = tc[q]; }
             checked = m;
         }
         if (!m_final && (a.last || a.done_iters >= a.m_max)) {     // nothing more is queued: end with what there is
-            m_final = checked; t_fin = st->t_prev; status = a.done_iters >= a.m_max ? 0 : 1;
+            m_final = checked; t_fin = s_prev; status = a.done_iters >= a.m_max ? 0 : 1;
         }
     }
     st->checked = checked;

@@ -124,6 +124,7 @@ SYMBOLS = {
     "pse_debug_copy_grid": (_i, [_vp, _i, _dp]),
     "pse_debug_spread": (_i, [_vp, _vp, _vp, _vp, _u]),
     "pse_debug_kvector": (_i, [_vp, _i, _ip, _dp]),
+    "pse_debug_grid_placement": (_i, [_vp, _ip, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
     "pse_team_unique_id": (_i, [_vp]),
     "pse_team_create": (_i, [ctypes.POINTER(_vp), _i, _vp, ctypes.POINTER(_vp)]),
     "pse_team_create_transport": (_i, [_vp, ctypes.POINTER(pse_transport), ctypes.POINTER(_vp)]),

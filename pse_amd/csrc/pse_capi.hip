@@ -92,6 +92,7 @@ struct pse_handle {
         bool verbose = false;     // PSE_VERBOSE
         bool team_sstep = true;      // PSE_TEAM_SSTEP=0: teams run one Lanczos iteration per exchange (default: two, see lanczos_team)
         int team_sched[3] = {1, 2, 3};   // PSE_TEAM_SCHED=a,b,c: far-field exchange k of a team step is issued before Lanczos exchange sched[k]
+        int place_trials = 6;        // PSE_PLACE_TRIALS=K: the two grids are allocated K times and the pair the inverse y + z passes run fastest on is kept (0, 1: off)
         int lz_extra = 2;            // PSE_LANCZOS_EXTRA: iterations a queue-only Brownian call queues beyond the starting count (gated on the device-side decision)
     } tun;
     DCells bidx_nc = {0, 0, 0};      // cell grid the boundary-cell indices on the device belong to
@@ -164,6 +165,7 @@ struct pse_handle {
     bool xfuse = false;                                      // power-of-two Nx: fused x pass (k_xfft_scale)
     bool own_y = false;                                      // y transforms by k_fft_cols, rocFFT does the z transforms only
     bool own_y_slab = false;                                 // ... on a slab rank, with the all-to-all block layout as its output / input
+    int place_tried = 0; float place_ms_first = 0, place_ms_kept = 0;   // place_grids: pairs tried, the probe's time on the first and on the kept one
     bool own_z = false;                                      // z transforms by k_zfft_rows (Nz = 256, 512): rocFFT is then off the path
     double2 *twiddle_z = nullptr, *twiddle_z_owned = nullptr;   // [Nz] exp(-2 pi i m / Nz)
     double2 *twiddle_y = nullptr;                            // [Ny] exp(-2 pi i m / Ny) (== twiddle when Ny == Nx)
@@ -220,6 +222,62 @@ static int dmalloc(pse_handle *h, T **p, size_t n) {
     HIPCHK(hipMalloc((void **)p, n * sizeof(T)));
     h->bytes += n * sizeof(T);
     return 0;
+}
+// The passes that READ the spectra (inverse z, both y passes, the x pass) run 5 - 20 % faster or slower depending on where the driver
+// placed the two grids -- a property of the allocation that holds for the life of the buffers (round 5: the two speeds of the 512^3 x
+// pass; round 6: at 256^3 the inverse y + z passes take 0.293 - 0.329 ms on six pairs allocated one after another in one process, the
+// step 3.15 - 3.26 ms from process to process: docs/HISTORY.md).  A planner's answer: with the first pair in place, allocate more
+// pairs (all alive at once, so that they ARE elsewhere), time the inverse y + z passes on each, keep the fastest and free the rest.
+// Only for grids large enough to matter, only while the device has room for all the candidates; results do not depend on the choice.
+static int place_grids(pse_handle *h, size_t nr, size_t ncx) {
+    const DGrid &G = h->G;
+    const size_t bytes_r = 3 * nr * sizeof(double), bytes_c = 3 * ncx * sizeof(double2);
+    int K = h->tun.place_trials;
+    if (K < 2 || bytes_c < ((size_t)96 << 20)) return 0;
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    K = (int)std::min<size_t>((size_t)K, 1 + free_b / 4 / (bytes_r + bytes_c));   // the candidates may take a quarter of what is free
+    if (K < 2) return 0;
+    struct Cand { double *r = nullptr; double2 *c = nullptr; float t = 1e30f; } cand[12];
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    int best = 0, got = 0, rc = 0;
+    for (int k = 0; k < K && rc == 0; ++k) {
+        Cand &c = cand[k];
+        if (k == 0) { c.r = h->rgrid; c.c = h->cgrid; }           // the pair the engine already holds
+        else {
+            if (hipMalloc((void **)&c.r, bytes_r) != hipSuccess) { (void)hipGetLastError(); c.r = nullptr; break; }
+            if (hipMalloc((void **)&c.c, bytes_c) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(c.r); c.r = nullptr; break; }
+        }
+        ++got;
+        auto probe = [&]() -> int {
+            HIPCHK(hipMemsetAsync(c.r, 0, bytes_r, h->stream));
+            HIPCHK(hipMemsetAsync(c.c, 0, bytes_c, h->stream));
+            double *zr[3]; double2 *zs[3];
+            for (int q = 0; q < 3; ++q) { zr[q] = c.r + q * nr + (size_t)G.hl * G.Ny * G.Nz; zs[q] = c.c + q * ncx; }
+            for (int it = 0; it < 4; ++it) {                      // (the first one untimed)
+                HIPCHK(hipEventRecord(e0, h->stream));
+                launch_yfft(c.c, G, true, h->twiddle_y, h->stream, h->tun.yfft_kb);
+                launch_zfft(zr, zs, G.Nx * G.Ny, G.Nz, G.Nzp, true, h->twiddle_z, h->stream);
+                HIPCHK(hipEventRecord(e1, h->stream));
+                HIPCHK(hipEventSynchronize(e1));
+                float ms = 0;
+                HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+                if (it && ms < c.t) c.t = ms;
+            }
+            return 0;
+        };
+        rc = probe();
+        if (h->tun.verbose) fprintf(stderr, "grid placement %d: real %p spectra %p: inverse y + z passes %.4f ms\n", k, (void *)c.r, (void *)c.c, c.t);
+        if (rc == 0 && c.t < cand[best].t) best = k;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc) best = 0;
+    for (int k = 1; k < got; ++k) if (k != best) { (void)hipFree(cand[k].r); (void)hipFree(cand[k].c); }
+    if (best != 0) { (void)hipFree(cand[0].r); (void)hipFree(cand[0].c); h->rgrid = cand[best].r; h->cgrid = cand[best].c; }
+    h->place_tried = got; h->place_ms_first = cand[0].t; h->place_ms_kept = cand[best].t;
+    if (h->tun.verbose) fprintf(stderr, "grid placement: kept %d of %d (%.4f ms; the first one %.4f)\n", best, got, cand[best].t, cand[0].t);
+    return rc;
 }
 static void set_dbox(pse_handle *h) {
     h->dbox = DBox{h->box.Lx, h->box.Ly, h->box.Lz, h->box.xy, 1.0 / h->box.Lx, 1.0 / h->box.Ly, 1.0 / h->box.Lz};
@@ -490,6 +548,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         t.verbose = ienv("PSE_VERBOSE", 0) > 0;
         t.team_sstep = ienv("PSE_TEAM_SSTEP", 1) > 0;
         t.lz_extra = std::max(0, std::min(32, ienv("PSE_LANCZOS_EXTRA", 2)));
+        t.place_trials = std::max(0, std::min(12, ienv("PSE_PLACE_TRIALS", 6)));
         if (const char *v = getenv("PSE_TEAM_SCHED")) {
             int a = 1, b = 2, c = 3;
             if (sscanf(v, "%d,%d,%d", &a, &b, &c) == 3) { t.team_sched[0] = a; t.team_sched[1] = b; t.team_sched[2] = c; }
@@ -690,6 +749,8 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         h->overlap_all = h->tun.overlap > 0;    // Brownian steps fork unless PSE_OVERLAP=0
     }
     TRY(make_plans(h));
+    if (h->tun.place_trials > 1 && h->own_z && h->own_y && h->grid_slabs == 1)
+        TRY(place_grids(h, (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, (size_t)G.nxl * G.Ny * G.Nzp));
 
     TRY(dmalloc(h, &h->V, (size_t)(M_MAX + 1) * n));
     TRY(dmalloc(h, &h->scal, (size_t)LZ_NSCAL));
@@ -2475,6 +2536,11 @@ extern "C" int pse_eval_realspace(pse_handle *h, const double *r_host, int n, do
     return 0;
 }
 
+extern "C" int pse_debug_grid_placement(pse_handle *h, int *tried, float *ms_first, float *ms_kept) {
+    if (!h || !tried || !ms_first || !ms_kept) return fail(PSE_ERR_INVALID, "pse_debug_grid_placement: null argument");
+    *tried = h->place_tried; *ms_first = h->place_ms_first; *ms_kept = h->place_ms_kept;
+    return 0;
+}
 extern "C" int pse_debug_kvector(pse_handle *h, int n, const int *ijk_host, double *out_host) {
     if (!h || !ijk_host || !out_host || n <= 0) return fail(PSE_ERR_INVALID, "bad argument");
     HIPCHK(hipSetDevice(h->device));

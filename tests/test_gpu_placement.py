@@ -1,0 +1,61 @@
+"""pse_create's grid-placement planner (place_grids, pse_capi.hip; PSE_PLACE_TRIALS): for far-field grids large enough to matter the
+pair (real grid, spectra) is allocated several times and the pair on which the inverse y + z passes run fastest is kept.  The choice
+must not change any result (beyond the 1e-14 by which two calls of ONE engine differ: the order of the particles inside a far-field
+bin is that of an atomic counter), must leave exactly one pair allocated, and must be off where it is said to be off."""
+import math
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(trials, grid, n, box):
+    import pse_amd
+    old = os.environ.get("PSE_PLACE_TRIALS")
+    if trials is None:
+        os.environ.pop("PSE_PLACE_TRIALS", None)
+    else:
+        os.environ["PSE_PLACE_TRIALS"] = str(trials)
+    try:      # (the developer switches are read in pse_create)
+        xi = math.pi * grid / (2.0 * box[0] * math.sqrt(-math.log(1e-3)))
+        return pse_amd.Engine(n, box, xi=xi, error=1e-3, seed=3, grid=(grid,) * 3)
+    finally:
+        if old is None:
+            os.environ.pop("PSE_PLACE_TRIALS", None)
+        else:
+            os.environ["PSE_PLACE_TRIALS"] = old
+
+
+def test_placement_planner_keeps_one_pair_and_changes_no_result():
+    import torch
+    from conftest import make_suspension, to4
+    n, grid = 20_000, 180                                # spectra 3 x 180 x 180 x 91 x 16 B = 141 MB: above the planner's threshold (96 MB)
+    pos, force, box = make_suspension(n, L=60.0)         # (h = 1/3: a grid the rule would pick for a box of this size)
+    dpos, dF = to4(pos, 1.0), to4(force)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    off = _engine(0, grid, n, box)
+    free_off = torch.cuda.mem_get_info()[0]
+    on = _engine(None, grid, n, box)                     # the default: six trials
+    free_on = torch.cuda.mem_get_info()[0]
+    p_off, p_on = off.grid_placement(), on.grid_placement()
+    assert p_off == {"tried": 0, "ms_first": 0.0, "ms_kept": 0.0}
+    assert 2 <= p_on["tried"] <= 6 and 0.0 < p_on["ms_kept"] <= p_on["ms_first"]
+    # the candidates that were not kept are freed: both engines hold the same amount of device memory (2 MB allocation granules)
+    assert abs((free0 - free_off) - (free_off - free_on)) < (64 << 20), (free0, free_off, free_on)
+    assert off.info()["device_bytes"] == on.info()["device_bytes"]
+    u_off, u_on = torch.zeros_like(dpos), torch.zeros_like(dpos)
+    off.mobility(dpos, dF, vel=u_off)
+    on.mobility(dpos, dF, vel=u_on)
+    assert (u_off - u_on).abs().max().item() < 1e-12 * u_off.abs().max().item()
+    u_near_off, u_near_on = torch.zeros_like(dpos), torch.zeros_like(dpos)
+    off.mobility(dpos, dF, vel=u_near_off, parts=1)      # (the near field has no such freedom: equal to the bit)
+    on.mobility(dpos, dF, vel=u_near_on, parts=1)
+    assert torch.equal(u_near_off, u_near_on)
+    v_off, v_on = torch.zeros_like(dpos), torch.zeros_like(dpos)
+    _, m0 = off.brownian_velocity(dpos, dF, 1.0, 1e-3, 7, vel=v_off)
+    _, m1 = on.brownian_velocity(dpos, dF, 1.0, 1e-3, 7, vel=v_on)
+    assert m0 == m1 and (v_off - v_on).abs().max().item() < 1e-11 * v_off.abs().max().item()
+    small = _engine(None, 64, 2000, (24.0, 24.0, 24.0, 0.0))       # a small grid: nothing to plan
+    assert small.grid_placement()["tried"] == 0

@@ -75,7 +75,7 @@ def measure_traffic(kernel_prefix, args):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
-    env = dict(os.environ, TMPDIR="/tmp", PSE_OVERLAP="0")
+    env = dict(os.environ, TMPDIR="/tmp", PSE_OVERLAP="-1")    # (every launch alone on one stream)
     py = os.path.realpath(sys.executable)
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -15,12 +15,25 @@ def short(name):
 
 
 def stats(src, dst, cmd):
+    """The profiler's per-kernel averages, and beside them the MEDIAN duration from the kernel trace of the same run: the averages of the
+    inverse y and z passes include the launches of pse_create's grid-placement probe (four per candidate pair, some on slow pairs)."""
+    import os
+    import statistics
     rows = list(csv.DictReader(open(src)))
+    med = {}
+    trace = src.replace("kernel_stats", "kernel_trace")
+    if trace != src and os.path.exists(trace):
+        d = collections.defaultdict(list)
+        for r in csv.DictReader(open(trace)):
+            d[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        med = {k: statistics.median(v) for k, v in d.items()}
     with open(dst, "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats -- {cmd}\n")
-        f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n")
+        f.write("# MedianNs: from the kernel trace of the same run (the averages of k_yfft_regs<..true..> and k_zfft_rows<..true..> include the create-time placement probe)\n")
+        f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MedianNs\n")
         for r in rows[:32]:
-            f.write(f"\"{short(r['Name'])}\",{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']}\n")
+            m = med.get(r["Name"])
+            f.write(f"\"{short(r['Name'])}\",{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},{'' if m is None else int(m)}\n")
 
 
 def pmc(fetch_csv, write_csv, dst, commit="unrecorded", cmd=""):

@@ -92,7 +92,7 @@ struct pse_handle {
         bool verbose = false;     // PSE_VERBOSE
         bool team_sstep = true;      // PSE_TEAM_SSTEP=0: teams run one Lanczos iteration per exchange (default: two, see lanczos_team)
         int team_sched[3] = {1, 2, 3};   // PSE_TEAM_SCHED=a,b,c: far-field exchange k of a team step is issued before Lanczos exchange sched[k]
-        int place_trials = 6;        // PSE_PLACE_TRIALS=K: the two grids are allocated K times and the pair the inverse y + z passes run fastest on is kept (0, 1: off)
+        int place_trials = 6;        // PSE_PLACE_TRIALS=K: the two grids are allocated K times and the pair the x + inverse y + z passes run fastest on is kept (0, 1: off)
         int lz_extra = 2;            // PSE_LANCZOS_EXTRA: iterations a queue-only Brownian call queues beyond the starting count (gated on the device-side decision)
     } tun;
     DCells bidx_nc = {0, 0, 0};      // cell grid the boundary-cell indices on the device belong to
@@ -226,9 +226,11 @@ static int dmalloc(pse_handle *h, T **p, size_t n) {
 // The passes that READ the spectra (inverse z, both y passes, the x pass) run 5 - 20 % faster or slower depending on where the driver
 // placed the two grids -- a property of the allocation that holds for the life of the buffers (round 5: the two speeds of the 512^3 x
 // pass; round 6: at 256^3 the inverse y + z passes take 0.293 - 0.329 ms on six pairs allocated one after another in one process, the
-// step 3.15 - 3.26 ms from process to process: docs/HISTORY.md).  A planner's answer: with the first pair in place, allocate more
-// pairs (all alive at once, so that they ARE elsewhere), time the inverse y + z passes on each, keep the fastest and free the rest.
+// step 3.15 - 3.26 ms from process to process; at 512^3 the FIRST pair of a process is the slow one, 4.60 ms for the three passes
+// against 3.98 - 4.05 on the next five: docs/HISTORY.md).  A planner's answer: with the first pair in place, allocate more
+// pairs (all alive at once, so that they ARE elsewhere), time the x pass + the inverse y + z passes on each, keep the fastest and free the rest.
 // Only for grids large enough to matter, only while the device has room for all the candidates; results do not depend on the choice.
+static ScaleArgs scale_args(pse_handle *h, bool noise, double kT, double dt, unsigned timestep);
 static int place_grids(pse_handle *h, size_t nr, size_t ncx) {
     const DGrid &G = h->G;
     const size_t bytes_r = 3 * nr * sizeof(double), bytes_c = 3 * ncx * sizeof(double2);
@@ -255,8 +257,10 @@ static int place_grids(pse_handle *h, size_t nr, size_t ncx) {
             HIPCHK(hipMemsetAsync(c.c, 0, bytes_c, h->stream));
             double *zr[3]; double2 *zs[3];
             for (int q = 0; q < 3; ++q) { zr[q] = c.r + q * nr + (size_t)G.hl * G.Ny * G.Nz; zs[q] = c.c + q * ncx; }
+            const ScaleArgs sa = scale_args(h, false, 0.0, 1.0, 0);
             for (int it = 0; it < 4; ++it) {                      // (the first one untimed)
                 HIPCHK(hipEventRecord(e0, h->stream));
+                if (h->xfuse) launch_xfft_scale(c.c, c.c + ncx, c.c + 2 * ncx, G, h->dbox, sa, h->twiddle, h->stream);   // (zeros in, zeros out)
                 launch_yfft(c.c, G, true, h->twiddle_y, h->stream, h->tun.yfft_kb);
                 launch_zfft(zr, zs, G.Nx * G.Ny, G.Nz, G.Nzp, true, h->twiddle_z, h->stream);
                 HIPCHK(hipEventRecord(e1, h->stream));
@@ -268,7 +272,7 @@ static int place_grids(pse_handle *h, size_t nr, size_t ncx) {
             return 0;
         };
         rc = probe();
-        if (h->tun.verbose) fprintf(stderr, "grid placement %d: real %p spectra %p: inverse y + z passes %.4f ms\n", k, (void *)c.r, (void *)c.c, c.t);
+        if (h->tun.verbose) fprintf(stderr, "grid placement %d: real %p spectra %p: x + inverse y + z passes %.4f ms\n", k, (void *)c.r, (void *)c.c, c.t);
         if (rc == 0 && c.t < cand[best].t) best = k;
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

@@ -241,7 +241,7 @@ class Engine:
 
     def grid_placement(self):
         """What pse_create's grid-placement planner did: {"tried": pairs timed (0: off or not applicable), "ms_first", "ms_kept": the
-        inverse y + z passes on the first pair allocated and on the one kept}."""
+        x pass + inverse y + z passes on the first pair allocated and on the one kept}."""
         n, a, b = ctypes.c_int(0), ctypes.c_float(0), ctypes.c_float(0)
         _lib.check(self._lib.pse_debug_grid_placement(self._h, ctypes.byref(n), ctypes.byref(a), ctypes.byref(b)))
         return {"tried": n.value, "ms_first": a.value, "ms_kept": b.value}

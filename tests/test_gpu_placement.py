@@ -1,5 +1,5 @@
 """pse_create's grid-placement planner (place_grids, pse_capi.hip; PSE_PLACE_TRIALS): for far-field grids large enough to matter the
-pair (real grid, spectra) is allocated several times and the pair on which the inverse y + z passes run fastest is kept.  The choice
+pair (real grid, spectra) is allocated several times and the pair on which the x pass and the inverse y + z passes run fastest is kept.  The choice
 must not change any result (beyond the 1e-14 by which two calls of ONE engine differ: the order of the particles inside a far-field
 bin is that of an atomic counter), must leave exactly one pair allocated, and must be off where it is said to be off."""
 import math

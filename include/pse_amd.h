@@ -213,6 +213,13 @@ int pse_debug_kvector(pse_handle *h, int n, const int *ijk_host, double *out_hos
  * not applicable), ms_first / ms_kept = the probe's time on the first pair and on the kept one.  No reference counterpart (cuFFT
  * plans own their work areas, PSEv1/Stokes.cc:262-269). */
 int pse_debug_grid_placement(pse_handle *h, int *tried, float *ms_first, float *ms_kept);
+/* the 16-byte form in which the single GPU's pair-list mat-vec reads its NEIGHBOURS' rows of the Lanczos vector (three 40-bit
+ * mantissas under one exponent, written beside every new vector; the double rows stay the truth for the diagonal term, the sums and
+ * the final combination): rows_host [n][3] -> packed on the device -> unpacked -> out_host [n][3].  |out - in| <= 2^-39 of the row's
+ * largest component.  Why: a gather of 64 scattered rows costs the texture path the same whether it fetches 8 or 16 bytes per lane,
+ * and 24 bytes of doubles are two of them per pair.  PSE_VQ=0 reads doubles (A/B).  No reference counterpart (the reference's
+ * mat-vec recomputes every pair from single-precision positions, PSEv1/Mobility.cu:495-600). */
+int pse_debug_vq_roundtrip(int n, const double *rows_host, double *out_host);
 
 /* -- multi-GPU: slab-decomposed far field + row-sharded near field (new design; the reference is single-GPU,
  *    PSEv1/Stokes.cc:104) ---------------------------------------------------------------------------------------

@@ -92,6 +92,7 @@ struct pse_handle {
         bool verbose = false;     // PSE_VERBOSE
         bool team_sstep = true;      // PSE_TEAM_SSTEP=0: teams run one Lanczos iteration per exchange (default: two, see lanczos_team)
         int team_sched[3] = {1, 2, 3};   // PSE_TEAM_SCHED=a,b,c: far-field exchange k of a team step is issued before Lanczos exchange sched[k]
+        int vq = 1;                  // PSE_VQ=0: the pair-list mat-vec gathers the neighbours' rows as doubles (two gathers per pair) (A/B)
         int place_trials = 6;        // PSE_PLACE_TRIALS=K: the two grids are allocated K times and the pair the x + inverse y + z passes run fastest on is kept (0, 1: off)
         int lz_extra = 2;            // PSE_LANCZOS_EXTRA: iterations a queue-only Brownian call queues beyond the starting count (gated on the device-side decision)
     } tun;
@@ -165,6 +166,7 @@ struct pse_handle {
     bool xfuse = false;                                      // power-of-two Nx: fused x pass (k_xfft_scale)
     bool own_y = false;                                      // y transforms by k_fft_cols, rocFFT does the z transforms only
     bool own_y_slab = false;                                 // ... on a slab rank, with the all-to-all block layout as its output / input
+    void *vq = nullptr;          // [n] 16-byte mirror of the newest Lanczos vector (single GPU; k_lz_update writes it, the pair-list mat-vec gathers from it)
     int place_tried = 0; float place_ms_first = 0, place_ms_kept = 0;   // place_grids: pairs tried, the probe's time on the first and on the kept one
     bool own_z = false;                                      // z transforms by k_zfft_rows (Nz = 256, 512): rocFFT is then off the path
     double2 *twiddle_z = nullptr, *twiddle_z_owned = nullptr;   // [Nz] exp(-2 pi i m / Nz)
@@ -380,7 +382,7 @@ extern "C" int pse_destroy(pse_handle *h) {
     if (h->info_inv) rocfft_execution_info_destroy(h->info_inv);
     void *ptrs[] = {h->keys, h->keys_s, h->vals, h->perm, h->tag_s, h->sort_tmp, h->cell_off, h->cnt_block, h->sw.rec_t, h->sw.fb.off, h->sw.fb.rank_s, h->sw.fb.tmp, h->nb.data, h->nb.cnt, h->vl.idx, h->vl.cnt, h->pos_build, h->pos_s, h->posf_s, h->pv,
                     h->f_s, h->uw_s, h->ur_s, h->ub_s, h->psi_s, h->w_s, h->coef, h->rgrid, h->cgrid, h->sendbuf, h->recvbuf, h->d_bidx, h->d_bounds, h->utot_s, h->w2_s, h->u_s, h->sums_all, h->twiddle, h->twiddle_y_owned, h->twiddle_z_owned, h->fft_work, h->V,
-                    h->scal, h->partials, h->lz_state};
+                    h->scal, h->partials, h->lz_state, h->vq};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &p : h->ph) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -553,6 +555,7 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         t.team_sstep = ienv("PSE_TEAM_SSTEP", 1) > 0;
         t.lz_extra = std::max(0, std::min(32, ienv("PSE_LANCZOS_EXTRA", 2)));
         t.place_trials = std::max(0, std::min(12, ienv("PSE_PLACE_TRIALS", 6)));
+        t.vq = ienv("PSE_VQ", 1);
         if (const char *v = getenv("PSE_TEAM_SCHED")) {
             int a = 1, b = 2, c = 3;
             if (sscanf(v, "%d,%d,%d", &a, &b, &c) == 3) { t.team_sched[0] = a; t.team_sched[1] = b; t.team_sched[2] = c; }
@@ -757,6 +760,8 @@ static int create_impl(const pse_params *p, pse_handle *h) {
         TRY(place_grids(h, (size_t)(G.nxl + G.hl + G.nhalo) * G.Ny * G.Nz, (size_t)G.nxl * G.Ny * G.Nzp));
 
     TRY(dmalloc(h, &h->V, (size_t)(M_MAX + 1) * n));
+    // single GPU: the newest Lanczos vector also in 16 bytes per row (vq_pack): what the pair-list mat-vec gathers its neighbours from
+    if (h->n_slabs == 1 && !h->loc.on && h->tun.vq > 0) TRY(dmalloc(h, (char **)&h->vq, (size_t)16 * n));
     TRY(dmalloc(h, &h->scal, (size_t)LZ_NSCAL));
     TRY(dmalloc(h, &h->lz_state, 1));
     HIPCHK(hipMemset(h->lz_state, 0, sizeof(LzState)));
@@ -1662,7 +1667,7 @@ static int lanczos_queued(pse_team &T, int N, double tol, double scale, int *m_i
     // the vector part of iteration j: x_{j+1} from the sums that are still in place
     auto vector_part = [&](int j, const int *gate) {
         launch_lz_update(vec(j), h->w_s, j > 0 ? vec(j - 1) : nullptr, h->V + (size_t)(j + 1) * stride, j, h->scal, rg, nrg_all, h->stream,
-                         nullptr, 0, h->sc_host_dev, gate);
+                         nullptr, 0, h->sc_host_dev, gate, h->vq);   // (+ the mirror of x_{j+1}: the next mat-vec's gathers)
     };
     auto iteration = [&](int j, bool scalars_only, const int *gate) -> int {
         const bool have_y = j == 0 && h->w_is_mpsi;
@@ -1675,7 +1680,7 @@ static int lanczos_queued(pse_team &T, int N, double tol, double scale, int *m_i
         if (fused)
             launch_mreal_lanczos(h->pos_s, vec(j), h->w_s, row_map(0, N), h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, h->nb,
                                  LzFuse{vjm1, h->partials, h->npart_cap, nullptr, nullptr, nullptr}, h->scal, nullptr, nullptr, h->stream,
-                                 h->vl_use ? h->vl : VerletList{}, 1, gate);
+                                 h->vl_use ? h->vl : VerletList{}, 1, gate, DevRowArgs{}, j > 0 ? h->vq : nullptr);
         else if (!(j == 0 && h->sums0_done))
             launch_lz_dots(vec(j), h->w_s, vjm1, 0, N, h->partials, h->npart_cap, h->scal, h->stream);
         h->w_is_mpsi = false; h->sums0_done = false;
@@ -1747,7 +1752,7 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
                     launch_mreal_lanczos(h->pos_s, xj, h->w_s, row_map(lo, hi), h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef,
                                          h->nb, LzFuse{vjm1, h->partials, h->npart_cap, nullptr, nullptr, nullptr}, h->scal,
                                          ev ? h->ph[PH_MATVEC].a : nullptr, ev ? h->ph[PH_MATVEC].b : nullptr, h->stream,
-                                         h->vl_use ? h->vl : VerletList{});
+                                         h->vl_use ? h->vl : VerletList{}, 1, nullptr, DevRowArgs{}, done > 0 && T.G <= 1 ? h->vq : nullptr);
                     if (timed) h->matvec_timed = true;
                 } else if (!(done == 0 && h->sums0_done)) {   // (iteration 0: the sums came with the pass that built the pair list)
                     launch_lz_dots(xj, h->w_s, vjm1, lo, hi, h->partials, h->npart_cap, h->scal, h->stream);
@@ -1768,7 +1773,8 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
                 const int nrg = scalars_only ? 0 : update_ranges(h, N, rg);
                 const double4 *xj = done == 0 ? h->psi_s : h->V + (size_t)done * stride;
                 launch_lz_update(xj, h->w_s, done > 1 ? h->V + (size_t)(done - 1) * stride : (done == 1 ? h->psi_s : nullptr),
-                                 h->V + (size_t)(done + 1) * stride, done, h->scal, rg, nrg, h->stream, h->sums_all, T.G > 1 ? T.G : 0, h == h0 ? h->sc_host_dev : nullptr);
+                                 h->V + (size_t)(done + 1) * stride, done, h->scal, rg, nrg, h->stream, h->sums_all, T.G > 1 ? T.G : 0, h == h0 ? h->sc_host_dev : nullptr,
+                                 nullptr, T.G <= 1 ? h->vq : nullptr);
             }
         }
         // (alpha, beta and the norm are already on their way: the update kernels write them to the mapped host buffer as well)
@@ -1819,7 +1825,8 @@ static int lanczos(pse_team &T, int N, double tol, double scale, int *m_io, cons
             const int j = done - 1;
             const double4 *xj = j == 0 ? h->psi_s : h->V + (size_t)j * stride;
             launch_lz_update(xj, h->w_s, j > 1 ? h->V + (size_t)(j - 1) * stride : (j == 1 ? h->psi_s : nullptr),
-                             h->V + (size_t)(j + 1) * stride, j, h->scal, rg, nrg, h->stream, h->sums_all, T.G > 1 ? T.G : 0, h == h0 ? h->sc_host_dev : nullptr);
+                             h->V + (size_t)(j + 1) * stride, j, h->scal, rg, nrg, h->stream, h->sums_all, T.G > 1 ? T.G : 0, h == h0 ? h->sc_host_dev : nullptr,
+                             nullptr, T.G <= 1 ? h->vq : nullptr);
         }
         pending_beta = done;
         target = std::min(M_MAX, done + std::max(2, done / 4));
@@ -2540,6 +2547,19 @@ extern "C" int pse_eval_realspace(pse_handle *h, const double *r_host, int n, do
     return 0;
 }
 
+extern "C" int pse_debug_vq_roundtrip(int n, const double *rows_host, double *out_host) {
+    if (n < 0 || (n > 0 && (!rows_host || !out_host))) return fail(PSE_ERR_INVALID, "pse_debug_vq_roundtrip: null argument");
+    if (n == 0) return 0;
+    double *d_in = nullptr, *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_in, (size_t)3 * n * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, (size_t)3 * n * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(d_in, rows_host, (size_t)3 * n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) { launch_vq_roundtrip(d_in, d_out, n, nullptr); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpy(out_host, d_out, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(PSE_ERR_HIP, "pse_debug_vq_roundtrip: %s", hipGetErrorString(e));
+    return 0;
+}
 extern "C" int pse_debug_grid_placement(pse_handle *h, int *tried, float *ms_first, float *ms_kept) {
     if (!h || !tried || !ms_first || !ms_kept) return fail(PSE_ERR_INVALID, "pse_debug_grid_placement: null argument");
     *tried = h->place_tried; *ms_first = h->place_ms_first; *ms_kept = h->place_ms_kept;

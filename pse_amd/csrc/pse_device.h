@@ -75,6 +75,38 @@ __device__ __forceinline__ int xcd_block(int b, int nb) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
+// ---- a Lanczos vector row in 16 bytes: three 40-bit mantissas under one exponent ------------------------------------------------
+// The pair-list mat-vec gathers its neighbours' vector rows, and a wavefront's gather of 64 scattered addresses costs the texture
+// path the same 64 cycles whether it fetches 16 or 8 bytes per lane: the 24 bytes of (x, y, z) in doubles are TWO such instructions
+// per pair, and the kernel is bound by them (TA 78 % busy).  One 16-byte word per row holds the three components as signed 40-bit
+// integers scaled by the power of two above the largest of them: absolute error <= 2^-39 of the row's largest component (1.8e-12),
+// four orders below the single-precision pair coefficients the same mat-vec already reads.  w = (x lo, y lo, z lo, x hi | y hi << 8 |
+// z hi << 16 | (e + 128) << 24).  Written by k_lz_update beside the double row it mirrors; the row itself stays the truth (diagonal
+// term, sums, basis combination).
+typedef unsigned vq4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ vq4 vq_pack(double x, double y, double z) {
+    const double m = fmax(fabs(x), fmax(fabs(y), fabs(z)));
+    int e = 0;
+    (void)frexp(m, &e);                                   // m = f 2^e, 0.5 <= f < 1  (m = 0: e = 0)
+    e = e < -100 ? -100 : (e > 127 ? 127 : e);
+    const double sc = __hiloint2double((39 - e + 1023) << 20, 0);   // 2^(39 - e): |component| sc < 2^39
+    const double lim = 549755813887.0;                    // 2^39 - 1 (f -> 1 may round up to 2^39)
+    const long long ix = (long long)fmax(-lim, fmin(lim, rint(x * sc))), iy = (long long)fmax(-lim, fmin(lim, rint(y * sc))),
+                    iz = (long long)fmax(-lim, fmin(lim, rint(z * sc)));
+    vq4 w;
+    w.x = (unsigned)ix; w.y = (unsigned)iy; w.z = (unsigned)iz;
+    w.w = ((unsigned)(ix >> 32) & 0xffu) | (((unsigned)(iy >> 32) & 0xffu) << 8) | (((unsigned)(iz >> 32) & 0xffu) << 16) | ((unsigned)(e + 128) << 24);
+    return w;
+}
+__device__ __forceinline__ void vq_unpack(vq4 w, double &x, double &y, double &z) {
+    const int e = (int)(w.w >> 24) - 128;
+    const double sc = __hiloint2double((e - 39 + 1023) << 20, 0);   // 2^(e - 39)
+    const int hx = (int)(w.w << 24) >> 24, hy = (int)(w.w << 16) >> 24, hz = (int)(w.w << 8) >> 24;   // sign-extended bits 39..32
+    x = fma((double)hx, 4294967296.0, (double)w.x) * sc;
+    y = fma((double)hy, 4294967296.0, (double)w.y) * sc;
+    z = fma((double)hz, 4294967296.0, (double)w.z) * sc;
+}
+
 __device__ __forceinline__ int wrapi(int a, int n) { a %= n; return a < 0 ? a + n : a; }
 
 // ---- Philox4x32-10 ------------------------------------------------------------------------------------

@@ -181,7 +181,8 @@ void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w
                           VerletList vl = VerletList{},   // in use this step: rows that overflowed the pair list walk it instead of the cells
                           int sums = 1,                   // 0 none, 1 one-step Lanczos sums, 2 Gram sums of a two-step block, 3 single step of that driver
                           const int *stop = nullptr,      // nullable: leave at once if *stop != 0 (the device-side Lanczos decision)
-                          DevRowArgs dr = DevRowArgs{});  // owned-particle ranks: rows from device memory
+                          DevRowArgs dr = DevRowArgs{},   // owned-particle ranks: rows from device memory
+                          const void *vec_q = nullptr);   // (sums == 1) the 16-byte mirror of vec_s (launch_lz_update's xq): the neighbours' rows in ONE gather per pair
 int mreal_partials_needed(int rows);
 void launch_lz_reduce3(const double *partials, int npart, int cap, double *scal, hipStream_t s);
 
@@ -295,9 +296,11 @@ void launch_lz_block(const LzBlockArgs &a, bool full, double *scal, const int (*
                      const double *sums_all = nullptr, int nranks = 0, double *sch = nullptr,
                      const RowRanges *rg_dev = nullptr, int rows_cap = 0,   // owned-particle ranks: the ranges come from device memory (vectors_off: scalars only)
                      bool vectors_off = false, const int *stop = nullptr);
+void launch_vq_roundtrip(const double *in, double *out, int n, hipStream_t s);   // debug: vq_unpack(vq_pack(row)) of n rows of three doubles
 void launch_lz_update(const double4 *xin, const double4 *y, const double4 *xprev, double4 *xnext, int j,
                       double *scal, const int (*row_ranges)[2], int n_ranges, hipStream_t s,   // up to three disjoint row ranges in one launch
-                      const double *sums_all = nullptr, int nranks = 0, double *sch = nullptr, const int *stop = nullptr);
+                      const double *sums_all = nullptr, int nranks = 0, double *sch = nullptr, const int *stop = nullptr,
+                      void *xq = nullptr);   // nullable: [rows] 16-byte mirror of xnext (vq_pack, pse_device.h), written on the same rows
 // ---- the convergence decision of the Lanczos iteration ON THE DEVICE (queue-only Brownian calls: pse_set_async) ----------------
 // Replaces, for calls that may not wait for the host, what the host driver does between batches of iterations (the reference's
 // LAPACKE_spteqr + host loops, PSEv1/Brownian.cu:540-582, and its step-norm test, PSEv1/Brownian.cu:673-724): one workgroup solves

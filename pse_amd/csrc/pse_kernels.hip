@@ -678,12 +678,13 @@ __device__ __forceinline__ void eval_fg_lean(double r2, const double *__restrict
 // through LDS): the waves resident on a CU then gather from a quarter as many neighbourhoods (the kernel is bound by L1 misses).
 // FUSE: 0 none; 1 the three sums of the one-step iteration; 2 the Gram sums of a two-step block (this launch is its SECOND
 // mat-vec: vec = w1 = M q, result w2); 3 the sums of a single step in the two-step driver (vec = q, result w1).
-template <int FUSE, int UNROLL, int NT, int WSP = 1>
+// VQ: the neighbours' rows come from the 16-byte mirror of the vector (vq_pack, pse_device.h): ONE gather per pair instead of two.
+template <int FUSE, int UNROLL, int NT, int WSP = 1, bool VQ = false>
 __global__ void __launch_bounds__(NT, (WSP == 4 ? 5 : 1))   // the split kernel: <= 96 VGPRs, five workgroups per CU (it is bound by the round trips its waves have in flight)
 k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_s, double4 *__restrict__ out_s, RowMap rm_arg,
              DBox box, double self, NbList nb, LzFuse lz,
              const int *__restrict__ cell_off, DCells nc, double rcut2, const double *__restrict__ coef, VerletList vl,
-             const int *__restrict__ stop, DevRowArgs dr) {
+             const int *__restrict__ stop, DevRowArgs dr, const vq4 *__restrict__ vec_q = nullptr) {
     if (stop && *stop) return;   // the Lanczos iteration has ended (device-side decision)
     const RowMapRegs rm(rm_arg, dr.rm);
     int nb_live = gridDim.x;
@@ -730,8 +731,10 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
                 }
                 double2 vxy[UNROLL];
                 double vz[UNROLL];
+                vq4 vq[UNROLL];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
+                    if (VQ) { vq[u] = vec_q[e[u] & JMASK]; continue; }   // the row in 16 bytes: one gather
                     const double4 *vj = vec_s + (e[u] & JMASK);   // 24 of the row's 32 bytes: a 16- and an 8-byte gather from one line
                     vxy[u] = *reinterpret_cast<const double2 *>(vj);
                     vz[u] = vj->z;
@@ -741,6 +744,7 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
                     PairCoef pc;
                     const bool ok = s0 + u < cnt;
                     pc.f = ok ? c[u].x : 0.0f; pc.sx = ok ? c[u].y : 0.0f; pc.sy = ok ? c[u].z : 0.0f; pc.sz = ok ? c[u].w : 0.0f; pc.neg = e[u] & NB_NEG;
+                    if (VQ) { vq_unpack(vq[u], vxy[u].x, vxy[u].y, vz[u]); }
                     pair_apply(pc, vxy[u].x, vxy[u].y, vz[u], ux, uy, uz);
                 }
             }
@@ -908,14 +912,17 @@ void launch_lz_reduce3(const double *partials, int npart, int cap, double *scal,
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, RowMap rm, const int *cell_off,
                           DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,
                           double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s, VerletList vl,
-                          int sums, const int *stop, DevRowArgs dr) {
+                          int sums, const int *stop, DevRowArgs dr, const void *vec_q) {
     const int rows = std::max(dr.rm ? dr.rows_cap : rm.list_rows(), 1);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     // Four waves per block of 64 rows, each taking every fourth group of slots: 0.166 ms against 0.191 with four blocks of rows
     // per workgroup (two waves: 0.182, eight: 0.196).
     const int nb64 = nblocks(rows, 64);
 #define PSE_LIST(F) hipLaunchKernelGGL((k_mreal_list<F, 4, 256, 4>), dim3(nb64), dim3(256), 0, s, pos_s, vec_s, w, rm, box, self, nb, lz, cell_off, nc, rcut * rcut, coef, vl, stop, dr)
-    if (sums == 0) PSE_LIST(0); else if (sums == 1) PSE_LIST(1); else if (sums == 2) PSE_LIST(2); else PSE_LIST(3);
+    if (sums == 1 && vec_q)
+        hipLaunchKernelGGL((k_mreal_list<1, 4, 256, 4, true>), dim3(nb64), dim3(256), 0, s, pos_s, vec_s, w, rm, box, self, nb, lz, cell_off, nc, rcut * rcut, coef, vl, stop, dr,
+                           (const vq4 *)vec_q);
+    else if (sums == 0) PSE_LIST(0); else if (sums == 1) PSE_LIST(1); else if (sums == 2) PSE_LIST(2); else PSE_LIST(3);
 #undef PSE_LIST
     if (ev_end) (void)hipEventRecord(ev_end, s);
     if (sums == 1) hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, lz.partials, nb64, lz.npart_cap, 3, scal, stop);
@@ -2199,7 +2206,7 @@ k_lz_reduce(const double *__restrict__ partials, int npart, int cap, int nsum, d
 __global__ void __launch_bounds__(TPB)
 k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, const double4 *__restrict__ xprev,
             double4 *__restrict__ xnext, int j, double *__restrict__ scal, RowRanges rg,
-            const double *__restrict__ sums_all, int nranks, double *__restrict__ sch, const int *__restrict__ stop) {
+            const double *__restrict__ sums_all, int nranks, double *__restrict__ sch, const int *__restrict__ stop, vq4 *__restrict__ xq) {
     if (stop && *stop) return;
     // the three sums: this GPU's (single GPU), or the ranks' partial sums added in rank order -- every rank holds all of them
     // (they travel with the ghost rows: no separate all-reduce) and adds them in the same order: identical scalars everywhere
@@ -2227,6 +2234,7 @@ k_lz_update(const double4 *__restrict__ xin, const double4 *__restrict__ y, cons
         double nx = (q.x - alpha * p.x) * inv, ny = (q.y - alpha * p.y) * inv, nz = (q.z - alpha * p.z) * inv;
         if (xprev) { const double4 m = xprev[i]; nx -= cp * m.x; ny -= cp * m.y; nz -= cp * m.z; }
         xnext[i] = make_double4(nx, ny, nz, 0.0);
+        if (xq) xq[i] = vq_pack(nx, ny, nz);   // the 16-byte mirror the next pair-list mat-vec gathers its neighbours from
     }
 }
 // ---- two Lanczos iterations per exchange (teams) ---------------------------------------------------------------------------
@@ -2497,12 +2505,22 @@ void launch_lz_dots(const double4 *x, const double4 *y, const double4 *vprev, in
 }
 void launch_lz_update(const double4 *xin, const double4 *y, const double4 *xprev, double4 *xnext, int j,
                       double *scal, const int (*rg)[2], int nrg, hipStream_t s, const double *sums_all, int nranks, double *sch,
-                      const int *stop) {
+                      const int *stop, void *xq) {
     RowRanges r{};
     r.n = nrg;
     int total = 0;
     for (int q = 0; q < nrg && q < 3; ++q) { r.lo[q] = rg[q][0]; r.hi[q] = rg[q][1]; total += rg[q][1] - rg[q][0]; }
-    hipLaunchKernelGGL(k_lz_update, dim3(vec_grid(std::max(1, total))), dim3(TPB), 0, s, xin, y, xprev, xnext, j, scal, r, sums_all, nranks, sch, stop);
+    hipLaunchKernelGGL(k_lz_update, dim3(vec_grid(std::max(1, total))), dim3(TPB), 0, s, xin, y, xprev, xnext, j, scal, r, sums_all, nranks, sch, stop, (vq4 *)xq);
+}
+__global__ void k_vq_roundtrip(const double *__restrict__ in, double *__restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x, y, z;
+    vq_unpack(vq_pack(in[3 * i], in[3 * i + 1], in[3 * i + 2]), x, y, z);
+    out[3 * i] = x; out[3 * i + 1] = y; out[3 * i + 2] = z;
+}
+void launch_vq_roundtrip(const double *in, double *out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_vq_roundtrip, dim3(nblocks(n, TPB)), dim3(TPB), 0, s, in, out, n);
 }
 // out[i] = a[i] + b[i] + c[i] on rows [lo, hi)  (each may be null)
 __global__ void k_sum_rows(const double4 *__restrict__ a, const double4 *__restrict__ b, const double4 *__restrict__ c,

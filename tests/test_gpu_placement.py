@@ -59,3 +59,28 @@ def test_placement_planner_keeps_one_pair_and_changes_no_result():
     assert m0 == m1 and (v_off - v_on).abs().max().item() < 1e-11 * v_off.abs().max().item()
     small = _engine(None, 64, 2000, (24.0, 24.0, 24.0, 0.0))       # a small grid: nothing to plan
     assert small.grid_placement()["tried"] == 0
+
+
+def test_packed_vector_rows_round_trip_within_their_bound():
+    """vq_pack / vq_unpack (pse_device.h): the 16-byte form in which the pair-list mat-vec gathers its neighbours' rows of the Lanczos
+    vector -- three 40-bit mantissas under the exponent of the row's largest component: |error| <= 2^-39 of that component, for any
+    scale of the row, components of either sign, zeros, and a largest component just below a power of two (the mantissa clamp)."""
+    import ctypes
+    import numpy as np
+    from pse_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    rows = rng.standard_normal((20000, 3)) * 10.0 ** rng.uniform(-25, 25, (20000, 1))
+    rows[:2000] *= 10.0 ** rng.uniform(-6, 0, (2000, 3))          # wide ratios inside a row
+    rows[2000:2100, 1] = 0.0
+    rows[2100] = 0.0
+    rows[2101] = (np.nextafter(1.0, 0.0), -np.nextafter(1.0, 0.0), 0.5)
+    rows[2102] = (np.nextafter(2.0 ** -30, 0.0), 2.0 ** -31, -2.0 ** -69)
+    rows[2103] = (1.0, -1.0, 2.0 ** -38)
+    out = np.zeros_like(rows)
+    dp = ctypes.POINTER(ctypes.c_double)
+    assert lib.pse_debug_vq_roundtrip(len(rows), rows.ctypes.data_as(dp), out.ctypes.data_as(dp)) == 0
+    bound = 2.0 ** -39 * np.abs(rows).max(axis=1, keepdims=True)
+    assert (np.abs(out - rows) <= bound).all()
+    assert (out[2100] == 0.0).all() and (out[2000:2100, 1] == 0.0).all()
+    assert out[2103, 2] == 2.0 ** -38                                 # one unit of the last place of the mantissa (1.0 = 0.5 x 2^1: scale 2^38)

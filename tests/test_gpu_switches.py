@@ -34,6 +34,7 @@ CASES = [
     ({"PSE_SIDE_PRIORITY": "default"}, ["test_gpu_local.py"], "velocities_match"),   # (an owned-particle rank's far-field lane is LOW by default)
     ({"PSE_SIDE_PRIORITY": "high"}, ["test_gpu_local.py"], "velocities_match"),
     ({"PSE_SKIN": "0"}, ["test_gpu_parity.py", "test_gpu_nlist.py"], "mreal_matches_oracle or brownian_velocity_matches_port or step_integrates"),
+    ({"PSE_VQ": "0"}, ["test_gpu_parity.py"], "brownian_velocity_matches_port or step_integrates"),   # the mat-vec's neighbour rows as doubles
     ({"PSE_LANCZOS_EXTRA": "0"}, ["test_gpu_async.py"], "captured"),       # no gated iterations queued: the starting count must suffice
     ({"PSE_LANCZOS_EXTRA": "4"}, ["test_gpu_async.py", "test_gpu_local.py"], "captured or velocities_match"),
     ({"PSE_TEAM_SSTEP": "0"}, ["test_gpu_slabs.py"], "clustered or particle_group or follows_tilt"),  # one Lanczos iteration per exchange (replicated-state teams)

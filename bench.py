@@ -877,6 +877,7 @@ def main():
     # at this kT dt outrun r_buff / 2 every step, so every step sorts and walks the cells, as with PSE_SKIN=0)
     nl_note = None
     eng = getattr(sim, "engine", None)
+    placement = eng.grid_placement() if eng is not None and hasattr(eng, "grid_placement") else None   # what pse_create's placement planner did
     if eng is not None and hasattr(eng, "neighbor_stats"):
         rb, nb_, nr_ = eng.neighbor_stats()
         nl_note = {"r_buff": rb, "calls_that_built": nb_, "calls_that_reused": nr_,
@@ -899,6 +900,7 @@ def main():
                           "frac_of_hbm_peak": a_step / t_step / 1e9 / (HBM_PEAK_GBS * world)},
         "lanczos_m": m_avg, "lanczos_matvecs_per_step": info["lanczos_matvecs"],
         "neighbor_list": nl_note,
+        "grid_placement": placement,
         "roofline": {"bound": "hbm", "limiter": limiters.get(dom), "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg[dom], "ms_per_launch": per_launch_ms[dom],
@@ -932,7 +934,8 @@ def main():
         torch.cuda.synchronize()
         ri = ref.info()
         out["reference_rule_grid"] = {"grid": [ri["Nx"], ri["Ny"], ri["Nz"]], "xi": 0.5, "rcut": ri["rcut"], "P": ri["P"],
-                                      "ms_per_step": (time.perf_counter() - t0) / n_ref * 1e3, "steps": n_ref, "lanczos_m": mr}
+                                      "ms_per_step": (time.perf_counter() - t0) / n_ref * 1e3, "steps": n_ref, "lanczos_m": mr,
+                                      "grid_placement": ref.engine.grid_placement() if hasattr(getattr(ref, "engine", None), "grid_placement") else None}
     if world == 1 and not args.no_cfg4:
         # BASELINE config 4 (N = 4194304, phi = 0.3, 512^3, xi from the grid) on this ONE GPU: what a multi-GPU line's config-4 block is
         # divided by (its own engine, a few steps; never the headline)
@@ -957,7 +960,8 @@ def main():
             torch.cuda.synchronize()
             t4 = (time.perf_counter() - t0) / n_c4
             out["config4_single_gpu"] = {"workload": f"N={n4}, phi={args.cfg4_phi}, grid {g4}^3, xi={xi4:.4f}", "ms_per_step": t4 * 1e3, "steps": n_c4,
-                                         "lanczos_m": m4, "particle_steps_per_s": n4 / t4}
+                                         "lanczos_m": m4, "particle_steps_per_s": n4 / t4,
+                                         "grid_placement": c4.engine.grid_placement() if hasattr(getattr(c4, "engine", None), "grid_placement") else None}
             out["config4_single_gpu_ms"] = t4 * 1e3
             del c4, pos4, force4
             torch.cuda.empty_cache()

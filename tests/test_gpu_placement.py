@@ -84,3 +84,30 @@ def test_packed_vector_rows_round_trip_within_their_bound():
     assert (np.abs(out - rows) <= bound).all()
     assert (out[2100] == 0.0).all() and (out[2000:2100, 1] == 0.0).all()
     assert out[2103, 2] == 2.0 ** -38                                 # one unit of the last place of the mantissa (1.0 = 0.5 x 2^1: scale 2^38)
+
+
+def _vq_model(rows):
+    """NumPy restatement of vq_pack followed by vq_unpack (pse_device.h): exponent e of the row's largest magnitude (m = f 2^e, 0.5 <= f < 1),
+    clamped to [-100, 127]; mantissas rint(component x 2^(39 - e)) clamped to +-(2^39 - 1); value = mantissa x 2^(e - 39)."""
+    import numpy as np
+    m = np.abs(rows).max(axis=1)
+    e = np.where(m > 0, np.frexp(m)[1], 0)
+    e = np.clip(e, -100, 127)
+    lim = 2.0 ** 39 - 1
+    mant = np.clip(np.rint(np.ldexp(rows, (39 - e)[:, None])), -lim, lim)
+    return np.ldexp(mant, (e - 39)[:, None])
+
+
+def test_packed_vector_rows_are_the_stated_format_to_the_bit():
+    import ctypes
+    import numpy as np
+    from pse_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    rows = rng.standard_normal((50000, 3)) * 10.0 ** rng.uniform(-12, 3, (50000, 1))
+    rows[:5000] *= 10.0 ** rng.uniform(-14, 0, (5000, 3))
+    rows[5000] = (np.nextafter(1.0, 0.0), 0.25, -0.125)            # rounds up to 2^39: clamped
+    out = np.zeros_like(rows)
+    dp = ctypes.POINTER(ctypes.c_double)
+    assert lib.pse_debug_vq_roundtrip(len(rows), rows.ctypes.data_as(dp), out.ctypes.data_as(dp)) == 0
+    assert np.array_equal(out, _vq_model(rows))

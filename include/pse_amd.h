@@ -206,10 +206,10 @@ int pse_debug_spread(pse_handle *h, const pse_double4 *pos, const pse_double4 *f
  * factor w) and gpu_stokes_Green_kernel / gpu_stokes_BrownianGridGenerate_kernel multiply by (PSEv1/Mobility.cu:290,
  * PSEv1/Brownian.cu:274-276) */
 int pse_debug_kvector(pse_handle *h, int n, const int *ijk_host, double *out_host);
-/* what pse_create's grid-placement planner did (single-GPU engines with grids of >= 96 MB of spectra; PSE_PLACE_TRIALS=K, default 6,
+/* what pse_create's grid-placement planner did (single-GPU engines with grids of >= 96 MB of spectra; PSE_PLACE_TRIALS=K, default 10,
  * 0 or 1: off): the transform passes that read the spectra run 5 - 20 % faster or slower depending on where the driver placed the
- * two far-field grids, for the life of the allocation, so pse_create allocates the pair up to K times, times the x pass and the inverse y + z passes
- * on each and keeps the fastest (+ ~10 ms at create; results do not depend on the choice).  *tried = pairs timed (0: planner off or
+ * two far-field grids, for the life of the allocation, so pse_create allocates the pair up to K times (it stops at the first pair 5 % below the slowest seen), times the x pass and the
+ * inverse y + z passes on each and keeps the fastest (+ 5 - 20 ms at create; results do not depend on the choice).  *tried = pairs timed (0: planner off or
  * not applicable), ms_first / ms_kept = the probe's time on the first pair and on the kept one.  No reference counterpart (cuFFT
  * plans own their work areas, PSEv1/Stokes.cc:262-269). */
 int pse_debug_grid_placement(pse_handle *h, int *tried, float *ms_first, float *ms_kept);

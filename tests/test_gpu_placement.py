@@ -37,11 +37,11 @@ def test_placement_planner_keeps_one_pair_and_changes_no_result():
     free0 = torch.cuda.mem_get_info()[0]
     off = _engine(0, grid, n, box)
     free_off = torch.cuda.mem_get_info()[0]
-    on = _engine(None, grid, n, box)                     # the default: six trials
+    on = _engine(None, grid, n, box)                     # the default: up to ten trials
     free_on = torch.cuda.mem_get_info()[0]
     p_off, p_on = off.grid_placement(), on.grid_placement()
     assert p_off == {"tried": 0, "ms_first": 0.0, "ms_kept": 0.0}
-    assert 2 <= p_on["tried"] <= 6 and 0.0 < p_on["ms_kept"] <= p_on["ms_first"]
+    assert 2 <= p_on["tried"] <= 10 and 0.0 < p_on["ms_kept"] <= p_on["ms_first"]
     # the candidates that were not kept are freed: both engines hold the same amount of device memory (2 MB allocation granules)
     assert abs((free0 - free_off) - (free_off - free_on)) < (64 << 20), (free0, free_off, free_on)
     assert off.info()["device_bytes"] == on.info()["device_bytes"]

@@ -203,7 +203,7 @@ def launch_ranks(args, argv, script=None):
 # "split" (two GPUs only): no spatial decomposition at all -- rank 0 the real-space half of the step (near field + Lanczos), rank 1 the
 # wave-space half (spread, FFTs, gather), each on ALL particles, one all-reduce of the two velocity halves per step: at G = 2 the slab
 # all-to-alls of the owned-particle step move 107 MB over the ONE link between the two GPUs twice per step.
-SEGMENTS = ("single", "one_stream", "lanes", "split")
+SEGMENTS = ("single", "one_stream", "lanes", "split", "host_fallback")   # (host_fallback: only when no RCCL mode ended with a verified trajectory)
 
 
 class Coordinator:
@@ -237,6 +237,19 @@ class Coordinator:
             return False
         try:
             return bool(self.store.check([f"pse_bench/failed/{k}"]))
+        except Exception:   # noqa: BLE001
+            return False
+
+    def decision(self, key, value=None):
+        """Rank 0 decides (value given), everyone learns: True / False.  Without a store between supervisors the answer is `value` for the
+        one that decides and False for the others (a step only some ranks take would hang)."""
+        if self.store is None:
+            return bool(value)
+        try:
+            if value is not None:
+                self.store.set(f"pse_bench/decision/{key}", "1" if value else "0")
+                return bool(value)
+            return self.store.get(f"pse_bench/decision/{key}").decode() == "1"
         except Exception:   # noqa: BLE001
             return False
 
@@ -277,12 +290,34 @@ def supervise_segments(args, argv, script=None):
             continue
         if seg == "split" and (world != 2 or args.modes not in ("both", "split")) or seg in ("one_stream", "lanes") and args.modes == "split":
             continue
+        extra = []
+        if seg == "host_fallback":
+            # No RCCL mode ended with a verified trajectory (a team over RCCL has never run before the first multi-GPU node): the same
+            # step once more with every exchange staged through host memory, so that the line still says whether the decomposition
+            # itself is right on these GPUs -- a measurement of the fallback transport, labelled as such, never of the RCCL path.
+            if args.transport == "host" or args.modes == "split":
+                continue
+            want = None
+            if rank == 0:
+                want = not any("error" not in r and (r.get("verify") or {}).get("ok", args.no_verify)
+                               for m, r in results.items() if m in ("one_stream", "lanes", "split"))
+                if want and os.environ.get("PSE_BENCH_FALLBACK_ANYWAY", "") != "1":
+                    # ranks that would SHARE a GPU measure nothing about a multi-GPU node: no fallback there (the run ends with the
+                    # refusal of the RCCL segments, exit code 3); the variable is for the test of this path on a one-GPU box
+                    try:
+                        import torch    # (device_count does not initialise the GPU; this process never does)
+                        want = torch.cuda.device_count() >= world
+                    except Exception:   # noqa: BLE001
+                        want = False
+            if not co.decision("host_fallback", want):
+                continue
+            extra = ["--transport", "host"]
         n_ranks = 1 if seg == "single" else world
         ranks = list(range(n_ranks)) if not under_launcher else [rank]
         env = dict(base_env, WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks), MASTER_PORT=str(co.ports[k]))
-        if seg in ("one_stream", "lanes"):
+        if seg in ("one_stream", "lanes", "host_fallback"):
             env["PSE_TEAM_LANES"] = "1" if seg == "lanes" else "0"
-        cmd = [sys.executable, me, "--segment", seg] + rest
+        cmd = [sys.executable, me, "--segment", "one_stream" if seg == "host_fallback" else seg] + rest + extra
         t0 = time.time()
         rc, line = run_children([(cmd, dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in ranks], deadline,
                                 json_of=0 if rank == 0 else -1, abort=(lambda k=k: co.failed(k)) if under_launcher and seg != "single" else None)
@@ -296,13 +331,13 @@ def supervise_segments(args, argv, script=None):
             except Exception:   # noqa: BLE001
                 results[seg] = {"error": "unreadable result line"}
     if rank != 0:
-        return 0 if any(codes.get(sg, 1) == 0 for sg in ("one_stream", "lanes", "split")) else next((c for c in codes.values() if c), 1)
+        return 0 if any(codes.get(sg, 1) == 0 for sg in ("one_stream", "lanes", "split", "host_fallback")) else next((c for c in codes.values() if c), 1)
     return merge_segments(args, results)
 
 
 def merge_segments(args, results):
     """ONE line from the segments' lines: `value` is the faster mode whose trajectory check against the single GPU passed."""
-    modes = {m: results[m] for m in ("one_stream", "lanes", "split") if m in results}
+    modes = {m: results[m] for m in ("one_stream", "lanes", "split", "host_fallback") if m in results}
     good = {m: r for m, r in modes.items() if "error" not in r and (r.get("verify") or {}).get("ok", args.no_verify)}
     single = results.get("single")
     if not good:
@@ -313,6 +348,9 @@ def merge_segments(args, results):
     out = dict(good[best])
     out.pop("segment", None)
     out["mode"] = best
+    if best == "host_fallback":
+        out["mode_note"] = ("NO RCCL mode ended with a verified trajectory (modes.*.error / verify): this is the one-stream step with every exchange "
+                            "staged through host memory -- the fallback transport, not the product's multi-GPU path")
     keep = ("ms_per_step", "value", "steps_per_s", "mf_evals_per_s", "lanczos_m", "lanczos_status", "lanczos_exchanges", "lanczos_extras_off", "verify",
             "exchanges_per_step", "exchange_us", "exchange_host_us", "exchange_bytes", "lanes_ms", "critical_path_ms", "device_flags", "particles_owned_sum",
             "config4", "error", "seconds")

@@ -30,7 +30,8 @@ def test_dry_run_prints_the_launch_command():
     assert cmd[1] == BENCH
     assert cmd[2:] == ["--gpus", "2", "--steps", "3", "--warmup", "1", "--n", "1000"]   # the ranks get the same arguments, minus --dry-run
     # the owned-particle run is a sequence of segments, each a fresh set of rank processes with a rendezvous port of its own
-    assert d["segments"] == ["single", "one_stream", "lanes", "split"]        # (split: the two-rank functional split, --gpus 2 only)
+    # (split: the two-rank functional split, --gpus 2 only; host_fallback: only when no RCCL mode ended with a verified trajectory)
+    assert d["segments"] == ["single", "one_stream", "lanes", "split", "host_fallback"]
     assert d["env"]["MASTER_ADDR"] == "127.0.0.1" and d["env"]["WORLD_SIZE"] == "2"
     r = _run(["--gpus", "2", "--replicated", "--dry-run"])           # one set of ranks: the launch line with its port
     d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -110,6 +111,9 @@ if seg == 'split':
     sys.exit(0)
 lanes = os.environ['PSE_TEAM_LANES']
 assert lanes == ('1' if seg == 'lanes' else '0')
+host = '--transport' in sys.argv and sys.argv[len(sys.argv) - 1 - sys.argv[::-1].index('--transport') + 1] == 'host'
+if fake == 'rccl_down' and not host:
+    sys.exit(5)                # (no communicator could be made)
 if fake == 'lanes_hang' and seg == 'lanes':
     if rank == 1:
         sys.exit(7)
@@ -134,7 +138,7 @@ def _supervise(tmp_path, capfd, monkeypatch, fake, gpus=3, extra=()):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("FAKE", fake)
     monkeypatch.setenv("TORCHELASTIC_USE_AGENT_STORE", "True")           # must not reach the ranks of a segment
-    ap = argparse.Namespace(gpus=gpus, dry_run=False, no_single=False, modes="both", no_verify=False)
+    ap = argparse.Namespace(gpus=gpus, dry_run=False, no_single=False, modes="both", no_verify=False, transport="rccl")
     for k in extra:
         setattr(ap, k, True)
     rc = bench.supervise_segments(ap, ["--gpus", str(gpus)], script=str(script))
@@ -169,6 +173,26 @@ def test_a_hang_in_the_second_mode_still_prints_the_first(tmp_path, capfd, monke
     assert d["mode"] == "one_stream" and d["ms_per_step"] == 2.5 and "error" in d["modes"]["lanes"] and "7" in d["modes"]["lanes"]["error"]
 
 
+def test_no_rccl_mode_at_all_falls_back_to_the_host_transport_and_says_so(tmp_path, capfd, monkeypatch):
+    """A team over RCCL has never run before the first multi-GPU node.  If neither lane mode ends with a verified trajectory the
+    supervisor runs the one-stream step once more over the host transport: the line then still says whether the decomposition is
+    right on these GPUs, labelled as the fallback it is; when an RCCL mode works the fallback is not run at all."""
+    # (ranks that would share a GPU measure nothing about a multi-GPU node: with fewer GPUs than ranks -- none here -- there is no
+    # fallback and the run ends with exit code 3 and no line; the variable is how this path is tested where GPUs are missing)
+    monkeypatch.delenv("PSE_BENCH_FALLBACK_ANYWAY", raising=False)
+    rc, out, err = _supervise(tmp_path, capfd, monkeypatch, "rccl_down")
+    assert rc == 3 and out.strip() == "" and "no mode of the team finished" in err
+    monkeypatch.setenv("PSE_BENCH_FALLBACK_ANYWAY", "1")
+    rc, out, err = _supervise(tmp_path, capfd, monkeypatch, "rccl_down")
+    assert rc == 0, err
+    d = json.loads(out.strip().splitlines()[-1])
+    assert d["mode"] == "host_fallback" and "fallback transport" in d["mode_note"] and d["ms_per_step"] == 2.5
+    assert "error" in d["modes"]["one_stream"] and "error" in d["modes"]["lanes"] and d["modes"]["host_fallback"]["verify"]["ok"]
+    rc, out, err = _supervise(tmp_path, capfd, monkeypatch, "")
+    d = json.loads(out.strip().splitlines()[-1])
+    assert rc == 0 and "host_fallback" not in d["modes"] and "mode_note" not in d
+
+
 def test_an_unverified_mode_is_never_the_value(tmp_path, capfd, monkeypatch):
     rc, out, err = _supervise(tmp_path, capfd, monkeypatch, "lanes_unverified")
     assert rc == 0, err
@@ -186,7 +210,7 @@ def test_segments_under_torch_distributed_run(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["PSE_BENCH_RANK_SCRIPT"] = str(script)
-    for fake, mode in (("", "lanes"), ("lanes_hang", "one_stream")):
+    for fake, mode in (("", "lanes"), ("lanes_hang", "one_stream"), ("rccl_down", "host_fallback")):
         env["FAKE"] = fake
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                             "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"],
@@ -195,7 +219,32 @@ def test_segments_under_torch_distributed_run(tmp_path):
         lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
         assert len(lines) == 1, r.stdout
         d = json.loads(lines[0])
-        assert d["mode"] == mode and set(d["modes"]) == {"one_stream", "lanes", "split"} and d["single_gpu"]["ms_per_step"] == 8.0
+        assert d["single_gpu"]["ms_per_step"] == 8.0
+        if fake == "rccl_down":    # (the split of the stand-in does not depend on RCCL: it is a verified mode, so no fallback is run)
+            assert d["mode"] == "split" and set(d["modes"]) == {"one_stream", "lanes", "split"}
+            continue
+        assert d["mode"] == mode and set(d["modes"]) == {"one_stream", "lanes", "split"}
         assert d["modes"]["split"]["ms_per_step"] == 3.0           # (two ranks: the functional split is timed too)
         if fake:
             assert "error" in d["modes"]["lanes"]
+
+
+def test_fallback_decision_reaches_every_supervisor_under_torch_distributed_run(tmp_path):
+    """Three ranks (no functional split), no RCCL mode works: rank 0's supervisor decides on the host-transport fallback and the other
+    supervisors learn it through the launcher's store -- all three start their rank of the fallback segment."""
+    import socket
+    script = tmp_path / "seg.py"
+    script.write_text(SEGMENT_STAND_IN)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PSE_BENCH_RANK_SCRIPT"] = str(script)
+    env["FAKE"] = "rccl_down"
+    env["PSE_BENCH_FALLBACK_ANYWAY"] = "1"      # (no GPUs here: see test_no_rccl_mode_at_all_...)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "3", "--steps", "2", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["mode"] == "host_fallback" and d["n_gpus"] == 3 and "error" in d["modes"]["lanes"] and "error" in d["modes"]["one_stream"]

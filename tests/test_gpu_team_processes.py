@@ -212,6 +212,39 @@ def test_bench_launches_its_own_ranks():
     assert v["particles_that_changed_rank"] > 0, v
 
 
+def _bench_rccl_refused():
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PSE_TEAM_LANES")}
+    env["PSE_BENCH_FALLBACK_ANYWAY"] = "1"      # (ranks sharing the one GPU of the box: never done outside this test)
+    env["PSE_BENCH_SEGMENT_TIMEOUT"] = "300"
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu", "--n", "100000",
+                           "--grid", "128", "--no-cfg4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=1200)
+
+
+_job("bench_rccl_refused", _bench_rccl_refused)
+
+
+def test_bench_without_a_working_rccl_mode_reports_the_host_transport_and_says_so():
+    """`bench.py --gpus 2` with the default transport on a box with ONE GPU: every RCCL segment is refused by its ranks (a communicator needs
+    a GPU per rank) -- what a broken RCCL set-up on a real node looks like to the supervisor.  The line is then the one-stream step over the
+    host transport, verified against the single GPU, and says that it is the fallback; without the test's variable a box with fewer GPUs than
+    ranks gets no line at all (exit code 3)."""
+    import json
+    import subprocess
+    r = _outcome("bench_rccl_refused")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["mode"] == "host_fallback" and "fallback transport" in d["mode_note"] and d["verify"]["ok"] and d["value"] > 0
+    assert all("error" in d["modes"][m] for m in ("one_stream", "lanes", "split")) and d["modes"]["host_fallback"]["verify"]["ok"]
+    assert "needs one GPU per rank" in r.stderr
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PSE_TEAM_LANES", "PSE_BENCH_FALLBACK_ANYWAY")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu", "--n", "100000", "--grid", "128",
+                        "--no-cfg4", "--no-single"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert r.returncode == 3 and not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+
+
 def _bench_under_launcher():
     import subprocess
     port = _free_port()

@@ -29,7 +29,7 @@ def stats(src, dst, cmd):
         med = {k: statistics.median(v) for k, v in d.items()}
     with open(dst, "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats -- {cmd}\n")
-        f.write("# MedianNs: from the kernel trace of the same run (the averages of k_xfft_scale_cols, k_yfft_regs<..true..> and k_zfft_rows<..true..> include the 24 launches of the create-time placement probe)\n")
+        f.write("# MedianNs: from the kernel trace of the same run (the averages of k_xfft_scale_cols, k_yfft_regs<..true..> and k_zfft_rows<..true..> include the launches of the create-time placement probe (four per candidate pair))\n")
         f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MedianNs\n")
         for r in rows[:32]:
             m = med.get(r["Name"])

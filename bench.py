@@ -840,6 +840,26 @@ def main():
         for k, v in sim.phase_times().items():
             phase_sum[k] = phase_sum.get(k, 0.0) + v
     sim.set_timing(False)
+    # What an event pair costs by itself: the `matvec` of phases_ms_per_step is ONE pair of HIP events around one launch of the pair-list
+    # mat-vec per step, and two event markers in a row are 4.5 us apart with nothing between them -- latency the profiler's per-kernel
+    # duration does not contain (in-step pair 132.2 us, empty pair 4.5 us, rocprofv3 127.8 us in one run).  Measured here, on the same
+    # stream, and taken off the dominant kernel's launch time below.  (Twenty launches back to back, pse_debug_matvec_ms, are reported
+    # too -- with the list and the vector warm in the Infinity Cache from the launch before they are 10 % FASTER than a launch inside an
+    # iteration: not what the roofline is computed from.)
+    pair_ms, mv_warm_ms = 0.0, None
+    if world == 1:
+        lat = []
+        for _ in range(40):
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record(); eb.record()
+            eb.synchronize()
+            lat.append(ea.elapsed_time(eb))
+        pair_ms = float(np.median(lat))
+        if args.kT > 0 and hasattr(getattr(sim, "engine", None), "matvec_ms"):
+            try:
+                mv_warm_ms = sim.engine.matvec_ms(20)
+            except Exception as e:   # noqa: BLE001  (no pair list, e.g. PSE_SKIN experiments)
+                print(f"bench.py: pse_debug_matvec_ms: {e}", file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed, t_mf], dtype=torch.float64, device="cpu" if host_transport else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -861,6 +881,9 @@ def main():
         "t_gather": 24 * ngloc + 64 * nloc, "t_real": 96 * nloc, "t_matvec": 96 * nloc,
     }
     per_launch_ms = {k: phases.get(k, 0.0) for k in alg}
+    mv_in_step_ms = per_launch_ms["t_matvec"]
+    if mv_in_step_ms > 2.0 * pair_ms:
+        per_launch_ms["t_matvec"] = mv_in_step_ms - pair_ms      # (the one phase that is a single kernel: see pair_ms above)
     # share of the step: the pair-list mat-vec runs once per Lanczos iteration except the first, whose M.psi is delivered by
     # the near-field pass that builds the list
     weight = dict(per_launch_ms)
@@ -942,6 +965,10 @@ def main():
         "roofline": {"bound": "hbm", "limiter": limiters.get(dom), "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg[dom], "ms_per_launch": per_launch_ms[dom],
+                     "ms_per_launch_how": "HIP event pair around one launch per step on the stream it is launched on, minus what an empty event pair "
+                                          "measures on that stream in this run (event_pair_latency_ms)",
+                     "ms_per_launch_event_pair": mv_in_step_ms if dom == "t_matvec" else None, "event_pair_latency_ms": pair_ms,
+                     "ms_per_launch_back_to_back_warm": mv_warm_ms if dom == "t_matvec" else None,
                      # what the kernel really moves, as a rate: how close it runs to the memory system on its own traffic
                      "traffic_rate": (traffic / (per_launch_ms[dom] * 1e-3) / 1e9) if traffic and per_launch_ms[dom] > 0 else None,
                      "traffic_rate_frac_of_peak": (traffic / (per_launch_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and per_launch_ms[dom] > 0 else None},

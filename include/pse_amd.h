@@ -220,6 +220,12 @@ int pse_debug_grid_placement(pse_handle *h, int *tried, float *ms_first, float *
  * and 24 bytes of doubles are two of them per pair.  PSE_VQ=0 reads doubles (A/B).  No reference counterpart (the reference's
  * mat-vec recomputes every pair from single-precision positions, PSEv1/Mobility.cu:495-600). */
 int pse_debug_vq_roundtrip(int n, const double *rows_host, double *out_host);
+/* the dominant kernel of a Brownian step by itself: `reps` launches of the pair-list mat-vec of a Lanczos iteration (k_mreal_list; the
+ * list, the vectors and the mirror of the Brownian call that has just ended; results go to scratch) back to back on the engine's
+ * stream between ONE pair of events -> milliseconds per launch.  What bench.py's `roofline` divides by: an event pair around a single
+ * launch inside a step carries 5 - 8 us of marker latency, this one a fraction of a microsecond.  Single-GPU engines, right after
+ * pse_step / pse_brownian_velocity with kT > 0 (PSE_ERR_INVALID otherwise). */
+int pse_debug_matvec_ms(pse_handle *h, int reps, float *ms_per_launch);
 
 /* -- multi-GPU: slab-decomposed far field + row-sharded near field (new design; the reference is single-GPU,
  *    PSEv1/Stokes.cc:104) ---------------------------------------------------------------------------------------

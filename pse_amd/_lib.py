@@ -126,6 +126,7 @@ SYMBOLS = {
     "pse_debug_kvector": (_i, [_vp, _i, _ip, _dp]),
     "pse_debug_grid_placement": (_i, [_vp, _ip, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
     "pse_debug_vq_roundtrip": (_i, [_i, _dp, _dp]),
+    "pse_debug_matvec_ms": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_float)]),
     "pse_team_unique_id": (_i, [_vp]),
     "pse_team_create": (_i, [ctypes.POINTER(_vp), _i, _vp, ctypes.POINTER(_vp)]),
     "pse_team_create_transport": (_i, [_vp, ctypes.POINTER(pse_transport), ctypes.POINTER(_vp)]),

@@ -2554,6 +2554,35 @@ extern "C" int pse_eval_realspace(pse_handle *h, const double *r_host, int n, do
     return 0;
 }
 
+extern "C" int pse_debug_matvec_ms(pse_handle *h, int reps, float *ms_per_launch) {
+    if (!h || !ms_per_launch || reps < 1) return fail(PSE_ERR_INVALID, "pse_debug_matvec_ms: bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->n_slabs != 1 || !h->nb_valid || h->nb.cap <= 0 || h->sorted_N <= 0)
+        return fail(PSE_ERR_INVALID, "pse_debug_matvec_ms: needs the pair list of a Brownian call on a single-GPU engine (call it right after one)");
+    const size_t stride = h->n_pad;
+    const int N = h->sorted_N;
+    RowMap rm{};
+    rm.n = 1; rm.lo[0] = 0; rm.hi[0] = N;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    auto run = [&](int n) {   // the launch of a Lanczos iteration j >= 1 (vector V[1], its mirror, the sums against V[0] = psi), the kernel alone
+        for (int r = 0; r < n; ++r)
+            launch_mreal_lanczos(h->pos_s, h->V + stride, h->w_s, rm, h->cell_off, h->dbox, h->nc, h->d.rcut, h->d.self, h->coef, h->nb,
+                                 LzFuse{h->psi_s, h->partials, h->npart_cap, nullptr, nullptr, nullptr}, h->scal, nullptr, nullptr, h->stream,
+                                 VerletList{}, 1, nullptr, DevRowArgs{}, h->vq, true);
+    };
+    run(2);
+    HIPCHK(hipEventRecord(e0, h->stream));
+    run(reps);
+    HIPCHK(hipEventRecord(e1, h->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIPCHK(hipGetLastError());
+    *ms_per_launch = ms / (float)reps;
+    return 0;
+}
 extern "C" int pse_debug_vq_roundtrip(int n, const double *rows_host, double *out_host) {
     if (n < 0 || (n > 0 && (!rows_host || !out_host))) return fail(PSE_ERR_INVALID, "pse_debug_vq_roundtrip: null argument");
     if (n == 0) return 0;

@@ -182,7 +182,8 @@ void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w
                           int sums = 1,                   // 0 none, 1 one-step Lanczos sums, 2 Gram sums of a two-step block, 3 single step of that driver
                           const int *stop = nullptr,      // nullable: leave at once if *stop != 0 (the device-side Lanczos decision)
                           DevRowArgs dr = DevRowArgs{},   // owned-particle ranks: rows from device memory
-                          const void *vec_q = nullptr);   // (sums == 1) the 16-byte mirror of vec_s (launch_lz_update's xq): the neighbours' rows in ONE gather per pair
+                          const void *vec_q = nullptr,    // (sums == 1) the 16-byte mirror of vec_s (launch_lz_update's xq): the neighbours' rows in ONE gather per pair
+                          bool no_reduce = false);        // the mat-vec kernel only: no reduction of its partial sums behind it
 int mreal_partials_needed(int rows);
 void launch_lz_reduce3(const double *partials, int npart, int cap, double *scal, hipStream_t s);
 

@@ -912,7 +912,7 @@ void launch_lz_reduce3(const double *partials, int npart, int cap, double *scal,
 void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w, RowMap rm, const int *cell_off,
                           DBox box, DCells nc, double rcut, double self, const double *coef, NbList nb, LzFuse lz,
                           double *scal, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t s, VerletList vl,
-                          int sums, const int *stop, DevRowArgs dr, const void *vec_q) {
+                          int sums, const int *stop, DevRowArgs dr, const void *vec_q, bool no_reduce) {
     const int rows = std::max(dr.rm ? dr.rows_cap : rm.list_rows(), 1);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     // Four waves per block of 64 rows, each taking every fourth group of slots: 0.166 ms against 0.191 with four blocks of rows
@@ -925,6 +925,7 @@ void launch_mreal_lanczos(const double4 *pos_s, const double4 *vec_s, double4 *w
     else if (sums == 0) PSE_LIST(0); else if (sums == 1) PSE_LIST(1); else if (sums == 2) PSE_LIST(2); else PSE_LIST(3);
 #undef PSE_LIST
     if (ev_end) (void)hipEventRecord(ev_end, s);
+    if (no_reduce) return;   // (pse_debug_matvec_ms: the mat-vec kernel alone, back to back)
     if (sums == 1) hipLaunchKernelGGL(k_lz_reduce, dim3(3), dim3(1024), 0, s, lz.partials, nb64, lz.npart_cap, 3, scal, stop);
     else if (sums >= 2) hipLaunchKernelGGL(k_lz_reduce, dim3(LZ_NGRAM), dim3(1024), 0, s, lz.partials, nb64, lz.npart_cap, LZ_NGRAM, scal, stop);
 }

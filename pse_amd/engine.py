@@ -239,6 +239,13 @@ class Engine:
                                                out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
         return out
 
+    def matvec_ms(self, reps=20):
+        """Milliseconds per launch of the pair-list mat-vec of a Lanczos iteration, `reps` launches back to back between one pair of
+        events (pse_debug_matvec_ms): right after a Brownian call of a single-GPU engine."""
+        ms = ctypes.c_float(0)
+        _lib.check(self._lib.pse_debug_matvec_ms(self._h, int(reps), ctypes.byref(ms)))
+        return ms.value
+
     def grid_placement(self):
         """What pse_create's grid-placement planner did: {"tried": pairs timed (0: off or not applicable), "ms_first", "ms_kept": the
         x pass + inverse y + z passes on the first pair allocated and on the one kept}."""

@@ -111,3 +111,26 @@ def test_packed_vector_rows_are_the_stated_format_to_the_bit():
     dp = ctypes.POINTER(ctypes.c_double)
     assert lib.pse_debug_vq_roundtrip(len(rows), rows.ctypes.data_as(dp), out.ctypes.data_as(dp)) == 0
     assert np.array_equal(out, _vq_model(rows))
+
+
+def test_the_mat_vec_alone_can_be_timed_after_a_brownian_call_only():
+    """pse_debug_matvec_ms (what bench.py's roofline divides by): the pair-list mat-vec back to back between one pair of events; it needs
+    the pair list of a Brownian call and leaves the engine usable (the next call's results are what they were)."""
+    import torch
+    from conftest import make_suspension, to4
+    import pse_amd
+    n = 40_000
+    pos, force, box = make_suspension(n, phi=0.1)
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3, seed=9)
+    dpos, dF = to4(pos, 1.0), to4(force)
+    with pytest.raises(RuntimeError, match="pair list"):
+        eng.matvec_ms(3)                                             # nothing has run yet
+    v0, m0 = eng.brownian_velocity(dpos, dF, 1.0, 1e-3, 5)
+    v0 = v0.clone()
+    ms = eng.matvec_ms(10)
+    assert 0.0 < ms < 5.0
+    v1, m1 = eng.brownian_velocity(dpos, dF, 1.0, 1e-3, 5)
+    assert m1 == m0 and (v1 - v0).abs().max().item() < 1e-11 * v0.abs().max().item()
+    eng.mobility(dpos, dF)                                           # a deterministic call: no pair list afterwards
+    with pytest.raises(RuntimeError, match="pair list"):
+        eng.matvec_ms(3)

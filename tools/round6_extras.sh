@@ -10,7 +10,7 @@ ONLY=${2:-all}     # "team": the team measurements only (the configurations take
 O=gpurun_out/$T; mkdir -p $O
 if [ "$ONLY" = all ]; then
 {
-for a in "--n 1000 --phi 0.05 --grid 64 --only-mf --steps 200" "--n 65536 --grid 64 --only-mf --steps 200" "--n 1048576 --phi 0.2 --grid 256 --steps 10" "--n 1048576 --phi 0.1 --grid 256 --xy 0.3 --steps 10" "--n 4194304 --phi 0.3 --grid 512 --steps 5" "--grid 0 --xi 0.5 --steps 5"; do
+for a in "--n 1000 --phi 0.05 --grid 64 --only-mf --steps 200" "--n 65536 --grid 64 --only-mf --steps 200" "--n 1048576 --phi 0.2 --grid 256 --steps 10" "--n 1048576 --phi 0.1 --grid 256 --xy 0.3 --steps 10" "--n 4194304 --phi 0.3 --grid 512 --steps 5" "--grid 0 --xi 0.5 --steps 40"; do
   echo "== tools/perf.py $a"; timeout 600 python3 tools/perf.py $a 2>&1 | grep -E "create|phases|M.F |^step|queue-only"
 done
 } > $O/configs.txt

@@ -495,7 +495,7 @@ def run_owned_particle_team(args, world, rank, host_transport, dist, torch, segm
         "segment": segment,
         "metric": "BD particle-steps/s (full PSE Brownian step: M.F + k-space noise + Lanczos M^1/2.psi + Euler), N=1e6, phi=0.1",
         "value": w["value"], "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": w["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64, Lanczos pair coefficients f32",
+        "ms_per_step": w["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "dtype_note": "all arithmetic fp64; inside the Lanczos mat-vec the pair coefficients are read from 16-byte records (26-bit fixed / 22-bit block-floating point: single-precision accuracy) and, on one GPU, the neighbours' vector rows from 40-bit mantissas",
         "data": "synthetic",
         "config": {"workload": w["workload"],
                    "parallelism": f"{world} ranks, {transport}; owned-particle decomposition (pse_team_step_local): {w['layout']}, far-field grid in "
@@ -582,7 +582,7 @@ def run_functional_split(args, rank, host_transport, dist, torch):
     out = {"segment": "split",
            "metric": "BD particle-steps/s (full PSE Brownian step: M.F + k-space noise + Lanczos M^1/2.psi + Euler), N=1e6, phi=0.1",
            "value": w["value"], "unit": "particle-steps/s", "n_gpus": 2, "steps": args.steps, "warmup": args.warmup, "ms_per_step": w["ms_per_step"],
-           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64, Lanczos pair coefficients f32", "data": "synthetic",
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "dtype_note": "all arithmetic fp64; inside the Lanczos mat-vec the pair coefficients are read from 16-byte records (26-bit fixed / 22-bit block-floating point: single-precision accuracy) and, on one GPU, the neighbours' vector rows from 40-bit mantissas", "data": "synthetic",
            "config": {"workload": w["workload"],
                       "parallelism": f"2 ranks, {transport}; FUNCTIONAL split (pse_brownian_velocity_part): rank 0 the real-space half of every step (near field + "
                                      f"Lanczos), rank 1 the wave-space half (spread, transforms, k-space scaling and noise, gather), both on all N particles, ONE "
@@ -949,7 +949,7 @@ def main():
         "value": n / t_step, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": t_step * 1e3, "ms_per_step_percentiles": pct, "step_modes": modes, "step_mode": mode,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64, Lanczos pair coefficients f32", "data": "synthetic",
+        "dtype": "f64", "dtype_note": "all arithmetic fp64; inside the Lanczos mat-vec the pair coefficients are read from 16-byte records (26-bit fixed / 22-bit block-floating point: single-precision accuracy) and, on one GPU, the neighbours' vector rows from 40-bit mantissas", "data": "synthetic",
         "config": {"workload": f"random-sphere suspension N={n}, phi={args.phi}, cubic L={L:.2f}, grid {grid}^3, "
                                f"xi={xi:.4f}, rcut={info['rcut']:.3f}, P={info['P']}, error={args.error}, kT={args.kT}, "
                                f"dt={args.dt}", "parallelism": sim.describe() + ("; steps through the queue-only form of pse_step (pse_set_async: device-side "

@@ -14,9 +14,11 @@
  * 1/(6 pi eta a) (PSEv1/Stokes.cc:314-319, PSEv1/Helper.cu:326); box centred on the origin with
  * HOOMD's triclinic tilt xy: a1=(Lx,0,0), a2=(xy*Ly,Ly,0), a3=(0,0,Lz) (PSEv1/Mobility.cu:223-230).
  * Arithmetic is fp64 (the reference is effectively fp32), with one stated exception: inside the Lanczos iteration
- * of M_real^{1/2} psi (tolerance `error`) the near-field operator reads its pair coefficients -- f(r) and d sqrt|(g - f) / r^2| -- in
- * single precision from the per-step pair list and accumulates in fp64; the operator stays exactly symmetric, the deterministic
- * U = M.F never sees those numbers (oracle/pse_oracle.c pair_term restates the rounding).
+ * of M_real^{1/2} psi (tolerance `error`) the near-field operator reads its pair coefficients -- f(r) and d sqrt|(g - f) / r^2| -- from
+ * the 16-byte records of the per-step pair list, rounded to single-precision accuracy (f to 2^-25 absolute, the vector to 2^-22 of its
+ * largest component), and (single GPU) its neighbours' vector rows to 2^-39 of their largest component; sums accumulate in fp64, the
+ * operator stays exactly symmetric, the deterministic U = M.F never sees those numbers (oracle/pse_oracle.c pair_term restates the
+ * rounding of the coefficients operation by operation; DESIGN.md sections 2 and 4).
  */
 #ifndef PSE_AMD_H
 #define PSE_AMD_H

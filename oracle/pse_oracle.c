@@ -293,29 +293,46 @@ int pse_oracle_mobility_dense(int N, const double *pos, const double *box, doubl
 /* real-space part truncated at rcut with minimum image only -- exactly the sum the product's
  * near-field kernel performs (PSEv1/Mobility.cu:594-687: pairs with r < rcut, self term), but with
  * the closed-form functions instead of a table. Requires rcut <= half the shortest box width. */
-/* One pair's term of the near-field sum.  f32 == 0: f F + (g - f) (r.F) r / r^2 in double precision.  f32 != 0: the term as the
- * build's Lanczos mat-vecs apply it (pse_amd/csrc/pse_kernels.hip, nb_store: the per-step pair list carries single-precision pair
- * coefficients): fr = (float) f, s = (float)(r sqrt|h|) with h = (g - f) / r^2 and the root taken in single precision, term
- * fr F + sgn(h) (s.F) s accumulated in double precision.  The reference's own pair coefficients are single precision throughout
- * (PSEv1/Mobility.cu:661-677 with Scalar = float); this restates the build's rounding so that M_real^{1/2} psi can be compared
- * at 1e-9 instead of 1e-7. */
-static void pair_term(const double r[3], double r2, double f, double g, const double *F, int f32, double u[3]) {
-    if (!f32) {
+/* One pair's term of the near-field sum.  rounded == 0: f F + (g - f) (r.F) r / r^2 in double precision.  rounded != 0: the term as the
+ * build's Lanczos mat-vecs apply it (pse_amd/csrc/pse_kernels.hip, pair_coef / nb_pack: the 16-byte records of the per-step pair list
+ * carry pair coefficients of single-precision accuracy): fr = f rounded to a multiple of 2^-24, s = r sqrt|h| with h = (g - f) / r^2 (the
+ * root taken in single precision) rounded to 22-bit mantissas under the exponent of its largest component, term fr F + sgn(h) (s.F) s
+ * accumulated in double precision.  The reference's own pair coefficients are single precision throughout (PSEv1/Mobility.cu:661-677
+ * with Scalar = float); this restates the build's rounding operation by operation so that M_real^{1/2} psi can be compared at 1e-9
+ * instead of 1e-7. */
+static void pair_term(const double r[3], double r2, double f, double g, const double *F, int rounded, double u[3]) {
+    if (!rounded) {
         double rdF = (r[0] * F[0] + r[1] * F[1] + r[2] * F[2]) / r2;
         for (int p = 0; p < 3; ++p) u[p] += f * F[p] + (g - f) * rdF * r[p];
         return;
     }
     double h = (g - f) / r2;
     double hs = (double)sqrtf((float)fabs(h));
-    double fr = (double)(float)f, s[3];
-    for (int p = 0; p < 3; ++p) s[p] = (double)(float)(r[p] * hs);
+    /* the 16-byte pair record of the device (pse_kernels.hip pair_coef): fr a signed 26-bit integer in units of 2^-24, s three signed
+     * 22-bit mantissas under the exponent of its largest component */
+    double sv[3] = { r[0] * hs, r[1] * hs, r[2] * hs }, s[3];
+    double m = fmax(fabs(sv[0]), fmax(fabs(sv[1]), fabs(sv[2])));
+    int e = 0;
+    if (m > 0.0) (void)frexp(m, &e);
+    if (e < -100) e = -100;
+    if (e > 100) e = 100;
+    for (int p = 0; p < 3; ++p) {
+        double q = rint(ldexp(sv[p], 21 - e));
+        if (q > 2097151.0) q = 2097151.0;
+        if (q < -2097151.0) q = -2097151.0;
+        s[p] = ldexp(q, e - 21);
+    }
+    double fq = rint(f * 16777216.0);
+    if (fq > 33554431.0) fq = 33554431.0;
+    if (fq < -33554431.0) fq = -33554431.0;
+    double fr = fq * 5.9604644775390625e-08;
     double sd = s[0] * F[0] + s[1] * F[1] + s[2] * F[2];
     if (h < 0.0) sd = -sd;
     for (int p = 0; p < 3; ++p) u[p] += fr * F[p] + sd * s[p];
 }
 
 static int mreal_cutoff(int N, const double *pos, const double *force, const double *box,
-                        double xi, double rcut, double *vel, int nthreads, int f32) {
+                        double xi, double rcut, double *vel, int nthreads, int rounded) {
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
@@ -338,7 +355,7 @@ static int mreal_cutoff(int N, const double *pos, const double *force, const dou
             }
             if (b2 >= rcut * rcut || b2 == 0.0) continue;
             double f, g; pse_oracle_fg_real(sqrt(b2), xi, &f, &g);
-            pair_term(best, b2, f, g, force + 3 * j, f32, u);
+            pair_term(best, b2, f, g, force + 3 * j, rounded, u);
         }
         vel[3 * i] = u[0]; vel[3 * i + 1] = u[1]; vel[3 * i + 2] = u[2];
     }
@@ -349,8 +366,8 @@ int pse_oracle_mreal_cutoff(int N, const double *pos, const double *force, const
                             double xi, double rcut, double *vel, int nthreads) {
     return mreal_cutoff(N, pos, force, box, xi, rcut, vel, nthreads, 0);
 }
-/* the same sum with the single-precision pair coefficients of the build's Lanczos mat-vecs (pair_term) */
-int pse_oracle_mreal_cutoff_f32(int N, const double *pos, const double *force, const double *box,
+/* the same sum with the rounded pair coefficients of the build's Lanczos mat-vecs (pair_term) */
+int pse_oracle_mreal_cutoff_rounded(int N, const double *pos, const double *force, const double *box,
                                 double xi, double rcut, double *vel, int nthreads) {
     return mreal_cutoff(N, pos, force, box, xi, rcut, vel, nthreads, 1);
 }

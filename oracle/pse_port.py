@@ -109,13 +109,13 @@ def mobility_dense(pos, box, xi, tol=1e-14, parts=3, nthreads=0):
     return M
 
 
-def mobility_real(pos, force, box, xi, rcut, nthreads=0, f32=False):
+def mobility_real(pos, force, box, xi, rcut, nthreads=0, rounded=False):
     """Near-field sum as the reference's Mreal kernel does it: minimum image, r < rcut, + self.
-    f32: with the single-precision pair coefficients the build's Lanczos mat-vecs use (oracle/pse_oracle.c pair_term; the
+    rounded: with the pair coefficients as the build's Lanczos mat-vecs read them from their 16-byte records (oracle/pse_oracle.c pair_term; the
     deterministic M.F is always the double-precision sum)."""
     pos = np.ascontiguousarray(pos, float); force = np.ascontiguousarray(force, float)
     box = np.ascontiguousarray(box, float); out = np.zeros_like(pos)
-    fn = lib().pse_oracle_mreal_cutoff_f32 if f32 else lib().pse_oracle_mreal_cutoff
+    fn = lib().pse_oracle_mreal_cutoff_rounded if rounded else lib().pse_oracle_mreal_cutoff
     fn(len(pos), _p(pos), _p(force), _p(box), ctypes.c_double(xi), ctypes.c_double(rcut), _p(out), int(nthreads))
     return out
 
@@ -416,9 +416,9 @@ def lanczos_sqrt(matvec, psi, m_in=2, tol=1e-3, m_max=100):
     return (norm * u).reshape(shape), m
 
 
-def brownian_velocity(pos, force, box, p, kT, dt, seed, timestep, m_in=2, pair_f32=True):
+def brownian_velocity(pos, force, box, p, kT, dt, seed, timestep, m_in=2, pair_rounded=True):
     """Brownian.cu:772-923: u = M.F + sqrt(2kT/dt) M^{1/2} psi, wave noise drawn in k-space.
-    pair_f32: the near-field operator inside the Lanczos iteration with single-precision pair coefficients, as the build applies it
+    pair_rounded: the near-field operator inside the Lanczos iteration with the rounded pair coefficients of the build's pair list
     (False: the all-double algorithm the golden fixture was pinned with; the two differ by ~1e-8 relative)."""
     nk = noise_k(box, p, kT, dt, seed, timestep) if kT > 0 else None
     u = mobility_wave(pos, force, box, p, extra_k=nk) + mobility_real(pos, force, box, p["xi"], p["rcut"])
@@ -426,8 +426,8 @@ def brownian_velocity(pos, force, box, p, kT, dt, seed, timestep, m_in=2, pair_f
     if kT > 0:
         psi = psi_particles(len(pos), seed, timestep)
         zero = np.zeros_like(pos)
-        # the operator of the Lanczos iteration carries single-precision pair coefficients (the build's per-step pair list)
-        mv = lambda v: mobility_real(pos, np.ascontiguousarray(v), box, p["xi"], p["rcut"], f32=pair_f32)
+        # the operator of the Lanczos iteration carries the rounded pair coefficients of the build's per-step pair list
+        mv = lambda v: mobility_real(pos, np.ascontiguousarray(v), box, p["xi"], p["rcut"], rounded=pair_rounded)
         ub, m = lanczos_sqrt(mv, psi, m_in=m_in, tol=p["error"])
         u = u + math.sqrt(2.0 * kT / dt) * ub
     return u, m

@@ -80,7 +80,7 @@ __device__ __forceinline__ int xcd_block(int b, int nb) {
 // path the same 64 cycles whether it fetches 16 or 8 bytes per lane: the 24 bytes of (x, y, z) in doubles are TWO such instructions
 // per pair, and the kernel is bound by them (TA 78 % busy).  One 16-byte word per row holds the three components as signed 40-bit
 // integers scaled by the power of two above the largest of them: absolute error <= 2^-39 of the row's largest component (1.8e-12),
-// four orders below the single-precision pair coefficients the same mat-vec already reads.  w = (x lo, y lo, z lo, x hi | y hi << 8 |
+// four orders below the rounding of the pair coefficients the same mat-vec reads (pse_kernels.hip PairCoef).  w = (x lo, y lo, z lo, x hi | y hi << 8 |
 // z hi << 16 | (e + 128) << 24).  Written by k_lz_update beside the double row it mirrors; the row itself stays the truth (diagonal
 // term, sums, basis combination).
 typedef unsigned vq4 __attribute__((ext_vector_type(4)));

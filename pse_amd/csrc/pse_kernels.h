@@ -126,10 +126,10 @@ void launch_permute(const double4 *pos, const double4 *vec, const unsigned *grou
 void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double4 *vec_s, hipStream_t s);
 
 // ---- near field (K9) -------------------------------------------------------------------------------------
-// Per-step pair list, 20 B per pair, in wave-blocked ELL layout: four slots of the 64 rows a wavefront owns form one
-// contiguous 5120-byte group [64 lanes][4 x u32 (neighbour row | sign of h << 27)][4 slots][64 x (f32 f, f32 s.xyz)] with
-// s = d sqrt|h| (pair term f v + sgn (s.v) s, nb_store in pse_kernels.hip), groups of one wave back to back -- a wave streams one
-// contiguous region with 16-byte loads only.  Read by the Lanczos mat-vecs only.
+// Per-step pair list, 16 B per pair, in wave-blocked ELL layout: four slots of the 64 rows a wavefront owns form one
+// contiguous 4096-byte group [4 slots][64 lanes] of records (neighbour row 27 bits | sign of h | fr 26-bit fixed point | s = d sqrt|h| as
+// three 22-bit mantissas under one exponent: nb_pack in pse_kernels.hip; pair term f v + sgn (s.v) s), groups of one wave back to back
+// -- a wave streams one contiguous region with 16-byte loads only.  Read by the Lanczos mat-vecs only.
 // Row r = i - lo (lo: first row of the rank, fixed within a step); record (r / 64) * cap + slot.
 struct NbList {
     char *data;
@@ -148,7 +148,7 @@ struct VerletList {
 };
 __host__ __device__ inline size_t verlet_list_bytes(size_t rows, int cap) { return ((rows + 63) / 64) * (size_t)(cap / 4) * 1024; }
 enum { VL_NONE = 0, VL_WRITE = 1, VL_USE = 2 };
-constexpr size_t NB_REC = 64 * 20;
+constexpr size_t NB_REC = 64 * 16;   // 64 rows x one 16-byte record
 __host__ __device__ inline size_t nb_list_bytes(size_t rows, int cap) { return ((rows + 63) / 64) * (size_t)cap * NB_REC; }
 enum { MREAL_CELLS = 0, MREAL_BUILD_LIST = 1, MREAL_USE_LIST = 2 };
 // Lanczos sums fused into the pair-list mat-vec (see k_lz_update): with x = vec and y = M x the kernel also leaves the

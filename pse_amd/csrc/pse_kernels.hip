@@ -280,47 +280,76 @@ void launch_permute_vec(const double4 *vec, const unsigned *tag_s, int N, double
 constexpr int QCAP = 44;
 constexpr unsigned JMASK = (1u << 27) - 1;
 
-// Four slots of the 64 rows of a wave form one 5120-byte group: [lane][4] entries, then [slot][lane] 16-byte coefficient records.
-// A mat-vec reads a group with one 16-byte load of the four entries and four 16-byte loads of the coefficients: a coalesced dword
-// or dwordx2 load occupies the texture addresser as long as a dwordx4 load (tools/microbench/stream_widths: 8 / 16 / 16 clk), so
-// the twelve narrow loads of the former (entry | f | h) planes cost twice what these five do.
+// Four slots of the 64 rows of a wave form one 4096-byte group of [slot][lane] 16-byte records: a mat-vec reads a group with four
+// 16-byte loads per lane (a coalesced dword or dwordx2 load occupies the texture addresser as long as a dwordx4 load,
+// tools/microbench/stream_widths: 8 / 16 / 16 clk -- the twelve narrow loads of the round-2 (entry | f | h) planes cost three times that).
 //
-// What a record holds (round 6): the pair's term of the mat-vec, f v + h (d.v) d with d = x_i - x_j (minimum image) and
-// h = (g - f) / r^2, as FOUR SINGLE-PRECISION numbers fr = (float) f and s = (float)(d sqrt|h|), the sign of h in bit 27 of the
-// entry: f v + sgn (s.v) s.  The mat-vecs then gather ONE thing per pair -- the neighbour's vector (24 bytes of its 32-byte row) --
-// instead of the 48-byte (position, vector) record, and neither subtract positions nor look up image shifts; the list is only ever
-// read by the Lanczos iteration of M_real^{1/2} psi (tolerance `error`, 1e-3 by default; the deterministic M.F of the pass that
-// builds the list stays fp64 -- the reference's whole path is fp32).  EVERY application of the operator inside a
-// Lanczos iteration uses these rounded numbers -- the vector that rides along with the build pass, the list mat-vecs, the rows that
-// did not fit the list -- so the iteration sees ONE symmetric matrix: d_ji = -d_ij exactly, so both directions of a pair round alike.
-struct PairCoef { float f, sx, sy, sz; unsigned neg; };
+// What a record holds (round 6): the neighbour's row and the pair's term of the mat-vec, f v + h (d.v) d with d = x_i - x_j (minimum
+// image) and h = (g - f) / r^2, as FOUR ROUNDED NUMBERS: fr = f and s = d sqrt|h| (the sign of h in a bit: f v + sgn (s.v) s) -- fr a
+// signed 26-bit integer in units of 2^-24 (|f| < 2), s three signed 22-bit mantissas under the exponent es of its largest component
+// (value = m 2^(es - 21)): absolute errors <= 3e-8 (fr) and 2^-22 |s|_max, what single precision gives for numbers of order one, in 100
+// bits instead of 128 (rounds 6a: four floats + the entry = 20 bytes per pair; the mat-vec is bound by this stream).  The mat-vecs then
+// gather ONE thing per pair -- the neighbour's vector row -- instead of the 48-byte (position, vector) record, and neither subtract
+// positions nor look up image shifts; the list is only ever read by the Lanczos iteration of M_real^{1/2} psi (tolerance `error`,
+// 1e-3 by default; the deterministic M.F of the pass that builds the list stays fp64 -- the reference's whole path is fp32,
+// SURVEY.md 2.4-1).  EVERY application of the operator inside a Lanczos iteration uses these rounded numbers -- the vector that
+// rides along with the build pass, the list mat-vecs, the rows that did not fit the list -- so the iteration sees ONE symmetric
+// matrix: d_ji = -d_ij exactly and rounding to nearest is odd, so both directions of a pair round alike.  (The tests' CPU restatement
+// of the algorithm repeats this rounding operation by operation: include/pse_amd.h, the precision note.)
+struct PairCoef { int f, mx, my, mz, es; unsigned neg; };
 __device__ __forceinline__ PairCoef pair_coef(double f, double h, double dx, double dy, double dz) {
-    // (single-precision square root, correctly rounded: the four numbers are single precision anyway, and the fp64 root with its
-    // Newton steps cost the build pass the registers of its third workgroup per CU)
     const double hs = (double)sqrtf((float)fabs(h));
+    const double sx = dx * hs, sy = dy * hs, sz = dz * hs;
+    const double m = fmax(fabs(sx), fmax(fabs(sy), fabs(sz)));
+    int e = 0;
+    (void)frexp(m, &e);
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    const double sc = __hiloint2double((21 - e + 1023) << 20, 0);   // 2^(21 - e): |component| sc < 2^21
+    const double lim = 2097151.0;                                   // 2^21 - 1
     PairCoef p;
-    p.f = (float)f; p.sx = (float)(dx * hs); p.sy = (float)(dy * hs); p.sz = (float)(dz * hs); p.neg = h < 0.0 ? 1u : 0u;
+    p.mx = (int)fmax(-lim, fmin(lim, rint(sx * sc))); p.my = (int)fmax(-lim, fmin(lim, rint(sy * sc))); p.mz = (int)fmax(-lim, fmin(lim, rint(sz * sc)));
+    p.es = e;
+    p.f = (int)fmax(-33554431.0, fmin(33554431.0, rint(f * 16777216.0)));
+    p.neg = h < 0.0 ? 1u : 0u;
     return p;
 }
 __device__ __forceinline__ void pair_apply(const PairCoef &p, double vx, double vy, double vz, double &ux, double &uy, double &uz) {
-    const double fr = p.f, sx = p.sx, sy = p.sy, sz = p.sz;
+    const double sc = __hiloint2double((p.es - 21 + 1023) << 20, 0);
+    const double fr = (double)p.f * 5.9604644775390625e-08, sx = (double)p.mx * sc, sy = (double)p.my * sc, sz = (double)p.mz * sc;   // (2^-24)
     double sd = sx * vx + sy * vy + sz * vz;
     if (p.neg) sd = -sd;
     ux += fr * vx + sd * sx; uy += fr * vy + sd * sy; uz += fr * vz + sd * sz;
 }
-constexpr unsigned NB_NEG = 1u << 27;   // entry = neighbour row | NB_NEG if h < 0
+// the 16-byte record: x = row (27) | neg (1) | fr[3:0] (4); y = fr[25:4] (22) | mx[9:0] (10); z = mx[21:10] (12) | my[19:0] (20);
+// w = my[21:20] (2) | mz (22) | es + 128 (8)
+typedef unsigned nb4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ nb4 nb_pack(unsigned j, const PairCoef &p) {
+    const unsigned f = (unsigned)p.f & 0x3FFFFFFu, mx = (unsigned)p.mx & 0x3FFFFFu, my = (unsigned)p.my & 0x3FFFFFu, mz = (unsigned)p.mz & 0x3FFFFFu;
+    nb4 w;
+    w.x = j | (p.neg ? (1u << 27) : 0u) | (f << 28);
+    w.y = (f >> 4) | (mx << 22);
+    w.z = (mx >> 10) | (my << 12);
+    w.w = (my >> 20) | (mz << 2) | ((unsigned)(p.es + 128) << 24);
+    return w;
+}
+__device__ __forceinline__ PairCoef nb_unpack(nb4 w, bool ok) {
+    PairCoef p;
+    p.neg = w.x & (1u << 27);
+    p.f = ok ? (int)((((w.y & 0x3FFFFFu) << 4) | (w.x >> 28)) << 6) >> 6 : 0;
+    p.mx = ok ? (int)((((w.z & 0xFFFu) << 10) | (w.y >> 22)) << 10) >> 10 : 0;
+    p.my = ok ? (int)((((w.w & 0x3u) << 20) | (w.z >> 12)) << 10) >> 10 : 0;
+    p.mz = ok ? (int)(((w.w >> 2) & 0x3FFFFFu) << 10) >> 10 : 0;
+    p.es = ok ? (int)(w.w >> 24) - 128 : 0;
+    return p;
+}
 template <bool STREAM = false>
 __device__ __forceinline__ void nb_store(char *rec, int slot, int lane, unsigned j, const PairCoef &p) {
     char *r = rec + (size_t)(slot >> 2) * (4 * NB_REC);
-    // plain stores: a lane's 4- and 16-byte pieces reach a line at different times and the L2 merges them; as non-temporal stores
-    // every piece went to memory on its own (WRITE_SIZE of the build pass 548 -> 805 MB)
-    ((unsigned *)r)[lane * 4 + (slot & 3)] = j | (p.neg ? NB_NEG : 0u);
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    f4v c; c.x = p.f; c.y = p.sx; c.z = p.sy; c.w = p.sz;
-    if (STREAM)   // the cell pass: most lanes of a wave append in the same drain round, the records of a round are whole lines
-        __builtin_nontemporal_store(c, (f4v *)(r + 1024) + (slot & 3) * 64 + lane);
-    else ((f4v *)(r + 1024))[(slot & 3) * 64 + lane] = c;
+    const nb4 w = nb_pack(j, p);
+    if (STREAM) __builtin_nontemporal_store(w, (nb4 *)r + (slot & 3) * 64 + lane);
+    else ((nb4 *)r)[(slot & 3) * 64 + lane] = w;
 }
+constexpr unsigned NB_NEG = 1u << 27;   // entry = neighbour row | NB_NEG if h < 0
 
 __device__ __forceinline__ void vl_store(char *vrec, int slot, int lane, unsigned j) {
     ((unsigned *)(vrec + (size_t)(slot >> 2) * 1024))[lane * 4 + (slot & 3)] = j;
@@ -428,7 +457,7 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
                 const bool in = live[u] && r2 < rcut2 && r2 > 0.0;   // the fp64 cutoff decides
                 if (!in) { f = 0.0; h = 0.0; }
                 // A pass that writes the pair list serves a Lanczos iteration: the vector of that iteration (vec2 when F rides in
-                // front, else vec itself) sees the single-precision pair coefficients the list carries (nb_store); F never does.
+                // front, else vec itself) sees the rounded pair coefficients the list carries (pair_coef, nb_store); F never does.
                 if (!LIST || TWO) {
                     const double rd = (dx * F[u].x + dy * F[u].y + dz * F[u].z) * h;
                     ux += f * F[u].x + rd * dx; uy += f * F[u].y + rd * dy; uz += f * F[u].z + rd * dz;
@@ -437,7 +466,7 @@ k_mreal_cells(const double4 *__restrict__ pos_s, const float4 *__restrict__ posf
                     const PairCoef pc = pair_coef(f, h, dx, dy, dz);
                     if (TWO) pair_apply(pc, G[u].x, G[u].y, G[u].z, wx, wy, wz);
                     else pair_apply(pc, F[u].x, F[u].y, F[u].z, ux, uy, uz);
-                    if (in) {   // 20 B per pair: (row | sign), (fr, s)
+                    if (in) {   // 16 B per pair: row | sign | fr | s
                         if (total < nb.cap) nb_store<true>(rec, total, lane, (unsigned)j[u], pc);
                         ++total;
                     }
@@ -672,8 +701,8 @@ __device__ __forceinline__ void eval_fg_lean(double r2, const double *__restrict
 }
 
 // mat-vec from the pair list (one thread per particle, ELL layout: slot-major so a wave reads contiguous rows).
-// Per pair 20 B of list from HBM -- (row | sign), (fr, s) in single precision, see nb_store -- plus 24 bytes of the neighbour's
-// vector row gathered through L2: no positions, no image shifts.  FUSE adds the Lanczos epilogue (see LzFuse).
+// Per pair 16 B of list from HBM -- row | sign | fr | s, see nb_pack -- plus the neighbour's vector row gathered through L2 (24 bytes
+// of doubles, or 16 from its mirror: VQ): no positions, no image shifts.  FUSE adds the Lanczos epilogue (see LzFuse).
 // WSP = 4: the four waves of a workgroup share ONE block of 64 rows and take every fourth group of slots each (partial sums
 // through LDS): the waves resident on a CU then gather from a quarter as many neighbourhoods (the kernel is bound by L1 misses).
 // FUSE: 0 none; 1 the three sums of the one-step iteration; 2 the Gram sums of a two-step block (this launch is its SECOND
@@ -719,14 +748,12 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
             for (int s0 = UNROLL * wv; s0 < cnt; s0 += UNROLL * WSP) {
                 const char *grp = rec + (size_t)(s0 >> 2) * (4 * NB_REC);
                 // streamed once: non-temporal, so the list does not evict the neighbour rows the gathers reuse from L1
-                typedef unsigned u4v __attribute__((ext_vector_type(4)));
-                typedef float f4v __attribute__((ext_vector_type(4)));
-                const u4v e4 = __builtin_nontemporal_load((const u4v *)grp + lane);
-                unsigned e[UNROLL] = {e4.x, e4.y, e4.z, e4.w};
-                f4v c[UNROLL];
+                unsigned e[UNROLL];
+                nb4 c[UNROLL];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
-                    c[u] = __builtin_nontemporal_load((const f4v *)(grp + 1024) + u * 64 + lane);
+                    c[u] = __builtin_nontemporal_load((const nb4 *)grp + u * 64 + lane);
+                    e[u] = c[u].x;
                     if (u && s0 + u >= cnt) e[u] = e[0];          // slots past the row's count were never written
                 }
                 double2 vxy[UNROLL];
@@ -741,9 +768,8 @@ k_mreal_list(const double4 *__restrict__ pos_s, const double4 *__restrict__ vec_
                 }
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
-                    PairCoef pc;
                     const bool ok = s0 + u < cnt;
-                    pc.f = ok ? c[u].x : 0.0f; pc.sx = ok ? c[u].y : 0.0f; pc.sy = ok ? c[u].z : 0.0f; pc.sz = ok ? c[u].w : 0.0f; pc.neg = e[u] & NB_NEG;
+                    const PairCoef pc = nb_unpack(c[u], ok);
                     if (VQ) { vq_unpack(vq[u], vxy[u].x, vxy[u].y, vz[u]); }
                     pair_apply(pc, vxy[u].x, vxy[u].y, vz[u], ux, uy, uz);
                 }

@@ -40,7 +40,7 @@ def oracle():
 # double precision end to end: 1e-9.  With kT > 0 the near-field operator inside the Lanczos iteration reads its pair coefficients in
 # SINGLE precision (the per-step pair list, pse_kernels.hip nb_store): rounding is discontinuous, so positions that differ by 1e-16
 # (summation order) now and then round a coefficient the other way, that particle's velocity moves by ~1e-8, its neighbours' pairs
-# follow, and within ~15 steps the two trajectories differ by the noise floor of single-precision coefficients (~1e-7 per step and
+# follow, and within ~15 steps the two trajectories differ by the noise floor of the rounded (single-precision-accurate) coefficients (~1e-7 per step and
 # particle at dt = 0.25) -- a single evaluation from identical positions still agrees to 1e-9 and better (tested next to this).
 # Once positions differ by 1e-8 a second discontinuity takes part: a pair within that distance of rcut is inside the cutoff in one run
 # and outside in the other (N nbar / 2 x 3 delta / rcut pairs per step: ~0.2 % per step at N = 40 000), and its term there is what the

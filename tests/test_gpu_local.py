@@ -263,7 +263,7 @@ def test_local_team_step_captured_into_a_graph(lanes, monkeypatch):
         pc, uc, ic, oc = cap.gather()
         assert [e.info()["lanczos_m"] for e in cap.engines] == [e.info()["lanczos_m"] for e in eager.engines], k
         # (two teams, six Brownian steps: the far-field bins fill in the order their atomics arrive, sums differ by 1e-16, and a
-        # single-precision pair coefficient that rounds the other way moves one particle by ~1e-9 dt: conftest.py TRAJ_TOL_BROWNIAN)
+        # rounded pair coefficient that rounds the other way moves one particle by ~1e-9 dt: conftest.py TRAJ_TOL_BROWNIAN)
         assert np.abs(pc - pe).max() < TRAJ_TOL_BROWNIAN * dt / 0.25 and np.array_equal(ic, ie) and np.array_equal(oc, oe), (k, np.abs(pc - pe).max())
 
 

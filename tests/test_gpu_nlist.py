@@ -147,7 +147,7 @@ def test_overflow_rows_on_the_kept_list(torch_cuda, oracle):
     moved = oracle.wrap(pos + 0.05 * rng.normal(size=(n, 3)).clip(-2, 2), np.zeros((n, 3), dtype=np.int64), box)[0]
     out, m = eng.sqrt_mreal(to4(moved), to4(psi), tol=1e-3)
     st = eng.neighbor_stats()
-    matvec = lambda v: oracle.mobility_real(moved, np.ascontiguousarray(v), box, 0.5, rcut, f32=True)
+    matvec = lambda v: oracle.mobility_real(moved, np.ascontiguousarray(v), box, 0.5, rcut, rounded=True)
     up, mp = oracle.lanczos_sqrt(matvec, psi, 2, 1e-3)
     assert m == mp, (m, mp)
     assert rel(out.cpu().numpy()[:, :3], up) < 1e-9
@@ -162,7 +162,7 @@ def test_overflow_rows_on_the_kept_list(torch_cuda, oracle):
     eng.sqrt_mreal(to4(pos2), to4(psi), tol=1e-3)
     out2, m2 = eng.sqrt_mreal(to4(pos2), to4(psi), tol=1e-3)
     assert eng.neighbor_stats()[1:] == (3, 1)
-    mv2 = lambda v: oracle.mobility_real(pos2, np.ascontiguousarray(v), box, 0.5, rcut, f32=True)
+    mv2 = lambda v: oracle.mobility_real(pos2, np.ascontiguousarray(v), box, 0.5, rcut, rounded=True)
     up2, mp2 = oracle.lanczos_sqrt(mv2, psi, 2, 1e-3)
     assert m2 == mp2 and rel(out2.cpu().numpy()[:, :3], up2) < 1e-9
 

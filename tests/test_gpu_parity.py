@@ -145,15 +145,15 @@ def test_lanczos_sqrt_matches_dense(torch_cuda, oracle):
     eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3)
     rcut = eng.info()["rcut"]
     eye = np.eye(3 * n)
-    # (f32=True: the operator of the Lanczos iteration carries the single-precision pair coefficients of the per-step pair list)
-    M = np.stack([oracle.mobility_real(pos, eye[c].reshape(n, 3), box, 0.5, rcut, f32=True).ravel() for c in range(3 * n)], 1)
+    # (rounded=True: the operator of the Lanczos iteration carries the rounded pair coefficients of the per-step pair list)
+    M = np.stack([oracle.mobility_real(pos, eye[c].reshape(n, 3), box, 0.5, rcut, rounded=True).ravel() for c in range(3 * n)], 1)
     psi = np.random.default_rng(5).normal(size=(n, 3))
     ref = (sl.sqrtm(M).real @ psi.ravel()).reshape(n, 3)
     for tol, bound in ((1e-3, 5e-3), (1e-8, 1e-7)):
         out, m = eng.sqrt_mreal(to4(pos), to4(psi), tol=tol)
         e = rel(out.cpu().numpy()[:, :3], ref)
         assert e < bound, (tol, m, e)
-        up, mp = oracle.lanczos_sqrt(lambda v: oracle.mobility_real(pos, np.ascontiguousarray(v), box, 0.5, rcut, f32=True), psi, 2, tol)
+        up, mp = oracle.lanczos_sqrt(lambda v: oracle.mobility_real(pos, np.ascontiguousarray(v), box, 0.5, rcut, rounded=True), psi, 2, tol)
         assert m == mp, (m, mp)
         assert rel(out.cpu().numpy()[:, :3], up) < 1e-9
 
@@ -171,7 +171,7 @@ def test_pair_list_overflow_rows(torch_cuda, oracle):
     eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3)
     rcut = eng.info()["rcut"]
     psi = rng.normal(size=(n, 3))
-    matvec = lambda v: oracle.mobility_real(pos, np.ascontiguousarray(v), box, 0.5, rcut, f32=True)
+    matvec = lambda v: oracle.mobility_real(pos, np.ascontiguousarray(v), box, 0.5, rcut, rounded=True)
     counts = (np.linalg.norm(pos[:, None] - pos[None], axis=2) < rcut).sum(1) - 1
     assert counts.max() > 100        # far beyond the list capacity of ~30 slots
     out, m = eng.sqrt_mreal(to4(pos), to4(psi), tol=1e-3)
@@ -422,7 +422,7 @@ def test_the_two_halves_of_a_brownian_evaluation_add_up(torch_cuda, oracle):
     assert rel(s, whole.cpu().numpy()[:, :3]) < 1e-13
     # the real-space half against the port: M_real.F + sqrt(2 kT / dt) M_real^{1/2} psi
     psi = oracle.psi_particles(n, seed, ts)
-    ub, mp = oracle.lanczos_sqrt(lambda v: oracle.mobility_real(pos, np.ascontiguousarray(v), box, 0.5, p["rcut"], f32=True), psi, 2, 1e-3)
+    ub, mp = oracle.lanczos_sqrt(lambda v: oracle.mobility_real(pos, np.ascontiguousarray(v), box, 0.5, p["rcut"], rounded=True), psi, 2, 1e-3)
     ref_a = oracle.mobility_real(pos, force, box, 0.5, p["rcut"]) + np.sqrt(2.0 * kT / dt) * ub
     assert mp == m and rel(a.cpu().numpy()[:, :3], ref_a) < 1e-9
     # kT = 0: the halves are pse_mobility's parts

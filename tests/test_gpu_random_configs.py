@@ -112,7 +112,7 @@ def test_random_configuration(oracle, seed):
         assert np.all(v[others, :3] == -3.0) and np.all(v[:, 3] == 1.25)
         psi = np.random.default_rng(seed + 1).normal(size=(n, 3))
         out, ms = eng.sqrt_mreal(to4(pos), to4(psi), tol=1e-4, group=g)
-        mv = lambda x: oracle.mobility_real(pos[members], np.ascontiguousarray(x), c["box"], c["xi"], i["rcut"], f32=True)   # noqa: E731
+        mv = lambda x: oracle.mobility_real(pos[members], np.ascontiguousarray(x), c["box"], c["xi"], i["rcut"], rounded=True)   # noqa: E731
         up, mp = oracle.lanczos_sqrt(mv, psi[members], 2, 1e-4)
         assert ms == mp and rel(out.cpu().numpy()[members, :3], up) < 1e-9, ("sqrt on a group", seed, ms, mp)
     if seed % 2 == 0 and c["n"] >= 8:

@@ -117,7 +117,7 @@ def test_loopback_step_keeps_replicas_identical():
         mr = ref.step(rp, rv, ra, ri, rF, 1.0, 1e-2, ts, shear_rate=0.5, lanczos_m=mr)
     assert m == mr
     for s in sim.s:
-        assert np.abs(s.pos.cpu().numpy() - rp.cpu().numpy()).max() < 1e-8     # (three steps of two engines: a single-precision pair coefficient may round the other way, conftest.py)
+        assert np.abs(s.pos.cpu().numpy() - rp.cpu().numpy()).max() < 1e-8     # (three steps of two engines: a rounded pair coefficient may round the other way, conftest.py)
         assert np.array_equal(s.image.cpu().numpy(), ri.cpu().numpy())
 
 

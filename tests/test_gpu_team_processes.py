@@ -345,7 +345,7 @@ def test_random_team_of_processes(seed):
 def _local_worker(rank, world, port, xy0, n, grid, out):
     """Owned-particle team between real processes (pse_team_step_local over the host-staged transport): 20 sheared steps against the
     single-GPU engine on rank 0 -- ten deterministic ones (positions 1e-9), ten Brownian ones (TRAJ_TOL_BROWNIAN, tests/conftest.py:
-    the pair coefficients of the Lanczos mat-vecs are single precision), equal Lanczos counts, particles migrating across every slab face."""
+    the pair coefficients of the Lanczos mat-vecs are rounded to single-precision accuracy), equal Lanczos counts, particles migrating across every slab face."""
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     try:

@@ -118,8 +118,8 @@ def test_lanczos_port_matches_dense_sqrt(oracle):
     assert abs(np.dot(u.ravel(), u.ravel()) - psi.ravel() @ M @ psi.ravel()) < 1e-7 * (psi.ravel() @ M @ psi.ravel())
 
 
-def test_single_precision_pair_coefficients_keep_one_symmetric_operator(oracle):
-    """The build's Lanczos mat-vecs read pair coefficients in single precision (pse_kernels.hip nb_store; restated in
+def test_rounded_pair_coefficients_keep_one_symmetric_operator(oracle):
+    """The build's Lanczos mat-vecs read pair coefficients rounded to single-precision accuracy (pse_kernels.hip pair_coef; restated in
     oracle/pse_oracle.c pair_term).  Both directions of a pair round alike, so the operator stays exactly symmetric; it is positive
     definite, within 3e-7 of the double-precision near-field matrix, and its Lanczos square root agrees with the dense one."""
     import scipy.linalg as sl
@@ -128,12 +128,12 @@ def test_single_precision_pair_coefficients_keep_one_symmetric_operator(oracle):
     rcut = 5.2565
     eye = np.eye(3 * n)
     M = np.stack([oracle.mobility_real(pos, eye[c].reshape(n, 3), box, 0.5, rcut).ravel() for c in range(3 * n)], 1)
-    Mf = np.stack([oracle.mobility_real(pos, eye[c].reshape(n, 3), box, 0.5, rcut, f32=True).ravel() for c in range(3 * n)], 1)
+    Mf = np.stack([oracle.mobility_real(pos, eye[c].reshape(n, 3), box, 0.5, rcut, rounded=True).ravel() for c in range(3 * n)], 1)
     assert np.array_equal(Mf, Mf.T)
     assert 1e-9 < np.abs(Mf - M).max() < 3e-7 * np.abs(M).max()
     assert np.linalg.eigvalsh(Mf).min() > 0.0
     psi = oracle.psi_particles(n, 3, 8)
-    u, m = oracle.lanczos_sqrt(lambda v: oracle.mobility_real(pos, np.ascontiguousarray(v), box, 0.5, rcut, f32=True), psi, 2, 1e-9)
+    u, m = oracle.lanczos_sqrt(lambda v: oracle.mobility_real(pos, np.ascontiguousarray(v), box, 0.5, rcut, rounded=True), psi, 2, 1e-9)
     ref = sl.sqrtm(Mf).real @ psi.ravel()
     assert np.linalg.norm(u.ravel() - ref) / np.linalg.norm(ref) < 1e-8
 
@@ -194,10 +194,10 @@ def test_golden_fixture(oracle):
     u = oracle.mobility_direct(pos, force, box, g["xi"])
     assert np.abs(u - np.array(g["u_direct"])).max() < 1e-13
     p = oracle.select_params(box, g["xi"], g["error"], 0.5)
-    ub, m = oracle.brownian_velocity(pos, force, box, p, g["kT"], g["dt"], g["seed"], g["timestep"], pair_f32=False)
+    ub, m = oracle.brownian_velocity(pos, force, box, p, g["kT"], g["dt"], g["seed"], g["timestep"], pair_rounded=False)
     assert m == g["lanczos_m"]
     assert np.abs(ub - np.array(g["u_brownian_port"])).max() < 1e-9 * np.abs(ub).max()
-    # the same step with the single-precision pair coefficients of the build's Lanczos mat-vecs: same m, within 1e-7
+    # the same step with the rounded pair coefficients of the build's Lanczos mat-vecs: same m, within 1e-7
     uf, mf = oracle.brownian_velocity(pos, force, box, p, g["kT"], g["dt"], g["seed"], g["timestep"])
     assert mf == m and 0.0 < np.abs(uf - ub).max() < 1e-7 * np.abs(ub).max()
     assert [int(x) for x in oracle.philox4x32(1, 2, 3, 4, 5, 6)] == g["philox_1_2_3_4_5_6"]

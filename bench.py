@@ -805,8 +805,21 @@ def main():
     if world == 1 and eng is not None and not args.no_async:
         eng.set_async(True)
         m_q = int(round(float(np.max(ms))))
-        for it in range(3):
-            sim.step(args.kT, args.dt, 500000 + it, lanczos_m=m_q)
+        # the steady state of a time-stepping loop (pse_amd.sharded.LanczosCount, the policy of the team bench): once `settle` steps in a
+        # row have ended at their starting count with status 0 the gated extra iterations are not queued at all (pse_set_lanczos_extra(0):
+        # ten launches per step that would leave at once); a step that then runs out says so -- pse_info.lanczos_open_calls is sticky,
+        # and a timed loop in which it moved is not the line's value
+        from pse_amd.sharded import LanczosCount
+        lc = LanczosCount(eng, m=m_q, settle=3, adaptive=not args.keep_extras)
+        it = 0
+        while it < 3 or (not lc.extras_off and not args.keep_extras and it < 12):
+            sim.step(args.kT, args.dt, 500000 + it, lanczos_m=lc.m)
+            torch.cuda.synchronize()
+            i_w = eng.info()
+            lc.seen(i_w["lanczos_m"], i_w["lanczos_status"])
+            it += 1
+        m_q = lc.m
+        open0 = eng.info()["lanczos_open_calls"]
         barrier()
         t0 = time.perf_counter()
         for it in range(args.steps):
@@ -814,10 +827,11 @@ def main():
         barrier()
         el_q = time.perf_counter() - t0
         iq = eng.info()
+        eng.set_lanczos_extra(-1)
         eng.set_async(False)
         modes["queue_only"] = {"ms_per_step": el_q / args.steps * 1e3, "lanczos_m": iq["lanczos_m"], "lanczos_status": iq["lanczos_status"],
-                               "starting_count": m_q}
-        if iq["lanczos_status"] == 0 and iq["lanczos_m"] == m_q and el_q < elapsed:
+                               "starting_count": m_q, "gated_extras_off": lc.extras_off, "steps_that_ran_out": int(iq["lanczos_open_calls"] - open0)}
+        if iq["lanczos_status"] == 0 and iq["lanczos_m"] == m_q and iq["lanczos_open_calls"] == open0 and el_q < elapsed:
             mode, elapsed = "queue_only", el_q
     # distribution of single steps (median, p10, p90), each bracketed by device events
     n_pct = max(10, min(50, args.steps))

@@ -83,6 +83,8 @@ typedef struct pse_info {
     int lanczos_status;               /* queue-only Brownian calls (pse_set_async): 0 the step norm passed, 1 the queued iterations ran
                                          out first (the result uses the last size checked: raise the starting count), 2 a
                                          non-finite coefficient or a failed eigen-solve */
+    unsigned long long lanczos_open_calls;   /* queue-only calls of this handle so far that ended with lanczos_status != 0 (sticky: a loop
+                                                that reads pse_info every hundred steps still learns that one of them ran out) */
 } pse_info;
 
 /* -- life cycle: replaces Stokes::Stokes/setParams/~Stokes (PSEv1/Stokes.cc:85-118,129-424) ------------- */
@@ -330,6 +332,11 @@ int pse_team_redistribute_local(pse_team *team, pse_double4 *const *pos, pse_dou
  * Between processes *lanczos_m of pse_team_step_local comes back UNCHANGED (within one process: the most recent m that has
  * reached the host): read pse_info.lanczos_m after a synchronisation and pass the same count on every rank. */
 int pse_team_set_lanczos_extra(pse_team *team, int extra);
+/* the same for the queue-only calls of a single-GPU handle (pse_set_async): iterations queued beyond the starting count, each gated on
+ * the device-side decision (default -1: PSE_LANCZOS_EXTRA, 2).  With 0 a step whose starting count suffices queues no gated iteration at
+ * all (ten launches that would leave at once: ~ 25 us of a 3 ms step at the metric point); pse_info.lanczos_status = 1 /
+ * lanczos_open_calls say when it did not.  The reference iterates until the step norm passes (PSEv1/Brownian.cu:606-724). */
+int pse_set_lanczos_extra(pse_handle *h, int extra);
 /* row capacities of an owned-particle handle: own rows (= capacity the caller's arrays need), ghost rows per side, records per
  * neighbour message of the first exchange; cell layers along x in all and per rank (any pointer may be null) */
 int pse_local_layout(pse_handle *h, int *rows_own, int *rows_ghost, int *records, int *layers, int *layers_per_rank);

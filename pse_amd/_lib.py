@@ -66,6 +66,7 @@ class pse_info(ctypes.Structure):
         ("t_records", ctypes.c_double),
         ("lanczos_exchanges", ctypes.c_int),
         ("lanczos_status", ctypes.c_int),
+        ("lanczos_open_calls", ctypes.c_ulonglong),
     ]
 
     def as_dict(self):
@@ -141,6 +142,7 @@ SYMBOLS = {
     "pse_local_layout": (_i, [_vp, _ip, _ip, _ip, _ip, _ip]),
     "pse_team_local_status": (_i, [_vp, _ip]),
     "pse_team_set_lanczos_extra": (_i, [_vp, _i]),
+    "pse_set_lanczos_extra": (_i, [_vp, _i]),
     "pse_team_redistribute_local": (_i, [_vp] + [ctypes.POINTER(_vp)] * 7),
     "pse_team_set_diag": (_i, [_vp, _i]),
     "pse_team_get_diag": (_i, [_vp, ctypes.POINTER(pse_team_diag)]),

@@ -166,6 +166,7 @@ struct pse_handle {
     bool xfuse = false;                                      // power-of-two Nx: fused x pass (k_xfft_scale)
     bool own_y = false;                                      // y transforms by k_fft_cols, rocFFT does the z transforms only
     bool own_y_slab = false;                                 // ... on a slab rank, with the all-to-all block layout as its output / input
+    int lz_extra = -1;           // pse_set_lanczos_extra: gated iterations a queue-only call queues beyond its starting count (-1: PSE_LANCZOS_EXTRA)
     void *vq = nullptr;          // [n] 16-byte mirror of the newest Lanczos vector (single GPU; k_lz_update writes it, the pair-list mat-vec gathers from it)
     int place_tried = 0; float place_ms_first = 0, place_ms_kept = 0;   // place_grids: pairs tried, the probe's time on the first and on the kept one
     bool own_z = false;                                      // z transforms by k_zfft_rows (Nz = 256, 512): rocFFT is then off the path
@@ -901,6 +902,7 @@ extern "C" int pse_get_info(pse_handle *h, pse_info *info) {
         h->info.lanczos_stepnorm = h->sc_host[LZ_HOST_STEPNORM];
         h->info.lanczos_status = (int)h->sc_host[LZ_HOST_STATUS];
     }
+    h->info.lanczos_open_calls = h->sc_host ? (unsigned long long)h->sc_host[LZ_HOST_OPEN] : 0ull;
     *info = h->info;
     return 0;
 }
@@ -1664,7 +1666,7 @@ static int lanczos_queued(pse_team &T, int N, double tol, double scale, int *m_i
     const size_t stride = h->n_pad;
     const int m_in = std::min(std::max(m_io ? *m_io : 2, 1), M_MAX);
     const int target = std::max(m_in, 2);
-    const int extra = std::max(0, std::min(h->tun.lz_extra, M_MAX - target));
+    const int extra = std::max(0, std::min(h->lz_extra >= 0 ? h->lz_extra : h->tun.lz_extra, M_MAX - target));
     const int *stop = &h->lz_state->done;
     const double seq = (double)++h->lz_seq;
     h->lz_last_queued = true;
@@ -2958,6 +2960,12 @@ extern "C" int pse_local_layout(pse_handle *h, int *rows_own, int *rows_ghost, i
     return 0;
 }
 
+extern "C" int pse_set_lanczos_extra(pse_handle *h, int extra) {
+    if (!h) return fail(PSE_ERR_INVALID, "null handle");
+    if (extra > 32) return fail(PSE_ERR_INVALID, "at most 32 extra Lanczos iterations");
+    h->lz_extra = extra < 0 ? -1 : extra;
+    return 0;
+}
 extern "C" int pse_team_set_lanczos_extra(pse_team *T, int extra) {
     if (!T) return fail(PSE_ERR_INVALID, "null team");
     if (extra > 32) return fail(PSE_ERR_INVALID, "at most 32 extra Lanczos iterations");

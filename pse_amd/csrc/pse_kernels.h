@@ -328,7 +328,7 @@ struct LzDecide {
     int m_max;
     double tol;
 };
-constexpr int LZ_HOST_M = 380, LZ_HOST_STEPNORM = 381, LZ_HOST_STATUS = 382, LZ_HOST_SEQ = 383;   // slots of the host mirror (sch) the decision writes
+constexpr int LZ_HOST_M = 380, LZ_HOST_STEPNORM = 381, LZ_HOST_STATUS = 382, LZ_HOST_SEQ = 383, LZ_HOST_OPEN = 384;   // (OPEN: calls so far that ended with status != 0)   // slots of the host mirror (sch) the decision writes
 void launch_lz_decide(const LzDecide &d, double *scal, LzState *st, double *sch, double seq, hipStream_t s);
 bool lz_decide_supported(int m_hi);   // the eigenvectors of both sizes fit the LDS of one workgroup
 // tag_s (nullable): out[i].w = the particle's index in the caller's arrays, so the rows can be scattered by ranks that did not sort them

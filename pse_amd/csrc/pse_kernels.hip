@@ -2508,7 +2508,10 @@ k_lz_decide(LzDecide a, double *__restrict__ scal, LzState *__restrict__ st, dou
         for (int q = 0; q < m; ++q) st->coef[q] = t_fin[q] / (q == 0 ? norm : (a.normalised ? 1.0 : beta[q]));
         st->m_final = m; st->status = status;
         st->done = 1;                                            // (read by LATER launches only: the kernel boundary orders it)
-        if (sch) { sch[LZ_HOST_M] = (double)m; sch[LZ_HOST_STEPNORM] = stepnorm; sch[LZ_HOST_STATUS] = (double)status; sch[LZ_HOST_SEQ] = seq; }
+        if (sch) {
+            sch[LZ_HOST_M] = (double)m; sch[LZ_HOST_STEPNORM] = stepnorm; sch[LZ_HOST_STATUS] = (double)status; sch[LZ_HOST_SEQ] = seq;
+            if (status != 0) sch[LZ_HOST_OPEN] = sch[LZ_HOST_OPEN] + 1.0;   // (sticky: a loop that reads pse_info only now and then still learns of it)
+        }
     }
 }
 static size_t lz_decide_lds(int m_lo, int m_hi) {

@@ -239,6 +239,11 @@ class Engine:
                                                out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
         return out
 
+    def set_lanczos_extra(self, extra):
+        """Gated iterations a queue-only Brownian call queues beyond its starting count (pse_set_lanczos_extra; -1: the default, 0: none --
+        for a time-stepping loop whose steps end at their starting count: pse_amd.sharded.LanczosCount)."""
+        _lib.check(self._lib.pse_set_lanczos_extra(self._h, int(extra)))
+
     def matvec_ms(self, reps=20):
         """Milliseconds per launch of the pair-list mat-vec of a Lanczos iteration, `reps` launches back to back between one pair of
         events (pse_debug_matvec_ms): right after a Brownian call of a single-GPU engine."""

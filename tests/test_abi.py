@@ -33,7 +33,7 @@ def test_struct_layout_matches_header():
     # 1 uint + pad, 7 doubles, uint + 3 int, int + pad, double, 3 int + pad
     assert ctypes.sizeof(pse_params) == 112
     assert pse_params.rcut.offset == 88 and pse_params.device.offset == 96
-    assert ctypes.sizeof(pse_info) % 8 == 0 and pse_info.t_matvec.offset == ctypes.sizeof(pse_info) - 24
+    assert ctypes.sizeof(pse_info) % 8 == 0 and pse_info.t_matvec.offset == ctypes.sizeof(pse_info) - 32
     assert pse_info.t_records.offset == pse_info.t_matvec.offset + 8 and pse_info.lanczos_exchanges.offset == pse_info.t_records.offset + 8
 
 

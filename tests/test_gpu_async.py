@@ -192,3 +192,50 @@ def test_step_captured_into_a_graph_follows_the_eager_trajectory(xy):
         assert rel(v1.cpu().numpy()[:, :3], v0.cpu().numpy()[:, :3]) < 1e-12, k
         assert np.abs(p1.cpu().numpy()[:, :3] - p0.cpu().numpy()[:, :3]).max() < 1e-12, k
         assert torch.equal(i1, i0)
+
+
+def test_queue_only_steps_without_the_gated_extras_and_the_sticky_count_of_steps_that_ran_out():
+    """pse_set_lanczos_extra(0) (the steady state of a time-stepping loop, pse_amd.sharded.LanczosCount): a queue-only call queues no
+    gated iteration; from the converged starting count the result is the one of the default form, bit for bit, one Lanczos mat-vec
+    and no decision more is launched than needed; from too low a count the call says so (status 1) and pse_info.lanczos_open_calls,
+    which is sticky, counts it -- also when pse_info is read only after later, converged calls."""
+    import torch
+    import pse_amd
+    from pse_amd.sharded import LanczosCount
+    n = 20000
+    pos, force, box = make_suspension(n, phi=0.15)
+    eng = pse_amd.Engine(n, box, xi=0.5, error=1e-3, seed=11)
+    eng.set_async(True)
+    dpos, dF = to4(pos), to4(force)
+    lc = LanczosCount(eng, m=2, settle=3)
+    for it in range(12):                                   # the policy finds the count, then switches the extras off
+        eng.brownian_velocity(dpos, dF, 1.0, 1e-3, 5, lanczos_m=lc.m)
+        torch.cuda.synchronize()
+        i = eng.info()
+        lc.seen(i["lanczos_m"], i["lanczos_status"])
+        if lc.extras_off:
+            break
+    assert lc.extras_off and lc.m >= 4
+    open0 = eng.info()["lanczos_open_calls"]
+    v_off, _ = eng.brownian_velocity(dpos, dF, 1.0, 1e-3, 5, lanczos_m=lc.m)
+    torch.cuda.synchronize()
+    i_off = eng.info()
+    v_off = v_off.clone()
+    eng.set_lanczos_extra(-1)
+    v_on, _ = eng.brownian_velocity(dpos, dF, 1.0, 1e-3, 5, lanczos_m=lc.m)
+    torch.cuda.synchronize()
+    i_on = eng.info()
+    assert i_off["lanczos_status"] == 0 and i_off["lanczos_m"] == lc.m == i_on["lanczos_m"] and i_off["lanczos_open_calls"] == open0
+    assert rel(v_off.cpu().numpy()[:, :3], v_on.cpu().numpy()[:, :3]) < 1e-12
+    assert i_off["lanczos_matvecs"] <= i_on["lanczos_matvecs"]
+    # too low a count without extras: status 1, counted; two converged calls later the count still says so
+    eng.set_lanczos_extra(0)
+    eng.brownian_velocity(dpos, dF, 1.0, 1e-3, 5, lanczos_m=lc.m - 2)
+    torch.cuda.synchronize()
+    assert eng.info()["lanczos_status"] == 1
+    eng.set_lanczos_extra(-1)
+    for _ in range(2):
+        eng.brownian_velocity(dpos, dF, 1.0, 1e-3, 5, lanczos_m=lc.m)
+    torch.cuda.synchronize()
+    i = eng.info()
+    assert i["lanczos_status"] == 0 and i["lanczos_open_calls"] == open0 + 1

@@ -87,6 +87,17 @@ int pse_eval_realspace(pse_handle *, const double *, int, double *, double *) { 
 int pse_debug_copy_grid(pse_handle *, int, double *) { return no_device("pse_debug_copy_grid"); }
 int pse_debug_spread(pse_handle *, const pse_double4 *, const pse_double4 *, const unsigned int *, unsigned int) { return no_device("pse_debug_spread"); }
 int pse_debug_kvector(pse_handle *, int, const int *, double *) { return no_device("pse_debug_kvector"); }
+int pse_debug_grid_placement(pse_handle *, int *, float *, float *) { return no_device("pse_debug_grid_placement"); }
+int pse_debug_vq_roundtrip(int, const double *, double *) { return no_device("pse_debug_vq_roundtrip"); }
+int pse_debug_matvec_ms(pse_handle *, int, float *) { return no_device("pse_debug_matvec_ms"); }
+int pse_set_lanczos_extra(pse_handle *, int) { return no_device("pse_set_lanczos_extra"); }
+int pse_brownian_velocity_part(pse_handle *, const pse_double4 *, const pse_double4 *, pse_double4 *, const unsigned int *, unsigned int, double,
+                               double, unsigned int, int, int *) { return no_device("pse_brownian_velocity_part"); }
+int pse_integrate(pse_handle *, pse_double4 *, const pse_double4 *, pse_double3 *, pse_int3 *, const pse_double4 *, const unsigned int *, unsigned int,
+                  double, double) { return no_device("pse_integrate"); }
+int pse_team_redistribute_local(pse_team *, pse_double4 *const *, pse_double4 *const *, pse_double3 *const *, pse_int3 *const *, pse_double4 *const *,
+                                unsigned int *const *, unsigned int *const *) { return no_device("pse_team_redistribute_local"); }
+int pse_team_set_lanczos_extra(pse_team *, int) { return no_device("pse_team_set_lanczos_extra"); }
 int pse_team_unique_id(void *) { return no_device("pse_team_unique_id"); }
 int pse_team_create(pse_handle **, int, const void *, pse_team **) { return no_device("pse_team_create"); }
 int pse_team_create_transport(pse_handle *, const pse_transport *, pse_team **) { return no_device("pse_team_create_transport"); }

@@ -110,3 +110,16 @@ def test_sanitizer_build_is_in_use():
     # a device entry point of the stub says what it is
     assert lib.pse_set_timing(None, 1) != 0 and b"sanitizer build" in lib.pse_last_error()
     assert isinstance(lib, ctypes.CDLL)
+
+
+def test_sanitizer_stub_defines_every_declared_entry_point():
+    """tools/asan.py runs this suite on a host-only build whose device entry points are stubs (pse_amd/csrc/asan_stub.cpp): an entry point
+    added to include/pse_amd.h and not to the stub breaks that build the first time someone runs it (round 6 found eight missing)."""
+    import glob
+    import re
+    header = open(os.path.join(ROOT, "include", "pse_amd.h")).read()
+    declared = set(re.findall(r"^(?:int|const char \*|void)\s*\*?(pse_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    assert len(declared) > 40
+    host = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "pse_amd", "csrc", "*.cpp")))
+    missing = sorted(n for n in declared if not re.search(r"\b" + n + r"\s*\(", host))
+    assert not missing, missing
